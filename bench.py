@@ -1,0 +1,316 @@
+#!/usr/bin/env python3
+"""bench.py -- the north-star measurement: plink_freq over a synthetic
+1,000,000-variant x 500,000-sample .pgen matrix resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one full pass of the hot path over the rank's resident variants:
+the genotype-class tally kernel (PgrGetCounts for every variant), the ALT_FREQ /
+OBS_CT epilogue kernel, and the device->pinned-host copy of the per-variant
+results (what the table function hands to DuckDB).  Inputs are generated in HBM
+before the timed region (seeded counter-based generator).
+
+N > 1: one process per GPU (torch.distributed, backend nccl == RCCL), variants
+sharded across ranks, no data-path collective for plink_freq;
+only the timing barrier / max-over-ranks uses the process group.
+
+Prints ONE JSON line on rank 0 (see the driver contract), including
+  "roofline":     algorithmic HBM bytes of the tally kernel / its mean launch
+                  duration (HIP events on the launch stream), against 8 TB/s;
+  "cpu_baseline": the CPU oracle run with the reference's scan structure
+                  (T threads claiming 128-variant batches) on a bounded sample.
+
+Other workloads (parity-tested configs, for DESIGN.md / profiles/):
+  --workload fused   plink_freq + plink_hardy + plink_missing from one tally pass
+  --workload unpack  read_pgen genotype column (2-bit -> int8 + validity)
+  --workload score   plink_score, 16 weight columns
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SEED = 20260807
+MISSING_RATE = 0.02
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector/matrix peak
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--variants", type=int, default=1_000_000, help="variants per rank (weak) or in total (strong)")
+    ap.add_argument("--samples", type=int, default=500_000)
+    ap.add_argument("--workload", choices=["freq", "fused", "unpack", "score"], default="freq")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 disables)")
+    ap.add_argument("--cpu-sample-variants", type=int, default=8192)
+    ap.add_argument("--score-cols", type=int, default=16)
+    return ap.parse_args()
+
+
+def cpu_baseline(ds, n_samples, budget_s, sample_variants):
+    """The oracle (kind 'port': the reference binary cannot be built)
+    scanning a bounded sample of the same matrix with the reference's thread structure."""
+    import numpy as np
+
+    from oracle import oracle
+
+    v1 = min(ds.v_end, ds.v_begin + sample_variants)
+    rows = ds.copy_rows_to_host(ds.v_begin, v1)
+    m = rows.shape[0]
+    head = bytes([0x6c, 0x1b, 0x02]) + int(m).to_bytes(4, "little") + int(n_samples).to_bytes(4, "little") + b"\x40"
+    image = np.concatenate([np.frombuffer(head, dtype=np.uint8), rows.reshape(-1)])
+    del rows
+    pg = oracle.Pgen(mem=image)
+    cores = os.cpu_count() or 1
+    # the reference's default: min(range/500 + 1, 16) scan threads (src/plink_freq.cpp:84-87)
+    threads = max(1, min(m // 500 + 1, 16, cores))
+    pg.scan_counts_mt(0, min(m, 256), threads)  # touch
+    passes, t0 = 0, time.perf_counter()
+    while True:
+        pg.scan_counts_mt(0, m, threads)
+        passes += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s:
+            break
+    geno_per_s = passes * m * n_samples / dt
+    return {
+        "value": geno_per_s,
+        "unit": "genotypes/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{m} variants x {n_samples} samples of the same matrix, {passes} passes in {dt:.1f} s, "
+                  f"{threads} threads claiming 128-variant batches ({cores} host cores visible)",
+    }
+
+
+def load_traffic(workload, variants, samples):
+    """Per-launch HBM bytes from the committed rocprofv3 PMC pass (profiles/traffic.json),
+    if it was collected for this exact launch shape."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        e = t.get(workload)
+        if e and e.get("variants") == variants and e.get("samples") == samples:
+            return e.get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+
+    import plinking_duck_amd.lib as L
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    L.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n = args.samples
+    if args.scaling == "weak":
+        v_begin, v_end = rank * args.variants, (rank + 1) * args.variants
+    else:
+        per = (args.variants + world - 1) // world
+        v_begin, v_end = min(args.variants, rank * per), min(args.variants, (rank + 1) * per)
+    m = v_end - v_begin
+    ds = L.Dataset.synth(v_begin, v_end, n, SEED, MISSING_RATE)
+    record_bytes = ds.info.record_bytes
+    stream = torch.cuda.current_stream()
+    st = stream.cuda_stream
+    dev = torch.device("cuda", local_rank)
+
+    kernel_events = []
+    units_per_step = m * n  # genotypes
+    algo_bytes = None
+    algo_flops = None
+    dtype = "u32"
+
+    if args.workload in ("freq", "fused"):
+        d_counts = torch.empty((m, 4), dtype=torch.int32, device=dev)
+        d_freq = torch.empty(m, dtype=torch.float64, device=dev)
+        d_obs = torch.empty(m, dtype=torch.int32, device=dev)
+        h_counts = torch.empty((m, 4), dtype=torch.int32, pin_memory=True)
+        h_freq = torch.empty(m, dtype=torch.float64, pin_memory=True)
+        h_obs = torch.empty(m, dtype=torch.int32, pin_memory=True)
+        if args.workload == "fused":
+            d_lnp = torch.empty(m, dtype=torch.float64, device=dev)
+            h_lnp = torch.empty(m, dtype=torch.float64, pin_memory=True)
+            d_miss = torch.empty((n + 63) // 64 * 64, dtype=torch.int32, device=dev)
+            h_miss = torch.empty(n, dtype=torch.int32, pin_memory=True)
+        algo_bytes = m * record_bytes  # ceil(N/4) bytes read per variant
+
+        def step(timed):
+            if timed:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+            ds.counts_range_dev(v_begin, v_end, d_counts.data_ptr(), st)
+            if timed:
+                e1.record(stream)
+                kernel_events.append((e0, e1))
+            L.freq_from_counts_dev(d_counts.data_ptr(), m, d_freq.data_ptr(), d_obs.data_ptr(), st)
+            h_counts.copy_(d_counts, non_blocking=True)
+            h_freq.copy_(d_freq, non_blocking=True)
+            h_obs.copy_(d_obs, non_blocking=True)
+            if args.workload == "fused":
+                # plink_hardy: exact test per variant from the same counts;
+                # plink_missing variant mode: counts[:,3]; sample mode: column sums
+                L.hwe_lnp_batch_dev(d_counts.data_ptr(), m, d_lnp.data_ptr(), False, st)
+                h_lnp.copy_(d_lnp, non_blocking=True)
+                ds.missing_per_sample_dev(v_begin, v_end, d_miss.data_ptr(), st)
+                h_miss.copy_(d_miss[:n], non_blocking=True)
+
+        kernel_name = "k_counts_block"
+        metric = "plink_freq genotypes/s" if args.workload == "freq" else "plink_freq+hardy+missing genotypes/s"
+    elif args.workload == "unpack":
+        # read_pgen genotype column: output is 4.5x the input, streamed in row chunks
+        # the way DuckDB consumes it (2048-row vectors; here 8 vectors per launch)
+        chunk = min(m, 16384)
+        out_pitch = (n + 15) // 16 * 16
+        val_words = (n + 63) // 64
+        d_out = torch.empty((chunk, out_pitch), dtype=torch.int8, device=dev)
+        d_val = torch.empty((chunk, val_words), dtype=torch.int64, device=dev)
+        algo_bytes = chunk * (record_bytes + n + val_words * 8)
+
+        def step(timed):
+            for c0 in range(0, m, chunk):
+                c1 = min(m, c0 + chunk)
+                if timed:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e0.record(stream)
+                ds.unpack_range_dev(v_begin + c0, v_begin + c1, d_out.data_ptr(), out_pitch, d_val.data_ptr(), 0, st)
+                if timed and c1 - c0 == chunk:
+                    e1.record(stream)
+                    kernel_events.append((e0, e1))
+
+        kernel_name = "k_unpack"
+        metric = "read_pgen genotypes/s"
+        dtype = "u8"
+    else:  # score
+        ncol = args.score_cols
+        rng = np.random.default_rng(SEED + 1)
+        vidx = np.arange(v_begin, v_end, dtype=np.uint32)
+        w = rng.standard_normal((m, ncol))
+        d_score = torch.empty((n, ncol), dtype=torch.float64, device=dev)
+        d_dos = torch.empty(n, dtype=torch.float64, device=dev)
+        d_ac = torch.empty(n, dtype=torch.int32, device=dev)
+        algo_bytes = m * (record_bytes + 8 * ncol)
+        algo_flops = 2.0 * m * n * ncol
+
+        def step(timed):
+            if timed:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+            ds.score_dev(vidx, w, d_score.data_ptr(), d_dos.data_ptr(), d_ac.data_ptr(), None, L.SCORE_MEAN_IMPUTE, st)
+            if timed:
+                e1.record(stream)
+                kernel_events.append((e0, e1))
+            if dist is not None:
+                # per-sample partials of the variant shards: RCCL reduce over xGMI
+                dist.reduce(d_score, dst=0)
+                dist.reduce(d_dos, dst=0)
+
+        kernel_name = "k_score_accumulate"
+        metric = f"plink_score genotypes/s ({ncol} weight columns)"
+        dtype = "f64"
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kernel_ms = [a.elapsed_time(b) for a, b in kernel_events]
+    kern_avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+    total_units = units_per_step * world if args.scaling == "weak" else args.variants * n
+    value = total_units * args.steps / elapsed
+
+    if algo_flops is not None and args.workload == "score" and args.score_cols >= 4:
+        achieved = algo_flops / (kern_avg_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None, "kernel": kernel_name,
+                    "kernel_ms_avg": kern_avg_ms, "launches_timed": len(kernel_ms)}
+    else:
+        achieved = algo_bytes / (kern_avg_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic(args.workload, m, n),
+                    "kernel": kernel_name, "kernel_ms_avg": kern_avg_ms, "launches_timed": len(kernel_ms),
+                    "algorithmic_bytes_per_launch": algo_bytes}
+
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        cpu = cpu_baseline(ds, n, args.cpu_seconds, args.cpu_sample_variants)
+
+    if rank == 0:
+        line = {
+            "metric": metric,
+            "value": value,
+            "unit": "genotypes/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": args.scaling,
+            "vs_baseline": None,
+            "dtype": dtype,
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}: {args.variants} variants x {n} samples "
+                            f"({'per GPU' if args.scaling == 'weak' else 'total'}), 2-bit hardcalls resident in HBM, "
+                            f"seed {SEED}, {MISSING_RATE:.0%} missing",
+                "variants_per_rank": m,
+                "samples": n,
+                "record_bytes": record_bytes,
+                "sharding": "contiguous variant ranges per GPU, no data-path collective"
+                            if args.workload != "score" else "variant shards + RCCL reduce of per-sample partials",
+            },
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

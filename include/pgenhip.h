@@ -1,0 +1,221 @@
+/*
+ * pgenhip.h -- C ABI of libpgenhip: the MI355X (gfx950) replacement for the
+ * plink-ng pgenlib calls on PlinkingDuck's .pgen decode-and-analyse hot path.
+ *
+ * Every entry point names the reference interface it replaces (file:line into
+ * teaguesterling/plinking_duck).  Conventions, all taken from pgenlib's own:
+ *   - every call returns an int status (PGH_OK == 0) and, where it can fail for
+ *     a reason worth reporting, writes a NUL-terminated message into a caller
+ *     buffer of PGH_ERRBUF_LEN bytes (pgenlib: PglErr + errstr_buf[kPglErrstrBufBlen]);
+ *   - no exception, torch type or C++ type crosses this boundary;
+ *   - the caller owns every output buffer; handles are opaque;
+ *   - a pgh_dataset is immutable after creation and may be read concurrently
+ *     by any number of scan threads; a pgh_reader belongs to one thread
+ *     (pgenlib: one PgenReader per thread, src/plink_freq.cpp:342-390);
+ *   - sample subsets follow pgenlib semantics: a bitmask over the raw samples,
+ *     outputs compacted to the included samples in ascending file order
+ *     (src/plink_common.cpp:1222-1250).
+ *
+ * Pointers named d_* are device (HBM) pointers owned by the caller; `stream`
+ * is a hipStream_t passed as void* (NULL = the library's own stream).  The
+ * *_dev entry points only enqueue work; the host-buffer forms synchronise and
+ * copy the result back.
+ */
+#ifndef PGENHIP_H_
+#define PGENHIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGH_ERRBUF_LEN 256
+
+enum {
+	PGH_OK = 0,
+	PGH_ERR_OPEN = 1,        /* file cannot be opened/read      (IOException at the shell) */
+	PGH_ERR_FORMAT = 2,      /* malformed or unsupported .pgen  (IOException)              */
+	PGH_ERR_ARG = 3,         /* bad argument / out of range     (InvalidInputException)    */
+	PGH_ERR_DEVICE = 4,      /* HIP runtime failure             (IOException)              */
+	PGH_ERR_NOMEM = 5,
+	PGH_ERR_UNSUPPORTED = 6  /* track kind the device path does not decode (multiallelic, phased dosage) */
+};
+
+typedef struct pgh_dataset pgh_dataset; /* packed 2-bit genotype matrix resident in HBM */
+typedef struct pgh_subset pgh_subset;   /* sample-include mask, staged on the device    */
+typedef struct pgh_reader pgh_reader;   /* per-scan-thread view (stream + staging)      */
+
+typedef struct pgh_info {
+	uint32_t raw_variant_ct;   /* pgfi.raw_variant_ct  (src/plink_freq.cpp:184) */
+	uint32_t raw_sample_ct;    /* pgfi.raw_sample_ct   (src/plink_freq.cpp:185) */
+	uint32_t variant_begin;    /* first variant resident on this device         */
+	uint32_t variant_end;      /* one past the last resident variant            */
+	uint32_t has_dosage;       /* gflags & kfPgenGlobalDosagePresent (src/plink_freq.cpp:201) */
+	uint32_t has_phase;        /* gflags & kfPgenGlobalHardcallPhasePresent     */
+	uint32_t max_record_bytes; /* max_vrec_width (src/plink_freq.cpp:193-197)   */
+	uint32_t record_bytes;     /* ceil(N/4): bytes of one normalised 2-bit record */
+	uint64_t pitch_bytes;      /* device row stride of one record               */
+	uint32_t vrtype_hist[8];   /* number of records per main-track type (vrtype & 7) */
+	int32_t device;            /* HIP device ordinal                            */
+} pgh_info;
+
+/* ---- library / device --------------------------------------------------- */
+
+/* Version string "pgenhip <n> gfx950". */
+const char *pgh_version(void);
+/* Number of visible HIP devices (0 without a GPU).  Never fails. */
+int pgh_device_count(void);
+/* Select the device used by datasets created afterwards from this thread. */
+int pgh_set_device(int device, char *errbuf);
+
+/* ---- dataset lifecycle --------------------------------------------------- */
+
+/* Replaces PreinitPgfi + PgfiInitPhase1 + PgfiInitPhase2 + PgrInit
+ * (src/plink_freq.cpp:168-208,344-390; same sequence in pgen_reader.cpp:227-266,
+ * plink_hardy/missing/score/pca).  Parses the header and record tables, expands
+ * every record of [variant_begin, variant_end) to a plain 2-bit row and leaves
+ * the rows resident in HBM.  variant_end == UINT32_MAX means "to the last
+ * variant".  pgi_path may be NULL (then "<pgen_path>.pgi" is tried for mode 0x20). */
+int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t variant_begin, uint32_t variant_end,
+             pgh_dataset **out, char *errbuf);
+
+/* Header probe only: no device work, works without a GPU (bind-time use:
+ * src/plink_freq.cpp:168-208). */
+int pgh_probe(const char *pgen_path, const char *pgi_path, pgh_info *out, char *errbuf);
+
+/* The host half of pgh_open on its own: expand the records of [variant_begin,
+ * variant_end) to plain 2-bit rows in HOST memory (row r at rows + r*row_stride,
+ * row_stride >= ceil(N/4), pad bytes zeroed).  No device work; used by ingest
+ * pipelines that stage rows themselves and by the CPU-only tests. */
+int pgh_normalize_range_host(const char *pgen_path, const char *pgi_path, uint32_t variant_begin,
+                             uint32_t variant_end, uint8_t *rows, size_t row_stride, char *errbuf);
+
+/* Dataset over caller-supplied plain 2-bit rows in HOST memory (row v at
+ * rows + v*row_stride, ceil(N/4) meaningful bytes each). */
+int pgh_from_host_rows(const uint8_t *rows, size_t row_stride, uint32_t variant_ct, uint32_t sample_ct,
+                       pgh_dataset **out, char *errbuf);
+
+/* Seeded synthetic dataset written directly into HBM (BASELINE.md section 3:
+ * p_v ~ U(0.01,0.5), g ~ Binomial(2,p_v), missing with probability
+ * missing_rate).  Variant v of the generator lands in row v - variant_begin, so
+ * ranks that own disjoint variant ranges hold slices of one global matrix. */
+int pgh_synth_create(uint32_t variant_begin, uint32_t variant_end, uint32_t sample_ct, uint64_t seed,
+                     double missing_rate, pgh_dataset **out, char *errbuf);
+/* The same generator on the host: one record (ceil(N/4) bytes) of variant v. */
+int pgh_synth_record_host(uint32_t v, uint32_t sample_ct, uint64_t seed, double missing_rate, uint8_t *out);
+/* Writes <prefix>.pgen (mode 0x10, vrtype-0 records), .pvar and .psam. */
+int pgh_synth_write_files(const char *prefix, uint32_t variant_ct, uint32_t sample_ct, uint64_t seed,
+                          double missing_rate, char *errbuf);
+
+/* Copy resident rows [v_begin, v_end) back to HOST memory as plain 2-bit rows
+ * (row r at rows + r*row_stride, ceil(N/4) bytes each). */
+int pgh_copy_rows_to_host(const pgh_dataset *ds, uint32_t v_begin, uint32_t v_end, uint8_t *rows, size_t row_stride,
+                          char *errbuf);
+
+int pgh_get_info(const pgh_dataset *ds, pgh_info *out);
+/* Device pointer of resident row 0 (pitch in pgh_info.pitch_bytes). */
+const void *pgh_device_rows(const pgh_dataset *ds);
+/* CleanupPgr + CleanupPgfi (src/plink_freq.cpp:109-115). */
+void pgh_close(pgh_dataset *ds);
+
+/* ---- sample subsets ------------------------------------------------------ */
+
+/* Replaces BuildSampleSubset / PgrSetSampleSubsetIndex (src/plink_common.cpp:1222-1250,
+ * src/plink_freq.cpp:393-397).  sample_include: ceil(N/64) words, bit s = sample s kept. */
+int pgh_subset_create(const pgh_dataset *ds, const uint64_t *sample_include, pgh_subset **out, char *errbuf);
+uint32_t pgh_subset_size(const pgh_subset *ss);
+void pgh_subset_destroy(pgh_subset *ss);
+
+/* ---- batched device calls (the fast path of the table functions) -------- */
+
+/* PgrGetCounts over a variant range (src/plink_freq.cpp:482, plink_hardy.cpp:510,
+ * plink_pca.cpp:394, pgen_reader.cpp:673,864): out[v - v_begin] = {hom_ref, het,
+ * hom_alt, missing} over the (subset of) samples.  subset may be NULL. */
+int pgh_counts_range(const pgh_dataset *ds, const pgh_subset *subset, uint32_t v_begin, uint32_t v_end,
+                     uint32_t (*out)[4], char *errbuf);
+int pgh_counts_range_dev(const pgh_dataset *ds, const pgh_subset *subset, uint32_t v_begin, uint32_t v_end,
+                         void *d_out, void *stream, char *errbuf);
+
+/* plink_freq's arithmetic on the device (src/plink_freq.cpp:495-544), from a
+ * device counts array: d_alt_freq[i] = (het + 2 hom_alt) / (2 obs) as double, NaN
+ * where the reference emits NULL (obs == 0); d_obs_ct[i] = 2 obs (int32). */
+int pgh_freq_from_counts_dev(const void *d_counts, uint32_t n, void *d_alt_freq, void *d_obs_ct, void *stream,
+                             char *errbuf);
+
+/* PgrGetMissingness + PopcountWords (src/plink_missing.cpp:479-486) is column 3
+ * of pgh_counts_range.  The per-sample form replaces the phase-1 accumulation of
+ * plink_missing sample mode (src/plink_missing.cpp:585-619):
+ * out[k] = number of variants in [v_begin, v_end) at which included sample k is missing. */
+int pgh_missing_per_sample(const pgh_dataset *ds, const pgh_subset *subset, uint32_t v_begin, uint32_t v_end,
+                           uint32_t *out, char *errbuf);
+/* d_out: uint32[raw_sample_ct] (raw order, no compaction), zeroed by the call. */
+int pgh_missing_per_sample_dev(const pgh_dataset *ds, uint32_t v_begin, uint32_t v_end, void *d_out, void *stream,
+                               char *errbuf);
+
+/* PgrGet + GenoarrToBytesMinus9 over a variant range (src/pgen_reader.cpp:727-733)
+ * plus the validity fill of the ARRAY/LIST child (src/pgen_reader.cpp:1009-1047).
+ * out: int8 [v_end-v_begin][n_out] with n_out = subset size or N; a missing call is
+ * stored as missing_code (-9 for pgenlib parity, 0 for the DuckDB child vector).
+ * validity (may be NULL): ceil(n_out/64) words per variant, bit set = non-missing. */
+int pgh_unpack_range(const pgh_dataset *ds, const pgh_subset *subset, uint32_t v_begin, uint32_t v_end, int8_t *out,
+                     uint64_t *validity, int missing_code, char *errbuf);
+/* d_out row stride = out_pitch bytes (>= n_out, multiple of 16); d_validity row
+ * stride = ceil(n_out/64) words; either may be NULL. */
+int pgh_unpack_range_dev(const pgh_dataset *ds, const pgh_subset *subset, uint32_t v_begin, uint32_t v_end,
+                         void *d_out, size_t out_pitch, void *d_validity, int missing_code, void *stream,
+                         char *errbuf);
+
+/* plink_score phase 1 (src/plink_score.cpp:575-654) for n_scored variants and
+ * n_cols weight columns (the reference has one; BASELINE config 4 uses 16).
+ *   vidx[i]      variant index (ascending; src/plink_score.cpp:407-408)
+ *   weights      [n_scored][n_cols] doubles, row-major
+ *   flip[i]      scored allele is REF (dosage 2 - alt)      (may be NULL)
+ *   mode         PGH_SCORE_MEAN_IMPUTE | _NO_MEAN_IMPUTATION | _CENTER
+ * Outputs over the included samples (ascending file order):
+ *   score_sum    [n_out][n_cols], dosage_sum [n_out], allele_ct [n_out]. */
+enum { PGH_SCORE_MEAN_IMPUTE = 0, PGH_SCORE_NO_MEAN_IMPUTATION = 1, PGH_SCORE_CENTER = 2 };
+int pgh_score(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_scored, const uint32_t *vidx,
+              const double *weights, const uint8_t *flip, uint32_t n_cols, int mode, double *score_sum,
+              double *dosage_sum, uint32_t *allele_ct, char *errbuf);
+/* Device form: raw-sample order (no compaction), outputs are caller-owned device
+ * buffers of raw_sample_ct rows, overwritten. */
+int pgh_score_dev(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_scored, const uint32_t *vidx,
+                  const double *weights, const uint8_t *flip, uint32_t n_cols, int mode, void *d_score_sum,
+                  void *d_dosage_sum, void *d_allele_ct, void *stream, char *errbuf);
+
+/* ---- per-variant calls mirroring pgenlib -------------------------------- */
+
+/* PgrInit + PgrSetSampleSubsetIndex per scan thread (src/plink_freq.cpp:381-397). */
+int pgh_reader_create(const pgh_dataset *ds, const pgh_subset *subset, pgh_reader **out, char *errbuf);
+void pgh_reader_destroy(pgh_reader *rd);
+/* PgrGet (src/pgen_reader.cpp:727): subset-compacted 2-bit genovec, ceil(n_out/32) words. */
+int pgh_get_2bit(pgh_reader *rd, uint32_t vidx, uint64_t *genovec);
+/* PgrGetCounts (src/plink_freq.cpp:482). */
+int pgh_get_counts(pgh_reader *rd, uint32_t vidx, uint32_t out[4]);
+/* PgrGetMissingness (src/plink_missing.cpp:479): ceil(n_out/64) words, bit set = missing. */
+int pgh_get_missingness(pgh_reader *rd, uint32_t vidx, uint64_t *bits);
+/* PgrGet + GenoarrToBytesMinus9 (src/plink_freq.cpp:463-469): {0,1,2,-9}. */
+int pgh_get_int8(pgh_reader *rd, uint32_t vidx, int8_t *out);
+/* PgrGetD + Dosage16ToDoublesMinus9 (src/plink_score.cpp:586-596): -9.0 = missing. */
+int pgh_get_dosage_f64(pgh_reader *rd, uint32_t vidx, double *out);
+const char *pgh_reader_error(const pgh_reader *rd);
+
+/* ---- HWE exact tests (host) --------------------------------------------- */
+
+/* plink2::HweLnP (src/plink_hardy.cpp:78): ln of the two-sided exact-test p. */
+double pgh_hwe_lnp(int32_t obs_hets, int32_t obs_hom1, int32_t obs_hom2, uint32_t midp);
+/* plink2::HweXchrLnP (src/plink_hardy.cpp:94). */
+double pgh_hwe_xchr_lnp(int32_t female_hets, int32_t female_hom1, int32_t female_hom2, int32_t male1, int32_t male2,
+                        uint32_t midp);
+/* Batch of autosomal tests on the device, straight from a counts array:
+ * ln_p[i] from counts[i] = {hom_ref, het, hom_alt, missing}. */
+int pgh_hwe_lnp_batch(const uint32_t (*counts)[4], uint32_t n, uint32_t midp, double *ln_p, char *errbuf);
+/* Same with device buffers: d_counts uint32[n][4] -> d_ln_p double[n]. */
+int pgh_hwe_lnp_batch_dev(const void *d_counts, uint32_t n, uint32_t midp, void *d_ln_p, void *stream, char *errbuf);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGENHIP_H_ */

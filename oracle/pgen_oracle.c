@@ -774,98 +774,47 @@ int pgo_missing_per_sample(const pgo_file *h, uint32_t v0, uint32_t v1, const ui
 /* HWE exact tests                                                           */
 /* ------------------------------------------------------------------------- */
 
-/* Relative tolerance when comparing table probabilities with the observed one:
- * tables whose probability is equal up to rounding count as ties. */
-#define PGO_TIE_EPS 9.094947017729282e-13 /* 2^-40 */
-
 /* Autosomal exact test (Wigginton, Cutler, Abecasis 2005), two-sided: sum of
  * the probabilities of all het counts no likelier than the observed one;
  * mid-p subtracts half the probability of the tables tied with the observed.
- * Computed from ratios relative to the modal table so nothing overflows. */
+ * Every table is evaluated directly in log space with lgamma (slow, O(range)
+ * lgamma calls, but with no recurrence to get wrong):
+ *   P(k hets) = 2^k n! nA! nB! / (hA! k! hB! (2n)!),  hA = (nA-k)/2, hB = (nB-k)/2 */
+static double hwe_lnprob(int64_t n, int64_t nA, int64_t nB, int64_t k) {
+	int64_t hA = (nA - k) / 2, hB = (nB - k) / 2;
+	return (double)k * M_LN2 + lgamma((double)n + 1) + lgamma((double)nA + 1) + lgamma((double)nB + 1) -
+	       lgamma((double)hA + 1) - lgamma((double)k + 1) - lgamma((double)hB + 1) - lgamma(2.0 * (double)n + 1);
+}
+
 double pgo_hwe_lnp(int32_t obs_hets, int32_t obs_hom1, int32_t obs_hom2, uint32_t midp) {
 	int64_t n = (int64_t)obs_hets + obs_hom1 + obs_hom2;
 	if (n == 0) {
 		return 0.0;
 	}
-	int64_t hom_r = obs_hom1 < obs_hom2 ? obs_hom1 : obs_hom2;
-	int64_t rare = 2 * hom_r + obs_hets;
-	int64_t common = 2 * n - rare;
-	/* modal het count with the right parity */
-	double exp_het = (double)rare * (double)common / (double)(2 * n - 1 > 0 ? 2 * n - 1 : 1);
-	int64_t mode = (int64_t)exp_het;
-	if ((mode & 1) != (rare & 1)) {
-		mode++;
-	}
-	if (mode > rare) {
-		mode -= 2;
-	}
-	if (mode < 0) {
-		mode += 2;
-	}
-/* ratio P(k+2)/P(k) */
-#define UP(k) (4.0 * (double)((rare - (k)) / 2) * (double)((common - (k)) / 2) / ((double)((k) + 2) * (double)((k) + 1)))
-	while (mode + 2 <= rare && UP(mode) > 1.0) {
-		mode += 2;
-	}
-	while (mode - 2 >= 0 && UP(mode - 2) < 1.0) {
-		mode -= 2;
-	}
-	/* pass 1: probability of the observed table relative to the mode */
-	double p_obs = 1.0;
-	if (obs_hets > mode) {
-		for (int64_t k = mode; k < obs_hets; k += 2) {
-			p_obs *= UP(k);
-			if (p_obs == 0.0) {
-				break;
-			}
-		}
-	} else {
-		for (int64_t k = mode; k > obs_hets; k -= 2) {
-			p_obs /= UP(k - 2);
-			if (p_obs == 0.0) {
-				break;
-			}
+	int64_t nA = 2 * (int64_t)obs_hom1 + obs_hets;
+	int64_t nB = 2 * (int64_t)obs_hom2 + obs_hets;
+	int64_t rare = nA < nB ? nA : nB;
+	double ln_obs = hwe_lnprob(n, nA, nB, obs_hets);
+	double ln_max = ln_obs;
+	for (int64_t k = rare & 1; k <= rare; k += 2) {
+		double lp = hwe_lnprob(n, nA, nB, k);
+		if (lp > ln_max) {
+			ln_max = lp;
 		}
 	}
-	if (p_obs == 0.0) {
-		return -INFINITY;
-	}
-	double thresh_hi = p_obs * (1.0 + PGO_TIE_EPS);
-	double thresh_lo = p_obs * (1.0 - PGO_TIE_EPS);
+	/* probabilities relative to the modal table, so nothing overflows */
 	double total = 0.0, tail = 0.0, ties = 0.0;
-	double p = 1.0;
-	for (int64_t k = mode;; k += 2) {
-		total += p;
-		if (p <= thresh_hi) {
-			tail += p;
-			if (p >= thresh_lo) {
-				ties += p;
+	for (int64_t k = rare & 1; k <= rare; k += 2) {
+		double lp = hwe_lnprob(n, nA, nB, k);
+		double rel = exp(lp - ln_max);
+		total += rel;
+		if (lp <= ln_obs + 1e-9) {
+			tail += rel;
+			if (lp >= ln_obs - 1e-9) {
+				ties += rel;
 			}
 		}
-		if (k + 2 > rare) {
-			break;
-		}
-		p *= UP(k);
-		if (p < total * 1e-30 && p < thresh_lo * 1e-30) {
-			break;
-		}
 	}
-	p = 1.0;
-	for (int64_t k = mode; k - 2 >= 0;) {
-		p /= UP(k - 2);
-		k -= 2;
-		total += p;
-		if (p <= thresh_hi) {
-			tail += p;
-			if (p >= thresh_lo) {
-				ties += p;
-			}
-		}
-		if (p < total * 1e-30 && p < thresh_lo * 1e-30) {
-			break;
-		}
-	}
-#undef UP
 	if (midp) {
 		tail -= 0.5 * ties;
 	}

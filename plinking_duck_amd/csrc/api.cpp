@@ -1,0 +1,1218 @@
+// api.cpp -- the C ABI of libpgenhip (include/pgenhip.h): handles, HBM residency,
+// launches.  Host code only; the kernels live in kernels.hip.
+#include "../../include/pgenhip.h"
+
+#include "hwe_core.hpp"
+#include "kernels.hpp"
+#include "pgen_file.hpp"
+#include "synth.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using pgh::PgenIndex;
+using pgh::RowView;
+
+// ---------------------------------------------------------------------------
+// handle types
+// ---------------------------------------------------------------------------
+
+struct pgh_dataset {
+	int device = 0;
+	bool has_file = false;
+	std::string pgen_path;
+	PgenIndex index; // valid when has_file
+	uint32_t raw_variant_ct = 0;
+	uint32_t sample_ct = 0;
+	uint32_t record_bytes = 0;
+	uint32_t v_begin = 0; // resident range
+	uint32_t v_end = 0;
+	uint64_t pitch = 0;
+	uint8_t *d_rows = nullptr;
+
+	RowView View() const {
+		return RowView {d_rows, pitch, sample_ct, record_bytes};
+	}
+};
+
+struct pgh_subset {
+	const pgh_dataset *ds = nullptr;
+	uint32_t n_out = 0;
+	std::vector<uint64_t> include; // ceil(N/64) words
+	std::vector<uint32_t> sel;     // raw index of each included sample, ascending
+	uint8_t *d_mask2 = nullptr;    // one pitched row of 01 slots
+	uint32_t *d_sel = nullptr;
+};
+
+struct pgh_reader {
+	const pgh_dataset *ds = nullptr;
+	const pgh_subset *subset = nullptr;
+	hipStream_t stream = nullptr;
+	// counts window: one launch serves the next kWindow per-variant calls
+	static constexpr uint32_t kWindow = 128; // the reference's claim batch (src/plink_freq.cpp:413)
+	uint32_t win_begin = 0, win_end = 0;
+	uint32_t *d_counts = nullptr;
+	uint32_t *h_counts = nullptr; // pinned
+	uint8_t *h_row = nullptr;     // pinned, pitch bytes
+	std::unique_ptr<pgh::RecordFile> file;
+	std::unique_ptr<pgh::Normalizer> norm;
+	std::string err;
+};
+
+namespace {
+
+void SetErr(char *errbuf, const std::string &msg) {
+	if (errbuf) {
+		std::snprintf(errbuf, PGH_ERRBUF_LEN, "%s", msg.c_str());
+	}
+}
+
+int DeviceFail(char *errbuf, const char *what, hipError_t e) {
+	SetErr(errbuf, std::string(what) + ": " + hipGetErrorString(e));
+	return PGH_ERR_DEVICE;
+}
+
+#define PGH_HIP(call, what)                                                                                            \
+	do {                                                                                                               \
+		hipError_t e_ = (call);                                                                                        \
+		if (e_ != hipSuccess) {                                                                                        \
+			return DeviceFail(errbuf, what, e_);                                                                       \
+		}                                                                                                              \
+	} while (0)
+
+uint64_t ChoosePitch(uint32_t record_bytes) {
+	// whole 16-byte lanes always; 128-byte (cache line) aligned rows once rows are long
+	const uint64_t align = record_bytes >= 512 ? 128 : 16;
+	uint64_t p = (static_cast<uint64_t>(record_bytes) + align - 1) / align * align;
+	return p ? p : align;
+}
+
+// RAII device buffer for the host-output entry points
+struct DevBuf {
+	void *p = nullptr;
+	~DevBuf() {
+		if (p) {
+			(void)hipFree(p);
+		}
+	}
+	hipError_t Alloc(size_t bytes) {
+		return hipMalloc(&p, bytes ? bytes : 16);
+	}
+	template <class T>
+	T *As() {
+		return static_cast<T *>(p);
+	}
+};
+
+int CheckRange(const pgh_dataset *ds, uint32_t v_begin, uint32_t v_end, char *errbuf) {
+	if (!ds) {
+		SetErr(errbuf, "null dataset");
+		return PGH_ERR_ARG;
+	}
+	if (v_begin > v_end || v_begin < ds->v_begin || v_end > ds->v_end) {
+		char msg[160];
+		std::snprintf(msg, sizeof msg, "variant range [%u, %u) is outside the resident range [%u, %u)", v_begin, v_end,
+		              ds->v_begin, ds->v_end);
+		SetErr(errbuf, msg);
+		return PGH_ERR_ARG;
+	}
+	return PGH_OK;
+}
+
+int CheckSubset(const pgh_dataset *ds, const pgh_subset *ss, char *errbuf) {
+	if (ss && ss->ds != ds) {
+		SetErr(errbuf, "sample subset belongs to a different dataset");
+		return PGH_ERR_ARG;
+	}
+	return PGH_OK;
+}
+
+// compact `raw` (one value per raw sample) to the included samples
+template <class T>
+void Compact(const pgh_subset *ss, const T *raw, size_t stride, T *out, uint32_t n_raw) {
+	if (!ss) {
+		for (uint32_t s = 0; s < n_raw; s++) {
+			std::memcpy(out + static_cast<size_t>(s) * stride, raw + static_cast<size_t>(s) * stride,
+			            sizeof(T) * stride);
+		}
+		return;
+	}
+	for (uint32_t k = 0; k < ss->n_out; k++) {
+		std::memcpy(out + static_cast<size_t>(k) * stride, raw + static_cast<size_t>(ss->sel[k]) * stride,
+		            sizeof(T) * stride);
+	}
+}
+
+int AllocRows(pgh_dataset *ds, char *errbuf) {
+	const uint64_t rows = ds->v_end - ds->v_begin;
+	const uint64_t bytes = rows * ds->pitch;
+	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_rows), bytes ? bytes : 16), "hipMalloc(genotype rows)");
+	return PGH_OK;
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------
+// library / device
+// ---------------------------------------------------------------------------
+
+extern "C" const char *pgh_version(void) {
+	return "pgenhip 1 gfx950";
+}
+
+extern "C" int pgh_device_count(void) {
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) {
+		return 0;
+	}
+	return n;
+}
+
+extern "C" int pgh_set_device(int device, char *errbuf) {
+	PGH_HIP(hipSetDevice(device), "hipSetDevice");
+	return PGH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// dataset lifecycle
+// ---------------------------------------------------------------------------
+
+static void FillInfo(const PgenIndex &ix, pgh_info *out) {
+	std::memset(out, 0, sizeof *out);
+	out->raw_variant_ct = ix.variant_ct;
+	out->raw_sample_ct = ix.sample_ct;
+	out->variant_begin = 0;
+	out->variant_end = ix.variant_ct;
+	out->has_dosage = ix.has_dosage;
+	out->has_phase = ix.has_phase;
+	out->max_record_bytes = ix.max_record_bytes;
+	out->record_bytes = ix.RecordBytes();
+	out->pitch_bytes = ChoosePitch(ix.RecordBytes());
+	for (int i = 0; i < 8; i++) {
+		out->vrtype_hist[i] = ix.vrtype_hist[i];
+	}
+	out->device = -1;
+}
+
+extern "C" int pgh_probe(const char *pgen_path, const char *pgi_path, pgh_info *out, char *errbuf) {
+	if (!pgen_path || !out) {
+		SetErr(errbuf, "null argument");
+		return PGH_ERR_ARG;
+	}
+	PgenIndex ix;
+	std::string err;
+	if (!pgh::ParsePgenIndex(pgen_path, pgi_path ? pgi_path : "", ix, err)) {
+		SetErr(errbuf, err);
+		return err.find("cannot open") != std::string::npos ? PGH_ERR_OPEN : PGH_ERR_FORMAT;
+	}
+	FillInfo(ix, out);
+	return PGH_OK;
+}
+
+extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t variant_begin, uint32_t variant_end,
+                        pgh_dataset **out, char *errbuf) {
+	if (!pgen_path || !out) {
+		SetErr(errbuf, "null argument");
+		return PGH_ERR_ARG;
+	}
+	*out = nullptr;
+	std::unique_ptr<pgh_dataset> ds(new pgh_dataset());
+	std::string err;
+	if (!pgh::ParsePgenIndex(pgen_path, pgi_path ? pgi_path : "", ds->index, err)) {
+		SetErr(errbuf, err);
+		return err.find("cannot open") != std::string::npos ? PGH_ERR_OPEN : PGH_ERR_FORMAT;
+	}
+	const PgenIndex &ix = ds->index;
+	if (ix.has_multiallelic) {
+		SetErr(errbuf, "multiallelic hardcall tracks are not supported");
+		return PGH_ERR_UNSUPPORTED;
+	}
+	if (variant_end == UINT32_MAX) {
+		variant_end = ix.variant_ct;
+	}
+	if (variant_begin > variant_end || variant_end > ix.variant_ct) {
+		SetErr(errbuf, "variant range out of bounds");
+		return PGH_ERR_ARG;
+	}
+	ds->has_file = true;
+	ds->pgen_path = pgen_path;
+	ds->raw_variant_ct = ix.variant_ct;
+	ds->sample_ct = ix.sample_ct;
+	ds->record_bytes = ix.RecordBytes();
+	ds->pitch = ChoosePitch(ds->record_bytes);
+	ds->v_begin = variant_begin;
+	ds->v_end = variant_end;
+	PGH_HIP(hipGetDevice(&ds->device), "hipGetDevice");
+	int rc = AllocRows(ds.get(), errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+
+	// Stream the body through two pinned staging buffers: the host normaliser
+	// fills one while the previous one is in flight to HBM.
+	pgh::RecordFile file;
+	if (!file.Open(pgen_path, err)) {
+		SetErr(errbuf, err);
+		pgh_close(ds.release());
+		return PGH_ERR_OPEN;
+	}
+	pgh::Normalizer norm(ix, file);
+	const uint64_t stage_bytes = 64ull << 20;
+	uint32_t rows_per_stage = static_cast<uint32_t>(std::max<uint64_t>(1, stage_bytes / ds->pitch));
+	uint8_t *stage[2] = {nullptr, nullptr};
+	hipEvent_t done[2] = {nullptr, nullptr};
+	hipStream_t stream = nullptr;
+	auto cleanup = [&]() {
+		for (int i = 0; i < 2; i++) {
+			if (stage[i]) {
+				(void)hipHostFree(stage[i]);
+			}
+			if (done[i]) {
+				(void)hipEventDestroy(done[i]);
+			}
+		}
+		if (stream) {
+			(void)hipStreamDestroy(stream);
+		}
+	};
+	hipError_t e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+	for (int i = 0; i < 2 && e == hipSuccess; i++) {
+		e = hipHostMalloc(reinterpret_cast<void **>(&stage[i]), static_cast<size_t>(rows_per_stage) * ds->pitch,
+		                  hipHostMallocDefault);
+		if (e == hipSuccess) {
+			e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+		}
+	}
+	if (e != hipSuccess) {
+		cleanup();
+		pgh_close(ds.release());
+		return DeviceFail(errbuf, "staging setup", e);
+	}
+	int which = 0;
+	bool used[2] = {false, false};
+	for (uint32_t v = variant_begin; v < variant_end; v += rows_per_stage) {
+		const uint32_t stop = std::min<uint64_t>(variant_end, static_cast<uint64_t>(v) + rows_per_stage);
+		if (used[which]) {
+			e = hipEventSynchronize(done[which]);
+			if (e != hipSuccess) {
+				break;
+			}
+		}
+		if (!norm.ExpandRange(v, stop, stage[which], ds->pitch, err)) {
+			(void)hipStreamSynchronize(stream);
+			cleanup();
+			SetErr(errbuf, err);
+			pgh_close(ds.release());
+			return PGH_ERR_FORMAT;
+		}
+		e = hipMemcpyAsync(ds->d_rows + static_cast<uint64_t>(v - variant_begin) * ds->pitch, stage[which],
+		                   static_cast<size_t>(stop - v) * ds->pitch, hipMemcpyHostToDevice, stream);
+		if (e == hipSuccess) {
+			e = hipEventRecord(done[which], stream);
+		}
+		if (e != hipSuccess) {
+			break;
+		}
+		used[which] = true;
+		which ^= 1;
+	}
+	if (e == hipSuccess) {
+		e = hipStreamSynchronize(stream);
+	}
+	cleanup();
+	if (e != hipSuccess) {
+		pgh_close(ds.release());
+		return DeviceFail(errbuf, "genotype upload", e);
+	}
+	*out = ds.release();
+	return PGH_OK;
+}
+
+extern "C" int pgh_normalize_range_host(const char *pgen_path, const char *pgi_path, uint32_t variant_begin,
+                                        uint32_t variant_end, uint8_t *rows, size_t row_stride, char *errbuf) {
+	if (!pgen_path || (!rows && variant_end > variant_begin)) {
+		SetErr(errbuf, "null argument");
+		return PGH_ERR_ARG;
+	}
+	PgenIndex ix;
+	std::string err;
+	if (!pgh::ParsePgenIndex(pgen_path, pgi_path ? pgi_path : "", ix, err)) {
+		SetErr(errbuf, err);
+		return err.find("cannot open") != std::string::npos ? PGH_ERR_OPEN : PGH_ERR_FORMAT;
+	}
+	if (variant_end == UINT32_MAX) {
+		variant_end = ix.variant_ct;
+	}
+	if (variant_begin > variant_end || variant_end > ix.variant_ct || row_stride < ix.RecordBytes()) {
+		SetErr(errbuf, "variant range or row_stride out of bounds");
+		return PGH_ERR_ARG;
+	}
+	pgh::RecordFile file;
+	if (!file.Open(pgen_path, err)) {
+		SetErr(errbuf, err);
+		return PGH_ERR_OPEN;
+	}
+	pgh::Normalizer norm(ix, file);
+	if (!norm.ExpandRange(variant_begin, variant_end, rows, row_stride, err)) {
+		SetErr(errbuf, err);
+		return PGH_ERR_FORMAT;
+	}
+	return PGH_OK;
+}
+
+extern "C" int pgh_from_host_rows(const uint8_t *rows, size_t row_stride, uint32_t variant_ct, uint32_t sample_ct,
+                                  pgh_dataset **out, char *errbuf) {
+	if (!out || (!rows && variant_ct) || sample_ct == 0) {
+		SetErr(errbuf, "bad argument");
+		return PGH_ERR_ARG;
+	}
+	*out = nullptr;
+	std::unique_ptr<pgh_dataset> ds(new pgh_dataset());
+	ds->raw_variant_ct = variant_ct;
+	ds->sample_ct = sample_ct;
+	ds->record_bytes = (sample_ct + 3) / 4;
+	ds->pitch = ChoosePitch(ds->record_bytes);
+	ds->v_begin = 0;
+	ds->v_end = variant_ct;
+	if (row_stride < ds->record_bytes) {
+		SetErr(errbuf, "row_stride smaller than ceil(N/4)");
+		return PGH_ERR_ARG;
+	}
+	PGH_HIP(hipGetDevice(&ds->device), "hipGetDevice");
+	int rc = AllocRows(ds.get(), errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	if (variant_ct) {
+		hipError_t e = hipMemset(ds->d_rows, 0, static_cast<size_t>(variant_ct) * ds->pitch);
+		if (e == hipSuccess) {
+			e = hipMemcpy2D(ds->d_rows, ds->pitch, rows, row_stride, ds->record_bytes, variant_ct,
+			                hipMemcpyHostToDevice);
+		}
+		if (e == hipSuccess) {
+			e = pgh::LaunchSanitizeTail(ds->d_rows, ds->pitch, sample_ct, variant_ct, nullptr);
+		}
+		if (e == hipSuccess) {
+			e = hipDeviceSynchronize();
+		}
+		if (e != hipSuccess) {
+			pgh_close(ds.release());
+			return DeviceFail(errbuf, "row upload", e);
+		}
+	}
+	*out = ds.release();
+	return PGH_OK;
+}
+
+extern "C" int pgh_synth_create(uint32_t variant_begin, uint32_t variant_end, uint32_t sample_ct, uint64_t seed,
+                                double missing_rate, pgh_dataset **out, char *errbuf) {
+	if (!out || variant_begin > variant_end || sample_ct == 0) {
+		SetErr(errbuf, "bad argument");
+		return PGH_ERR_ARG;
+	}
+	*out = nullptr;
+	std::unique_ptr<pgh_dataset> ds(new pgh_dataset());
+	ds->raw_variant_ct = variant_end;
+	ds->sample_ct = sample_ct;
+	ds->record_bytes = (sample_ct + 3) / 4;
+	ds->pitch = ChoosePitch(ds->record_bytes);
+	ds->v_begin = variant_begin;
+	ds->v_end = variant_end;
+	PGH_HIP(hipGetDevice(&ds->device), "hipGetDevice");
+	int rc = AllocRows(ds.get(), errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	hipError_t e = pgh::LaunchSynthFill(ds->d_rows, ds->pitch, sample_ct, variant_begin, variant_end - variant_begin,
+	                                    seed, pgh::SynthMissThreshold(missing_rate), nullptr);
+	if (e == hipSuccess) {
+		e = hipDeviceSynchronize();
+	}
+	if (e != hipSuccess) {
+		pgh_close(ds.release());
+		return DeviceFail(errbuf, "synthetic fill", e);
+	}
+	*out = ds.release();
+	return PGH_OK;
+}
+
+extern "C" int pgh_synth_record_host(uint32_t v, uint32_t sample_ct, uint64_t seed, double missing_rate,
+                                     uint8_t *out) {
+	if (!out || sample_ct == 0) {
+		return PGH_ERR_ARG;
+	}
+	const uint32_t thr = pgh::SynthMissThreshold(missing_rate);
+	const pgh::SynthVariant sv = pgh::SynthVariantParams(seed, v);
+	std::memset(out, 0, (static_cast<size_t>(sample_ct) + 3) / 4);
+	for (uint32_t s = 0; s < sample_ct; s++) {
+		out[s >> 2] |= static_cast<uint8_t>(pgh::SynthGenotype(sv, s, thr) << (2 * (s & 3)));
+	}
+	return PGH_OK;
+}
+
+extern "C" int pgh_synth_write_files(const char *prefix, uint32_t variant_ct, uint32_t sample_ct, uint64_t seed,
+                                     double missing_rate, char *errbuf) {
+	if (!prefix || sample_ct == 0) {
+		SetErr(errbuf, "bad argument");
+		return PGH_ERR_ARG;
+	}
+	const std::string base(prefix);
+	const uint32_t rb = (sample_ct + 3) / 4;
+	if (rb > 0xffffffu) {
+		SetErr(errbuf, "sample count too large for 3-byte record lengths");
+		return PGH_ERR_ARG;
+	}
+	FILE *f = std::fopen((base + ".pgen").c_str(), "wb");
+	if (!f) {
+		SetErr(errbuf, "cannot create '" + base + ".pgen'");
+		return PGH_ERR_OPEN;
+	}
+	// mode 0x10; ctrl: 4-bit vrtypes + the narrowest record-length width, nonref mode 1
+	const uint32_t len_bytes = rb < 0x100 ? 1 : (rb < 0x10000 ? 2 : 3);
+	const uint8_t ctrl = static_cast<uint8_t>(0x40 | (len_bytes - 1));
+	std::vector<uint8_t> head = {0x6c, 0x1b, 0x10};
+	auto put = [&](uint64_t v, int n) {
+		for (int i = 0; i < n; i++) {
+			head.push_back(static_cast<uint8_t>(v >> (8 * i)));
+		}
+	};
+	put(variant_ct, 4);
+	put(sample_ct, 4);
+	head.push_back(ctrl);
+	const uint32_t blocks = (variant_ct + 65535) / 65536;
+	uint64_t table_bytes = 12 + 8ull * blocks;
+	for (uint32_t b = 0; b < blocks; b++) {
+		const uint32_t cnt = std::min<uint32_t>(65536, variant_ct - b * 65536u);
+		table_bytes += (cnt + 1) / 2 + static_cast<uint64_t>(cnt) * len_bytes;
+	}
+	for (uint32_t b = 0; b < blocks; b++) {
+		put(table_bytes + static_cast<uint64_t>(b) * 65536ull * rb, 8);
+	}
+	for (uint32_t b = 0; b < blocks; b++) {
+		const uint32_t cnt = std::min<uint32_t>(65536, variant_ct - b * 65536u);
+		head.insert(head.end(), (cnt + 1) / 2, 0); // vrtype 0
+		for (uint32_t i = 0; i < cnt; i++) {
+			put(rb, static_cast<int>(len_bytes));
+		}
+	}
+	bool ok = std::fwrite(head.data(), 1, head.size(), f) == head.size();
+	std::vector<uint8_t> rec(rb);
+	for (uint32_t v = 0; ok && v < variant_ct; v++) {
+		pgh_synth_record_host(v, sample_ct, seed, missing_rate, rec.data());
+		ok = std::fwrite(rec.data(), 1, rb, f) == rb;
+	}
+	ok = (std::fclose(f) == 0) && ok;
+	if (!ok) {
+		SetErr(errbuf, "write failed on '" + base + ".pgen'");
+		return PGH_ERR_OPEN;
+	}
+	f = std::fopen((base + ".pvar").c_str(), "w");
+	if (!f) {
+		SetErr(errbuf, "cannot create '" + base + ".pvar'");
+		return PGH_ERR_OPEN;
+	}
+	std::fprintf(f, "#CHROM\tPOS\tID\tREF\tALT\n");
+	for (uint32_t v = 0; v < variant_ct; v++) {
+		// 22 autosomes, equal-sized runs, ascending positions
+		const uint32_t per_chrom = (variant_ct + 21) / 22;
+		std::fprintf(f, "%u\t%u\tsv%u\tA\tG\n", v / per_chrom + 1, (v % per_chrom + 1) * 100, v);
+	}
+	std::fclose(f);
+	f = std::fopen((base + ".psam").c_str(), "w");
+	if (!f) {
+		SetErr(errbuf, "cannot create '" + base + ".psam'");
+		return PGH_ERR_OPEN;
+	}
+	std::fprintf(f, "#FID\tIID\tSEX\n");
+	for (uint32_t s = 0; s < sample_ct; s++) {
+		std::fprintf(f, "F%u\tS%u\t%u\n", s / 4, s, 1 + (s & 1));
+	}
+	std::fclose(f);
+	return PGH_OK;
+}
+
+extern "C" int pgh_copy_rows_to_host(const pgh_dataset *ds, uint32_t v_begin, uint32_t v_end, uint8_t *rows,
+                                     size_t row_stride, char *errbuf) {
+	int rc = CheckRange(ds, v_begin, v_end, errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	if (v_end == v_begin) {
+		return PGH_OK;
+	}
+	if (!rows || row_stride < ds->record_bytes) {
+		SetErr(errbuf, "bad destination");
+		return PGH_ERR_ARG;
+	}
+	PGH_HIP(hipMemcpy2D(rows, row_stride, ds->d_rows + static_cast<uint64_t>(v_begin - ds->v_begin) * ds->pitch,
+	                    ds->pitch, ds->record_bytes, v_end - v_begin, hipMemcpyDeviceToHost),
+	        "row download");
+	return PGH_OK;
+}
+
+extern "C" int pgh_get_info(const pgh_dataset *ds, pgh_info *out) {
+	if (!ds || !out) {
+		return PGH_ERR_ARG;
+	}
+	if (ds->has_file) {
+		FillInfo(ds->index, out);
+	} else {
+		std::memset(out, 0, sizeof *out);
+		out->raw_variant_ct = ds->raw_variant_ct;
+		out->raw_sample_ct = ds->sample_ct;
+		out->record_bytes = ds->record_bytes;
+		out->max_record_bytes = ds->record_bytes;
+		out->vrtype_hist[0] = ds->v_end - ds->v_begin;
+	}
+	out->variant_begin = ds->v_begin;
+	out->variant_end = ds->v_end;
+	out->pitch_bytes = ds->pitch;
+	out->device = ds->device;
+	return PGH_OK;
+}
+
+extern "C" const void *pgh_device_rows(const pgh_dataset *ds) {
+	return ds ? ds->d_rows : nullptr;
+}
+
+extern "C" void pgh_close(pgh_dataset *ds) {
+	if (!ds) {
+		return;
+	}
+	if (ds->d_rows) {
+		(void)hipFree(ds->d_rows);
+	}
+	delete ds;
+}
+
+// ---------------------------------------------------------------------------
+// sample subsets
+// ---------------------------------------------------------------------------
+
+extern "C" int pgh_subset_create(const pgh_dataset *ds, const uint64_t *sample_include, pgh_subset **out,
+                                 char *errbuf) {
+	if (!ds || !sample_include || !out) {
+		SetErr(errbuf, "null argument");
+		return PGH_ERR_ARG;
+	}
+	*out = nullptr;
+	std::unique_ptr<pgh_subset> ss(new pgh_subset());
+	ss->ds = ds;
+	const uint32_t N = ds->sample_ct;
+	ss->include.assign(sample_include, sample_include + (N + 63) / 64);
+	std::vector<uint8_t> mask2(ds->pitch, 0);
+	for (uint32_t s = 0; s < N; s++) {
+		if ((ss->include[s >> 6] >> (s & 63)) & 1ull) {
+			ss->sel.push_back(s);
+			mask2[s >> 2] |= static_cast<uint8_t>(1u << (2 * (s & 3)));
+		}
+	}
+	ss->n_out = static_cast<uint32_t>(ss->sel.size());
+	hipError_t e = hipMalloc(reinterpret_cast<void **>(&ss->d_mask2), ds->pitch);
+	if (e == hipSuccess) {
+		e = hipMemcpy(ss->d_mask2, mask2.data(), ds->pitch, hipMemcpyHostToDevice);
+	}
+	if (e == hipSuccess) {
+		e = hipMalloc(reinterpret_cast<void **>(&ss->d_sel), sizeof(uint32_t) * std::max<uint32_t>(1, ss->n_out));
+	}
+	if (e == hipSuccess && ss->n_out) {
+		e = hipMemcpy(ss->d_sel, ss->sel.data(), sizeof(uint32_t) * ss->n_out, hipMemcpyHostToDevice);
+	}
+	if (e != hipSuccess) {
+		pgh_subset_destroy(ss.release());
+		return DeviceFail(errbuf, "subset upload", e);
+	}
+	*out = ss.release();
+	return PGH_OK;
+}
+
+extern "C" uint32_t pgh_subset_size(const pgh_subset *ss) {
+	return ss ? ss->n_out : 0;
+}
+
+extern "C" void pgh_subset_destroy(pgh_subset *ss) {
+	if (!ss) {
+		return;
+	}
+	if (ss->d_mask2) {
+		(void)hipFree(ss->d_mask2);
+	}
+	if (ss->d_sel) {
+		(void)hipFree(ss->d_sel);
+	}
+	delete ss;
+}
+
+// ---------------------------------------------------------------------------
+// batched device calls
+// ---------------------------------------------------------------------------
+
+extern "C" int pgh_counts_range_dev(const pgh_dataset *ds, const pgh_subset *subset, uint32_t v_begin, uint32_t v_end,
+                                    void *d_out, void *stream, char *errbuf) {
+	int rc = CheckRange(ds, v_begin, v_end, errbuf);
+	if (rc == PGH_OK) {
+		rc = CheckSubset(ds, subset, errbuf);
+	}
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	PGH_HIP(pgh::LaunchCounts(ds->View(), v_begin - ds->v_begin, nullptr, v_end - v_begin,
+	                          subset ? subset->d_mask2 : nullptr, subset ? subset->n_out : ds->sample_ct,
+	                          static_cast<uint32_t *>(d_out), static_cast<hipStream_t>(stream)),
+	        "counts kernel");
+	return PGH_OK;
+}
+
+extern "C" int pgh_counts_range(const pgh_dataset *ds, const pgh_subset *subset, uint32_t v_begin, uint32_t v_end,
+                                uint32_t (*out)[4], char *errbuf) {
+	int rc = CheckRange(ds, v_begin, v_end, errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	const size_t n = v_end - v_begin;
+	if (n == 0) {
+		return PGH_OK;
+	}
+	DevBuf buf;
+	PGH_HIP(buf.Alloc(n * 16), "hipMalloc(counts)");
+	rc = pgh_counts_range_dev(ds, subset, v_begin, v_end, buf.p, hipStreamPerThread, errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	PGH_HIP(hipMemcpyAsync(out, buf.p, n * 16, hipMemcpyDeviceToHost, hipStreamPerThread), "counts copy");
+	PGH_HIP(hipStreamSynchronize(hipStreamPerThread), "counts sync");
+	return PGH_OK;
+}
+
+extern "C" int pgh_freq_from_counts_dev(const void *d_counts, uint32_t n, void *d_alt_freq, void *d_obs_ct,
+                                        void *stream, char *errbuf) {
+	if (n && (!d_counts || !d_alt_freq || !d_obs_ct)) {
+		SetErr(errbuf, "null argument");
+		return PGH_ERR_ARG;
+	}
+	PGH_HIP(pgh::LaunchFreqFromCounts(static_cast<const uint32_t *>(d_counts), n, static_cast<double *>(d_alt_freq),
+	                                  static_cast<int32_t *>(d_obs_ct), static_cast<hipStream_t>(stream)),
+	        "freq kernel");
+	return PGH_OK;
+}
+
+extern "C" int pgh_missing_per_sample_dev(const pgh_dataset *ds, uint32_t v_begin, uint32_t v_end, void *d_out,
+                                          void *stream, char *errbuf) {
+	int rc = CheckRange(ds, v_begin, v_end, errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	PGH_HIP(hipMemsetAsync(d_out, 0, sizeof(uint32_t) * ds->sample_ct, st), "missing memset");
+	PGH_HIP(pgh::LaunchMissingPerSample(ds->View(), v_begin - ds->v_begin, nullptr, v_end - v_begin,
+	                                    static_cast<uint32_t *>(d_out), st),
+	        "missing-per-sample kernel");
+	return PGH_OK;
+}
+
+extern "C" int pgh_missing_per_sample(const pgh_dataset *ds, const pgh_subset *subset, uint32_t v_begin,
+                                      uint32_t v_end, uint32_t *out, char *errbuf) {
+	int rc = CheckRange(ds, v_begin, v_end, errbuf);
+	if (rc == PGH_OK) {
+		rc = CheckSubset(ds, subset, errbuf);
+	}
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	const uint32_t N = ds->sample_ct;
+	const uint32_t padded = (N + 63) / 64 * 64;
+	DevBuf buf;
+	PGH_HIP(buf.Alloc(sizeof(uint32_t) * padded), "hipMalloc(missing)");
+	rc = pgh_missing_per_sample_dev(ds, v_begin, v_end, buf.p, hipStreamPerThread, errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	std::vector<uint32_t> raw(N);
+	PGH_HIP(hipMemcpyAsync(raw.data(), buf.p, sizeof(uint32_t) * N, hipMemcpyDeviceToHost, hipStreamPerThread),
+	        "missing copy");
+	PGH_HIP(hipStreamSynchronize(hipStreamPerThread), "missing sync");
+	Compact<uint32_t>(subset, raw.data(), 1, out, N);
+	return PGH_OK;
+}
+
+extern "C" int pgh_unpack_range_dev(const pgh_dataset *ds, const pgh_subset *subset, uint32_t v_begin, uint32_t v_end,
+                                    void *d_out, size_t out_pitch, void *d_validity, int missing_code, void *stream,
+                                    char *errbuf) {
+	int rc = CheckRange(ds, v_begin, v_end, errbuf);
+	if (rc == PGH_OK) {
+		rc = CheckSubset(ds, subset, errbuf);
+	}
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	const uint32_t n_out = subset ? subset->n_out : ds->sample_ct;
+	if (d_out && (out_pitch % 16 != 0 || out_pitch < (static_cast<size_t>(n_out) + 15) / 16 * 16)) {
+		SetErr(errbuf, "out_pitch must be a multiple of 16 covering the row");
+		return PGH_ERR_ARG;
+	}
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	if (subset) {
+		PGH_HIP(pgh::LaunchUnpackSubset(ds->View(), v_begin - ds->v_begin, v_end - v_begin, subset->d_sel, n_out,
+		                                static_cast<int8_t *>(d_out), out_pitch, static_cast<uint64_t *>(d_validity),
+		                                static_cast<int8_t>(missing_code), st),
+		        "unpack kernel");
+	} else {
+		PGH_HIP(pgh::LaunchUnpack(ds->View(), v_begin - ds->v_begin, v_end - v_begin, static_cast<int8_t *>(d_out),
+		                          out_pitch, static_cast<uint64_t *>(d_validity), static_cast<int8_t>(missing_code),
+		                          st),
+		        "unpack kernel");
+	}
+	return PGH_OK;
+}
+
+extern "C" int pgh_unpack_range(const pgh_dataset *ds, const pgh_subset *subset, uint32_t v_begin, uint32_t v_end,
+                                int8_t *out, uint64_t *validity, int missing_code, char *errbuf) {
+	int rc = CheckRange(ds, v_begin, v_end, errbuf);
+	if (rc == PGH_OK) {
+		rc = CheckSubset(ds, subset, errbuf);
+	}
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	const uint32_t n_out = subset ? subset->n_out : ds->sample_ct;
+	const size_t rows = v_end - v_begin;
+	if (rows == 0 || n_out == 0) {
+		return PGH_OK;
+	}
+	const size_t out_pitch = (static_cast<size_t>(n_out) + 15) / 16 * 16;
+	const size_t val_words = (n_out + 63) / 64;
+	// chunk the range so the device staging stays bounded (output is 4x the input)
+	const size_t max_rows = std::max<size_t>(1, (512ull << 20) / out_pitch);
+	DevBuf d_out, d_val;
+	const size_t chunk_rows = std::min(rows, max_rows);
+	if (out) {
+		PGH_HIP(d_out.Alloc(chunk_rows * out_pitch), "hipMalloc(unpack)");
+	}
+	if (validity) {
+		PGH_HIP(d_val.Alloc(chunk_rows * val_words * 8), "hipMalloc(validity)");
+	}
+	for (size_t r0 = 0; r0 < rows; r0 += chunk_rows) {
+		const size_t r1 = std::min(rows, r0 + chunk_rows);
+		rc = pgh_unpack_range_dev(ds, subset, v_begin + static_cast<uint32_t>(r0), v_begin + static_cast<uint32_t>(r1),
+		                          d_out.p, out_pitch, d_val.p, missing_code, hipStreamPerThread, errbuf);
+		if (rc != PGH_OK) {
+			return rc;
+		}
+		if (out) {
+			PGH_HIP(hipMemcpy2DAsync(out + r0 * n_out, n_out, d_out.p, out_pitch, n_out, r1 - r0,
+			                         hipMemcpyDeviceToHost, hipStreamPerThread),
+			        "unpack copy");
+		}
+		if (validity) {
+			PGH_HIP(hipMemcpyAsync(validity + r0 * val_words, d_val.p, (r1 - r0) * val_words * 8,
+			                       hipMemcpyDeviceToHost, hipStreamPerThread),
+			        "validity copy");
+		}
+		PGH_HIP(hipStreamSynchronize(hipStreamPerThread), "unpack sync");
+	}
+	return PGH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// plink_score
+// ---------------------------------------------------------------------------
+
+namespace {
+
+struct ScoreScratch {
+	DevBuf vlist, weights, flip, counts, ts, td, ac;
+};
+
+int ScoreEnqueue(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_scored, const uint32_t *vidx,
+                 const double *weights, const uint8_t *flip, uint32_t n_cols, int mode, ScoreScratch &sc,
+                 double *d_score, double *d_dosage, uint32_t *d_allele, hipStream_t st, char *errbuf) {
+	if (!ds || (n_scored && (!vidx || !weights))) {
+		SetErr(errbuf, "null argument");
+		return PGH_ERR_ARG;
+	}
+	if (mode < 0 || mode > 2) {
+		SetErr(errbuf, "unknown score mode");
+		return PGH_ERR_ARG;
+	}
+	if (!(n_cols == 1 || n_cols == 2 || n_cols == 4 || n_cols == 8 || n_cols == 16)) {
+		SetErr(errbuf, "n_cols must be 1, 2, 4, 8 or 16");
+		return PGH_ERR_ARG;
+	}
+	int rc = CheckSubset(ds, subset, errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	std::vector<uint32_t> local(n_scored);
+	for (uint32_t i = 0; i < n_scored; i++) {
+		if (vidx[i] < ds->v_begin || vidx[i] >= ds->v_end) {
+			SetErr(errbuf, "scored variant index outside the resident range");
+			return PGH_ERR_ARG;
+		}
+		local[i] = vidx[i] - ds->v_begin;
+	}
+	const uint32_t N = ds->sample_ct;
+	PGH_HIP(hipMemsetAsync(d_score, 0, sizeof(double) * N * n_cols, st), "score memset");
+	PGH_HIP(hipMemsetAsync(d_dosage, 0, sizeof(double) * N, st), "score memset");
+	PGH_HIP(hipMemsetAsync(d_allele, 0, sizeof(uint32_t) * N, st), "score memset");
+	if (n_scored == 0) {
+		return PGH_OK;
+	}
+	PGH_HIP(sc.vlist.Alloc(sizeof(uint32_t) * n_scored), "hipMalloc(score)");
+	PGH_HIP(sc.weights.Alloc(sizeof(double) * n_scored * n_cols), "hipMalloc(score)");
+	PGH_HIP(sc.counts.Alloc(16ull * n_scored), "hipMalloc(score)");
+	PGH_HIP(sc.ts.Alloc(32ull * n_scored), "hipMalloc(score)");
+	PGH_HIP(sc.td.Alloc(32ull * n_scored), "hipMalloc(score)");
+	PGH_HIP(sc.ac.Alloc(4ull * n_scored), "hipMalloc(score)");
+	PGH_HIP(hipMemcpyAsync(sc.vlist.p, local.data(), sizeof(uint32_t) * n_scored, hipMemcpyHostToDevice, st),
+	        "score upload");
+	PGH_HIP(hipMemcpyAsync(sc.weights.p, weights, sizeof(double) * n_scored * n_cols, hipMemcpyHostToDevice, st),
+	        "score upload");
+	if (flip) {
+		PGH_HIP(sc.flip.Alloc(n_scored), "hipMalloc(score)");
+		PGH_HIP(hipMemcpyAsync(sc.flip.p, flip, n_scored, hipMemcpyHostToDevice, st), "score upload");
+	}
+	// the host vectors above must outlive the async copies
+	PGH_HIP(hipStreamSynchronize(st), "score upload sync");
+	PGH_HIP(pgh::LaunchCounts(ds->View(), 0, sc.vlist.As<uint32_t>(), n_scored, subset ? subset->d_mask2 : nullptr,
+	                          subset ? subset->n_out : N, sc.counts.As<uint32_t>(), st),
+	        "score counts kernel");
+	PGH_HIP(pgh::LaunchScoreTables(sc.counts.As<uint32_t>(), sc.flip.As<uint8_t>(), n_scored, mode, sc.ts.As<double>(),
+	                               sc.td.As<double>(), sc.ac.As<uint32_t>(), st),
+	        "score table kernel");
+	PGH_HIP(pgh::LaunchScoreAccumulate(ds->View(), sc.vlist.As<uint32_t>(), n_scored, sc.weights.As<double>(), n_cols,
+	                                   sc.ts.As<double>(), sc.td.As<double>(), sc.ac.As<uint32_t>(), d_score, d_dosage,
+	                                   d_allele, st),
+	        "score accumulate kernel");
+	return PGH_OK;
+}
+
+} // namespace
+
+extern "C" int pgh_score_dev(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_scored, const uint32_t *vidx,
+                             const double *weights, const uint8_t *flip, uint32_t n_cols, int mode, void *d_score_sum,
+                             void *d_dosage_sum, void *d_allele_ct, void *stream, char *errbuf) {
+	ScoreScratch sc;
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	int rc = ScoreEnqueue(ds, subset, n_scored, vidx, weights, flip, n_cols, mode, sc, static_cast<double *>(d_score_sum),
+	                      static_cast<double *>(d_dosage_sum), static_cast<uint32_t *>(d_allele_ct), st, errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	// scratch is freed on return, so the work must have drained
+	PGH_HIP(hipStreamSynchronize(st), "score sync");
+	return PGH_OK;
+}
+
+extern "C" int pgh_score(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_scored, const uint32_t *vidx,
+                         const double *weights, const uint8_t *flip, uint32_t n_cols, int mode, double *score_sum,
+                         double *dosage_sum, uint32_t *allele_ct, char *errbuf) {
+	if (!ds) {
+		SetErr(errbuf, "null dataset");
+		return PGH_ERR_ARG;
+	}
+	const uint32_t N = ds->sample_ct;
+	DevBuf d_score, d_dos, d_ac;
+	PGH_HIP(d_score.Alloc(sizeof(double) * N * std::max<uint32_t>(1, n_cols)), "hipMalloc(score out)");
+	PGH_HIP(d_dos.Alloc(sizeof(double) * N), "hipMalloc(score out)");
+	PGH_HIP(d_ac.Alloc(sizeof(uint32_t) * N), "hipMalloc(score out)");
+	int rc = pgh_score_dev(ds, subset, n_scored, vidx, weights, flip, n_cols, mode, d_score.p, d_dos.p, d_ac.p,
+	                       hipStreamPerThread, errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	std::vector<double> h_score(static_cast<size_t>(N) * n_cols), h_dos(N);
+	std::vector<uint32_t> h_ac(N);
+	PGH_HIP(hipMemcpy(h_score.data(), d_score.p, sizeof(double) * N * n_cols, hipMemcpyDeviceToHost), "score copy");
+	PGH_HIP(hipMemcpy(h_dos.data(), d_dos.p, sizeof(double) * N, hipMemcpyDeviceToHost), "score copy");
+	PGH_HIP(hipMemcpy(h_ac.data(), d_ac.p, sizeof(uint32_t) * N, hipMemcpyDeviceToHost), "score copy");
+	Compact<double>(subset, h_score.data(), n_cols, score_sum, N);
+	Compact<double>(subset, h_dos.data(), 1, dosage_sum, N);
+	Compact<uint32_t>(subset, h_ac.data(), 1, allele_ct, N);
+	return PGH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// per-variant reader
+// ---------------------------------------------------------------------------
+
+extern "C" int pgh_reader_create(const pgh_dataset *ds, const pgh_subset *subset, pgh_reader **out, char *errbuf) {
+	if (!ds || !out) {
+		SetErr(errbuf, "null argument");
+		return PGH_ERR_ARG;
+	}
+	*out = nullptr;
+	int rc = CheckSubset(ds, subset, errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	std::unique_ptr<pgh_reader> rd(new pgh_reader());
+	rd->ds = ds;
+	rd->subset = subset;
+	hipError_t e = hipStreamCreateWithFlags(&rd->stream, hipStreamNonBlocking);
+	if (e == hipSuccess) {
+		e = hipMalloc(reinterpret_cast<void **>(&rd->d_counts), 16 * pgh_reader::kWindow);
+	}
+	if (e == hipSuccess) {
+		e = hipHostMalloc(reinterpret_cast<void **>(&rd->h_counts), 16 * pgh_reader::kWindow, hipHostMallocDefault);
+	}
+	if (e == hipSuccess) {
+		e = hipHostMalloc(reinterpret_cast<void **>(&rd->h_row), ds->pitch, hipHostMallocDefault);
+	}
+	if (e != hipSuccess) {
+		pgh_reader_destroy(rd.release());
+		return DeviceFail(errbuf, "reader setup", e);
+	}
+	if (ds->has_file && (ds->index.has_dosage || ds->index.has_phase)) {
+		rd->file.reset(new pgh::RecordFile());
+		std::string err;
+		if (!rd->file->Open(ds->pgen_path, err)) {
+			SetErr(errbuf, err);
+			pgh_reader_destroy(rd.release());
+			return PGH_ERR_OPEN;
+		}
+		rd->norm.reset(new pgh::Normalizer(ds->index, *rd->file));
+	}
+	*out = rd.release();
+	return PGH_OK;
+}
+
+extern "C" void pgh_reader_destroy(pgh_reader *rd) {
+	if (!rd) {
+		return;
+	}
+	if (rd->stream) {
+		(void)hipStreamSynchronize(rd->stream);
+	}
+	if (rd->d_counts) {
+		(void)hipFree(rd->d_counts);
+	}
+	if (rd->h_counts) {
+		(void)hipHostFree(rd->h_counts);
+	}
+	if (rd->h_row) {
+		(void)hipHostFree(rd->h_row);
+	}
+	if (rd->stream) {
+		(void)hipStreamDestroy(rd->stream);
+	}
+	delete rd;
+}
+
+extern "C" const char *pgh_reader_error(const pgh_reader *rd) {
+	return rd ? rd->err.c_str() : "null reader";
+}
+
+namespace {
+
+int ReaderFail(pgh_reader *rd, int code, const std::string &msg) {
+	rd->err = msg;
+	return code;
+}
+
+int ReaderCheck(pgh_reader *rd, uint32_t vidx) {
+	if (!rd) {
+		return PGH_ERR_ARG;
+	}
+	if (vidx < rd->ds->v_begin || vidx >= rd->ds->v_end) {
+		return ReaderFail(rd, PGH_ERR_ARG, "variant index " + std::to_string(vidx) + " outside the resident range");
+	}
+	return PGH_OK;
+}
+
+// raw 2-bit row of one variant -> pinned host buffer
+int FetchRow(pgh_reader *rd, uint32_t vidx) {
+	const pgh_dataset *ds = rd->ds;
+	hipError_t e = hipMemcpyAsync(rd->h_row, ds->d_rows + static_cast<uint64_t>(vidx - ds->v_begin) * ds->pitch,
+	                              ds->record_bytes, hipMemcpyDeviceToHost, rd->stream);
+	if (e == hipSuccess) {
+		e = hipStreamSynchronize(rd->stream);
+	}
+	if (e != hipSuccess) {
+		return ReaderFail(rd, PGH_ERR_DEVICE, std::string("row fetch: ") + hipGetErrorString(e));
+	}
+	return PGH_OK;
+}
+
+inline uint32_t RowCode(const uint8_t *row, uint32_t s) {
+	return (row[s >> 2] >> (2 * (s & 3))) & 3u;
+}
+
+template <class Fn>
+void ForEachIncluded(const pgh_reader *rd, Fn &&fn) {
+	if (rd->subset) {
+		for (uint32_t k = 0; k < rd->subset->n_out; k++) {
+			fn(k, rd->subset->sel[k]);
+		}
+	} else {
+		for (uint32_t s = 0; s < rd->ds->sample_ct; s++) {
+			fn(s, s);
+		}
+	}
+}
+
+} // namespace
+
+extern "C" int pgh_get_counts(pgh_reader *rd, uint32_t vidx, uint32_t out[4]) {
+	int rc = ReaderCheck(rd, vidx);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	if (vidx < rd->win_begin || vidx >= rd->win_end) {
+		const pgh_dataset *ds = rd->ds;
+		const uint32_t stop = std::min<uint64_t>(ds->v_end, static_cast<uint64_t>(vidx) + pgh_reader::kWindow);
+		char errbuf[PGH_ERRBUF_LEN];
+		rc = pgh_counts_range_dev(ds, rd->subset, vidx, stop, rd->d_counts, rd->stream, errbuf);
+		if (rc != PGH_OK) {
+			return ReaderFail(rd, rc, errbuf);
+		}
+		hipError_t e = hipMemcpyAsync(rd->h_counts, rd->d_counts, 16ull * (stop - vidx), hipMemcpyDeviceToHost,
+		                              rd->stream);
+		if (e == hipSuccess) {
+			e = hipStreamSynchronize(rd->stream);
+		}
+		if (e != hipSuccess) {
+			rd->win_begin = rd->win_end = 0;
+			return ReaderFail(rd, PGH_ERR_DEVICE, std::string("counts fetch: ") + hipGetErrorString(e));
+		}
+		rd->win_begin = vidx;
+		rd->win_end = stop;
+	}
+	std::memcpy(out, rd->h_counts + 4 * static_cast<size_t>(vidx - rd->win_begin), 16);
+	return PGH_OK;
+}
+
+extern "C" int pgh_get_2bit(pgh_reader *rd, uint32_t vidx, uint64_t *genovec) {
+	int rc = ReaderCheck(rd, vidx);
+	if (rc == PGH_OK) {
+		rc = FetchRow(rd, vidx);
+	}
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	const uint32_t n_out = rd->subset ? rd->subset->n_out : rd->ds->sample_ct;
+	std::memset(genovec, 0, sizeof(uint64_t) * ((n_out + 31) / 32));
+	ForEachIncluded(rd, [&](uint32_t k, uint32_t s) {
+		genovec[k >> 5] |= static_cast<uint64_t>(RowCode(rd->h_row, s)) << (2 * (k & 31));
+	});
+	return PGH_OK;
+}
+
+extern "C" int pgh_get_missingness(pgh_reader *rd, uint32_t vidx, uint64_t *bits) {
+	int rc = ReaderCheck(rd, vidx);
+	if (rc == PGH_OK) {
+		rc = FetchRow(rd, vidx);
+	}
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	const uint32_t n_out = rd->subset ? rd->subset->n_out : rd->ds->sample_ct;
+	std::memset(bits, 0, sizeof(uint64_t) * ((n_out + 63) / 64));
+	ForEachIncluded(rd, [&](uint32_t k, uint32_t s) {
+		if (RowCode(rd->h_row, s) == 3u) {
+			bits[k >> 6] |= 1ull << (k & 63);
+		}
+	});
+	return PGH_OK;
+}
+
+extern "C" int pgh_get_int8(pgh_reader *rd, uint32_t vidx, int8_t *out) {
+	int rc = ReaderCheck(rd, vidx);
+	if (rc == PGH_OK) {
+		rc = FetchRow(rd, vidx);
+	}
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	ForEachIncluded(rd, [&](uint32_t k, uint32_t s) {
+		const uint32_t c = RowCode(rd->h_row, s);
+		out[k] = c == 3u ? static_cast<int8_t>(-9) : static_cast<int8_t>(c);
+	});
+	return PGH_OK;
+}
+
+extern "C" int pgh_get_dosage_f64(pgh_reader *rd, uint32_t vidx, double *out) {
+	int rc = ReaderCheck(rd, vidx);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	const pgh_dataset *ds = rd->ds;
+	if (rd->norm && (ds->index.vrtype[vidx] & 0x60)) {
+		// explicit dosage track: decoded on the host from the record
+		std::vector<uint8_t> row;
+		std::vector<uint16_t> dos;
+		std::string err;
+		if (!rd->norm->DecodeDosage(vidx, row, dos, err)) {
+			return ReaderFail(rd, PGH_ERR_FORMAT, err);
+		}
+		ForEachIncluded(rd, [&](uint32_t k, uint32_t s) {
+			if (dos[s] != 0xffff) {
+				out[k] = static_cast<double>(dos[s]) / 16384.0;
+			} else {
+				const uint32_t c = RowCode(row.data(), s);
+				out[k] = c == 3u ? -9.0 : static_cast<double>(c);
+			}
+		});
+		return PGH_OK;
+	}
+	rc = FetchRow(rd, vidx);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	ForEachIncluded(rd, [&](uint32_t k, uint32_t s) {
+		const uint32_t c = RowCode(rd->h_row, s);
+		out[k] = c == 3u ? -9.0 : static_cast<double>(c);
+	});
+	return PGH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// HWE
+// ---------------------------------------------------------------------------
+
+extern "C" double pgh_hwe_lnp(int32_t obs_hets, int32_t obs_hom1, int32_t obs_hom2, uint32_t midp) {
+	return pgh::HweLnP(obs_hets, obs_hom1, obs_hom2, midp);
+}
+
+extern "C" double pgh_hwe_xchr_lnp(int32_t female_hets, int32_t female_hom1, int32_t female_hom2, int32_t male1,
+                                   int32_t male2, uint32_t midp) {
+	return pgh::HweXchrLnP(female_hets, female_hom1, female_hom2, male1, male2, midp);
+}
+
+extern "C" int pgh_hwe_lnp_batch_dev(const void *d_counts, uint32_t n, uint32_t midp, void *d_ln_p, void *stream,
+                                     char *errbuf) {
+	if (n && (!d_counts || !d_ln_p)) {
+		SetErr(errbuf, "null argument");
+		return PGH_ERR_ARG;
+	}
+	PGH_HIP(pgh::LaunchHweBatch(static_cast<const uint32_t *>(d_counts), n, midp, static_cast<double *>(d_ln_p),
+	                            static_cast<hipStream_t>(stream)),
+	        "hwe kernel");
+	return PGH_OK;
+}
+
+extern "C" int pgh_hwe_lnp_batch(const uint32_t (*counts)[4], uint32_t n, uint32_t midp, double *ln_p, char *errbuf) {
+	if (n == 0) {
+		return PGH_OK;
+	}
+	if (!counts || !ln_p) {
+		SetErr(errbuf, "null argument");
+		return PGH_ERR_ARG;
+	}
+	DevBuf d_counts, d_lnp;
+	PGH_HIP(d_counts.Alloc(16ull * n), "hipMalloc(hwe)");
+	PGH_HIP(d_lnp.Alloc(8ull * n), "hipMalloc(hwe)");
+	PGH_HIP(hipMemcpyAsync(d_counts.p, counts, 16ull * n, hipMemcpyHostToDevice, hipStreamPerThread), "hwe upload");
+	PGH_HIP(pgh::LaunchHweBatch(d_counts.As<uint32_t>(), n, midp, d_lnp.As<double>(), hipStreamPerThread),
+	        "hwe kernel");
+	PGH_HIP(hipMemcpyAsync(ln_p, d_lnp.p, 8ull * n, hipMemcpyDeviceToHost, hipStreamPerThread), "hwe copy");
+	PGH_HIP(hipStreamSynchronize(hipStreamPerThread), "hwe sync");
+	return PGH_OK;
+}

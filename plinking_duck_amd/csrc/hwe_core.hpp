@@ -1,0 +1,242 @@
+// hwe_core.hpp -- Hardy-Weinberg exact tests, host + device.
+//
+// Replaces plink2::HweLnP / HweXchrLnP (plink2_stats.cc, absent from the
+// reference tree; call sites src/plink_hardy.cpp:78,94).  Definitions:
+//   autosomal  Wigginton, Cutler & Abecasis (2005): two-sided p = sum of P(k hets)
+//              over all tables no likelier than the observed one;
+//   chrX       Graffelman & Weir (2016): same rule over the joint distribution of
+//              (A-allele males, female hets);
+//   mid-p      subtract half the probability of the tables tied with the observed.
+// Probabilities are carried relative to the modal table and advanced with the
+// exact ratios P(k+2)/P(k), so 500k-sample counts neither overflow nor need
+// lgamma; work is O(distance to the mode + width of the distribution).
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define PGH_HD __host__ __device__
+#else
+#define PGH_HD
+#endif
+
+namespace pgh {
+
+// tables whose probability equals the observed one up to rounding count as ties
+constexpr double kHweTieEps = 9.313225746154785e-10; // 2^-30
+
+// P(k+2 hets) / P(k hets) for rare-allele count `rare`, common-allele count `common`
+PGH_HD inline double HweStepUp(int64_t rare, int64_t common, int64_t k) {
+	return 4.0 * static_cast<double>((rare - k) >> 1) * static_cast<double>((common - k) >> 1) /
+	       (static_cast<double>(k + 2) * static_cast<double>(k + 1));
+}
+
+PGH_HD inline double HweLnP(int32_t obs_hets, int32_t obs_hom1, int32_t obs_hom2, uint32_t midp) {
+	const int64_t n = static_cast<int64_t>(obs_hets) + obs_hom1 + obs_hom2;
+	if (n <= 0) {
+		return 0.0;
+	}
+	const int64_t hom_rare = obs_hom1 < obs_hom2 ? obs_hom1 : obs_hom2;
+	const int64_t rare = 2 * hom_rare + obs_hets;
+	const int64_t common = 2 * n - rare;
+	// start near the expected het count, fix parity, then climb to the true mode
+	int64_t mode = static_cast<int64_t>(static_cast<double>(rare) * static_cast<double>(common) /
+	                                    static_cast<double>(2 * n));
+	if ((mode ^ rare) & 1) {
+		mode++;
+	}
+	if (mode > rare) {
+		mode -= 2;
+	}
+	if (mode < 0) {
+		mode += 2;
+	}
+	while (mode + 2 <= rare && HweStepUp(rare, common, mode) > 1.0) {
+		mode += 2;
+	}
+	while (mode >= 2 && HweStepUp(rare, common, mode - 2) < 1.0) {
+		mode -= 2;
+	}
+	// observed table relative to the mode
+	double p_obs = 1.0;
+	if (obs_hets > mode) {
+		for (int64_t k = mode; k < obs_hets && p_obs > 0.0; k += 2) {
+			p_obs *= HweStepUp(rare, common, k);
+		}
+	} else {
+		for (int64_t k = mode; k > obs_hets && p_obs > 0.0; k -= 2) {
+			p_obs /= HweStepUp(rare, common, k - 2);
+		}
+	}
+	if (!(p_obs > 0.0)) {
+		return -INFINITY; // p underflows double: exp(lnP) is 0 either way
+	}
+	const double hi = p_obs * (1.0 + kHweTieEps);
+	const double lo = p_obs * (1.0 - kHweTieEps);
+	const double negligible = lo * 1e-30;
+	double total = 1.0;
+	double tail = 0.0;
+	double ties = 0.0;
+	if (1.0 <= hi) {
+		tail = 1.0;
+		ties = 1.0 >= lo ? 1.0 : 0.0;
+	}
+	double p = 1.0;
+	for (int64_t k = mode; k + 2 <= rare; k += 2) {
+		p *= HweStepUp(rare, common, k);
+		total += p;
+		if (p <= hi) {
+			tail += p;
+			if (p >= lo) {
+				ties += p;
+			}
+			if (p < negligible && p < total * 1e-30) {
+				break;
+			}
+		}
+	}
+	p = 1.0;
+	for (int64_t k = mode; k >= 2; k -= 2) {
+		p /= HweStepUp(rare, common, k - 2);
+		total += p;
+		if (p <= hi) {
+			tail += p;
+			if (p >= lo) {
+				ties += p;
+			}
+			if (p < negligible && p < total * 1e-30) {
+				break;
+			}
+		}
+	}
+	if (midp) {
+		tail -= 0.5 * ties;
+	}
+	double pv = tail / total;
+	if (pv > 1.0) {
+		pv = 1.0;
+	}
+	return log(pv);
+}
+
+// Het-count distribution of `n` diploid individuals carrying `a` copies of one
+// allele, relative to its modal table: calls fn(k, rel) for every het count k
+// whose relative probability is not negligible, and returns the sum of rel.
+template <class Fn>
+inline double HweWalk(int64_t n, int64_t a, Fn &&fn) {
+	const int64_t b = 2 * n - a;
+	const int64_t rare = a < b ? a : b;
+	const int64_t common = 2 * n - rare;
+	int64_t mode = n > 0 ? static_cast<int64_t>(static_cast<double>(rare) * static_cast<double>(common) /
+	                                            static_cast<double>(2 * n))
+	                     : 0;
+	if ((mode ^ rare) & 1) {
+		mode++;
+	}
+	if (mode > rare) {
+		mode -= 2;
+	}
+	if (mode < 0) {
+		mode += 2;
+	}
+	while (mode + 2 <= rare && HweStepUp(rare, common, mode) > 1.0) {
+		mode += 2;
+	}
+	while (mode >= 2 && HweStepUp(rare, common, mode - 2) < 1.0) {
+		mode -= 2;
+	}
+	double total = 1.0;
+	fn(mode, 1.0);
+	double p = 1.0;
+	for (int64_t k = mode; k + 2 <= rare && p > 1e-300; k += 2) {
+		p *= HweStepUp(rare, common, k);
+		total += p;
+		fn(k + 2, p);
+	}
+	p = 1.0;
+	for (int64_t k = mode; k >= 2 && p > 1e-300; k -= 2) {
+		p /= HweStepUp(rare, common, k - 2);
+		total += p;
+		fn(k - 2, p);
+	}
+	return total;
+}
+
+// chrX exact test.  A table is (mA = males carrying allele A, k = female hets);
+// its probability factors into a hypergeometric term for the split of the A
+// alleles between the sexes and the autosomal het distribution of the females:
+//   P(mA, k) = C(nm, mA) C(2 nf, nA - mA) / C(nt, nA) * P_hwe(k | nf, nA - mA).
+// Host only (one call per chrX variant).
+inline double HweXchrLnP(int32_t female_hets, int32_t female_hom1, int32_t female_hom2, int32_t male1, int32_t male2,
+                         uint32_t midp) {
+	const int64_t nf = static_cast<int64_t>(female_hets) + female_hom1 + female_hom2;
+	const int64_t nm = static_cast<int64_t>(male1) + male2;
+	if (nf + nm <= 0) {
+		return 0.0;
+	}
+	const int64_t nA = 2 * static_cast<int64_t>(female_hom1) + female_hets + male1;
+	const int64_t m_lo = nA - 2 * nf > 0 ? nA - 2 * nf : 0;
+	const int64_t m_hi = nA < nm ? nA : nm;
+	// hypergeometric weight of each mA relative to mA = m_lo, in log space
+	// (ratio H(m+1)/H(m) = (nm-m)(nA-m) / ((m+1)(2nf-nA+m+1)))
+	const int64_t span = m_hi - m_lo + 1;
+	double *lh = new double[span];
+	lh[0] = 0.0;
+	double lh_max = 0.0;
+	for (int64_t m = m_lo; m < m_hi; m++) {
+		const double r = static_cast<double>(nm - m) * static_cast<double>(nA - m) /
+		                 (static_cast<double>(m + 1) * static_cast<double>(2 * nf - nA + m + 1));
+		lh[m - m_lo + 1] = lh[m - m_lo] + log(r);
+		if (lh[m - m_lo + 1] > lh_max) {
+			lh_max = lh[m - m_lo + 1];
+		}
+	}
+	// observed table
+	double w_obs = 0.0;
+	const double t_obs = HweWalk(nf, nA - male1, [&](int64_t k, double rel) {
+		if (k == female_hets) {
+			w_obs = rel;
+		}
+	});
+	const double p_obs = exp(lh[male1 - m_lo] - lh_max) * w_obs / t_obs;
+	double result;
+	if (!(p_obs > 0.0)) {
+		result = -INFINITY;
+	} else {
+		const double hi = p_obs * (1.0 + kHweTieEps);
+		const double lo = p_obs * (1.0 - kHweTieEps);
+		double total = 0.0, tail = 0.0, ties = 0.0;
+		for (int64_t m = m_lo; m <= m_hi; m++) {
+			const double h = exp(lh[m - m_lo] - lh_max);
+			total += h;
+			if (h <= lo) {
+				tail += h; // every table of this column is less likely than the observed one
+				continue;
+			}
+			const double t = HweWalk(nf, nA - m, [](int64_t, double) {});
+			const double scale = h / t;
+			HweWalk(nf, nA - m, [&](int64_t, double rel) {
+				const double joint = rel * scale;
+				if (joint <= hi) {
+					tail += joint;
+					if (joint >= lo) {
+						ties += joint;
+					}
+				}
+			});
+		}
+		if (midp) {
+			tail -= 0.5 * ties;
+		}
+		double pv = tail / total;
+		if (pv > 1.0) {
+			pv = 1.0;
+		}
+		result = log(pv);
+	}
+	delete[] lh;
+	return result;
+}
+
+} // namespace pgh

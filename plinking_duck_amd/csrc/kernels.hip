@@ -1,0 +1,790 @@
+// kernels.hip -- hand-written gfx950 (CDNA4) kernels of libpgenhip.
+//
+// Data layout: the genotype matrix is variant-major; row v holds ceil(N/4)
+// bytes of packed 2-bit calls (00 hom-ref, 01 het, 10 hom-alt, 11 missing;
+// sample s in bits 2*(s%4) of byte s/4) followed by zero bytes up to `pitch`
+// (a multiple of 16, so every row can be streamed as whole 16-byte lanes and
+// the pad decodes as hom-ref, which every kernel cancels against N).
+//
+// All of these are HBM-bound byte/bit kernels: 16 B per lane coalesced loads,
+// v_bcnt_u32_b32 tallies with its free accumulate operand, wave reductions by
+// DPP/ds_swizzle shuffles, LDS only for the cross-wave step and table staging.
+#include "kernels.hpp"
+
+#include "hwe_core.hpp"
+#include "synth.hpp"
+
+namespace pgh {
+
+namespace {
+
+constexpr uint32_t kLow = 0x55555555u; // low bit of every 2-bit slot
+
+__device__ __forceinline__ uint32_t WaveSum(uint32_t x) {
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) {
+		x += __shfl_xor(x, off, 64);
+	}
+	return x;
+}
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint4 LoadStream(const uint4 *p) {
+	// once-read stream: non-temporal so it does not evict the mask / tables from L2
+	const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+	return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+__device__ __forceinline__ void StoreStream(uint4 *p, const uint4 &o) {
+	u32x4 v = {o.x, o.y, o.z, o.w};
+	__builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p));
+}
+
+// ---------------------------------------------------------------------------
+// synthetic generator
+// ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_synth_fill(uint8_t *rows, uint64_t pitch, uint32_t sample_ct,
+                                                    uint32_t variant_begin, uint32_t variant_ct, uint64_t seed,
+                                                    uint32_t miss_threshold) {
+	const uint32_t dwords = static_cast<uint32_t>(pitch / 4);
+	const uint32_t d = blockIdx.x * 256u + threadIdx.x;
+	if (d >= dwords) {
+		return;
+	}
+	for (uint32_t r = blockIdx.y; r < variant_ct; r += gridDim.y) {
+		const SynthVariant sv = SynthVariantParams(seed, variant_begin + r);
+		uint32_t w = 0;
+		const uint32_t s0 = d * 16u;
+#pragma unroll 4
+		for (uint32_t j = 0; j < 16; j++) {
+			const uint32_t s = s0 + j;
+			if (s < sample_ct) {
+				w |= SynthGenotype(sv, s, miss_threshold) << (2 * j);
+			}
+		}
+		reinterpret_cast<uint32_t *>(rows + static_cast<uint64_t>(r) * pitch)[d] = w;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_sanitize_tail(uint8_t *rows, uint64_t pitch, uint32_t sample_ct,
+                                                       uint32_t variant_ct) {
+	// one thread per (row, pad byte); rows are short on pad so this is tiny
+	const uint32_t record_bytes = (sample_ct + 3) / 4;
+	const uint32_t pad = static_cast<uint32_t>(pitch - record_bytes) + 1; // + the last data byte
+	const uint64_t idx = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x;
+	const uint64_t total = static_cast<uint64_t>(variant_ct) * pad;
+	if (idx >= total) {
+		return;
+	}
+	const uint32_t r = static_cast<uint32_t>(idx / pad);
+	const uint32_t k = static_cast<uint32_t>(idx % pad);
+	uint8_t *row = rows + static_cast<uint64_t>(r) * pitch;
+	if (k == 0) {
+		const uint32_t rem = sample_ct & 3;
+		if (rem) {
+			row[record_bytes - 1] &= static_cast<uint8_t>((1u << (2 * rem)) - 1);
+		}
+	} else {
+		row[record_bytes - 1 + k] = 0;
+	}
+}
+
+// ---------------------------------------------------------------------------
+// genotype-class tally
+// ---------------------------------------------------------------------------
+
+struct Tally {
+	uint32_t lo = 0;   // slots with the low bit set  (het + missing)
+	uint32_t hi = 0;   // slots with the high bit set (hom-alt + missing)
+	uint32_t both = 0; // missing
+};
+
+template <bool MASKED>
+__device__ __forceinline__ void TallyWord(Tally &t, uint32_t w, uint32_t m) {
+	const uint32_t sel = MASKED ? m : kLow;
+	const uint32_t lo = w & sel;
+	const uint32_t hi = (w >> 1) & sel;
+	t.lo += __popc(lo);
+	t.hi += __popc(hi);
+	t.both += __popc(lo & hi);
+}
+
+template <bool MASKED>
+__device__ __forceinline__ void TallyQuad(Tally &t, const uint4 &w, const uint4 &m) {
+	TallyWord<MASKED>(t, w.x, m.x);
+	TallyWord<MASKED>(t, w.y, m.y);
+	TallyWord<MASKED>(t, w.z, m.z);
+	TallyWord<MASKED>(t, w.w, m.w);
+}
+
+// One 256-thread workgroup per variant row: for long rows (>= 4 KiB).
+template <bool MASKED>
+__global__ __launch_bounds__(256) void k_counts_block(const uint8_t *__restrict__ rows, uint64_t pitch,
+                                                      uint32_t chunks, uint32_t v_first,
+                                                      const uint32_t *__restrict__ vlist, uint32_t v_count,
+                                                      const uint4 *__restrict__ mask2, uint32_t n_eff,
+                                                      uint4 *__restrict__ out) {
+	__shared__ uint32_t part[4][3];
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wave = threadIdx.x >> 6;
+	for (uint32_t i = blockIdx.x; i < v_count; i += gridDim.x) {
+		const uint32_t v = vlist ? vlist[i] : v_first + i;
+		const uint4 *row = reinterpret_cast<const uint4 *>(rows + static_cast<uint64_t>(v) * pitch);
+		Tally t;
+		uint32_t c = threadIdx.x;
+		// 4 independent 16-byte loads in flight per lane
+		for (; c + 768u < chunks; c += 1024u) {
+			const uint4 w0 = LoadStream(row + c);
+			const uint4 w1 = LoadStream(row + c + 256u);
+			const uint4 w2 = LoadStream(row + c + 512u);
+			const uint4 w3 = LoadStream(row + c + 768u);
+			uint4 m0 = {0, 0, 0, 0}, m1 = m0, m2 = m0, m3 = m0;
+			if (MASKED) {
+				m0 = mask2[c];
+				m1 = mask2[c + 256u];
+				m2 = mask2[c + 512u];
+				m3 = mask2[c + 768u];
+			}
+			TallyQuad<MASKED>(t, w0, m0);
+			TallyQuad<MASKED>(t, w1, m1);
+			TallyQuad<MASKED>(t, w2, m2);
+			TallyQuad<MASKED>(t, w3, m3);
+		}
+		for (; c < chunks; c += 256u) {
+			const uint4 w = LoadStream(row + c);
+			uint4 m = {0, 0, 0, 0};
+			if (MASKED) {
+				m = mask2[c];
+			}
+			TallyQuad<MASKED>(t, w, m);
+		}
+		const uint32_t lo = WaveSum(t.lo);
+		const uint32_t hi = WaveSum(t.hi);
+		const uint32_t both = WaveSum(t.both);
+		if (lane == 0) {
+			part[wave][0] = lo;
+			part[wave][1] = hi;
+			part[wave][2] = both;
+		}
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			const uint32_t l = part[0][0] + part[1][0] + part[2][0] + part[3][0];
+			const uint32_t h = part[0][1] + part[1][1] + part[2][1] + part[3][1];
+			const uint32_t b = part[0][2] + part[1][2] + part[2][2] + part[3][2];
+			uint4 r;
+			r.y = l - b;                 // het
+			r.z = h - b;                 // hom-alt
+			r.w = b;                     // missing
+			r.x = n_eff - r.y - r.z - b; // hom-ref (zero pad cancels here)
+			out[i] = r;
+		}
+		__syncthreads();
+	}
+}
+
+// One wave per variant row: short rows.  4 rows per 256-thread workgroup.
+template <bool MASKED>
+__global__ __launch_bounds__(256) void k_counts_wave(const uint8_t *__restrict__ rows, uint64_t pitch,
+                                                     uint32_t chunks, uint32_t v_first,
+                                                     const uint32_t *__restrict__ vlist, uint32_t v_count,
+                                                     const uint4 *__restrict__ mask2, uint32_t n_eff,
+                                                     uint4 *__restrict__ out) {
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wave = threadIdx.x >> 6;
+	for (uint32_t i = blockIdx.x * 4u + wave; i < v_count; i += gridDim.x * 4u) {
+		const uint32_t v = vlist ? vlist[i] : v_first + i;
+		const uint4 *row = reinterpret_cast<const uint4 *>(rows + static_cast<uint64_t>(v) * pitch);
+		Tally t;
+		for (uint32_t c = lane; c < chunks; c += 64u) {
+			const uint4 w = LoadStream(row + c);
+			uint4 m = {0, 0, 0, 0};
+			if (MASKED) {
+				m = mask2[c];
+			}
+			TallyQuad<MASKED>(t, w, m);
+		}
+		const uint32_t lo = WaveSum(t.lo);
+		const uint32_t hi = WaveSum(t.hi);
+		const uint32_t both = WaveSum(t.both);
+		if (lane == 0) {
+			uint4 r;
+			r.y = lo - both;
+			r.z = hi - both;
+			r.w = both;
+			r.x = n_eff - r.y - r.z - both;
+			out[i] = r;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------
+// per-sample missing tally (column sums of the missing indicator)
+// ---------------------------------------------------------------------------
+//
+// A lane owns one 16-byte column (64 samples) and walks down a slice of rows.
+// The indicator m = w & (w>>1) & 0x5555.. has one bit per 2-bit slot, so it is
+// added SWAR-style: 2-bit fields (<=3 rows) -> 4-bit fields (<=15) -> 8-bit
+// fields (<=255), then flushed to the uint32 output with atomics.
+
+struct MissAcc {
+	uint32_t a4[8];
+	uint32_t a8[16];
+};
+
+__device__ __forceinline__ uint32_t MissBits(uint32_t w) {
+	return w & (w >> 1) & kLow;
+}
+
+__device__ __forceinline__ void Fold2To4(MissAcc &acc, const uint32_t a2[4]) {
+#pragma unroll
+	for (int j = 0; j < 4; j++) {
+		acc.a4[2 * j] += a2[j] & 0x33333333u;
+		acc.a4[2 * j + 1] += (a2[j] >> 2) & 0x33333333u;
+	}
+}
+
+__device__ __forceinline__ void Fold4To8(MissAcc &acc) {
+#pragma unroll
+	for (int j = 0; j < 4; j++) {
+		acc.a8[4 * j + 0] += acc.a4[2 * j] & 0x0f0f0f0fu;
+		acc.a8[4 * j + 1] += (acc.a4[2 * j] >> 4) & 0x0f0f0f0fu;
+		acc.a8[4 * j + 2] += acc.a4[2 * j + 1] & 0x0f0f0f0fu;
+		acc.a8[4 * j + 3] += (acc.a4[2 * j + 1] >> 4) & 0x0f0f0f0fu;
+		acc.a4[2 * j] = 0;
+		acc.a4[2 * j + 1] = 0;
+	}
+}
+
+__device__ __forceinline__ void Flush8(MissAcc &acc, uint32_t *out, uint32_t sample0) {
+	// a8[4j+q] byte b counts sample 16j + 4b + {0,2,1,3}[q]
+#pragma unroll
+	for (int j = 0; j < 4; j++) {
+#pragma unroll
+		for (int q = 0; q < 4; q++) {
+			const uint32_t word = acc.a8[4 * j + q];
+			acc.a8[4 * j + q] = 0;
+			const uint32_t within = (q == 0) ? 0u : (q == 1 ? 2u : (q == 2 ? 1u : 3u));
+#pragma unroll
+			for (int b = 0; b < 4; b++) {
+				const uint32_t val = (word >> (8 * b)) & 0xffu;
+				if (val) {
+					atomicAdd(out + sample0 + 16u * j + 4u * b + within, val);
+				}
+			}
+		}
+	}
+}
+
+__global__ __launch_bounds__(256) void k_missing_cols(const uint8_t *__restrict__ rows, uint64_t pitch,
+                                                      uint32_t chunks, uint32_t v_first,
+                                                      const uint32_t *__restrict__ vlist, uint32_t v_count,
+                                                      uint32_t slice_len, uint32_t *__restrict__ out) {
+	const uint32_t col = blockIdx.x * 256u + threadIdx.x;
+	if (col >= chunks) {
+		return;
+	}
+	const uint32_t i_begin = blockIdx.y * slice_len;
+	const uint32_t i_end = min(i_begin + slice_len, v_count);
+	MissAcc acc;
+#pragma unroll
+	for (int j = 0; j < 8; j++) {
+		acc.a4[j] = 0;
+	}
+#pragma unroll
+	for (int j = 0; j < 16; j++) {
+		acc.a8[j] = 0;
+	}
+	uint32_t n4 = 0, n8 = 0; // rows folded into the 4-bit / 8-bit fields so far
+	uint32_t i = i_begin;
+	auto row_ptr = [&](uint32_t idx) {
+		const uint32_t v = vlist ? vlist[idx] : v_first + idx;
+		return reinterpret_cast<const uint4 *>(rows + static_cast<uint64_t>(v) * pitch) + col;
+	};
+	while (i < i_end) {
+		uint32_t a2[4] = {0, 0, 0, 0};
+		uint32_t take;
+		if (i + 3 <= i_end) {
+			const uint4 w0 = LoadStream(row_ptr(i));
+			const uint4 w1 = LoadStream(row_ptr(i + 1));
+			const uint4 w2 = LoadStream(row_ptr(i + 2));
+			a2[0] = MissBits(w0.x) + MissBits(w1.x) + MissBits(w2.x);
+			a2[1] = MissBits(w0.y) + MissBits(w1.y) + MissBits(w2.y);
+			a2[2] = MissBits(w0.z) + MissBits(w1.z) + MissBits(w2.z);
+			a2[3] = MissBits(w0.w) + MissBits(w1.w) + MissBits(w2.w);
+			take = 3;
+		} else {
+			const uint4 w0 = LoadStream(row_ptr(i));
+			a2[0] = MissBits(w0.x);
+			a2[1] = MissBits(w0.y);
+			a2[2] = MissBits(w0.z);
+			a2[3] = MissBits(w0.w);
+			take = 1;
+		}
+		i += take;
+		Fold2To4(acc, a2);
+		n4 += take;
+		if (n4 + 3 > 15) {
+			Fold4To8(acc);
+			n8 += n4;
+			n4 = 0;
+			if (n8 + 15 > 255) {
+				Flush8(acc, out, col * 64u);
+				n8 = 0;
+			}
+		}
+	}
+	Fold4To8(acc);
+	Flush8(acc, out, col * 64u);
+}
+
+// ---------------------------------------------------------------------------
+// 2-bit -> int8 unpack
+// ---------------------------------------------------------------------------
+
+// 8 bits (4 calls) -> 4 bytes, one call per byte
+__device__ __forceinline__ uint32_t Spread4(uint32_t x) {
+	uint32_t t = (x | (x << 12)) & 0x000f000fu;
+	return (t | (t << 6)) & 0x03030303u;
+}
+
+__global__ __launch_bounds__(256) void k_unpack(const uint8_t *__restrict__ rows, uint64_t pitch, uint32_t sample_ct,
+                                                uint32_t v_first, uint32_t v_count, int8_t *__restrict__ out,
+                                                uint64_t out_pitch, uint64_t *__restrict__ validity,
+                                                uint32_t fill4) {
+	const uint32_t dwords = (sample_ct + 15) / 16;           // input dwords holding data
+	const uint32_t val_words16 = ((sample_ct + 63) / 64) * 4; // uint16 slots per validity row
+	const uint32_t d = blockIdx.x * 256u + threadIdx.x;
+	if (d >= val_words16) {
+		return;
+	}
+	for (uint32_t i = blockIdx.y; i < v_count; i += gridDim.y) {
+		const uint8_t *row = rows + static_cast<uint64_t>(v_first + i) * pitch;
+		uint32_t valid16 = 0;
+		if (d < dwords) {
+			const uint32_t w = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(row) + d);
+			uint4 o;
+			uint32_t vbits = 0;
+			uint32_t *op = &o.x;
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				const uint32_t t = Spread4((w >> (8 * k)) & 0xffu);
+				const uint32_t miss = t & (t >> 1) & 0x01010101u; // 1 in each missing byte
+				const uint32_t mm = miss * 0xffu;                 // 0xff in each missing byte
+				op[k] = (t & ~mm) | (fill4 & mm);
+				vbits |= (((miss * 0x01020408u) >> 24) & 0xfu) << (4 * k);
+			}
+			valid16 = ~vbits & 0xffffu;
+			const uint32_t left = sample_ct - d * 16u;
+			if (left < 16u) {
+				valid16 &= (1u << left) - 1u;
+			}
+			if (out) {
+				StoreStream(reinterpret_cast<uint4 *>(out + static_cast<uint64_t>(i) * out_pitch) + d, o);
+			}
+		}
+		if (validity) {
+			uint16_t *vrow = reinterpret_cast<uint16_t *>(validity + static_cast<uint64_t>(i) * (val_words16 / 4));
+			vrow[d] = static_cast<uint16_t>(valid16);
+		}
+	}
+}
+
+__global__ __launch_bounds__(256) void k_unpack_subset(const uint8_t *__restrict__ rows, uint64_t pitch,
+                                                       uint32_t v_first, uint32_t v_count,
+                                                       const uint32_t *__restrict__ sel, uint32_t n_out,
+                                                       int8_t *__restrict__ out, uint64_t out_pitch,
+                                                       uint64_t *__restrict__ validity, int32_t fill) {
+	// one lane per 16 output samples: gathers their 2-bit calls from the raw row
+	const uint32_t val_words16 = ((n_out + 63) / 64) * 4;
+	const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+	if (g >= val_words16) {
+		return;
+	}
+	for (uint32_t i = blockIdx.y; i < v_count; i += gridDim.y) {
+		const uint8_t *row = rows + static_cast<uint64_t>(v_first + i) * pitch;
+		uint32_t valid16 = 0;
+		const uint32_t k0 = g * 16u;
+		if (k0 < n_out) {
+			uint32_t o[4] = {0, 0, 0, 0};
+#pragma unroll
+			for (uint32_t j = 0; j < 16; j++) {
+				const uint32_t k = k0 + j;
+				uint32_t byte = 0;
+				if (k < n_out) {
+					const uint32_t s = sel[k];
+					const uint32_t code = (row[s >> 2] >> (2 * (s & 3))) & 3u;
+					if (code == 3u) {
+						byte = static_cast<uint32_t>(fill) & 0xffu;
+					} else {
+						byte = code;
+						valid16 |= 1u << j;
+					}
+				}
+				o[j >> 2] |= byte << (8 * (j & 3));
+			}
+			if (out) {
+				uint4 q = {o[0], o[1], o[2], o[3]};
+				reinterpret_cast<uint4 *>(out + static_cast<uint64_t>(i) * out_pitch)[g] = q;
+			}
+		}
+		if (validity) {
+			uint16_t *vrow = reinterpret_cast<uint16_t *>(validity + static_cast<uint64_t>(i) * (val_words16 / 4));
+			vrow[g] = static_cast<uint16_t>(valid16);
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------
+// plink_score
+// ---------------------------------------------------------------------------
+
+// Per scored variant: the value a sample of genotype class g contributes
+// (src/plink_score.cpp:598-652), from the variant's class counts.
+__global__ __launch_bounds__(256) void k_score_tables(const uint32_t *__restrict__ counts,
+                                                      const uint8_t *__restrict__ flip, uint32_t n_scored, int mode,
+                                                      double *__restrict__ ts, double *__restrict__ td,
+                                                      uint32_t *__restrict__ ac) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n_scored) {
+		return;
+	}
+	const uint32_t het = counts[4 * i + 1];
+	const uint32_t hom_alt = counts[4 * i + 2];
+	const uint32_t non_missing = counts[4 * i] + het + hom_alt;
+	double s[4] = {0.0, 0.0, 0.0, 0.0};
+	double d[4] = {0.0, 0.0, 0.0, 0.0};
+	uint32_t inc = 0;
+	if (non_missing != 0) {
+		const bool fl = flip && flip[i];
+		const double sum_alt = static_cast<double>(het) + 2.0 * static_cast<double>(hom_alt);
+		const double mean_alt = sum_alt / static_cast<double>(non_missing);
+		if (mode == 2) { // center
+			const double freq = mean_alt / 2.0;
+			const double sd = sqrt(2.0 * freq * (1.0 - freq));
+			if (sd != 0.0) {
+				const double mean_scored = fl ? (2.0 - mean_alt) : mean_alt;
+				for (int g = 0; g < 3; g++) {
+					const double scored = fl ? (2.0 - static_cast<double>(g)) : static_cast<double>(g);
+					s[g] = (scored - mean_scored) / sd;
+				}
+				inc = 2u;
+			}
+		} else {
+			for (int g = 0; g < 3; g++) {
+				const double scored = fl ? (2.0 - static_cast<double>(g)) : static_cast<double>(g);
+				s[g] = scored;
+				d[g] = scored;
+			}
+			inc = 2u;
+			if (mode == 0) { // mean imputation
+				const double scored = fl ? (2.0 - mean_alt) : mean_alt;
+				s[3] = scored;
+				d[3] = scored;
+				inc = 2u | (2u << 8);
+			}
+		}
+	}
+	for (int g = 0; g < 4; g++) {
+		ts[4 * static_cast<uint64_t>(i) + g] = s[g];
+		td[4 * static_cast<uint64_t>(i) + g] = d[g];
+	}
+	ac[i] = inc;
+}
+
+// First (VALU) form of the accumulate: one lane per sample, a slice of the scored
+// variants per workgroup row; tables staged in LDS, weights read wave-uniformly.
+template <int NCOLS>
+__global__ __launch_bounds__(256) void k_score_accumulate(const uint8_t *__restrict__ rows, uint64_t pitch,
+                                                          uint32_t sample_ct, const uint32_t *__restrict__ vlist,
+                                                          uint32_t n_scored, uint32_t slice_len,
+                                                          const double *__restrict__ weights,
+                                                          const double *__restrict__ ts,
+                                                          const double *__restrict__ td,
+                                                          const uint32_t *__restrict__ ac, double *__restrict__ score,
+                                                          double *__restrict__ dosage_sum,
+                                                          uint32_t *__restrict__ allele_ct) {
+	constexpr uint32_t kStage = 64; // variants staged in LDS at a time
+	__shared__ double s_ts[kStage][4];
+	__shared__ double s_td[kStage][4];
+	__shared__ double s_w[kStage][NCOLS];
+	__shared__ uint32_t s_ac[kStage];
+	__shared__ uint32_t s_v[kStage];
+	const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+	const bool live = s < sample_ct;
+	const uint32_t shift = 2u * (s & 15u);
+	const uint32_t dword = s >> 4;
+	const uint32_t i_begin = blockIdx.y * slice_len;
+	const uint32_t i_end = min(i_begin + slice_len, n_scored);
+	double acc[NCOLS];
+#pragma unroll
+	for (int c = 0; c < NCOLS; c++) {
+		acc[c] = 0.0;
+	}
+	double dsum = 0.0;
+	uint32_t act = 0;
+	for (uint32_t base = i_begin; base < i_end; base += kStage) {
+		const uint32_t cnt = min(kStage, i_end - base);
+		__syncthreads();
+		for (uint32_t k = threadIdx.x; k < cnt * 4u; k += 256u) {
+			s_ts[k >> 2][k & 3] = ts[4 * static_cast<uint64_t>(base) + k];
+			s_td[k >> 2][k & 3] = td[4 * static_cast<uint64_t>(base) + k];
+		}
+		for (uint32_t k = threadIdx.x; k < cnt * NCOLS; k += 256u) {
+			s_w[k / NCOLS][k % NCOLS] = weights[static_cast<uint64_t>(base) * NCOLS + k];
+		}
+		for (uint32_t k = threadIdx.x; k < cnt; k += 256u) {
+			s_ac[k] = ac[base + k];
+			s_v[k] = vlist[base + k];
+		}
+		__syncthreads();
+		if (live) {
+			for (uint32_t k = 0; k < cnt; k++) {
+				const uint32_t w =
+				    reinterpret_cast<const uint32_t *>(rows + static_cast<uint64_t>(s_v[k]) * pitch)[dword];
+				const uint32_t g = (w >> shift) & 3u;
+				const double x = s_ts[k][g];
+				dsum += s_td[k][g];
+				act += (s_ac[k] >> (g == 3u ? 8 : 0)) & 0xffu;
+#pragma unroll
+				for (int c = 0; c < NCOLS; c++) {
+					acc[c] = fma(s_w[k][c], x, acc[c]);
+				}
+			}
+		}
+	}
+	if (live) {
+#pragma unroll
+		for (int c = 0; c < NCOLS; c++) {
+			unsafeAtomicAdd(score + static_cast<uint64_t>(s) * NCOLS + c, acc[c]);
+		}
+		unsafeAtomicAdd(dosage_sum + s, dsum);
+		atomicAdd(allele_ct + s, act);
+	}
+}
+
+// ---------------------------------------------------------------------------
+// plink_freq epilogue
+// ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_freq_from_counts(const uint4 *__restrict__ counts, uint32_t n,
+                                                          double *__restrict__ alt_freq, int32_t *__restrict__ obs_ct) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) {
+		return;
+	}
+	const uint4 c = counts[i];
+	const uint32_t obs = c.x + c.y + c.z;
+	// src/plink_freq.cpp:541-543
+	alt_freq[i] = obs ? (static_cast<double>(c.y) + 2.0 * static_cast<double>(c.z)) / (2.0 * static_cast<double>(obs))
+	                  : __builtin_nan("");
+	obs_ct[i] = static_cast<int32_t>(2u * obs);
+}
+
+// ---------------------------------------------------------------------------
+// HWE
+// ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(64) void k_hwe_batch(const uint32_t *__restrict__ counts, uint32_t n, uint32_t midp,
+                                                  double *__restrict__ ln_p) {
+	const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+	if (i >= n) {
+		return;
+	}
+	ln_p[i] = HweLnP(static_cast<int32_t>(counts[4 * i + 1]), static_cast<int32_t>(counts[4 * i]),
+	                 static_cast<int32_t>(counts[4 * i + 2]), midp);
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------
+// launch wrappers
+// ---------------------------------------------------------------------------
+
+hipError_t LaunchSynthFill(uint8_t *rows, uint64_t pitch, uint32_t sample_ct, uint32_t variant_begin,
+                           uint32_t variant_ct, uint64_t seed, uint32_t miss_threshold, hipStream_t stream) {
+	if (variant_ct == 0) {
+		return hipSuccess;
+	}
+	const uint32_t dwords = static_cast<uint32_t>(pitch / 4);
+	dim3 grid((dwords + 255) / 256, variant_ct < 65535u ? variant_ct : 65535u);
+	hipLaunchKernelGGL(k_synth_fill, grid, dim3(256), 0, stream, rows, pitch, sample_ct, variant_begin, variant_ct,
+	                   seed, miss_threshold);
+	return hipGetLastError();
+}
+
+hipError_t LaunchSanitizeTail(uint8_t *rows, uint64_t pitch, uint32_t sample_ct, uint32_t variant_ct,
+                              hipStream_t stream) {
+	if (variant_ct == 0) {
+		return hipSuccess;
+	}
+	const uint32_t record_bytes = (sample_ct + 3) / 4;
+	const uint64_t total = static_cast<uint64_t>(variant_ct) * (pitch - record_bytes + 1);
+	const uint64_t blocks = (total + 255) / 256;
+	hipLaunchKernelGGL(k_sanitize_tail, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, stream, rows, pitch,
+	                   sample_ct, variant_ct);
+	return hipGetLastError();
+}
+
+hipError_t LaunchCounts(const RowView &view, uint32_t v_first, const uint32_t *vlist, uint32_t v_count,
+                        const uint8_t *mask2, uint32_t n_eff, uint32_t *out, hipStream_t stream) {
+	if (v_count == 0) {
+		return hipSuccess;
+	}
+	const uint32_t chunks = static_cast<uint32_t>((static_cast<uint64_t>(view.record_bytes) + 15) / 16);
+	const uint4 *m = reinterpret_cast<const uint4 *>(mask2);
+	uint4 *o = reinterpret_cast<uint4 *>(out);
+	if (chunks >= 256) {
+		// 256 CUs x 8 resident workgroups; beyond that the grid strides
+		const uint32_t grid = v_count < (1u << 20) ? v_count : (1u << 20);
+		if (mask2) {
+			hipLaunchKernelGGL(k_counts_block<true>, dim3(grid), dim3(256), 0, stream, view.rows, view.pitch, chunks,
+			                   v_first, vlist, v_count, m, n_eff, o);
+		} else {
+			hipLaunchKernelGGL(k_counts_block<false>, dim3(grid), dim3(256), 0, stream, view.rows, view.pitch, chunks,
+			                   v_first, vlist, v_count, m, n_eff, o);
+		}
+	} else {
+		const uint32_t blocks = (v_count + 3) / 4;
+		const uint32_t grid = blocks < (1u << 20) ? blocks : (1u << 20);
+		if (mask2) {
+			hipLaunchKernelGGL(k_counts_wave<true>, dim3(grid), dim3(256), 0, stream, view.rows, view.pitch, chunks,
+			                   v_first, vlist, v_count, m, n_eff, o);
+		} else {
+			hipLaunchKernelGGL(k_counts_wave<false>, dim3(grid), dim3(256), 0, stream, view.rows, view.pitch, chunks,
+			                   v_first, vlist, v_count, m, n_eff, o);
+		}
+	}
+	return hipGetLastError();
+}
+
+hipError_t LaunchFreqFromCounts(const uint32_t *counts, uint32_t n, double *alt_freq, int32_t *obs_ct,
+                                hipStream_t stream) {
+	if (n == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_freq_from_counts, dim3((n + 255) / 256), dim3(256), 0, stream,
+	                   reinterpret_cast<const uint4 *>(counts), n, alt_freq, obs_ct);
+	return hipGetLastError();
+}
+
+hipError_t LaunchMissingPerSample(const RowView &view, uint32_t v_first, const uint32_t *vlist, uint32_t v_count,
+                                  uint32_t *out, hipStream_t stream) {
+	if (v_count == 0) {
+		return hipSuccess;
+	}
+	const uint32_t chunks = static_cast<uint32_t>((static_cast<uint64_t>(view.record_bytes) + 15) / 16);
+	const uint32_t col_blocks = (chunks + 255) / 256;
+	// enough row slices to put >= ~4096 workgroups on the chip, each a multiple of 15 rows
+	uint32_t want_slices = (4096 + col_blocks - 1) / col_blocks;
+	uint32_t slice_len = (v_count + want_slices - 1) / want_slices;
+	slice_len = ((slice_len + 14) / 15) * 15;
+	if (slice_len < 60) {
+		slice_len = 60;
+	}
+	uint32_t slices = (v_count + slice_len - 1) / slice_len;
+	if (slices > 65535u) {
+		slices = 65535u;
+		slice_len = (v_count + slices - 1) / slices;
+		slice_len = ((slice_len + 14) / 15) * 15;
+		slices = (v_count + slice_len - 1) / slice_len;
+	}
+	hipLaunchKernelGGL(k_missing_cols, dim3(col_blocks, slices), dim3(256), 0, stream, view.rows, view.pitch, chunks,
+	                   v_first, vlist, v_count, slice_len, out);
+	return hipGetLastError();
+}
+
+hipError_t LaunchUnpack(const RowView &view, uint32_t v_first, uint32_t v_count, int8_t *out, uint64_t out_pitch,
+                        uint64_t *validity, int8_t fill, hipStream_t stream) {
+	if (v_count == 0) {
+		return hipSuccess;
+	}
+	const uint32_t val_words16 = ((view.sample_ct + 63) / 64) * 4;
+	const uint32_t f = static_cast<uint8_t>(fill);
+	const uint32_t fill4 = f * 0x01010101u;
+	dim3 grid((val_words16 + 255) / 256, v_count < 65535u ? v_count : 65535u);
+	hipLaunchKernelGGL(k_unpack, grid, dim3(256), 0, stream, view.rows, view.pitch, view.sample_ct, v_first, v_count,
+	                   out, out_pitch, validity, fill4);
+	return hipGetLastError();
+}
+
+hipError_t LaunchUnpackSubset(const RowView &view, uint32_t v_first, uint32_t v_count, const uint32_t *sel,
+                              uint32_t n_out, int8_t *out, uint64_t out_pitch, uint64_t *validity, int8_t fill,
+                              hipStream_t stream) {
+	if (v_count == 0 || n_out == 0) {
+		return hipSuccess;
+	}
+	const uint32_t val_words16 = ((n_out + 63) / 64) * 4;
+	dim3 grid((val_words16 + 255) / 256, v_count < 65535u ? v_count : 65535u);
+	hipLaunchKernelGGL(k_unpack_subset, grid, dim3(256), 0, stream, view.rows, view.pitch, v_first, v_count, sel,
+	                   n_out, out, out_pitch, validity, static_cast<int32_t>(fill));
+	return hipGetLastError();
+}
+
+hipError_t LaunchScoreTables(const uint32_t *counts, const uint8_t *flip, uint32_t n_scored, int mode, double *ts,
+                             double *td, uint32_t *ac, hipStream_t stream) {
+	if (n_scored == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_score_tables, dim3((n_scored + 255) / 256), dim3(256), 0, stream, counts, flip, n_scored,
+	                   mode, ts, td, ac);
+	return hipGetLastError();
+}
+
+template <int NCOLS>
+static hipError_t LaunchScoreAccumulateN(const RowView &view, const uint32_t *vlist, uint32_t n_scored,
+                                         const double *weights, const double *ts, const double *td,
+                                         const uint32_t *ac, double *score, double *dosage_sum, uint32_t *allele_ct,
+                                         hipStream_t stream) {
+	const uint32_t sample_blocks = (view.sample_ct + 255) / 256;
+	uint32_t want_slices = (2048 + sample_blocks - 1) / sample_blocks;
+	uint32_t slice_len = (n_scored + want_slices - 1) / want_slices;
+	slice_len = ((slice_len + 63) / 64) * 64;
+	uint32_t slices = (n_scored + slice_len - 1) / slice_len;
+	if (slices > 65535u) {
+		slices = 65535u;
+		slice_len = (n_scored + slices - 1) / slices;
+	}
+	hipLaunchKernelGGL((k_score_accumulate<NCOLS>), dim3(sample_blocks, slices), dim3(256), 0, stream, view.rows,
+	                   view.pitch, view.sample_ct, vlist, n_scored, slice_len, weights, ts, td, ac, score, dosage_sum,
+	                   allele_ct);
+	return hipGetLastError();
+}
+
+hipError_t LaunchScoreAccumulate(const RowView &view, const uint32_t *vlist, uint32_t n_scored, const double *weights,
+                                 uint32_t n_cols, const double *ts, const double *td, const uint32_t *ac,
+                                 double *score, double *dosage_sum, uint32_t *allele_ct, hipStream_t stream) {
+	if (n_scored == 0) {
+		return hipSuccess;
+	}
+	switch (n_cols) {
+	case 1:
+		return LaunchScoreAccumulateN<1>(view, vlist, n_scored, weights, ts, td, ac, score, dosage_sum, allele_ct,
+		                                 stream);
+	case 2:
+		return LaunchScoreAccumulateN<2>(view, vlist, n_scored, weights, ts, td, ac, score, dosage_sum, allele_ct,
+		                                 stream);
+	case 4:
+		return LaunchScoreAccumulateN<4>(view, vlist, n_scored, weights, ts, td, ac, score, dosage_sum, allele_ct,
+		                                 stream);
+	case 8:
+		return LaunchScoreAccumulateN<8>(view, vlist, n_scored, weights, ts, td, ac, score, dosage_sum, allele_ct,
+		                                 stream);
+	case 16:
+		return LaunchScoreAccumulateN<16>(view, vlist, n_scored, weights, ts, td, ac, score, dosage_sum, allele_ct,
+		                                  stream);
+	default:
+		return hipErrorInvalidValue;
+	}
+}
+
+hipError_t LaunchHweBatch(const uint32_t *counts, uint32_t n, uint32_t midp, double *ln_p, hipStream_t stream) {
+	if (n == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_hwe_batch, dim3((n + 63) / 64), dim3(64), 0, stream, counts, n, midp, ln_p);
+	return hipGetLastError();
+}
+
+} // namespace pgh

@@ -1,0 +1,71 @@
+// kernels.hpp -- launch wrappers of the gfx950 kernels (definitions in kernels.hip).
+// All pointers are device pointers unless named h_*.  Every wrapper only
+// enqueues work on `stream` and returns the hipError_t of the launch.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace pgh {
+
+// Geometry of the resident genotype matrix: row r starts at rows + r*pitch.
+struct RowView {
+	const uint8_t *rows;   // first resident row
+	uint64_t pitch;        // bytes between rows (multiple of 16)
+	uint32_t sample_ct;    // raw N
+	uint32_t record_bytes; // ceil(N/4)
+};
+
+// ---- synthetic generator (host twin in synth.hpp) -------------------------
+hipError_t LaunchSynthFill(uint8_t *rows, uint64_t pitch, uint32_t sample_ct, uint32_t variant_begin,
+                           uint32_t variant_ct, uint64_t seed, uint32_t miss_threshold, hipStream_t stream);
+
+// zero genotype bits past sample_ct and the pad bytes up to pitch
+hipError_t LaunchSanitizeTail(uint8_t *rows, uint64_t pitch, uint32_t sample_ct, uint32_t variant_ct,
+                              hipStream_t stream);
+
+// ---- genotype-class tally --------------------------------------------------
+// out[i] = {hom_ref, het, hom_alt, missing} of row (vlist ? vlist[i] : v_first + i)
+// over the samples selected by mask2 (NULL = all).  mask2: one row of `pitch`
+// bytes holding 01 in the 2-bit slot of every included sample.  n_eff = number of
+// included samples.
+hipError_t LaunchCounts(const RowView &view, uint32_t v_first, const uint32_t *vlist, uint32_t v_count,
+                        const uint8_t *mask2, uint32_t n_eff, uint32_t *out, hipStream_t stream);
+
+// alt_freq / obs_ct per variant from its counts (NaN where obs == 0)
+hipError_t LaunchFreqFromCounts(const uint32_t *counts, uint32_t n, double *alt_freq, int32_t *obs_ct,
+                                hipStream_t stream);
+
+// ---- per-sample missing tally ----------------------------------------------
+// out[s] += number of rows in [v_first, v_first + v_count) where sample s is missing
+// (out: uint32[round_up(N,64)], zeroed by the caller).
+hipError_t LaunchMissingPerSample(const RowView &view, uint32_t v_first, const uint32_t *vlist, uint32_t v_count,
+                                  uint32_t *out, hipStream_t stream);
+
+// ---- 2-bit -> int8 unpack --------------------------------------------------
+// out row i: int8[N] (+pad to out_pitch, multiple of 16) with missing -> fill;
+// validity row i (optional): ceil(N/64) uint64 words, bit = non-missing.
+hipError_t LaunchUnpack(const RowView &view, uint32_t v_first, uint32_t v_count, int8_t *out, uint64_t out_pitch,
+                        uint64_t *validity, int8_t fill, hipStream_t stream);
+// Subset form: sel[k] = raw index of the k-th included sample, n_out entries.
+hipError_t LaunchUnpackSubset(const RowView &view, uint32_t v_first, uint32_t v_count, const uint32_t *sel,
+                              uint32_t n_out, int8_t *out, uint64_t out_pitch, uint64_t *validity, int8_t fill,
+                              hipStream_t stream);
+
+// ---- plink_score ------------------------------------------------------------
+// Per scored variant i, from its counts: the scored-dosage table ts[i][g], the
+// dosage-sum table td[i][g] and the allele-count increments ac[i] (byte 0: g<3,
+// byte 1: g==3).  Skipped variants get all-zero tables.
+hipError_t LaunchScoreTables(const uint32_t *counts, const uint8_t *flip, uint32_t n_scored, int mode, double *ts,
+                             double *td, uint32_t *ac, hipStream_t stream);
+// score[s][c] += sum_i w[i][c]*ts[i][g]; dosage_sum[s] += td[i][g]; allele_ct[s] += ac.
+// Outputs are raw-sample order, zeroed by the caller.
+hipError_t LaunchScoreAccumulate(const RowView &view, const uint32_t *vlist, uint32_t n_scored, const double *weights,
+                                 uint32_t n_cols, const double *ts, const double *td, const uint32_t *ac,
+                                 double *score, double *dosage_sum, uint32_t *allele_ct, hipStream_t stream);
+
+// ---- HWE --------------------------------------------------------------------
+hipError_t LaunchHweBatch(const uint32_t *counts, uint32_t n, uint32_t midp, double *ln_p, hipStream_t stream);
+
+} // namespace pgh

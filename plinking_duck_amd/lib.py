@@ -1,0 +1,418 @@
+"""ctypes binding of libpgenhip.so -- one Python method per C entry point of
+``include/pgenhip.h``.  Thin on purpose: argument marshalling and status ->
+exception translation only (PGH_ERR_ARG -> ValueError ~ InvalidInputException,
+everything else -> IOError ~ IOException, the reference's convention,
+src/plink_freq.cpp:152,181,485)."""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpgenhip.so")
+
+ERRBUF_LEN = 256
+PGH_OK, PGH_ERR_OPEN, PGH_ERR_FORMAT, PGH_ERR_ARG, PGH_ERR_DEVICE, PGH_ERR_NOMEM, PGH_ERR_UNSUPPORTED = range(7)
+SCORE_MEAN_IMPUTE, SCORE_NO_MEAN_IMPUTATION, SCORE_CENTER = 0, 1, 2
+
+# every symbol include/pgenhip.h declares (tests/test_abi.py checks the .so exports each)
+EXPORTED_SYMBOLS = [
+    "pgh_version", "pgh_device_count", "pgh_set_device", "pgh_open", "pgh_probe", "pgh_normalize_range_host",
+    "pgh_from_host_rows",
+    "pgh_synth_create", "pgh_synth_record_host", "pgh_synth_write_files", "pgh_copy_rows_to_host", "pgh_get_info", "pgh_device_rows",
+    "pgh_close", "pgh_subset_create", "pgh_subset_size", "pgh_subset_destroy", "pgh_counts_range",
+    "pgh_counts_range_dev", "pgh_freq_from_counts_dev", "pgh_missing_per_sample", "pgh_missing_per_sample_dev", "pgh_unpack_range",
+    "pgh_unpack_range_dev", "pgh_score", "pgh_score_dev", "pgh_reader_create", "pgh_reader_destroy",
+    "pgh_get_2bit", "pgh_get_counts", "pgh_get_missingness", "pgh_get_int8", "pgh_get_dosage_f64",
+    "pgh_reader_error", "pgh_hwe_lnp", "pgh_hwe_xchr_lnp", "pgh_hwe_lnp_batch", "pgh_hwe_lnp_batch_dev",
+]
+
+
+class PghInfo(C.Structure):
+    _fields_ = [
+        ("raw_variant_ct", C.c_uint32), ("raw_sample_ct", C.c_uint32), ("variant_begin", C.c_uint32),
+        ("variant_end", C.c_uint32), ("has_dosage", C.c_uint32), ("has_phase", C.c_uint32),
+        ("max_record_bytes", C.c_uint32), ("record_bytes", C.c_uint32), ("pitch_bytes", C.c_uint64),
+        ("vrtype_hist", C.c_uint32 * 8), ("device", C.c_int32),
+    ]
+
+
+class PghError(IOError):
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+class PghArgError(ValueError):
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with plinking_duck_amd/csrc/build.sh "
+            "(python -c 'import __graft_entry__ as g; g.build()').  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, u32, u64, i32, cp = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32, C.c_char_p
+    sigs = {
+        "pgh_version": (cp, []),
+        "pgh_device_count": (C.c_int, []),
+        "pgh_set_device": (C.c_int, [C.c_int, cp]),
+        "pgh_open": (C.c_int, [cp, cp, u32, u32, C.POINTER(vp), cp]),
+        "pgh_probe": (C.c_int, [cp, cp, C.POINTER(PghInfo), cp]),
+        "pgh_normalize_range_host": (C.c_int, [cp, cp, u32, u32, vp, C.c_size_t, cp]),
+        "pgh_from_host_rows": (C.c_int, [vp, C.c_size_t, u32, u32, C.POINTER(vp), cp]),
+        "pgh_synth_create": (C.c_int, [u32, u32, u32, u64, C.c_double, C.POINTER(vp), cp]),
+        "pgh_synth_record_host": (C.c_int, [u32, u32, u64, C.c_double, vp]),
+        "pgh_synth_write_files": (C.c_int, [cp, u32, u32, u64, C.c_double, cp]),
+        "pgh_copy_rows_to_host": (C.c_int, [vp, u32, u32, vp, C.c_size_t, cp]),
+        "pgh_freq_from_counts_dev": (C.c_int, [vp, u32, vp, vp, vp, cp]),
+        "pgh_hwe_lnp_batch_dev": (C.c_int, [vp, u32, u32, vp, vp, cp]),
+        "pgh_get_info": (C.c_int, [vp, C.POINTER(PghInfo)]),
+        "pgh_device_rows": (vp, [vp]),
+        "pgh_close": (None, [vp]),
+        "pgh_subset_create": (C.c_int, [vp, vp, C.POINTER(vp), cp]),
+        "pgh_subset_size": (u32, [vp]),
+        "pgh_subset_destroy": (None, [vp]),
+        "pgh_counts_range": (C.c_int, [vp, vp, u32, u32, vp, cp]),
+        "pgh_counts_range_dev": (C.c_int, [vp, vp, u32, u32, vp, vp, cp]),
+        "pgh_missing_per_sample": (C.c_int, [vp, vp, u32, u32, vp, cp]),
+        "pgh_missing_per_sample_dev": (C.c_int, [vp, u32, u32, vp, vp, cp]),
+        "pgh_unpack_range": (C.c_int, [vp, vp, u32, u32, vp, vp, C.c_int, cp]),
+        "pgh_unpack_range_dev": (C.c_int, [vp, vp, u32, u32, vp, C.c_size_t, vp, C.c_int, vp, cp]),
+        "pgh_score": (C.c_int, [vp, vp, u32, vp, vp, vp, u32, C.c_int, vp, vp, vp, cp]),
+        "pgh_score_dev": (C.c_int, [vp, vp, u32, vp, vp, vp, u32, C.c_int, vp, vp, vp, vp, cp]),
+        "pgh_reader_create": (C.c_int, [vp, vp, C.POINTER(vp), cp]),
+        "pgh_reader_destroy": (None, [vp]),
+        "pgh_get_2bit": (C.c_int, [vp, u32, vp]),
+        "pgh_get_counts": (C.c_int, [vp, u32, vp]),
+        "pgh_get_missingness": (C.c_int, [vp, u32, vp]),
+        "pgh_get_int8": (C.c_int, [vp, u32, vp]),
+        "pgh_get_dosage_f64": (C.c_int, [vp, u32, vp]),
+        "pgh_reader_error": (cp, [vp]),
+        "pgh_hwe_lnp": (C.c_double, [i32, i32, i32, u32]),
+        "pgh_hwe_xchr_lnp": (C.c_double, [i32, i32, i32, i32, i32, u32]),
+        "pgh_hwe_lnp_batch": (C.c_int, [vp, u32, u32, vp, cp]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_lib = _load()
+
+
+def raw():
+    """The ctypes CDLL (for tests that probe the ABI directly)."""
+    return _lib
+
+
+def _check(rc, errbuf):
+    if rc == PGH_OK:
+        return
+    msg = errbuf.value.decode("utf-8", "replace") if errbuf is not None else f"pgenhip error {rc}"
+    if rc == PGH_ERR_ARG:
+        raise PghArgError(rc, msg)
+    raise PghError(rc, msg)
+
+
+def _errbuf():
+    return C.create_string_buffer(ERRBUF_LEN)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def version() -> str:
+    return _lib.pgh_version().decode()
+
+
+def device_count() -> int:
+    return _lib.pgh_device_count()
+
+
+def set_device(dev: int):
+    eb = _errbuf()
+    _check(_lib.pgh_set_device(dev, eb), eb)
+
+
+def probe(path: str, pgi_path: str | None = None) -> PghInfo:
+    info = PghInfo()
+    eb = _errbuf()
+    _check(_lib.pgh_probe(path.encode(), pgi_path.encode() if pgi_path else None, C.byref(info), eb), eb)
+    return info
+
+
+def normalize_range_host(path: str, v_begin: int = 0, v_end: int | None = None, pgi_path: str | None = None):
+    """Host normaliser only: plain 2-bit rows uint8[v_end-v_begin][ceil(N/4)]."""
+    info = probe(path, pgi_path)
+    v_end = info.raw_variant_ct if v_end is None else v_end
+    rows = np.zeros((max(0, v_end - v_begin), info.record_bytes), dtype=np.uint8)
+    eb = _errbuf()
+    _check(_lib.pgh_normalize_range_host(path.encode(), pgi_path.encode() if pgi_path else None, v_begin, v_end,
+                                         _ptr(rows), info.record_bytes, eb), eb)
+    return rows
+
+
+def hwe_lnp(hets: int, hom1: int, hom2: int, midp: bool = False) -> float:
+    return _lib.pgh_hwe_lnp(hets, hom1, hom2, 1 if midp else 0)
+
+
+def hwe_xchr_lnp(fhets: int, fhom1: int, fhom2: int, male1: int, male2: int, midp: bool = False) -> float:
+    return _lib.pgh_hwe_xchr_lnp(fhets, fhom1, fhom2, male1, male2, 1 if midp else 0)
+
+
+def hwe_lnp_batch(counts: np.ndarray, midp: bool = False) -> np.ndarray:
+    counts = np.ascontiguousarray(counts, dtype=np.uint32).reshape(-1, 4)
+    out = np.empty(len(counts), dtype=np.float64)
+    eb = _errbuf()
+    _check(_lib.pgh_hwe_lnp_batch(_ptr(counts), len(counts), 1 if midp else 0, _ptr(out), eb), eb)
+    return out
+
+
+def freq_from_counts_dev(d_counts: int, n: int, d_alt_freq: int, d_obs_ct: int, stream: int = 0):
+    eb = _errbuf()
+    _check(_lib.pgh_freq_from_counts_dev(d_counts, n, d_alt_freq, d_obs_ct, stream, eb), eb)
+
+
+def hwe_lnp_batch_dev(d_counts: int, n: int, d_ln_p: int, midp: bool = False, stream: int = 0):
+    eb = _errbuf()
+    _check(_lib.pgh_hwe_lnp_batch_dev(d_counts, n, 1 if midp else 0, d_ln_p, stream, eb), eb)
+
+
+def synth_record_host(v: int, n: int, seed: int, missing_rate: float) -> np.ndarray:
+    out = np.zeros((n + 3) // 4, dtype=np.uint8)
+    rc = _lib.pgh_synth_record_host(v, n, seed, missing_rate, _ptr(out))
+    if rc != PGH_OK:
+        raise PghArgError(rc, "pgh_synth_record_host: bad argument")
+    return out
+
+
+def synth_write_files(prefix: str, m: int, n: int, seed: int, missing_rate: float):
+    eb = _errbuf()
+    _check(_lib.pgh_synth_write_files(prefix.encode(), m, n, seed, missing_rate, eb), eb)
+
+
+class Subset:
+    def __init__(self, ds: "Dataset", include_mask: np.ndarray):
+        """include_mask: bool[N]."""
+        include_mask = np.asarray(include_mask, dtype=bool)
+        n = ds.info.raw_sample_ct
+        assert include_mask.shape == (n,)
+        words = np.zeros((n + 63) // 64, dtype=np.uint64)
+        bits = np.packbits(include_mask, bitorder="little")
+        words.view(np.uint8)[: len(bits)] = bits
+        self._h = C.c_void_p()
+        self.ds = ds
+        eb = _errbuf()
+        _check(_lib.pgh_subset_create(ds._h, _ptr(words), C.byref(self._h), eb), eb)
+        self.size = _lib.pgh_subset_size(self._h)
+
+    def close(self):
+        if self._h:
+            _lib.pgh_subset_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        self.close()
+
+
+class Dataset:
+    """A genotype matrix resident in HBM (pgh_dataset)."""
+
+    def __init__(self, handle):
+        self._h = handle
+        self.info = PghInfo()
+        _lib.pgh_get_info(self._h, C.byref(self.info))
+
+    @classmethod
+    def open(cls, path: str, pgi_path: str | None = None, variant_begin: int = 0, variant_end: int | None = None):
+        h = C.c_void_p()
+        eb = _errbuf()
+        _check(_lib.pgh_open(path.encode(), pgi_path.encode() if pgi_path else None, variant_begin,
+                             0xFFFFFFFF if variant_end is None else variant_end, C.byref(h), eb), eb)
+        return cls(h)
+
+    @classmethod
+    def from_host_rows(cls, rows: np.ndarray, n_samples: int):
+        rows = np.ascontiguousarray(rows, dtype=np.uint8)
+        assert rows.ndim == 2
+        h = C.c_void_p()
+        eb = _errbuf()
+        _check(_lib.pgh_from_host_rows(_ptr(rows), rows.shape[1], rows.shape[0], n_samples, C.byref(h), eb), eb)
+        return cls(h)
+
+    @classmethod
+    def synth(cls, variant_begin: int, variant_end: int, n_samples: int, seed: int, missing_rate: float):
+        h = C.c_void_p()
+        eb = _errbuf()
+        _check(_lib.pgh_synth_create(variant_begin, variant_end, n_samples, seed, missing_rate, C.byref(h), eb), eb)
+        return cls(h)
+
+    # -- properties -------------------------------------------------------
+    @property
+    def n_samples(self):
+        return self.info.raw_sample_ct
+
+    @property
+    def v_begin(self):
+        return self.info.variant_begin
+
+    @property
+    def v_end(self):
+        return self.info.variant_end
+
+    @property
+    def device_rows(self) -> int:
+        return _lib.pgh_device_rows(self._h)
+
+    def copy_rows_to_host(self, v_begin: int, v_end: int) -> np.ndarray:
+        rows = np.zeros((max(0, v_end - v_begin), self.info.record_bytes), dtype=np.uint8)
+        eb = _errbuf()
+        _check(_lib.pgh_copy_rows_to_host(self._h, v_begin, v_end, _ptr(rows), self.info.record_bytes, eb), eb)
+        return rows
+
+    def subset(self, include_mask) -> Subset:
+        return Subset(self, include_mask)
+
+    def close(self):
+        if self._h:
+            _lib.pgh_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        self.close()
+
+    # -- batched calls ------------------------------------------------------
+    def counts_range(self, v_begin=None, v_end=None, subset: Subset | None = None) -> np.ndarray:
+        v_begin = self.v_begin if v_begin is None else v_begin
+        v_end = self.v_end if v_end is None else v_end
+        out = np.zeros((max(0, v_end - v_begin), 4), dtype=np.uint32)
+        eb = _errbuf()
+        _check(_lib.pgh_counts_range(self._h, subset._h if subset else None, v_begin, v_end, _ptr(out), eb), eb)
+        return out
+
+    def counts_range_dev(self, v_begin, v_end, d_out: int, stream: int = 0, subset: Subset | None = None):
+        eb = _errbuf()
+        _check(_lib.pgh_counts_range_dev(self._h, subset._h if subset else None, v_begin, v_end, d_out, stream, eb), eb)
+
+    def missing_per_sample(self, v_begin=None, v_end=None, subset: Subset | None = None) -> np.ndarray:
+        v_begin = self.v_begin if v_begin is None else v_begin
+        v_end = self.v_end if v_end is None else v_end
+        n_out = subset.size if subset else self.n_samples
+        out = np.zeros(n_out, dtype=np.uint32)
+        eb = _errbuf()
+        _check(_lib.pgh_missing_per_sample(self._h, subset._h if subset else None, v_begin, v_end, _ptr(out), eb), eb)
+        return out
+
+    def missing_per_sample_dev(self, v_begin, v_end, d_out: int, stream: int = 0):
+        eb = _errbuf()
+        _check(_lib.pgh_missing_per_sample_dev(self._h, v_begin, v_end, d_out, stream, eb), eb)
+
+    def unpack_range(self, v_begin=None, v_end=None, subset: Subset | None = None, missing_code: int = -9,
+                     want_validity: bool = True):
+        v_begin = self.v_begin if v_begin is None else v_begin
+        v_end = self.v_end if v_end is None else v_end
+        n_out = subset.size if subset else self.n_samples
+        rows = max(0, v_end - v_begin)
+        out = np.zeros((rows, n_out), dtype=np.int8)
+        val = np.zeros((rows, (n_out + 63) // 64), dtype=np.uint64) if want_validity else None
+        eb = _errbuf()
+        _check(_lib.pgh_unpack_range(self._h, subset._h if subset else None, v_begin, v_end, _ptr(out), _ptr(val),
+                                     missing_code, eb), eb)
+        return out, val
+
+    def unpack_range_dev(self, v_begin, v_end, d_out: int, out_pitch: int, d_validity: int, missing_code: int = 0,
+                         stream: int = 0, subset: Subset | None = None):
+        eb = _errbuf()
+        _check(_lib.pgh_unpack_range_dev(self._h, subset._h if subset else None, v_begin, v_end, d_out, out_pitch,
+                                         d_validity, missing_code, stream, eb), eb)
+
+    def score(self, vidx, weights, flip=None, mode: int = SCORE_MEAN_IMPUTE, subset: Subset | None = None):
+        vidx = np.ascontiguousarray(vidx, dtype=np.uint32)
+        weights = np.ascontiguousarray(weights, dtype=np.float64)
+        if weights.ndim == 1:
+            weights = weights.reshape(-1, 1)
+        n_scored, n_cols = weights.shape
+        assert len(vidx) == n_scored
+        flip_a = None if flip is None else np.ascontiguousarray(flip, dtype=np.uint8)
+        n_out = subset.size if subset else self.n_samples
+        score = np.zeros((n_out, n_cols), dtype=np.float64)
+        dos = np.zeros(n_out, dtype=np.float64)
+        ac = np.zeros(n_out, dtype=np.uint32)
+        eb = _errbuf()
+        _check(_lib.pgh_score(self._h, subset._h if subset else None, n_scored, _ptr(vidx), _ptr(weights), _ptr(flip_a),
+                              n_cols, mode, _ptr(score), _ptr(dos), _ptr(ac), eb), eb)
+        return score, dos, ac
+
+    def score_dev(self, vidx, weights, d_score: int, d_dosage: int, d_allele: int, flip=None,
+                  mode: int = SCORE_MEAN_IMPUTE, stream: int = 0, subset: Subset | None = None):
+        vidx = np.ascontiguousarray(vidx, dtype=np.uint32)
+        weights = np.ascontiguousarray(weights, dtype=np.float64)
+        if weights.ndim == 1:
+            weights = weights.reshape(-1, 1)
+        flip_a = None if flip is None else np.ascontiguousarray(flip, dtype=np.uint8)
+        eb = _errbuf()
+        _check(_lib.pgh_score_dev(self._h, subset._h if subset else None, weights.shape[0], _ptr(vidx), _ptr(weights),
+                                  _ptr(flip_a), weights.shape[1], mode, d_score, d_dosage, d_allele, stream, eb), eb)
+
+    def reader(self, subset: Subset | None = None) -> "Reader":
+        return Reader(self, subset)
+
+
+class Reader:
+    """Per-scan-thread view with pgenlib-shaped per-variant calls (pgh_reader)."""
+
+    def __init__(self, ds: Dataset, subset: Subset | None = None):
+        self.ds = ds
+        self.subset = subset
+        self.n_out = subset.size if subset else ds.n_samples
+        self._h = C.c_void_p()
+        eb = _errbuf()
+        _check(_lib.pgh_reader_create(ds._h, subset._h if subset else None, C.byref(self._h), eb), eb)
+
+    def _chk(self, rc):
+        if rc != PGH_OK:
+            msg = _lib.pgh_reader_error(self._h).decode("utf-8", "replace")
+            raise (PghArgError if rc == PGH_ERR_ARG else PghError)(rc, msg)
+
+    def get_counts(self, vidx: int) -> np.ndarray:
+        out = np.zeros(4, dtype=np.uint32)
+        self._chk(_lib.pgh_get_counts(self._h, vidx, _ptr(out)))
+        return out
+
+    def get_2bit(self, vidx: int) -> np.ndarray:
+        out = np.zeros((self.n_out + 31) // 32, dtype=np.uint64)
+        self._chk(_lib.pgh_get_2bit(self._h, vidx, _ptr(out)))
+        return out
+
+    def get_missingness(self, vidx: int) -> np.ndarray:
+        out = np.zeros((self.n_out + 63) // 64, dtype=np.uint64)
+        self._chk(_lib.pgh_get_missingness(self._h, vidx, _ptr(out)))
+        return out
+
+    def get_int8(self, vidx: int) -> np.ndarray:
+        out = np.zeros(self.n_out, dtype=np.int8)
+        self._chk(_lib.pgh_get_int8(self._h, vidx, _ptr(out)))
+        return out
+
+    def get_dosage_f64(self, vidx: int) -> np.ndarray:
+        out = np.zeros(self.n_out, dtype=np.float64)
+        self._chk(_lib.pgh_get_dosage_f64(self._h, vidx, _ptr(out)))
+        return out
+
+    def close(self):
+        if self._h:
+            _lib.pgh_reader_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        self.close()

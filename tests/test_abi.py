@@ -1,0 +1,165 @@
+"""CPU-only checks of the product's host side: the C-ABI library loads and
+exports every symbol include/pgenhip.h declares, the header probe and the host
+record normaliser agree with the oracle on every reference fixture, and the HWE
+routines agree with the oracle.  No device work happens here."""
+
+import ctypes as C
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, data_path
+
+FIXTURES = ["pgen_example", "all_missing", "large_example", "streaming_example", "sexchr_example", "rare_small",
+            "pca_example", "phased_example", "dosage_example", "pgen_split"]
+
+
+def test_library_exports_every_declared_symbol(lib):
+    header = open(os.path.join(ROOT, "include", "pgenhip.h")).read()
+    declared = set(re.findall(r"\b(pgh_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    cdll = lib.raw()
+    for name in sorted(declared):
+        assert hasattr(cdll, name), f"{name} declared in pgenhip.h but not exported"
+    assert declared == set(lib.EXPORTED_SYMBOLS)
+    assert lib.version().startswith("pgenhip")
+
+
+def test_probe_matches_oracle(lib, oracle):
+    for name in FIXTURES:
+        info = lib.probe(data_path(name + ".pgen"))
+        pg = oracle.Pgen(data_path(name + ".pgen"))
+        assert (info.raw_variant_ct, info.raw_sample_ct) == (pg.M, pg.N)
+        assert bool(info.has_dosage) == pg.has_dosage and bool(info.has_phase) == pg.has_phase
+        hist = np.bincount([pg.vrtype(v) & 7 for v in range(pg.M)], minlength=8)
+        assert list(info.vrtype_hist) == hist.tolist()
+        assert info.record_bytes == (pg.N + 3) // 4 and info.pitch_bytes % 16 == 0
+
+
+def test_probe_errors(lib, tmp_path):
+    with pytest.raises(IOError):
+        lib.probe(str(tmp_path / "nope.pgen"))
+    bad = tmp_path / "bad.pgen"
+    bad.write_bytes(b"\x00\x01\x02\x03" * 8)
+    with pytest.raises(IOError) as e:
+        lib.probe(str(bad))
+    assert "magic" in str(e.value)
+    trunc = tmp_path / "trunc.pgen"
+    trunc.write_bytes(open(data_path("pgen_example.pgen"), "rb").read()[:20])
+    with pytest.raises(IOError):
+        lib.probe(str(trunc))
+
+
+def pack_rows(codes):
+    n = codes.shape[-1]
+    pad = np.zeros(codes.shape[:-1] + (((n + 3) // 4) * 4,), dtype=np.uint8)
+    pad[..., :n] = codes
+    return (pad[..., 0::4] | (pad[..., 1::4] << 2) | (pad[..., 2::4] << 4) | (pad[..., 3::4] << 6)).astype(np.uint8)
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_host_normaliser_matches_oracle(lib, oracle, name):
+    path = data_path(name + ".pgen")
+    rows = lib.normalize_range_host(path)
+    pg = oracle.Pgen(path)
+    step = max(1, pg.M // 1500)
+    for v in range(0, pg.M, step):
+        assert np.array_equal(rows[v], pack_rows(pg.raw(v))), (name, v)
+
+
+def test_host_normaliser_mid_chain_start(lib):
+    """Starting inside an LD chain must resolve the base record first."""
+    path = data_path("pca_example.pgen")
+    full = lib.normalize_range_host(path)
+    for vb in (1, 7, 133, 250, 499):
+        part = lib.normalize_range_host(path, vb, min(500, vb + 9))
+        assert np.array_equal(part, full[vb:vb + 9])
+
+
+def test_hwe_matches_oracle(lib, oracle):
+    rng = np.random.default_rng(7)
+    cases = [(1, 1, 1), (2, 1, 1), (1, 2, 1), (0, 1, 1), (2, 2, 2), (0, 0, 5), (5, 0, 0), (0, 3, 0)]
+    for _ in range(200):
+        n = int(rng.integers(1, 3000))
+        p = rng.uniform(0.01, 0.99)
+        f = rng.uniform(-0.2, 0.4)  # inbreeding: pushes tables away from HWE
+        probs = [(1 - p) ** 2 + f * p * (1 - p), 2 * p * (1 - p) * (1 - f), p * p + f * p * (1 - p)]
+        probs = np.clip(probs, 0, None)
+        hom1, het, hom2 = rng.multinomial(n, probs / probs.sum())
+        cases.append((int(het), int(hom1), int(hom2)))
+    for het, hom1, hom2 in cases:
+        for midp in (False, True):
+            a = lib.hwe_lnp(het, hom1, hom2, midp)
+            b = oracle.hwe_lnp(het, hom1, hom2, midp)
+            if math.isinf(b):
+                assert a < -700
+            else:
+                assert a == pytest.approx(b, rel=1e-9, abs=1e-9), (het, hom1, hom2, midp)
+    # large, biobank-sized counts
+    for het, hom1, hom2 in [(49000, 26000, 25000), (120000, 300000, 80000), (249000, 125500, 125500)]:
+        a, b = lib.hwe_lnp(het, hom1, hom2), oracle.hwe_lnp(het, hom1, hom2)
+        assert a == pytest.approx(b, rel=1e-8, abs=1e-8)
+    assert lib.hwe_lnp(0, 0, 0) == 0.0
+
+
+def test_hwe_xchr_matches_oracle(lib, oracle):
+    rng = np.random.default_rng(11)
+    cases = [(1, 1, 1, 2, 1), (0, 0, 0, 3, 2), (2, 2, 2, 0, 0), (1, 0, 0, 0, 1)]
+    for _ in range(120):
+        nf, nm = int(rng.integers(0, 60)), int(rng.integers(0, 60))
+        p = rng.uniform(0.05, 0.95)
+        hom1, het, hom2 = rng.multinomial(nf, [(1 - p) ** 2, 2 * p * (1 - p), p * p])
+        m2 = int(rng.binomial(nm, p))
+        cases.append((int(het), int(hom1), int(hom2), nm - m2, m2))
+    for c in cases:
+        for midp in (False, True):
+            a, b = lib.hwe_xchr_lnp(*c, midp), oracle.hwe_xchr_lnp(*c, midp)
+            assert a == pytest.approx(b, rel=1e-8, abs=1e-8), (c, midp)
+
+
+def test_synth_files_roundtrip_through_oracle(lib, oracle, tmp_path):
+    """The product's .pgen writer and host generator against the oracle's reader."""
+    prefix = str(tmp_path / "syn")
+    M, N, seed = 300, 1003, 20260807
+    lib.synth_write_files(prefix, M, N, seed, 0.02)
+    pg = oracle.Pgen(prefix + ".pgen")
+    assert (pg.M, pg.N) == (M, N)
+    info = lib.probe(prefix + ".pgen")
+    assert list(info.vrtype_hist)[0] == M
+    tot = np.zeros(4, dtype=np.int64)
+    for v in range(0, M, 7):
+        rec = lib.synth_record_host(v, N, seed, 0.02)
+        assert np.array_equal(rec, pack_rows(pg.raw(v)))
+        tot += pg.counts(v)
+    # generator sanity: ~2 % missing, all three genotype classes present
+    assert 0.01 < tot[3] / tot.sum() < 0.03 and (tot[:3] > 0).all()
+    pvar = oracle.load_pvar(prefix + ".pvar")
+    psam = oracle.load_psam(prefix + ".psam")
+    assert len(pvar["id"]) == M and len(psam["iid"]) == N
+    rows = lib.normalize_range_host(prefix + ".pgen", 10, 20)
+    assert np.array_equal(rows[3], lib.synth_record_host(13, N, seed, 0.02))
+
+
+def test_multi_block_header_roundtrip(lib, oracle, tmp_path):
+    """> 65536 variants: per-block tables, parsed identically by both decoders."""
+    prefix = str(tmp_path / "blocks")
+    M, N = 70000, 9
+    lib.synth_write_files(prefix, M, N, 5, 0.1)
+    info = lib.probe(prefix + ".pgen")
+    assert info.raw_variant_ct == M
+    pg = oracle.Pgen(prefix + ".pgen")
+    for v in (0, 65535, 65536, 69999):
+        assert np.array_equal(lib.normalize_range_host(prefix + ".pgen", v, v + 1)[0], pack_rows(pg.raw(v)))
+        assert np.array_equal(lib.synth_record_host(v, N, 5, 0.1), pack_rows(pg.raw(v)))
+
+
+def test_no_gpu_means_loud_failure(lib):
+    if lib.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(IOError):
+        lib.Dataset.open(data_path("pgen_example.pgen"))
+    with pytest.raises(IOError):
+        lib.Dataset.synth(0, 4, 16, 1, 0.0)

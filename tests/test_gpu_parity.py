@@ -1,0 +1,318 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle.
+
+Integer outputs are compared bit-exact; floating outputs within 1e-6 relative
+(BASELINE.json north_star), with tighter bounds where the arithmetic allows.
+"""
+
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import data_path
+
+pytestmark = pytest.mark.gpu
+
+FIXTURES = ["pgen_example", "all_missing", "large_example", "streaming_example", "sexchr_example", "rare_small",
+            "pca_example", "phased_example", "dosage_example", "pgen_split"]
+SEED = 20260807
+REL = 1e-6
+
+with open(os.path.join(os.path.dirname(__file__), "golden", "known_answers.json")) as f:
+    KA = json.load(f)
+
+
+def subset_masks(n, rng):
+    """A few include masks: single sample, alternating, random, all-but-one."""
+    masks = []
+    m = np.zeros(n, dtype=bool)
+    m[n // 2] = True
+    masks.append(m)
+    if n > 1:
+        masks.append(np.arange(n) % 2 == 0)
+        masks.append(rng.random(n) < 0.4)
+        m = np.ones(n, dtype=bool)
+        m[0] = False
+        masks.append(m)
+    return [m for m in masks if m.any()]
+
+
+def validity_bits(val_row, n):
+    return np.unpackbits(val_row.view(np.uint8), bitorder="little")[:n].astype(bool)
+
+
+# --------------------------------------------------------------------------
+# reference fixtures (all record types)
+# --------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_fixture_counts_unpack_missing(gpu_lib, oracle, name):
+    path = data_path(name + ".pgen")
+    ds = gpu_lib.Dataset.open(path)
+    pg = oracle.Pgen(path)
+    assert (ds.info.raw_variant_ct, ds.n_samples) == (pg.M, pg.N)
+    rng = np.random.default_rng(3)
+    # counts: whole file, bit-exact
+    assert np.array_equal(ds.counts_range(), pg.counts_range())
+    # unpack + validity
+    out, val = ds.unpack_range(missing_code=-9)
+    out0, _ = ds.unpack_range(missing_code=0, want_validity=False)
+    step = max(1, pg.M // 400)
+    for v in range(0, pg.M, step):
+        g = pg.geno(v)
+        assert np.array_equal(out[v], g), (name, v)
+        assert np.array_equal(out0[v], np.where(g == -9, 0, g))
+        assert np.array_equal(validity_bits(val[v], pg.N), g != -9)
+    # per-sample missing tallies
+    assert np.array_equal(ds.missing_per_sample(), pg.missing_per_sample())
+    # sub-range
+    if pg.M > 10:
+        a, b = pg.M // 3, pg.M // 3 + 7
+        assert np.array_equal(ds.counts_range(a, b), pg.counts_range(a, b))
+        assert np.array_equal(ds.missing_per_sample(a, b), pg.missing_per_sample(a, b))
+    # sample subsets (pgenlib semantics: ascending file order)
+    for mask in subset_masks(pg.N, rng):
+        ss = ds.subset(mask)
+        inc = mask.astype(np.uint8)
+        assert ss.size == int(mask.sum())
+        assert np.array_equal(ds.counts_range(subset=ss), pg.counts_range(include=inc))
+        assert np.array_equal(ds.missing_per_sample(subset=ss), pg.missing_per_sample(include=inc))
+        o, vb = ds.unpack_range(subset=ss, missing_code=-9)
+        for v in range(0, pg.M, max(1, pg.M // 50)):
+            g = pg.geno(v, inc)
+            assert np.array_equal(o[v], g)
+            assert np.array_equal(validity_bits(vb[v], ss.size), g != -9)
+    ds.close()
+
+
+@pytest.mark.parametrize("name", ["pgen_example", "rare_small", "dosage_example", "pca_example"])
+def test_fixture_reader_calls(gpu_lib, oracle, name):
+    """The pgenlib-shaped per-variant calls (PgrGet / PgrGetCounts / ...)."""
+    path = data_path(name + ".pgen")
+    ds = gpu_lib.Dataset.open(path)
+    pg = oracle.Pgen(path)
+    rng = np.random.default_rng(5)
+    for mask in [None] + subset_masks(pg.N, rng)[:2]:
+        ss = ds.subset(mask) if mask is not None else None
+        inc = None if mask is None else mask.astype(np.uint8)
+        rd = ds.reader(ss)
+        n_out = pg.N if mask is None else int(mask.sum())
+        for v in list(range(0, pg.M, max(1, pg.M // 40))) + [pg.M - 1, 0]:
+            g = pg.geno(v, inc)
+            assert np.array_equal(rd.get_counts(v), pg.counts(v, inc))
+            assert np.array_equal(rd.get_int8(v), g)
+            two = rd.get_2bit(v)
+            codes = (np.repeat(two, 32) >> np.tile(np.arange(0, 64, 2, dtype=np.uint64), len(two))) & np.uint64(3)
+            assert np.array_equal(codes[:n_out].astype(np.int8), np.where(g == -9, 3, g))
+            assert np.array_equal(validity_bits(rd.get_missingness(v), n_out), g == -9)
+            assert np.array_equal(rd.get_dosage_f64(v), pg.dosage(v, inc))
+        with pytest.raises(ValueError):
+            rd.get_counts(pg.M)
+        rd.close()
+    ds.close()
+
+
+def test_known_answers_through_the_gpu(gpu_lib, oracle):
+    """Spot-check the reference's goldens straight off the HIP path."""
+    ds = gpu_lib.Dataset.open(data_path("pgen_example.pgen"))
+    ka = KA["pgen_example_freq"]
+    counts = ds.counts_range()
+    assert counts.tolist() == ka["counts"]
+    for v in range(4):
+        assert oracle.freq_from_counts(counts[v]) == (ka["alt_freq"][v], ka["obs_ct"][v])
+    out, _ = ds.unpack_range(missing_code=-9)
+    assert out.tolist() == KA["pgen_example_genotypes"]["matrix"]
+    assert ds.missing_per_sample().tolist() == KA["missing_pgen_example"]["sample_missing_ct"]
+    rs = gpu_lib.Dataset.open(data_path("rare_small.pgen"))
+    t = rs.counts_range().sum(axis=0)
+    k = KA["rare_small_totals"]
+    assert t.tolist() == [k["hom_ref"], k["het"], k["hom_alt"], k["missing"]]
+    # HWE on the device from the device counts
+    lnp = gpu_lib.hwe_lnp_batch(counts)
+    for v, row in enumerate(KA["hardy_pgen_example"]["rows"]):
+        assert round(float(np.exp(lnp[v])), 6) == row["p"]
+    lnp = gpu_lib.hwe_lnp_batch(counts, midp=True)
+    for v, row in enumerate(KA["hardy_pgen_example"]["rows"]):
+        assert round(float(np.exp(lnp[v])), 6) == row["p_midp"]
+
+
+def test_score_known_answers_through_the_gpu(gpu_lib):
+    ds = gpu_lib.Dataset.open(data_path("pgen_example.pgen"))
+    ka = KA["score_pgen_example"]
+    s, d, ac = ds.score(np.arange(4), ka["weights"])
+    assert s[:, 0].tolist() == ka["default"]["score_sum"]
+    assert d.tolist() == ka["default"]["dosage_sum"]
+    assert ac.tolist() == ka["default"]["allele_ct"]
+    s, d, ac = ds.score(np.arange(4), ka["weights"], mode=gpu_lib.SCORE_NO_MEAN_IMPUTATION)
+    assert (int(ac[1]), s[1, 0], d[1]) == (6, 1.5, 2.0) and (int(ac[3]), s[3, 0], d[3]) == (6, 5.0, 4.0)
+    s, d, ac = ds.score([1], [1.0], mode=gpu_lib.SCORE_CENTER)
+    assert np.allclose(s[:, 0], ka["center_rs2_weight1"]["score_sum"], rtol=1e-15, atol=0)
+    assert set(ac.tolist()) == {2} and not d.any()
+    s, _, _ = ds.score([0], [1.0], flip=[1])
+    assert (s[0, 0], s[2, 0]) == (2.0, 0.0)
+    am = gpu_lib.Dataset.open(data_path("all_missing.pgen"))
+    s, d, ac = am.score([0, 1], [1.0, 0.5])
+    assert not s.any() and not ac.any() and not d.any()
+
+
+# --------------------------------------------------------------------------
+# seeded synthetic data, sizes the oracle finishes in seconds
+# --------------------------------------------------------------------------
+
+SHAPES = [(64, 1), (33, 5), (257, 63), (130, 64), (90, 65), (50, 1000), (40, 4099), (24, 16384), (12, 70001)]
+
+
+@pytest.mark.parametrize("m,n", SHAPES)
+def test_synth_matches_host_generator_and_oracle(gpu_lib, oracle, m, n):
+    ds = gpu_lib.Dataset.synth(0, m, n, SEED, 0.02)
+    host = np.stack([gpu_lib.synth_record_host(v, n, SEED, 0.02) for v in range(m)])
+    # the on-device generator reproduces the host twin bit for bit
+    rd = ds.reader()
+    for v in (0, m // 2, m - 1):
+        two = rd.get_2bit(v)
+        assert np.array_equal(two.view(np.uint8)[: host.shape[1]], host[v])
+    # oracle over the same records (vrtype-0 .pgen built in memory)
+    pg = oracle.Pgen(mem=mem_pgen(host, n))
+    assert np.array_equal(ds.counts_range(), pg.counts_range())
+    assert np.array_equal(ds.missing_per_sample(), pg.missing_per_sample())
+    out, val = ds.unpack_range(missing_code=0)
+    for v in range(0, m, max(1, m // 16)):
+        g = pg.geno(v)
+        assert np.array_equal(out[v], np.where(g == -9, 0, g))
+        assert np.array_equal(validity_bits(val[v], n), g != -9)
+    rng = np.random.default_rng(n)
+    for mask in subset_masks(n, rng)[1:3]:
+        ss = ds.subset(mask)
+        inc = mask.astype(np.uint8)
+        assert np.array_equal(ds.counts_range(subset=ss), pg.counts_range(include=inc))
+        o, vb = ds.unpack_range(2, min(m, 9), subset=ss, missing_code=-9)
+        for i, v in enumerate(range(2, min(m, 9))):
+            assert np.array_equal(o[i], pg.geno(v, inc))
+    # a dataset built from host rows behaves the same as the generated one
+    ds2 = gpu_lib.Dataset.from_host_rows(host, n)
+    assert np.array_equal(ds2.counts_range(), ds.counts_range())
+
+
+def mem_pgen(rows, n):
+    """mode-0x02 (fixed-width) .pgen image around plain 2-bit rows."""
+    m = rows.shape[0]
+    head = bytes([0x6c, 0x1b, 0x02]) + int(m).to_bytes(4, "little") + int(n).to_bytes(4, "little") + bytes([0x40])
+    return np.frombuffer(head + rows.tobytes(), dtype=np.uint8)
+
+
+def test_variant_sharded_dataset_is_a_slice_of_the_global_one(gpu_lib):
+    """Rank r generates rows [a,b) of the same global matrix (multi-GPU sharding)."""
+    n = 3001
+    whole = gpu_lib.Dataset.synth(0, 96, n, SEED, 0.02)
+    part = gpu_lib.Dataset.synth(32, 64, n, SEED, 0.02)
+    assert np.array_equal(part.counts_range(), whole.counts_range(32, 64))
+    with pytest.raises(ValueError):
+        part.counts_range(0, 8)
+
+
+@pytest.mark.parametrize("mode", ["default", "no_mean_imputation", "center"])
+@pytest.mark.parametrize("ncols", [1, 16])
+def test_score_matches_oracle(gpu_lib, oracle, mode, ncols):
+    m, n = 300, 2000
+    ds = gpu_lib.Dataset.synth(0, m, n, SEED, 0.05)
+    host = np.stack([gpu_lib.synth_record_host(v, n, SEED, 0.05) for v in range(m)])
+    # force an all-missing and a monomorphic variant into the scored set
+    host[5] = 0xFF
+    host[9] = 0x00
+    ds = gpu_lib.Dataset.from_host_rows(host, n)
+    pg = oracle.Pgen(mem=mem_pgen(host, n))
+    rng = np.random.default_rng(17)
+    vidx = np.sort(rng.choice(m, size=180, replace=False))
+    vidx = np.union1d(vidx, [5, 9])
+    w = rng.standard_normal((len(vidx), ncols))
+    flip = (rng.random(len(vidx)) < 0.3).astype(np.uint8)
+    code = {"default": gpu_lib.SCORE_MEAN_IMPUTE, "no_mean_imputation": gpu_lib.SCORE_NO_MEAN_IMPUTATION,
+            "center": gpu_lib.SCORE_CENTER}[mode]
+    for mask in (None, rng.random(n) < 0.5):
+        ss = None if mask is None else ds.subset(mask)
+        inc = None if mask is None else mask.astype(np.uint8)
+        s, d, ac = ds.score(vidx, w, flip=flip, mode=code, subset=ss)
+        es, ed, eac = oracle.score(pg, vidx, w, flip=flip, mode=mode, include=inc)
+        assert np.array_equal(ac, eac)
+        scale = np.abs(w).sum(axis=0) * 2.0  # magnitude of the terms being summed
+        assert np.all(np.abs(s - es) <= REL * np.maximum(np.abs(es), 1e-9 * scale))
+        assert np.allclose(d, ed, rtol=REL, atol=1e-9)
+
+
+def test_hwe_batch_matches_oracle(gpu_lib, oracle):
+    rng = np.random.default_rng(23)
+    rows = []
+    for _ in range(400):
+        n = int(rng.integers(1, 200000))
+        p = rng.uniform(0.001, 0.999)
+        f = rng.uniform(-0.05, 0.1)
+        pr = np.clip([(1 - p) ** 2 + f * p * (1 - p), 2 * p * (1 - p) * (1 - f), p * p + f * p * (1 - p)], 0, None)
+        hom1, het, hom2 = rng.multinomial(n, pr / pr.sum())
+        rows.append([hom1, het, hom2, int(rng.integers(0, 50))])
+    rows += [[0, 0, 0, 7], [1, 1, 1, 0], [0, 10, 0, 0]]
+    counts = np.array(rows, dtype=np.uint32)
+    for midp in (False, True):
+        got = gpu_lib.hwe_lnp_batch(counts, midp)
+        for i in range(0, len(counts), 7):
+            hom1, het, hom2 = (int(x) for x in counts[i, :3])
+            exp = oracle.hwe_lnp(het, hom1, hom2, midp)
+            if np.isinf(exp):
+                assert got[i] < -700
+            else:
+                # 1e-6 relative on the p-value == 1e-6 absolute on ln p
+                assert abs(got[i] - exp) < 1e-6, (counts[i], midp)
+        # the device result equals the library's host routine
+        host = np.array([gpu_lib.hwe_lnp(int(c[1]), int(c[0]), int(c[2]), midp) for c in counts[:50]])
+        assert np.allclose(got[:50], host, rtol=1e-12, atol=1e-12)
+
+
+# --------------------------------------------------------------------------
+# BASELINE-sized rows (N = 500k) through size-independent properties
+# --------------------------------------------------------------------------
+
+def test_full_width_rows_properties(gpu_lib, oracle):
+    """N = 500,000 (BASELINE configs 2/3 row width), a few thousand variants."""
+    n, m = 500_000, 2048
+    ds = gpu_lib.Dataset.synth(0, m, n, SEED, 0.02)
+    counts = ds.counts_range()
+    # every row tallies to N
+    assert (counts.sum(axis=1, dtype=np.int64) == n).all()
+    # checksum of checksums: per-sample missing tallies and per-variant missing
+    # counts are two reductions of the same indicator matrix
+    miss = ds.missing_per_sample()
+    assert int(miss.sum(dtype=np.int64)) == int(counts[:, 3].sum(dtype=np.int64))
+    # linearity over variant ranges
+    a = ds.missing_per_sample(0, 700)
+    b = ds.missing_per_sample(700, m)
+    assert np.array_equal(a + b, miss)
+    # complementary subsets partition the counts
+    rng = np.random.default_rng(1)
+    mask = rng.random(n) < 0.37
+    c1 = ds.counts_range(0, 256, subset=ds.subset(mask))
+    c2 = ds.counts_range(0, 256, subset=ds.subset(~mask))
+    assert np.array_equal(c1 + c2, counts[:256])
+    # unpack is consistent with the tallies, and three rows match the oracle exactly
+    out, val = ds.unpack_range(0, 64, missing_code=0)
+    vb = np.unpackbits(val.view(np.uint8), axis=1, bitorder="little")[:, :n]
+    assert np.array_equal((vb == 0).sum(axis=1), counts[:64, 3])
+    assert np.array_equal(((out == 1) & (vb == 1)).sum(axis=1), counts[:64, 1])
+    assert np.array_equal((out == 2).sum(axis=1), counts[:64, 2])
+    host = np.stack([gpu_lib.synth_record_host(v, n, SEED, 0.02) for v in (0, 31, 63)])
+    pg = oracle.Pgen(mem=mem_pgen(host, n))
+    for i, v in enumerate((0, 31, 63)):
+        g = pg.geno(i)
+        assert np.array_equal(out[v], np.where(g == -9, 0, g))
+        assert np.array_equal(counts[v], pg.counts(i))
+    # generator statistics: ~2 % missing, allele frequencies inside U(0.01, 0.5)
+    assert 0.019 < counts[:, 3].mean() / n < 0.021
+    af = (counts[:, 1] + 2.0 * counts[:, 2]) / (2.0 * counts[:, :3].sum(axis=1))
+    assert 0.005 < af.min() and af.max() < 0.505
+    # score: all-ones weights reproduce the dosage sum; shards add up
+    vidx = np.arange(0, 512)
+    s, d, ac = ds.score(vidx, np.ones(len(vidx)))
+    assert np.allclose(s[:, 0], d, rtol=1e-12)
+    assert set(ac.tolist()) == {2 * len(vidx)}
+    s1, _, _ = ds.score(vidx[:200], np.ones(200))
+    s2, _, _ = ds.score(vidx[200:], np.ones(312))
+    assert np.allclose(s1 + s2, s, rtol=1e-9)
