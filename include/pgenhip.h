@@ -185,6 +185,21 @@ int pgh_score_dev(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_sc
                   const double *weights, const uint8_t *flip, uint32_t n_cols, int mode, void *d_score_sum,
                   void *d_dosage_sum, void *d_allele_ct, void *stream, char *errbuf);
 
+/* plink_pca's randomized subspace iteration (src/plink_pca.cpp:630-1080): n_pcs + 1
+ * passes of Y = X G1 (Step A) and G1 = X^T Y / M (Step B) over the n_var effective
+ * variants, thin SVD of the M x (n_pcs+1)*2*n_pcs Krylov block, then B = X^T U and
+ * its thin SVD.  X is never materialised: both contractions read the packed 2-bit
+ * rows and normalise on the fly (x = (g - center) * inv_stdev, missing -> 0).
+ *   vidx/center/inv_stdev  effective variants and their norms, as the reference's
+ *                          bind computes them (src/plink_pca.cpp:392-416)
+ *   g1_init                [n_out][2*n_pcs] row-major start matrix (src/plink_pca.cpp:517-523)
+ *   eigenvalues            [n_pcs]  (S^2 / n_var)
+ *   eigenvectors           [n_out][n_pcs] row-major, defined up to sign
+ * The two SVDs run on the host, as the reference's Eigen::BDCSVD does. */
+int pgh_pca(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_var, const uint32_t *vidx,
+            const double *center, const double *inv_stdev, uint32_t n_pcs, const double *g1_init,
+            double *eigenvalues, double *eigenvectors, char *errbuf);
+
 /* ---- per-variant calls mirroring pgenlib -------------------------------- */
 
 /* PgrInit + PgrSetSampleSubsetIndex per scan thread (src/plink_freq.cpp:381-397). */
@@ -200,6 +215,10 @@ int pgh_get_missingness(pgh_reader *rd, uint32_t vidx, uint64_t *bits);
 int pgh_get_int8(pgh_reader *rd, uint32_t vidx, int8_t *out);
 /* PgrGetD + Dosage16ToDoublesMinus9 (src/plink_score.cpp:586-596): -9.0 = missing. */
 int pgh_get_dosage_f64(pgh_reader *rd, uint32_t vidx, double *out);
+/* PgrGetP (src/pgen_reader.cpp:715): genovec as pgh_get_2bit plus the
+ * phasepresent / phaseinfo bitarrays (ceil(n_out/64) words each, zero for
+ * variants without a phase track).  The phase track is decoded on the host. */
+int pgh_get_phased(pgh_reader *rd, uint32_t vidx, uint64_t *genovec, uint64_t *phasepresent, uint64_t *phaseinfo);
 const char *pgh_reader_error(const pgh_reader *rd);
 
 /* ---- HWE exact tests (host) --------------------------------------------- */

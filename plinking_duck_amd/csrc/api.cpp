@@ -4,6 +4,7 @@
 
 #include "hwe_core.hpp"
 #include "kernels.hpp"
+#include "linalg.hpp"
 #include "pgen_file.hpp"
 #include "synth.hpp"
 
@@ -940,6 +941,113 @@ extern "C" int pgh_score(const pgh_dataset *ds, const pgh_subset *subset, uint32
 }
 
 // ---------------------------------------------------------------------------
+// plink_pca
+// ---------------------------------------------------------------------------
+
+extern "C" int pgh_pca(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_var, const uint32_t *vidx,
+                       const double *center, const double *inv_stdev, uint32_t n_pcs, const double *g1_init,
+                       double *eigenvalues, double *eigenvectors, char *errbuf) {
+	if (!ds || !vidx || !center || !inv_stdev || !g1_init || !eigenvalues || !eigenvectors || n_pcs == 0) {
+		SetErr(errbuf, "null or empty argument");
+		return PGH_ERR_ARG;
+	}
+	int rc = CheckSubset(ds, subset, errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	const uint32_t N = ds->sample_ct;
+	const uint32_t n_out = subset ? subset->n_out : N;
+	const uint32_t M = n_var;
+	const uint32_t k2 = 2 * n_pcs;
+	const uint32_t qq = (n_pcs + 1) * k2;
+	if (M < qq || n_out < qq) {
+		SetErr(errbuf, "too few variants or samples for the requested number of PCs");
+		return PGH_ERR_ARG;
+	}
+	std::vector<uint32_t> local(M);
+	for (uint32_t i = 0; i < M; i++) {
+		if (vidx[i] < ds->v_begin || vidx[i] >= ds->v_end) {
+			SetErr(errbuf, "effective variant index outside the resident range");
+			return PGH_ERR_ARG;
+		}
+		local[i] = vidx[i] - ds->v_begin;
+	}
+	hipStream_t st = hipStreamPerThread;
+	DevBuf d_vlist, d_center, d_inv, d_ts, d_g1, d_g2, d_qq, d_bb;
+	PGH_HIP(d_vlist.Alloc(sizeof(uint32_t) * M), "hipMalloc(pca)");
+	PGH_HIP(d_center.Alloc(sizeof(double) * M), "hipMalloc(pca)");
+	PGH_HIP(d_inv.Alloc(sizeof(double) * M), "hipMalloc(pca)");
+	PGH_HIP(d_ts.Alloc(32ull * M), "hipMalloc(pca)");
+	PGH_HIP(d_g1.Alloc(sizeof(double) * N * k2), "hipMalloc(pca)");
+	PGH_HIP(d_g2.Alloc(sizeof(double) * N * k2), "hipMalloc(pca)");
+	PGH_HIP(d_qq.Alloc(sizeof(double) * static_cast<size_t>(M) * qq), "hipMalloc(pca)");
+	PGH_HIP(hipMemcpy(d_vlist.p, local.data(), sizeof(uint32_t) * M, hipMemcpyHostToDevice), "pca upload");
+	PGH_HIP(hipMemcpy(d_center.p, center, sizeof(double) * M, hipMemcpyHostToDevice), "pca upload");
+	PGH_HIP(hipMemcpy(d_inv.p, inv_stdev, sizeof(double) * M, hipMemcpyHostToDevice), "pca upload");
+	{
+		// start matrix in raw-sample rows (excluded samples stay zero)
+		std::vector<double> g1_raw(static_cast<size_t>(N) * k2, 0.0);
+		for (uint32_t k = 0; k < n_out; k++) {
+			const uint32_t s = subset ? subset->sel[k] : k;
+			std::memcpy(&g1_raw[static_cast<size_t>(s) * k2], g1_init + static_cast<size_t>(k) * k2, sizeof(double) * k2);
+		}
+		PGH_HIP(hipMemcpy(d_g1.p, g1_raw.data(), sizeof(double) * g1_raw.size(), hipMemcpyHostToDevice), "pca upload");
+	}
+	PGH_HIP(pgh::LaunchNormTables(d_center.As<double>(), d_inv.As<double>(), M, d_ts.As<double>(), st), "pca tables");
+	const RowView view = ds->View();
+	double *g1 = d_g1.As<double>();
+	double *g2 = d_g2.As<double>();
+	const uint8_t *mask2 = subset ? subset->d_mask2 : nullptr;
+	for (uint32_t pass = 0; pass <= n_pcs; pass++) {
+		double *y = d_qq.As<double>() + static_cast<size_t>(pass) * k2;
+		// Step A: QQ[:, pass*2k : (pass+1)*2k] = X * G1
+		PGH_HIP(pgh::LaunchVariantReduce(view, d_vlist.As<uint32_t>(), M, d_ts.As<double>(), g1, k2, k2, y, qq, st),
+		        "pca step A");
+		if (pass < n_pcs) {
+			// Step B + merge: G1 = X^T Y / M
+			PGH_HIP(hipMemsetAsync(g2, 0, sizeof(double) * N * k2, st), "pca memset");
+			PGH_HIP(pgh::LaunchTableAccumulate(view, d_vlist.As<uint32_t>(), M, y, qq, k2, d_ts.As<double>(), nullptr,
+			                                   nullptr, g2, k2, nullptr, nullptr, st),
+			        "pca step B");
+			PGH_HIP(pgh::LaunchMaskRows(g2, N, k2, k2, mask2, st), "pca mask");
+			PGH_HIP(pgh::LaunchScale(g2, static_cast<uint64_t>(N) * k2, 1.0 / static_cast<double>(M), st), "pca scale");
+			std::swap(g1, g2);
+		}
+	}
+	// Krylov block -> left singular vectors (host)
+	std::vector<double> qq_host(static_cast<size_t>(M) * qq);
+	PGH_HIP(hipMemcpyAsync(qq_host.data(), d_qq.p, sizeof(double) * qq_host.size(), hipMemcpyDeviceToHost, st),
+	        "pca download");
+	PGH_HIP(hipStreamSynchronize(st), "pca sync");
+	std::vector<double> sv;
+	pgh::ThinSvdInPlace(qq_host.data(), M, qq, sv);
+	PGH_HIP(hipMemcpyAsync(d_qq.p, qq_host.data(), sizeof(double) * qq_host.size(), hipMemcpyHostToDevice, st),
+	        "pca upload");
+	// Phase 3: BB = X^T U
+	PGH_HIP(d_bb.Alloc(sizeof(double) * static_cast<size_t>(N) * qq), "hipMalloc(pca)");
+	PGH_HIP(hipMemsetAsync(d_bb.p, 0, sizeof(double) * static_cast<size_t>(N) * qq, st), "pca memset");
+	PGH_HIP(pgh::LaunchTableAccumulate(view, d_vlist.As<uint32_t>(), M, d_qq.As<double>(), qq, qq, d_ts.As<double>(),
+	                                   nullptr, nullptr, d_bb.As<double>(), qq, nullptr, nullptr, st),
+	        "pca phase 3");
+	std::vector<double> bb_raw(static_cast<size_t>(N) * qq);
+	PGH_HIP(hipMemcpyAsync(bb_raw.data(), d_bb.p, sizeof(double) * bb_raw.size(), hipMemcpyDeviceToHost, st),
+	        "pca download");
+	PGH_HIP(hipStreamSynchronize(st), "pca sync");
+	std::vector<double> bb(static_cast<size_t>(n_out) * qq);
+	Compact<double>(subset, bb_raw.data(), qq, bb.data(), N);
+	pgh::ThinSvdInPlace(bb.data(), n_out, qq, sv);
+	for (uint32_t s = 0; s < n_out; s++) {
+		for (uint32_t pc = 0; pc < n_pcs; pc++) {
+			eigenvectors[static_cast<size_t>(s) * n_pcs + pc] = bb[static_cast<size_t>(s) * qq + pc];
+		}
+	}
+	for (uint32_t pc = 0; pc < n_pcs; pc++) {
+		eigenvalues[pc] = sv[pc] * sv[pc] / static_cast<double>(M);
+	}
+	return PGH_OK;
+}
+
+// ---------------------------------------------------------------------------
 // per-variant reader
 // ---------------------------------------------------------------------------
 
@@ -1134,6 +1242,37 @@ extern "C" int pgh_get_int8(pgh_reader *rd, uint32_t vidx, int8_t *out) {
 	ForEachIncluded(rd, [&](uint32_t k, uint32_t s) {
 		const uint32_t c = RowCode(rd->h_row, s);
 		out[k] = c == 3u ? static_cast<int8_t>(-9) : static_cast<int8_t>(c);
+	});
+	return PGH_OK;
+}
+
+extern "C" int pgh_get_phased(pgh_reader *rd, uint32_t vidx, uint64_t *genovec, uint64_t *phasepresent,
+                              uint64_t *phaseinfo) {
+	int rc = ReaderCheck(rd, vidx);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	const pgh_dataset *ds = rd->ds;
+	const uint32_t n_out = rd->subset ? rd->subset->n_out : ds->sample_ct;
+	std::memset(phasepresent, 0, sizeof(uint64_t) * ((n_out + 63) / 64));
+	std::memset(phaseinfo, 0, sizeof(uint64_t) * ((n_out + 63) / 64));
+	if (!(rd->norm && (ds->index.vrtype[vidx] & 0x10))) {
+		return pgh_get_2bit(rd, vidx, genovec);
+	}
+	std::vector<uint8_t> row, pp, pi;
+	std::string err;
+	if (!rd->norm->DecodePhase(vidx, row, pp, pi, err)) {
+		return ReaderFail(rd, PGH_ERR_FORMAT, err);
+	}
+	std::memset(genovec, 0, sizeof(uint64_t) * ((n_out + 31) / 32));
+	ForEachIncluded(rd, [&](uint32_t k, uint32_t s) {
+		genovec[k >> 5] |= static_cast<uint64_t>(RowCode(row.data(), s)) << (2 * (k & 31));
+		if (pp[s]) {
+			phasepresent[k >> 6] |= 1ull << (k & 63);
+		}
+		if (pi[s]) {
+			phaseinfo[k >> 6] |= 1ull << (k & 63);
+		}
 	});
 	return PGH_OK;
 }

@@ -5,7 +5,7 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result"
 mkdir -p build
-for f in kernels.hip api.cpp pgen_file.cpp; do
+for f in kernels.hip api.cpp pgen_file.cpp linalg.cpp; do
 	o=build/${f%.*}.o
 	if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ -n "$(find . -maxdepth 1 -name '*.hpp' -newer "$o")" ] || [ ../../include/pgenhip.h -nt "$o" ]; then
 		if [ "${f##*.}" = "hip" ]; then
@@ -15,5 +15,19 @@ for f in kernels.hip api.cpp pgen_file.cpp; do
 		fi
 	fi
 done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libpgenhip.so build/kernels.o build/api.o build/pgen_file.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libpgenhip.so build/kernels.o build/api.o build/pgen_file.o build/linalg.o
 echo "built $(cd .. && pwd)/libpgenhip.so"
+
+# host-side table-function shells (plain C++; link against the C ABI only)
+CXX=${CXX:-g++}
+SHELL_SRCS="plink_common pgen_reader plink_freq plink_hardy plink_missing plink_score plink_pca extension"
+objs=""
+for n in $SHELL_SRCS; do
+	o=build/shell_$n.o
+	if [ ! -f "$o" ] || [ shell/$n.cpp -nt "$o" ] || [ -n "$(find shell -maxdepth 1 -name '*.hpp' -newer "$o")" ] || [ ../../include/pgenhip.h -nt "$o" ]; then
+		$CXX -O2 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter -Wno-redundant-move -c shell/$n.cpp -o "$o"
+	fi
+	objs="$objs $o"
+done
+$CXX -shared -fPIC -o ../libplinking_duck_amd.so $objs -L.. -lpgenhip -Wl,-rpath,'$ORIGIN' -lpthread
+echo "built $(cd .. && pwd)/libplinking_duck_amd.so"

@@ -499,8 +499,8 @@ template <int NCOLS>
 __global__ __launch_bounds__(256) void k_score_accumulate(const uint8_t *__restrict__ rows, uint64_t pitch,
                                                           uint32_t sample_ct, const uint32_t *__restrict__ vlist,
                                                           uint32_t n_scored, uint32_t slice_len,
-                                                          const double *__restrict__ weights,
-                                                          const double *__restrict__ ts,
+                                                          const double *__restrict__ weights, uint32_t w_stride,
+                                                          uint32_t out_stride, const double *__restrict__ ts,
                                                           const double *__restrict__ td,
                                                           const uint32_t *__restrict__ ac, double *__restrict__ score,
                                                           double *__restrict__ dosage_sum,
@@ -529,13 +529,13 @@ __global__ __launch_bounds__(256) void k_score_accumulate(const uint8_t *__restr
 		__syncthreads();
 		for (uint32_t k = threadIdx.x; k < cnt * 4u; k += 256u) {
 			s_ts[k >> 2][k & 3] = ts[4 * static_cast<uint64_t>(base) + k];
-			s_td[k >> 2][k & 3] = td[4 * static_cast<uint64_t>(base) + k];
+			s_td[k >> 2][k & 3] = td ? td[4 * static_cast<uint64_t>(base) + k] : 0.0;
 		}
 		for (uint32_t k = threadIdx.x; k < cnt * NCOLS; k += 256u) {
-			s_w[k / NCOLS][k % NCOLS] = weights[static_cast<uint64_t>(base) * NCOLS + k];
+			s_w[k / NCOLS][k % NCOLS] = weights[static_cast<uint64_t>(base + k / NCOLS) * w_stride + (k % NCOLS)];
 		}
 		for (uint32_t k = threadIdx.x; k < cnt; k += 256u) {
-			s_ac[k] = ac[base + k];
+			s_ac[k] = ac ? ac[base + k] : 0u;
 			s_v[k] = vlist[base + k];
 		}
 		__syncthreads();
@@ -557,10 +557,127 @@ __global__ __launch_bounds__(256) void k_score_accumulate(const uint8_t *__restr
 	if (live) {
 #pragma unroll
 		for (int c = 0; c < NCOLS; c++) {
-			unsafeAtomicAdd(score + static_cast<uint64_t>(s) * NCOLS + c, acc[c]);
+			unsafeAtomicAdd(score + static_cast<uint64_t>(s) * out_stride + c, acc[c]);
 		}
-		unsafeAtomicAdd(dosage_sum + s, dsum);
-		atomicAdd(allele_ct + s, act);
+		if (dosage_sum) {
+			unsafeAtomicAdd(dosage_sum + s, dsum);
+		}
+		if (allele_ct) {
+			atomicAdd(allele_ct + s, act);
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------
+// plink_pca
+// ---------------------------------------------------------------------------
+
+// Normalised-genotype table of each effective variant (NormalizeGenotypes,
+// src/plink_common.cpp:1535-1543): t[g] = (g - center) * inv_stdev, missing -> 0.
+__global__ __launch_bounds__(256) void k_norm_tables(const double *__restrict__ center,
+                                                     const double *__restrict__ inv_stdev, uint32_t n,
+                                                     double *__restrict__ ts) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) {
+		return;
+	}
+	const double c = center[i], is = inv_stdev[i];
+	ts[4 * static_cast<uint64_t>(i) + 0] = (0.0 - c) * is;
+	ts[4 * static_cast<uint64_t>(i) + 1] = (1.0 - c) * is;
+	ts[4 * static_cast<uint64_t>(i) + 2] = (2.0 - c) * is;
+	ts[4 * static_cast<uint64_t>(i) + 3] = 0.0;
+}
+
+// out[i][c] = sum over samples of ts[i][g(i,s)] * G[s][c]   (Step A, src/plink_pca.cpp:632-645)
+// One workgroup per tile of VT variants; a lane walks samples s = tid, tid+256, ...,
+// loads its G row once per sample and feeds all VT variants of the tile.
+template <int NCOLS, int VT>
+__global__ __launch_bounds__(256) void k_variant_reduce(const uint8_t *__restrict__ rows, uint64_t pitch,
+                                                        uint32_t sample_ct, const uint32_t *__restrict__ vlist,
+                                                        uint32_t n_var, const double *__restrict__ ts,
+                                                        const double *__restrict__ G, uint32_t g_stride,
+                                                        double *__restrict__ out, uint32_t out_stride) {
+	__shared__ double red[4][VT * NCOLS];
+	__shared__ double s_t[VT][4];
+	__shared__ uint32_t s_v[VT];
+	const uint32_t i0 = blockIdx.x * VT;
+	const uint32_t nv = min(static_cast<uint32_t>(VT), n_var - i0);
+	if (threadIdx.x < VT * 4) {
+		const uint32_t k = threadIdx.x >> 2;
+		s_t[k][threadIdx.x & 3] = k < nv ? ts[4 * static_cast<uint64_t>(i0 + k) + (threadIdx.x & 3)] : 0.0;
+	}
+	if (threadIdx.x < VT) {
+		s_v[threadIdx.x] = threadIdx.x < nv ? vlist[i0 + threadIdx.x] : vlist[i0];
+	}
+	__syncthreads();
+	double acc[VT][NCOLS];
+#pragma unroll
+	for (int k = 0; k < VT; k++) {
+#pragma unroll
+		for (int c = 0; c < NCOLS; c++) {
+			acc[k][c] = 0.0;
+		}
+	}
+	for (uint32_t s = threadIdx.x; s < sample_ct; s += 256u) {
+		double g[NCOLS];
+#pragma unroll
+		for (int c = 0; c < NCOLS; c++) {
+			g[c] = G[static_cast<uint64_t>(s) * g_stride + c];
+		}
+		const uint32_t shift = 2u * (s & 15u);
+#pragma unroll
+		for (int k = 0; k < VT; k++) {
+			const uint32_t w = reinterpret_cast<const uint32_t *>(rows + static_cast<uint64_t>(s_v[k]) * pitch)[s >> 4];
+			const double x = s_t[k][(w >> shift) & 3u];
+#pragma unroll
+			for (int c = 0; c < NCOLS; c++) {
+				acc[k][c] = fma(x, g[c], acc[k][c]);
+			}
+		}
+	}
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#pragma unroll
+	for (int k = 0; k < VT; k++) {
+#pragma unroll
+		for (int c = 0; c < NCOLS; c++) {
+			double v = acc[k][c];
+#pragma unroll
+			for (int off = 32; off > 0; off >>= 1) {
+				v += __shfl_xor(v, off, 64);
+			}
+			if (lane == 0) {
+				red[wave][k * NCOLS + c] = v;
+			}
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x < VT * NCOLS) {
+		const uint32_t k = threadIdx.x / NCOLS, c = threadIdx.x % NCOLS;
+		if (k < nv) {
+			// fixed order: deterministic
+			out[static_cast<uint64_t>(i0 + k) * out_stride + c] =
+			    ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+		}
+	}
+}
+
+// rows of excluded samples -> 0 (keeps a sample subset out of the power iteration)
+__global__ __launch_bounds__(256) void k_mask_rows(double *__restrict__ m, uint32_t n_rows, uint32_t stride,
+                                                   uint32_t ncols, const uint8_t *__restrict__ mask2) {
+	const uint64_t idx = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x;
+	if (idx >= static_cast<uint64_t>(n_rows) * ncols) {
+		return;
+	}
+	const uint32_t s = static_cast<uint32_t>(idx / ncols), c = static_cast<uint32_t>(idx % ncols);
+	if (!((mask2[s >> 2] >> (2 * (s & 3))) & 1u)) {
+		m[static_cast<uint64_t>(s) * stride + c] = 0.0;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_scale(double *__restrict__ m, uint64_t n, double f) {
+	const uint64_t idx = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x;
+	if (idx < n) {
+		m[idx] *= f;
 	}
 }
 
@@ -733,10 +850,10 @@ hipError_t LaunchScoreTables(const uint32_t *counts, const uint8_t *flip, uint32
 }
 
 template <int NCOLS>
-static hipError_t LaunchScoreAccumulateN(const RowView &view, const uint32_t *vlist, uint32_t n_scored,
-                                         const double *weights, const double *ts, const double *td,
-                                         const uint32_t *ac, double *score, double *dosage_sum, uint32_t *allele_ct,
-                                         hipStream_t stream) {
+static hipError_t LaunchAccumulateN(const RowView &view, const uint32_t *vlist, uint32_t n_scored,
+                                    const double *weights, uint32_t w_stride, const double *ts, const double *td,
+                                    const uint32_t *ac, double *score, uint32_t out_stride, double *dosage_sum,
+                                    uint32_t *allele_ct, hipStream_t stream) {
 	const uint32_t sample_blocks = (view.sample_ct + 255) / 256;
 	uint32_t want_slices = (2048 + sample_blocks - 1) / sample_blocks;
 	uint32_t slice_len = (n_scored + want_slices - 1) / want_slices;
@@ -747,36 +864,122 @@ static hipError_t LaunchScoreAccumulateN(const RowView &view, const uint32_t *vl
 		slice_len = (n_scored + slices - 1) / slices;
 	}
 	hipLaunchKernelGGL((k_score_accumulate<NCOLS>), dim3(sample_blocks, slices), dim3(256), 0, stream, view.rows,
-	                   view.pitch, view.sample_ct, vlist, n_scored, slice_len, weights, ts, td, ac, score, dosage_sum,
-	                   allele_ct);
+	                   view.pitch, view.sample_ct, vlist, n_scored, slice_len, weights, w_stride, out_stride, ts, td,
+	                   ac, score, dosage_sum, allele_ct);
 	return hipGetLastError();
+}
+
+hipError_t LaunchTableAccumulate(const RowView &view, const uint32_t *vlist, uint32_t n_var, const double *weights,
+                                 uint32_t w_stride, uint32_t n_cols, const double *ts, const double *td,
+                                 const uint32_t *ac, double *out, uint32_t out_stride, double *dosage_sum,
+                                 uint32_t *allele_ct, hipStream_t stream) {
+	if (n_var == 0) {
+		return hipSuccess;
+	}
+	// column blocks of 16/8/4/2/1; the per-sample extras ride on the first block only
+	uint32_t c0 = 0;
+	hipError_t e = hipSuccess;
+	while (c0 < n_cols && e == hipSuccess) {
+		const uint32_t left = n_cols - c0;
+		const double *td_b = c0 == 0 ? td : nullptr;
+		const uint32_t *ac_b = c0 == 0 ? ac : nullptr;
+		double *ds_b = c0 == 0 ? dosage_sum : nullptr;
+		uint32_t *al_b = c0 == 0 ? allele_ct : nullptr;
+		if (left >= 16) {
+			e = LaunchAccumulateN<16>(view, vlist, n_var, weights + c0, w_stride, ts, td_b, ac_b, out + c0, out_stride,
+			                          ds_b, al_b, stream);
+			c0 += 16;
+		} else if (left >= 8) {
+			e = LaunchAccumulateN<8>(view, vlist, n_var, weights + c0, w_stride, ts, td_b, ac_b, out + c0, out_stride,
+			                         ds_b, al_b, stream);
+			c0 += 8;
+		} else if (left >= 4) {
+			e = LaunchAccumulateN<4>(view, vlist, n_var, weights + c0, w_stride, ts, td_b, ac_b, out + c0, out_stride,
+			                         ds_b, al_b, stream);
+			c0 += 4;
+		} else if (left >= 2) {
+			e = LaunchAccumulateN<2>(view, vlist, n_var, weights + c0, w_stride, ts, td_b, ac_b, out + c0, out_stride,
+			                         ds_b, al_b, stream);
+			c0 += 2;
+		} else {
+			e = LaunchAccumulateN<1>(view, vlist, n_var, weights + c0, w_stride, ts, td_b, ac_b, out + c0, out_stride,
+			                         ds_b, al_b, stream);
+			c0 += 1;
+		}
+	}
+	return e;
 }
 
 hipError_t LaunchScoreAccumulate(const RowView &view, const uint32_t *vlist, uint32_t n_scored, const double *weights,
                                  uint32_t n_cols, const double *ts, const double *td, const uint32_t *ac,
                                  double *score, double *dosage_sum, uint32_t *allele_ct, hipStream_t stream) {
-	if (n_scored == 0) {
+	return LaunchTableAccumulate(view, vlist, n_scored, weights, n_cols, n_cols, ts, td, ac, score, n_cols, dosage_sum,
+	                             allele_ct, stream);
+}
+
+hipError_t LaunchNormTables(const double *center, const double *inv_stdev, uint32_t n, double *ts,
+                            hipStream_t stream) {
+	if (n == 0) {
 		return hipSuccess;
 	}
-	switch (n_cols) {
-	case 1:
-		return LaunchScoreAccumulateN<1>(view, vlist, n_scored, weights, ts, td, ac, score, dosage_sum, allele_ct,
-		                                 stream);
-	case 2:
-		return LaunchScoreAccumulateN<2>(view, vlist, n_scored, weights, ts, td, ac, score, dosage_sum, allele_ct,
-		                                 stream);
-	case 4:
-		return LaunchScoreAccumulateN<4>(view, vlist, n_scored, weights, ts, td, ac, score, dosage_sum, allele_ct,
-		                                 stream);
-	case 8:
-		return LaunchScoreAccumulateN<8>(view, vlist, n_scored, weights, ts, td, ac, score, dosage_sum, allele_ct,
-		                                 stream);
-	case 16:
-		return LaunchScoreAccumulateN<16>(view, vlist, n_scored, weights, ts, td, ac, score, dosage_sum, allele_ct,
-		                                  stream);
-	default:
-		return hipErrorInvalidValue;
+	hipLaunchKernelGGL(k_norm_tables, dim3((n + 255) / 256), dim3(256), 0, stream, center, inv_stdev, n, ts);
+	return hipGetLastError();
+}
+
+template <int NCOLS>
+static hipError_t LaunchVariantReduceN(const RowView &view, const uint32_t *vlist, uint32_t n_var, const double *ts,
+                                       const double *G, uint32_t g_stride, double *out, uint32_t out_stride,
+                                       hipStream_t stream) {
+	constexpr int VT = 8;
+	hipLaunchKernelGGL((k_variant_reduce<NCOLS, VT>), dim3((n_var + VT - 1) / VT), dim3(256), 0, stream, view.rows,
+	                   view.pitch, view.sample_ct, vlist, n_var, ts, G, g_stride, out, out_stride);
+	return hipGetLastError();
+}
+
+hipError_t LaunchVariantReduce(const RowView &view, const uint32_t *vlist, uint32_t n_var, const double *ts,
+                               const double *G, uint32_t g_stride, uint32_t n_cols, double *out, uint32_t out_stride,
+                               hipStream_t stream) {
+	if (n_var == 0) {
+		return hipSuccess;
 	}
+	uint32_t c0 = 0;
+	hipError_t e = hipSuccess;
+	while (c0 < n_cols && e == hipSuccess) {
+		const uint32_t left = n_cols - c0;
+		if (left >= 8) {
+			e = LaunchVariantReduceN<8>(view, vlist, n_var, ts, G + c0, g_stride, out + c0, out_stride, stream);
+			c0 += 8;
+		} else if (left >= 4) {
+			e = LaunchVariantReduceN<4>(view, vlist, n_var, ts, G + c0, g_stride, out + c0, out_stride, stream);
+			c0 += 4;
+		} else if (left >= 2) {
+			e = LaunchVariantReduceN<2>(view, vlist, n_var, ts, G + c0, g_stride, out + c0, out_stride, stream);
+			c0 += 2;
+		} else {
+			e = LaunchVariantReduceN<1>(view, vlist, n_var, ts, G + c0, g_stride, out + c0, out_stride, stream);
+			c0 += 1;
+		}
+	}
+	return e;
+}
+
+hipError_t LaunchMaskRows(double *m, uint32_t n_rows, uint32_t stride, uint32_t n_cols, const uint8_t *mask2,
+                          hipStream_t stream) {
+	const uint64_t total = static_cast<uint64_t>(n_rows) * n_cols;
+	if (total == 0 || !mask2) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_mask_rows, dim3(static_cast<uint32_t>((total + 255) / 256)), dim3(256), 0, stream, m, n_rows,
+	                   stride, n_cols, mask2);
+	return hipGetLastError();
+}
+
+hipError_t LaunchScale(double *m, uint64_t n, double f, hipStream_t stream) {
+	if (n == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_scale, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, stream, m, n, f);
+	return hipGetLastError();
 }
 
 hipError_t LaunchHweBatch(const uint32_t *counts, uint32_t n, uint32_t midp, double *ln_p, hipStream_t stream) {

@@ -65,6 +65,26 @@ hipError_t LaunchScoreAccumulate(const RowView &view, const uint32_t *vlist, uin
                                  uint32_t n_cols, const double *ts, const double *td, const uint32_t *ac,
                                  double *score, double *dosage_sum, uint32_t *allele_ct, hipStream_t stream);
 
+// General form: out[s*out_stride + c] += sum_i weights[i*w_stride + c] * ts[i][g(i,s)]
+// for any n_cols (split into column blocks); td/ac/dosage_sum/allele_ct may be NULL.
+hipError_t LaunchTableAccumulate(const RowView &view, const uint32_t *vlist, uint32_t n_var, const double *weights,
+                                 uint32_t w_stride, uint32_t n_cols, const double *ts, const double *td,
+                                 const uint32_t *ac, double *out, uint32_t out_stride, double *dosage_sum,
+                                 uint32_t *allele_ct, hipStream_t stream);
+
+// ---- plink_pca ----------------------------------------------------------------
+// ts[i] = {(0-c)is, (1-c)is, (2-c)is, 0} (NormalizeGenotypes)
+hipError_t LaunchNormTables(const double *center, const double *inv_stdev, uint32_t n, double *ts,
+                            hipStream_t stream);
+// out[i*out_stride + c] = sum_s ts[i][g(i,s)] * G[s*g_stride + c]
+hipError_t LaunchVariantReduce(const RowView &view, const uint32_t *vlist, uint32_t n_var, const double *ts,
+                               const double *G, uint32_t g_stride, uint32_t n_cols, double *out, uint32_t out_stride,
+                               hipStream_t stream);
+// zero the rows of samples whose slot in mask2 is clear
+hipError_t LaunchMaskRows(double *m, uint32_t n_rows, uint32_t stride, uint32_t n_cols, const uint8_t *mask2,
+                          hipStream_t stream);
+hipError_t LaunchScale(double *m, uint64_t n, double f, hipStream_t stream);
+
 // ---- HWE --------------------------------------------------------------------
 hipError_t LaunchHweBatch(const uint32_t *counts, uint32_t n, uint32_t midp, double *ln_p, hipStream_t stream);
 

@@ -1,0 +1,367 @@
+// extension.cpp -- registration of the six table functions (the reference's
+// LoadInternal, src/plinking_duck_extension.cpp:89-102) and a C entry point that
+// drives one of them through DuckDB's call protocol without DuckDB:
+//
+//   bind -> init_global -> MaxThreads() -> per thread { init_local; scan until 0 rows }
+//
+// pdk_query() is what the tests and embedders call; with DuckDB present the same
+// Register* functions are handed to its ExtensionLoader instead.
+#include "duck_api.hpp"
+#include "json.hpp"
+
+#include <algorithm>
+#include <mutex>
+#include <thread>
+
+namespace duckdb {
+
+void RegisterPgenReader(ExtensionLoader &loader);
+void RegisterPlinkFreq(ExtensionLoader &loader);
+void RegisterPlinkHardy(ExtensionLoader &loader);
+void RegisterPlinkMissing(ExtensionLoader &loader);
+void RegisterPlinkScore(ExtensionLoader &loader);
+void RegisterPlinkPca(ExtensionLoader &loader);
+
+static void LoadInternal(ExtensionLoader &loader) {
+	RegisterPgenReader(loader);
+	RegisterPlinkFreq(loader);
+	RegisterPlinkHardy(loader);
+	RegisterPlinkMissing(loader);
+	RegisterPlinkScore(loader);
+	RegisterPlinkPca(loader);
+}
+
+namespace {
+
+using pdkjson::Json;
+
+Value JsonToValue(const Json &j) {
+	switch (j.kind) {
+	case Json::NUL:
+		return Value();
+	case Json::BOOL:
+		return Value::BOOLEAN(j.b);
+	case Json::INT:
+		return Value::BIGINT(j.i);
+	case Json::DBL:
+		return Value::DOUBLE(j.d);
+	case Json::STR:
+		return Value::VARCHAR(j.s);
+	case Json::ARR: {
+		vector<Value> kids;
+		for (auto &e : j.arr) {
+			kids.push_back(JsonToValue(e));
+		}
+		LogicalType child = LogicalType::INTEGER;
+		bool any_double = false, all_numeric = !kids.empty();
+		for (auto &k : kids) {
+			auto id = k.type().id();
+			any_double |= id == LogicalTypeId::DOUBLE;
+			all_numeric &= id == LogicalTypeId::DOUBLE || id == LogicalTypeId::BIGINT;
+		}
+		if (!kids.empty()) {
+			child = (all_numeric && any_double) ? LogicalType(LogicalType::DOUBLE) : kids[0].type();
+		}
+		return Value::LIST(child, std::move(kids));
+	}
+	case Json::OBJ: {
+		vector<std::pair<string, Value>> fields;
+		for (auto &kv : j.obj) {
+			fields.emplace_back(kv.first, JsonToValue(kv.second));
+		}
+		return Value::STRUCT(std::move(fields));
+	}
+	}
+	return Value();
+}
+
+void CellToJson(string &out, Vector &v, idx_t row) {
+	if (!v.validity.RowIsValid(row)) {
+		out += "null";
+		return;
+	}
+	switch (v.type.id()) {
+	case LogicalTypeId::BOOLEAN:
+		out += FlatVector::GetData<int8_t>(v)[row] ? "true" : "false";
+		break;
+	case LogicalTypeId::TINYINT:
+		out += std::to_string(static_cast<int>(FlatVector::GetData<int8_t>(v)[row]));
+		break;
+	case LogicalTypeId::INTEGER:
+		out += std::to_string(FlatVector::GetData<int32_t>(v)[row]);
+		break;
+	case LogicalTypeId::UINTEGER:
+		out += std::to_string(FlatVector::GetData<uint32_t>(v)[row]);
+		break;
+	case LogicalTypeId::BIGINT:
+		out += std::to_string(FlatVector::GetData<int64_t>(v)[row]);
+		break;
+	case LogicalTypeId::DOUBLE:
+		pdkjson::DoubleTo(out, FlatVector::GetData<double>(v)[row]);
+		break;
+	case LogicalTypeId::VARCHAR:
+		pdkjson::EscapeTo(out, v.heap[FlatVector::GetData<string_t>(v)[row].index]);
+		break;
+	case LogicalTypeId::LIST: {
+		auto e = FlatVector::GetData<list_entry_t>(v)[row];
+		out += '[';
+		for (idx_t k = 0; k < e.length; k++) {
+			if (k) {
+				out += ',';
+			}
+			CellToJson(out, *v.children[0], e.offset + k);
+		}
+		out += ']';
+		break;
+	}
+	case LogicalTypeId::ARRAY: {
+		out += '[';
+		for (idx_t k = 0; k < v.type.array_size; k++) {
+			if (k) {
+				out += ',';
+			}
+			CellToJson(out, *v.children[0], row * v.type.array_size + k);
+		}
+		out += ']';
+		break;
+	}
+	case LogicalTypeId::STRUCT: {
+		out += '{';
+		for (size_t k = 0; k < v.children.size(); k++) {
+			if (k) {
+				out += ',';
+			}
+			pdkjson::EscapeTo(out, (*v.type.fields)[k].first);
+			out += ':';
+			CellToJson(out, *v.children[k], row);
+		}
+		out += '}';
+		break;
+	}
+	default:
+		out += "null";
+	}
+}
+
+string ErrorJson(const char *kind, const string &msg) {
+	string out = "{\"error\":{\"kind\":";
+	pdkjson::EscapeTo(out, kind);
+	out += ",\"message\":";
+	pdkjson::EscapeTo(out, msg);
+	out += "}}";
+	return out;
+}
+
+string RunQuery(const string &request) {
+	Json req = pdkjson::Parser(request).Parse();
+	ExtensionLoader loader;
+	LoadInternal(loader);
+	const Json *fn = req.Get("function");
+	if (!fn || fn->kind != Json::STR) {
+		return ErrorJson("Binder Error", "request needs a \"function\" name");
+	}
+	auto it = loader.functions.find(fn->s);
+	if (it == loader.functions.end()) {
+		return ErrorJson("Catalog Error", "Table Function with name " + fn->s + " does not exist!");
+	}
+	TableFunction &tf = it->second;
+
+	ClientContext context;
+	if (const Json *th = req.Get("threads")) {
+		context.db_threads = static_cast<idx_t>(std::max<long long>(1, th->i));
+	}
+	if (const Json *st = req.Get("settings")) {
+		for (auto &kv : st->obj) {
+			context.settings[kv.first] = JsonToValue(kv.second);
+		}
+	}
+	TableFunctionBindInput bind_input;
+	if (const Json *args = req.Get("args")) {
+		for (auto &a : args->arr) {
+			bind_input.inputs.push_back(JsonToValue(a));
+		}
+	}
+	if (bind_input.inputs.size() != tf.arguments.size()) {
+		return ErrorJson("Binder Error", "No function matches the given name and argument types '" + tf.name + "()'");
+	}
+	if (const Json *named = req.Get("named")) {
+		for (auto &kv : named->obj) {
+			if (!tf.named_parameters.count(kv.first)) {
+				return ErrorJson("Binder Error",
+				                 "Invalid named parameter \"" + kv.first + "\" for function " + tf.name);
+			}
+			bind_input.named_parameters[kv.first] = JsonToValue(kv.second);
+		}
+	}
+
+	vector<LogicalType> return_types;
+	vector<string> names;
+	auto bind_data = tf.bind(context, bind_input, return_types, names);
+
+	// projection pushdown: "columns": [names] or absent for all
+	TableFunctionInitInput init_input;
+	init_input.bind_data = bind_data.get();
+	vector<idx_t> projected;
+	if (const Json *cols = req.Get("columns")) {
+		for (auto &c : cols->arr) {
+			auto pos = std::find(names.begin(), names.end(), c.s);
+			if (pos == names.end()) {
+				return ErrorJson("Binder Error", "Referenced column \"" + c.s + "\" not found in FROM clause!");
+			}
+			projected.push_back(static_cast<idx_t>(pos - names.begin()));
+		}
+	} else {
+		for (idx_t i = 0; i < names.size(); i++) {
+			projected.push_back(i);
+		}
+	}
+	init_input.column_ids.assign(projected.begin(), projected.end());
+	vector<LogicalType> out_types;
+	for (auto c : projected) {
+		out_types.push_back(return_types[c]);
+	}
+
+	auto gstate = tf.init_global(context, init_input);
+	idx_t n_threads = std::max<idx_t>(1, std::min<idx_t>(gstate->MaxThreads(), context.db_threads));
+
+	std::mutex result_mutex;
+	vector<string> row_chunks;
+	idx_t total_rows = 0;
+	string first_error, first_error_kind;
+	auto worker = [&]() {
+		try {
+			ExecutionContext exec {context};
+			auto lstate = tf.init_local(exec, init_input, gstate.get());
+			TableFunctionInput in;
+			in.bind_data = bind_data.get();
+			in.global_state = gstate.get();
+			in.local_state = lstate.get();
+			DataChunk chunk;
+			chunk.Initialize(out_types);
+			while (true) {
+				chunk.Reset();
+				tf.function(context, in, chunk);
+				if (chunk.size() == 0) {
+					break; // DuckDB marks the thread FINISHED on an empty chunk
+				}
+				string rows;
+				for (idx_t r = 0; r < chunk.size(); r++) {
+					rows += rows.empty() ? "[" : ",[";
+					for (size_t c = 0; c < chunk.data.size(); c++) {
+						if (c) {
+							rows += ',';
+						}
+						CellToJson(rows, chunk.data[c], r);
+					}
+					rows += ']';
+				}
+				std::lock_guard<std::mutex> lock(result_mutex);
+				total_rows += chunk.size();
+				row_chunks.push_back(std::move(rows));
+			}
+		} catch (const InvalidInputException &e) {
+			std::lock_guard<std::mutex> lock(result_mutex);
+			if (first_error.empty()) {
+				first_error = e.what();
+				first_error_kind = InvalidInputException::Kind();
+			}
+		} catch (const IOException &e) {
+			std::lock_guard<std::mutex> lock(result_mutex);
+			if (first_error.empty()) {
+				first_error = e.what();
+				first_error_kind = IOException::Kind();
+			}
+		} catch (const std::exception &e) {
+			std::lock_guard<std::mutex> lock(result_mutex);
+			if (first_error.empty()) {
+				first_error = e.what();
+				first_error_kind = InternalException::Kind();
+			}
+		}
+	};
+	vector<std::thread> threads;
+	for (idx_t t = 1; t < n_threads; t++) {
+		threads.emplace_back(worker);
+	}
+	worker();
+	for (auto &t : threads) {
+		t.join();
+	}
+	if (!first_error.empty()) {
+		return ErrorJson(first_error_kind.c_str(), first_error);
+	}
+
+	string out = "{\"names\":[";
+	for (size_t i = 0; i < projected.size(); i++) {
+		if (i) {
+			out += ',';
+		}
+		pdkjson::EscapeTo(out, names[projected[i]]);
+	}
+	out += "],\"types\":[";
+	for (size_t i = 0; i < projected.size(); i++) {
+		if (i) {
+			out += ',';
+		}
+		pdkjson::EscapeTo(out, out_types[i].ToString());
+	}
+	out += "],\"all_names\":[";
+	for (size_t i = 0; i < names.size(); i++) {
+		if (i) {
+			out += ',';
+		}
+		pdkjson::EscapeTo(out, names[i]);
+	}
+	out += "],\"threads\":" + std::to_string(n_threads) + ",\"row_count\":" + std::to_string(total_rows) + ",\"rows\":[";
+	bool first = true;
+	for (auto &rc : row_chunks) {
+		if (!first) {
+			out += ',';
+		}
+		out += rc;
+		first = false;
+	}
+	out += "]}";
+	return out;
+}
+
+} // namespace
+} // namespace duckdb
+
+extern "C" {
+
+// Run one table function call described in JSON; returns a malloc'ed JSON result
+// (free with pdk_free).  Never throws: errors come back as {"error": {...}}.
+char *pdk_query(const char *request_json) {
+	std::string out;
+	try {
+		out = duckdb::RunQuery(request_json ? request_json : "");
+	} catch (const duckdb::InvalidInputException &e) {
+		out = duckdb::ErrorJson(duckdb::InvalidInputException::Kind(), e.what());
+	} catch (const duckdb::IOException &e) {
+		out = duckdb::ErrorJson(duckdb::IOException::Kind(), e.what());
+	} catch (const std::exception &e) {
+		out = duckdb::ErrorJson("Error", e.what());
+	}
+	char *buf = static_cast<char *>(std::malloc(out.size() + 1));
+	std::memcpy(buf, out.c_str(), out.size() + 1);
+	return buf;
+}
+
+void pdk_free(char *p) {
+	std::free(p);
+}
+
+// Names of the registered table functions, comma separated (static storage).
+const char *pdk_functions(void) {
+	static std::string names;
+	if (names.empty()) {
+		duckdb::ExtensionLoader loader;
+		duckdb::LoadInternal(loader);
+		for (auto &kv : loader.functions) {
+			names += (names.empty() ? "" : ",") + kv.first;
+		}
+	}
+	return names.c_str();
+}
+}

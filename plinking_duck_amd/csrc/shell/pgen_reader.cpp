@@ -1,0 +1,414 @@
+// pgen_reader.cpp -- read_pgen(path, pvar, psam, samples, genotypes, dosages, phased,
+//                               af_range, ac_range, include_genotypes, genotype_range, orient)
+//
+// Surface of the reference's src/pgen_reader.cpp for the variant-oriented
+// genotype column: ARRAY/LIST(TINYINT) hardcalls (missing -> NULL element),
+// dosages, phased pairs, and the counts / stats aggregate structs.  Per chunk
+// the hardcall path is one 2-bit -> int8 unpack launch (pgh_unpack_range) over
+// the claimed variants instead of PgrGet + GenoarrToBytesMinus9 + a scalar
+// per-sample copy (src/pgen_reader.cpp:727-733, 1009-1047).  Dosage and phase
+// tracks are decoded per variant through the reader calls.
+// Not carried over: genotypes := 'columns' / 'struct' and the `variants`
+// parameter (metadata plumbing outside the hot path).
+#include "variant_scan.hpp"
+
+#include <cmath>
+#include <limits>
+
+namespace duckdb {
+
+static constexpr idx_t COL_GENOTYPES = 5;
+static constexpr uint32_t kUnpackSpan = 2048; // variants unpacked per launch (one output vector)
+
+struct PgenBindData : public TableFunctionData {
+	PgenBindCommon c;
+	bool include_dosages = false;
+	bool include_phased = false;
+	GenotypeMode genotype_mode = GenotypeMode::ARRAY;
+	CountFilter count_filter;
+	GenotypeRangeFilter genotype_filter;
+	uint32_t output_sample_ct = 0;
+};
+
+struct PgenGlobalState : public GlobalTableFunctionState {
+	VariantScanGlobal scan;
+	vector<column_t> column_ids;
+	bool need_genotypes = false;
+	bool need_counts = false;
+	uint32_t max_threads_config = 0;
+	idx_t MaxThreads() const override {
+		uint32_t total = scan.end_variant_idx - scan.start_variant_idx;
+		return ApplyMaxThreadsCap(total / 1000 + 1, max_threads_config);
+	}
+};
+
+struct PgenLocalState : public LocalTableFunctionState {
+	VariantScanLocal scan;
+	pgh_reader *reader = nullptr;
+	vector<int8_t> bytes;       // unpacked span [rows][n_out]
+	vector<uint64_t> validity;  // [rows][ceil(n_out/64)]
+	vector<double> dosage_doubles;
+	vector<uint64_t> genovec, phasepresent, phaseinfo;
+	~PgenLocalState() override {
+		if (reader) {
+			pgh_reader_destroy(reader);
+		}
+	}
+};
+
+static unique_ptr<FunctionData> PgenBind(ClientContext &context, TableFunctionBindInput &input,
+                                         vector<LogicalType> &return_types, vector<string> &names) {
+	auto bind_data = make_uniq<PgenBindData>();
+	for (auto &kv : input.named_parameters) {
+		if (kv.first == "dosages") {
+			bind_data->include_dosages = kv.second.GetValue<bool>();
+		} else if (kv.first == "phased") {
+			bind_data->include_phased = kv.second.GetValue<bool>();
+		} else if (kv.first == "orient") {
+			auto v = kv.second.GetValue<string>();
+			string lower = v;
+			for (auto &ch : lower) {
+				ch = static_cast<char>(std::tolower(static_cast<unsigned char>(ch)));
+			}
+			if (lower != "variant") {
+				throw InvalidInputException("read_pgen: orient := '%s' is not supported "
+				                            "(read_pgen only supports orient := 'variant'; "
+				                            "use read_pfile for orient := 'genotype' or 'sample')",
+				                            v);
+			}
+		} else if (kv.first == "variants" || kv.first == "region") {
+			throw InvalidInputException("read_pgen: the '%s' parameter is not available in this build", kv.first);
+		}
+	}
+	if (bind_data->include_dosages && bind_data->include_phased) {
+		throw InvalidInputException("read_pgen: dosages and phased cannot both be true");
+	}
+	auto &c = bind_data->c;
+	c.Bind(context, input, "read_pgen", false);
+	uint32_t output_sample_ct = c.effective_sample_ct;
+	bind_data->output_sample_ct = output_sample_ct;
+
+	auto af_it = input.named_parameters.find("af_range");
+	if (af_it != input.named_parameters.end()) {
+		bind_data->count_filter.af_filter = ParseRangeFilter(af_it->second, "af_range", 0.0, 1.0, "read_pgen");
+	}
+	auto ac_it = input.named_parameters.find("ac_range");
+	if (ac_it != input.named_parameters.end()) {
+		bind_data->count_filter.ac_filter =
+		    ParseRangeFilter(ac_it->second, "ac_range", 0.0, static_cast<double>(2 * output_sample_ct), "read_pgen");
+	}
+	auto ig_it = input.named_parameters.find("include_genotypes");
+	auto gr_it = input.named_parameters.find("genotype_range");
+	bool has_ig = ig_it != input.named_parameters.end();
+	bool has_gr = gr_it != input.named_parameters.end();
+	if (has_ig && has_gr) {
+		throw InvalidInputException(
+		    "read_pgen: specify only one of include_genotypes or genotype_range (genotype_range is the numeric "
+		    "alias of include_genotypes)");
+	}
+	if ((has_ig || has_gr) && bind_data->include_dosages) {
+		throw InvalidInputException("read_pgen: %s is incompatible with dosages := true",
+		                            has_ig ? "include_genotypes" : "genotype_range");
+	}
+	if (has_ig) {
+		ParseIncludeGenotypes(ig_it->second, bind_data->genotype_filter, "read_pgen");
+	} else if (has_gr) {
+		bool inc_missing = false;
+		RangeFilter range = ParseRangeFilter(gr_it->second, "genotype_range", 0.0, 2.0, "read_pgen", &inc_missing);
+		bind_data->genotype_filter.SetFromRange(range, inc_missing);
+	}
+
+	string genotypes_str = "auto";
+	auto genotypes_it = input.named_parameters.find("genotypes");
+	if (genotypes_it != input.named_parameters.end()) {
+		genotypes_str = genotypes_it->second.GetValue<string>();
+	}
+	bind_data->genotype_mode = ResolveGenotypeMode(genotypes_str, output_sample_ct, "read_pgen");
+	if (IsAggregateGenotypeMode(bind_data->genotype_mode)) {
+		const char *label = bind_data->genotype_mode == GenotypeMode::COUNTS ? "counts" : "stats";
+		if (bind_data->include_phased) {
+			throw InvalidInputException("read_pgen: genotypes := '%s' is incompatible with phased := true", label);
+		}
+		if (bind_data->include_dosages) {
+			throw InvalidInputException("read_pgen: genotypes := '%s' is incompatible with dosages := true", label);
+		}
+	}
+	if (bind_data->genotype_mode == GenotypeMode::COLUMNS || bind_data->genotype_mode == GenotypeMode::STRUCT) {
+		throw InvalidInputException("read_pgen: genotypes := '%s' is not available in this build "
+		                            "(use 'array', 'list', 'counts' or 'stats')",
+		                            genotypes_str);
+	}
+
+	names = {"CHROM", "POS", "ID", "REF", "ALT", "genotypes"};
+	return_types = {LogicalType::VARCHAR, LogicalType::INTEGER, LogicalType::VARCHAR, LogicalType::VARCHAR,
+	                LogicalType::VARCHAR};
+	if (bind_data->genotype_mode == GenotypeMode::COUNTS) {
+		return_types.push_back(MakeGenotypeCountsType());
+	} else if (bind_data->genotype_mode == GenotypeMode::STATS) {
+		return_types.push_back(MakeGenotypeStatsType());
+	} else {
+		LogicalType elem_type = bind_data->include_phased    ? LogicalType::ARRAY(LogicalType::TINYINT, 2)
+		                        : bind_data->include_dosages ? LogicalType(LogicalType::DOUBLE)
+		                                                     : LogicalType(LogicalType::TINYINT);
+		return_types.push_back(bind_data->genotype_mode == GenotypeMode::ARRAY
+		                           ? LogicalType::ARRAY(elem_type, output_sample_ct)
+		                           : LogicalType::LIST(elem_type));
+	}
+	return std::move(bind_data);
+}
+
+static unique_ptr<GlobalTableFunctionState> PgenInitGlobal(ClientContext &context, TableFunctionInitInput &input) {
+	auto &bind_data = input.bind_data->Cast<PgenBindData>();
+	auto state = make_uniq<PgenGlobalState>();
+	state->scan.start_variant_idx = 0;
+	state->scan.end_variant_idx = bind_data.c.raw_variant_ct;
+	state->scan.effective_sample_ct = bind_data.c.effective_sample_ct;
+	state->column_ids = input.column_ids;
+	state->max_threads_config = GetPlinkingMaxThreads(context);
+	for (auto col_id : input.column_ids) {
+		if (col_id == COL_GENOTYPES) {
+			state->need_genotypes = true;
+		}
+	}
+	state->need_counts = bind_data.count_filter.HasFilter() || bind_data.genotype_filter.active ||
+	                     (state->need_genotypes && IsAggregateGenotypeMode(bind_data.genotype_mode));
+	state->scan.want_counts = state->need_counts;
+	if (state->need_genotypes || state->need_counts) {
+		state->scan.dataset = DeviceDataset::Acquire(bind_data.c.pgen_path, "read_pgen");
+		if (bind_data.c.has_sample_subset) {
+			state->scan.subset =
+			    make_uniq<DeviceSubset>(*state->scan.dataset, bind_data.c.sample_subset->sample_include, "read_pgen");
+		}
+	}
+	return std::move(state);
+}
+
+static unique_ptr<LocalTableFunctionState> PgenInitLocal(ExecutionContext &, TableFunctionInitInput &input,
+                                                         GlobalTableFunctionState *global_state) {
+	auto &bind_data = input.bind_data->Cast<PgenBindData>();
+	auto &gstate = global_state->Cast<PgenGlobalState>();
+	auto state = make_uniq<PgenLocalState>();
+	if (gstate.need_genotypes && (bind_data.include_dosages || bind_data.include_phased)) {
+		char errbuf[PGH_ERRBUF_LEN] = {0};
+		int rc = pgh_reader_create(gstate.scan.dataset->handle, gstate.scan.subset ? gstate.scan.subset->handle : nullptr,
+		                           &state->reader, errbuf);
+		if (rc != PGH_OK) {
+			throw IOException("read_pgen: thread init failed: %s", string(errbuf));
+		}
+		uint32_t n = bind_data.output_sample_ct;
+		state->dosage_doubles.resize(n);
+		state->genovec.resize((n + 31) / 32);
+		state->phasepresent.resize((n + 63) / 64);
+		state->phaseinfo.resize((n + 63) / 64);
+	}
+	return std::move(state);
+}
+
+namespace {
+
+struct RowPlan {
+	uint32_t vidx;
+	bool geno_range_all_pass;
+};
+
+// child element slot for row `row`: ARRAY rows are fixed stride, LIST rows append
+idx_t BeginGenotypeRow(const PgenBindData &bind_data, Vector &vec, idx_t row, uint32_t n) {
+	if (bind_data.genotype_mode == GenotypeMode::ARRAY) {
+		return row * n;
+	}
+	idx_t offset = ListVector::GetListSize(vec);
+	ListVector::Reserve(vec, offset + n);
+	auto *entries = FlatVector::GetData<list_entry_t>(vec);
+	entries[row].offset = offset;
+	entries[row].length = n;
+	ListVector::SetListSize(vec, offset + n);
+	return offset;
+}
+
+Vector &GenotypeChild(const PgenBindData &bind_data, Vector &vec) {
+	return bind_data.genotype_mode == GenotypeMode::ARRAY ? ArrayVector::GetEntry(vec) : ListVector::GetEntry(vec);
+}
+
+} // namespace
+
+static void PgenScan(ClientContext &, TableFunctionInput &data_p, DataChunk &output) {
+	auto &bind_data = data_p.bind_data->Cast<PgenBindData>();
+	auto &gstate = data_p.global_state->Cast<PgenGlobalState>();
+	auto &lstate = data_p.local_state->Cast<PgenLocalState>();
+	auto &column_ids = gstate.column_ids;
+	const uint32_t n = bind_data.output_sample_ct;
+	const bool plain_hardcalls = gstate.need_genotypes && !IsAggregateGenotypeMode(bind_data.genotype_mode) &&
+	                             !bind_data.include_dosages && !bind_data.include_phased;
+	auto no_strata = [](uint32_t, uint32_t) { return false; };
+
+	// 1. choose the variants of this chunk (filters run off the batched tallies)
+	vector<RowPlan> plan;
+	plan.reserve(STANDARD_VECTOR_SIZE);
+	uint32_t vidx = 0;
+	while (plan.size() < STANDARD_VECTOR_SIZE) {
+		if (!plan.empty() && vidx + 1 - plan.front().vidx >= kUnpackSpan) {
+			break; // keep the unpack span bounded; the next Scan call continues
+		}
+		if (!lstate.scan.Next(gstate.scan, "read_pgen", no_strata, vidx)) {
+			break;
+		}
+		bool all_pass = true;
+		if (bind_data.count_filter.HasFilter() || bind_data.genotype_filter.active) {
+			auto pf = CheckPreDecompFilters(bind_data.count_filter, bind_data.genotype_filter, lstate.scan.Counts(vidx),
+			                                n);
+			if (pf.skip) {
+				continue;
+			}
+			all_pass = pf.all_pass;
+		}
+		plan.push_back({vidx, all_pass});
+	}
+	if (plan.empty()) {
+		CompatSetOutputCardinality(output, 0);
+		return;
+	}
+
+	// 2. one unpack launch for the span the chunk covers
+	const uint32_t span_begin = plan.front().vidx;
+	const uint32_t span_end = plan.back().vidx + 1;
+	const size_t val_words = (n + 63) / 64;
+	if (plain_hardcalls) {
+		lstate.bytes.resize(static_cast<size_t>(span_end - span_begin) * n);
+		lstate.validity.resize(static_cast<size_t>(span_end - span_begin) * val_words);
+		char errbuf[PGH_ERRBUF_LEN] = {0};
+		int rc = pgh_unpack_range(gstate.scan.dataset->handle, gstate.scan.subset ? gstate.scan.subset->handle : nullptr,
+		                          span_begin, span_end, lstate.bytes.data(), lstate.validity.data(), 0, errbuf);
+		if (rc != PGH_OK) {
+			throw IOException("read_pgen: PgrGet failed for variants [%u, %u): %s", span_begin, span_end,
+			                  string(errbuf));
+		}
+	}
+
+	// 3. fill the projected columns
+	for (idx_t row = 0; row < plan.size(); row++) {
+		const uint32_t v = plan[row].vidx;
+		for (idx_t out_col = 0; out_col < column_ids.size(); out_col++) {
+			auto file_col = column_ids[out_col];
+			if (file_col == COLUMN_IDENTIFIER_ROW_ID) {
+				continue;
+			}
+			auto &vec = output.data[out_col];
+			if (FillVariantMetadataColumn(bind_data.c.variants, file_col, v, vec, row)) {
+				continue;
+			}
+			if (file_col != COL_GENOTYPES) {
+				continue;
+			}
+			if (IsAggregateGenotypeMode(bind_data.genotype_mode)) {
+				const uint32_t *gc = lstate.scan.Counts(v);
+				auto &entries = StructVector::GetEntries(vec);
+				for (int k = 0; k < 4; k++) {
+					FlatVector::GetData<uint32_t>(*entries[k])[row] = gc[k];
+				}
+				if (bind_data.genotype_mode == GenotypeMode::STATS) {
+					const double nan = std::numeric_limits<double>::quiet_NaN();
+					uint32_t nn = gc[0] + gc[1] + gc[2];
+					uint32_t total = nn + gc[3];
+					FlatVector::GetData<uint32_t>(*entries[4])[row] = nn;
+					double af = nn ? (static_cast<double>(gc[1]) + 2.0 * gc[2]) / (2.0 * nn) : nan;
+					FlatVector::GetData<double>(*entries[5])[row] = af;
+					FlatVector::GetData<double>(*entries[6])[row] = nn ? std::min(af, 1.0 - af) : nan;
+					FlatVector::GetData<double>(*entries[7])[row] =
+					    total ? static_cast<double>(gc[3]) / static_cast<double>(total) : nan;
+					FlatVector::GetData<uint32_t>(*entries[8])[row] = gc[1] + gc[2];
+					FlatVector::GetData<double>(*entries[9])[row] =
+					    nn ? static_cast<double>(gc[1]) / static_cast<double>(nn) : nan;
+				}
+				continue;
+			}
+			const idx_t base = BeginGenotypeRow(bind_data, vec, row, n);
+			Vector &child = GenotypeChild(bind_data, vec);
+			auto &child_validity = FlatVector::Validity(child);
+			if (bind_data.include_dosages) {
+				if (pgh_get_dosage_f64(lstate.reader, v, lstate.dosage_doubles.data()) != PGH_OK) {
+					throw IOException("read_pgen: PgrGetD failed for variant %u: %s", v,
+					                  string(pgh_reader_error(lstate.reader)));
+				}
+				auto *dst = FlatVector::GetData<double>(child);
+				for (uint32_t s = 0; s < n; s++) {
+					double d = lstate.dosage_doubles[s];
+					if (d == -9.0) {
+						child_validity.SetInvalid(base + s);
+						dst[base + s] = 0.0;
+					} else {
+						dst[base + s] = d;
+					}
+				}
+			} else if (bind_data.include_phased) {
+				if (pgh_get_phased(lstate.reader, v, lstate.genovec.data(), lstate.phasepresent.data(),
+				                   lstate.phaseinfo.data()) != PGH_OK) {
+					throw IOException("read_pgen: PgrGetP failed for variant %u: %s", v,
+					                  string(pgh_reader_error(lstate.reader)));
+				}
+				// UnpackPhasedGenotypes (src/plink_common.cpp:1549-1584): child = ARRAY(TINYINT, 2)
+				Vector &pair = ArrayVector::GetEntry(child);
+				auto *dst = FlatVector::GetData<int8_t>(pair);
+				for (uint32_t s = 0; s < n; s++) {
+					uint32_t code = (lstate.genovec[s >> 5] >> (2 * (s & 31))) & 3u;
+					bool ignore = bind_data.genotype_filter.active && !plan[row].geno_range_all_pass &&
+					              !bind_data.genotype_filter.AllowsCall(static_cast<double>(code));
+					int8_t a0 = 0, a1 = 0;
+					if (code == 3 || ignore) {
+						child_validity.SetInvalid(base + s);
+					} else if (code == 2) {
+						a0 = a1 = 1;
+					} else if (code == 1) {
+						bool alt_first = ((lstate.phasepresent[s >> 6] >> (s & 63)) & 1ull) &&
+						                 ((lstate.phaseinfo[s >> 6] >> (s & 63)) & 1ull);
+						a0 = alt_first ? 1 : 0;
+						a1 = alt_first ? 0 : 1;
+					}
+					dst[2 * (base + s)] = a0;
+					dst[2 * (base + s) + 1] = a1;
+				}
+			} else {
+				const int8_t *src = lstate.bytes.data() + static_cast<size_t>(v - span_begin) * n;
+				const uint64_t *val = lstate.validity.data() + static_cast<size_t>(v - span_begin) * val_words;
+				auto *dst = FlatVector::GetData<int8_t>(child);
+				std::memcpy(dst + base, src, n); // missing calls are already stored as 0
+				const bool null_out = bind_data.genotype_filter.active && !plan[row].geno_range_all_pass;
+				for (size_t w = 0; w < val_words; w++) {
+					uint64_t bits = val[w];
+					const uint32_t lim = static_cast<uint32_t>(std::min<size_t>(64, n - w * 64));
+					const uint64_t full = lim == 64 ? ~0ull : ((1ull << lim) - 1);
+					if (!null_out && (bits & full) == full) {
+						continue;
+					}
+					for (uint32_t b = 0; b < lim; b++) {
+						const uint32_t s = static_cast<uint32_t>(w * 64 + b);
+						if (!((bits >> b) & 1ull) ||
+						    (null_out && !bind_data.genotype_filter.AllowsCall(static_cast<double>(src[s])))) {
+							child_validity.SetInvalid(base + s);
+							dst[base + s] = 0;
+						}
+					}
+				}
+			}
+		}
+	}
+	CompatSetOutputCardinality(output, plan.size());
+}
+
+void RegisterPgenReader(ExtensionLoader &loader) {
+	TableFunction read_pgen("read_pgen", {LogicalType::VARCHAR}, PgenScan, PgenBind, PgenInitGlobal, PgenInitLocal);
+	read_pgen.projection_pushdown = true;
+	read_pgen.named_parameters["pvar"] = LogicalType::VARCHAR;
+	read_pgen.named_parameters["psam"] = LogicalType::VARCHAR;
+	read_pgen.named_parameters["dosages"] = LogicalType::BOOLEAN;
+	read_pgen.named_parameters["phased"] = LogicalType::BOOLEAN;
+	read_pgen.named_parameters["samples"] = LogicalType::ANY;
+	read_pgen.named_parameters["genotypes"] = LogicalType::VARCHAR;
+	read_pgen.named_parameters["orient"] = LogicalType::VARCHAR;
+	read_pgen.named_parameters["af_range"] = LogicalType::ANY;
+	read_pgen.named_parameters["ac_range"] = LogicalType::ANY;
+	read_pgen.named_parameters["genotype_range"] = LogicalType::ANY;
+	read_pgen.named_parameters["include_genotypes"] = LogicalType::LIST(LogicalType::VARCHAR);
+	loader.RegisterFunction(read_pgen);
+}
+
+} // namespace duckdb

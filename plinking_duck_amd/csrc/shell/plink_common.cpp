@@ -1,0 +1,866 @@
+// plink_common.cpp -- see plink_common.hpp.
+#include "plink_common.hpp"
+
+#include <algorithm>
+#include <cerrno>
+#include <cmath>
+#include <cstdlib>
+#include <fstream>
+#include <limits>
+#include <sstream>
+#include <sys/stat.h>
+#include <unordered_set>
+
+namespace duckdb {
+
+namespace {
+
+string Lower(string s) {
+	for (auto &c : s) {
+		c = static_cast<char>(std::tolower(static_cast<unsigned char>(c)));
+	}
+	return s;
+}
+
+string Trim(const string &s) {
+	size_t a = 0, b = s.size();
+	while (a < b && std::isspace(static_cast<unsigned char>(s[a]))) {
+		a++;
+	}
+	while (b > a && std::isspace(static_cast<unsigned char>(s[b - 1]))) {
+		b--;
+	}
+	return s.substr(a, b - a);
+}
+
+string ReplaceExtension(const string &path, const string &ext) {
+	auto slash = path.find_last_of('/');
+	auto dot = path.find_last_of('.');
+	if (dot == string::npos || (slash != string::npos && dot < slash)) {
+		return path + ext;
+	}
+	return path.substr(0, dot) + ext;
+}
+
+bool ReadWholeFile(const string &path, string &out) {
+	std::ifstream f(path, std::ios::binary);
+	if (!f) {
+		return false;
+	}
+	std::ostringstream ss;
+	ss << f.rdbuf();
+	out = ss.str();
+	return true;
+}
+
+// split on tabs (.pvar/.psam) or runs of blanks (.bim/.fam)
+vector<string> SplitFields(const string &line, bool whitespace) {
+	vector<string> out;
+	if (!whitespace) {
+		size_t start = 0;
+		while (true) {
+			size_t tab = line.find('\t', start);
+			if (tab == string::npos) {
+				out.push_back(line.substr(start));
+				break;
+			}
+			out.push_back(line.substr(start, tab - start));
+			start = tab + 1;
+		}
+		return out;
+	}
+	size_t i = 0;
+	while (i < line.size()) {
+		while (i < line.size() && (line[i] == ' ' || line[i] == '\t')) {
+			i++;
+		}
+		size_t j = i;
+		while (j < line.size() && line[j] != ' ' && line[j] != '\t') {
+			j++;
+		}
+		if (j > i) {
+			out.push_back(line.substr(i, j - i));
+		}
+		i = j;
+	}
+	return out;
+}
+
+vector<string> Lines(const string &content) {
+	vector<string> out;
+	size_t pos = 0;
+	while (pos < content.size()) {
+		size_t nl = content.find('\n', pos);
+		if (nl == string::npos) {
+			nl = content.size();
+		}
+		size_t end = nl;
+		if (end > pos && content[end - 1] == '\r') {
+			end--;
+		}
+		out.push_back(content.substr(pos, end - pos));
+		pos = nl + 1;
+	}
+	return out;
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------
+// files
+// ---------------------------------------------------------------------------
+
+bool FileExists(const string &path) {
+	struct stat st;
+	return ::stat(path.c_str(), &st) == 0 && S_ISREG(st.st_mode);
+}
+
+string FindCompanionFile(const string &pgen_path, const vector<string> &extensions) {
+	for (auto &ext : extensions) {
+		auto candidate = ReplaceExtension(pgen_path, ext);
+		if (FileExists(candidate)) {
+			return candidate;
+		}
+	}
+	return "";
+}
+
+// ---------------------------------------------------------------------------
+// variant metadata
+// ---------------------------------------------------------------------------
+
+VariantMetadataIndex LoadVariantMetadata(ClientContext &, const string &path, const string &func_name) {
+	string content;
+	if (!ReadWholeFile(path, content)) {
+		throw IOException("%s: cannot open .pvar/.bim file '%s'", func_name, path);
+	}
+	if (content.empty()) {
+		throw InvalidInputException("%s: .pvar/.bim file '%s' is empty", func_name, path);
+	}
+	VariantMetadataIndex idx;
+	auto lines = Lines(content);
+	size_t li = 0;
+	while (li < lines.size() && (lines[li].empty() || lines[li].compare(0, 2, "##") == 0)) {
+		li++;
+	}
+	if (li >= lines.size()) {
+		throw InvalidInputException("%s: .pvar/.bim file '%s' contains no header or data", func_name, path);
+	}
+	constexpr size_t kNone = static_cast<size_t>(-1);
+	size_t chrom_f = kNone, pos_f = kNone, id_f = kNone, ref_f = kNone, alt_f = kNone;
+	if (lines[li].compare(0, 6, "#CHROM") == 0) {
+		auto fields = SplitFields(lines[li].substr(1), false);
+		for (size_t i = 0; i < fields.size(); i++) {
+			if (fields[i] == "CHROM") {
+				chrom_f = i;
+			} else if (fields[i] == "POS") {
+				pos_f = i;
+			} else if (fields[i] == "ID") {
+				id_f = i;
+			} else if (fields[i] == "REF") {
+				ref_f = i;
+			} else if (fields[i] == "ALT") {
+				alt_f = i;
+			}
+		}
+		li++;
+	} else {
+		// .bim: CHROM ID CM POS ALT REF
+		idx.is_bim = true;
+		chrom_f = 0;
+		id_f = 1;
+		pos_f = 3;
+		alt_f = 4;
+		ref_f = 5;
+	}
+	if (chrom_f == kNone || pos_f == kNone || id_f == kNone || ref_f == kNone || alt_f == kNone) {
+		throw InvalidInputException("%s: .pvar/.bim file '%s' is missing required columns "
+		                            "(need CHROM, POS, ID, REF, ALT)",
+		                            func_name, path);
+	}
+	const size_t max_f = std::max({chrom_f, pos_f, id_f, ref_f, alt_f});
+	for (; li < lines.size(); li++) {
+		if (lines[li].empty()) {
+			continue;
+		}
+		auto f = SplitFields(lines[li], idx.is_bim);
+		if (f.size() <= max_f) {
+			throw InvalidInputException("%s: .pvar/.bim file '%s' has a line missing required fields (line %llu)",
+			                            func_name, path, static_cast<unsigned long long>(li + 1));
+		}
+		char *end;
+		errno = 0;
+		long p = std::strtol(f[pos_f].c_str(), &end, 10);
+		if (end == f[pos_f].c_str() || *end != '\0' || errno != 0) {
+			throw InvalidInputException("%s: invalid POS value '%s' at line %llu", func_name, f[pos_f],
+			                            static_cast<unsigned long long>(li + 1));
+		}
+		idx.chroms.push_back(f[chrom_f]);
+		idx.positions.push_back(static_cast<int32_t>(p));
+		idx.ids.push_back(f[id_f] == "." ? "" : f[id_f]);
+		idx.refs.push_back(f[ref_f]);
+		idx.alts.push_back(f[alt_f] == "." ? "" : f[alt_f]);
+	}
+	idx.variant_ct = idx.chroms.size();
+	// contiguous chromosome runs (region lookups binary-search POS inside a run)
+	idx_t run_start = 0;
+	for (idx_t i = 1; i <= idx.variant_ct; i++) {
+		if (i == idx.variant_ct || idx.chroms[i] != idx.chroms[run_start]) {
+			if (idx.variant_ct == 0) {
+				break;
+			}
+			auto ins = idx.chrom_offsets.emplace(idx.chroms[run_start], std::make_pair(run_start, i));
+			if (!ins.second) {
+				throw InvalidInputException("%s: chromosome '%s' appears in non-contiguous runs (variants must be "
+				                            "sorted by (CHROM, POS) as required by the PLINK spec)",
+				                            path, idx.chroms[run_start]);
+			}
+			run_start = i;
+		}
+	}
+	return idx;
+}
+
+// ---------------------------------------------------------------------------
+// sample metadata
+// ---------------------------------------------------------------------------
+
+void SampleInfo::EnsureIidMap(const string &source_label) {
+	if (!iid_to_idx.empty() || iids.empty()) {
+		return;
+	}
+	for (idx_t i = 0; i < iids.size(); i++) {
+		if (!iid_to_idx.emplace(iids[i], i).second) {
+			throw InvalidInputException("%s: duplicate IID '%s' in sample file", source_label, iids[i]);
+		}
+	}
+}
+
+static bool IsMissingValue(const string &s) {
+	return s.empty() || s == "NA" || s == "na" || s == "." || s == "-9" || s == "nan" || s == "NaN";
+}
+
+SampleInfo LoadSampleMetadata(ClientContext &, const string &path) {
+	string content;
+	if (!ReadWholeFile(path, content)) {
+		throw IOException("cannot open .psam/.fam file '%s'", path);
+	}
+	SampleInfo info;
+	auto lines = Lines(content);
+	size_t li = 0;
+	while (li < lines.size() && (lines[li].empty() || lines[li].compare(0, 2, "##") == 0)) {
+		li++;
+	}
+	constexpr size_t kNone = static_cast<size_t>(-1);
+	size_t iid_f = kNone, fid_f = kNone, sex_f = kNone;
+	bool whitespace = false;
+	if (li < lines.size() && !lines[li].empty() && lines[li][0] == '#') {
+		auto fields = SplitFields(lines[li].substr(1), false);
+		if (fields.size() == 1) {
+			fields = SplitFields(lines[li].substr(1), true);
+			whitespace = fields.size() > 1;
+		}
+		for (size_t i = 0; i < fields.size(); i++) {
+			if (fields[i] == "IID") {
+				iid_f = i;
+			} else if (fields[i] == "FID") {
+				fid_f = i;
+			} else if (fields[i] == "SEX") {
+				sex_f = i;
+			}
+		}
+		if (iid_f == kNone) {
+			throw InvalidInputException("'%s' missing required IID column", path);
+		}
+		li++;
+	} else {
+		// .fam: FID IID PAT MAT SEX PHENO1
+		whitespace = true;
+		fid_f = 0;
+		iid_f = 1;
+		sex_f = 4;
+	}
+	for (; li < lines.size(); li++) {
+		if (lines[li].empty()) {
+			continue;
+		}
+		auto f = SplitFields(lines[li], whitespace);
+		if (f.size() <= iid_f) {
+			throw InvalidInputException("'%s': line %llu has too few fields", path,
+			                            static_cast<unsigned long long>(li + 1));
+		}
+		info.iids.push_back(f[iid_f]);
+		if (fid_f != kNone) {
+			info.fids.push_back(fid_f < f.size() ? f[fid_f] : "");
+		}
+		if (sex_f != kNone) {
+			uint8_t code = 0;
+			if (sex_f < f.size() && !IsMissingValue(f[sex_f])) {
+				code = f[sex_f] == "1" ? 1 : (f[sex_f] == "2" ? 2 : 0);
+			}
+			info.sexes.push_back(code);
+		}
+	}
+	info.sample_ct = info.iids.size();
+	return info;
+}
+
+// ---------------------------------------------------------------------------
+// samples parameter
+// ---------------------------------------------------------------------------
+
+vector<uint32_t> ResolveSampleIndices(const Value &samples_val, uint32_t raw_sample_ct, const SampleInfo *sample_info,
+                                      const string &func_name) {
+	if (samples_val.IsNull()) {
+		throw InvalidInputException("%s: samples list must not be empty", func_name);
+	}
+	if (samples_val.type().id() != LogicalTypeId::LIST) {
+		throw InvalidInputException("%s: samples parameter must be LIST(VARCHAR) or LIST(INTEGER)", func_name);
+	}
+	auto &child_type = ListType::GetChildType(samples_val.type());
+	auto &children = ListValue::GetChildren(samples_val);
+	if (children.empty()) {
+		throw InvalidInputException("%s: samples list must not be empty", func_name);
+	}
+	vector<uint32_t> indices;
+	if (child_type.id() == LogicalTypeId::INTEGER || child_type.id() == LogicalTypeId::BIGINT) {
+		for (auto &child : children) {
+			int64_t idx = child.GetValue<int64_t>();
+			if (idx < 0 || static_cast<uint64_t>(idx) >= raw_sample_ct) {
+				throw InvalidInputException("%s: sample index %lld out of range (sample count: %u)", func_name,
+				                            static_cast<long long>(idx), raw_sample_ct);
+			}
+			indices.push_back(static_cast<uint32_t>(idx));
+		}
+	} else if (child_type.id() == LogicalTypeId::VARCHAR) {
+		if (!sample_info) {
+			throw InvalidInputException("%s: samples parameter requires LIST(INTEGER) when no .psam "
+			                            "is available (no sample IDs to match against)",
+			                            func_name);
+		}
+		const_cast<SampleInfo *>(sample_info)->EnsureIidMap(func_name);
+		for (auto &child : children) {
+			auto iid = child.GetValue<string>();
+			auto it = sample_info->iid_to_idx.find(iid);
+			if (it == sample_info->iid_to_idx.end()) {
+				throw InvalidInputException("%s: sample '%s' not found in .psam", func_name, iid);
+			}
+			indices.push_back(static_cast<uint32_t>(it->second));
+		}
+	} else {
+		throw InvalidInputException("%s: samples parameter must be LIST(VARCHAR) or LIST(INTEGER)", func_name);
+	}
+	std::unordered_set<uint32_t> seen;
+	for (auto idx : indices) {
+		if (!seen.insert(idx).second) {
+			throw InvalidInputException("%s: duplicate sample index %u in samples list", func_name, idx);
+		}
+	}
+	return indices;
+}
+
+SampleSubset BuildSampleSubset(uint32_t raw_sample_ct, const vector<uint32_t> &sample_indices) {
+	SampleSubset r;
+	r.raw_sample_ct = raw_sample_ct;
+	r.subset_sample_ct = static_cast<uint32_t>(sample_indices.size());
+	r.sample_include.assign((raw_sample_ct + 63) / 64, 0);
+	for (auto idx : sample_indices) {
+		r.sample_include[idx >> 6] |= 1ull << (idx & 63);
+	}
+	r.sorted_indices = sample_indices;
+	std::sort(r.sorted_indices.begin(), r.sorted_indices.end());
+	return r;
+}
+
+// ---------------------------------------------------------------------------
+// region
+// ---------------------------------------------------------------------------
+
+VariantRange ParseRegion(const string &region_str, const VariantMetadataIndex &variants, const string &func_name) {
+	auto colon = region_str.find(':');
+	if (colon == string::npos || colon == 0) {
+		throw InvalidInputException("%s: invalid region format '%s' (expected 'chr:start-end')", func_name, region_str);
+	}
+	string chrom = region_str.substr(0, colon);
+	string range_part = region_str.substr(colon + 1);
+	auto dash = range_part.find('-');
+	if (dash == string::npos) {
+		throw InvalidInputException("%s: invalid region format '%s' (expected 'chr:start-end')", func_name, region_str);
+	}
+	string start_str = range_part.substr(0, dash);
+	string end_str = range_part.substr(dash + 1);
+	char *parse_end;
+	errno = 0;
+	long start_pos = std::strtol(start_str.c_str(), &parse_end, 10);
+	if (parse_end == start_str.c_str() || *parse_end != '\0' || errno != 0 || start_pos < 0) {
+		throw InvalidInputException("%s: invalid region start position in '%s'", func_name, region_str);
+	}
+	errno = 0;
+	long end_pos = std::strtol(end_str.c_str(), &parse_end, 10);
+	if (parse_end == end_str.c_str() || *parse_end != '\0' || errno != 0 || end_pos < 0) {
+		throw InvalidInputException("%s: invalid region end position in '%s'", func_name, region_str);
+	}
+	VariantRange range;
+	range.has_filter = true;
+	auto it = variants.chrom_offsets.find(chrom); // exact string match, no chr-prefix normalisation
+	if (it == variants.chrom_offsets.end()) {
+		return range; // empty
+	}
+	auto first = variants.positions.begin() + static_cast<std::ptrdiff_t>(it->second.first);
+	auto last = variants.positions.begin() + static_cast<std::ptrdiff_t>(it->second.second);
+	auto lo = std::lower_bound(first, last, static_cast<int32_t>(start_pos));
+	auto hi = std::upper_bound(first, last, static_cast<int32_t>(end_pos));
+	range.start_idx = static_cast<uint32_t>(lo - variants.positions.begin());
+	range.end_idx = static_cast<uint32_t>(hi - variants.positions.begin());
+	if (range.end_idx < range.start_idx) {
+		range.end_idx = range.start_idx;
+	}
+	return range;
+}
+
+// ---------------------------------------------------------------------------
+// read_pgen filters
+// ---------------------------------------------------------------------------
+
+void GenotypeRangeFilter::SetFromRange(const RangeFilter &r, bool inc_missing) {
+	for (int g = 0; g <= 2; g++) {
+		allowed[g] = r.Passes(static_cast<double>(g));
+	}
+	include_missing = inc_missing;
+	active = r.active;
+}
+
+RangeFilter ParseRangeFilter(const Value &val, const string &param_name, double valid_min, double valid_max,
+                             const string &func_name, bool *include_missing_out) {
+	RangeFilter result;
+	if (val.type().id() != LogicalTypeId::STRUCT) {
+		throw InvalidInputException("%s: %s must be a STRUCT (e.g. {min: 0.0, max: 0.5})", func_name, param_name);
+	}
+	auto &child_types = StructType::GetChildTypes(val.type());
+	auto &children = StructValue::GetChildren(val);
+	if (children.empty()) {
+		return result;
+	}
+	for (idx_t i = 0; i < child_types.size(); i++) {
+		auto &field_name = child_types[i].first;
+		auto &child_val = children[i];
+		if (include_missing_out && field_name == "include_missing") {
+			if (!child_val.IsNull()) {
+				*include_missing_out = child_val.GetValue<bool>();
+			}
+			continue;
+		}
+		if (field_name != "min" && field_name != "max") {
+			throw InvalidInputException("%s: %s has unknown field '%s' (expected %s)", func_name, param_name,
+			                            field_name,
+			                            include_missing_out ? "'min', 'max', and/or 'include_missing'"
+			                                                : "'min' and/or 'max'");
+		}
+		if (child_val.IsNull()) {
+			continue;
+		}
+		double v = child_val.GetValue<double>();
+		if (v < valid_min || v > valid_max) {
+			throw InvalidInputException("%s: %s.%s value %g is out of range [%g, %g]", func_name, param_name,
+			                            field_name, v, valid_min, valid_max);
+		}
+		if (field_name == "min") {
+			result.min = v;
+		} else {
+			result.max = v;
+		}
+	}
+	if (result.min > result.max) {
+		throw InvalidInputException("%s: %s min (%g) > max (%g)", func_name, param_name, result.min, result.max);
+	}
+	result.active = true;
+	return result;
+}
+
+void ParseIncludeGenotypes(const Value &val, GenotypeRangeFilter &out, const string &func_name) {
+	if (val.IsNull()) {
+		return;
+	}
+	if (val.type().id() != LogicalTypeId::LIST) {
+		throw InvalidInputException("%s: include_genotypes must be a LIST of category names "
+		                            "(e.g. ['het', 'hom_alt'])",
+		                            func_name);
+	}
+	auto &children = ListValue::GetChildren(val);
+	if (children.empty()) {
+		return;
+	}
+	for (auto &child : children) {
+		if (child.IsNull()) {
+			throw InvalidInputException("%s: include_genotypes contains a NULL category name", func_name);
+		}
+		string label = Lower(Trim(child.GetValue<string>()));
+		if (label == "hom_ref") {
+			out.allowed[0] = true;
+		} else if (label == "het") {
+			out.allowed[1] = true;
+		} else if (label == "hom_alt") {
+			out.allowed[2] = true;
+		} else if (label == "missing") {
+			out.include_missing = true;
+		} else {
+			throw InvalidInputException("%s: include_genotypes has unknown category '%s' "
+			                            "(expected 'hom_ref', 'het', 'hom_alt', and/or 'missing')",
+			                            func_name, label);
+		}
+	}
+	out.active = true;
+}
+
+PreDecompFilterResult CheckPreDecompFilters(const CountFilter &count_filter, const GenotypeRangeFilter &genotype_filter,
+                                            const uint32_t c[4], uint32_t) {
+	PreDecompFilterResult result;
+	if (count_filter.HasFilter()) {
+		uint32_t non_missing = c[0] + c[1] + c[2];
+		if (non_missing == 0) {
+			result.skip = true;
+			return result;
+		}
+		uint32_t ac = c[1] + 2 * c[2];
+		if (count_filter.ac_filter.active && !count_filter.ac_filter.Passes(static_cast<double>(ac))) {
+			result.skip = true;
+			return result;
+		}
+		if (count_filter.af_filter.active) {
+			double af = static_cast<double>(ac) / (2.0 * static_cast<double>(non_missing));
+			if (!count_filter.af_filter.Passes(af)) {
+				result.skip = true;
+				return result;
+			}
+		}
+	}
+	if (genotype_filter.active) {
+		bool any_pass = false, all_pass = true;
+		for (int g = 0; g <= 2; g++) {
+			if (genotype_filter.allowed[g] && c[g] > 0) {
+				any_pass = true;
+			}
+			if (!genotype_filter.allowed[g] && c[g] > 0) {
+				all_pass = false;
+			}
+		}
+		if (genotype_filter.include_missing && c[3] > 0) {
+			any_pass = true;
+		}
+		if (!any_pass) {
+			result.skip = true;
+			return result;
+		}
+		result.all_pass = all_pass;
+	}
+	return result;
+}
+
+GenotypeMode ResolveGenotypeMode(const string &mode_str, uint32_t sample_ct, const string &func_name) {
+	auto mode = Lower(mode_str);
+	if (mode == "auto") {
+		return sample_ct <= ArrayType::MAX_ARRAY_SIZE ? GenotypeMode::ARRAY : GenotypeMode::LIST;
+	} else if (mode == "array") {
+		if (sample_ct > ArrayType::MAX_ARRAY_SIZE) {
+			throw InvalidInputException("%s: genotypes := 'array' requires sample count (%u) <= %u. "
+			                            "Use genotypes := 'list' or genotypes := 'auto' for large cohorts.",
+			                            func_name, sample_ct, static_cast<uint32_t>(ArrayType::MAX_ARRAY_SIZE));
+		}
+		return GenotypeMode::ARRAY;
+	} else if (mode == "list") {
+		return GenotypeMode::LIST;
+	} else if (mode == "columns") {
+		return GenotypeMode::COLUMNS;
+	} else if (mode == "struct") {
+		return GenotypeMode::STRUCT;
+	} else if (mode == "counts") {
+		return GenotypeMode::COUNTS;
+	} else if (mode == "stats") {
+		return GenotypeMode::STATS;
+	}
+	throw InvalidInputException(
+	    "%s: invalid genotypes value '%s' (expected 'auto', 'array', 'list', 'columns', 'struct', 'counts', or "
+	    "'stats')",
+	    func_name, mode_str);
+}
+
+LogicalType MakeGenotypeCountsType() {
+	return LogicalType::STRUCT({{"hom_ref", LogicalType::UINTEGER},
+	                            {"het", LogicalType::UINTEGER},
+	                            {"hom_alt", LogicalType::UINTEGER},
+	                            {"missing", LogicalType::UINTEGER}});
+}
+
+LogicalType MakeGenotypeStatsType() {
+	return LogicalType::STRUCT({{"hom_ref", LogicalType::UINTEGER},
+	                            {"het", LogicalType::UINTEGER},
+	                            {"hom_alt", LogicalType::UINTEGER},
+	                            {"missing", LogicalType::UINTEGER},
+	                            {"n", LogicalType::UINTEGER},
+	                            {"af", LogicalType::DOUBLE},
+	                            {"maf", LogicalType::DOUBLE},
+	                            {"missing_rate", LogicalType::DOUBLE},
+	                            {"carrier_count", LogicalType::UINTEGER},
+	                            {"het_rate", LogicalType::DOUBLE}});
+}
+
+// ---------------------------------------------------------------------------
+// PCA normalisation, threads
+// ---------------------------------------------------------------------------
+
+VariantNorm ComputeVariantNorm(double alt_freq) {
+	VariantNorm norm;
+	if (alt_freq <= 0.0 || alt_freq >= 1.0) {
+		return norm;
+	}
+	norm.center = 2.0 * alt_freq;
+	norm.inv_stdev = 1.0 / std::sqrt(2.0 * alt_freq * (1.0 - alt_freq));
+	norm.skip = false;
+	return norm;
+}
+
+uint32_t GetPlinkingMaxThreads(ClientContext &context) {
+	Value val;
+	if (context.TryGetCurrentSetting("plinking_max_threads", val)) {
+		auto v = val.GetValue<int64_t>();
+		if (v > 0) {
+			return static_cast<uint32_t>(v);
+		}
+	}
+	return 0;
+}
+
+idx_t ApplyMaxThreadsCap(idx_t computed, uint32_t config_max_threads) {
+	if (config_max_threads > 0) {
+		return std::min<idx_t>(computed, config_max_threads);
+	}
+	return std::min<idx_t>(computed, 16);
+}
+
+// ---------------------------------------------------------------------------
+// ploidy / sex
+// ---------------------------------------------------------------------------
+
+ParBounds ResolveParBounds(const string &build, const string &func_name) {
+	string norm;
+	for (char c : Lower(build)) {
+		if (c != '-' && c != '_' && c != ' ' && c != '.') {
+			norm.push_back(c);
+		}
+	}
+	ParBounds pb;
+	if (norm.empty() || norm == "none") {
+		return pb;
+	}
+	if (norm == "grch38" || norm == "hg38" || norm == "b38" || norm == "38") {
+		pb.par1_end = 2781479;
+		pb.par2_start = 155701383;
+		pb.par2_end = 156030895;
+		pb.active = true;
+		return pb;
+	}
+	if (norm == "grch37" || norm == "hg19" || norm == "b37" || norm == "37") {
+		pb.par1_end = 2699520;
+		pb.par2_start = 154931044;
+		pb.par2_end = 155260560;
+		pb.active = true;
+		return pb;
+	}
+	throw InvalidInputException("%s: unrecognized build '%s' (expected 'GRCh38'/'hg38', 'GRCh37'/'hg19', or 'none')",
+	                            func_name, build);
+}
+
+ChromPloidy ClassifyChromPloidy(const string &chrom, int32_t pos, const ParBounds &par) {
+	string c = Lower(chrom);
+	if (c.compare(0, 3, "chr") == 0) {
+		c = c.substr(3);
+	}
+	if (c == "par1" || c == "par2" || c == "xy" || c == "25") {
+		return ChromPloidy::AUTOSOMAL;
+	}
+	if (c == "y" || c == "24") {
+		return ChromPloidy::CHR_Y;
+	}
+	if (c == "mt" || c == "m" || c == "26") {
+		return ChromPloidy::CHR_MT;
+	}
+	if (c == "x" || c == "23") {
+		if (par.active && ((pos > 0 && pos <= par.par1_end) || (pos >= par.par2_start && pos <= par.par2_end))) {
+			return ChromPloidy::AUTOSOMAL;
+		}
+		return ChromPloidy::CHR_X;
+	}
+	return ChromPloidy::AUTOSOMAL;
+}
+
+vector<uint8_t> BuildAlignedSex(const SampleInfo &sample_info, const vector<uint32_t> *subset_sorted) {
+	if (sample_info.sexes.empty()) {
+		return {};
+	}
+	if (!subset_sorted) {
+		return sample_info.sexes;
+	}
+	vector<uint8_t> aligned;
+	aligned.reserve(subset_sorted->size());
+	for (uint32_t idx : *subset_sorted) {
+		aligned.push_back(idx < sample_info.sexes.size() ? sample_info.sexes[idx] : uint8_t {0});
+	}
+	return aligned;
+}
+
+SexAwareCounts SexAwareFromStrata(ChromPloidy ploidy, const uint32_t total[4], const uint32_t male[4],
+                                  const uint32_t female[4], bool have_sex) {
+	SexAwareCounts r;
+	if ((ploidy == ChromPloidy::CHR_X || ploidy == ChromPloidy::CHR_Y) && !have_sex) {
+		r.sex_unavailable = true;
+		return r;
+	}
+	auto haploid = [&](const uint32_t c[4]) {
+		// one allele per sample; a heterozygous hardcall is invalid -> missing
+		r.obs_allele_ct += c[0] + c[2];
+		r.alt_allele_ct += c[2];
+		r.geno_hom_ref += c[0];
+		r.geno_hom_alt += c[2];
+		r.geno_missing += c[1] + c[3];
+	};
+	auto diploid = [&](const uint32_t c[4]) {
+		r.obs_allele_ct += 2 * (c[0] + c[1] + c[2]);
+		r.alt_allele_ct += c[1] + 2 * c[2];
+		r.hwe_hom_ref += c[0];
+		r.hwe_het += c[1];
+		r.hwe_hom_alt += c[2];
+		r.geno_hom_ref += c[0];
+		r.geno_het += c[1];
+		r.geno_hom_alt += c[2];
+		r.geno_missing += c[3];
+	};
+	const uint32_t n_total = total[0] + total[1] + total[2] + total[3];
+	const uint32_t n_male = male[0] + male[1] + male[2] + male[3];
+	const uint32_t n_female = female[0] + female[1] + female[2] + female[3];
+	switch (ploidy) {
+	case ChromPloidy::CHR_MT:
+		haploid(total);
+		break;
+	case ChromPloidy::CHR_Y:
+		haploid(male);
+		r.geno_missing += n_total - n_male; // females and unknown sex carry no Y
+		break;
+	case ChromPloidy::CHR_X:
+		diploid(female);
+		haploid(male);
+		r.geno_missing += n_total - n_male - n_female; // unknown sex: ploidy undetermined
+		break;
+	case ChromPloidy::AUTOSOMAL:
+	default:
+		diploid(total);
+		break;
+	}
+	r.hwe_defined = (ploidy == ChromPloidy::CHR_X || ploidy == ChromPloidy::AUTOSOMAL);
+	return r;
+}
+
+// ---------------------------------------------------------------------------
+// libpgenhip wrappers
+// ---------------------------------------------------------------------------
+
+void ThrowOnPghError(int rc, const char *errbuf, const string &func_name, const string &what) {
+	if (rc == PGH_OK) {
+		return;
+	}
+	if (rc == PGH_ERR_ARG) {
+		throw InvalidInputException("%s: %s: %s", func_name, what, string(errbuf));
+	}
+	throw IOException("%s: %s: %s", func_name, what, string(errbuf));
+}
+
+pgh_info ProbePgen(const string &pgen_path, const string &func_name) {
+	pgh_info info;
+	char errbuf[PGH_ERRBUF_LEN] = {0};
+	int rc = pgh_probe(pgen_path.c_str(), nullptr, &info, errbuf);
+	if (rc != PGH_OK) {
+		throw IOException("%s: failed to open '%s': %s", func_name, pgen_path, string(errbuf));
+	}
+	return info;
+}
+
+DeviceDataset::~DeviceDataset() {
+	if (handle) {
+		pgh_close(handle);
+	}
+}
+
+namespace {
+struct CacheKey {
+	string path;
+	int64_t mtime_ns;
+	int64_t size;
+	bool operator==(const CacheKey &o) const {
+		return path == o.path && mtime_ns == o.mtime_ns && size == o.size;
+	}
+};
+struct CacheEntry {
+	CacheKey key;
+	shared_ptr<DeviceDataset> ds;
+	uint64_t bytes;
+};
+std::mutex g_cache_mutex;
+vector<CacheEntry> g_cache; // most recently used last
+
+uint64_t CacheBudgetBytes() {
+	const char *env = std::getenv("PLINKING_HBM_CACHE_GB");
+	double gb = env ? std::atof(env) : 160.0;
+	return static_cast<uint64_t>(gb * 1e9);
+}
+} // namespace
+
+shared_ptr<DeviceDataset> DeviceDataset::Acquire(const string &pgen_path, const string &func_name) {
+	struct stat st;
+	if (::stat(pgen_path.c_str(), &st) != 0) {
+		throw IOException("%s: failed to open '%s': %s", func_name, pgen_path, string(std::strerror(errno)));
+	}
+	CacheKey key {pgen_path, static_cast<int64_t>(st.st_mtim.tv_sec) * 1000000000LL + st.st_mtim.tv_nsec,
+	              static_cast<int64_t>(st.st_size)};
+	std::lock_guard<std::mutex> lock(g_cache_mutex);
+	for (size_t i = 0; i < g_cache.size(); i++) {
+		if (g_cache[i].key == key) {
+			auto e = g_cache[i];
+			g_cache.erase(g_cache.begin() + static_cast<std::ptrdiff_t>(i));
+			g_cache.push_back(e);
+			return e.ds;
+		}
+	}
+	auto ds = make_shared<DeviceDataset>();
+	ds->path = pgen_path;
+	char errbuf[PGH_ERRBUF_LEN] = {0};
+	int rc = pgh_open(pgen_path.c_str(), nullptr, 0, UINT32_MAX, &ds->handle, errbuf);
+	if (rc != PGH_OK) {
+		throw IOException("%s: failed to open '%s': %s", func_name, pgen_path, string(errbuf));
+	}
+	pgh_get_info(ds->handle, &ds->info);
+	uint64_t bytes = ds->info.pitch_bytes * (ds->info.variant_end - ds->info.variant_begin);
+	g_cache.push_back({key, ds, bytes});
+	// evict least recently used datasets beyond the HBM budget (in-flight queries keep theirs alive)
+	uint64_t total = 0;
+	for (auto &e : g_cache) {
+		total += e.bytes;
+	}
+	while (g_cache.size() > 1 && total > CacheBudgetBytes()) {
+		total -= g_cache.front().bytes;
+		g_cache.erase(g_cache.begin());
+	}
+	return ds;
+}
+
+DeviceSubset::DeviceSubset(const DeviceDataset &ds, const vector<uint64_t> &include, const string &func_name) {
+	char errbuf[PGH_ERRBUF_LEN] = {0};
+	int rc = pgh_subset_create(ds.handle, include.data(), &handle, errbuf);
+	ThrowOnPghError(rc, errbuf, func_name, "sample subset");
+}
+
+DeviceSubset::~DeviceSubset() {
+	if (handle) {
+		pgh_subset_destroy(handle);
+	}
+}
+
+} // namespace duckdb

@@ -1,0 +1,207 @@
+// plink_common.hpp -- helpers shared by the table-function shells: companion
+// metadata, sample subsets, regions, ploidy rules, thread caps, and the handle
+// wrappers over libpgenhip.  Mirrors the on-path parts of the reference's
+// src/plink_common.{hpp,cpp}; the text readers are
+// minimal (pvar/bim/psam/fam only, local files) because metadata plumbing is out
+// of scope for this path.
+#pragma once
+
+#include "../../../include/pgenhip.h"
+#include "duck_api.hpp"
+
+#include <mutex>
+#include <unordered_map>
+
+namespace duckdb {
+
+// ---- variant / sample metadata ---------------------------------------------------
+
+struct VariantMetadataIndex {
+	vector<string> chroms, ids, refs, alts;
+	vector<int32_t> positions;
+	idx_t variant_ct = 0;
+	bool is_bim = false;
+	std::unordered_map<string, std::pair<idx_t, idx_t>> chrom_offsets; // contiguous CHROM runs
+
+	const string &GetChrom(idx_t v) const {
+		return chroms[v];
+	}
+	int32_t GetPos(idx_t v) const {
+		return positions[v];
+	}
+	const string &GetId(idx_t v) const {
+		return ids[v];
+	}
+	const string &GetRef(idx_t v) const {
+		return refs[v];
+	}
+	const string &GetAlt(idx_t v) const {
+		return alts[v];
+	}
+};
+
+//! src/plink_common.cpp:171-375 (text path only)
+VariantMetadataIndex LoadVariantMetadata(ClientContext &context, const string &path, const string &func_name);
+
+struct SampleInfo {
+	vector<string> iids;
+	vector<string> fids;   // empty when the file has no FID column
+	vector<uint8_t> sexes; // 1 male, 2 female, 0 unknown; empty when no SEX column
+	idx_t sample_ct = 0;
+	std::unordered_map<string, idx_t> iid_to_idx;
+	void EnsureIidMap(const string &source_label = "sample file");
+};
+
+//! src/psam_reader.cpp (.psam with #FID/#IID header, or headerless .fam)
+SampleInfo LoadSampleMetadata(ClientContext &context, const string &path);
+
+//! src/plink_common.cpp:553-595 (native text companions only)
+string FindCompanionFile(const string &pgen_path, const vector<string> &extensions);
+bool FileExists(const string &path);
+
+// ---- samples / regions ------------------------------------------------------------
+
+//! src/plink_common.cpp:1161-1216
+vector<uint32_t> ResolveSampleIndices(const Value &samples_val, uint32_t raw_sample_ct, const SampleInfo *sample_info,
+                                      const string &func_name);
+
+//! src/plink_common.hpp:373-396, cpp:1222-1250: the include bitmask; the
+//! interleaved vector / cumulative popcounts of pgenlib live inside pgh_subset.
+struct SampleSubset {
+	uint32_t raw_sample_ct = 0;
+	uint32_t subset_sample_ct = 0;
+	vector<uint64_t> sample_include;
+	vector<uint32_t> sorted_indices; // ascending file order == output order
+};
+SampleSubset BuildSampleSubset(uint32_t raw_sample_ct, const vector<uint32_t> &sample_indices);
+
+struct VariantRange {
+	bool has_filter = false;
+	uint32_t start_idx = 0;
+	uint32_t end_idx = 0;
+};
+//! src/plink_common.cpp:1256-1334
+VariantRange ParseRegion(const string &region_str, const VariantMetadataIndex &variants, const string &func_name);
+
+// ---- filters of read_pgen ------------------------------------------------------------
+
+struct RangeFilter {
+	bool active = false;
+	double min = -std::numeric_limits<double>::infinity();
+	double max = std::numeric_limits<double>::infinity();
+	bool Passes(double v) const {
+		return v >= min && v <= max;
+	}
+};
+struct CountFilter {
+	RangeFilter af_filter, ac_filter;
+	bool HasFilter() const {
+		return af_filter.active || ac_filter.active;
+	}
+};
+struct GenotypeRangeFilter {
+	bool active = false;
+	bool allowed[3] = {false, false, false};
+	bool include_missing = false;
+	bool AllowsCall(double g) const {
+		int i = static_cast<int>(g);
+		return i >= 0 && i <= 2 && allowed[i];
+	}
+	void SetFromRange(const RangeFilter &r, bool inc_missing);
+};
+struct PreDecompFilterResult {
+	bool skip = false;
+	bool all_pass = true;
+};
+//! src/plink_common.cpp:1340-1391
+RangeFilter ParseRangeFilter(const Value &val, const string &param_name, double valid_min, double valid_max,
+                             const string &func_name, bool *include_missing_out = nullptr);
+//! src/plink_common.cpp:1393-1436
+void ParseIncludeGenotypes(const Value &val, GenotypeRangeFilter &out, const string &func_name);
+//! src/plink_common.cpp:1494-1515
+PreDecompFilterResult CheckPreDecompFilters(const CountFilter &count_filter, const GenotypeRangeFilter &genotype_filter,
+                                            const uint32_t genocounts[4], uint32_t sample_ct);
+
+enum class GenotypeMode { ARRAY, LIST, COLUMNS, STRUCT, COUNTS, STATS };
+//! src/plink_common.cpp:17-57
+GenotypeMode ResolveGenotypeMode(const string &mode_str, uint32_t sample_ct, const string &func_name);
+inline bool IsAggregateGenotypeMode(GenotypeMode m) {
+	return m == GenotypeMode::COUNTS || m == GenotypeMode::STATS;
+}
+LogicalType MakeGenotypeCountsType();
+LogicalType MakeGenotypeStatsType();
+
+// ---- PCA normalisation ----------------------------------------------------------------
+
+struct VariantNorm {
+	double center = 0.0;
+	double inv_stdev = 0.0;
+	bool skip = true;
+};
+//! src/plink_common.cpp:1521-1533
+VariantNorm ComputeVariantNorm(double alt_freq);
+
+// ---- threads ---------------------------------------------------------------------------
+
+//! src/plink_common.cpp:1894-1911
+uint32_t GetPlinkingMaxThreads(ClientContext &context);
+idx_t ApplyMaxThreadsCap(idx_t computed, uint32_t config_max_threads);
+
+// ---- ploidy / sex -----------------------------------------------------------------------
+
+enum class ChromPloidy { AUTOSOMAL, CHR_X, CHR_Y, CHR_MT };
+struct ParBounds {
+	bool active = false;
+	int32_t par1_end = 0, par2_start = 0, par2_end = 0;
+};
+//! src/plink_common.cpp:1928-1958
+ParBounds ResolveParBounds(const string &build, const string &func_name);
+//! src/plink_common.cpp:1960-1979
+ChromPloidy ClassifyChromPloidy(const string &chrom, int32_t pos, const ParBounds &par);
+//! src/plink_common.cpp:1981-1994
+vector<uint8_t> BuildAlignedSex(const SampleInfo &sample_info, const vector<uint32_t> *subset_sorted);
+
+struct SexAwareCounts {
+	uint32_t obs_allele_ct = 0, alt_allele_ct = 0;
+	uint32_t geno_hom_ref = 0, geno_het = 0, geno_hom_alt = 0, geno_missing = 0;
+	uint32_t hwe_hom_ref = 0, hwe_het = 0, hwe_hom_alt = 0;
+	bool hwe_defined = false;
+	bool sex_unavailable = false;
+};
+//! ComputeSexAwareCounts (src/plink_common.cpp:1996-2108) restated over class
+//! counts per sex stratum -- what the device tally produces with a male and a
+//! female sample mask -- instead of a per-sample loop over decoded bytes.
+//! total/male/female = {hom_ref, het, hom_alt, missing} of the stratum.
+SexAwareCounts SexAwareFromStrata(ChromPloidy ploidy, const uint32_t total[4], const uint32_t male[4],
+                                  const uint32_t female[4], bool have_sex);
+
+// ---- libpgenhip handle wrappers ------------------------------------------------------------
+
+//! Status + errbuf -> the reference's exception types (PGH_ERR_ARG ->
+//! InvalidInputException, everything else -> IOException).
+void ThrowOnPghError(int rc, const char *errbuf, const string &func_name, const string &what);
+
+//! A genotype matrix resident in HBM, shared by every scan thread of a query and
+//! kept across queries on the same file (process-wide cache).
+class DeviceDataset {
+public:
+	~DeviceDataset();
+	pgh_dataset *handle = nullptr;
+	pgh_info info;
+	string path;
+	static shared_ptr<DeviceDataset> Acquire(const string &pgen_path, const string &func_name);
+};
+
+//! RAII pgh_subset
+class DeviceSubset {
+public:
+	DeviceSubset(const DeviceDataset &ds, const vector<uint64_t> &include, const string &func_name);
+	~DeviceSubset();
+	DeviceSubset(const DeviceSubset &) = delete;
+	pgh_subset *handle = nullptr;
+};
+
+//! Header probe (replaces the bind-time PgfiInitPhase1/2 of every function).
+pgh_info ProbePgen(const string &pgen_path, const string &func_name);
+
+} // namespace duckdb

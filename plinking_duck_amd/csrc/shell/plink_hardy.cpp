@@ -1,0 +1,279 @@
+// plink_hardy.cpp -- plink_hardy(path, pvar, psam, samples, region, midp, build)
+//
+// Surface of the reference's src/plink_hardy.cpp; counts come from the batched
+// device tally, the exact tests from libpgenhip's HWE routines (pgh_hwe_lnp /
+// pgh_hwe_xchr_lnp, the replacements for plink2::HweLnP / HweXchrLnP).
+#include "variant_scan.hpp"
+
+#include <cmath>
+
+namespace duckdb {
+
+// CHROM(0) POS(1) ID(2) REF(3) ALT(4) A1(5) HOM_REF_CT(6) HET_CT(7) HOM_ALT_CT(8) O_HET(9) E_HET(10) P_HWE(11)
+static constexpr idx_t COL_A1 = 5;
+static constexpr idx_t COL_HOM_REF_CT = 6;
+static constexpr idx_t COL_HET_CT = 7;
+static constexpr idx_t COL_HOM_ALT_CT = 8;
+static constexpr idx_t COL_O_HET = 9;
+static constexpr idx_t COL_E_HET = 10;
+static constexpr idx_t COL_P_HWE = 11;
+
+//! src/plink_hardy.cpp:52-64
+static double LnPToPvalue(double ln_p) {
+	if (std::isnan(ln_p)) {
+		return 1.0;
+	}
+	double p = std::exp(ln_p);
+	return p < 0.0 ? 0.0 : (p > 1.0 ? 1.0 : p);
+}
+
+//! src/plink_hardy.cpp:67-79
+static double HweExactTestAutosomal(int32_t obs_hom_ref, int32_t obs_hets, int32_t obs_hom_alt, bool midp) {
+	if (obs_hom_ref < 0 || obs_hets < 0 || obs_hom_alt < 0 || obs_hom_ref + obs_hets + obs_hom_alt == 0) {
+		return 1.0;
+	}
+	return LnPToPvalue(pgh_hwe_lnp(obs_hets, obs_hom_ref, obs_hom_alt, midp ? 1U : 0U));
+}
+
+//! src/plink_hardy.cpp:83-95
+static double HweExactTestXchr(int32_t female_hom_ref, int32_t female_hets, int32_t female_hom_alt, int32_t male_ref,
+                               int32_t male_alt, bool midp) {
+	if (female_hom_ref < 0 || female_hets < 0 || female_hom_alt < 0 || male_ref < 0 || male_alt < 0 ||
+	    female_hom_ref + female_hets + female_hom_alt + male_ref + male_alt == 0) {
+		return 1.0;
+	}
+	return LnPToPvalue(
+	    pgh_hwe_xchr_lnp(female_hets, female_hom_ref, female_hom_alt, male_ref, male_alt, midp ? 1U : 0U));
+}
+
+struct PlinkHardyBindData : public TableFunctionData {
+	PgenBindCommon c;
+	bool midp = false;
+	ParBounds par_bounds;
+	bool have_sex = false;
+};
+
+struct PlinkHardyGlobalState : public GlobalTableFunctionState {
+	VariantScanGlobal scan;
+	vector<column_t> column_ids;
+	bool need_genotype_counts = false;
+	uint32_t max_threads_config = 0;
+	idx_t MaxThreads() const override {
+		uint32_t range = scan.end_variant_idx - scan.start_variant_idx;
+		return ApplyMaxThreadsCap(range / 500 + 1, max_threads_config);
+	}
+};
+
+struct PlinkHardyLocalState : public LocalTableFunctionState {
+	VariantScanLocal scan;
+};
+
+static unique_ptr<FunctionData> PlinkHardyBind(ClientContext &context, TableFunctionBindInput &input,
+                                               vector<LogicalType> &return_types, vector<string> &names) {
+	auto bind_data = make_uniq<PlinkHardyBindData>();
+	string build_str = "GRCh38";
+	for (auto &kv : input.named_parameters) {
+		if (kv.first == "midp") {
+			bind_data->midp = kv.second.GetValue<bool>();
+		} else if (kv.first == "build") {
+			build_str = kv.second.GetValue<string>();
+		}
+	}
+	bind_data->par_bounds = ResolveParBounds(build_str, "plink_hardy");
+	bind_data->c.Bind(context, input, "plink_hardy", false);
+	bind_data->have_sex = bind_data->c.has_sample_info && !bind_data->c.sample_info.sexes.empty();
+	names = {"CHROM", "POS", "ID", "REF", "ALT", "A1", "HOM_REF_CT", "HET_CT", "HOM_ALT_CT", "O_HET", "E_HET", "P_HWE"};
+	return_types = {LogicalType::VARCHAR, LogicalType::INTEGER, LogicalType::VARCHAR, LogicalType::VARCHAR,
+	                LogicalType::VARCHAR, LogicalType::VARCHAR, LogicalType::INTEGER, LogicalType::INTEGER,
+	                LogicalType::INTEGER, LogicalType::DOUBLE,  LogicalType::DOUBLE,  LogicalType::DOUBLE};
+	return std::move(bind_data);
+}
+
+static unique_ptr<GlobalTableFunctionState> PlinkHardyInitGlobal(ClientContext &context,
+                                                                 TableFunctionInitInput &input) {
+	auto &bind_data = input.bind_data->Cast<PlinkHardyBindData>();
+	auto state = make_uniq<PlinkHardyGlobalState>();
+	state->scan.start_variant_idx = bind_data.c.RangeStart();
+	state->scan.end_variant_idx = bind_data.c.RangeEnd();
+	state->scan.next_variant_idx.store(state->scan.start_variant_idx);
+	state->scan.effective_sample_ct = bind_data.c.effective_sample_ct;
+	state->column_ids = input.column_ids;
+	state->max_threads_config = GetPlinkingMaxThreads(context);
+	for (auto col_id : input.column_ids) {
+		if (col_id != COLUMN_IDENTIFIER_ROW_ID && col_id >= COL_HOM_REF_CT && col_id <= COL_P_HWE) {
+			state->need_genotype_counts = true;
+			break;
+		}
+	}
+	if (state->need_genotype_counts) {
+		state->scan.dataset = DeviceDataset::Acquire(bind_data.c.pgen_path, "plink_hardy");
+		if (bind_data.c.has_sample_subset) {
+			state->scan.subset =
+			    make_uniq<DeviceSubset>(*state->scan.dataset, bind_data.c.sample_subset->sample_include, "plink_hardy");
+		}
+		if (bind_data.have_sex) {
+			BuildSexStrata(state->scan, bind_data.c.sample_info, bind_data.c.sample_subset.get(),
+			               bind_data.c.raw_sample_ct, "plink_hardy");
+		}
+	}
+	return std::move(state);
+}
+
+static unique_ptr<LocalTableFunctionState> PlinkHardyInitLocal(ExecutionContext &, TableFunctionInitInput &,
+                                                               GlobalTableFunctionState *) {
+	return make_uniq<PlinkHardyLocalState>();
+}
+
+static void PlinkHardyScan(ClientContext &, TableFunctionInput &data_p, DataChunk &output) {
+	auto &bind_data = data_p.bind_data->Cast<PlinkHardyBindData>();
+	auto &gstate = data_p.global_state->Cast<PlinkHardyGlobalState>();
+	auto &lstate = data_p.local_state->Cast<PlinkHardyLocalState>();
+	auto &column_ids = gstate.column_ids;
+	auto &variants = bind_data.c.variants;
+
+	auto needs_strata = [&](uint32_t begin, uint32_t end) {
+		for (uint32_t v = begin; v < end; v++) {
+			if (ClassifyChromPloidy(variants.GetChrom(v), variants.GetPos(v), bind_data.par_bounds) !=
+			    ChromPloidy::AUTOSOMAL) {
+				return true;
+			}
+		}
+		return false;
+	};
+
+	idx_t rows_emitted = 0;
+	uint32_t vidx;
+	while (rows_emitted < STANDARD_VECTOR_SIZE && lstate.scan.Next(gstate.scan, "plink_hardy", needs_strata, vidx)) {
+		ChromPloidy ploidy = ChromPloidy::AUTOSOMAL;
+		if (gstate.need_genotype_counts) {
+			ploidy = ClassifyChromPloidy(variants.GetChrom(vidx), variants.GetPos(vidx), bind_data.par_bounds);
+		}
+		const bool sex_aware = ploidy != ChromPloidy::AUTOSOMAL;
+		uint32_t genocounts[4] = {0, 0, 0, 0};
+		SexAwareCounts sac;
+		if (gstate.need_genotype_counts) {
+			std::memcpy(genocounts, lstate.scan.Counts(vidx), sizeof genocounts);
+			if (sex_aware) {
+				static const uint32_t zero[4] = {0, 0, 0, 0};
+				const bool strata = lstate.scan.have_strata;
+				sac = SexAwareFromStrata(ploidy, genocounts, strata ? lstate.scan.MaleCounts(vidx) : zero,
+				                         strata ? lstate.scan.FemaleCounts(vidx) : zero, bind_data.have_sex);
+			}
+		}
+
+		// Reported HOM/HET counts are the HWE-test stratum: females on chrX,
+		// haploid carriers (HET = 0) on chrY / chrMT.
+		int32_t out_hom_ref = 0, out_het = 0, out_hom_alt = 0;
+		double o_het = 0.0, e_het = 0.0, p_hwe = 1.0;
+		bool stats_are_null;
+		bool counts_are_null = false;
+		if (sex_aware) {
+			if (sac.sex_unavailable) {
+				counts_are_null = true;
+				stats_are_null = true;
+			} else if (sac.hwe_defined) {
+				out_hom_ref = static_cast<int32_t>(sac.hwe_hom_ref);
+				out_het = static_cast<int32_t>(sac.hwe_het);
+				out_hom_alt = static_cast<int32_t>(sac.hwe_hom_alt);
+				uint32_t fobs = sac.hwe_hom_ref + sac.hwe_het + sac.hwe_hom_alt;
+				if (fobs == 0) {
+					stats_are_null = true;
+				} else {
+					stats_are_null = false;
+					o_het = static_cast<double>(sac.hwe_het) / static_cast<double>(fobs);
+					double p = (2.0 * sac.hwe_hom_ref + sac.hwe_het) / (2.0 * fobs);
+					e_het = 2.0 * p * (1.0 - p);
+					// males contribute only to geno_hom_* (het -> missing), females to both
+					int32_t male_ref = static_cast<int32_t>(sac.geno_hom_ref) - static_cast<int32_t>(sac.hwe_hom_ref);
+					int32_t male_alt = static_cast<int32_t>(sac.geno_hom_alt) - static_cast<int32_t>(sac.hwe_hom_alt);
+					p_hwe = HweExactTestXchr(out_hom_ref, out_het, out_hom_alt, male_ref, male_alt, bind_data.midp);
+				}
+			} else {
+				out_hom_ref = static_cast<int32_t>(sac.geno_hom_ref);
+				out_het = static_cast<int32_t>(sac.geno_het);
+				out_hom_alt = static_cast<int32_t>(sac.geno_hom_alt);
+				stats_are_null = true;
+			}
+		} else {
+			uint32_t hom_ref = genocounts[0], het = genocounts[1], hom_alt = genocounts[2];
+			uint32_t obs = hom_ref + het + hom_alt;
+			out_hom_ref = static_cast<int32_t>(hom_ref);
+			out_het = static_cast<int32_t>(het);
+			out_hom_alt = static_cast<int32_t>(hom_alt);
+			stats_are_null = (obs == 0);
+			if (!stats_are_null) {
+				o_het = static_cast<double>(het) / static_cast<double>(obs);
+				double p = (2.0 * hom_ref + het) / (2.0 * obs);
+				e_het = 2.0 * p * (1.0 - p);
+				p_hwe = HweExactTestAutosomal(out_hom_ref, out_het, out_hom_alt, bind_data.midp);
+			}
+		}
+
+		for (idx_t out_col = 0; out_col < column_ids.size(); out_col++) {
+			auto file_col = column_ids[out_col];
+			if (file_col == COLUMN_IDENTIFIER_ROW_ID) {
+				continue;
+			}
+			auto &vec = output.data[out_col];
+			if (FillVariantMetadataColumn(variants, file_col, vidx, vec, rows_emitted)) {
+				continue;
+			}
+			auto put_count = [&](int32_t v) {
+				if (counts_are_null) {
+					FlatVector::SetNull(vec, rows_emitted, true);
+				} else {
+					FlatVector::GetData<int32_t>(vec)[rows_emitted] = v;
+				}
+			};
+			auto put_stat = [&](double v) {
+				if (stats_are_null) {
+					FlatVector::SetNull(vec, rows_emitted, true);
+				} else {
+					FlatVector::GetData<double>(vec)[rows_emitted] = v;
+				}
+			};
+			switch (file_col) {
+			case COL_A1: // tested allele = ALT
+				FillVariantMetadataColumn(variants, 4, vidx, vec, rows_emitted);
+				break;
+			case COL_HOM_REF_CT:
+				put_count(out_hom_ref);
+				break;
+			case COL_HET_CT:
+				put_count(out_het);
+				break;
+			case COL_HOM_ALT_CT:
+				put_count(out_hom_alt);
+				break;
+			case COL_O_HET:
+				put_stat(o_het);
+				break;
+			case COL_E_HET:
+				put_stat(e_het);
+				break;
+			case COL_P_HWE:
+				put_stat(p_hwe);
+				break;
+			default:
+				break;
+			}
+		}
+		rows_emitted++;
+	}
+	CompatSetOutputCardinality(output, rows_emitted);
+}
+
+void RegisterPlinkHardy(ExtensionLoader &loader) {
+	TableFunction plink_hardy("plink_hardy", {LogicalType::VARCHAR}, PlinkHardyScan, PlinkHardyBind,
+	                          PlinkHardyInitGlobal, PlinkHardyInitLocal);
+	plink_hardy.projection_pushdown = true;
+	plink_hardy.named_parameters["pvar"] = LogicalType::VARCHAR;
+	plink_hardy.named_parameters["psam"] = LogicalType::VARCHAR;
+	plink_hardy.named_parameters["samples"] = LogicalType::ANY;
+	plink_hardy.named_parameters["region"] = LogicalType::VARCHAR;
+	plink_hardy.named_parameters["midp"] = LogicalType::BOOLEAN;
+	plink_hardy.named_parameters["build"] = LogicalType::VARCHAR;
+	loader.RegisterFunction(plink_hardy);
+}
+
+} // namespace duckdb

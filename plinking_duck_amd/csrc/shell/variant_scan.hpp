@@ -1,0 +1,232 @@
+// variant_scan.hpp -- the per-variant scan skeleton shared by plink_freq,
+// plink_hardy and plink_missing (variant mode).
+//
+// Reference shape (src/plink_freq.cpp:434-488): each scan thread claims 128
+// variants with fetch_add and calls PgrGetCounts once per variant.  Here a
+// thread claims a *device batch* (kDeviceBatch variants, a multiple of the
+// reference's 128), runs ONE tally launch for it on its own stream, copies the
+// 16 B/variant results back, and then serves its Scan calls (<= 2048 rows each)
+// out of that batch.  A GPU launch + wait always happens inside a Scan call,
+// never by yielding an empty chunk (scan protocol).
+#pragma once
+
+#include "plink_common.hpp"
+
+#include <atomic>
+
+namespace duckdb {
+
+constexpr uint32_t kDeviceBatch = 16384;
+
+struct VariantScanGlobal {
+	std::atomic<uint32_t> next_variant_idx {0};
+	uint32_t start_variant_idx = 0;
+	uint32_t end_variant_idx = 0;
+	shared_ptr<DeviceDataset> dataset;     // null when no genotype-derived column is projected
+	unique_ptr<DeviceSubset> subset;       // samples := [...]
+	unique_ptr<DeviceSubset> male_subset;  // sex strata for chrX/Y/MT (intersected with the subset)
+	unique_ptr<DeviceSubset> female_subset;
+	uint32_t effective_sample_ct = 0;
+	bool want_counts = true;               // false: only the batch claim is needed (read_pgen without filters)
+};
+
+struct VariantScanLocal {
+	uint32_t batch_begin = 0, batch_end = 0, cursor = 0;
+	vector<uint32_t> counts, male_counts, female_counts; // [batch][4]
+	bool have_strata = false;
+
+	//! Advance to the next variant of this thread; returns false when the range is drained.
+	//! needs_strata(begin, end) says whether any variant of the batch is on chrX/Y/MT.
+	template <class NeedStrata>
+	bool Next(VariantScanGlobal &g, const string &func_name, NeedStrata &&needs_strata, uint32_t &vidx) {
+		if (cursor >= batch_end) {
+			uint32_t begin = g.next_variant_idx.fetch_add(kDeviceBatch);
+			if (begin >= g.end_variant_idx) {
+				return false;
+			}
+			uint32_t end = std::min<uint64_t>(g.end_variant_idx, static_cast<uint64_t>(begin) + kDeviceBatch);
+			batch_begin = begin;
+			batch_end = end;
+			cursor = begin;
+			have_strata = false;
+			if (g.dataset && g.want_counts) {
+				Tally(g, g.subset.get(), counts, func_name);
+				if (needs_strata(begin, end) && g.male_subset && g.female_subset) {
+					Tally(g, g.male_subset.get(), male_counts, func_name);
+					Tally(g, g.female_subset.get(), female_counts, func_name);
+					have_strata = true;
+				}
+			}
+		}
+		vidx = cursor++;
+		return true;
+	}
+
+	const uint32_t *Counts(uint32_t vidx) const {
+		return counts.data() + 4 * static_cast<size_t>(vidx - batch_begin);
+	}
+	const uint32_t *MaleCounts(uint32_t vidx) const {
+		return male_counts.data() + 4 * static_cast<size_t>(vidx - batch_begin);
+	}
+	const uint32_t *FemaleCounts(uint32_t vidx) const {
+		return female_counts.data() + 4 * static_cast<size_t>(vidx - batch_begin);
+	}
+
+private:
+	void Tally(VariantScanGlobal &g, DeviceSubset *ss, vector<uint32_t> &out, const string &func_name) {
+		out.resize(4 * static_cast<size_t>(batch_end - batch_begin));
+		char errbuf[PGH_ERRBUF_LEN] = {0};
+		int rc = pgh_counts_range(g.dataset->handle, ss ? ss->handle : nullptr, batch_begin, batch_end,
+		                          reinterpret_cast<uint32_t(*)[4]>(out.data()), errbuf);
+		if (rc != PGH_OK) {
+			throw IOException("%s: PgrGetCounts failed for variants [%u, %u): %s", func_name, batch_begin, batch_end,
+			                  string(errbuf));
+		}
+	}
+};
+
+//! Sex strata masks (male / female, each ANDed with the sample subset if any).
+inline void BuildSexStrata(VariantScanGlobal &g, const SampleInfo &sample_info, const SampleSubset *subset,
+                           uint32_t raw_sample_ct, const string &func_name) {
+	if (sample_info.sexes.empty() || !g.dataset) {
+		return;
+	}
+	vector<uint64_t> male((raw_sample_ct + 63) / 64, 0), female((raw_sample_ct + 63) / 64, 0);
+	for (uint32_t s = 0; s < raw_sample_ct && s < sample_info.sexes.size(); s++) {
+		if (subset && !((subset->sample_include[s >> 6] >> (s & 63)) & 1ull)) {
+			continue;
+		}
+		if (sample_info.sexes[s] == 1) {
+			male[s >> 6] |= 1ull << (s & 63);
+		} else if (sample_info.sexes[s] == 2) {
+			female[s >> 6] |= 1ull << (s & 63);
+		}
+	}
+	g.male_subset = make_uniq<DeviceSubset>(*g.dataset, male, func_name);
+	g.female_subset = make_uniq<DeviceSubset>(*g.dataset, female, func_name);
+}
+
+//! The five metadata columns every per-variant function emits first
+//! (src/plink_freq.cpp:576-607): ID empty -> NULL, ALT "" or "." -> NULL.
+inline bool FillVariantMetadataColumn(const VariantMetadataIndex &variants, idx_t file_col, uint32_t vidx, Vector &vec,
+                                      idx_t row) {
+	switch (file_col) {
+	case 0:
+		FlatVector::GetData<string_t>(vec)[row] = StringVector::AddString(vec, variants.GetChrom(vidx));
+		return true;
+	case 1:
+		FlatVector::GetData<int32_t>(vec)[row] = variants.GetPos(vidx);
+		return true;
+	case 2: {
+		auto &val = variants.GetId(vidx);
+		if (val.empty()) {
+			FlatVector::SetNull(vec, row, true);
+		} else {
+			FlatVector::GetData<string_t>(vec)[row] = StringVector::AddString(vec, val);
+		}
+		return true;
+	}
+	case 3:
+		FlatVector::GetData<string_t>(vec)[row] = StringVector::AddString(vec, variants.GetRef(vidx));
+		return true;
+	case 4: {
+		auto &val = variants.GetAlt(vidx);
+		if (val.empty() || val == ".") {
+			FlatVector::SetNull(vec, row, true);
+		} else {
+			FlatVector::GetData<string_t>(vec)[row] = StringVector::AddString(vec, val);
+		}
+		return true;
+	}
+	default:
+		return false;
+	}
+}
+
+//! Common bind work: companions, header probe, metadata, count checks, samples, region.
+struct PgenBindCommon {
+	string pgen_path, pvar_path, psam_path;
+	VariantMetadataIndex variants;
+	SampleInfo sample_info;
+	bool has_sample_info = false;
+	uint32_t raw_variant_ct = 0, raw_sample_ct = 0;
+	bool file_has_dosage = false, file_has_phase = false;
+	bool has_sample_subset = false;
+	unique_ptr<SampleSubset> sample_subset;
+	uint32_t effective_sample_ct = 0;
+	VariantRange variant_range;
+
+	//! psam_required: plink_score / plink_pca / plink_missing sample mode need IIDs.
+	void Bind(ClientContext &context, TableFunctionBindInput &input, const string &func_name, bool psam_required) {
+		pgen_path = input.inputs[0].GetValue<string>();
+		auto it = input.named_parameters.find("pvar");
+		if (it != input.named_parameters.end()) {
+			pvar_path = it->second.GetValue<string>();
+		}
+		it = input.named_parameters.find("psam");
+		if (it != input.named_parameters.end()) {
+			psam_path = it->second.GetValue<string>();
+		}
+		if (pvar_path.empty()) {
+			pvar_path = FindCompanionFile(pgen_path, {".pvar", ".bim"});
+			if (pvar_path.empty()) {
+				throw InvalidInputException("%s: cannot find .pvar or .bim companion for '%s' "
+				                            "(use pvar := 'path' to specify explicitly)",
+				                            func_name, pgen_path);
+			}
+		}
+		if (psam_path.empty()) {
+			psam_path = FindCompanionFile(pgen_path, {".psam", ".fam"});
+			if (psam_path.empty() && psam_required) {
+				throw InvalidInputException("%s: cannot find .psam or .fam companion for '%s' "
+				                            "(use psam := 'path' to specify explicitly)",
+				                            func_name, pgen_path);
+			}
+		}
+		pgh_info info = ProbePgen(pgen_path, func_name);
+		raw_variant_ct = info.raw_variant_ct;
+		raw_sample_ct = info.raw_sample_ct;
+		file_has_dosage = info.has_dosage != 0;
+		file_has_phase = info.has_phase != 0;
+
+		variants = LoadVariantMetadata(context, pvar_path, func_name);
+		if (variants.variant_ct != raw_variant_ct) {
+			throw InvalidInputException("%s: variant count mismatch: .pgen has %u variants, "
+			                            ".pvar/.bim '%s' has %llu variants",
+			                            func_name, raw_variant_ct, pvar_path,
+			                            static_cast<unsigned long long>(variants.variant_ct));
+		}
+		if (!psam_path.empty()) {
+			sample_info = LoadSampleMetadata(context, psam_path);
+			has_sample_info = true;
+			if (static_cast<uint32_t>(sample_info.sample_ct) != raw_sample_ct) {
+				throw InvalidInputException("%s: sample count mismatch: .pgen has %u samples, "
+				                            ".psam/.fam '%s' has %llu samples",
+				                            func_name, raw_sample_ct, psam_path,
+				                            static_cast<unsigned long long>(sample_info.sample_ct));
+			}
+		}
+		effective_sample_ct = raw_sample_ct;
+		auto samples_it = input.named_parameters.find("samples");
+		if (samples_it != input.named_parameters.end()) {
+			auto indices = ResolveSampleIndices(samples_it->second, raw_sample_ct,
+			                                    has_sample_info ? &sample_info : nullptr, func_name);
+			sample_subset = make_uniq<SampleSubset>(BuildSampleSubset(raw_sample_ct, indices));
+			has_sample_subset = true;
+			effective_sample_ct = sample_subset->subset_sample_ct;
+		}
+		auto region_it = input.named_parameters.find("region");
+		if (region_it != input.named_parameters.end()) {
+			variant_range = ParseRegion(region_it->second.GetValue<string>(), variants, func_name);
+		}
+	}
+
+	uint32_t RangeStart() const {
+		return variant_range.has_filter ? variant_range.start_idx : 0;
+	}
+	uint32_t RangeEnd() const {
+		return variant_range.has_filter ? variant_range.end_idx : raw_variant_ct;
+	}
+};
+
+} // namespace duckdb

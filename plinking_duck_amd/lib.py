@@ -25,8 +25,8 @@ EXPORTED_SYMBOLS = [
     "pgh_synth_create", "pgh_synth_record_host", "pgh_synth_write_files", "pgh_copy_rows_to_host", "pgh_get_info", "pgh_device_rows",
     "pgh_close", "pgh_subset_create", "pgh_subset_size", "pgh_subset_destroy", "pgh_counts_range",
     "pgh_counts_range_dev", "pgh_freq_from_counts_dev", "pgh_missing_per_sample", "pgh_missing_per_sample_dev", "pgh_unpack_range",
-    "pgh_unpack_range_dev", "pgh_score", "pgh_score_dev", "pgh_reader_create", "pgh_reader_destroy",
-    "pgh_get_2bit", "pgh_get_counts", "pgh_get_missingness", "pgh_get_int8", "pgh_get_dosage_f64",
+    "pgh_unpack_range_dev", "pgh_score", "pgh_score_dev", "pgh_pca", "pgh_reader_create", "pgh_reader_destroy",
+    "pgh_get_2bit", "pgh_get_counts", "pgh_get_missingness", "pgh_get_int8", "pgh_get_dosage_f64", "pgh_get_phased",
     "pgh_reader_error", "pgh_hwe_lnp", "pgh_hwe_xchr_lnp", "pgh_hwe_lnp_batch", "pgh_hwe_lnp_batch_dev",
 ]
 
@@ -87,6 +87,7 @@ def _load():
         "pgh_unpack_range_dev": (C.c_int, [vp, vp, u32, u32, vp, C.c_size_t, vp, C.c_int, vp, cp]),
         "pgh_score": (C.c_int, [vp, vp, u32, vp, vp, vp, u32, C.c_int, vp, vp, vp, cp]),
         "pgh_score_dev": (C.c_int, [vp, vp, u32, vp, vp, vp, u32, C.c_int, vp, vp, vp, vp, cp]),
+        "pgh_pca": (C.c_int, [vp, vp, u32, vp, vp, vp, u32, vp, vp, vp, cp]),
         "pgh_reader_create": (C.c_int, [vp, vp, C.POINTER(vp), cp]),
         "pgh_reader_destroy": (None, [vp]),
         "pgh_get_2bit": (C.c_int, [vp, u32, vp]),
@@ -94,6 +95,7 @@ def _load():
         "pgh_get_missingness": (C.c_int, [vp, u32, vp]),
         "pgh_get_int8": (C.c_int, [vp, u32, vp]),
         "pgh_get_dosage_f64": (C.c_int, [vp, u32, vp]),
+        "pgh_get_phased": (C.c_int, [vp, u32, vp, vp, vp]),
         "pgh_reader_error": (cp, [vp]),
         "pgh_hwe_lnp": (C.c_double, [i32, i32, i32, u32]),
         "pgh_hwe_xchr_lnp": (C.c_double, [i32, i32, i32, i32, i32, u32]),
@@ -364,6 +366,20 @@ class Dataset:
         _check(_lib.pgh_score_dev(self._h, subset._h if subset else None, weights.shape[0], _ptr(vidx), _ptr(weights),
                                   _ptr(flip_a), weights.shape[1], mode, d_score, d_dosage, d_allele, stream, eb), eb)
 
+    def pca(self, vidx, center, inv_stdev, n_pcs: int, g1_init, subset: Subset | None = None):
+        vidx = np.ascontiguousarray(vidx, dtype=np.uint32)
+        center = np.ascontiguousarray(center, dtype=np.float64)
+        inv_stdev = np.ascontiguousarray(inv_stdev, dtype=np.float64)
+        g1 = np.ascontiguousarray(g1_init, dtype=np.float64)
+        n_out = subset.size if subset else self.n_samples
+        assert g1.shape == (n_out, 2 * n_pcs)
+        ev = np.zeros(n_pcs, dtype=np.float64)
+        vecs = np.zeros((n_out, n_pcs), dtype=np.float64)
+        eb = _errbuf()
+        _check(_lib.pgh_pca(self._h, subset._h if subset else None, len(vidx), _ptr(vidx), _ptr(center),
+                            _ptr(inv_stdev), n_pcs, _ptr(g1), _ptr(ev), _ptr(vecs), eb), eb)
+        return ev, vecs
+
     def reader(self, subset: Subset | None = None) -> "Reader":
         return Reader(self, subset)
 
@@ -403,6 +419,13 @@ class Reader:
         out = np.zeros(self.n_out, dtype=np.int8)
         self._chk(_lib.pgh_get_int8(self._h, vidx, _ptr(out)))
         return out
+
+    def get_phased(self, vidx: int):
+        g = np.zeros((self.n_out + 31) // 32, dtype=np.uint64)
+        pp = np.zeros((self.n_out + 63) // 64, dtype=np.uint64)
+        pi = np.zeros((self.n_out + 63) // 64, dtype=np.uint64)
+        self._chk(_lib.pgh_get_phased(self._h, vidx, _ptr(g), _ptr(pp), _ptr(pi)))
+        return g, pp, pi
 
     def get_dosage_f64(self, vidx: int) -> np.ndarray:
         out = np.zeros(self.n_out, dtype=np.float64)

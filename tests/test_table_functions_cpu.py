@@ -1,0 +1,148 @@
+"""The table-function shells (C++, csrc/shell) exercised WITHOUT a GPU: what the
+reference's *_negative.test files assert happens at bind time, the registration
+contract, projection pushdown of metadata-only queries, and MaxThreads().
+Message substrings are the ones the reference's tests require."""
+
+import pytest
+
+from conftest import data_path
+
+F = pytest.importorskip("plinking_duck_amd.functions")
+
+EX = data_path("pgen_example.pgen")
+ORPHAN = data_path("pgen_orphan.pgen")
+W = [1.0, 0.5, -0.5, 2.0]
+
+
+def test_registered_functions():
+    assert sorted(F.functions()) == ["plink_freq", "plink_hardy", "plink_missing", "plink_pca", "plink_score",
+                                     "read_pgen"]
+
+
+def err(fn, *args, exc=F.InvalidInputException, **kw):
+    with pytest.raises(exc) as e:
+        F.query(fn, *args, **kw)
+    return str(e.value)
+
+
+@pytest.mark.parametrize("fn", ["plink_freq", "plink_hardy", "plink_missing", "read_pgen"])
+def test_common_bind_errors(fn):
+    # file not found: the function name is in the message (plink_freq_negative.test etc.)
+    assert fn in err(fn, "nonexistent.pgen")
+    assert "cannot find .pvar or .bim" in err(fn, data_path("pgen_no_pvar.pgen"))
+    assert "variant count mismatch" in err(fn, EX, pvar=data_path("mismatched_variants.pvar"))
+    assert "sample count mismatch" in err(fn, EX, psam=data_path("mismatched_samples.psam"))
+    assert "not found" in err(fn, EX, samples=["NONEXISTENT"])
+    assert "out of range" in err(fn, EX, samples=[999])
+    assert "duplicate sample index" in err(fn, EX, samples=[0, 1, 0])
+    assert "samples list must not be empty" in err(fn, EX, samples=[])
+    assert "LIST(INTEGER)" in err(fn, ORPHAN, samples=["SAMPLE1"])
+    with pytest.raises(F.BinderException):
+        F.query(fn, EX, no_such_parameter=1)
+    with pytest.raises(F.BinderException):
+        F.query(fn)
+
+
+@pytest.mark.parametrize("fn", ["plink_freq", "plink_hardy", "plink_missing"])
+def test_region_errors(fn):
+    assert "region" in err(fn, EX, region="invalid")
+    assert "region" in err(fn, EX, region="1:abc-100")
+    assert "region" in err(fn, EX, region=":1-100")
+
+
+def test_build_parameter():
+    assert "unrecognized build" in err("plink_freq", EX, build="hg17")
+    assert "unrecognized build" in err("plink_hardy", EX, build="hg17")
+
+
+def test_missing_mode_errors():
+    assert "mode must be 'variant' or 'sample'" in err("plink_missing", EX, mode="invalid")
+    assert "sample mode requires" in err("plink_missing", ORPHAN, mode="sample")
+
+
+def test_score_bind_errors():
+    assert "plink_score" in err("plink_score", "nonexistent.pgen", weights=[1.0, 0.5])
+    assert "weights parameter is required" in err("plink_score", EX)
+    assert "weights list length" in err("plink_score", EX, weights=[1.0, 0.5])
+    assert "weights list is empty" in err("plink_score", EX, weights=[])
+    assert "weights must not be NULL" in err("plink_score", EX, weights=None)
+    assert "ID-keyed weights must be" in err("plink_score", EX, weights=[{"variant": "rs1", "a1": "G", "beta": 1.0}])
+    assert "cannot find .psam or .fam" in err("plink_score", ORPHAN, weights=W)
+    assert "center and no_mean_imputation cannot both be true" in err("plink_score", EX, weights=W, center=True,
+                                                                     no_mean_imputation=True)
+    assert "variant count mismatch" in err("plink_score", EX, weights=W, pvar=data_path("mismatched_variants.pvar"))
+    assert "region" in err("plink_score", EX, weights=W, region="invalid")
+
+
+def test_pca_bind_errors():
+    pca = data_path("pca_example.pgen")
+    assert "n_pcs must be >= 1" in err("plink_pca", pca, n_pcs=0)
+    assert "n_pcs must be >= 1" in err("plink_pca", pca, n_pcs=-1)
+    assert "invalid mode" in err("plink_pca", pca, mode="invalid")
+    assert "cannot find .pvar" in err("plink_pca", data_path("nonexistent.pgen"))
+    assert "cannot find .psam" in err("plink_pca", ORPHAN)
+
+
+def test_read_pgen_bind_errors():
+    assert "min (0.8) > max (0.2)" in err("read_pgen", EX, af_range={"min": 0.8, "max": 0.2})
+    assert "unknown field 'minimum'" in err("read_pgen", EX, af_range={"minimum": 0.1})
+    assert "out of range" in err("read_pgen", EX, af_range={"min": -0.5})
+    assert "must be a STRUCT" in err("read_pgen", EX, af_range=0.5)
+    assert "unknown category" in err("read_pgen", EX, include_genotypes=["homozygous"])
+    assert "specify only one of" in err("read_pgen", EX, include_genotypes=["het"], genotype_range={"min": 1})
+    assert "dosages and phased cannot both be true" in err("read_pgen", EX, dosages=True, phased=True)
+    assert "incompatible with dosages" in err("read_pgen", EX, genotypes="counts", dosages=True)
+    assert "incompatible with phased" in err("read_pgen", EX, genotypes="stats", phased=True)
+    assert "invalid genotypes value" in err("read_pgen", EX, genotypes="matrix")
+    assert "orient" in err("read_pgen", EX, orient="sample")
+
+
+def test_metadata_only_projection_needs_no_device():
+    """Projection pushdown: with no genotype-derived column projected the shells
+    never open the device (reference: need_frequencies, src/plink_freq.cpp:309-323)."""
+    r = F.query("plink_freq", EX, columns=["CHROM", "POS", "ID", "REF", "ALT"])
+    assert r.sorted("CHROM", "POS") == [("1", 10000, "rs1", "A", "G"), ("1", 20000, "rs2", "C", "T"),
+                                        ("1", 30000, "rs3", "G", "A"), ("2", 15000, "rs4", "T", "C")]
+    assert r.types == ["VARCHAR", "INTEGER", "VARCHAR", "VARCHAR", "VARCHAR"]
+    r = F.query("plink_hardy", EX, columns=["ID", "A1"])
+    assert sorted(r.rows) == [("rs1", "G"), ("rs2", "T"), ("rs3", "A"), ("rs4", "C")]
+    r = F.query("plink_missing", EX, columns=["ID"], region="1:10000-20000")
+    assert sorted(r.column("ID")) == ["rs1", "rs2"]
+    assert len(F.query("plink_freq", EX, columns=["ID"], region="99:1-100")) == 0
+    assert len(F.query("plink_freq", EX, columns=["ID"], region="1:1-9999")) == 0
+    r = F.query("plink_missing", EX, mode="sample", columns=["FID", "IID"])
+    assert sorted(r.rows, key=lambda t: t[1]) == [(None, f"SAMPLE{i}") for i in range(1, 5)]
+    r = F.query("read_pgen", EX, columns=["ID", "POS"])
+    assert len(r) == 4
+    # .bim companion, ALT '.' / empty ID -> NULL handling lives in the same column fill
+    r = F.query("plink_freq", EX, pvar=data_path("pgen_example.bim"), columns=["ID", "REF", "ALT"])
+    assert sorted(r.rows)[0] == ("rs1", "A", "G")
+
+
+def test_output_schemas():
+    r = F.query("plink_freq", EX, columns=["ID"], counts=True, dosage=True)
+    assert r.all_names == ["CHROM", "POS", "ID", "REF", "ALT", "ALT_FREQ", "OBS_CT", "HOM_REF_CT", "HET_CT",
+                           "HOM_ALT_CT", "MISSING_CT", "IMP_R2"]
+    assert F.query("plink_freq", EX, columns=["ID"], dosage=True).all_names[-1] == "IMP_R2"
+    assert F.query("plink_hardy", EX, columns=["ID"]).all_names == [
+        "CHROM", "POS", "ID", "REF", "ALT", "A1", "HOM_REF_CT", "HET_CT", "HOM_ALT_CT", "O_HET", "E_HET", "P_HWE"]
+    assert F.query("plink_missing", EX, columns=["ID"]).all_names[-3:] == ["MISSING_CT", "OBS_CT", "F_MISS"]
+    assert F.query("plink_missing", EX, mode="sample", columns=["IID"]).all_names == [
+        "FID", "IID", "MISSING_CT", "OBS_CT", "F_MISS"]
+    assert F.query("plink_score", EX, weights=W, columns=["IID"]).all_names == [
+        "FID", "IID", "ALLELE_CT", "DENOM", "NAMED_ALLELE_DOSAGE_SUM", "SCORE_SUM", "SCORE_AVG"]
+
+
+def test_max_threads_follow_the_reference_formulas():
+    """MaxThreads(): freq/hardy min(range/500 + 1, cap), cap = plinking_max_threads or 16
+    (src/plink_freq.cpp:84-87, plink_common.cpp:1906-1911); metadata-only scan here."""
+    big = data_path("streaming_example.pgen")  # 50,000 variants
+    assert F.query("plink_freq", big, columns=["ID"], threads=64).threads == 16
+    assert F.query("plink_freq", big, columns=["ID"], threads=64, settings={"plinking_max_threads": 2}).threads == 2
+    assert F.query("plink_freq", big, columns=["ID"], threads=3).threads == 3
+    assert F.query("plink_freq", EX, columns=["ID"], threads=8).threads == 1
+    r = F.query("plink_freq", big, columns=["ID"], threads=8)
+    ids = r.column("ID")
+    assert len(ids) == 50000 and len(set(ids)) == 50000  # no duplicate rows from thread races
+    assert F.query("read_pgen", big, columns=["ID"], threads=64).threads == 16
+    assert F.query("plink_missing", big, columns=["ID"], threads=5).threads == 5

@@ -1,0 +1,365 @@
+"""The six table functions end to end on the GPU, asserting the reference's own
+known answers (tests/golden/known_answers.json <- test/sql/*.test).  Each call
+goes SQL-shaped parameters -> C++ shell (bind/init/scan, multi-threaded) ->
+libpgenhip C ABI -> HIP kernels."""
+
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import data_path
+
+pytestmark = pytest.mark.gpu
+
+F = pytest.importorskip("plinking_duck_amd.functions")
+
+with open(os.path.join(os.path.dirname(__file__), "golden", "known_answers.json")) as f:
+    KA = json.load(f)
+
+EX = data_path("pgen_example.pgen")
+W = [1.0, 0.5, -0.5, 2.0]
+
+
+def r6(x):
+    return None if x is None else round(x, 6)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu(gpu_lib):
+    return gpu_lib
+
+
+# ---- plink_freq (plink_freq.test) ------------------------------------------
+
+def test_freq_known_answers():
+    r = F.query("plink_freq", EX, columns=["CHROM", "POS", "ID", "REF", "ALT", "ALT_FREQ", "OBS_CT"])
+    assert r.sorted("CHROM", "POS") == [("1", 10000, "rs1", "A", "G", 0.5, 6), ("1", 20000, "rs2", "C", "T", 0.5, 8),
+                                        ("1", 30000, "rs3", "G", "A", 0.5, 6), ("2", 15000, "rs4", "T", "C", 0.375, 8)]
+    assert r.types == ["VARCHAR", "INTEGER", "VARCHAR", "VARCHAR", "VARCHAR", "DOUBLE", "INTEGER"]
+    r = F.query("plink_freq", EX, counts=True,
+                columns=["ID", "HOM_REF_CT", "HET_CT", "HOM_ALT_CT", "MISSING_CT", "OBS_CT"])
+    assert r.sorted("ID") == [("rs1", 1, 1, 1, 1, 6), ("rs2", 1, 2, 1, 0, 8), ("rs3", 1, 1, 1, 1, 6),
+                              ("rs4", 2, 1, 1, 0, 8)]
+    assert np.mean(F.query("plink_freq", EX, columns=["ALT_FREQ"]).column("ALT_FREQ")) == 0.46875
+
+
+def test_freq_subsets_regions_companions():
+    for samples in (["SAMPLE1", "SAMPLE3"], [0, 2]):
+        r = dict((row[0], row[1:]) for row in
+                 F.query("plink_freq", EX, samples=samples, columns=["ID", "ALT_FREQ", "OBS_CT"]).rows)
+        assert r["rs1"] == (0.5, 4) and r["rs2"] == (0.25, 4) and r["rs4"] == (0.25, 4)
+    r = F.query("plink_freq", EX, samples=["SAMPLE1", "SAMPLE3"], counts=True,
+                columns=["ID", "HOM_REF_CT", "HET_CT", "HOM_ALT_CT", "MISSING_CT", "OBS_CT"])
+    assert ("rs2", 1, 1, 0, 0, 4) in r.rows
+    assert F.query("plink_freq", data_path("pgen_orphan.pgen"), samples=[0, 2],
+                   columns=["ID", "ALT_FREQ", "OBS_CT"]).sorted("ID")[0] == ("rs1", 0.5, 4)
+    r = F.query("plink_freq", EX, region="1:10000-20000", columns=["ID", "ALT_FREQ", "OBS_CT"])
+    assert r.sorted("ID") == [("rs1", 0.5, 6), ("rs2", 0.5, 8)]
+    assert F.query("plink_freq", EX, region="2:15000-15000", columns=["ID", "ALT_FREQ", "OBS_CT"]).rows == [
+        ("rs4", 0.375, 8)]
+    assert len(F.query("plink_freq", EX, region="1:1-100000")) == 3
+    assert F.query("plink_freq", EX, region="1:10000-10000", samples=["SAMPLE1", "SAMPLE3"],
+                   columns=["ID", "ALT_FREQ", "OBS_CT"]).rows == [("rs1", 0.5, 4)]
+    assert ("rs1", 0.5, 6) in F.query("plink_freq", EX, pvar=data_path("pgen_example.bim"),
+                                      columns=["ID", "ALT_FREQ", "OBS_CT"]).rows
+
+
+def test_freq_all_missing_and_large():
+    r = F.query("plink_freq", data_path("all_missing.pgen"), counts=True,
+                columns=["ID", "ALT_FREQ", "OBS_CT", "HOM_REF_CT", "HET_CT", "HOM_ALT_CT", "MISSING_CT"])
+    assert r.sorted("ID") == [("rs_miss1", None, 0, 0, 0, 0, 2), ("rs_miss2", None, 0, 0, 0, 0, 2)]
+    r = F.query("plink_freq", data_path("large_example.pgen"), columns=["CHROM", "ID", "ALT_FREQ", "OBS_CT"])
+    assert len(r) == 3000 and len(set(r.column("ID"))) == 3000
+    assert set((a, o) for _, _, a, o in r.rows) == {(0.5, 12)}
+    chroms = r.column("CHROM")
+    assert [chroms.count(c) for c in ("1", "2", "3")] == [1000, 1000, 1000]
+    assert len(F.query("plink_freq", data_path("large_example.pgen"), region="1:100-1000")) == 10
+    assert len(F.query("plink_freq", data_path("large_example.pgen"), region="2:100-500")) == 5
+
+
+def test_freq_thread_counts_give_the_same_rows():
+    """streaming_threading.test: exact row count, no duplicates, any thread count."""
+    big = data_path("streaming_example.pgen")
+    base = None
+    for threads, cap in ((1, None), (4, None), (16, 2)):
+        settings = {"plinking_max_threads": cap} if cap else None
+        r = F.query("plink_freq", big, threads=threads, settings=settings, counts=True,
+                    columns=["ID", "ALT_FREQ", "OBS_CT", "HOM_REF_CT", "MISSING_CT"])
+        rows = sorted(r.rows, key=lambda t: t[0])
+        assert len(rows) == 50000 and len(set(t[0] for t in rows)) == 50000
+        base = base or rows
+        assert rows == base
+
+
+def test_freq_dosage():
+    ka = KA["dosage_example"]
+    dz = data_path("dosage_example.pgen")
+    r = F.query("plink_freq", EX, dosage=True, columns=["ID", "ALT_FREQ", "OBS_CT", "IMP_R2"])
+    assert r.sorted("ID") == [("rs1", 0.5, 6, None), ("rs2", 0.5, 8, None), ("rs3", 0.5, 6, None),
+                              ("rs4", 0.375, 8, None)]
+    r = F.query("plink_freq", EX, dosage=True, samples=["SAMPLE1", "SAMPLE3"], columns=["ID", "ALT_FREQ", "OBS_CT"])
+    assert r.sorted("ID") == [("rs1", 0.5, 4), ("rs2", 0.25, 4), ("rs3", 0.75, 4), ("rs4", 0.25, 4)]
+    h = F.query("plink_freq", dz, columns=["ID", "ALT_FREQ", "OBS_CT"]).sorted("ID")
+    d = F.query("plink_freq", dz, dosage=True, columns=["ID", "ALT_FREQ", "OBS_CT", "IMP_R2"]).sorted("ID")
+    for v in range(4):
+        assert h[v][1:] == (ka["hardcall_freq"][v], ka["hardcall_obs"][v])
+        assert d[v][1:3] == (ka["dosage_freq"][v], ka["dosage_obs"][v])
+        assert d[v][3] == pytest.approx(ka["imp_r2"][v], rel=1e-12)
+
+
+# ---- plink_hardy (plink_hardy.test, plink_sexchr.test) ---------------------------
+
+def test_hardy_known_answers():
+    cols = ["ID", "A1", "HOM_REF_CT", "HET_CT", "HOM_ALT_CT", "O_HET", "E_HET", "P_HWE"]
+    rows = F.query("plink_hardy", EX, columns=cols).sorted("ID")
+    mid = F.query("plink_hardy", EX, midp=True, columns=["ID", "P_HWE"]).sorted("ID")
+    for v, exp in enumerate(KA["hardy_pgen_example"]["rows"]):
+        vid, a1, c0, c1, c2, o_het, e_het, p = rows[v]
+        assert (vid, [c0, c1, c2]) == (exp["id"], exp["counts"])
+        assert (r6(o_het), r6(e_het), r6(p)) == (exp["o_het"], exp["e_het"], exp["p"])
+        assert r6(mid[v][1]) == exp["p_midp"]
+        assert mid[v][1] <= p + 1e-6
+    assert [r[1] for r in rows] == ["G", "T", "A", "C"]
+    assert r6(float(np.mean([r[7] for r in rows]))) == 0.857143
+    r = F.query("plink_hardy", EX, samples=["SAMPLE1", "SAMPLE2"], columns=["ID", "HOM_REF_CT", "HET_CT", "HOM_ALT_CT"])
+    assert ("rs1", 1, 1, 0) in r.rows
+    r = F.query("plink_hardy", data_path("pgen_orphan.pgen"), samples=[0, 2], columns=["ID", "P_HWE"])
+    assert r6(dict(r.rows)["rs1"]) == 0.333333
+    r = F.query("plink_hardy", EX, region="1:10000-10000", samples=["SAMPLE1", "SAMPLE3"],
+                columns=["ID", "HOM_REF_CT", "HET_CT", "HOM_ALT_CT"])
+    assert r.rows == [("rs1", 1, 0, 1)]
+    r = F.query("plink_hardy", data_path("all_missing.pgen"),
+                columns=["ID", "HOM_REF_CT", "HET_CT", "HOM_ALT_CT", "O_HET", "P_HWE"])
+    assert r.sorted("ID") == [("rs_miss1", 0, 0, 0, None, None), ("rs_miss2", 0, 0, 0, None, None)]
+    r = F.query("plink_hardy", data_path("large_example.pgen"), columns=["ID", "P_HWE"])
+    assert len(r) == 3000 and set(r6(p) for _, p in r.rows) == {0.480519}
+
+
+def test_sex_chromosomes():
+    sx = data_path("sexchr_example.pgen")
+    ka = KA["sexchr"]
+    fr = dict((r[0], r[1:]) for r in F.query("plink_freq", sx, columns=["ID", "ALT_FREQ", "OBS_CT"]).rows)
+    for vid, (af, obs) in ka["freq"].items():
+        assert (r6(fr[vid][0]), fr[vid][1]) == (af, obs)
+    hw = dict((r[0], r[1:]) for r in F.query(
+        "plink_hardy", sx, columns=["ID", "HOM_REF_CT", "HET_CT", "HOM_ALT_CT", "O_HET", "E_HET", "P_HWE"]).rows)
+    for vid, exp in ka["hardy"].items():
+        c0, c1, c2, o_het, e_het, p = hw[vid]
+        assert [c0, c1, c2] == exp["counts"]
+        if "p" in exp:
+            assert (r6(o_het), r6(e_het), r6(p)) == (exp["o_het"], exp["e_het"], exp["p"])
+        else:
+            assert (o_het, e_het, p) == (None, None, None)  # haploid: HWE undefined
+    mid = dict(F.query("plink_hardy", sx, midp=True, columns=["ID", "P_HWE"]).rows)
+    assert r6(mid["x1"]) == ka["hardy"]["x1"]["p_midp"]
+    cnt = dict((r[0], list(r[1:])) for r in F.query(
+        "plink_freq", sx, counts=True, columns=["ID", "HOM_REF_CT", "HET_CT", "HOM_ALT_CT", "MISSING_CT"]).rows)
+    assert cnt["y1"] == ka["freq_counts_y1"]
+    xp = data_path("sexchr_xpar.pvar")
+    r = dict((r[0], r[1:]) for r in F.query("plink_freq", sx, pvar=xp, columns=["ID", "ALT_FREQ", "OBS_CT"]).rows)
+    assert (r6(r["par1"][0]), r["par1"][1]) == (0.333333, 12)
+    r = dict((r[0], r[1:]) for r in
+             F.query("plink_freq", sx, pvar=xp, build="none", columns=["ID", "ALT_FREQ", "OBS_CT"]).rows)
+    assert list(r["par1"]) == ka["xpar_build_none_par1"]
+
+
+# ---- plink_missing (plink_missing.test, plink_missing_sample.test) ---------------------
+
+def test_missing_variant_and_sample_modes():
+    r = F.query("plink_missing", EX, columns=["ID", "MISSING_CT", "OBS_CT", "F_MISS"])
+    assert r.sorted("ID") == [("rs1", 1, 3, 0.25), ("rs2", 0, 4, 0.0), ("rs3", 1, 3, 0.25), ("rs4", 0, 4, 0.0)]
+    r = F.query("plink_missing", EX, mode="sample", columns=["FID", "IID", "MISSING_CT", "OBS_CT", "F_MISS"])
+    assert r.sorted("IID") == [(None, "SAMPLE1", 0, 4, 0.0), (None, "SAMPLE2", 1, 3, 0.25),
+                               (None, "SAMPLE3", 0, 4, 0.0), (None, "SAMPLE4", 1, 3, 0.25)]
+    r = F.query("plink_missing", EX, mode="sample", samples=["SAMPLE1", "SAMPLE2"],
+                columns=["IID", "MISSING_CT", "OBS_CT", "F_MISS"])
+    assert r.sorted("IID") == [("SAMPLE1", 0, 4, 0.0), ("SAMPLE2", 1, 3, 0.25)]
+    r = F.query("plink_missing", EX, mode="sample", region="1:10000-20000",
+                columns=["IID", "MISSING_CT", "OBS_CT", "F_MISS"])
+    assert r.sorted("IID") == [("SAMPLE1", 0, 2, 0.0), ("SAMPLE2", 0, 2, 0.0), ("SAMPLE3", 0, 2, 0.0),
+                               ("SAMPLE4", 1, 1, 0.5)]
+    r = F.query("plink_missing", EX, mode="sample", region="1:10000-20000", samples=["SAMPLE1", "SAMPLE4"],
+                columns=["IID", "MISSING_CT", "OBS_CT", "F_MISS"])
+    assert r.sorted("IID") == [("SAMPLE1", 0, 2, 0.0), ("SAMPLE4", 1, 1, 0.5)]
+    r = F.query("plink_missing", data_path("all_missing.pgen"), mode="sample",
+                columns=["IID", "MISSING_CT", "OBS_CT", "F_MISS"])
+    assert r.sorted("IID") == [("SAMPLE1", 2, 0, 1.0), ("SAMPLE2", 2, 0, 1.0)]
+    r = F.query("plink_missing", data_path("large_example.pgen"), mode="sample",
+                columns=["MISSING_CT", "OBS_CT", "F_MISS"])
+    assert len(r) == 8 and set(r.rows) == {(750, 2250, 0.25)}
+    # variant mode with a subset: denominator is the subset size
+    r = F.query("plink_missing", EX, samples=[0, 3], columns=["ID", "MISSING_CT", "OBS_CT", "F_MISS"])
+    assert ("rs1", 1, 1, 0.5) in r.rows
+
+
+# ---- plink_score (plink_score.test) -----------------------------------------------
+
+def test_score_known_answers():
+    ka = KA["score_pgen_example"]
+    cols = ["FID", "IID", "ALLELE_CT", "DENOM", "NAMED_ALLELE_DOSAGE_SUM", "SCORE_SUM", "SCORE_AVG"]
+    rows = F.query("plink_score", EX, weights=W, columns=cols).sorted("IID")
+    for i, row in enumerate(rows):
+        assert row == (None, f"SAMPLE{i + 1}", ka["default"]["allele_ct"][i], ka["default"]["allele_ct"][i],
+                       ka["default"]["dosage_sum"][i], ka["default"]["score_sum"][i], ka["default"]["score_avg"][i])
+    idw = [{"id": "rs1", "allele": "G", "weight": 1.0}, {"id": "rs2", "allele": "T", "weight": 0.5},
+           {"id": "rs3", "allele": "A", "weight": -0.5}, {"id": "rs4", "allele": "C", "weight": 2.0}]
+    assert dict(F.query("plink_score", EX, weights=idw, columns=["IID", "SCORE_SUM"]).rows)["SAMPLE1"] == -0.5
+    flip = dict(F.query("plink_score", EX, weights=[{"id": "rs1", "allele": "A", "weight": 1.0}],
+                        columns=["IID", "SCORE_SUM"]).rows)
+    assert (flip["SAMPLE1"], flip["SAMPLE2"], flip["SAMPLE3"], flip["SAMPLE4"]) == (2.0, 1.0, 0.0, 1.0)
+    part = dict(F.query("plink_score", EX, weights=idw[:2], columns=["IID", "SCORE_SUM"]).rows)
+    assert part["SAMPLE1"] == 0.5
+    skip = dict(F.query("plink_score", EX, weights=[idw[0], {"id": "rs_nonexistent", "allele": "A", "weight": 99.0}],
+                        columns=["IID", "SCORE_SUM"]).rows)
+    assert skip["SAMPLE2"] == 1.0
+    z = F.query("plink_score", EX, weights=[0.0] * 4, columns=["IID", "ALLELE_CT", "SCORE_SUM", "SCORE_AVG"])
+    assert ("SAMPLE1", 0, 0.0, 0.0) in z.rows
+    sub = F.query("plink_score", EX, weights=W, samples=["SAMPLE1", "SAMPLE3"], columns=["IID", "SCORE_SUM"])
+    assert len(sub) == 2 and dict(sub.rows)["SAMPLE1"] == -0.5
+    assert len(F.query("plink_score", EX, weights=W, samples=[0, 2])) == 2
+    nm = dict((r[0], r[1:]) for r in F.query("plink_score", EX, weights=W, no_mean_imputation=True,
+                                             columns=["IID", "ALLELE_CT", "SCORE_SUM", "NAMED_ALLELE_DOSAGE_SUM"]).rows)
+    assert nm["SAMPLE2"] == (6, 1.5, 2.0) and nm["SAMPLE4"] == (6, 5.0, 4.0) and nm["SAMPLE1"][1] == -0.5
+    am = F.query("plink_score", data_path("all_missing.pgen"), weights=[1.0, 0.5],
+                 columns=["IID", "ALLELE_CT", "SCORE_SUM", "SCORE_AVG"])
+    assert ("SAMPLE1", 0, 0.0, 0.0) in am.rows
+    rg = dict(F.query("plink_score", EX, weights=[1.0, 0.5], region="1:10000-20000",
+                      columns=["IID", "SCORE_SUM"]).rows)
+    assert rg["SAMPLE1"] == 0.5
+    ce = dict((r[0], r[1:]) for r in F.query("plink_score", EX, weights=[1.0], region="1:20000-20000", center=True,
+                                             columns=["IID", "ALLELE_CT", "NAMED_ALLELE_DOSAGE_SUM", "SCORE_SUM"]).rows)
+    assert ce["SAMPLE1"] == (2, 0.0, 0.0)
+    assert ce["SAMPLE3"][2] == pytest.approx(-1.414213562373095, rel=1e-15)
+    assert ce["SAMPLE4"][2] == pytest.approx(1.414213562373095, rel=1e-15)
+    c2 = dict(F.query("plink_score", EX, weights=W, center=True, columns=["IID", "ALLELE_CT"]).rows)
+    assert c2["SAMPLE2"] == 6
+    assert sum(1 for s in F.query("plink_score", EX, weights=W, columns=["SCORE_SUM"]).column("SCORE_SUM") if s > 0) == 3
+
+
+def test_score_on_a_dosage_file_uses_the_dosages(oracle):
+    """Dosage tracks are honoured (PgrGetD semantics), checked against the oracle."""
+    dz = data_path("dosage_example.pgen")
+    w = [0.3, -1.2, 0.7, 2.0]
+    rows = F.query("plink_score", dz, weights=w, columns=["IID", "ALLELE_CT", "NAMED_ALLELE_DOSAGE_SUM", "SCORE_SUM"])
+    pg = oracle.Pgen(dz)
+    s, d, ac = oracle.score(pg, range(4), w)
+    got = rows.sorted("IID")
+    for i in range(4):
+        assert got[i][1] == ac[i]
+        assert got[i][2] == pytest.approx(d[i], rel=1e-12)
+        assert got[i][3] == pytest.approx(s[i, 0], rel=1e-12)
+
+
+# ---- read_pgen (read_pgen.test, read_pgen_genotypes/filter/dosage/phased.test) ------------------
+
+def test_read_pgen_genotypes():
+    exp = [[(None if g == -9 else g) for g in row] for row in KA["pgen_example_genotypes"]["matrix"]]
+    for mode, typ in (("array", "TINYINT[4]"), ("list", "TINYINT[]"), ("auto", "TINYINT[4]")):
+        r = F.query("read_pgen", EX, genotypes=mode, columns=["ID", "genotypes"])
+        assert r.types[1] == typ
+        assert [g for _, g in r.sorted("ID")] == exp
+    r = F.query("read_pgen", EX, samples=[0, 2], columns=["ID", "genotypes"])
+    assert r.types[1] == "TINYINT[2]" and [g for _, g in r.sorted("ID")] == [[row[0], row[2]] for row in exp]
+    # a samples list is applied as a mask: output order is file order
+    r = F.query("read_pgen", EX, samples=["SAMPLE3", "SAMPLE1"], columns=["ID", "genotypes"])
+    assert [g for _, g in r.sorted("ID")] == [[row[0], row[2]] for row in exp]
+    am = F.query("read_pgen", data_path("all_missing.pgen"), columns=["ID", "genotypes"])
+    assert [g for _, g in am.sorted("ID")] == [[None, None], [None, None]]
+    big = F.query("read_pgen", data_path("large_example.pgen"), columns=["ID", "genotypes"], threads=4)
+    assert len(big) == 3000 and all(len(g) == 8 for _, g in big.rows)
+
+
+def test_read_pgen_counts_stats_and_filters():
+    r = F.query("read_pgen", EX, genotypes="counts", columns=["ID", "genotypes"])
+    got = {vid: [g["hom_ref"], g["het"], g["hom_alt"], g["missing"]] for vid, g in r.rows}
+    assert [got[v] for v in ("rs1", "rs2", "rs3", "rs4")] == KA["pgen_example_freq"]["counts"]
+    r = F.query("read_pgen", EX, genotypes="stats", columns=["ID", "genotypes"])
+    st = dict(r.rows)["rs4"]
+    assert (st["n"], st["af"], st["maf"], st["missing_rate"], st["carrier_count"], st["het_rate"]) == (
+        4, 0.375, 0.375, 0.0, 2, 0.25)
+    st = dict(F.query("read_pgen", data_path("all_missing.pgen"), genotypes="stats",
+                      columns=["ID", "genotypes"]).rows)["rs_miss1"]
+    assert st["n"] == 0 and np.isnan(st["af"]) and st["missing_rate"] == 1.0
+    # af_range keeps rs4 only (0.375); ac_range on the allele count
+    assert F.query("read_pgen", EX, af_range={"max": 0.4}, columns=["ID"]).column("ID") == ["rs4"]
+    assert sorted(F.query("read_pgen", EX, ac_range={"min": 4}, columns=["ID"]).column("ID")) == ["rs2"]
+    # include_genotypes nulls out the other calls but keeps the row if any sample matches
+    r = dict(F.query("read_pgen", EX, include_genotypes=["het"], columns=["ID", "genotypes"]).rows)
+    assert r["rs1"] == [None, 1, None, None] and r["rs2"] == [1, 1, None, None]
+    r = dict(F.query("read_pgen", EX, genotype_range={"min": 2}, columns=["ID", "genotypes"]).rows)
+    assert r["rs1"] == [None, None, 2, None] and "rs1" in r and len(r) == 4
+    r = F.query("read_pgen", data_path("all_missing.pgen"), include_genotypes=["het"], columns=["ID"])
+    assert len(r) == 0
+
+
+def test_read_pgen_dosages_and_phase():
+    ka = KA["dosage_example"]
+    r = F.query("read_pgen", data_path("dosage_example.pgen"), dosages=True, columns=["ID", "genotypes"])
+    assert r.types[1] == "DOUBLE[4]"
+    assert [g for _, g in r.sorted("ID")] == ka["dosages"]
+    h = dict(F.query("read_pgen", data_path("dosage_example.pgen"), columns=["ID", "genotypes"]).rows)
+    assert h["rs2"][0] is None
+    ph = data_path("phased_example.pgen")
+    r = F.query("read_pgen", ph, phased=True, columns=["ID", "genotypes"])
+    assert r.types[1] == "TINYINT[2][4]"
+    assert [g for _, g in r.sorted("ID")] == KA["phased_example"]["pairs"]
+    r = F.query("read_pgen", ph, phased=True, genotypes="list", columns=["ID", "genotypes"])
+    assert r.types[1] == "TINYINT[2][]" and dict(r.rows)["rs2"] == [[0, 1], [1, 0], [0, 0], [1, 1]]
+    r = dict(F.query("read_pgen", ph, phased=True, samples=[0, 2], columns=["ID", "genotypes"]).rows)
+    assert r["rs1"] == [[0, 0], [1, 0]] and r["rs2"] == [[0, 1], [0, 0]]
+    r = dict(F.query("read_pgen", ph, phased=True, samples=["SAMPLE2", "SAMPLE4"], columns=["ID", "genotypes"]).rows)
+    assert r["rs3"] == [None, [0, 0]]
+    assert F.query("read_pgen", ph, columns=["genotypes"]).types == ["TINYINT[4]"]
+
+
+# ---- plink_pca (plink_pca.test) ------------------------------------------------------
+
+def test_pca_known_answers():
+    pca = data_path("pca_example.pgen")
+    ka = KA["pca_example"]
+    for threads in (1, 4):
+        r = F.query("plink_pca", pca, n_pcs=3, mode="pcs", threads=threads)
+        assert r.names == ["PC", "EIGENVALUE", "VARIANCE_PROPORTION", "CUMULATIVE_VARIANCE"]
+        rows = r.sorted("PC")
+        assert [row[0] for row in rows] == [1, 2, 3]
+        assert [round(row[1], 10) for row in rows] == ka["eigenvalues_round10"]
+        assert rows[0][1] == pytest.approx(ka["eigenvalue1_full"], rel=1e-9)
+        assert round(sum(row[2] for row in rows), 6) == 1.0 and max(row[3] for row in rows) == pytest.approx(1.0)
+    r = F.query("plink_pca", pca, n_pcs=3)
+    assert r.names == ["FID", "IID", "PC1", "PC2", "PC3"] and len(r) == 250
+    assert sorted(r.column("IID"))[:3] == ["per0", "per1", "per10"] and None not in r.column("PC1")
+    vecs = np.array([row[2:] for row in r.rows])
+    assert np.allclose(vecs.T @ vecs, np.eye(3), atol=1e-9)
+    assert len(F.query("plink_pca", pca, columns=["IID"]).all_names) == 12  # default n_pcs = 10
+    both = F.query("plink_pca", pca, n_pcs=3, mode="both")
+    assert len(both) == 1 and len(both.rows[0][0]) == 250
+    assert [round(x, 10) for x in both.rows[0][1]] == ka["eigenvalues_round10"]
+    assert len(F.query("plink_pca", pca, n_pcs=3, region="1:1-5000")) == 250
+    ten = [f"per{i}" for i in range(10)]
+    assert len(F.query("plink_pca", pca, n_pcs=1, samples=ten)) == 10
+    with pytest.raises(F.InvalidInputException, match="too few samples"):
+        F.query("plink_pca", data_path("large_example.pgen"), n_pcs=3)
+    with pytest.raises(F.InvalidInputException, match="too few variants"):
+        F.query("plink_pca", data_path("pgen_example.pgen"), n_pcs=1)
+    with pytest.raises(F.InvalidInputException, match="n_pcs"):
+        F.query("plink_pca", pca, n_pcs=250)
+
+
+def test_pca_matches_oracle_with_subset(gpu_lib, oracle):
+    """pgh_pca against the numpy restatement, eigenvectors up to sign."""
+    path = data_path("pca_example.pgen")
+    pg = oracle.Pgen(path)
+    rng = np.random.default_rng(4)
+    mask = rng.random(pg.N) < 0.8
+    ev, vecs, m_eff = oracle.pca(pg, 2, include=mask.astype(np.uint8))
+    names = oracle.load_psam(data_path("pca_example.psam"))["iid"]
+    r = F.query("plink_pca", path, n_pcs=2, samples=[names[i] for i in np.flatnonzero(mask)])
+    got = np.array([row[2:] for row in sorted(r.rows, key=lambda t: names.index(t[1]))])
+    for pc in range(2):
+        sign = np.sign(np.dot(got[:, pc], vecs[:, pc]))
+        assert np.allclose(got[:, pc] * sign, vecs[:, pc], rtol=0, atol=1e-7)
+    ev_got = F.query("plink_pca", path, n_pcs=2, mode="pcs",
+                     samples=[names[i] for i in np.flatnonzero(mask)]).sorted("PC")
+    assert [row[1] for row in ev_got] == pytest.approx(list(ev), rel=1e-6)
