@@ -114,6 +114,7 @@ def main():
     import torch
 
     import plinking_duck_amd.lib as L
+    from plinking_duck_amd import sharding
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -132,11 +133,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     n = args.samples
-    if args.scaling == "weak":
-        v_begin, v_end = rank * args.variants, (rank + 1) * args.variants
-    else:
-        per = (args.variants + world - 1) // world
-        v_begin, v_end = min(args.variants, rank * per), min(args.variants, (rank + 1) * per)
+    v_begin, v_end = sharding.shard_range(rank, world, args.variants, args.scaling)
     m = v_end - v_begin
     ds = L.Dataset.synth(v_begin, v_end, n, SEED, MISSING_RATE)
     record_bytes = ds.info.record_bytes
@@ -234,8 +231,7 @@ def main():
                 kernel_events.append((e0, e1))
             if dist is not None:
                 # per-sample partials of the variant shards: RCCL reduce over xGMI
-                dist.reduce(d_score, dst=0)
-                dist.reduce(d_dos, dst=0)
+                sharding.reduce_partials(dist, [d_score, d_dos, d_ac])
 
         kernel_name = "k_score_accumulate"
         metric = f"plink_score genotypes/s ({ncol} weight columns)"
@@ -255,13 +251,11 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = sharding.max_over_ranks(dist, elapsed, dev)
 
     kernel_ms = [a.elapsed_time(b) for a, b in kernel_events]
     kern_avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
-    total_units = units_per_step * world if args.scaling == "weak" else args.variants * n
+    total_units = sharding.total_variants(world, args.variants, args.scaling) * n
     value = total_units * args.steps / elapsed
 
     if algo_flops is not None and args.workload == "score" and args.score_cols >= 4:

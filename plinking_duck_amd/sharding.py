@@ -1,0 +1,42 @@
+"""Variant sharding across ranks (one process per GPU).
+
+plink_freq / plink_hardy / plink_missing(variant) / read_pgen shard by contiguous
+variant ranges with no data-path collective; plink_missing(sample)
+and plink_score additionally sum their per-sample partials with one reduce."""
+
+from __future__ import annotations
+
+
+def shard_range(rank: int, world: int, variants: int, scaling: str = "weak") -> tuple[int, int]:
+    """[v_begin, v_end) of the global variant axis owned by `rank`.
+
+    weak:   every rank owns `variants` rows of a world*variants-row matrix
+    strong: the `variants` rows are split into `world` contiguous, near-equal ranges"""
+    if not 0 <= rank < world:
+        raise ValueError("rank outside world")
+    if scaling == "weak":
+        return rank * variants, (rank + 1) * variants
+    if scaling == "strong":
+        per = (variants + world - 1) // world
+        return min(variants, rank * per), min(variants, (rank + 1) * per)
+    raise ValueError("scaling must be 'weak' or 'strong'")
+
+
+def total_variants(world: int, variants: int, scaling: str = "weak") -> int:
+    return variants * world if scaling == "weak" else variants
+
+
+def reduce_partials(dist, tensors, dst: int = 0):
+    """Sum per-sample partials of the variant shards onto rank `dst` (RCCL over xGMI
+    when the process group is nccl; gloo in the CPU tests)."""
+    for t in tensors:
+        dist.reduce(t, dst=dst)
+
+
+def max_over_ranks(dist, seconds: float, device=None) -> float:
+    """The bench contract: a step takes as long as the slowest rank."""
+    import torch
+
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
