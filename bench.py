@@ -219,13 +219,14 @@ def main():
         d_ac = torch.empty(n, dtype=torch.int32, device=dev)
         algo_bytes = m * (record_bytes + 8 * ncol)
         algo_flops = 2.0 * m * n * ncol
+        plan = ds.score_plan(vidx, w, None, L.SCORE_MEAN_IMPUTE)  # weights + per-variant tables resident
 
         def step(timed):
             if timed:
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
-            ds.score_dev(vidx, w, d_score.data_ptr(), d_dos.data_ptr(), d_ac.data_ptr(), None, L.SCORE_MEAN_IMPUTE, st)
+            plan.run_dev(d_score.data_ptr(), d_dos.data_ptr(), d_ac.data_ptr(), st)
             if timed:
                 e1.record(stream)
                 kernel_events.append((e0, e1))
@@ -233,7 +234,7 @@ def main():
                 # per-sample partials of the variant shards: RCCL reduce over xGMI
                 sharding.reduce_partials(dist, [d_score, d_dos, d_ac])
 
-        kernel_name = "k_score_accumulate"
+        kernel_name = "k_accumulate_mfma"
         metric = f"plink_score genotypes/s ({ncol} weight columns)"
         dtype = "f64"
 

@@ -185,6 +185,18 @@ int pgh_score_dev(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_sc
                   const double *weights, const uint8_t *flip, uint32_t n_cols, int mode, void *d_score_sum,
                   void *d_dosage_sum, void *d_allele_ct, void *stream, char *errbuf);
 
+/* The same in two steps, for callers that score the same weight set repeatedly or
+ * want an enqueue-only launch: the plan uploads vidx / weights / flip once and
+ * runs the tally + table kernels; pgh_score_run_dev only enqueues the memsets
+ * and the accumulate kernel on `stream`. */
+typedef struct pgh_score_plan pgh_score_plan;
+int pgh_score_plan_create(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_scored, const uint32_t *vidx,
+                          const double *weights, const uint8_t *flip, uint32_t n_cols, int mode,
+                          pgh_score_plan **out, char *errbuf);
+int pgh_score_run_dev(const pgh_score_plan *plan, void *d_score_sum, void *d_dosage_sum, void *d_allele_ct,
+                      void *stream, char *errbuf);
+void pgh_score_plan_destroy(pgh_score_plan *plan);
+
 /* plink_pca's randomized subspace iteration (src/plink_pca.cpp:630-1080): n_pcs + 1
  * passes of Y = X G1 (Step A) and G1 = X^T Y / M (Step B) over the n_var effective
  * variants, thin SVD of the M x (n_pcs+1)*2*n_pcs Krylov block, then B = X^T U and

@@ -712,10 +712,14 @@ extern "C" int pgh_missing_per_sample_dev(const pgh_dataset *ds, uint32_t v_begi
 		return rc;
 	}
 	hipStream_t st = static_cast<hipStream_t>(stream);
-	PGH_HIP(hipMemsetAsync(d_out, 0, sizeof(uint32_t) * ds->sample_ct, st), "missing memset");
-	PGH_HIP(pgh::LaunchMissingPerSample(ds->View(), v_begin - ds->v_begin, nullptr, v_end - v_begin,
-	                                    static_cast<uint32_t *>(d_out), st),
-	        "missing-per-sample kernel");
+	// per-slice partial rows: a few MB, stream-ordered so the call stays enqueue-only
+	const size_t scratch_bytes = pgh::MissingPerSampleScratchBytes(ds->record_bytes, v_end - v_begin);
+	void *scratch = nullptr;
+	PGH_HIP(hipMallocAsync(&scratch, scratch_bytes ? scratch_bytes : 16, st), "missing scratch");
+	hipError_t e = pgh::LaunchMissingPerSample(ds->View(), v_begin - ds->v_begin, nullptr, v_end - v_begin,
+	                                           static_cast<uint32_t *>(scratch), static_cast<uint32_t *>(d_out), st);
+	(void)hipFreeAsync(scratch, st);
+	PGH_HIP(e, "missing-per-sample kernel");
 	return PGH_OK;
 }
 
@@ -826,25 +830,40 @@ extern "C" int pgh_unpack_range(const pgh_dataset *ds, const pgh_subset *subset,
 // plink_score
 // ---------------------------------------------------------------------------
 
-namespace {
-
-struct ScoreScratch {
-	DevBuf vlist, weights, flip, counts, ts, td, ac;
+struct pgh_score_plan {
+	const pgh_dataset *ds = nullptr;
+	uint32_t n_scored = 0, n_cols = 0;
+	int mode = 0;
+	void *d_vlist = nullptr, *d_weights = nullptr, *d_flip = nullptr, *d_counts = nullptr, *d_ts = nullptr,
+	     *d_td = nullptr, *d_ac = nullptr;
 };
 
-int ScoreEnqueue(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_scored, const uint32_t *vidx,
-                 const double *weights, const uint8_t *flip, uint32_t n_cols, int mode, ScoreScratch &sc,
-                 double *d_score, double *d_dosage, uint32_t *d_allele, hipStream_t st, char *errbuf) {
-	if (!ds || (n_scored && (!vidx || !weights))) {
+extern "C" void pgh_score_plan_destroy(pgh_score_plan *plan) {
+	if (!plan) {
+		return;
+	}
+	for (void *p : {plan->d_vlist, plan->d_weights, plan->d_flip, plan->d_counts, plan->d_ts, plan->d_td, plan->d_ac}) {
+		if (p) {
+			(void)hipFree(p);
+		}
+	}
+	delete plan;
+}
+
+extern "C" int pgh_score_plan_create(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_scored,
+                                     const uint32_t *vidx, const double *weights, const uint8_t *flip, uint32_t n_cols,
+                                     int mode, pgh_score_plan **out, char *errbuf) {
+	if (!ds || !out || (n_scored && (!vidx || !weights))) {
 		SetErr(errbuf, "null argument");
 		return PGH_ERR_ARG;
 	}
+	*out = nullptr;
 	if (mode < 0 || mode > 2) {
 		SetErr(errbuf, "unknown score mode");
 		return PGH_ERR_ARG;
 	}
-	if (!(n_cols == 1 || n_cols == 2 || n_cols == 4 || n_cols == 8 || n_cols == 16)) {
-		SetErr(errbuf, "n_cols must be 1, 2, 4, 8 or 16");
+	if (n_cols == 0 || n_cols > 4096) {
+		SetErr(errbuf, "n_cols must be between 1 and 4096");
 		return PGH_ERR_ARG;
 	}
 	int rc = CheckSubset(ds, subset, errbuf);
@@ -859,57 +878,82 @@ int ScoreEnqueue(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_sco
 		}
 		local[i] = vidx[i] - ds->v_begin;
 	}
+	std::unique_ptr<pgh_score_plan, void (*)(pgh_score_plan *)> plan(new pgh_score_plan(), pgh_score_plan_destroy);
+	plan->ds = ds;
+	plan->n_scored = n_scored;
+	plan->n_cols = n_cols;
+	plan->mode = mode;
+	if (n_scored) {
+		const uint32_t N = ds->sample_ct;
+		hipStream_t st = hipStreamPerThread;
+		PGH_HIP(hipMalloc(&plan->d_vlist, sizeof(uint32_t) * n_scored), "hipMalloc(score)");
+		PGH_HIP(hipMalloc(&plan->d_weights, sizeof(double) * n_scored * n_cols), "hipMalloc(score)");
+		PGH_HIP(hipMalloc(&plan->d_counts, 16ull * n_scored), "hipMalloc(score)");
+		PGH_HIP(hipMalloc(&plan->d_ts, 32ull * n_scored), "hipMalloc(score)");
+		PGH_HIP(hipMalloc(&plan->d_td, 32ull * n_scored), "hipMalloc(score)");
+		PGH_HIP(hipMalloc(&plan->d_ac, 4ull * n_scored), "hipMalloc(score)");
+		PGH_HIP(hipMemcpyAsync(plan->d_vlist, local.data(), sizeof(uint32_t) * n_scored, hipMemcpyHostToDevice, st),
+		        "score upload");
+		PGH_HIP(hipMemcpyAsync(plan->d_weights, weights, sizeof(double) * n_scored * n_cols, hipMemcpyHostToDevice, st),
+		        "score upload");
+		if (flip) {
+			PGH_HIP(hipMalloc(&plan->d_flip, n_scored), "hipMalloc(score)");
+			PGH_HIP(hipMemcpyAsync(plan->d_flip, flip, n_scored, hipMemcpyHostToDevice, st), "score upload");
+		}
+		// per-variant statistics and contribution tables depend on the data only: once per plan
+		PGH_HIP(pgh::LaunchCounts(ds->View(), 0, static_cast<uint32_t *>(plan->d_vlist), n_scored,
+		                          subset ? subset->d_mask2 : nullptr, subset ? subset->n_out : N,
+		                          static_cast<uint32_t *>(plan->d_counts), st),
+		        "score counts kernel");
+		PGH_HIP(pgh::LaunchScoreTables(static_cast<uint32_t *>(plan->d_counts), static_cast<uint8_t *>(plan->d_flip),
+		                               n_scored, mode, static_cast<double *>(plan->d_ts),
+		                               static_cast<double *>(plan->d_td), static_cast<uint32_t *>(plan->d_ac), st),
+		        "score table kernel");
+		PGH_HIP(hipStreamSynchronize(st), "score plan sync"); // host staging vectors die with this frame
+	}
+	*out = plan.release();
+	return PGH_OK;
+}
+
+extern "C" int pgh_score_run_dev(const pgh_score_plan *plan, void *d_score_sum, void *d_dosage_sum, void *d_allele_ct,
+                                 void *stream, char *errbuf) {
+	if (!plan || !d_score_sum || !d_dosage_sum || !d_allele_ct) {
+		SetErr(errbuf, "null argument");
+		return PGH_ERR_ARG;
+	}
+	const pgh_dataset *ds = plan->ds;
 	const uint32_t N = ds->sample_ct;
-	PGH_HIP(hipMemsetAsync(d_score, 0, sizeof(double) * N * n_cols, st), "score memset");
-	PGH_HIP(hipMemsetAsync(d_dosage, 0, sizeof(double) * N, st), "score memset");
-	PGH_HIP(hipMemsetAsync(d_allele, 0, sizeof(uint32_t) * N, st), "score memset");
-	if (n_scored == 0) {
-		return PGH_OK;
-	}
-	PGH_HIP(sc.vlist.Alloc(sizeof(uint32_t) * n_scored), "hipMalloc(score)");
-	PGH_HIP(sc.weights.Alloc(sizeof(double) * n_scored * n_cols), "hipMalloc(score)");
-	PGH_HIP(sc.counts.Alloc(16ull * n_scored), "hipMalloc(score)");
-	PGH_HIP(sc.ts.Alloc(32ull * n_scored), "hipMalloc(score)");
-	PGH_HIP(sc.td.Alloc(32ull * n_scored), "hipMalloc(score)");
-	PGH_HIP(sc.ac.Alloc(4ull * n_scored), "hipMalloc(score)");
-	PGH_HIP(hipMemcpyAsync(sc.vlist.p, local.data(), sizeof(uint32_t) * n_scored, hipMemcpyHostToDevice, st),
-	        "score upload");
-	PGH_HIP(hipMemcpyAsync(sc.weights.p, weights, sizeof(double) * n_scored * n_cols, hipMemcpyHostToDevice, st),
-	        "score upload");
-	if (flip) {
-		PGH_HIP(sc.flip.Alloc(n_scored), "hipMalloc(score)");
-		PGH_HIP(hipMemcpyAsync(sc.flip.p, flip, n_scored, hipMemcpyHostToDevice, st), "score upload");
-	}
-	// the host vectors above must outlive the async copies
-	PGH_HIP(hipStreamSynchronize(st), "score upload sync");
-	PGH_HIP(pgh::LaunchCounts(ds->View(), 0, sc.vlist.As<uint32_t>(), n_scored, subset ? subset->d_mask2 : nullptr,
-	                          subset ? subset->n_out : N, sc.counts.As<uint32_t>(), st),
-	        "score counts kernel");
-	PGH_HIP(pgh::LaunchScoreTables(sc.counts.As<uint32_t>(), sc.flip.As<uint8_t>(), n_scored, mode, sc.ts.As<double>(),
-	                               sc.td.As<double>(), sc.ac.As<uint32_t>(), st),
-	        "score table kernel");
-	PGH_HIP(pgh::LaunchScoreAccumulate(ds->View(), sc.vlist.As<uint32_t>(), n_scored, sc.weights.As<double>(), n_cols,
-	                                   sc.ts.As<double>(), sc.td.As<double>(), sc.ac.As<uint32_t>(), d_score, d_dosage,
-	                                   d_allele, st),
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	PGH_HIP(hipMemsetAsync(d_score_sum, 0, sizeof(double) * N * plan->n_cols, st), "score memset");
+	PGH_HIP(hipMemsetAsync(d_dosage_sum, 0, sizeof(double) * N, st), "score memset");
+	PGH_HIP(hipMemsetAsync(d_allele_ct, 0, sizeof(uint32_t) * N, st), "score memset");
+	PGH_HIP(pgh::LaunchScoreAccumulate(ds->View(), static_cast<uint32_t *>(plan->d_vlist), plan->n_scored,
+	                                   static_cast<double *>(plan->d_weights), plan->n_cols,
+	                                   static_cast<double *>(plan->d_ts), static_cast<double *>(plan->d_td),
+	                                   static_cast<uint32_t *>(plan->d_ac), plan->mode != PGH_SCORE_CENTER,
+	                                   static_cast<double *>(d_score_sum), static_cast<double *>(d_dosage_sum),
+	                                   static_cast<uint32_t *>(d_allele_ct), st),
 	        "score accumulate kernel");
 	return PGH_OK;
 }
 
-} // namespace
-
 extern "C" int pgh_score_dev(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_scored, const uint32_t *vidx,
                              const double *weights, const uint8_t *flip, uint32_t n_cols, int mode, void *d_score_sum,
                              void *d_dosage_sum, void *d_allele_ct, void *stream, char *errbuf) {
-	ScoreScratch sc;
-	hipStream_t st = static_cast<hipStream_t>(stream);
-	int rc = ScoreEnqueue(ds, subset, n_scored, vidx, weights, flip, n_cols, mode, sc, static_cast<double *>(d_score_sum),
-	                      static_cast<double *>(d_dosage_sum), static_cast<uint32_t *>(d_allele_ct), st, errbuf);
+	pgh_score_plan *plan = nullptr;
+	int rc = pgh_score_plan_create(ds, subset, n_scored, vidx, weights, flip, n_cols, mode, &plan, errbuf);
 	if (rc != PGH_OK) {
 		return rc;
 	}
-	// scratch is freed on return, so the work must have drained
-	PGH_HIP(hipStreamSynchronize(st), "score sync");
-	return PGH_OK;
+	rc = pgh_score_run_dev(plan, d_score_sum, d_dosage_sum, d_allele_ct, stream, errbuf);
+	if (rc == PGH_OK) {
+		hipError_t e = hipStreamSynchronize(static_cast<hipStream_t>(stream)); // the plan's buffers are freed next
+		if (e != hipSuccess) {
+			rc = DeviceFail(errbuf, "score sync", e);
+		}
+	}
+	pgh_score_plan_destroy(plan);
+	return rc;
 }
 
 extern "C" int pgh_score(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_scored, const uint32_t *vidx,
@@ -1007,7 +1051,7 @@ extern "C" int pgh_pca(const pgh_dataset *ds, const pgh_subset *subset, uint32_t
 			// Step B + merge: G1 = X^T Y / M
 			PGH_HIP(hipMemsetAsync(g2, 0, sizeof(double) * N * k2, st), "pca memset");
 			PGH_HIP(pgh::LaunchTableAccumulate(view, d_vlist.As<uint32_t>(), M, y, qq, k2, d_ts.As<double>(), nullptr,
-			                                   nullptr, g2, k2, nullptr, nullptr, st),
+			                                   nullptr, false, g2, k2, nullptr, nullptr, st),
 			        "pca step B");
 			PGH_HIP(pgh::LaunchMaskRows(g2, N, k2, k2, mask2, st), "pca mask");
 			PGH_HIP(pgh::LaunchScale(g2, static_cast<uint64_t>(N) * k2, 1.0 / static_cast<double>(M), st), "pca scale");
@@ -1027,7 +1071,7 @@ extern "C" int pgh_pca(const pgh_dataset *ds, const pgh_subset *subset, uint32_t
 	PGH_HIP(d_bb.Alloc(sizeof(double) * static_cast<size_t>(N) * qq), "hipMalloc(pca)");
 	PGH_HIP(hipMemsetAsync(d_bb.p, 0, sizeof(double) * static_cast<size_t>(N) * qq, st), "pca memset");
 	PGH_HIP(pgh::LaunchTableAccumulate(view, d_vlist.As<uint32_t>(), M, d_qq.As<double>(), qq, qq, d_ts.As<double>(),
-	                                   nullptr, nullptr, d_bb.As<double>(), qq, nullptr, nullptr, st),
+	                                   nullptr, nullptr, false, d_bb.As<double>(), qq, nullptr, nullptr, st),
 	        "pca phase 3");
 	std::vector<double> bb_raw(static_cast<size_t>(N) * qq);
 	PGH_HIP(hipMemcpyAsync(bb_raw.data(), d_bb.p, sizeof(double) * bb_raw.size(), hipMemcpyDeviceToHost, st),

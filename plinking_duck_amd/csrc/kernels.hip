@@ -226,11 +226,15 @@ __global__ __launch_bounds__(256) void k_counts_wave(const uint8_t *__restrict__
 // A lane owns one 16-byte column (64 samples) and walks down a slice of rows.
 // The indicator m = w & (w>>1) & 0x5555.. has one bit per 2-bit slot, so it is
 // added SWAR-style: 2-bit fields (<=3 rows) -> 4-bit fields (<=15) -> 8-bit
-// fields (<=255), then flushed to the uint32 output with atomics.
+// fields (<=255) -> 64 uint32 registers.  Each slice writes its totals to its
+// own slab row with plain stores; k_sum_slabs adds the slices.  No atomics: a
+// lane's 64 counters sit 256 B apart from its neighbour's, the worst shape for
+// the memory-side atomic units.
 
 struct MissAcc {
 	uint32_t a4[8];
 	uint32_t a8[16];
+	uint32_t a32[64];
 };
 
 __device__ __forceinline__ uint32_t MissBits(uint32_t w) {
@@ -257,7 +261,7 @@ __device__ __forceinline__ void Fold4To8(MissAcc &acc) {
 	}
 }
 
-__device__ __forceinline__ void Flush8(MissAcc &acc, uint32_t *out, uint32_t sample0) {
+__device__ __forceinline__ void Fold8To32(MissAcc &acc) {
 	// a8[4j+q] byte b counts sample 16j + 4b + {0,2,1,3}[q]
 #pragma unroll
 	for (int j = 0; j < 4; j++) {
@@ -265,13 +269,10 @@ __device__ __forceinline__ void Flush8(MissAcc &acc, uint32_t *out, uint32_t sam
 		for (int q = 0; q < 4; q++) {
 			const uint32_t word = acc.a8[4 * j + q];
 			acc.a8[4 * j + q] = 0;
-			const uint32_t within = (q == 0) ? 0u : (q == 1 ? 2u : (q == 2 ? 1u : 3u));
+			const int within = (q == 0) ? 0 : (q == 1 ? 2 : (q == 2 ? 1 : 3));
 #pragma unroll
 			for (int b = 0; b < 4; b++) {
-				const uint32_t val = (word >> (8 * b)) & 0xffu;
-				if (val) {
-					atomicAdd(out + sample0 + 16u * j + 4u * b + within, val);
-				}
+				acc.a32[16 * j + 4 * b + within] += (word >> (8 * b)) & 0xffu;
 			}
 		}
 	}
@@ -280,7 +281,8 @@ __device__ __forceinline__ void Flush8(MissAcc &acc, uint32_t *out, uint32_t sam
 __global__ __launch_bounds__(256) void k_missing_cols(const uint8_t *__restrict__ rows, uint64_t pitch,
                                                       uint32_t chunks, uint32_t v_first,
                                                       const uint32_t *__restrict__ vlist, uint32_t v_count,
-                                                      uint32_t slice_len, uint32_t *__restrict__ out) {
+                                                      uint32_t slice_len, uint32_t *__restrict__ slabs,
+                                                      uint32_t slab_stride) {
 	const uint32_t col = blockIdx.x * 256u + threadIdx.x;
 	if (col >= chunks) {
 		return;
@@ -296,33 +298,17 @@ __global__ __launch_bounds__(256) void k_missing_cols(const uint8_t *__restrict_
 	for (int j = 0; j < 16; j++) {
 		acc.a8[j] = 0;
 	}
+#pragma unroll
+	for (int j = 0; j < 64; j++) {
+		acc.a32[j] = 0;
+	}
 	uint32_t n4 = 0, n8 = 0; // rows folded into the 4-bit / 8-bit fields so far
 	uint32_t i = i_begin;
 	auto row_ptr = [&](uint32_t idx) {
 		const uint32_t v = vlist ? vlist[idx] : v_first + idx;
 		return reinterpret_cast<const uint4 *>(rows + static_cast<uint64_t>(v) * pitch) + col;
 	};
-	while (i < i_end) {
-		uint32_t a2[4] = {0, 0, 0, 0};
-		uint32_t take;
-		if (i + 3 <= i_end) {
-			const uint4 w0 = LoadStream(row_ptr(i));
-			const uint4 w1 = LoadStream(row_ptr(i + 1));
-			const uint4 w2 = LoadStream(row_ptr(i + 2));
-			a2[0] = MissBits(w0.x) + MissBits(w1.x) + MissBits(w2.x);
-			a2[1] = MissBits(w0.y) + MissBits(w1.y) + MissBits(w2.y);
-			a2[2] = MissBits(w0.z) + MissBits(w1.z) + MissBits(w2.z);
-			a2[3] = MissBits(w0.w) + MissBits(w1.w) + MissBits(w2.w);
-			take = 3;
-		} else {
-			const uint4 w0 = LoadStream(row_ptr(i));
-			a2[0] = MissBits(w0.x);
-			a2[1] = MissBits(w0.y);
-			a2[2] = MissBits(w0.z);
-			a2[3] = MissBits(w0.w);
-			take = 1;
-		}
-		i += take;
+	auto fold = [&](const uint32_t a2[4], uint32_t take) {
 		Fold2To4(acc, a2);
 		n4 += take;
 		if (n4 + 3 > 15) {
@@ -330,13 +316,59 @@ __global__ __launch_bounds__(256) void k_missing_cols(const uint8_t *__restrict_
 			n8 += n4;
 			n4 = 0;
 			if (n8 + 15 > 255) {
-				Flush8(acc, out, col * 64u);
+				Fold8To32(acc);
 				n8 = 0;
 			}
 		}
+	};
+	// main loop: six independent 16-byte loads in flight per lane
+	while (i + 6 <= i_end) {
+		const uint4 w0 = LoadStream(row_ptr(i));
+		const uint4 w1 = LoadStream(row_ptr(i + 1));
+		const uint4 w2 = LoadStream(row_ptr(i + 2));
+		const uint4 w3 = LoadStream(row_ptr(i + 3));
+		const uint4 w4 = LoadStream(row_ptr(i + 4));
+		const uint4 w5 = LoadStream(row_ptr(i + 5));
+		uint32_t a[4], b[4];
+		a[0] = MissBits(w0.x) + MissBits(w1.x) + MissBits(w2.x);
+		a[1] = MissBits(w0.y) + MissBits(w1.y) + MissBits(w2.y);
+		a[2] = MissBits(w0.z) + MissBits(w1.z) + MissBits(w2.z);
+		a[3] = MissBits(w0.w) + MissBits(w1.w) + MissBits(w2.w);
+		b[0] = MissBits(w3.x) + MissBits(w4.x) + MissBits(w5.x);
+		b[1] = MissBits(w3.y) + MissBits(w4.y) + MissBits(w5.y);
+		b[2] = MissBits(w3.z) + MissBits(w4.z) + MissBits(w5.z);
+		b[3] = MissBits(w3.w) + MissBits(w4.w) + MissBits(w5.w);
+		fold(a, 3);
+		fold(b, 3);
+		i += 6;
+	}
+	while (i < i_end) {
+		const uint4 w0 = LoadStream(row_ptr(i));
+		uint32_t a[4] = {MissBits(w0.x), MissBits(w0.y), MissBits(w0.z), MissBits(w0.w)};
+		fold(a, 1);
+		i += 1;
 	}
 	Fold4To8(acc);
-	Flush8(acc, out, col * 64u);
+	Fold8To32(acc);
+	uint4 *dst = reinterpret_cast<uint4 *>(slabs + static_cast<uint64_t>(blockIdx.y) * slab_stride + col * 64u);
+#pragma unroll
+	for (int k = 0; k < 16; k++) {
+		dst[k] = make_uint4(acc.a32[4 * k], acc.a32[4 * k + 1], acc.a32[4 * k + 2], acc.a32[4 * k + 3]);
+	}
+}
+
+// out[s] = sum over slices of slabs[slice][s]
+__global__ __launch_bounds__(256) void k_sum_slabs(const uint32_t *__restrict__ slabs, uint32_t slab_stride,
+                                                   uint32_t n_slabs, uint32_t n, uint32_t *__restrict__ out) {
+	const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+	if (s >= n) {
+		return;
+	}
+	uint32_t acc = 0;
+	for (uint32_t k = 0; k < n_slabs; k++) {
+		acc += slabs[static_cast<uint64_t>(k) * slab_stride + s];
+	}
+	out[s] = acc;
 }
 
 // ---------------------------------------------------------------------------
@@ -568,6 +600,135 @@ __global__ __launch_bounds__(256) void k_score_accumulate(const uint8_t *__restr
 	}
 }
 
+// MFMA form of the accumulate: a true dense contraction
+//   out[s][c] += sum_v  T_v[g(v,s)] * W[v][c]
+// on v_mfma_f64_16x16x4_f64 tiles: M = 16 samples, K = 4 variants, N = 16 columns.
+//   A[i][k] = T_{v_k}[g(v_k, sample i)]   lane l: i = l & 15, k = l >> 4  (table lookup from LDS)
+//   B[k][j] = W[v_k][j]                   lane l: k = l >> 4, j = l & 15
+//   D[i][j]                               lane l, reg r: i = (l >> 4) + 4 r, j = l & 15
+// A wave owns 64 consecutive samples (4 tiles) x NCT column tiles; one 16-byte
+// load per lane (16 lanes share a row, 4 rows per wave) feeds all 4 tiles of a
+// 4-variant group.  Tables / weights / row ids are staged through LDS 64 variants
+// at a time; variant slices (blockIdx.y) are combined with FP64 atomics whose
+// lanes cover 128-byte row segments.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+template <int NCT>
+__global__ __launch_bounds__(256) void k_accumulate_mfma(const uint8_t *__restrict__ rows, uint64_t pitch,
+                                                         uint32_t sample_ct, const uint32_t *__restrict__ vlist,
+                                                         uint32_t n_var, uint32_t slice_len,
+                                                         const double *__restrict__ weights, uint32_t w_stride,
+                                                         uint32_t n_cols, const double *__restrict__ ts,
+                                                         const uint32_t *__restrict__ ac, int track_dosage,
+                                                         double *__restrict__ out, uint32_t out_stride,
+                                                         double *__restrict__ dosage_sum,
+                                                         uint32_t *__restrict__ allele_ct) {
+	constexpr uint32_t kStage = 64;
+	constexpr uint32_t kCols = 16 * NCT;
+	__shared__ double s_ts[kStage][4];
+	__shared__ double s_w[kStage][kCols];
+	__shared__ uint32_t s_ac[kStage];
+	__shared__ uint32_t s_v[kStage];
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wave = threadIdx.x >> 6;
+	const uint32_t li = lane & 15u; // sample within tile (A), column within tile (B, D)
+	const uint32_t lk = lane >> 4;  // variant within the group of 4 (A, B); row group (D)
+	const uint32_t sample_base = (blockIdx.x * 4u + wave) * 64u;
+	const bool wave_live = sample_base < sample_ct; // wave-uniform
+	const uint32_t col_byte = sample_base >> 2;
+	const uint32_t shift = 2u * li;
+	const uint32_t i_begin = blockIdx.y * slice_len;
+	const uint32_t i_end = min(i_begin + slice_len, n_var);
+
+	f64x4 acc[4][NCT];
+#pragma unroll
+	for (int t = 0; t < 4; t++) {
+#pragma unroll
+		for (int c = 0; c < NCT; c++) {
+			acc[t][c] = f64x4 {0.0, 0.0, 0.0, 0.0};
+		}
+	}
+	double dsum[4] = {0.0, 0.0, 0.0, 0.0};
+	uint32_t act[4] = {0, 0, 0, 0};
+
+	for (uint32_t base = i_begin; base < i_end; base += kStage) {
+		const uint32_t cnt = min(kStage, i_end - base);
+		__syncthreads();
+		for (uint32_t k = threadIdx.x; k < kStage * 4u; k += 256u) {
+			s_ts[k >> 2][k & 3] = (k >> 2) < cnt ? ts[4 * static_cast<uint64_t>(base) + k] : 0.0;
+		}
+		for (uint32_t k = threadIdx.x; k < kStage * kCols; k += 256u) {
+			const uint32_t v = k / kCols, c = k % kCols;
+			s_w[v][c] = (v < cnt && c < n_cols) ? weights[static_cast<uint64_t>(base + v) * w_stride + c] : 0.0;
+		}
+		if (threadIdx.x < kStage) {
+			const uint32_t k = threadIdx.x;
+			s_ac[k] = (ac && k < cnt) ? ac[base + k] : 0u;
+			s_v[k] = vlist[base + (k < cnt ? k : 0)];
+		}
+		__syncthreads();
+		if (!wave_live) {
+			continue;
+		}
+		const uint32_t groups = (cnt + 3) / 4;
+		for (uint32_t g4 = 0; g4 < groups; g4++) {
+			const uint32_t k = g4 * 4u + lk;
+			const uint4 w = *reinterpret_cast<const uint4 *>(rows + static_cast<uint64_t>(s_v[k]) * pitch + col_byte);
+			double b[NCT];
+#pragma unroll
+			for (int c = 0; c < NCT; c++) {
+				b[c] = s_w[k][16 * c + li];
+			}
+			const uint32_t ack = s_ac[k];
+			const uint32_t wt[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+			for (int t = 0; t < 4; t++) {
+				const uint32_t g = (wt[t] >> shift) & 3u;
+				const double a = s_ts[k][g];
+				dsum[t] += a;
+				act[t] += (ack >> (g == 3u ? 8 : 0)) & 0xffu;
+#pragma unroll
+				for (int c = 0; c < NCT; c++) {
+					acc[t][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[c], acc[t][c], 0, 0, 0);
+				}
+			}
+		}
+	}
+	if (!wave_live) {
+		return;
+	}
+#pragma unroll
+	for (int t = 0; t < 4; t++) {
+#pragma unroll
+		for (int c = 0; c < NCT; c++) {
+			const uint32_t col = 16u * c + li;
+#pragma unroll
+			for (int r = 0; r < 4; r++) {
+				const uint32_t s = sample_base + 16u * t + lk + 4u * r;
+				if (s < sample_ct && col < n_cols) {
+					unsafeAtomicAdd(out + static_cast<uint64_t>(s) * out_stride + col, acc[t][c][r]);
+				}
+			}
+		}
+		// per-sample extras: this lane saw variants == lk (mod 4) of sample 16t + li
+		double d = dsum[t];
+		uint32_t a = act[t];
+		d += __shfl_xor(d, 16, 64);
+		a += __shfl_xor(a, 16, 64);
+		d += __shfl_xor(d, 32, 64);
+		a += __shfl_xor(a, 32, 64);
+		const uint32_t s = sample_base + 16u * t + li;
+		if (lk == 0 && s < sample_ct) {
+			if (dosage_sum && track_dosage) {
+				unsafeAtomicAdd(dosage_sum + s, d);
+			}
+			if (allele_ct) {
+				atomicAdd(allele_ct + s, a);
+			}
+		}
+	}
+}
+
 // ---------------------------------------------------------------------------
 // plink_pca
 // ---------------------------------------------------------------------------
@@ -786,29 +947,48 @@ hipError_t LaunchFreqFromCounts(const uint32_t *counts, uint32_t n, double *alt_
 	return hipGetLastError();
 }
 
+void MissingPerSamplePlan(uint32_t record_bytes, uint32_t v_count, uint32_t *slice_len_out, uint32_t *slices_out) {
+	const uint32_t chunks = (record_bytes + 15) / 16;
+	const uint32_t col_blocks = (chunks + 255) / 256;
+	// enough row slices for >= ~2048 workgroups (256 CUs x 4 resident x 2), each a multiple of 6 rows
+	uint32_t want_slices = (2048 + col_blocks - 1) / col_blocks;
+	if (want_slices > 1024) {
+		want_slices = 1024;
+	}
+	uint32_t slice_len = (v_count + want_slices - 1) / want_slices;
+	slice_len = ((slice_len + 5) / 6) * 6;
+	if (slice_len < 96) {
+		slice_len = 96;
+	}
+	*slice_len_out = slice_len;
+	*slices_out = v_count ? (v_count + slice_len - 1) / slice_len : 0;
+}
+
+size_t MissingPerSampleScratchBytes(uint32_t record_bytes, uint32_t v_count) {
+	uint32_t slice_len, slices;
+	MissingPerSamplePlan(record_bytes, v_count, &slice_len, &slices);
+	const uint64_t stride = static_cast<uint64_t>((record_bytes + 15) / 16) * 64;
+	return static_cast<size_t>(slices) * stride * sizeof(uint32_t);
+}
+
 hipError_t LaunchMissingPerSample(const RowView &view, uint32_t v_first, const uint32_t *vlist, uint32_t v_count,
-                                  uint32_t *out, hipStream_t stream) {
+                                  uint32_t *scratch, uint32_t *out, hipStream_t stream) {
 	if (v_count == 0) {
-		return hipSuccess;
+		return hipMemsetAsync(out, 0, sizeof(uint32_t) * view.sample_ct, stream);
 	}
 	const uint32_t chunks = static_cast<uint32_t>((static_cast<uint64_t>(view.record_bytes) + 15) / 16);
 	const uint32_t col_blocks = (chunks + 255) / 256;
-	// enough row slices to put >= ~4096 workgroups on the chip, each a multiple of 15 rows
-	uint32_t want_slices = (4096 + col_blocks - 1) / col_blocks;
-	uint32_t slice_len = (v_count + want_slices - 1) / want_slices;
-	slice_len = ((slice_len + 14) / 15) * 15;
-	if (slice_len < 60) {
-		slice_len = 60;
-	}
-	uint32_t slices = (v_count + slice_len - 1) / slice_len;
-	if (slices > 65535u) {
-		slices = 65535u;
-		slice_len = (v_count + slices - 1) / slices;
-		slice_len = ((slice_len + 14) / 15) * 15;
-		slices = (v_count + slice_len - 1) / slice_len;
-	}
+	uint32_t slice_len, slices;
+	MissingPerSamplePlan(view.record_bytes, v_count, &slice_len, &slices);
+	const uint32_t stride = chunks * 64u;
 	hipLaunchKernelGGL(k_missing_cols, dim3(col_blocks, slices), dim3(256), 0, stream, view.rows, view.pitch, chunks,
-	                   v_first, vlist, v_count, slice_len, out);
+	                   v_first, vlist, v_count, slice_len, scratch, stride);
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess) {
+		return e;
+	}
+	hipLaunchKernelGGL(k_sum_slabs, dim3((view.sample_ct + 255) / 256), dim3(256), 0, stream, scratch, stride, slices,
+	                   view.sample_ct, out);
 	return hipGetLastError();
 }
 
@@ -869,14 +1049,62 @@ static hipError_t LaunchAccumulateN(const RowView &view, const uint32_t *vlist, 
 	return hipGetLastError();
 }
 
+template <int NCT>
+static hipError_t LaunchAccumulateMfma(const RowView &view, const uint32_t *vlist, uint32_t n_var,
+                                       const double *weights, uint32_t w_stride, uint32_t n_cols, const double *ts,
+                                       const uint32_t *ac, int track_dosage, double *out, uint32_t out_stride,
+                                       double *dosage_sum, uint32_t *allele_ct, hipStream_t stream) {
+	const uint32_t sample_blocks = (view.sample_ct + 255) / 256;
+	// >= ~2048 workgroups so every CU holds several; slices are multiples of the 64-variant stage
+	uint32_t want_slices = (2048 + sample_blocks - 1) / sample_blocks;
+	uint32_t slice_len = (n_var + want_slices - 1) / want_slices;
+	slice_len = ((slice_len + 63) / 64) * 64;
+	uint32_t slices = (n_var + slice_len - 1) / slice_len;
+	if (slices > 65535u) {
+		slices = 65535u;
+		slice_len = ((n_var + slices - 1) / slices + 63) / 64 * 64;
+		slices = (n_var + slice_len - 1) / slice_len;
+	}
+	hipLaunchKernelGGL((k_accumulate_mfma<NCT>), dim3(sample_blocks, slices), dim3(256), 0, stream, view.rows,
+	                   view.pitch, view.sample_ct, vlist, n_var, slice_len, weights, w_stride, n_cols, ts, ac,
+	                   track_dosage, out, out_stride, dosage_sum, allele_ct);
+	return hipGetLastError();
+}
+
 hipError_t LaunchTableAccumulate(const RowView &view, const uint32_t *vlist, uint32_t n_var, const double *weights,
                                  uint32_t w_stride, uint32_t n_cols, const double *ts, const double *td,
-                                 const uint32_t *ac, double *out, uint32_t out_stride, double *dosage_sum,
-                                 uint32_t *allele_ct, hipStream_t stream) {
+                                 const uint32_t *ac, bool track_dosage, double *out, uint32_t out_stride,
+                                 double *dosage_sum, uint32_t *allele_ct, hipStream_t stream) {
 	if (n_var == 0) {
 		return hipSuccess;
 	}
-	// column blocks of 16/8/4/2/1; the per-sample extras ride on the first block only
+	if (!track_dosage) {
+		td = nullptr;
+	}
+	if (n_cols >= 3) {
+		// dense contraction: FP64 MFMA tiles, 32 columns (2 tiles) per pass, 16 for the tail.
+		// the dosage-sum table equals the score table whenever it is tracked (non-centred plink_score)
+		const int track = track_dosage && dosage_sum != nullptr ? 1 : 0;
+		uint32_t c0 = 0;
+		hipError_t e = hipSuccess;
+		while (c0 < n_cols && e == hipSuccess) {
+			const uint32_t left = n_cols - c0;
+			const bool first = c0 == 0;
+			if (left > 16) {
+				e = LaunchAccumulateMfma<2>(view, vlist, n_var, weights + c0, w_stride, left < 32 ? left : 32, ts,
+				                            first ? ac : nullptr, first && track == 1, out + c0, out_stride,
+				                            first ? dosage_sum : nullptr, first ? allele_ct : nullptr, stream);
+				c0 += 32;
+			} else {
+				e = LaunchAccumulateMfma<1>(view, vlist, n_var, weights + c0, w_stride, left, ts, first ? ac : nullptr,
+				                            first && track == 1, out + c0, out_stride, first ? dosage_sum : nullptr,
+				                            first ? allele_ct : nullptr, stream);
+				c0 += 16;
+			}
+		}
+		return e;
+	}
+	// GEMV-shaped (1-2 columns): HBM-bound, plain FP64 FMAs
 	uint32_t c0 = 0;
 	hipError_t e = hipSuccess;
 	while (c0 < n_cols && e == hipSuccess) {
@@ -885,19 +1113,7 @@ hipError_t LaunchTableAccumulate(const RowView &view, const uint32_t *vlist, uin
 		const uint32_t *ac_b = c0 == 0 ? ac : nullptr;
 		double *ds_b = c0 == 0 ? dosage_sum : nullptr;
 		uint32_t *al_b = c0 == 0 ? allele_ct : nullptr;
-		if (left >= 16) {
-			e = LaunchAccumulateN<16>(view, vlist, n_var, weights + c0, w_stride, ts, td_b, ac_b, out + c0, out_stride,
-			                          ds_b, al_b, stream);
-			c0 += 16;
-		} else if (left >= 8) {
-			e = LaunchAccumulateN<8>(view, vlist, n_var, weights + c0, w_stride, ts, td_b, ac_b, out + c0, out_stride,
-			                         ds_b, al_b, stream);
-			c0 += 8;
-		} else if (left >= 4) {
-			e = LaunchAccumulateN<4>(view, vlist, n_var, weights + c0, w_stride, ts, td_b, ac_b, out + c0, out_stride,
-			                         ds_b, al_b, stream);
-			c0 += 4;
-		} else if (left >= 2) {
+		if (left >= 2) {
 			e = LaunchAccumulateN<2>(view, vlist, n_var, weights + c0, w_stride, ts, td_b, ac_b, out + c0, out_stride,
 			                         ds_b, al_b, stream);
 			c0 += 2;
@@ -912,9 +1128,10 @@ hipError_t LaunchTableAccumulate(const RowView &view, const uint32_t *vlist, uin
 
 hipError_t LaunchScoreAccumulate(const RowView &view, const uint32_t *vlist, uint32_t n_scored, const double *weights,
                                  uint32_t n_cols, const double *ts, const double *td, const uint32_t *ac,
-                                 double *score, double *dosage_sum, uint32_t *allele_ct, hipStream_t stream) {
-	return LaunchTableAccumulate(view, vlist, n_scored, weights, n_cols, n_cols, ts, td, ac, score, n_cols, dosage_sum,
-	                             allele_ct, stream);
+                                 bool track_dosage, double *score, double *dosage_sum, uint32_t *allele_ct,
+                                 hipStream_t stream) {
+	return LaunchTableAccumulate(view, vlist, n_scored, weights, n_cols, n_cols, ts, td, ac, track_dosage, score,
+	                             n_cols, dosage_sum, allele_ct, stream);
 }
 
 hipError_t LaunchNormTables(const double *center, const double *inv_stdev, uint32_t n, double *ts,

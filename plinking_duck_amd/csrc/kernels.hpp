@@ -38,10 +38,12 @@ hipError_t LaunchFreqFromCounts(const uint32_t *counts, uint32_t n, double *alt_
                                 hipStream_t stream);
 
 // ---- per-sample missing tally ----------------------------------------------
-// out[s] += number of rows in [v_first, v_first + v_count) where sample s is missing
-// (out: uint32[round_up(N,64)], zeroed by the caller).
+// out[s] = number of rows in [v_first, v_first + v_count) where sample s is missing
+// (out: uint32[N]).  scratch: MissingPerSampleScratchBytes() bytes of device memory
+// holding one partial row per slice of variants.
+size_t MissingPerSampleScratchBytes(uint32_t record_bytes, uint32_t v_count);
 hipError_t LaunchMissingPerSample(const RowView &view, uint32_t v_first, const uint32_t *vlist, uint32_t v_count,
-                                  uint32_t *out, hipStream_t stream);
+                                  uint32_t *scratch, uint32_t *out, hipStream_t stream);
 
 // ---- 2-bit -> int8 unpack --------------------------------------------------
 // out row i: int8[N] (+pad to out_pitch, multiple of 16) with missing -> fill;
@@ -61,16 +63,19 @@ hipError_t LaunchScoreTables(const uint32_t *counts, const uint8_t *flip, uint32
                              double *td, uint32_t *ac, hipStream_t stream);
 // score[s][c] += sum_i w[i][c]*ts[i][g]; dosage_sum[s] += td[i][g]; allele_ct[s] += ac.
 // Outputs are raw-sample order, zeroed by the caller.
+// track_dosage: dosage_sum[s] += td[i][g] (false in plink_score's center mode, where td is all zero)
 hipError_t LaunchScoreAccumulate(const RowView &view, const uint32_t *vlist, uint32_t n_scored, const double *weights,
                                  uint32_t n_cols, const double *ts, const double *td, const uint32_t *ac,
-                                 double *score, double *dosage_sum, uint32_t *allele_ct, hipStream_t stream);
+                                 bool track_dosage, double *score, double *dosage_sum, uint32_t *allele_ct,
+                                 hipStream_t stream);
 
 // General form: out[s*out_stride + c] += sum_i weights[i*w_stride + c] * ts[i][g(i,s)]
-// for any n_cols (split into column blocks); td/ac/dosage_sum/allele_ct may be NULL.
+// for any n_cols: >= 3 columns run on FP64 MFMA tiles (k_accumulate_mfma), 1-2 columns on
+// plain FMAs; td/ac/dosage_sum/allele_ct may be NULL.
 hipError_t LaunchTableAccumulate(const RowView &view, const uint32_t *vlist, uint32_t n_var, const double *weights,
                                  uint32_t w_stride, uint32_t n_cols, const double *ts, const double *td,
-                                 const uint32_t *ac, double *out, uint32_t out_stride, double *dosage_sum,
-                                 uint32_t *allele_ct, hipStream_t stream);
+                                 const uint32_t *ac, bool track_dosage, double *out, uint32_t out_stride,
+                                 double *dosage_sum, uint32_t *allele_ct, hipStream_t stream);
 
 // ---- plink_pca ----------------------------------------------------------------
 // ts[i] = {(0-c)is, (1-c)is, (2-c)is, 0} (NormalizeGenotypes)

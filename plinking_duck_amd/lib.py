@@ -25,7 +25,8 @@ EXPORTED_SYMBOLS = [
     "pgh_synth_create", "pgh_synth_record_host", "pgh_synth_write_files", "pgh_copy_rows_to_host", "pgh_get_info", "pgh_device_rows",
     "pgh_close", "pgh_subset_create", "pgh_subset_size", "pgh_subset_destroy", "pgh_counts_range",
     "pgh_counts_range_dev", "pgh_freq_from_counts_dev", "pgh_missing_per_sample", "pgh_missing_per_sample_dev", "pgh_unpack_range",
-    "pgh_unpack_range_dev", "pgh_score", "pgh_score_dev", "pgh_pca", "pgh_reader_create", "pgh_reader_destroy",
+    "pgh_unpack_range_dev", "pgh_score", "pgh_score_dev", "pgh_score_plan_create", "pgh_score_run_dev",
+    "pgh_score_plan_destroy", "pgh_pca", "pgh_reader_create", "pgh_reader_destroy",
     "pgh_get_2bit", "pgh_get_counts", "pgh_get_missingness", "pgh_get_int8", "pgh_get_dosage_f64", "pgh_get_phased",
     "pgh_reader_error", "pgh_hwe_lnp", "pgh_hwe_xchr_lnp", "pgh_hwe_lnp_batch", "pgh_hwe_lnp_batch_dev",
 ]
@@ -87,6 +88,9 @@ def _load():
         "pgh_unpack_range_dev": (C.c_int, [vp, vp, u32, u32, vp, C.c_size_t, vp, C.c_int, vp, cp]),
         "pgh_score": (C.c_int, [vp, vp, u32, vp, vp, vp, u32, C.c_int, vp, vp, vp, cp]),
         "pgh_score_dev": (C.c_int, [vp, vp, u32, vp, vp, vp, u32, C.c_int, vp, vp, vp, vp, cp]),
+        "pgh_score_plan_create": (C.c_int, [vp, vp, u32, vp, vp, vp, u32, C.c_int, C.POINTER(vp), cp]),
+        "pgh_score_run_dev": (C.c_int, [vp, vp, vp, vp, vp, cp]),
+        "pgh_score_plan_destroy": (None, [vp]),
         "pgh_pca": (C.c_int, [vp, vp, u32, vp, vp, vp, u32, vp, vp, vp, cp]),
         "pgh_reader_create": (C.c_int, [vp, vp, C.POINTER(vp), cp]),
         "pgh_reader_destroy": (None, [vp]),
@@ -366,6 +370,9 @@ class Dataset:
         _check(_lib.pgh_score_dev(self._h, subset._h if subset else None, weights.shape[0], _ptr(vidx), _ptr(weights),
                                   _ptr(flip_a), weights.shape[1], mode, d_score, d_dosage, d_allele, stream, eb), eb)
 
+    def score_plan(self, vidx, weights, flip=None, mode: int = SCORE_MEAN_IMPUTE, subset: Subset | None = None):
+        return ScorePlan(self, vidx, weights, flip, mode, subset)
+
     def pca(self, vidx, center, inv_stdev, n_pcs: int, g1_init, subset: Subset | None = None):
         vidx = np.ascontiguousarray(vidx, dtype=np.uint32)
         center = np.ascontiguousarray(center, dtype=np.float64)
@@ -382,6 +389,35 @@ class Dataset:
 
     def reader(self, subset: Subset | None = None) -> "Reader":
         return Reader(self, subset)
+
+
+class ScorePlan:
+    """Uploaded weights + per-variant tables of one plink_score call (pgh_score_plan)."""
+
+    def __init__(self, ds: Dataset, vidx, weights, flip, mode, subset):
+        vidx = np.ascontiguousarray(vidx, dtype=np.uint32)
+        weights = np.ascontiguousarray(weights, dtype=np.float64)
+        if weights.ndim == 1:
+            weights = weights.reshape(-1, 1)
+        flip_a = None if flip is None else np.ascontiguousarray(flip, dtype=np.uint8)
+        self.ds = ds
+        self.n_cols = weights.shape[1]
+        self._h = C.c_void_p()
+        eb = _errbuf()
+        _check(_lib.pgh_score_plan_create(ds._h, subset._h if subset else None, weights.shape[0], _ptr(vidx),
+                                          _ptr(weights), _ptr(flip_a), weights.shape[1], mode, C.byref(self._h), eb), eb)
+
+    def run_dev(self, d_score: int, d_dosage: int, d_allele: int, stream: int = 0):
+        eb = _errbuf()
+        _check(_lib.pgh_score_run_dev(self._h, d_score, d_dosage, d_allele, stream, eb), eb)
+
+    def close(self):
+        if self._h:
+            _lib.pgh_score_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        self.close()
 
 
 class Reader:
