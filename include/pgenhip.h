@@ -207,7 +207,10 @@ void pgh_score_plan_destroy(pgh_score_plan *plan);
  *   g1_init                [n_out][2*n_pcs] row-major start matrix (src/plink_pca.cpp:517-523)
  *   eigenvalues            [n_pcs]  (S^2 / n_var)
  *   eigenvectors           [n_out][n_pcs] row-major, defined up to sign
- * The two SVDs run on the host, as the reference's Eigen::BDCSVD does. */
+ * Everything tall stays on the device: the Krylov block is orthonormalised by block
+ * Gram-Schmidt (any orthonormal basis of its column space serves where the reference
+ * takes the left singular vectors), and the final SVD goes through the small
+ * (n_pcs+1)*2*n_pcs square Gram matrix, whose eigen-decomposition runs on the host. */
 int pgh_pca(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_var, const uint32_t *vidx,
             const double *center, const double *inv_stdev, uint32_t n_pcs, const double *g1_init,
             double *eigenvalues, double *eigenvectors, char *errbuf);

@@ -716,7 +716,7 @@ extern "C" int pgh_missing_per_sample_dev(const pgh_dataset *ds, uint32_t v_begi
 	const size_t scratch_bytes = pgh::MissingPerSampleScratchBytes(ds->record_bytes, v_end - v_begin);
 	void *scratch = nullptr;
 	PGH_HIP(hipMallocAsync(&scratch, scratch_bytes ? scratch_bytes : 16, st), "missing scratch");
-	hipError_t e = pgh::LaunchMissingPerSample(ds->View(), v_begin - ds->v_begin, nullptr, v_end - v_begin,
+	hipError_t e = pgh::LaunchMissingPerSample(ds->View(), v_begin - ds->v_begin, nullptr, v_end - v_begin, nullptr,
 	                                           static_cast<uint32_t *>(scratch), static_cast<uint32_t *>(d_out), st);
 	(void)hipFreeAsync(scratch, st);
 	PGH_HIP(e, "missing-per-sample kernel");
@@ -926,7 +926,10 @@ extern "C" int pgh_score_run_dev(const pgh_score_plan *plan, void *d_score_sum, 
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	PGH_HIP(hipMemsetAsync(d_score_sum, 0, sizeof(double) * N * plan->n_cols, st), "score memset");
 	PGH_HIP(hipMemsetAsync(d_dosage_sum, 0, sizeof(double) * N, st), "score memset");
-	PGH_HIP(hipMemsetAsync(d_allele_ct, 0, sizeof(uint32_t) * N, st), "score memset");
+	if (plan->n_scored == 0) {
+		PGH_HIP(hipMemsetAsync(d_allele_ct, 0, sizeof(uint32_t) * N, st), "score memset");
+		return PGH_OK;
+	}
 	PGH_HIP(pgh::LaunchScoreAccumulate(ds->View(), static_cast<uint32_t *>(plan->d_vlist), plan->n_scored,
 	                                   static_cast<double *>(plan->d_weights), plan->n_cols,
 	                                   static_cast<double *>(plan->d_ts), static_cast<double *>(plan->d_td),
@@ -934,6 +937,29 @@ extern "C" int pgh_score_run_dev(const pgh_score_plan *plan, void *d_score_sum, 
 	                                   static_cast<double *>(d_score_sum), static_cast<double *>(d_dosage_sum),
 	                                   static_cast<uint32_t *>(d_allele_ct), st),
 	        "score accumulate kernel");
+	// ALLELE_CT is integer bookkeeping: 2 per scored, non-skipped variant, minus 2 per such
+	// variant at which the sample is missing unless missing calls are mean-imputed
+	// (src/plink_score.cpp:632-651).
+	if (plan->mode == PGH_SCORE_MEAN_IMPUTE) {
+		PGH_HIP(pgh::LaunchAlleleCt(static_cast<uint32_t *>(plan->d_ac), plan->n_scored, nullptr, N,
+		                            static_cast<uint32_t *>(d_allele_ct), st),
+		        "allele count kernel");
+	} else {
+		const size_t scratch_bytes = pgh::MissingPerSampleScratchBytes(ds->record_bytes, plan->n_scored);
+		void *scratch = nullptr, *miss = nullptr;
+		PGH_HIP(hipMallocAsync(&scratch, scratch_bytes ? scratch_bytes : 16, st), "score scratch");
+		PGH_HIP(hipMallocAsync(&miss, sizeof(uint32_t) * ((N + 63) / 64 * 64), st), "score scratch");
+		hipError_t e = pgh::LaunchMissingPerSample(ds->View(), 0, static_cast<uint32_t *>(plan->d_vlist),
+		                                           plan->n_scored, static_cast<uint32_t *>(plan->d_ac),
+		                                           static_cast<uint32_t *>(scratch), static_cast<uint32_t *>(miss), st);
+		if (e == hipSuccess) {
+			e = pgh::LaunchAlleleCt(static_cast<uint32_t *>(plan->d_ac), plan->n_scored, static_cast<uint32_t *>(miss),
+			                        N, static_cast<uint32_t *>(d_allele_ct), st);
+		}
+		(void)hipFreeAsync(scratch, st);
+		(void)hipFreeAsync(miss, st);
+		PGH_HIP(e, "allele count kernels");
+	}
 	return PGH_OK;
 }
 
@@ -1058,35 +1084,98 @@ extern "C" int pgh_pca(const pgh_dataset *ds, const pgh_subset *subset, uint32_t
 			std::swap(g1, g2);
 		}
 	}
-	// Krylov block -> left singular vectors (host)
-	std::vector<double> qq_host(static_cast<size_t>(M) * qq);
-	PGH_HIP(hipMemcpyAsync(qq_host.data(), d_qq.p, sizeof(double) * qq_host.size(), hipMemcpyDeviceToHost, st),
-	        "pca download");
-	PGH_HIP(hipStreamSynchronize(st), "pca sync");
-	std::vector<double> sv;
-	pgh::ThinSvdInPlace(qq_host.data(), M, qq, sv);
-	PGH_HIP(hipMemcpyAsync(d_qq.p, qq_host.data(), sizeof(double) * qq_host.size(), hipMemcpyHostToDevice, st),
-	        "pca upload");
-	// Phase 3: BB = X^T U
+	// Orthonormal basis of the Krylov block's column space, on the device.  The
+	// reference takes the left singular vectors of QQ (src/plink_pca.cpp:683-697); the
+	// only thing phase 3 uses of them is that they are an orthonormal basis of that
+	// space (singular values of B = X^T U do not change under a rotation of U), so a
+	// block Gram-Schmidt does the same job without an M x qq SVD on the host:
+	// per block of 2k columns, project out the finished blocks twice (BCGS2), then
+	// orthonormalise inside the block twice through its 2k x 2k Gram matrix.
+	{
+		DevBuf d_small, d_tmp;
+		PGH_HIP(d_small.Alloc(sizeof(double) * static_cast<size_t>(qq) * k2), "hipMalloc(pca)");
+		PGH_HIP(d_tmp.Alloc(sizeof(double) * static_cast<size_t>(M) * k2), "hipMalloc(pca)");
+		double *q = d_qq.As<double>();
+		std::vector<double> g(static_cast<size_t>(k2) * k2), lam, vec, t(static_cast<size_t>(k2) * k2);
+		for (uint32_t p = 0; p <= n_pcs; p++) {
+			double *bp = q + static_cast<size_t>(p) * k2;
+			const uint32_t prev = p * k2;
+			for (int rep = 0; rep < 2 && prev > 0; rep++) {
+				PGH_HIP(hipMemsetAsync(d_small.p, 0, sizeof(double) * prev * k2, st), "pca memset");
+				PGH_HIP(pgh::LaunchTallGram(q, qq, prev, bp, qq, k2, M, d_small.As<double>(), k2, st), "pca gram");
+				PGH_HIP(pgh::LaunchTallTimesSmall(q, qq, prev, d_small.As<double>(), k2, k2, -1.0, 1.0, bp, qq, bp, qq, M,
+				                                  st),
+				        "pca project");
+			}
+			for (int rep = 0; rep < 2; rep++) {
+				PGH_HIP(hipMemsetAsync(d_small.p, 0, sizeof(double) * k2 * k2, st), "pca memset");
+				PGH_HIP(pgh::LaunchTallGram(bp, qq, k2, bp, qq, k2, M, d_small.As<double>(), k2, st), "pca gram");
+				PGH_HIP(hipMemcpyAsync(g.data(), d_small.p, sizeof(double) * k2 * k2, hipMemcpyDeviceToHost, st),
+				        "pca download");
+				PGH_HIP(hipStreamSynchronize(st), "pca sync");
+				pgh::SymmetricEigen(g, k2, lam, vec);
+				const double floor = lam[0] * 1e-13; // below this a direction is rounding noise
+				for (uint32_t i = 0; i < k2; i++) {
+					for (uint32_t j = 0; j < k2; j++) {
+						t[static_cast<size_t>(i) * k2 + j] =
+						    lam[j] > floor && lam[j] > 0.0 ? vec[static_cast<size_t>(i) * k2 + j] / std::sqrt(lam[j]) : 0.0;
+					}
+				}
+				PGH_HIP(hipMemcpyAsync(d_small.p, t.data(), sizeof(double) * k2 * k2, hipMemcpyHostToDevice, st),
+				        "pca upload");
+				PGH_HIP(pgh::LaunchTallTimesSmall(bp, qq, k2, d_small.As<double>(), k2, k2, 1.0, 0.0, nullptr, 0,
+				                                  d_tmp.As<double>(), k2, M, st),
+				        "pca orthonormalise");
+				PGH_HIP(pgh::LaunchCopyCols(d_tmp.As<double>(), k2, bp, qq, k2, M, st), "pca copy");
+				PGH_HIP(hipStreamSynchronize(st), "pca sync"); // t is reused by the next repetition
+			}
+		}
+	}
+	// Phase 3: BB = X^T U   (src/plink_pca.cpp:664-676)
 	PGH_HIP(d_bb.Alloc(sizeof(double) * static_cast<size_t>(N) * qq), "hipMalloc(pca)");
 	PGH_HIP(hipMemsetAsync(d_bb.p, 0, sizeof(double) * static_cast<size_t>(N) * qq, st), "pca memset");
 	PGH_HIP(pgh::LaunchTableAccumulate(view, d_vlist.As<uint32_t>(), M, d_qq.As<double>(), qq, qq, d_ts.As<double>(),
 	                                   nullptr, nullptr, false, d_bb.As<double>(), qq, nullptr, nullptr, st),
 	        "pca phase 3");
-	std::vector<double> bb_raw(static_cast<size_t>(N) * qq);
-	PGH_HIP(hipMemcpyAsync(bb_raw.data(), d_bb.p, sizeof(double) * bb_raw.size(), hipMemcpyDeviceToHost, st),
-	        "pca download");
-	PGH_HIP(hipStreamSynchronize(st), "pca sync");
-	std::vector<double> bb(static_cast<size_t>(n_out) * qq);
-	Compact<double>(subset, bb_raw.data(), qq, bb.data(), N);
-	pgh::ThinSvdInPlace(bb.data(), n_out, qq, sv);
-	for (uint32_t s = 0; s < n_out; s++) {
-		for (uint32_t pc = 0; pc < n_pcs; pc++) {
-			eigenvectors[static_cast<size_t>(s) * n_pcs + pc] = bb[static_cast<size_t>(s) * qq + pc];
+	PGH_HIP(pgh::LaunchMaskRows(d_bb.As<double>(), N, qq, qq, mask2, st), "pca mask");
+	// Final SVD of BB (src/plink_pca.cpp:700-720) through its qq x qq Gram matrix:
+	// BB^T BB = V S^2 V^T gives the eigenvalues S^2 / M directly and U_k = BB V_k S_k^-1.
+	{
+		DevBuf d_g, d_vk, d_uk;
+		PGH_HIP(d_g.Alloc(sizeof(double) * static_cast<size_t>(qq) * qq), "hipMalloc(pca)");
+		PGH_HIP(d_vk.Alloc(sizeof(double) * static_cast<size_t>(qq) * n_pcs), "hipMalloc(pca)");
+		PGH_HIP(d_uk.Alloc(sizeof(double) * static_cast<size_t>(N) * n_pcs), "hipMalloc(pca)");
+		PGH_HIP(hipMemsetAsync(d_g.p, 0, sizeof(double) * static_cast<size_t>(qq) * qq, st), "pca memset");
+		PGH_HIP(pgh::LaunchTallGram(d_bb.As<double>(), qq, qq, d_bb.As<double>(), qq, qq, N, d_g.As<double>(), qq, st),
+		        "pca gram");
+		std::vector<double> g(static_cast<size_t>(qq) * qq), lam, vec;
+		PGH_HIP(hipMemcpyAsync(g.data(), d_g.p, sizeof(double) * g.size(), hipMemcpyDeviceToHost, st), "pca download");
+		PGH_HIP(hipStreamSynchronize(st), "pca sync");
+		for (uint32_t i = 0; i < qq; i++) { // symmetrise away the atomics' rounding asymmetry
+			for (uint32_t j = i + 1; j < qq; j++) {
+				const double avg = 0.5 * (g[static_cast<size_t>(i) * qq + j] + g[static_cast<size_t>(j) * qq + i]);
+				g[static_cast<size_t>(i) * qq + j] = g[static_cast<size_t>(j) * qq + i] = avg;
+			}
 		}
-	}
-	for (uint32_t pc = 0; pc < n_pcs; pc++) {
-		eigenvalues[pc] = sv[pc] * sv[pc] / static_cast<double>(M);
+		pgh::SymmetricEigen(g, qq, lam, vec);
+		std::vector<double> vk(static_cast<size_t>(qq) * n_pcs);
+		for (uint32_t pc = 0; pc < n_pcs; pc++) {
+			const double l = lam[pc] > 0.0 ? lam[pc] : 0.0;
+			eigenvalues[pc] = l / static_cast<double>(M);
+			const double inv_s = l > 0.0 ? 1.0 / std::sqrt(l) : 0.0;
+			for (uint32_t i = 0; i < qq; i++) {
+				vk[static_cast<size_t>(i) * n_pcs + pc] = vec[static_cast<size_t>(i) * qq + pc] * inv_s;
+			}
+		}
+		PGH_HIP(hipMemcpyAsync(d_vk.p, vk.data(), sizeof(double) * vk.size(), hipMemcpyHostToDevice, st), "pca upload");
+		PGH_HIP(pgh::LaunchTallTimesSmall(d_bb.As<double>(), qq, qq, d_vk.As<double>(), n_pcs, n_pcs, 1.0, 0.0, nullptr, 0,
+		                                  d_uk.As<double>(), n_pcs, N, st),
+		        "pca eigenvectors");
+		std::vector<double> uk_raw(static_cast<size_t>(N) * n_pcs);
+		PGH_HIP(hipMemcpyAsync(uk_raw.data(), d_uk.p, sizeof(double) * uk_raw.size(), hipMemcpyDeviceToHost, st),
+		        "pca download");
+		PGH_HIP(hipStreamSynchronize(st), "pca sync");
+		Compact<double>(subset, uk_raw.data(), n_pcs, eigenvectors, N);
 	}
 	return PGH_OK;
 }

@@ -281,8 +281,9 @@ __device__ __forceinline__ void Fold8To32(MissAcc &acc) {
 __global__ __launch_bounds__(256) void k_missing_cols(const uint8_t *__restrict__ rows, uint64_t pitch,
                                                       uint32_t chunks, uint32_t v_first,
                                                       const uint32_t *__restrict__ vlist, uint32_t v_count,
-                                                      uint32_t slice_len, uint32_t *__restrict__ slabs,
-                                                      uint32_t slab_stride) {
+                                                      uint32_t slice_len, const uint32_t *__restrict__ row_flags,
+                                                      uint32_t *__restrict__ slabs, uint32_t slab_stride) {
+	// row_flags (optional): rows whose low byte is zero are not counted (skipped scored variants)
 	const uint32_t col = blockIdx.x * 256u + threadIdx.x;
 	if (col >= chunks) {
 		return;
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(256) void k_missing_cols(const uint8_t *__restrict_
 		}
 	};
 	// main loop: six independent 16-byte loads in flight per lane
-	while (i + 6 <= i_end) {
+	while (!row_flags && i + 6 <= i_end) {
 		const uint4 w0 = LoadStream(row_ptr(i));
 		const uint4 w1 = LoadStream(row_ptr(i + 1));
 		const uint4 w2 = LoadStream(row_ptr(i + 2));
@@ -343,9 +344,11 @@ __global__ __launch_bounds__(256) void k_missing_cols(const uint8_t *__restrict_
 		i += 6;
 	}
 	while (i < i_end) {
-		const uint4 w0 = LoadStream(row_ptr(i));
-		uint32_t a[4] = {MissBits(w0.x), MissBits(w0.y), MissBits(w0.z), MissBits(w0.w)};
-		fold(a, 1);
+		if (!row_flags || (row_flags[i] & 0xffu)) { // wave-uniform
+			const uint4 w0 = LoadStream(row_ptr(i));
+			uint32_t a[4] = {MissBits(w0.x), MissBits(w0.y), MissBits(w0.z), MissBits(w0.w)};
+			fold(a, 1);
+		}
 		i += 1;
 	}
 	Fold4To8(acc);
@@ -613,29 +616,28 @@ __global__ __launch_bounds__(256) void k_score_accumulate(const uint8_t *__restr
 // lanes cover 128-byte row segments.
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-template <int NCT>
+template <int NCT, bool TRACK_DOSAGE>
 __global__ __launch_bounds__(256) void k_accumulate_mfma(const uint8_t *__restrict__ rows, uint64_t pitch,
                                                          uint32_t sample_ct, const uint32_t *__restrict__ vlist,
                                                          uint32_t n_var, uint32_t slice_len,
                                                          const double *__restrict__ weights, uint32_t w_stride,
                                                          uint32_t n_cols, const double *__restrict__ ts,
-                                                         const uint32_t *__restrict__ ac, int track_dosage,
                                                          double *__restrict__ out, uint32_t out_stride,
-                                                         double *__restrict__ dosage_sum,
-                                                         uint32_t *__restrict__ allele_ct) {
+                                                         double *__restrict__ dosage_sum) {
 	constexpr uint32_t kStage = 64;
 	constexpr uint32_t kCols = 16 * NCT;
-	__shared__ double s_ts[kStage][4];
-	__shared__ double s_w[kStage][kCols];
-	__shared__ uint32_t s_ac[kStage];
-	__shared__ uint32_t s_v[kStage];
+	constexpr uint32_t kWPerThread = kStage * kCols / 256; // weight doubles each thread stages
+	// double-buffered stage: tables / weights / row offsets of 64 variants
+	__shared__ double s_ts[2][kStage][4];
+	__shared__ double s_w[2][kStage][kCols];
+	__shared__ uint64_t s_off[2][kStage];
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = threadIdx.x >> 6;
 	const uint32_t li = lane & 15u; // sample within tile (A), column within tile (B, D)
 	const uint32_t lk = lane >> 4;  // variant within the group of 4 (A, B); row group (D)
 	const uint32_t sample_base = (blockIdx.x * 4u + wave) * 64u;
 	const bool wave_live = sample_base < sample_ct; // wave-uniform
-	const uint32_t col_byte = sample_base >> 2;
+	const uint8_t *col_ptr = rows + (sample_base >> 2);
 	const uint32_t shift = 2u * li;
 	const uint32_t i_begin = blockIdx.y * slice_len;
 	const uint32_t i_end = min(i_begin + slice_len, n_var);
@@ -649,50 +651,86 @@ __global__ __launch_bounds__(256) void k_accumulate_mfma(const uint8_t *__restri
 		}
 	}
 	double dsum[4] = {0.0, 0.0, 0.0, 0.0};
-	uint32_t act[4] = {0, 0, 0, 0};
 
-	for (uint32_t base = i_begin; base < i_end; base += kStage) {
+	// staging registers: the next stage is fetched from global memory while the
+	// current one is being multiplied, then dropped into the other LDS buffer
+	double r_ts = 0.0;
+	double r_w[kWPerThread];
+	uint64_t r_off = 0;
+	auto fetch = [&](uint32_t base) {
 		const uint32_t cnt = min(kStage, i_end - base);
-		__syncthreads();
-		for (uint32_t k = threadIdx.x; k < kStage * 4u; k += 256u) {
-			s_ts[k >> 2][k & 3] = (k >> 2) < cnt ? ts[4 * static_cast<uint64_t>(base) + k] : 0.0;
-		}
-		for (uint32_t k = threadIdx.x; k < kStage * kCols; k += 256u) {
-			const uint32_t v = k / kCols, c = k % kCols;
-			s_w[v][c] = (v < cnt && c < n_cols) ? weights[static_cast<uint64_t>(base + v) * w_stride + c] : 0.0;
+		const uint32_t k = threadIdx.x; // kStage * 4 == 256
+		r_ts = (k >> 2) < cnt ? ts[4 * static_cast<uint64_t>(base) + k] : 0.0;
+#pragma unroll
+		for (uint32_t j = 0; j < kWPerThread; j++) {
+			const uint32_t e = threadIdx.x + 256u * j;
+			const uint32_t v = e / kCols, c = e % kCols;
+			r_w[j] = (v < cnt && c < n_cols) ? weights[static_cast<uint64_t>(base + v) * w_stride + c] : 0.0;
 		}
 		if (threadIdx.x < kStage) {
-			const uint32_t k = threadIdx.x;
-			s_ac[k] = (ac && k < cnt) ? ac[base + k] : 0u;
-			s_v[k] = vlist[base + (k < cnt ? k : 0)];
+			r_off = static_cast<uint64_t>(vlist[base + (threadIdx.x < cnt ? threadIdx.x : 0)]) * pitch;
 		}
-		__syncthreads();
-		if (!wave_live) {
-			continue;
+	};
+	auto commit = [&](uint32_t buf) {
+		s_ts[buf][threadIdx.x >> 2][threadIdx.x & 3] = r_ts;
+#pragma unroll
+		for (uint32_t j = 0; j < kWPerThread; j++) {
+			const uint32_t e = threadIdx.x + 256u * j;
+			s_w[buf][e / kCols][e % kCols] = r_w[j];
 		}
-		const uint32_t groups = (cnt + 3) / 4;
-		for (uint32_t g4 = 0; g4 < groups; g4++) {
-			const uint32_t k = g4 * 4u + lk;
-			const uint4 w = *reinterpret_cast<const uint4 *>(rows + static_cast<uint64_t>(s_v[k]) * pitch + col_byte);
-			double b[NCT];
-#pragma unroll
-			for (int c = 0; c < NCT; c++) {
-				b[c] = s_w[k][16 * c + li];
-			}
-			const uint32_t ack = s_ac[k];
-			const uint32_t wt[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-			for (int t = 0; t < 4; t++) {
-				const uint32_t g = (wt[t] >> shift) & 3u;
-				const double a = s_ts[k][g];
-				dsum[t] += a;
-				act[t] += (ack >> (g == 3u ? 8 : 0)) & 0xffu;
+		if (threadIdx.x < kStage) {
+			s_off[buf][threadIdx.x] = r_off;
+		}
+	};
+
+	if (i_begin < i_end) {
+		fetch(i_begin);
+		commit(0);
+	}
+	__syncthreads();
+	uint32_t buf = 0;
+	for (uint32_t base = i_begin; base < i_end; base += kStage, buf ^= 1u) {
+		const uint32_t cnt = min(kStage, i_end - base);
+		const bool more = base + kStage < i_end;
+		if (more) {
+			fetch(base + kStage);
+		}
+		if (wave_live) {
+			const uint32_t groups = (cnt + 3) / 4;
+			// software pipeline: the next group's 16-byte load is in flight while this one is multiplied
+			uint4 w_next = *reinterpret_cast<const uint4 *>(col_ptr + s_off[buf][lk]);
+			for (uint32_t g4 = 0; g4 < groups; g4++) {
+				const uint32_t k = g4 * 4u + lk;
+				const uint4 w = w_next;
+				if (g4 + 1 < groups) {
+					w_next = *reinterpret_cast<const uint4 *>(col_ptr + s_off[buf][k + 4u]);
+				}
+				double b[NCT];
 #pragma unroll
 				for (int c = 0; c < NCT; c++) {
-					acc[t][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[c], acc[t][c], 0, 0, 0);
+					b[c] = s_w[buf][k][16 * c + li];
+				}
+				const uint32_t wt[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+				for (int t = 0; t < 4; t++) {
+					const uint32_t g = (wt[t] >> shift) & 3u;
+					const double a = s_ts[buf][k][g];
+					if (TRACK_DOSAGE) {
+						dsum[t] += a;
+					}
+#pragma unroll
+					for (int c = 0; c < NCT; c++) {
+						acc[t][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[c], acc[t][c], 0, 0, 0);
+					}
 				}
 			}
 		}
+		if (more) {
+			// buffer buf^1 was last read during the previous stage; every wave has
+			// passed the barrier that ended it
+			commit(buf ^ 1u);
+		}
+		__syncthreads();
 	}
 	if (!wave_live) {
 		return;
@@ -710,22 +748,38 @@ __global__ __launch_bounds__(256) void k_accumulate_mfma(const uint8_t *__restri
 				}
 			}
 		}
-		// per-sample extras: this lane saw variants == lk (mod 4) of sample 16t + li
-		double d = dsum[t];
-		uint32_t a = act[t];
-		d += __shfl_xor(d, 16, 64);
-		a += __shfl_xor(a, 16, 64);
-		d += __shfl_xor(d, 32, 64);
-		a += __shfl_xor(a, 32, 64);
-		const uint32_t s = sample_base + 16u * t + li;
-		if (lk == 0 && s < sample_ct) {
-			if (dosage_sum && track_dosage) {
+		if (TRACK_DOSAGE) {
+			// this lane saw the variants == lk (mod 4) of sample 16t + li
+			double d = dsum[t];
+			d += __shfl_xor(d, 16, 64);
+			d += __shfl_xor(d, 32, 64);
+			const uint32_t s = sample_base + 16u * t + li;
+			if (lk == 0 && s < sample_ct) {
 				unsafeAtomicAdd(dosage_sum + s, d);
 			}
-			if (allele_ct) {
-				atomicAdd(allele_ct + s, a);
-			}
 		}
+	}
+}
+
+// allele_ct[s] = total - 2 * (scored, non-skipped variants at which s is missing)
+// total = sum of the per-variant increments (ac[i] & 0xff); miss == NULL: mean imputation,
+// every sample gets the full total.
+__global__ __launch_bounds__(256) void k_allele_ct(const uint32_t *__restrict__ ac, uint32_t n_scored,
+                                                   const uint32_t *__restrict__ miss, uint32_t sample_ct,
+                                                   uint32_t *__restrict__ allele_ct) {
+	__shared__ uint32_t part[4];
+	uint32_t t = 0;
+	for (uint32_t i = threadIdx.x; i < n_scored; i += 256u) {
+		t += ac[i] & 0xffu;
+	}
+	t = WaveSum(t);
+	if ((threadIdx.x & 63u) == 0) {
+		part[threadIdx.x >> 6] = t;
+	}
+	__syncthreads();
+	const uint32_t total = part[0] + part[1] + part[2] + part[3];
+	for (uint32_t s = blockIdx.x * 256u + threadIdx.x; s < sample_ct; s += gridDim.x * 256u) {
+		allele_ct[s] = total - (miss ? 2u * miss[s] : 0u);
 	}
 }
 
@@ -840,6 +894,95 @@ __global__ __launch_bounds__(256) void k_scale(double *__restrict__ m, uint64_t 
 	if (idx < n) {
 		m[idx] *= f;
 	}
+}
+
+// ---------------------------------------------------------------------------
+// tall-skinny dense helpers for plink_pca's orthonormalisation (FP64)
+// ---------------------------------------------------------------------------
+
+// C[i][j] += sum_r A[r][i] * B[r][j]   (A: m x na, B: m x nb, row-major; C zeroed by the caller)
+// One wave per 16x16 tile of C and per chunk of rows, on v_mfma_f64_16x16x4_f64:
+// K runs over rows, 4 at a time; both operands are 128-byte row segments.
+__global__ __launch_bounds__(256) void k_tall_gram(const double *__restrict__ A, uint32_t lda, uint32_t na,
+                                                   const double *__restrict__ B, uint32_t ldb, uint32_t nb,
+                                                   uint64_t m, uint32_t rows_per_wave, double *__restrict__ C,
+                                                   uint32_t ldc) {
+	const uint32_t tiles_b = (nb + 15) / 16;
+	const uint32_t ta = blockIdx.x / tiles_b, tb = blockIdx.x % tiles_b;
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const uint32_t li = lane & 15u, lk = lane >> 4;
+	const uint64_t r_begin = (static_cast<uint64_t>(blockIdx.y) * 4u + wave) * rows_per_wave;
+	const uint64_t r_end = min(r_begin + rows_per_wave, m);
+	const uint32_t ca = ta * 16u + li, cb = tb * 16u + li;
+	const bool a_ok = ca < na, b_ok = cb < nb;
+	f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+	for (uint64_t r = r_begin; r < r_end; r += 4) {
+		const uint64_t row = r + lk;
+		const bool in = row < r_end;
+		const double a = (in && a_ok) ? A[row * lda + ca] : 0.0;
+		const double b = (in && b_ok) ? B[row * ldb + cb] : 0.0;
+		acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+	}
+	if (r_begin < r_end) {
+#pragma unroll
+		for (int r = 0; r < 4; r++) {
+			const uint32_t i = ta * 16u + lk + 4u * r, j = tb * 16u + li;
+			if (i < na && j < nb) {
+				unsafeAtomicAdd(C + static_cast<uint64_t>(i) * ldc + j, acc[r]);
+			}
+		}
+	}
+}
+
+// out[r][j] = beta * B[r][j] + alpha * sum_i A[r][i] * C[i][j]   (j < nb; C: na x nb, small)
+// 4 rows per workgroup staged in LDS; a lane produces 4 adjacent columns of one row.
+__global__ __launch_bounds__(256) void k_tall_times_small(const double *__restrict__ A, uint32_t lda, uint32_t na,
+                                                          const double *__restrict__ C, uint32_t ldc, uint32_t nb,
+                                                          double alpha, double beta, const double *__restrict__ B,
+                                                          uint32_t ldb, double *__restrict__ out, uint32_t ldo,
+                                                          uint64_t m) {
+	extern __shared__ double s_rows[]; // [4][na]
+	const uint32_t rr = threadIdx.x >> 6, jg = threadIdx.x & 63u;
+	const uint64_t r0 = static_cast<uint64_t>(blockIdx.x) * 4u;
+	for (uint32_t e = threadIdx.x; e < 4u * na; e += 256u) {
+		const uint64_t row = r0 + e / na;
+		s_rows[e] = row < m ? A[row * lda + e % na] : 0.0;
+	}
+	__syncthreads();
+	const uint64_t row = r0 + rr;
+	if (row >= m) {
+		return;
+	}
+	for (uint32_t j0 = jg * 4u; j0 < nb; j0 += 256u) {
+		double acc[4] = {0.0, 0.0, 0.0, 0.0};
+		const uint32_t w = min(4u, nb - j0);
+		for (uint32_t i = 0; i < na; i++) {
+			const double a = s_rows[rr * na + i];
+			const double *c = C + static_cast<uint64_t>(i) * ldc + j0;
+#pragma unroll
+			for (uint32_t q = 0; q < 4; q++) {
+				if (q < w) {
+					acc[q] = fma(a, c[q], acc[q]);
+				}
+			}
+		}
+		for (uint32_t q = 0; q < w; q++) {
+			const double prev = beta != 0.0 ? beta * B[row * ldb + j0 + q] : 0.0;
+			out[row * ldo + j0 + q] = prev + alpha * acc[q];
+		}
+	}
+}
+
+// dst[r][j] = src[r][j] for j < n (strided 2-D copy)
+__global__ __launch_bounds__(256) void k_copy_cols(const double *__restrict__ src, uint32_t lds_, double *__restrict__ dst,
+                                                   uint32_t ldd, uint32_t n, uint64_t m) {
+	const uint64_t idx = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x;
+	if (idx >= m * n) {
+		return;
+	}
+	const uint64_t r = idx / n;
+	const uint32_t j = static_cast<uint32_t>(idx % n);
+	dst[r * ldd + j] = src[r * lds_ + j];
 }
 
 // ---------------------------------------------------------------------------
@@ -972,7 +1115,7 @@ size_t MissingPerSampleScratchBytes(uint32_t record_bytes, uint32_t v_count) {
 }
 
 hipError_t LaunchMissingPerSample(const RowView &view, uint32_t v_first, const uint32_t *vlist, uint32_t v_count,
-                                  uint32_t *scratch, uint32_t *out, hipStream_t stream) {
+                                  const uint32_t *row_flags, uint32_t *scratch, uint32_t *out, hipStream_t stream) {
 	if (v_count == 0) {
 		return hipMemsetAsync(out, 0, sizeof(uint32_t) * view.sample_ct, stream);
 	}
@@ -982,7 +1125,7 @@ hipError_t LaunchMissingPerSample(const RowView &view, uint32_t v_first, const u
 	MissingPerSamplePlan(view.record_bytes, v_count, &slice_len, &slices);
 	const uint32_t stride = chunks * 64u;
 	hipLaunchKernelGGL(k_missing_cols, dim3(col_blocks, slices), dim3(256), 0, stream, view.rows, view.pitch, chunks,
-	                   v_first, vlist, v_count, slice_len, scratch, stride);
+	                   v_first, vlist, v_count, slice_len, row_flags, scratch, stride);
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) {
 		return e;
@@ -1052,22 +1195,32 @@ static hipError_t LaunchAccumulateN(const RowView &view, const uint32_t *vlist, 
 template <int NCT>
 static hipError_t LaunchAccumulateMfma(const RowView &view, const uint32_t *vlist, uint32_t n_var,
                                        const double *weights, uint32_t w_stride, uint32_t n_cols, const double *ts,
-                                       const uint32_t *ac, int track_dosage, double *out, uint32_t out_stride,
-                                       double *dosage_sum, uint32_t *allele_ct, hipStream_t stream) {
+                                       bool track_dosage, double *out, uint32_t out_stride, double *dosage_sum,
+                                       hipStream_t stream) {
 	const uint32_t sample_blocks = (view.sample_ct + 255) / 256;
-	// >= ~2048 workgroups so every CU holds several; slices are multiples of the 64-variant stage
-	uint32_t want_slices = (2048 + sample_blocks - 1) / sample_blocks;
+	// >= ~16k workgroups (each CU holds ~6; many short ones keep the tail of the launch
+	// small); slices are multiples of the 64-variant stage and at least 8 stages long
+	uint32_t want_slices = (16384 + sample_blocks - 1) / sample_blocks;
 	uint32_t slice_len = (n_var + want_slices - 1) / want_slices;
 	slice_len = ((slice_len + 63) / 64) * 64;
+	if (slice_len < 512) {
+		slice_len = 512;
+	}
 	uint32_t slices = (n_var + slice_len - 1) / slice_len;
 	if (slices > 65535u) {
 		slices = 65535u;
 		slice_len = ((n_var + slices - 1) / slices + 63) / 64 * 64;
 		slices = (n_var + slice_len - 1) / slice_len;
 	}
-	hipLaunchKernelGGL((k_accumulate_mfma<NCT>), dim3(sample_blocks, slices), dim3(256), 0, stream, view.rows,
-	                   view.pitch, view.sample_ct, vlist, n_var, slice_len, weights, w_stride, n_cols, ts, ac,
-	                   track_dosage, out, out_stride, dosage_sum, allele_ct);
+	if (track_dosage) {
+		hipLaunchKernelGGL((k_accumulate_mfma<NCT, true>), dim3(sample_blocks, slices), dim3(256), 0, stream,
+		                   view.rows, view.pitch, view.sample_ct, vlist, n_var, slice_len, weights, w_stride, n_cols,
+		                   ts, out, out_stride, dosage_sum);
+	} else {
+		hipLaunchKernelGGL((k_accumulate_mfma<NCT, false>), dim3(sample_blocks, slices), dim3(256), 0, stream,
+		                   view.rows, view.pitch, view.sample_ct, vlist, n_var, slice_len, weights, w_stride, n_cols,
+		                   ts, out, out_stride, dosage_sum);
+	}
 	return hipGetLastError();
 }
 
@@ -1083,22 +1236,22 @@ hipError_t LaunchTableAccumulate(const RowView &view, const uint32_t *vlist, uin
 	}
 	if (n_cols >= 3) {
 		// dense contraction: FP64 MFMA tiles, 32 columns (2 tiles) per pass, 16 for the tail.
-		// the dosage-sum table equals the score table whenever it is tracked (non-centred plink_score)
-		const int track = track_dosage && dosage_sum != nullptr ? 1 : 0;
+		// The dosage-sum table equals the score table whenever it is tracked (non-centred
+		// plink_score); allele counts are integer bookkeeping done by the caller (k_allele_ct).
+		(void)ac;
+		(void)allele_ct;
 		uint32_t c0 = 0;
 		hipError_t e = hipSuccess;
 		while (c0 < n_cols && e == hipSuccess) {
 			const uint32_t left = n_cols - c0;
-			const bool first = c0 == 0;
+			const bool track = c0 == 0 && track_dosage && dosage_sum != nullptr;
 			if (left > 16) {
-				e = LaunchAccumulateMfma<2>(view, vlist, n_var, weights + c0, w_stride, left < 32 ? left : 32, ts,
-				                            first ? ac : nullptr, first && track == 1, out + c0, out_stride,
-				                            first ? dosage_sum : nullptr, first ? allele_ct : nullptr, stream);
+				e = LaunchAccumulateMfma<2>(view, vlist, n_var, weights + c0, w_stride, left < 32 ? left : 32, ts, track,
+				                            out + c0, out_stride, dosage_sum, stream);
 				c0 += 32;
 			} else {
-				e = LaunchAccumulateMfma<1>(view, vlist, n_var, weights + c0, w_stride, left, ts, first ? ac : nullptr,
-				                            first && track == 1, out + c0, out_stride, first ? dosage_sum : nullptr,
-				                            first ? allele_ct : nullptr, stream);
+				e = LaunchAccumulateMfma<1>(view, vlist, n_var, weights + c0, w_stride, left, ts, track, out + c0,
+				                            out_stride, dosage_sum, stream);
 				c0 += 16;
 			}
 		}
@@ -1110,20 +1263,29 @@ hipError_t LaunchTableAccumulate(const RowView &view, const uint32_t *vlist, uin
 	while (c0 < n_cols && e == hipSuccess) {
 		const uint32_t left = n_cols - c0;
 		const double *td_b = c0 == 0 ? td : nullptr;
-		const uint32_t *ac_b = c0 == 0 ? ac : nullptr;
 		double *ds_b = c0 == 0 ? dosage_sum : nullptr;
-		uint32_t *al_b = c0 == 0 ? allele_ct : nullptr;
 		if (left >= 2) {
-			e = LaunchAccumulateN<2>(view, vlist, n_var, weights + c0, w_stride, ts, td_b, ac_b, out + c0, out_stride,
-			                         ds_b, al_b, stream);
+			e = LaunchAccumulateN<2>(view, vlist, n_var, weights + c0, w_stride, ts, td_b, nullptr, out + c0, out_stride,
+			                         ds_b, nullptr, stream);
 			c0 += 2;
 		} else {
-			e = LaunchAccumulateN<1>(view, vlist, n_var, weights + c0, w_stride, ts, td_b, ac_b, out + c0, out_stride,
-			                         ds_b, al_b, stream);
+			e = LaunchAccumulateN<1>(view, vlist, n_var, weights + c0, w_stride, ts, td_b, nullptr, out + c0, out_stride,
+			                         ds_b, nullptr, stream);
 			c0 += 1;
 		}
 	}
 	return e;
+}
+
+hipError_t LaunchAlleleCt(const uint32_t *ac, uint32_t n_scored, const uint32_t *miss, uint32_t sample_ct,
+                          uint32_t *allele_ct, hipStream_t stream) {
+	uint32_t blocks = (sample_ct + 255) / 256;
+	if (blocks > 1024) {
+		blocks = 1024;
+	}
+	hipLaunchKernelGGL(k_allele_ct, dim3(blocks ? blocks : 1), dim3(256), 0, stream, ac, n_scored, miss, sample_ct,
+	                   allele_ct);
+	return hipGetLastError();
 }
 
 hipError_t LaunchScoreAccumulate(const RowView &view, const uint32_t *vlist, uint32_t n_scored, const double *weights,
@@ -1196,6 +1358,47 @@ hipError_t LaunchScale(double *m, uint64_t n, double f, hipStream_t stream) {
 		return hipSuccess;
 	}
 	hipLaunchKernelGGL(k_scale, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, stream, m, n, f);
+	return hipGetLastError();
+}
+
+hipError_t LaunchTallGram(const double *A, uint32_t lda, uint32_t na, const double *B, uint32_t ldb, uint32_t nb,
+                          uint64_t m, double *C, uint32_t ldc, hipStream_t stream) {
+	if (m == 0 || na == 0 || nb == 0) {
+		return hipSuccess;
+	}
+	const uint32_t tiles = ((na + 15) / 16) * ((nb + 15) / 16);
+	// ~1024 waves per tile pair at most, >= 256 rows per wave
+	uint32_t rows_per_wave = 1024;
+	uint64_t chunks = (m + 4ull * rows_per_wave - 1) / (4ull * rows_per_wave);
+	while (chunks > 65535) {
+		rows_per_wave *= 2;
+		chunks = (m + 4ull * rows_per_wave - 1) / (4ull * rows_per_wave);
+	}
+	hipLaunchKernelGGL(k_tall_gram, dim3(tiles, static_cast<uint32_t>(chunks)), dim3(256), 0, stream, A, lda, na, B, ldb,
+	                   nb, m, rows_per_wave, C, ldc);
+	return hipGetLastError();
+}
+
+hipError_t LaunchTallTimesSmall(const double *A, uint32_t lda, uint32_t na, const double *C, uint32_t ldc, uint32_t nb,
+                                double alpha, double beta, const double *B, uint32_t ldb, double *out, uint32_t ldo,
+                                uint64_t m, hipStream_t stream) {
+	if (m == 0 || nb == 0) {
+		return hipSuccess;
+	}
+	const uint64_t blocks = (m + 3) / 4;
+	hipLaunchKernelGGL(k_tall_times_small, dim3(static_cast<uint32_t>(blocks)), dim3(256), 4 * na * sizeof(double), stream,
+	                   A, lda, na, C, ldc, nb, alpha, beta, B, ldb, out, ldo, m);
+	return hipGetLastError();
+}
+
+hipError_t LaunchCopyCols(const double *src, uint32_t ld_src, double *dst, uint32_t ld_dst, uint32_t n, uint64_t m,
+                          hipStream_t stream) {
+	const uint64_t total = m * n;
+	if (total == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_copy_cols, dim3(static_cast<uint32_t>((total + 255) / 256)), dim3(256), 0, stream, src, ld_src,
+	                   dst, ld_dst, n, m);
 	return hipGetLastError();
 }
 

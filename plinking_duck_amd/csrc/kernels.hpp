@@ -42,8 +42,9 @@ hipError_t LaunchFreqFromCounts(const uint32_t *counts, uint32_t n, double *alt_
 // (out: uint32[N]).  scratch: MissingPerSampleScratchBytes() bytes of device memory
 // holding one partial row per slice of variants.
 size_t MissingPerSampleScratchBytes(uint32_t record_bytes, uint32_t v_count);
+// row_flags (optional, one per row): rows whose low byte is zero are left out.
 hipError_t LaunchMissingPerSample(const RowView &view, uint32_t v_first, const uint32_t *vlist, uint32_t v_count,
-                                  uint32_t *scratch, uint32_t *out, hipStream_t stream);
+                                  const uint32_t *row_flags, uint32_t *scratch, uint32_t *out, hipStream_t stream);
 
 // ---- 2-bit -> int8 unpack --------------------------------------------------
 // out row i: int8[N] (+pad to out_pitch, multiple of 16) with missing -> fill;
@@ -69,9 +70,14 @@ hipError_t LaunchScoreAccumulate(const RowView &view, const uint32_t *vlist, uin
                                  bool track_dosage, double *score, double *dosage_sum, uint32_t *allele_ct,
                                  hipStream_t stream);
 
+// allele_ct[s] = sum_i (ac[i] & 0xff) - 2 * miss[s]   (miss == NULL: every sample gets the full sum)
+hipError_t LaunchAlleleCt(const uint32_t *ac, uint32_t n_scored, const uint32_t *miss, uint32_t sample_ct,
+                          uint32_t *allele_ct, hipStream_t stream);
+
 // General form: out[s*out_stride + c] += sum_i weights[i*w_stride + c] * ts[i][g(i,s)]
 // for any n_cols: >= 3 columns run on FP64 MFMA tiles (k_accumulate_mfma), 1-2 columns on
-// plain FMAs; td/ac/dosage_sum/allele_ct may be NULL.
+// plain FMAs; td/dosage_sum may be NULL.  ac/allele_ct are accepted for symmetry but the
+// allele-count bookkeeping is the caller's (LaunchAlleleCt).
 hipError_t LaunchTableAccumulate(const RowView &view, const uint32_t *vlist, uint32_t n_var, const double *weights,
                                  uint32_t w_stride, uint32_t n_cols, const double *ts, const double *td,
                                  const uint32_t *ac, bool track_dosage, double *out, uint32_t out_stride,
@@ -89,6 +95,17 @@ hipError_t LaunchVariantReduce(const RowView &view, const uint32_t *vlist, uint3
 hipError_t LaunchMaskRows(double *m, uint32_t n_rows, uint32_t stride, uint32_t n_cols, const uint8_t *mask2,
                           hipStream_t stream);
 hipError_t LaunchScale(double *m, uint64_t n, double f, hipStream_t stream);
+
+// tall-skinny FP64 helpers (row-major, leading dimensions in elements)
+// C[na x nb] += A^T B over m rows (C zeroed by the caller)
+hipError_t LaunchTallGram(const double *A, uint32_t lda, uint32_t na, const double *B, uint32_t ldb, uint32_t nb,
+                          uint64_t m, double *C, uint32_t ldc, hipStream_t stream);
+// out = beta * B + alpha * A C   (A: m x na, C: na x nb, B/out: m x nb; out may alias B, not A)
+hipError_t LaunchTallTimesSmall(const double *A, uint32_t lda, uint32_t na, const double *C, uint32_t ldc, uint32_t nb,
+                                double alpha, double beta, const double *B, uint32_t ldb, double *out, uint32_t ldo,
+                                uint64_t m, hipStream_t stream);
+hipError_t LaunchCopyCols(const double *src, uint32_t ld_src, double *dst, uint32_t ld_dst, uint32_t n, uint64_t m,
+                          hipStream_t stream);
 
 // ---- HWE --------------------------------------------------------------------
 hipError_t LaunchHweBatch(const uint32_t *counts, uint32_t n, uint32_t midp, double *ln_p, hipStream_t stream);

@@ -71,6 +71,65 @@ void JacobiSvd(std::vector<double> &r, size_t n, std::vector<double> &s) {
 
 } // namespace
 
+void SymmetricEigen(const std::vector<double> &g, size_t n, std::vector<double> &eigenvalues,
+                    std::vector<double> &v) {
+	std::vector<double> a(g);
+	v.assign(n * n, 0.0);
+	for (size_t i = 0; i < n; i++) {
+		v[i * n + i] = 1.0;
+	}
+	for (int sweep = 0; sweep < 100; sweep++) {
+		double off = 0.0, diag = 0.0;
+		for (size_t i = 0; i < n; i++) {
+			diag += a[i * n + i] * a[i * n + i];
+			for (size_t j = i + 1; j < n; j++) {
+				off += a[i * n + j] * a[i * n + j];
+			}
+		}
+		if (off <= 1e-32 * diag || off == 0.0) {
+			break;
+		}
+		for (size_t p = 0; p + 1 < n; p++) {
+			for (size_t q = p + 1; q < n; q++) {
+				const double apq = a[p * n + q];
+				if (apq == 0.0) {
+					continue;
+				}
+				const double theta = (a[q * n + q] - a[p * n + p]) / (2.0 * apq);
+				const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(1.0 + theta * theta));
+				const double c = 1.0 / std::sqrt(1.0 + t * t), sn = t * c;
+				for (size_t k = 0; k < n; k++) { // rotate columns p, q
+					const double x = a[k * n + p], y = a[k * n + q];
+					a[k * n + p] = c * x - sn * y;
+					a[k * n + q] = sn * x + c * y;
+				}
+				for (size_t k = 0; k < n; k++) { // rotate rows p, q
+					const double x = a[p * n + k], y = a[q * n + k];
+					a[p * n + k] = c * x - sn * y;
+					a[q * n + k] = sn * x + c * y;
+				}
+				for (size_t k = 0; k < n; k++) {
+					const double x = v[k * n + p], y = v[k * n + q];
+					v[k * n + p] = c * x - sn * y;
+					v[k * n + q] = sn * x + c * y;
+				}
+			}
+		}
+	}
+	std::vector<size_t> order(n);
+	std::iota(order.begin(), order.end(), 0);
+	std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return a[x * n + x] > a[y * n + y]; });
+	eigenvalues.resize(n);
+	std::vector<double> vs(n * n);
+	for (size_t k = 0; k < n; k++) {
+		eigenvalues[k] = a[order[k] * n + order[k]];
+		for (size_t i = 0; i < n; i++) {
+			vs[i * n + k] = v[i * n + order[k]];
+		}
+	}
+	v.swap(vs);
+}
+
 void ThinSvdInPlace(double *a, size_t m, size_t n, std::vector<double> &s) {
 	if (n == 0 || m == 0) {
 		s.clear();

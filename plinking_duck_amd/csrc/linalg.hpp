@@ -13,4 +13,9 @@ namespace pgh {
 // order.  Householder QR, then one-sided Jacobi on the n x n factor.
 void ThinSvdInPlace(double *a, size_t m, size_t n, std::vector<double> &s);
 
+// Eigen-decomposition of the symmetric n x n matrix g (row-major): eigenvalues in
+// descending order, eigenvectors as the columns of v (n x n, row-major).  Cyclic Jacobi.
+void SymmetricEigen(const std::vector<double> &g, size_t n, std::vector<double> &eigenvalues,
+                    std::vector<double> &v);
+
 } // namespace pgh
