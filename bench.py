@@ -49,7 +49,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--variants", type=int, default=1_000_000, help="variants per rank (weak) or in total (strong)")
     ap.add_argument("--samples", type=int, default=500_000)
-    ap.add_argument("--workload", choices=["freq", "fused", "unpack", "score"], default="freq")
+    ap.add_argument("--workload", choices=["freq", "fused", "unpack", "score", "pca"], default="freq")
+    ap.add_argument("--n-pcs", type=int, default=10)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 disables)")
     ap.add_argument("--cpu-sample-variants", type=int, default=8192)
@@ -166,7 +167,11 @@ def main():
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
-            ds.counts_range_dev(v_begin, v_end, d_counts.data_ptr(), st)
+            if args.workload == "fused":
+                # row sums (class tallies) and column sums (per-sample missing) in ONE pass
+                ds.fused_tally_dev(v_begin, v_end, d_counts.data_ptr(), d_miss.data_ptr(), st)
+            else:
+                ds.counts_range_dev(v_begin, v_end, d_counts.data_ptr(), st)
             if timed:
                 e1.record(stream)
                 kernel_events.append((e0, e1))
@@ -179,10 +184,9 @@ def main():
                 # plink_missing variant mode: counts[:,3]; sample mode: column sums
                 L.hwe_lnp_batch_dev(d_counts.data_ptr(), m, d_lnp.data_ptr(), False, st)
                 h_lnp.copy_(d_lnp, non_blocking=True)
-                ds.missing_per_sample_dev(v_begin, v_end, d_miss.data_ptr(), st)
                 h_miss.copy_(d_miss[:n], non_blocking=True)
 
-        kernel_name = "k_counts_block"
+        kernel_name = "k_counts_block" if args.workload == "freq" else "k_fused_tally"
         metric = "plink_freq genotypes/s" if args.workload == "freq" else "plink_freq+hardy+missing genotypes/s"
     elif args.workload == "unpack":
         # read_pgen genotype column: output is 4.5x the input, streamed in row chunks
@@ -209,6 +213,38 @@ def main():
         kernel_name = "k_unpack"
         metric = "read_pgen genotypes/s"
         dtype = "u8"
+    elif args.workload == "pca":
+        # BASELINE config 5 shape: plink_pca, k = n_pcs (qq = (k+1)*2k), all passes + orthonormalisation
+        k = args.n_pcs
+        counts = ds.counts_range().astype(np.float64)
+        obs = counts[:, :3].sum(axis=1)
+        af = (counts[:, 1] + 2 * counts[:, 2]) / (2 * np.maximum(obs, 1))
+        keep = (obs > 0) & (af > 0) & (af < 1)
+        p_vidx = (np.flatnonzero(keep) + v_begin).astype(np.uint32)
+        p_center = 2 * af[keep]
+        p_inv = 1.0 / np.sqrt(2 * af[keep] * (1 - af[keep]))
+        g1 = np.random.default_rng(SEED + 2).standard_normal((n, 2 * k))
+        m_eff = len(p_vidx)
+        qq = (k + 1) * 2 * k
+        algo_bytes = (k + 2) * m_eff * record_bytes
+        # k power passes (A+B) + the last Step A + phase 3
+        algo_flops = k * (2 * 2.0 * m_eff * n * 2 * k) + 2.0 * m_eff * n * 2 * k + 2.0 * m_eff * n * qq
+        pca_ev = []
+
+        def step(timed):
+            if timed:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+            ev, _ = ds.pca(p_vidx, p_center, p_inv, k, g1)
+            pca_ev.append(ev)
+            if timed:
+                e1.record(stream)
+                kernel_events.append((e0, e1))
+
+        kernel_name = "pgh_pca (k_variant_reduce_mfma + k_accumulate_mfma + orthonormalisation)"
+        metric = f"plink_pca genotypes/s (n_pcs={k}, {k + 2} passes)"
+        dtype = "f64"
     else:  # score
         ncol = args.score_cols
         rng = np.random.default_rng(SEED + 1)
@@ -259,7 +295,7 @@ def main():
     total_units = sharding.total_variants(world, args.variants, args.scaling) * n
     value = total_units * args.steps / elapsed
 
-    if algo_flops is not None and args.workload == "score" and args.score_cols >= 4:
+    if algo_flops is not None and (args.workload == "pca" or args.score_cols >= 3):
         achieved = algo_flops / (kern_avg_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None, "kernel": kernel_name,

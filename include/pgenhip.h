@@ -154,6 +154,12 @@ int pgh_missing_per_sample(const pgh_dataset *ds, const pgh_subset *subset, uint
 int pgh_missing_per_sample_dev(const pgh_dataset *ds, uint32_t v_begin, uint32_t v_end, void *d_out, void *stream,
                                char *errbuf);
 
+/* plink_freq + plink_hardy + plink_missing (variant and sample mode) off ONE pass over
+ * the rows: d_counts uint32[v_end-v_begin][4] as pgh_counts_range_dev (all samples) and
+ * d_missing uint32[raw_sample_ct] as pgh_missing_per_sample_dev, each byte read once. */
+int pgh_fused_tally_dev(const pgh_dataset *ds, uint32_t v_begin, uint32_t v_end, void *d_counts, void *d_missing,
+                        void *stream, char *errbuf);
+
 /* PgrGet + GenoarrToBytesMinus9 over a variant range (src/pgen_reader.cpp:727-733)
  * plus the validity fill of the ARRAY/LIST child (src/pgen_reader.cpp:1009-1047).
  * out: int8 [v_end-v_begin][n_out] with n_out = subset size or N; a missing call is

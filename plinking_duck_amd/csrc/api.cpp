@@ -723,6 +723,28 @@ extern "C" int pgh_missing_per_sample_dev(const pgh_dataset *ds, uint32_t v_begi
 	return PGH_OK;
 }
 
+extern "C" int pgh_fused_tally_dev(const pgh_dataset *ds, uint32_t v_begin, uint32_t v_end, void *d_counts,
+                                   void *d_missing, void *stream, char *errbuf) {
+	int rc = CheckRange(ds, v_begin, v_end, errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	if (!d_counts || !d_missing) {
+		SetErr(errbuf, "null argument");
+		return PGH_ERR_ARG;
+	}
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	const size_t scratch_bytes = pgh::MissingPerSampleScratchBytes(ds->record_bytes, v_end - v_begin);
+	void *scratch = nullptr;
+	PGH_HIP(hipMallocAsync(&scratch, scratch_bytes ? scratch_bytes : 16, st), "fused scratch");
+	hipError_t e = pgh::LaunchFusedTally(ds->View(), v_begin - ds->v_begin, v_end - v_begin,
+	                                     static_cast<uint32_t *>(scratch), static_cast<uint32_t *>(d_counts),
+	                                     static_cast<uint32_t *>(d_missing), st);
+	(void)hipFreeAsync(scratch, st);
+	PGH_HIP(e, "fused tally kernel");
+	return PGH_OK;
+}
+
 extern "C" int pgh_missing_per_sample(const pgh_dataset *ds, const pgh_subset *subset, uint32_t v_begin,
                                       uint32_t v_end, uint32_t *out, char *errbuf) {
 	int rc = CheckRange(ds, v_begin, v_end, errbuf);

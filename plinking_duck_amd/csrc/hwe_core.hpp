@@ -58,15 +58,30 @@ PGH_HD inline double HweLnP(int32_t obs_hets, int32_t obs_hom1, int32_t obs_hom2
 	while (mode >= 2 && HweStepUp(rare, common, mode - 2) < 1.0) {
 		mode -= 2;
 	}
+	// The walks below carry (k, homozygote-pair counts) as doubles -- all exact
+	// integers < 2^53 -- so the inner loops are pure FP64: the ratio of step k,
+	//   P(k+2)/P(k) = 4 * hr * hc / ((k+2)(k+1)),  hr = (rare-k)/2, hc = (common-k)/2,
+	// does not depend on the running product and pipelines ahead of it.
+	const double kd0 = static_cast<double>(mode);
+	const double hr0 = static_cast<double>((rare - mode) >> 1);
+	const double hc0 = static_cast<double>((common - mode) >> 1);
 	// observed table relative to the mode
 	double p_obs = 1.0;
 	if (obs_hets > mode) {
-		for (int64_t k = mode; k < obs_hets && p_obs > 0.0; k += 2) {
-			p_obs *= HweStepUp(rare, common, k);
+		double k = kd0, hr = hr0, hc = hc0;
+		for (int64_t it = (obs_hets - mode) >> 1; it > 0 && p_obs > 0.0; it--) {
+			p_obs *= 4.0 * hr * hc / ((k + 2.0) * (k + 1.0));
+			k += 2.0;
+			hr -= 1.0;
+			hc -= 1.0;
 		}
 	} else {
-		for (int64_t k = mode; k > obs_hets && p_obs > 0.0; k -= 2) {
-			p_obs /= HweStepUp(rare, common, k - 2);
+		double k = kd0, hr = hr0, hc = hc0;
+		for (int64_t it = (mode - obs_hets) >> 1; it > 0 && p_obs > 0.0; it--) {
+			p_obs *= k * (k - 1.0) / (4.0 * (hr + 1.0) * (hc + 1.0));
+			k -= 2.0;
+			hr += 1.0;
+			hc += 1.0;
 		}
 	}
 	if (!(p_obs > 0.0)) {
@@ -82,31 +97,41 @@ PGH_HD inline double HweLnP(int32_t obs_hets, int32_t obs_hom1, int32_t obs_hom2
 		tail = 1.0;
 		ties = 1.0 >= lo ? 1.0 : 0.0;
 	}
-	double p = 1.0;
-	for (int64_t k = mode; k + 2 <= rare; k += 2) {
-		p *= HweStepUp(rare, common, k);
-		total += p;
-		if (p <= hi) {
-			tail += p;
-			if (p >= lo) {
-				ties += p;
-			}
-			if (p < negligible && p < total * 1e-30) {
-				break;
+	{
+		double p = 1.0, k = kd0, hr = hr0, hc = hc0;
+		for (int64_t it = (rare - mode) >> 1; it > 0; it--) {
+			p *= 4.0 * hr * hc / ((k + 2.0) * (k + 1.0));
+			k += 2.0;
+			hr -= 1.0;
+			hc -= 1.0;
+			total += p;
+			if (p <= hi) {
+				tail += p;
+				if (p >= lo) {
+					ties += p;
+				}
+				if (p < negligible && p < total * 1e-30) {
+					break;
+				}
 			}
 		}
 	}
-	p = 1.0;
-	for (int64_t k = mode; k >= 2; k -= 2) {
-		p /= HweStepUp(rare, common, k - 2);
-		total += p;
-		if (p <= hi) {
-			tail += p;
-			if (p >= lo) {
-				ties += p;
-			}
-			if (p < negligible && p < total * 1e-30) {
-				break;
+	{
+		double p = 1.0, k = kd0, hr = hr0, hc = hc0;
+		for (int64_t it = mode >> 1; it > 0; it--) {
+			p *= k * (k - 1.0) / (4.0 * (hr + 1.0) * (hc + 1.0));
+			k -= 2.0;
+			hr += 1.0;
+			hc += 1.0;
+			total += p;
+			if (p <= hi) {
+				tail += p;
+				if (p >= lo) {
+					ties += p;
+				}
+				if (p < negligible && p < total * 1e-30) {
+					break;
+				}
 			}
 		}
 	}

@@ -11,6 +11,8 @@
 // DPP/ds_swizzle shuffles, LDS only for the cross-wave step and table staging.
 #include "kernels.hpp"
 
+#include <cstdlib>
+
 #include "hwe_core.hpp"
 #include "synth.hpp"
 
@@ -360,6 +362,213 @@ __global__ __launch_bounds__(256) void k_missing_cols(const uint8_t *__restrict_
 	}
 }
 
+// ---------------------------------------------------------------------------
+// fused pass: per-variant class tallies AND per-sample missing tallies
+// ---------------------------------------------------------------------------
+//
+// plink_freq + plink_hardy + plink_missing (both modes) need the row sums and the
+// column sums of the same matrix; this kernel reads every byte once for both.
+// Ownership is by column (as k_missing_cols): a lane keeps its 64 samples' missing
+// counters in registers.  The row sums cross lanes: each lane's per-row popcounts
+// go through an LDS tile [12 rows][256 lanes] (packed 10-bit fields), a 16-lane
+// shuffle tree finishes the row, and 36 lanes add the workgroup's partials to the
+// per-variant totals with one coalesced atomic instruction per 12 rows.
+constexpr uint32_t kFusedRows = 12;
+
+// column counters of the fused kernel: as MissAcc but the last level is 16-bit
+// (<= 65535 rows per slice), which keeps the kernel under 168 VGPRs
+struct MissAcc16 {
+	uint32_t a4[8];
+	uint32_t a8[16];
+	uint32_t a16[32];
+};
+
+__device__ __forceinline__ void Fold8To16(MissAcc16 &acc) {
+	// a16[2i + e] half h <- byte 2h + e of a8[i]
+#pragma unroll
+	for (int i = 0; i < 16; i++) {
+		acc.a16[2 * i] += acc.a8[i] & 0x00ff00ffu;
+		acc.a16[2 * i + 1] += (acc.a8[i] >> 8) & 0x00ff00ffu;
+		acc.a8[i] = 0;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_fused_tally(const uint8_t *__restrict__ rows, uint64_t pitch,
+                                                     uint32_t chunks, uint32_t v_first, uint32_t v_count,
+                                                     uint32_t slice_len, uint32_t *__restrict__ tallies,
+                                                     uint32_t *__restrict__ slabs, uint32_t slab_stride) {
+	__shared__ uint32_t s_p[kFusedRows][256];
+	__shared__ uint32_t s_res[kFusedRows][3];
+	const uint32_t col = blockIdx.x * 256u + threadIdx.x;
+	const bool live = col < chunks;
+	const uint32_t i_begin = blockIdx.y * slice_len;
+	const uint32_t i_end = min(i_begin + slice_len, v_count);
+	MissAcc16 acc;
+#pragma unroll
+	for (int j = 0; j < 8; j++) {
+		acc.a4[j] = 0;
+	}
+#pragma unroll
+	for (int j = 0; j < 16; j++) {
+		acc.a8[j] = 0;
+	}
+#pragma unroll
+	for (int j = 0; j < 32; j++) {
+		acc.a16[j] = 0;
+	}
+	uint32_t n4 = 0, n8 = 0;
+	auto fold = [&](const uint32_t a2[4], uint32_t take) {
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			acc.a4[2 * j] += a2[j] & 0x33333333u;
+			acc.a4[2 * j + 1] += (a2[j] >> 2) & 0x33333333u;
+		}
+		n4 += take;
+		if (n4 + 3 > 15) {
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				acc.a8[4 * j + 0] += acc.a4[2 * j] & 0x0f0f0f0fu;
+				acc.a8[4 * j + 1] += (acc.a4[2 * j] >> 4) & 0x0f0f0f0fu;
+				acc.a8[4 * j + 2] += acc.a4[2 * j + 1] & 0x0f0f0f0fu;
+				acc.a8[4 * j + 3] += (acc.a4[2 * j + 1] >> 4) & 0x0f0f0f0fu;
+				acc.a4[2 * j] = 0;
+				acc.a4[2 * j + 1] = 0;
+			}
+			n8 += n4;
+			n4 = 0;
+			if (n8 + 15 > 255) {
+				Fold8To16(acc);
+				n8 = 0;
+			}
+		}
+	};
+	// one row: class popcounts packed as lo | hi << 10 | both << 20, missing bits into a2
+	auto one_row = [&](const uint4 &w, uint32_t a2[4]) -> uint32_t {
+		const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+		uint32_t lo_ct = 0, hi_ct = 0, both_ct = 0;
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			const uint32_t lo = ws[j] & kLow;
+			const uint32_t hi = (ws[j] >> 1) & kLow;
+			const uint32_t both = lo & hi;
+			lo_ct += __popc(lo);
+			hi_ct += __popc(hi);
+			both_ct += __popc(both);
+			a2[j] += both;
+		}
+		return lo_ct | (hi_ct << 10) | (both_ct << 20);
+	};
+	const uint4 zero4 = make_uint4(0, 0, 0, 0);
+	auto load_row = [&](uint32_t idx) {
+		return live ? LoadStream(reinterpret_cast<const uint4 *>(rows + static_cast<uint64_t>(v_first + idx) * pitch) +
+		                         col)
+		            : zero4;
+	};
+	for (uint32_t i = i_begin; i < i_end; i += kFusedRows) {
+		const uint32_t nb = min(kFusedRows, i_end - i);
+		if (nb == kFusedRows) {
+#pragma unroll
+			for (uint32_t h = 0; h < kFusedRows; h += 6) {
+				const uint4 w0 = load_row(i + h), w1 = load_row(i + h + 1), w2 = load_row(i + h + 2);
+				const uint4 w3 = load_row(i + h + 3), w4 = load_row(i + h + 4), w5 = load_row(i + h + 5);
+				uint32_t a[4] = {0, 0, 0, 0};
+				s_p[h + 0][threadIdx.x] = one_row(w0, a);
+				s_p[h + 1][threadIdx.x] = one_row(w1, a);
+				s_p[h + 2][threadIdx.x] = one_row(w2, a);
+				fold(a, 3);
+				uint32_t b[4] = {0, 0, 0, 0};
+				s_p[h + 3][threadIdx.x] = one_row(w3, b);
+				s_p[h + 4][threadIdx.x] = one_row(w4, b);
+				s_p[h + 5][threadIdx.x] = one_row(w5, b);
+				fold(b, 3);
+			}
+		} else {
+			for (uint32_t r = 0; r < nb; r++) {
+				const uint4 w = load_row(i + r);
+				uint32_t a[4] = {0, 0, 0, 0};
+				s_p[r][threadIdx.x] = one_row(w, a);
+				fold(a, 1);
+			}
+		}
+		__syncthreads();
+		// row sums: lane t -> (row t >> 4, sixteenth t & 15) sums 16 packed lanes (8 + 8 so the
+		// 10-bit fields cannot overflow), then a 16-lane shuffle tree
+		{
+			const uint32_t row = threadIdx.x >> 4, part = threadIdx.x & 15u;
+			uint32_t lo = 0, hi = 0, both = 0;
+			if (row < nb) {
+				const uint4 *src = reinterpret_cast<const uint4 *>(&s_p[row][part * 16u]);
+				const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+				const uint32_t p0 = q0.x + q0.y + q0.z + q0.w + q1.x + q1.y + q1.z + q1.w;
+				const uint32_t p1 = q2.x + q2.y + q2.z + q2.w + q3.x + q3.y + q3.z + q3.w;
+				lo = (p0 & 0x3ffu) + (p1 & 0x3ffu);
+				hi = ((p0 >> 10) & 0x3ffu) + ((p1 >> 10) & 0x3ffu);
+				both = (p0 >> 20) + (p1 >> 20);
+			}
+#pragma unroll
+			for (int off = 8; off > 0; off >>= 1) {
+				lo += __shfl_xor(lo, off, 64);
+				hi += __shfl_xor(hi, off, 64);
+				both += __shfl_xor(both, off, 64);
+			}
+			if (part == 0 && row < nb) {
+				s_res[row][0] = lo;
+				s_res[row][1] = hi;
+				s_res[row][2] = both;
+			}
+		}
+		__syncthreads();
+		if (threadIdx.x < nb * 3u) {
+			const uint32_t r = threadIdx.x / 3u, f = threadIdx.x % 3u;
+			atomicAdd(tallies + 4ull * (i + r) + 1u + f, s_res[r][f]);
+		}
+	}
+	if (live) {
+		// drain the narrow levels, then unscramble: a16[2(4j+q)+e] half h counts sample
+		// 16j + 8h + 4e + {0,2,1,3}[q]
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			acc.a8[4 * j + 0] += acc.a4[2 * j] & 0x0f0f0f0fu;
+			acc.a8[4 * j + 1] += (acc.a4[2 * j] >> 4) & 0x0f0f0f0fu;
+			acc.a8[4 * j + 2] += acc.a4[2 * j + 1] & 0x0f0f0f0fu;
+			acc.a8[4 * j + 3] += (acc.a4[2 * j + 1] >> 4) & 0x0f0f0f0fu;
+		}
+		Fold8To16(acc);
+		uint32_t *dst = slabs + static_cast<uint64_t>(blockIdx.y) * slab_stride + col * 64u;
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+#pragma unroll
+			for (int h = 0; h < 2; h++) {
+#pragma unroll
+				for (int e = 0; e < 2; e++) {
+					// samples 16j + 8h + 4e + {0,1,2,3}  <-  q = {0,2,1,3}
+					uint4 o;
+					o.x = (acc.a16[2 * (4 * j + 0) + e] >> (16 * h)) & 0xffffu;
+					o.y = (acc.a16[2 * (4 * j + 2) + e] >> (16 * h)) & 0xffffu;
+					o.z = (acc.a16[2 * (4 * j + 1) + e] >> (16 * h)) & 0xffffu;
+					o.w = (acc.a16[2 * (4 * j + 3) + e] >> (16 * h)) & 0xffffu;
+					reinterpret_cast<uint4 *>(dst)[4 * j + 2 * h + e] = o;
+				}
+			}
+		}
+	}
+}
+
+// (., lo, hi, both) -> (hom_ref, het, hom_alt, missing)
+__global__ __launch_bounds__(256) void k_finish_tallies(uint4 *__restrict__ tallies, uint32_t n, uint32_t n_eff) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) {
+		return;
+	}
+	const uint4 t = tallies[i];
+	uint4 r;
+	r.y = t.y - t.w;
+	r.z = t.z - t.w;
+	r.w = t.w;
+	r.x = n_eff - r.y - r.z - r.w;
+	tallies[i] = r;
+}
+
 // out[s] = sum over slices of slabs[slice][s]
 __global__ __launch_bounds__(256) void k_sum_slabs(const uint32_t *__restrict__ slabs, uint32_t slab_stride,
                                                    uint32_t n_slabs, uint32_t n, uint32_t *__restrict__ out) {
@@ -422,6 +631,78 @@ __global__ __launch_bounds__(256) void k_unpack(const uint8_t *__restrict__ rows
 		if (validity) {
 			uint16_t *vrow = reinterpret_cast<uint16_t *>(validity + static_cast<uint64_t>(i) * (val_words16 / 4));
 			vrow[d] = static_cast<uint16_t>(valid16);
+		}
+	}
+}
+
+// Wide form for long rows: a lane takes 16 bytes (64 calls), expands them to 64 output
+// bytes + one 64-bit validity word, and the wave's 4 KiB of output goes through LDS so
+// that every global store instruction writes 1 KiB contiguous (lane-major -> piece-major).
+template <bool NT_STORE>
+__global__ __launch_bounds__(256) void k_unpack_wide(const uint8_t *__restrict__ rows, uint64_t pitch,
+                                                     uint32_t sample_ct, uint32_t v_first, uint32_t v_count,
+                                                     int8_t *__restrict__ out, uint64_t out_pitch,
+                                                     uint64_t *__restrict__ validity, uint32_t fill4) {
+	__shared__ uint4 s_tile[4][256]; // per wave: 64 lanes x 4 pieces of 16 bytes
+	const uint32_t chunks = (sample_ct + 63) / 64; // 16-byte input chunks == validity words per row
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const uint32_t col = blockIdx.x * 256u + threadIdx.x;
+	const uint32_t wave_col0 = blockIdx.x * 256u + wave * 64u;
+	if (wave_col0 >= chunks) {
+		return; // whole wave past the row (no barriers in this kernel)
+	}
+	for (uint32_t i = blockIdx.y; i < v_count; i += gridDim.y) {
+		const uint8_t *row = rows + static_cast<uint64_t>(v_first + i) * pitch;
+		uint4 w = make_uint4(0, 0, 0, 0);
+		if (col < chunks) {
+			w = LoadStream(reinterpret_cast<const uint4 *>(row) + col);
+		}
+		const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+		uint64_t vbits = 0;
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			uint4 o;
+			uint32_t *op = &o.x;
+			uint32_t miss16 = 0;
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				const uint32_t t = Spread4((ws[j] >> (8 * k)) & 0xffu);
+				const uint32_t miss = t & (t >> 1) & 0x01010101u;
+				const uint32_t mm = miss * 0xffu;
+				op[k] = (t & ~mm) | (fill4 & mm);
+				miss16 |= (((miss * 0x01020408u) >> 24) & 0xfu) << (4 * k);
+			}
+			vbits |= static_cast<uint64_t>(~miss16 & 0xffffu) << (16 * j);
+			s_tile[wave][lane * 4u + j] = o;
+		}
+		// same-wave LDS exchange: LDS serves one wave's instructions in order, so a
+		// wavefront-scope fence (ordering for the compiler, a waitcnt for the hardware) is
+		// all the tile needs -- no workgroup barrier
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		if (out) {
+			uint8_t *orow = reinterpret_cast<uint8_t *>(out) + static_cast<uint64_t>(i) * out_pitch +
+			                static_cast<uint64_t>(wave_col0) * 64u;
+			const uint64_t row_left = out_pitch - static_cast<uint64_t>(wave_col0) * 64u;
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				const uint32_t piece = k * 64u + lane;
+				const uint4 o = s_tile[wave][piece];
+				if (static_cast<uint64_t>(piece) * 16u + 16u <= row_left) {
+					if (NT_STORE) {
+						StoreStream(reinterpret_cast<uint4 *>(orow) + piece, o);
+					} else {
+						reinterpret_cast<uint4 *>(orow)[piece] = o;
+					}
+				}
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // reads done before the next row's writes
+		if (validity && col < chunks) {
+			const uint32_t left = sample_ct - col * 64u;
+			if (left < 64u) {
+				vbits &= (1ull << left) - 1ull;
+			}
+			validity[static_cast<uint64_t>(i) * chunks + col] = vbits;
 		}
 	}
 }
@@ -876,6 +1157,130 @@ __global__ __launch_bounds__(256) void k_variant_reduce(const uint8_t *__restric
 	}
 }
 
+// MFMA form of Step A:  out[v][c] = sum_s T_v[g(v,s)] * G[s][c]
+// on v_mfma_f64_16x16x4_f64 tiles: M = 16 variants, K = 4 samples, N = 16 columns.
+//   A[i][k] = T_{v_i}[g(v_i, s_k)]   lane l: i = l & 15 (variant), k = l >> 4 (sample 4q + k)
+//   B[k][j] = G[s_k][j]              lane l: k = l >> 4, j = l & 15        (from the LDS chunk)
+// A workgroup owns 128 variants (4 waves x 2 tiles) and streams every sample in chunks of
+// 128: the G chunk (128 x 32 doubles) is staged through LDS once per workgroup, prefetched
+// into registers while the previous chunk is multiplied.  Each lane reads its variant's
+// 32 bytes of the chunk (the 4 lane groups of a variant share the load) and peels sample
+// 4q + k at step q with a per-lane constant shift.  No atomics: a variant's whole sum
+// lives in one wave.
+template <int NCT>
+__global__ __launch_bounds__(256) void k_variant_reduce_mfma(const uint8_t *__restrict__ rows, uint64_t pitch,
+                                                             uint32_t sample_ct, const uint32_t *__restrict__ vlist,
+                                                             uint32_t n_var, const double *__restrict__ ts,
+                                                             const double *__restrict__ G, uint32_t g_stride,
+                                                             uint32_t n_cols, double *__restrict__ out,
+                                                             uint32_t out_stride) {
+	constexpr uint32_t kChunk = 128;           // samples per LDS chunk
+	constexpr uint32_t kCols = 16 * NCT;
+	constexpr uint32_t kGPerThread = kChunk * kCols / 256;
+	constexpr uint32_t kVT = 2;                // variant tiles per wave
+	__shared__ double s_g[kChunk][kCols];
+	__shared__ double s_t[4 * kVT * 16][4];    // tables of the workgroup's 128 variants
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const uint32_t li = lane & 15u, lk = lane >> 4;
+	const uint32_t v_wg = blockIdx.x * (4u * kVT * 16u);
+
+	// tables + row pointers of this lane's two variants
+	for (uint32_t e = threadIdx.x; e < 4u * kVT * 16u * 4u; e += 256u) {
+		const uint32_t v = v_wg + (e >> 2);
+		s_t[e >> 2][e & 3] = v < n_var ? ts[4 * static_cast<uint64_t>(v) + (e & 3)] : 0.0;
+	}
+	const uint8_t *row_ptr[kVT];
+	uint32_t t_base[kVT];
+#pragma unroll
+	for (uint32_t t = 0; t < kVT; t++) {
+		const uint32_t v_local = (wave * kVT + t) * 16u + li;
+		const uint32_t v = v_wg + v_local;
+		row_ptr[t] = rows + static_cast<uint64_t>(vlist[v < n_var ? v : 0]) * pitch;
+		t_base[t] = v_local;
+	}
+	f64x4 acc[kVT][NCT];
+#pragma unroll
+	for (uint32_t t = 0; t < kVT; t++) {
+#pragma unroll
+		for (int c = 0; c < NCT; c++) {
+			acc[t][c] = f64x4 {0.0, 0.0, 0.0, 0.0};
+		}
+	}
+	double r_g[kGPerThread];
+	auto fetch = [&](uint32_t s0) {
+#pragma unroll
+		for (uint32_t j = 0; j < kGPerThread; j++) {
+			const uint32_t e = threadIdx.x + 256u * j;
+			const uint32_t s = s0 + e / kCols, c = e % kCols;
+			r_g[j] = (s < sample_ct && c < n_cols) ? G[static_cast<uint64_t>(s) * g_stride + c] : 0.0;
+		}
+	};
+	auto commit = [&]() {
+#pragma unroll
+		for (uint32_t j = 0; j < kGPerThread; j++) {
+			const uint32_t e = threadIdx.x + 256u * j;
+			s_g[e / kCols][e % kCols] = r_g[j];
+		}
+	};
+	const uint32_t n_chunks = (sample_ct + kChunk - 1) / kChunk;
+	const uint32_t lane_shift = 2u * lk; // sample 4q + k sits at bit 2*(4*(q&3) + k) of word q >> 2
+	fetch(0);
+	for (uint32_t ch = 0; ch < n_chunks; ch++) {
+		__syncthreads(); // everyone is done reading the previous chunk
+		commit();
+		__syncthreads();
+		if (ch + 1 < n_chunks) {
+			fetch((ch + 1) * kChunk);
+		}
+		// this lane's 128 calls (32 bytes) of each of its variants
+		uint32_t w[kVT][8];
+#pragma unroll
+		for (uint32_t t = 0; t < kVT; t++) {
+			const uint4 *p = reinterpret_cast<const uint4 *>(row_ptr[t] + static_cast<uint64_t>(ch) * (kChunk / 4));
+			const uint4 a = p[0], b = p[1];
+			w[t][0] = a.x;
+			w[t][1] = a.y;
+			w[t][2] = a.z;
+			w[t][3] = a.w;
+			w[t][4] = b.x;
+			w[t][5] = b.y;
+			w[t][6] = b.z;
+			w[t][7] = b.w;
+		}
+#pragma unroll
+		for (uint32_t q = 0; q < kChunk / 4; q++) {
+			double b[NCT];
+#pragma unroll
+			for (int c = 0; c < NCT; c++) {
+				b[c] = s_g[4u * q + lk][16 * c + li];
+			}
+#pragma unroll
+			for (uint32_t t = 0; t < kVT; t++) {
+				const uint32_t g = (w[t][q >> 2] >> (8u * (q & 3u) + lane_shift)) & 3u;
+				const double a = s_t[t_base[t]][g];
+#pragma unroll
+				for (int c = 0; c < NCT; c++) {
+					acc[t][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[c], acc[t][c], 0, 0, 0);
+				}
+			}
+		}
+	}
+#pragma unroll
+	for (uint32_t t = 0; t < kVT; t++) {
+#pragma unroll
+		for (int c = 0; c < NCT; c++) {
+#pragma unroll
+			for (int r = 0; r < 4; r++) {
+				const uint32_t v = v_wg + (wave * kVT + t) * 16u + lk + 4u * r;
+				const uint32_t col = 16u * c + li;
+				if (v < n_var && col < n_cols) {
+					out[static_cast<uint64_t>(v) * out_stride + col] = acc[t][c][r];
+				}
+			}
+		}
+	}
+}
+
 // rows of excluded samples -> 0 (keeps a sample subset out of the power iteration)
 __global__ __launch_bounds__(256) void k_mask_rows(double *__restrict__ m, uint32_t n_rows, uint32_t stride,
                                                    uint32_t ncols, const uint8_t *__restrict__ mask2) {
@@ -1103,6 +1508,9 @@ void MissingPerSamplePlan(uint32_t record_bytes, uint32_t v_count, uint32_t *sli
 	if (slice_len < 96) {
 		slice_len = 96;
 	}
+	if (slice_len > 65280u) {
+		slice_len = 65280u; // the fused kernel keeps 16-bit column counters; 65280 = 12 * 5440
+	}
 	*slice_len_out = slice_len;
 	*slices_out = v_count ? (v_count + slice_len - 1) / slice_len : 0;
 }
@@ -1135,6 +1543,31 @@ hipError_t LaunchMissingPerSample(const RowView &view, uint32_t v_first, const u
 	return hipGetLastError();
 }
 
+hipError_t LaunchFusedTally(const RowView &view, uint32_t v_first, uint32_t v_count, uint32_t *scratch,
+                            uint32_t *counts, uint32_t *missing_per_sample, hipStream_t stream) {
+	if (v_count == 0) {
+		return hipMemsetAsync(missing_per_sample, 0, sizeof(uint32_t) * view.sample_ct, stream);
+	}
+	const uint32_t chunks = static_cast<uint32_t>((static_cast<uint64_t>(view.record_bytes) + 15) / 16);
+	const uint32_t col_blocks = (chunks + 255) / 256;
+	uint32_t slice_len, slices;
+	MissingPerSamplePlan(view.record_bytes, v_count, &slice_len, &slices);
+	slice_len = (slice_len + kFusedRows - 1) / kFusedRows * kFusedRows; // <= 65280, so never more slices
+	slices = (v_count + slice_len - 1) / slice_len;
+	const uint32_t stride = chunks * 64u;
+	hipError_t e = hipMemsetAsync(counts, 0, 16ull * v_count, stream);
+	if (e != hipSuccess) {
+		return e;
+	}
+	hipLaunchKernelGGL(k_fused_tally, dim3(col_blocks, slices), dim3(256), 0, stream, view.rows, view.pitch, chunks,
+	                   v_first, v_count, slice_len, counts, scratch, stride);
+	hipLaunchKernelGGL(k_finish_tallies, dim3((v_count + 255) / 256), dim3(256), 0, stream,
+	                   reinterpret_cast<uint4 *>(counts), v_count, view.sample_ct);
+	hipLaunchKernelGGL(k_sum_slabs, dim3((view.sample_ct + 255) / 256), dim3(256), 0, stream, scratch, stride, slices,
+	                   view.sample_ct, missing_per_sample);
+	return hipGetLastError();
+}
+
 hipError_t LaunchUnpack(const RowView &view, uint32_t v_first, uint32_t v_count, int8_t *out, uint64_t out_pitch,
                         uint64_t *validity, int8_t fill, hipStream_t stream) {
 	if (v_count == 0) {
@@ -1143,6 +1576,26 @@ hipError_t LaunchUnpack(const RowView &view, uint32_t v_first, uint32_t v_count,
 	const uint32_t val_words16 = ((view.sample_ct + 63) / 64) * 4;
 	const uint32_t f = static_cast<uint8_t>(fill);
 	const uint32_t fill4 = f * 0x01010101u;
+	if (view.sample_ct >= 4096) {
+		const uint32_t chunks = (view.sample_ct + 63) / 64;
+		dim3 grid_w((chunks + 255) / 256, v_count < 65535u ? v_count : 65535u);
+		static const int variant = [] {
+			const char *e = getenv("PGH_UNPACK_VARIANT"); // tuning knob: 0 = non-temporal stores, 1 = plain stores
+			return e ? atoi(e) : 0;
+		}();
+		if (variant == 1) {
+			hipLaunchKernelGGL(k_unpack_wide<false>, grid_w, dim3(256), 0, stream, view.rows, view.pitch,
+			                   view.sample_ct, v_first, v_count, out, out_pitch, validity, fill4);
+		} else if (variant == 2) {
+			dim3 grid((val_words16 + 255) / 256, v_count < 65535u ? v_count : 65535u);
+			hipLaunchKernelGGL(k_unpack, grid, dim3(256), 0, stream, view.rows, view.pitch, view.sample_ct, v_first,
+			                   v_count, out, out_pitch, validity, fill4);
+		} else {
+			hipLaunchKernelGGL(k_unpack_wide<true>, grid_w, dim3(256), 0, stream, view.rows, view.pitch,
+			                   view.sample_ct, v_first, v_count, out, out_pitch, validity, fill4);
+		}
+		return hipGetLastError();
+	}
 	dim3 grid((val_words16 + 255) / 256, v_count < 65535u ? v_count : 65535u);
 	hipLaunchKernelGGL(k_unpack, grid, dim3(256), 0, stream, view.rows, view.pitch, view.sample_ct, v_first, v_count,
 	                   out, out_pitch, validity, fill4);
@@ -1321,11 +1774,28 @@ hipError_t LaunchVariantReduce(const RowView &view, const uint32_t *vlist, uint3
 	if (n_var == 0) {
 		return hipSuccess;
 	}
+	// The MFMA form reads whole 32-byte (128-call) pieces of a row: the row pitch must cover
+	// ceil(N/128) of them, which holds for 128-byte-aligned pitches (rows >= 512 bytes).
+	const bool mfma_ok = n_cols >= 3 && view.pitch % 32 == 0 &&
+	                     static_cast<uint64_t>((view.sample_ct + 127) / 128) * 32 <= view.pitch;
 	uint32_t c0 = 0;
 	hipError_t e = hipSuccess;
 	while (c0 < n_cols && e == hipSuccess) {
 		const uint32_t left = n_cols - c0;
-		if (left >= 8) {
+		if (mfma_ok) {
+			const uint32_t blocks = (n_var + 127) / 128;
+			if (left > 16) {
+				hipLaunchKernelGGL((k_variant_reduce_mfma<2>), dim3(blocks), dim3(256), 0, stream, view.rows, view.pitch,
+				                   view.sample_ct, vlist, n_var, ts, G + c0, g_stride, left < 32 ? left : 32, out + c0,
+				                   out_stride);
+				c0 += 32;
+			} else {
+				hipLaunchKernelGGL((k_variant_reduce_mfma<1>), dim3(blocks), dim3(256), 0, stream, view.rows, view.pitch,
+				                   view.sample_ct, vlist, n_var, ts, G + c0, g_stride, left, out + c0, out_stride);
+				c0 += 16;
+			}
+			e = hipGetLastError();
+		} else if (left >= 8) {
 			e = LaunchVariantReduceN<8>(view, vlist, n_var, ts, G + c0, g_stride, out + c0, out_stride, stream);
 			c0 += 8;
 		} else if (left >= 4) {

@@ -46,6 +46,12 @@ size_t MissingPerSampleScratchBytes(uint32_t record_bytes, uint32_t v_count);
 hipError_t LaunchMissingPerSample(const RowView &view, uint32_t v_first, const uint32_t *vlist, uint32_t v_count,
                                   const uint32_t *row_flags, uint32_t *scratch, uint32_t *out, hipStream_t stream);
 
+// Both reductions in one pass over [v_first, v_first + v_count): counts[i] = class tallies
+// of row i (all samples), missing_per_sample[s] as above.  Same scratch size as
+// LaunchMissingPerSample.
+hipError_t LaunchFusedTally(const RowView &view, uint32_t v_first, uint32_t v_count, uint32_t *scratch,
+                            uint32_t *counts, uint32_t *missing_per_sample, hipStream_t stream);
+
 // ---- 2-bit -> int8 unpack --------------------------------------------------
 // out row i: int8[N] (+pad to out_pitch, multiple of 16) with missing -> fill;
 // validity row i (optional): ceil(N/64) uint64 words, bit = non-missing.

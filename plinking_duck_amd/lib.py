@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = [
     "pgh_from_host_rows",
     "pgh_synth_create", "pgh_synth_record_host", "pgh_synth_write_files", "pgh_copy_rows_to_host", "pgh_get_info", "pgh_device_rows",
     "pgh_close", "pgh_subset_create", "pgh_subset_size", "pgh_subset_destroy", "pgh_counts_range",
-    "pgh_counts_range_dev", "pgh_freq_from_counts_dev", "pgh_missing_per_sample", "pgh_missing_per_sample_dev", "pgh_unpack_range",
+    "pgh_counts_range_dev", "pgh_freq_from_counts_dev", "pgh_fused_tally_dev", "pgh_missing_per_sample", "pgh_missing_per_sample_dev", "pgh_unpack_range",
     "pgh_unpack_range_dev", "pgh_score", "pgh_score_dev", "pgh_score_plan_create", "pgh_score_run_dev",
     "pgh_score_plan_destroy", "pgh_pca", "pgh_reader_create", "pgh_reader_destroy",
     "pgh_get_2bit", "pgh_get_counts", "pgh_get_missingness", "pgh_get_int8", "pgh_get_dosage_f64", "pgh_get_phased",
@@ -82,6 +82,7 @@ def _load():
         "pgh_subset_destroy": (None, [vp]),
         "pgh_counts_range": (C.c_int, [vp, vp, u32, u32, vp, cp]),
         "pgh_counts_range_dev": (C.c_int, [vp, vp, u32, u32, vp, vp, cp]),
+        "pgh_fused_tally_dev": (C.c_int, [vp, u32, u32, vp, vp, vp, cp]),
         "pgh_missing_per_sample": (C.c_int, [vp, vp, u32, u32, vp, cp]),
         "pgh_missing_per_sample_dev": (C.c_int, [vp, u32, u32, vp, vp, cp]),
         "pgh_unpack_range": (C.c_int, [vp, vp, u32, u32, vp, vp, C.c_int, cp]),
@@ -318,6 +319,10 @@ class Dataset:
         eb = _errbuf()
         _check(_lib.pgh_missing_per_sample(self._h, subset._h if subset else None, v_begin, v_end, _ptr(out), eb), eb)
         return out
+
+    def fused_tally_dev(self, v_begin, v_end, d_counts: int, d_missing: int, stream: int = 0):
+        eb = _errbuf()
+        _check(_lib.pgh_fused_tally_dev(self._h, v_begin, v_end, d_counts, d_missing, stream, eb), eb)
 
     def missing_per_sample_dev(self, v_begin, v_end, d_out: int, stream: int = 0):
         eb = _errbuf()

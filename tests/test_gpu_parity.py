@@ -201,6 +201,26 @@ def mem_pgen(rows, n):
     return np.frombuffer(head + rows.tobytes(), dtype=np.uint8)
 
 
+@pytest.mark.parametrize("m,n", [(1, 1), (7, 63), (12, 64), (25, 1000), (300, 4099), (1000, 70001), (64, 500_000)])
+def test_fused_tally_equals_the_two_separate_passes(gpu_lib, m, n):
+    """plink_freq/hardy/missing off one pass: same integers as the separate kernels."""
+    import torch
+    ds = gpu_lib.Dataset.synth(3, 3 + m, n, SEED, 0.04)
+    d_counts = torch.full((m, 4), -1, dtype=torch.int32, device="cuda")
+    d_miss = torch.full(((n + 63) // 64 * 64,), -1, dtype=torch.int32, device="cuda")
+    ds.fused_tally_dev(3, 3 + m, d_counts.data_ptr(), d_miss.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_counts.cpu().numpy().astype(np.uint32), ds.counts_range())
+    assert np.array_equal(d_miss[:n].cpu().numpy().astype(np.uint32), ds.missing_per_sample())
+    if m > 20:  # sub-range
+        ds.fused_tally_dev(10, 3 + m - 5, d_counts.data_ptr(), d_miss.data_ptr(),
+                           torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        k = 3 + m - 5 - 10
+        assert np.array_equal(d_counts[:k].cpu().numpy().astype(np.uint32), ds.counts_range(10, 3 + m - 5))
+        assert np.array_equal(d_miss[:n].cpu().numpy().astype(np.uint32), ds.missing_per_sample(10, 3 + m - 5))
+
+
 def test_variant_sharded_dataset_is_a_slice_of_the_global_one(gpu_lib):
     """Rank r generates rows [a,b) of the same global matrix (multi-GPU sharding)."""
     n = 3001
@@ -238,6 +258,24 @@ def test_score_matches_oracle(gpu_lib, oracle, mode, ncols):
         scale = np.abs(w).sum(axis=0) * 2.0  # magnitude of the terms being summed
         assert np.all(np.abs(s - es) <= REL * np.maximum(np.abs(es), 1e-9 * scale))
         assert np.allclose(d, ed, rtol=REL, atol=1e-9)
+
+
+@pytest.mark.parametrize("ncols", [2, 3, 5, 15, 17, 33])
+def test_score_any_number_of_columns(gpu_lib, oracle, ncols):
+    """1-2 columns run as FMAs, >= 3 on FP64 MFMA tiles (16/32 columns per pass, ragged tails)."""
+    m, n = 150, 1500
+    host = np.stack([gpu_lib.synth_record_host(v, n, SEED + 3, 0.05) for v in range(m)])
+    ds = gpu_lib.Dataset.from_host_rows(host, n)
+    pg = oracle.Pgen(mem=mem_pgen(host, n))
+    rng = np.random.default_rng(ncols)
+    vidx = np.sort(rng.choice(m, size=131, replace=False))
+    w = rng.standard_normal((len(vidx), ncols))
+    s, d, ac = ds.score(vidx, w)
+    es, ed, eac = oracle.score(pg, vidx, w)
+    assert np.array_equal(ac, eac)
+    scale = np.abs(w).sum(axis=0) * 2.0
+    assert np.all(np.abs(s - es) <= REL * np.maximum(np.abs(es), 1e-9 * scale))
+    assert np.allclose(d, ed, rtol=REL, atol=1e-9)
 
 
 def test_hwe_batch_matches_oracle(gpu_lib, oracle):
