@@ -1,0 +1,41 @@
+#!/bin/bash
+# Runs on the MI355X box (via gpurun): the round's benches + rocprofv3 summaries.
+# Outputs under gpurun_out/profiles/; the judged copies are committed under profiles/.
+set -u
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/profiles
+mkdir -p $OUT
+run_bench() { # name args...
+	local name=$1; shift
+	python3 bench.py "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err
+	echo "bench $name exit $?"
+}
+stats() { # name args...
+	local name=$1; shift
+	rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$name -- python3 bench.py "$@" --cpu-seconds 0 > /dev/null 2> $OUT/stats_$name.err
+	cp $OUT/stats_$name/*/*_kernel_stats.csv $OUT/${name}_kernel_stats.csv 2>/dev/null
+	echo "stats $name exit $?"
+}
+pmc() { # name counter args...
+	local name=$1; local ctr=$2; shift 2
+	rocprofv3 --pmc $ctr --output-format csv -d $OUT/pmc_${name}_$ctr -- python3 bench.py "$@" --cpu-seconds 0 > /dev/null 2> $OUT/pmc_${name}_$ctr.err
+	cp $OUT/pmc_${name}_$ctr/*/*_counter_collection.csv $OUT/${name}_$ctr.csv 2>/dev/null
+	echo "pmc $name $ctr exit $?"
+}
+run_bench freq --steps 20 --warmup 3
+run_bench fused --workload fused --steps 10 --warmup 2 --cpu-seconds 0
+run_bench unpack --workload unpack --steps 5 --warmup 1 --cpu-seconds 0
+run_bench score --workload score --steps 3 --warmup 1 --cpu-seconds 0
+run_bench score1 --workload score --score-cols 1 --steps 3 --warmup 1 --cpu-seconds 0
+run_bench pca --workload pca --variants 100000 --steps 2 --warmup 1 --cpu-seconds 0
+stats freq --steps 10 --warmup 2
+stats fused --workload fused --steps 5 --warmup 1
+stats unpack --workload unpack --steps 3 --warmup 1
+stats score --workload score --variants 200000 --steps 3 --warmup 1
+stats pca --workload pca --variants 100000 --steps 1 --warmup 0
+for c in FETCH_SIZE WRITE_SIZE; do
+	pmc freq $c --steps 3 --warmup 1
+	pmc fused $c --workload fused --steps 3 --warmup 1
+	pmc unpack $c --workload unpack --steps 2 --warmup 1
+done
+ls $OUT | head -60
