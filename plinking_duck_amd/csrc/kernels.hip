@@ -884,6 +884,131 @@ __global__ __launch_bounds__(256) void k_score_accumulate(const uint8_t *__restr
 	}
 }
 
+// GEMV form (one weight column, the reference's SQL contract): 2 flop per call, so the
+// contraction is not matrix-core work -- plain FP64 adds would cost more than the HBM
+// stream.  "Four Russians" instead: for every group of 4 scored variants the workgroup
+// tabulates the 256 possible (score, dosage) sums of one sample's 4 calls in LDS, and a
+// lane then needs one 16-byte LDS lookup + 2 FP64 adds per 4 calls.  The 8-bit pattern
+// of sample j is assembled from the 4 rows' words with a 2-bit field transposition
+// (even / odd fields -> nibbles -> bytes).  16 variants (4 tables) per barrier, tables
+// double-buffered; variant slices combine by FP64 atomics.
+struct alignas(16) ScorePair {
+	double score;
+	double dosage;
+};
+
+__global__ __launch_bounds__(256) void k_score_gemv(const uint8_t *__restrict__ rows, uint64_t pitch,
+                                                    uint32_t sample_ct, const uint32_t *__restrict__ vlist,
+                                                    uint32_t n_var, uint32_t slice_len,
+                                                    const double *__restrict__ weights, uint32_t w_stride,
+                                                    const double *__restrict__ ts, const double *__restrict__ td,
+                                                    double *__restrict__ score, uint32_t out_stride,
+                                                    double *__restrict__ dosage_sum) {
+	constexpr uint32_t kGroups = 4; // 4-variant groups per stage
+	__shared__ ScorePair s_tab[2][kGroups][256];
+	const uint32_t d = blockIdx.x * 256u + threadIdx.x;   // this lane's 4-byte column: samples 16d .. 16d+15
+	const uint32_t n_dwords = (sample_ct + 15) / 16;
+	const bool live = d < n_dwords;
+	const uint32_t i_begin = blockIdx.y * slice_len;
+	const uint32_t i_end = min(i_begin + slice_len, n_var);
+	double acc_s[16], acc_d[16];
+#pragma unroll
+	for (int j = 0; j < 16; j++) {
+		acc_s[j] = 0.0;
+		acc_d[j] = 0.0;
+	}
+	// entry `threadIdx.x` of the 4 tables of the stage starting at scored-variant index base
+	auto build = [&](uint32_t base, uint32_t buf) {
+#pragma unroll
+		for (uint32_t grp = 0; grp < kGroups; grp++) {
+			double sc = 0.0, ds = 0.0;
+#pragma unroll
+			for (uint32_t q = 0; q < 4; q++) {
+				const uint32_t i = base + grp * 4u + q;
+				if (i < i_end) { // uniform
+					const uint32_t g = (threadIdx.x >> (2 * q)) & 3u;
+					const double w = weights[static_cast<uint64_t>(i) * w_stride];
+					sc += w * ts[4 * static_cast<uint64_t>(i) + g];
+					if (td) {
+						ds += td[4 * static_cast<uint64_t>(i) + g];
+					}
+				}
+			}
+			s_tab[buf][grp][threadIdx.x] = ScorePair {sc, ds};
+		}
+	};
+	auto load_words = [&](uint32_t base, uint32_t w[kGroups * 4]) {
+#pragma unroll
+		for (uint32_t k = 0; k < kGroups * 4; k++) {
+			const uint32_t i = base + k;
+			w[k] = (live && i < i_end)
+			           ? __builtin_nontemporal_load(
+			                 reinterpret_cast<const uint32_t *>(rows + static_cast<uint64_t>(vlist[i]) * pitch) + d)
+			           : 0u;
+		}
+	};
+	uint32_t w_cur[kGroups * 4], w_next[kGroups * 4];
+	if (i_begin < i_end) {
+		load_words(i_begin, w_cur);
+		build(i_begin, 0);
+	}
+	__syncthreads();
+	uint32_t buf = 0;
+	for (uint32_t base = i_begin; base < i_end; base += kGroups * 4, buf ^= 1u) {
+		const bool more = base + kGroups * 4 < i_end;
+		if (more) {
+			load_words(base + kGroups * 4, w_next);
+			build(base + kGroups * 4, buf ^ 1u);
+		}
+#pragma unroll
+		for (uint32_t grp = 0; grp < kGroups; grp++) {
+			const uint32_t w0 = w_cur[4 * grp], w1 = w_cur[4 * grp + 1], w2 = w_cur[4 * grp + 2],
+			               w3 = w_cur[4 * grp + 3];
+			// 2-bit field transposition: byte b of pat[r] = 8-bit pattern of sample 4b + {0,2,1,3}[r]
+			const uint32_t kE = 0x33333333u, kN = 0x0f0f0f0fu;
+			const uint32_t t01 = (w0 & kE) | ((w1 & kE) << 2);
+			const uint32_t t23 = (w2 & kE) | ((w3 & kE) << 2);
+			const uint32_t u01 = ((w0 >> 2) & kE) | (w1 & ~kE);
+			const uint32_t u23 = ((w2 >> 2) & kE) | (w3 & ~kE);
+			uint32_t pat[4];
+			pat[0] = (t01 & kN) | ((t23 & kN) << 4);   // samples 0, 4, 8, 12
+			pat[1] = ((t01 >> 4) & kN) | (t23 & ~kN);  // samples 2, 6, 10, 14
+			pat[2] = (u01 & kN) | ((u23 & kN) << 4);   // samples 1, 5, 9, 13
+			pat[3] = ((u01 >> 4) & kN) | (u23 & ~kN);  // samples 3, 7, 11, 15
+			const ScorePair *tab = s_tab[buf][grp];
+#pragma unroll
+			for (int r = 0; r < 4; r++) {
+				const int within = r == 0 ? 0 : (r == 1 ? 2 : (r == 2 ? 1 : 3));
+#pragma unroll
+				for (int b = 0; b < 4; b++) {
+					const ScorePair e = tab[(pat[r] >> (8 * b)) & 0xffu];
+					acc_s[4 * b + within] += e.score;
+					acc_d[4 * b + within] += e.dosage;
+				}
+			}
+		}
+		if (more) {
+#pragma unroll
+			for (uint32_t k = 0; k < kGroups * 4; k++) {
+				w_cur[k] = w_next[k];
+			}
+		}
+		__syncthreads();
+	}
+	if (live) {
+#pragma unroll
+		for (int j = 0; j < 16; j++) {
+			const uint32_t s0 = d * 16u + j;
+			if (s0 < sample_ct) {
+				unsafeAtomicAdd(score + static_cast<uint64_t>(s0) * out_stride, acc_s[j]);
+				if (dosage_sum) {
+					unsafeAtomicAdd(dosage_sum + s0, acc_d[j]);
+				}
+			}
+		}
+	}
+}
+
 // MFMA form of the accumulate: a true dense contraction
 //   out[s][c] += sum_v  T_v[g(v,s)] * W[v][c]
 // on v_mfma_f64_16x16x4_f64 tiles: M = 16 samples, K = 4 variants, N = 16 columns.
@@ -1710,7 +1835,28 @@ hipError_t LaunchTableAccumulate(const RowView &view, const uint32_t *vlist, uin
 		}
 		return e;
 	}
-	// GEMV-shaped (1-2 columns): HBM-bound, plain FP64 FMAs
+	if (n_cols == 1) {
+		// GEMV: table-lookup kernel, HBM/LDS-bound
+		const uint32_t n_dwords = (view.sample_ct + 15) / 16;
+		const uint32_t col_blocks = (n_dwords + 255) / 256;
+		uint32_t want_slices = (4096 + col_blocks - 1) / col_blocks;
+		uint32_t slice_len = (n_var + want_slices - 1) / want_slices;
+		slice_len = ((slice_len + 15) / 16) * 16;
+		if (slice_len < 256) {
+			slice_len = 256;
+		}
+		uint32_t slices = (n_var + slice_len - 1) / slice_len;
+		if (slices > 65535u) {
+			slices = 65535u;
+			slice_len = ((n_var + slices - 1) / slices + 15) / 16 * 16;
+			slices = (n_var + slice_len - 1) / slice_len;
+		}
+		hipLaunchKernelGGL(k_score_gemv, dim3(col_blocks, slices), dim3(256), 0, stream, view.rows, view.pitch,
+		                   view.sample_ct, vlist, n_var, slice_len, weights, w_stride, ts, td, out, out_stride,
+		                   dosage_sum);
+		return hipGetLastError();
+	}
+	// 2 columns: plain FP64 FMAs
 	uint32_t c0 = 0;
 	hipError_t e = hipSuccess;
 	while (c0 < n_cols && e == hipSuccess) {
