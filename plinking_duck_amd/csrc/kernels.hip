@@ -1023,7 +1023,7 @@ __global__ __launch_bounds__(256) void k_score_gemv(const uint8_t *__restrict__ 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 template <int NCT, bool TRACK_DOSAGE>
-__global__ __launch_bounds__(256) void k_accumulate_mfma(const uint8_t *__restrict__ rows, uint64_t pitch,
+__global__ __launch_bounds__(256, NCT == 1 ? 4 : 2) void k_accumulate_mfma(const uint8_t *__restrict__ rows, uint64_t pitch,
                                                          uint32_t sample_ct, const uint32_t *__restrict__ vlist,
                                                          uint32_t n_var, uint32_t slice_len,
                                                          const double *__restrict__ weights, uint32_t w_stride,
@@ -1103,15 +1103,9 @@ __global__ __launch_bounds__(256) void k_accumulate_mfma(const uint8_t *__restri
 		}
 		if (wave_live) {
 			const uint32_t groups = (cnt + 3) / 4;
-			// software pipeline: the next group's 16-byte load is in flight while this one is multiplied
-			uint4 w_next = *reinterpret_cast<const uint4 *>(col_ptr + s_off[buf][lk]);
-			for (uint32_t g4 = 0; g4 < groups; g4++) {
-				const uint32_t k = g4 * 4u + lk;
-				const uint4 w = w_next;
-				if (g4 + 1 < groups) {
-					w_next = *reinterpret_cast<const uint4 *>(col_ptr + s_off[buf][k + 4u]);
-				}
-				double b[NCT];
+			// two-deep software pipeline: while group g is on the matrix pipe, group g+1's
+			// operands are being looked up in LDS and the row loads of g+2..g+4 are in flight
+			auto operands = [&](uint32_t k, const uint4 &w, double a[4], double b[NCT]) {
 #pragma unroll
 				for (int c = 0; c < NCT; c++) {
 					b[c] = s_w[buf][k][16 * c + li];
@@ -1119,15 +1113,51 @@ __global__ __launch_bounds__(256) void k_accumulate_mfma(const uint8_t *__restri
 				const uint32_t wt[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
 				for (int t = 0; t < 4; t++) {
-					const uint32_t g = (wt[t] >> shift) & 3u;
-					const double a = s_ts[buf][k][g];
+					a[t] = s_ts[buf][k][(wt[t] >> shift) & 3u];
+				}
+			};
+			auto row_load = [&](uint32_t g) {
+				return *reinterpret_cast<const uint4 *>(col_ptr + s_off[buf][g * 4u + lk]);
+			};
+			auto multiply = [&](const double a[4], const double b[NCT]) {
+#pragma unroll
+				for (int t = 0; t < 4; t++) {
 					if (TRACK_DOSAGE) {
-						dsum[t] += a;
+						dsum[t] += a[t];
 					}
 #pragma unroll
 					for (int c = 0; c < NCT; c++) {
-						acc[t][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[c], acc[t][c], 0, 0, 0);
+						acc[t][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], b[c], acc[t][c], 0, 0, 0);
 					}
+				}
+			};
+			if (groups == kStage / 4) {
+				// full stage, fully unrolled so the ring of 4 row loads and the operand
+				// double buffer are plain register renaming (no moves, no early waits)
+				constexpr uint32_t kRing = 3; // row loads in flight (3 keeps NCT = 1 at 128 VGPRs = 4 waves/SIMD)
+				uint4 w[kRing];
+#pragma unroll
+				for (uint32_t j = 0; j < kRing; j++) {
+					w[j] = row_load(j);
+				}
+				double a[2][4], b[2][NCT];
+				operands(lk, w[0], a[0], b[0]);
+#pragma unroll
+				for (uint32_t g4 = 0; g4 < kStage / 4; g4++) {
+					if (g4 + kRing < kStage / 4) {
+						w[g4 % kRing] = row_load(g4 + kRing); // slot of group g4, already turned into operands
+					}
+					if (g4 + 1 < kStage / 4) {
+						operands((g4 + 1u) * 4u + lk, w[(g4 + 1) % kRing], a[(g4 + 1) % 2], b[(g4 + 1) % 2]);
+					}
+					multiply(a[g4 % 2], b[g4 % 2]);
+				}
+			} else {
+				// ragged last stage of a slice
+				for (uint32_t g4 = 0; g4 < groups; g4++) {
+					double a[4], b[NCT];
+					operands(g4 * 4u + lk, row_load(g4), a, b);
+					multiply(a, b);
 				}
 			}
 		}
