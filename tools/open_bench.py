@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Times pgh_open (host parse + normalise + H2D) on a synthetic .pgen written to local disk."""
+import argparse
+import os
+import sys
+import tempfile
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import plinking_duck_amd.lib as L  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--variants", type=int, default=4000)
+ap.add_argument("--samples", type=int, default=500000)
+args = ap.parse_args()
+d = tempfile.mkdtemp(prefix="pgh_open_")
+prefix = os.path.join(d, "syn")
+t0 = time.perf_counter()
+L.synth_write_files(prefix, args.variants, args.samples, 1, 0.02)
+t1 = time.perf_counter()
+size = os.path.getsize(prefix + ".pgen")
+print(f"wrote {size / 1e9:.2f} GB in {t1 - t0:.1f} s")
+for i in range(3):
+    t0 = time.perf_counter()
+    ds = L.Dataset.open(prefix + ".pgen")
+    t1 = time.perf_counter()
+    print(f"pgh_open #{i}: {t1 - t0:.3f} s = {size / (t1 - t0) / 1e9:.2f} GB/s (page cache warm)")
+    c = ds.counts_range(0, 8)
+    ds.close()
+os.remove(prefix + ".pgen"); os.remove(prefix + ".pvar"); os.remove(prefix + ".psam"); os.rmdir(d)
