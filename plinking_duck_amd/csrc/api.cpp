@@ -249,6 +249,50 @@ static bool ReadParallel(const pgh::RecordFile &file, uint64_t offset, size_t by
 	return true;
 }
 
+// Host normalisation of compressed records, split over a few threads.  Each worker owns a
+// Normalizer (LD-base scratch) and a contiguous sub-range; a sub-range that starts inside an
+// LD run resolves its base by walking back, exactly as a range that starts mid-file does.
+static bool ExpandParallel(const pgh::PgenIndex &ix, const pgh::RecordFile &file, pgh::Normalizer &first,
+                           uint32_t v_begin, uint32_t v_end, uint8_t *dst, size_t pitch, std::string &err) {
+	constexpr uint32_t kMinRows = 64;
+	const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+	const uint32_t rows = v_end - v_begin;
+	const unsigned parts = std::min<unsigned>(std::min(8u, hw), std::max<uint32_t>(1, rows / kMinRows));
+	if (parts <= 1) {
+		return first.ExpandRange(v_begin, v_end, dst, pitch, err);
+	}
+	std::vector<std::thread> pool;
+	std::vector<std::string> errs(parts);
+	std::vector<char> ok(parts, 1);
+	const uint32_t slice = (rows + parts - 1) / parts;
+	for (unsigned t = 0; t < parts; t++) {
+		const uint32_t lo = std::min<uint64_t>(v_end, static_cast<uint64_t>(v_begin) + static_cast<uint64_t>(t) * slice);
+		const uint32_t hi = std::min<uint64_t>(v_end, static_cast<uint64_t>(lo) + slice);
+		pool.emplace_back([&, t, lo, hi] {
+			if (lo >= hi) {
+				return;
+			}
+			uint8_t *out = dst + static_cast<size_t>(lo - v_begin) * pitch;
+			if (t == 0) {
+				ok[t] = first.ExpandRange(lo, hi, out, pitch, errs[t]) ? 1 : 0;
+			} else {
+				pgh::Normalizer mine(ix, file);
+				ok[t] = mine.ExpandRange(lo, hi, out, pitch, errs[t]) ? 1 : 0;
+			}
+		});
+	}
+	for (auto &th : pool) {
+		th.join();
+	}
+	for (unsigned t = 0; t < parts; t++) {
+		if (!ok[t]) {
+			err = errs[t];
+			return false;
+		}
+	}
+	return true;
+}
+
 extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t variant_begin, uint32_t variant_end,
                         pgh_dataset **out, char *errbuf) {
 	if (!pgen_path || !out) {
@@ -364,7 +408,7 @@ extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t va
 				e = pgh::LaunchSanitizeTail(d_dst, ds->pitch, ds->sample_ct, stop - v, stream);
 			}
 		} else {
-			if (!norm.ExpandRange(v, stop, stage[which], ds->pitch, err)) {
+			if (!ExpandParallel(ix, file, norm, v, stop, stage[which], ds->pitch, err)) {
 				(void)hipStreamSynchronize(stream);
 				cleanup();
 				SetErr(errbuf, err);

@@ -7,9 +7,10 @@
 // the hardcall path is one 2-bit -> int8 unpack launch (pgh_unpack_range) over
 // the claimed variants instead of PgrGet + GenoarrToBytesMinus9 + a scalar
 // per-sample copy (src/pgen_reader.cpp:727-733, 1009-1047).  Dosage and phase
-// tracks are decoded per variant through the reader calls.
-// Not carried over: genotypes := 'columns' / 'struct' and the `variants`
-// parameter (metadata plumbing outside the hot path).
+// tracks are decoded per variant through the reader calls.  genotypes :=
+// 'columns' / 'struct' lay the same unpacked bytes out as one scalar column (or
+// struct field) per sample (src/pgen_reader.cpp:386-433, 781-845); `variants :=`
+// scans a caller-ordered list of variant indices (src/pgen_reader.cpp:304-312).
 #include "variant_scan.hpp"
 
 #include <cmath>
@@ -28,6 +29,9 @@ struct PgenBindData : public TableFunctionData {
 	CountFilter count_filter;
 	GenotypeRangeFilter genotype_filter;
 	uint32_t output_sample_ct = 0;
+	bool has_variant_list = false;
+	vector<uint32_t> variant_indices; // `variants :=`, caller order
+	vector<string> genotype_column_names; // columns / struct modes: IIDs in ascending file order
 };
 
 struct PgenGlobalState : public GlobalTableFunctionState {
@@ -37,7 +41,8 @@ struct PgenGlobalState : public GlobalTableFunctionState {
 	bool need_counts = false;
 	uint32_t max_threads_config = 0;
 	idx_t MaxThreads() const override {
-		uint32_t total = scan.end_variant_idx - scan.start_variant_idx;
+		uint32_t total = scan.has_variant_list ? static_cast<uint32_t>(scan.variant_list.size())
+		                                       : scan.end_variant_idx - scan.start_variant_idx;
 		return ApplyMaxThreadsCap(total / 1000 + 1, max_threads_config);
 	}
 };
@@ -76,8 +81,6 @@ static unique_ptr<FunctionData> PgenBind(ClientContext &context, TableFunctionBi
 				                            "use read_pfile for orient := 'genotype' or 'sample')",
 				                            v);
 			}
-		} else if (kv.first == "variants" || kv.first == "region") {
-			throw InvalidInputException("read_pgen: the '%s' parameter is not available in this build", kv.first);
 		}
 	}
 	if (bind_data->include_dosages && bind_data->include_phased) {
@@ -87,6 +90,13 @@ static unique_ptr<FunctionData> PgenBind(ClientContext &context, TableFunctionBi
 	c.Bind(context, input, "read_pgen", false);
 	uint32_t output_sample_ct = c.effective_sample_ct;
 	bind_data->output_sample_ct = output_sample_ct;
+
+	auto variants_it = input.named_parameters.find("variants");
+	if (variants_it != input.named_parameters.end()) {
+		bind_data->variant_indices =
+		    ResolveVariantsParameter(variants_it->second, c.variants, c.raw_variant_ct, "read_pgen");
+		bind_data->has_variant_list = true;
+	}
 
 	auto af_it = input.named_parameters.find("af_range");
 	if (af_it != input.named_parameters.end()) {
@@ -133,23 +143,50 @@ static unique_ptr<FunctionData> PgenBind(ClientContext &context, TableFunctionBi
 			throw InvalidInputException("read_pgen: genotypes := '%s' is incompatible with dosages := true", label);
 		}
 	}
-	if (bind_data->genotype_mode == GenotypeMode::COLUMNS || bind_data->genotype_mode == GenotypeMode::STRUCT) {
-		throw InvalidInputException("read_pgen: genotypes := '%s' is not available in this build "
-		                            "(use 'array', 'list', 'counts' or 'stats')",
-		                            genotypes_str);
+	const bool per_sample_names =
+	    bind_data->genotype_mode == GenotypeMode::COLUMNS || bind_data->genotype_mode == GenotypeMode::STRUCT;
+	if (per_sample_names) {
+		if (!c.has_sample_info) {
+			throw InvalidInputException("read_pgen: genotypes := '%s' requires a .psam/.fam file for sample IDs "
+			                            "(no companion file found)",
+			                            bind_data->genotype_mode == GenotypeMode::COLUMNS ? "columns" : "struct");
+		}
+		// the subset is a mask, so fields come out in ascending file order whatever order was asked for
+		for (uint32_t s = 0; s < c.raw_sample_ct; s++) {
+			if (!c.has_sample_subset || ((c.sample_subset->sample_include[s >> 6] >> (s & 63)) & 1ull)) {
+				bind_data->genotype_column_names.push_back(c.sample_info.iids[s]);
+			}
+		}
 	}
 
-	names = {"CHROM", "POS", "ID", "REF", "ALT", "genotypes"};
+	names = {"CHROM", "POS", "ID", "REF", "ALT"};
 	return_types = {LogicalType::VARCHAR, LogicalType::INTEGER, LogicalType::VARCHAR, LogicalType::VARCHAR,
 	                LogicalType::VARCHAR};
-	if (bind_data->genotype_mode == GenotypeMode::COUNTS) {
+	LogicalType elem_type = bind_data->include_phased    ? LogicalType::ARRAY(LogicalType::TINYINT, 2)
+	                        : bind_data->include_dosages ? LogicalType(LogicalType::DOUBLE)
+	                                                     : LogicalType(LogicalType::TINYINT);
+	if (bind_data->genotype_mode == GenotypeMode::COLUMNS) {
+		// scalar columns carry hardcalls or dosages; phase is not representable here
+		LogicalType col_type =
+		    bind_data->include_dosages ? LogicalType(LogicalType::DOUBLE) : LogicalType(LogicalType::TINYINT);
+		for (auto &iid : bind_data->genotype_column_names) {
+			names.push_back(iid);
+			return_types.push_back(col_type);
+		}
+		return std::move(bind_data);
+	}
+	names.push_back("genotypes");
+	if (bind_data->genotype_mode == GenotypeMode::STRUCT) {
+		child_list_t fields;
+		for (auto &iid : bind_data->genotype_column_names) {
+			fields.push_back({iid, elem_type});
+		}
+		return_types.push_back(LogicalType::STRUCT(std::move(fields)));
+	} else if (bind_data->genotype_mode == GenotypeMode::COUNTS) {
 		return_types.push_back(MakeGenotypeCountsType());
 	} else if (bind_data->genotype_mode == GenotypeMode::STATS) {
 		return_types.push_back(MakeGenotypeStatsType());
 	} else {
-		LogicalType elem_type = bind_data->include_phased    ? LogicalType::ARRAY(LogicalType::TINYINT, 2)
-		                        : bind_data->include_dosages ? LogicalType(LogicalType::DOUBLE)
-		                                                     : LogicalType(LogicalType::TINYINT);
 		return_types.push_back(bind_data->genotype_mode == GenotypeMode::ARRAY
 		                           ? LogicalType::ARRAY(elem_type, output_sample_ct)
 		                           : LogicalType::LIST(elem_type));
@@ -165,8 +202,14 @@ static unique_ptr<GlobalTableFunctionState> PgenInitGlobal(ClientContext &contex
 	state->scan.effective_sample_ct = bind_data.c.effective_sample_ct;
 	state->column_ids = input.column_ids;
 	state->max_threads_config = GetPlinkingMaxThreads(context);
+	if (bind_data.has_variant_list) {
+		state->scan.has_variant_list = true;
+		state->scan.variant_list = bind_data.variant_indices;
+	}
 	for (auto col_id : input.column_ids) {
-		if (col_id == COL_GENOTYPES) {
+		// columns mode: every column from COL_GENOTYPES on is one sample
+		if (col_id != COLUMN_IDENTIFIER_ROW_ID &&
+		    (col_id == COL_GENOTYPES || (bind_data.genotype_mode == GenotypeMode::COLUMNS && col_id > COL_GENOTYPES))) {
 			state->need_genotypes = true;
 		}
 	}
@@ -188,7 +231,8 @@ static unique_ptr<LocalTableFunctionState> PgenInitLocal(ExecutionContext &, Tab
 	auto &bind_data = input.bind_data->Cast<PgenBindData>();
 	auto &gstate = global_state->Cast<PgenGlobalState>();
 	auto state = make_uniq<PgenLocalState>();
-	if (gstate.need_genotypes && (bind_data.include_dosages || bind_data.include_phased)) {
+	const bool phased_out = bind_data.include_phased && bind_data.genotype_mode != GenotypeMode::COLUMNS;
+	if (gstate.need_genotypes && (bind_data.include_dosages || phased_out)) {
 		char errbuf[PGH_ERRBUF_LEN] = {0};
 		int rc = pgh_reader_create(gstate.scan.dataset->handle, gstate.scan.subset ? gstate.scan.subset->handle : nullptr,
 		                           &state->reader, errbuf);
@@ -237,17 +281,23 @@ static void PgenScan(ClientContext &, TableFunctionInput &data_p, DataChunk &out
 	auto &lstate = data_p.local_state->Cast<PgenLocalState>();
 	auto &column_ids = gstate.column_ids;
 	const uint32_t n = bind_data.output_sample_ct;
-	const bool plain_hardcalls = gstate.need_genotypes && !IsAggregateGenotypeMode(bind_data.genotype_mode) &&
-	                             !bind_data.include_dosages && !bind_data.include_phased;
+	const GenotypeMode mode = bind_data.genotype_mode;
+	const bool listed = gstate.scan.has_variant_list;
+	const bool phased_out = bind_data.include_phased && mode != GenotypeMode::COLUMNS;
+	const bool per_variant_decode = gstate.need_genotypes && (bind_data.include_dosages || phased_out);
+	const bool plain_hardcalls =
+	    gstate.need_genotypes && !IsAggregateGenotypeMode(mode) && !bind_data.include_dosages && !phased_out;
 	auto no_strata = [](uint32_t, uint32_t) { return false; };
 
-	// 1. choose the variants of this chunk (filters run off the batched tallies)
+	// 1. choose the variants of this chunk (filters run off the batched tallies).  A chunk
+	//    never straddles two claimed batches: their tallies and unpack span are per batch.
 	vector<RowPlan> plan;
 	plan.reserve(STANDARD_VECTOR_SIZE);
 	uint32_t vidx = 0;
 	while (plan.size() < STANDARD_VECTOR_SIZE) {
-		if (!plan.empty() && vidx + 1 - plan.front().vidx >= kUnpackSpan) {
-			break; // keep the unpack span bounded; the next Scan call continues
+		if (!plan.empty() &&
+		    (lstate.scan.BatchDrained() || (!listed && vidx + 1 - plan.front().vidx >= kUnpackSpan))) {
+			break; // the next Scan call continues
 		}
 		if (!lstate.scan.Next(gstate.scan, "read_pgen", no_strata, vidx)) {
 			break;
@@ -268,25 +318,92 @@ static void PgenScan(ClientContext &, TableFunctionInput &data_p, DataChunk &out
 		return;
 	}
 
-	// 2. one unpack launch for the span the chunk covers
+	// 2. unpack: one launch for the span the chunk covers, or one per listed variant
 	const uint32_t span_begin = plan.front().vidx;
 	const uint32_t span_end = plan.back().vidx + 1;
 	const size_t val_words = (n + 63) / 64;
 	if (plain_hardcalls) {
-		lstate.bytes.resize(static_cast<size_t>(span_end - span_begin) * n);
-		lstate.validity.resize(static_cast<size_t>(span_end - span_begin) * val_words);
+		const size_t rows = listed ? plan.size() : span_end - span_begin;
+		lstate.bytes.resize(rows * n);
+		lstate.validity.resize(rows * val_words);
+		pgh_dataset *ds = gstate.scan.dataset->handle;
+		pgh_subset *ss = gstate.scan.subset ? gstate.scan.subset->handle : nullptr;
 		char errbuf[PGH_ERRBUF_LEN] = {0};
-		int rc = pgh_unpack_range(gstate.scan.dataset->handle, gstate.scan.subset ? gstate.scan.subset->handle : nullptr,
-		                          span_begin, span_end, lstate.bytes.data(), lstate.validity.data(), 0, errbuf);
+		int rc = PGH_OK;
+		if (listed) {
+			for (size_t r = 0; r < plan.size() && rc == PGH_OK; r++) {
+				rc = pgh_unpack_range(ds, ss, plan[r].vidx, plan[r].vidx + 1, lstate.bytes.data() + r * n,
+				                      lstate.validity.data() + r * val_words, 0, errbuf);
+			}
+		} else {
+			rc = pgh_unpack_range(ds, ss, span_begin, span_end, lstate.bytes.data(), lstate.validity.data(), 0, errbuf);
+		}
 		if (rc != PGH_OK) {
 			throw IOException("read_pgen: PgrGet failed for variants [%u, %u): %s", span_begin, span_end,
 			                  string(errbuf));
 		}
 	}
 
+	// per-call writers shared by the ARRAY / LIST / STRUCT / COLUMNS layouts: `slot` is the
+	// element index inside `dst` (child offset, or the output row for scalar layouts)
+	auto put_dosage = [&](Vector &dst, idx_t slot, uint32_t s) {
+		double d = lstate.dosage_doubles[s];
+		if (d == -9.0) {
+			FlatVector::Validity(dst).SetInvalid(slot);
+			FlatVector::GetData<double>(dst)[slot] = 0.0;
+		} else {
+			FlatVector::GetData<double>(dst)[slot] = d;
+		}
+	};
+	// UnpackPhasedGenotypes (src/plink_common.cpp:1549-1584): dst = ARRAY(TINYINT, 2)
+	auto put_phased = [&](Vector &dst, idx_t slot, uint32_t s, bool null_out) {
+		auto *alleles = FlatVector::GetData<int8_t>(ArrayVector::GetEntry(dst));
+		uint32_t code = (lstate.genovec[s >> 5] >> (2 * (s & 31))) & 3u;
+		bool ignore = null_out && !bind_data.genotype_filter.AllowsCall(static_cast<double>(code));
+		int8_t a0 = 0, a1 = 0;
+		if (code == 3 || ignore) {
+			FlatVector::Validity(dst).SetInvalid(slot);
+		} else if (code == 2) {
+			a0 = a1 = 1;
+		} else if (code == 1) {
+			bool alt_first = ((lstate.phasepresent[s >> 6] >> (s & 63)) & 1ull) &&
+			                 ((lstate.phaseinfo[s >> 6] >> (s & 63)) & 1ull);
+			a0 = alt_first ? 1 : 0;
+			a1 = alt_first ? 0 : 1;
+		}
+		alleles[2 * slot] = a0;
+		alleles[2 * slot + 1] = a1;
+	};
+	auto put_hardcall = [&](Vector &dst, idx_t slot, const int8_t *src, const uint64_t *val, uint32_t s,
+	                        bool null_out) {
+		const bool present = (val[s >> 6] >> (s & 63)) & 1ull;
+		if (!present || (null_out && !bind_data.genotype_filter.AllowsCall(static_cast<double>(src[s])))) {
+			FlatVector::Validity(dst).SetInvalid(slot);
+			FlatVector::GetData<int8_t>(dst)[slot] = 0;
+		} else {
+			FlatVector::GetData<int8_t>(dst)[slot] = src[s];
+		}
+	};
+
 	// 3. fill the projected columns
 	for (idx_t row = 0; row < plan.size(); row++) {
 		const uint32_t v = plan[row].vidx;
+		const bool null_out = bind_data.genotype_filter.active && !plan[row].geno_range_all_pass;
+		const size_t src_row = listed ? row : v - span_begin;
+		const int8_t *src = plain_hardcalls ? lstate.bytes.data() + src_row * n : nullptr;
+		const uint64_t *val = plain_hardcalls ? lstate.validity.data() + src_row * val_words : nullptr;
+		if (per_variant_decode) {
+			if (bind_data.include_dosages) {
+				if (pgh_get_dosage_f64(lstate.reader, v, lstate.dosage_doubles.data()) != PGH_OK) {
+					throw IOException("read_pgen: PgrGetD failed for variant %u: %s", v,
+					                  string(pgh_reader_error(lstate.reader)));
+				}
+			} else if (pgh_get_phased(lstate.reader, v, lstate.genovec.data(), lstate.phasepresent.data(),
+			                          lstate.phaseinfo.data()) != PGH_OK) {
+				throw IOException("read_pgen: PgrGetP failed for variant %u: %s", v,
+				                  string(pgh_reader_error(lstate.reader)));
+			}
+		}
 		for (idx_t out_col = 0; out_col < column_ids.size(); out_col++) {
 			auto file_col = column_ids[out_col];
 			if (file_col == COLUMN_IDENTIFIER_ROW_ID) {
@@ -296,16 +413,41 @@ static void PgenScan(ClientContext &, TableFunctionInput &data_p, DataChunk &out
 			if (FillVariantMetadataColumn(bind_data.c.variants, file_col, v, vec, row)) {
 				continue;
 			}
+			if (mode == GenotypeMode::COLUMNS) {
+				const uint32_t s = static_cast<uint32_t>(file_col - COL_GENOTYPES);
+				if (s >= n) {
+					continue;
+				}
+				if (bind_data.include_dosages) {
+					put_dosage(vec, row, s);
+				} else {
+					put_hardcall(vec, row, src, val, s, null_out);
+				}
+				continue;
+			}
 			if (file_col != COL_GENOTYPES) {
 				continue;
 			}
-			if (IsAggregateGenotypeMode(bind_data.genotype_mode)) {
+			if (mode == GenotypeMode::STRUCT) {
+				auto &entries = StructVector::GetEntries(vec);
+				for (uint32_t s = 0; s < n; s++) {
+					if (bind_data.include_dosages) {
+						put_dosage(*entries[s], row, s);
+					} else if (phased_out) {
+						put_phased(*entries[s], row, s, null_out);
+					} else {
+						put_hardcall(*entries[s], row, src, val, s, null_out);
+					}
+				}
+				continue;
+			}
+			if (IsAggregateGenotypeMode(mode)) {
 				const uint32_t *gc = lstate.scan.Counts(v);
 				auto &entries = StructVector::GetEntries(vec);
 				for (int k = 0; k < 4; k++) {
 					FlatVector::GetData<uint32_t>(*entries[k])[row] = gc[k];
 				}
-				if (bind_data.genotype_mode == GenotypeMode::STATS) {
+				if (mode == GenotypeMode::STATS) {
 					const double nan = std::numeric_limits<double>::quiet_NaN();
 					uint32_t nn = gc[0] + gc[1] + gc[2];
 					uint32_t total = nn + gc[3];
@@ -323,55 +465,18 @@ static void PgenScan(ClientContext &, TableFunctionInput &data_p, DataChunk &out
 			}
 			const idx_t base = BeginGenotypeRow(bind_data, vec, row, n);
 			Vector &child = GenotypeChild(bind_data, vec);
-			auto &child_validity = FlatVector::Validity(child);
 			if (bind_data.include_dosages) {
-				if (pgh_get_dosage_f64(lstate.reader, v, lstate.dosage_doubles.data()) != PGH_OK) {
-					throw IOException("read_pgen: PgrGetD failed for variant %u: %s", v,
-					                  string(pgh_reader_error(lstate.reader)));
-				}
-				auto *dst = FlatVector::GetData<double>(child);
 				for (uint32_t s = 0; s < n; s++) {
-					double d = lstate.dosage_doubles[s];
-					if (d == -9.0) {
-						child_validity.SetInvalid(base + s);
-						dst[base + s] = 0.0;
-					} else {
-						dst[base + s] = d;
-					}
+					put_dosage(child, base + s, s);
 				}
-			} else if (bind_data.include_phased) {
-				if (pgh_get_phased(lstate.reader, v, lstate.genovec.data(), lstate.phasepresent.data(),
-				                   lstate.phaseinfo.data()) != PGH_OK) {
-					throw IOException("read_pgen: PgrGetP failed for variant %u: %s", v,
-					                  string(pgh_reader_error(lstate.reader)));
-				}
-				// UnpackPhasedGenotypes (src/plink_common.cpp:1549-1584): child = ARRAY(TINYINT, 2)
-				Vector &pair = ArrayVector::GetEntry(child);
-				auto *dst = FlatVector::GetData<int8_t>(pair);
+			} else if (phased_out) {
 				for (uint32_t s = 0; s < n; s++) {
-					uint32_t code = (lstate.genovec[s >> 5] >> (2 * (s & 31))) & 3u;
-					bool ignore = bind_data.genotype_filter.active && !plan[row].geno_range_all_pass &&
-					              !bind_data.genotype_filter.AllowsCall(static_cast<double>(code));
-					int8_t a0 = 0, a1 = 0;
-					if (code == 3 || ignore) {
-						child_validity.SetInvalid(base + s);
-					} else if (code == 2) {
-						a0 = a1 = 1;
-					} else if (code == 1) {
-						bool alt_first = ((lstate.phasepresent[s >> 6] >> (s & 63)) & 1ull) &&
-						                 ((lstate.phaseinfo[s >> 6] >> (s & 63)) & 1ull);
-						a0 = alt_first ? 1 : 0;
-						a1 = alt_first ? 0 : 1;
-					}
-					dst[2 * (base + s)] = a0;
-					dst[2 * (base + s) + 1] = a1;
+					put_phased(child, base + s, s, null_out);
 				}
 			} else {
-				const int8_t *src = lstate.bytes.data() + static_cast<size_t>(v - span_begin) * n;
-				const uint64_t *val = lstate.validity.data() + static_cast<size_t>(v - span_begin) * val_words;
+				auto &child_validity = FlatVector::Validity(child);
 				auto *dst = FlatVector::GetData<int8_t>(child);
 				std::memcpy(dst + base, src, n); // missing calls are already stored as 0
-				const bool null_out = bind_data.genotype_filter.active && !plan[row].geno_range_all_pass;
 				for (size_t w = 0; w < val_words; w++) {
 					uint64_t bits = val[w];
 					const uint32_t lim = static_cast<uint32_t>(std::min<size_t>(64, n - w * 64));
@@ -406,6 +511,7 @@ void RegisterPgenReader(ExtensionLoader &loader) {
 	read_pgen.named_parameters["orient"] = LogicalType::VARCHAR;
 	read_pgen.named_parameters["af_range"] = LogicalType::ANY;
 	read_pgen.named_parameters["ac_range"] = LogicalType::ANY;
+	read_pgen.named_parameters["variants"] = LogicalType::ANY;
 	read_pgen.named_parameters["genotype_range"] = LogicalType::ANY;
 	read_pgen.named_parameters["include_genotypes"] = LogicalType::LIST(LogicalType::VARCHAR);
 	loader.RegisterFunction(read_pgen);

@@ -373,6 +373,242 @@ SampleSubset BuildSampleSubset(uint32_t raw_sample_ct, const vector<uint32_t> &s
 }
 
 // ---------------------------------------------------------------------------
+// variants := ...
+// ---------------------------------------------------------------------------
+
+namespace {
+
+// One `variants` parameter being resolved: owns the lazily built ID -> index map.
+class VariantSelector {
+public:
+	VariantSelector(const VariantMetadataIndex &variants, uint32_t raw_variant_ct, const string &func_name)
+	    : variants_(variants), raw_variant_ct_(raw_variant_ct), func_(func_name) {
+	}
+
+	uint32_t FromIndex(int64_t idx) const {
+		if (idx < 0 || idx >= static_cast<int64_t>(raw_variant_ct_)) {
+			throw InvalidInputException("%s: variant index %lld out of range (variant count: %u)", func_,
+			                            static_cast<long long>(idx), raw_variant_ct_);
+		}
+		return static_cast<uint32_t>(idx);
+	}
+
+	// an rsid, or CHROM:POS / CHROM:POS:REF:ALT when the text carries a ':'
+	uint32_t FromText(const string &text) {
+		if (text.find(':') == string::npos) {
+			if (by_id_.empty()) {
+				by_id_.reserve(variants_.ids.size());
+				for (idx_t v = 0; v < variants_.ids.size(); v++) {
+					if (!variants_.ids[v].empty()) {
+						by_id_[variants_.ids[v]] = static_cast<uint32_t>(v); // duplicates: last one wins
+					}
+				}
+			}
+			auto hit = by_id_.find(text);
+			if (hit == by_id_.end()) {
+				throw InvalidInputException("%s: variant '%s' not found", func_, text);
+			}
+			return hit->second;
+		}
+		vector<string> parts;
+		size_t from = 0;
+		while (true) {
+			size_t colon = text.find(':', from);
+			parts.push_back(text.substr(from, colon == string::npos ? string::npos : colon - from));
+			if (colon == string::npos) {
+				break;
+			}
+			from = colon + 1;
+		}
+		if (parts.size() != 2 && parts.size() != 4) {
+			throw InvalidInputException("%s: invalid CPRA format '%s' (expected CHROM:POS or CHROM:POS:REF:ALT)", func_,
+			                            text);
+		}
+		errno = 0;
+		char *tail = nullptr;
+		long pos = std::strtol(parts[1].c_str(), &tail, 10);
+		if (*tail != '\0' || errno != 0) {
+			throw InvalidInputException("%s: invalid position in CPRA '%s'", func_, text);
+		}
+		const bool alleles = parts.size() == 4;
+		return FromLocus(parts[0], static_cast<int32_t>(pos), alleles ? &parts[2] : nullptr,
+		                 alleles ? &parts[3] : nullptr, text);
+	}
+
+	uint32_t FromLocusStruct(const Value &val) {
+		auto &fields = StructType::GetChildTypes(val.type());
+		auto &kids = StructValue::GetChildren(val);
+		string chrom, ref, alt;
+		int32_t pos = 0;
+		bool has_ref = false, has_alt = false;
+		for (idx_t i = 0; i < fields.size(); i++) {
+			const string &name = fields[i].first;
+			if (name == "chrom") {
+				chrom = kids[i].GetValue<string>();
+			} else if (name == "pos") {
+				pos = kids[i].GetValue<int32_t>();
+			} else if (name == "ref") {
+				ref = kids[i].GetValue<string>();
+				has_ref = true;
+			} else if (name == "alt") {
+				alt = kids[i].GetValue<string>();
+				has_alt = true;
+			}
+		}
+		const bool alleles = has_ref && has_alt;
+		string desc = chrom + ":" + std::to_string(pos);
+		if (alleles) {
+			desc += ":" + ref + ":" + alt;
+		}
+		return FromLocus(chrom, pos, alleles ? &ref : nullptr, alleles ? &alt : nullptr, desc);
+	}
+
+	vector<uint32_t> FromRangeStruct(const Value &val) {
+		auto &fields = StructType::GetChildTypes(val.type());
+		auto &kids = StructValue::GetChildren(val);
+		const Value *start = nullptr, *stop = nullptr;
+		for (idx_t i = 0; i < fields.size(); i++) {
+			if (fields[i].first == "start") {
+				start = &kids[i];
+			} else if (fields[i].first == "stop") {
+				stop = &kids[i];
+			}
+		}
+		if (!start || !stop) {
+			throw InvalidInputException("%s: range struct must have 'start' and 'stop' fields", func_);
+		}
+		uint32_t lo, hi;
+		auto kind = start->type().id();
+		if (kind == LogicalTypeId::INTEGER || kind == LogicalTypeId::BIGINT) {
+			lo = FromIndex(start->GetValue<int64_t>());
+			hi = FromIndex(stop->GetValue<int64_t>());
+		} else if (kind == LogicalTypeId::VARCHAR) {
+			lo = FromText(start->GetValue<string>());
+			hi = FromText(stop->GetValue<string>());
+		} else {
+			throw InvalidInputException("%s: range struct start/stop must be INTEGER or VARCHAR", func_);
+		}
+		if (lo > hi) {
+			throw InvalidInputException("%s: variants range start (%u) is after stop (%u)", func_, lo, hi);
+		}
+		vector<uint32_t> out(hi - lo + 1);
+		for (uint32_t v = lo; v <= hi; v++) {
+			out[v - lo] = v;
+		}
+		return out;
+	}
+
+private:
+	// POS is ascending inside a CHROM run: lower_bound, then walk the ties for the alleles.
+	uint32_t FromLocus(const string &chrom, int32_t pos, const string *ref, const string *alt, const string &desc) const {
+		auto run = variants_.chrom_offsets.find(chrom);
+		if (run != variants_.chrom_offsets.end()) {
+			auto first = variants_.positions.begin() + static_cast<std::ptrdiff_t>(run->second.first);
+			auto last = variants_.positions.begin() + static_cast<std::ptrdiff_t>(run->second.second);
+			for (auto it = std::lower_bound(first, last, pos); it != last && *it == pos; ++it) {
+				idx_t v = static_cast<idx_t>(it - variants_.positions.begin());
+				if (!ref || (variants_.refs[v] == *ref && variants_.alts[v] == *alt)) {
+					return static_cast<uint32_t>(v);
+				}
+			}
+		}
+		throw InvalidInputException("%s: variant '%s' not found", func_, desc);
+	}
+
+	const VariantMetadataIndex &variants_;
+	uint32_t raw_variant_ct_;
+	const string &func_;
+	std::unordered_map<string, uint32_t> by_id_;
+};
+
+} // namespace
+
+vector<uint32_t> ResolveVariantsParameter(const Value &val, const VariantMetadataIndex &variants,
+                                          uint32_t raw_variant_ct, const string &func_name) {
+	if (val.IsNull()) {
+		throw InvalidInputException("%s: variants must not be NULL", func_name);
+	}
+	VariantSelector pick(variants, raw_variant_ct, func_name);
+	vector<uint32_t> out;
+	auto has_field = [](const LogicalType &t, const char *name) {
+		for (auto &f : StructType::GetChildTypes(t)) {
+			if (f.first == name) {
+				return true;
+			}
+		}
+		return false;
+	};
+	const auto &type = val.type();
+	switch (type.id()) {
+	case LogicalTypeId::INTEGER:
+	case LogicalTypeId::BIGINT:
+		out.push_back(pick.FromIndex(val.GetValue<int64_t>()));
+		break;
+	case LogicalTypeId::VARCHAR:
+		out.push_back(pick.FromText(val.GetValue<string>()));
+		break;
+	case LogicalTypeId::STRUCT: {
+		const bool range = has_field(type, "start"), locus = has_field(type, "chrom");
+		if (range && locus) {
+			throw InvalidInputException("%s: ambiguous variants struct — has both 'start' and 'chrom' fields. "
+			                            "Use {start:, stop:} for a range or {chrom:, pos:} for a CPRA lookup.",
+			                            func_name);
+		}
+		if (range) {
+			out = pick.FromRangeStruct(val);
+		} else if (locus) {
+			out.push_back(pick.FromLocusStruct(val));
+		} else {
+			throw InvalidInputException(
+			    "%s: variants struct must have either 'start'/'stop' (range) or 'chrom'/'pos' (CPRA) fields", func_name);
+		}
+		break;
+	}
+	case LogicalTypeId::LIST: {
+		auto &kids = ListValue::GetChildren(val);
+		if (kids.empty()) {
+			throw InvalidInputException("%s: variants list must not be empty", func_name);
+		}
+		auto &elem = ListType::GetChildType(type);
+		for (auto &kid : kids) {
+			switch (elem.id()) {
+			case LogicalTypeId::INTEGER:
+			case LogicalTypeId::BIGINT:
+				out.push_back(pick.FromIndex(kid.GetValue<int64_t>()));
+				break;
+			case LogicalTypeId::VARCHAR:
+				out.push_back(pick.FromText(kid.GetValue<string>()));
+				break;
+			case LogicalTypeId::STRUCT:
+				out.push_back(pick.FromLocusStruct(kid));
+				break;
+			default:
+				throw InvalidInputException("%s: variants list elements must be INTEGER, VARCHAR, or STRUCT (got %s)",
+				                            func_name, elem.ToString());
+			}
+		}
+		break;
+	}
+	default:
+		throw InvalidInputException("%s: variants parameter must be an integer, string, struct, or list (got %s)",
+		                            func_name, type.ToString());
+	}
+	vector<uint32_t> sorted = out;
+	std::sort(sorted.begin(), sorted.end());
+	auto dup = std::adjacent_find(sorted.begin(), sorted.end());
+	if (dup != sorted.end()) {
+		// the reference names the first repeat met in caller order
+		std::unordered_set<uint32_t> seen;
+		for (auto v : out) {
+			if (!seen.insert(v).second) {
+				throw InvalidInputException("%s: duplicate variant index %u in variants parameter", func_name, v);
+			}
+		}
+	}
+	return out;
+}
+
+// ---------------------------------------------------------------------------
 // region
 // ---------------------------------------------------------------------------
 

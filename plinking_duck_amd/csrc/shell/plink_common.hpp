@@ -83,6 +83,13 @@ struct VariantRange {
 //! src/plink_common.cpp:1256-1334
 VariantRange ParseRegion(const string &region_str, const VariantMetadataIndex &variants, const string &func_name);
 
+//! read_pgen's `variants :=` (src/plink_common.cpp:1787-1885): an index, an ID, a
+//! 'CHROM:POS[:REF:ALT]' string, a {start, stop} range (inclusive), a {chrom, pos[, ref, alt]}
+//! struct, or a list of one of those kinds.  Returns file variant indices in caller order;
+//! duplicates are an error.
+vector<uint32_t> ResolveVariantsParameter(const Value &val, const VariantMetadataIndex &variants,
+                                          uint32_t raw_variant_ct, const string &func_name);
+
 // ---- filters of read_pgen ------------------------------------------------------------
 
 struct RangeFilter {

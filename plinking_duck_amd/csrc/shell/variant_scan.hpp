@@ -13,6 +13,7 @@
 #include "plink_common.hpp"
 
 #include <atomic>
+#include <unordered_map>
 
 namespace duckdb {
 
@@ -28,7 +29,13 @@ struct VariantScanGlobal {
 	unique_ptr<DeviceSubset> female_subset;
 	uint32_t effective_sample_ct = 0;
 	bool want_counts = true;               // false: only the batch claim is needed (read_pgen without filters)
+	// read_pgen's `variants :=` list: the scan walks list positions (caller order, as the
+	// reference's effective_variant_indices does) and claims kListBatch of them at a time.
+	bool has_variant_list = false;
+	vector<uint32_t> variant_list;
 };
+
+constexpr uint32_t kListBatch = 128;
 
 struct VariantScanLocal {
 	uint32_t batch_begin = 0, batch_end = 0, cursor = 0;
@@ -37,8 +44,18 @@ struct VariantScanLocal {
 
 	//! Advance to the next variant of this thread; returns false when the range is drained.
 	//! needs_strata(begin, end) says whether any variant of the batch is on chrX/Y/MT.
+	//! True once every variant of the claimed batch has been handed out: callers that defer
+	//! work on a batch (read_pgen's chunk plan) stop here, because the next claim replaces
+	//! the batch's tallies.
+	bool BatchDrained() const {
+		return cursor >= batch_end;
+	}
+
 	template <class NeedStrata>
 	bool Next(VariantScanGlobal &g, const string &func_name, NeedStrata &&needs_strata, uint32_t &vidx) {
+		if (g.has_variant_list) {
+			return NextListed(g, func_name, vidx);
+		}
 		if (cursor >= batch_end) {
 			uint32_t begin = g.next_variant_idx.fetch_add(kDeviceBatch);
 			if (begin >= g.end_variant_idx) {
@@ -63,6 +80,9 @@ struct VariantScanLocal {
 	}
 
 	const uint32_t *Counts(uint32_t vidx) const {
+		if (!list_slot.empty()) {
+			return counts.data() + 4 * static_cast<size_t>(list_slot.at(vidx));
+		}
 		return counts.data() + 4 * static_cast<size_t>(vidx - batch_begin);
 	}
 	const uint32_t *MaleCounts(uint32_t vidx) const {
@@ -73,6 +93,39 @@ struct VariantScanLocal {
 	}
 
 private:
+	std::unordered_map<uint32_t, uint32_t> list_slot; // list mode: variant index -> row of `counts`
+
+	bool NextListed(VariantScanGlobal &g, const string &func_name, uint32_t &vidx) {
+		if (cursor >= batch_end) {
+			const uint32_t total = static_cast<uint32_t>(g.variant_list.size());
+			uint32_t begin = g.next_variant_idx.fetch_add(kListBatch);
+			if (begin >= total) {
+				return false;
+			}
+			batch_begin = begin;
+			batch_end = std::min<uint64_t>(total, static_cast<uint64_t>(begin) + kListBatch);
+			cursor = begin;
+			have_strata = false;
+			list_slot.clear();
+			if (g.dataset && g.want_counts) {
+				counts.resize(4 * static_cast<size_t>(batch_end - batch_begin));
+				char errbuf[PGH_ERRBUF_LEN] = {0};
+				for (uint32_t pos = batch_begin; pos < batch_end; pos++) {
+					const uint32_t v = g.variant_list[pos];
+					list_slot[v] = pos - batch_begin;
+					int rc = pgh_counts_range(g.dataset->handle, g.subset ? g.subset->handle : nullptr, v, v + 1,
+					                          reinterpret_cast<uint32_t(*)[4]>(counts.data() + 4 * (pos - batch_begin)),
+					                          errbuf);
+					if (rc != PGH_OK) {
+						throw IOException("%s: PgrGetCounts failed for variant %u: %s", func_name, v, string(errbuf));
+					}
+				}
+			}
+		}
+		vidx = g.variant_list[cursor++];
+		return true;
+	}
+
 	void Tally(VariantScanGlobal &g, DeviceSubset *ss, vector<uint32_t> &out, const string &func_name) {
 		out.resize(4 * static_cast<size_t>(batch_end - batch_begin));
 		char errbuf[PGH_ERRBUF_LEN] = {0};

@@ -95,6 +95,37 @@ def test_read_pgen_bind_errors():
     assert "incompatible with phased" in err("read_pgen", EX, genotypes="stats", phased=True)
     assert "invalid genotypes value" in err("read_pgen", EX, genotypes="matrix")
     assert "orient" in err("read_pgen", EX, orient="sample")
+    # read_pgen_genotypes_columns_negative.test:12-14
+    assert "genotypes := 'columns' requires a .psam/.fam file" in err(
+        "read_pgen", data_path("pgen_orphan.pgen"), genotypes="columns")
+    assert "genotypes := 'struct' requires a .psam/.fam file" in err(
+        "read_pgen", data_path("pgen_orphan.pgen"), genotypes="struct")
+
+
+def test_read_pgen_variants_parameter_binds():
+    """read_pgen_variants.test: every accepted shape of `variants :=`, metadata-only so no device is needed."""
+    ids = lambda **kw: F.query("read_pgen", EX, columns=["ID"], **kw).column("ID")
+    assert ids(variants=0) == ["rs1"] and ids(variants=3) == ["rs4"]
+    assert ids(variants="rs1") == ["rs1"]
+    assert ids(variants=[0, 2]) == ["rs1", "rs3"]
+    assert ids(variants=[2, 0]) == ["rs3", "rs1"]          # caller order is kept
+    assert ids(variants=["rs1", "rs4"]) == ["rs1", "rs4"]
+    assert ids(variants="1:10000") == ["rs1"] and ids(variants="1:10000:A:G") == ["rs1"]
+    assert ids(variants={"start": 0, "stop": 1}) == ["rs1", "rs2"]
+    assert ids(variants={"start": "rs2", "stop": "rs4"}) == ["rs2", "rs3", "rs4"]
+    assert ids(variants={"chrom": "2", "pos": 15000}) == ["rs4"]
+    assert ids(variants=[{"chrom": "1", "pos": 20000}, {"chrom": "2", "pos": 15000}]) == ["rs2", "rs4"]
+    assert "out of range" in err("read_pgen", EX, variants=999)
+    assert "not found" in err("read_pgen", EX, variants="rs999")
+    assert "not found" in err("read_pgen", EX, variants="1:10000:A:T")
+    assert "not found" in err("read_pgen", EX, variants={"chrom": "7", "pos": 1})
+    assert "invalid CPRA format" in err("read_pgen", EX, variants="1:2:3")
+    assert "duplicate variant index 0" in err("read_pgen", EX, variants=[0, 1, 0])
+    assert "must not be empty" in err("read_pgen", EX, variants=[])
+    assert "must not be NULL" in err("read_pgen", EX, variants=None)
+    assert "ambiguous" in err("read_pgen", EX, variants={"start": 0, "chrom": "1"})
+    assert "after stop" in err("read_pgen", EX, variants={"start": 2, "stop": 1})
+    assert "must be an integer, string, struct, or list" in err("read_pgen", EX, variants=1.5)
 
 
 def test_metadata_only_projection_needs_no_device():

@@ -314,6 +314,91 @@ def test_read_pgen_dosages_and_phase():
     assert F.query("read_pgen", ph, columns=["genotypes"]).types == ["TINYINT[4]"]
 
 
+def test_read_pgen_columns_and_struct_modes():
+    """read_pgen_genotypes_columns.test, read_pfile_genotypes_struct.test:48-60, read_pgen_dosage.test:85-95."""
+    exp = {vid: [(None if g == -9 else g) for g in row]
+           for vid, row in zip(("rs1", "rs2", "rs3", "rs4"), KA["pgen_example_genotypes"]["matrix"])}
+    S = ["SAMPLE1", "SAMPLE2", "SAMPLE3", "SAMPLE4"]
+    r = F.query("read_pgen", EX, genotypes="columns", columns=["ID"] + S)
+    assert r.all_names == ["CHROM", "POS", "ID", "REF", "ALT"] + S
+    assert r.types == ["VARCHAR"] + ["TINYINT"] * 4 and len(r) == 4
+    assert {row[0]: list(row[1:]) for row in r.rows} == exp
+    assert exp["rs1"] == [0, 1, 2, None] and exp["rs2"] == [1, 1, 0, 2]
+    r = F.query("read_pgen", EX, genotypes="columns", samples=["SAMPLE3", "SAMPLE1"],
+                columns=["ID", "SAMPLE1", "SAMPLE3"])
+    assert r.all_names[5:] == ["SAMPLE1", "SAMPLE3"]
+    assert dict((row[0], row[1:]) for row in r.rows) == {"rs1": (0, 2), "rs2": (1, 0), "rs3": (2, 1), "rs4": (0, 1)}
+    # projecting one sample column out of order still reads the right sample
+    r = F.query("read_pgen", EX, genotypes="columns", columns=["SAMPLE4", "ID"])
+    assert sorted(r.rows, key=lambda t: t[1]) == [(None, "rs1"), (2, "rs2"), (0, "rs3"), (2, "rs4")]
+    r = F.query("read_pgen", EX, genotypes="columns", columns=["CHROM", "POS"])
+    assert r.sorted("CHROM", "POS") == [("1", 10000), ("1", 20000), ("1", 30000), ("2", 15000)]
+    r = F.query("read_pgen", data_path("all_missing.pgen"), genotypes="columns", columns=["ID", "SAMPLE1", "SAMPLE2"])
+    assert r.sorted("ID") == [("rs_miss1", None, None), ("rs_miss2", None, None)]
+    r = F.query("read_pgen", EX, genotypes="columns", dosages=True, columns=["ID", "SAMPLE1", "SAMPLE4"])
+    assert r.types == ["VARCHAR", "DOUBLE", "DOUBLE"] and dict((a, (b, c)) for a, b, c in r.rows)["rs1"] == (0.0, None)
+    r = F.query("read_pgen", EX, genotypes="columns", include_genotypes=["het"], columns=["ID"] + S)
+    assert dict((row[0], list(row[1:])) for row in r.rows)["rs2"] == [1, 1, None, None]
+
+    r = F.query("read_pgen", EX, genotypes="struct", columns=["ID", "genotypes"])
+    assert r.types[1] == "STRUCT(SAMPLE1 TINYINT, SAMPLE2 TINYINT, SAMPLE3 TINYINT, SAMPLE4 TINYINT)"
+    assert {vid: [g[s] for s in S] for vid, g in r.rows} == exp
+    r = F.query("read_pgen", EX, genotypes="struct", samples=["SAMPLE1", "SAMPLE3"], columns=["ID", "genotypes"])
+    assert dict(r.rows) == {"rs1": {"SAMPLE1": 0, "SAMPLE3": 2}, "rs2": {"SAMPLE1": 1, "SAMPLE3": 0},
+                            "rs3": {"SAMPLE1": 2, "SAMPLE3": 1}, "rs4": {"SAMPLE1": 0, "SAMPLE3": 1}}
+    ph = data_path("phased_example.pgen")
+    r = dict(F.query("read_pgen", ph, phased=True, genotypes="struct", columns=["ID", "genotypes"]).rows)
+    assert [r["rs2"][f"SAMPLE{i}"] for i in range(1, 5)] == [[0, 1], [1, 0], [0, 0], [1, 1]]
+    d = dict(F.query("read_pgen", data_path("dosage_example.pgen"), dosages=True, genotypes="struct",
+                     columns=["ID", "genotypes"]).rows)
+    assert [[d[v][f"SAMPLE{i}"] for i in range(1, 5)] for v in sorted(d)] == KA["dosage_example"]["dosages"]
+
+
+def test_read_pgen_variants_parameter(oracle):
+    """read_pgen_variants.test with genotype columns, plus lists that cross the list-batch size."""
+    exp = [[(None if g == -9 else g) for g in row] for row in KA["pgen_example_genotypes"]["matrix"]]
+    r = F.query("read_pgen", EX, variants=[3, 0], columns=["ID", "genotypes"])
+    assert r.rows == [("rs4", exp[3]), ("rs1", exp[0])]
+    r = F.query("read_pgen", EX, variants={"start": 1, "stop": 2}, genotypes="counts", columns=["ID", "genotypes"])
+    assert [(v, [g["hom_ref"], g["het"], g["hom_alt"], g["missing"]]) for v, g in r.rows] == [
+        ("rs2", KA["pgen_example_freq"]["counts"][1]), ("rs3", KA["pgen_example_freq"]["counts"][2])]
+    assert F.query("read_pgen", EX, variants=[0, 1, 2, 3], af_range={"max": 0.4}, columns=["ID"]).column("ID") == ["rs4"]
+    big = data_path("large_example.pgen")
+    pg = oracle.Pgen(big)
+    rng = np.random.default_rng(5)
+    pick = [int(v) for v in rng.permutation(3000)[:700]]
+    allrows = F.query("read_pgen", big, columns=["CHROM", "POS", "genotypes"])
+    full = {(c, p): g for c, p, g in allrows.rows}
+    sel = F.query("read_pgen", big, variants=pick, columns=["CHROM", "POS", "genotypes"], threads=3)
+    assert len(sel) == 700 and len(set((c, p) for c, p, _ in sel.rows)) == 700
+    assert all(full[(c, p)] == g for c, p, g in sel.rows)
+    got = sorted(tuple(-9 if x is None else x for x in g) for _, _, g in sel.rows)
+    assert got == sorted(tuple(int(x) for x in pg.geno(v)) for v in pick)
+    # one thread walks the list in caller order
+    one = F.query("read_pgen", big, variants=pick[:300], columns=["genotypes"], threads=1)
+    assert [tuple(-9 if x is None else x for x in g) for (g,) in one.rows] == [
+        tuple(int(x) for x in pg.geno(v)) for v in pick[:300]]
+
+
+def test_read_pgen_filters_across_device_batches(oracle):
+    """50,000 variants = 4 device batches: filtered chunks must not straddle a batch claim."""
+    path = data_path("streaming_example.pgen")
+    pg = oracle.Pgen(path)
+    c = np.array([pg.counts(v) for v in range(pg.M)], dtype=np.int64)
+    obs = c[:, 0] + c[:, 1] + c[:, 2]
+    af = np.where(obs > 0, (c[:, 1] + 2 * c[:, 2]) / np.maximum(2 * obs, 1), np.nan)
+    keep = np.flatnonzero((obs > 0) & (af >= 0.3) & (af <= 0.6))
+    for threads in (1, 4):
+        r = F.query("read_pgen", path, af_range={"min": 0.3, "max": 0.6}, genotypes="counts",
+                    columns=["POS", "CHROM", "genotypes"], threads=threads)
+        assert len(r) == len(keep)
+        got = sorted((g["hom_ref"], g["het"], g["hom_alt"], g["missing"]) for _, _, g in r.rows)
+        assert got == sorted(tuple(int(x) for x in c[v]) for v in keep)
+    r = F.query("read_pgen", path, af_range={"min": 0.3, "max": 0.6}, columns=["genotypes"], threads=2)
+    got = sorted(tuple(-9 if x is None else x for x in g) for (g,) in r.rows)
+    assert got == sorted(tuple(int(x) for x in pg.geno(v)) for v in keep)
+
+
 # ---- plink_pca (plink_pca.test) ------------------------------------------------------
 
 def test_pca_known_answers():
