@@ -226,6 +226,15 @@ def main():
         g1 = np.random.default_rng(SEED + 2).standard_normal((n, 2 * k))
         m_eff = len(p_vidx)
         qq = (k + 1) * 2 * k
+        m_total = m_eff
+        pca_allreduce = None
+        if dist is not None:
+            # one PCA over every rank's variants: X is split by rows, G2 / Gram blocks / BB are
+            # all-reduced over RCCL through the library's callback (pgh_pca_sharded)
+            t_total = torch.tensor([m_eff], dtype=torch.int64, device=dev)
+            dist.all_reduce(t_total)
+            m_total = int(t_total.item())
+            pca_allreduce = sharding.device_allreduce(dist)
         algo_bytes = (k + 2) * m_eff * record_bytes
         # k power passes (A+B) + the last Step A + phase 3
         algo_flops = k * (2 * 2.0 * m_eff * n * 2 * k) + 2.0 * m_eff * n * 2 * k + 2.0 * m_eff * n * qq
@@ -236,7 +245,10 @@ def main():
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
-            ev, _ = ds.pca(p_vidx, p_center, p_inv, k, g1)
+            if pca_allreduce is None:
+                ev, _ = ds.pca(p_vidx, p_center, p_inv, k, g1)
+            else:
+                ev, _ = ds.pca_sharded(p_vidx, p_center, p_inv, m_total, k, g1, pca_allreduce)
             pca_ev.append(ev)
             if timed:
                 e1.record(stream)

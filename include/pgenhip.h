@@ -221,6 +221,24 @@ int pgh_pca(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_var, con
             const double *center, const double *inv_stdev, uint32_t n_pcs, const double *g1_init,
             double *eigenvalues, double *eigenvectors, char *errbuf);
 
+/* The same over variant shards, one process per GPU (variants
+ * sharded, one exchange per pass).  Each rank passes ITS shard's effective variants
+ * (n_var may be 0) and the job-wide count n_var_total; X is split by rows, so G2 = X^T Y,
+ * the Gram matrices of the Krylov block and B = X^T U are sums of per-shard terms.
+ * The library leaves the transport to the host: `allreduce` must sum `count` doubles at
+ * device pointer `d_buf` in place over all ranks.  Work that produces d_buf has been
+ * enqueued on `stream`; the callback either enqueues its collective there (RCCL:
+ * ncclAllReduce(d_buf, d_buf, count, ncclDouble, ncclSum, comm, stream)) or synchronises
+ * the stream itself before a host transport, and returns 0 on success.  Calls happen in
+ * the same order with the same counts on every rank: n_pcs of N*2k, O(n_pcs) small Gram
+ * blocks, one of N*qq.  g1_init must be identical on all ranks; eigenvalues and
+ * eigenvectors come back replicated.  allreduce == NULL requires n_var_total == n_var. */
+typedef int (*pgh_allreduce_fn)(void *ctx, void *d_buf, uint64_t count, void *stream);
+int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_var, const uint32_t *vidx,
+                    const double *center, const double *inv_stdev, uint64_t n_var_total, uint32_t n_pcs,
+                    const double *g1_init, pgh_allreduce_fn allreduce, void *allreduce_ctx, double *eigenvalues,
+                    double *eigenvectors, char *errbuf);
+
 /* ---- per-variant calls mirroring pgenlib -------------------------------- */
 
 /* PgrInit + PgrSetSampleSubsetIndex per scan thread (src/plink_freq.cpp:381-397). */

@@ -1141,8 +1141,21 @@ extern "C" int pgh_score(const pgh_dataset *ds, const pgh_subset *subset, uint32
 extern "C" int pgh_pca(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_var, const uint32_t *vidx,
                        const double *center, const double *inv_stdev, uint32_t n_pcs, const double *g1_init,
                        double *eigenvalues, double *eigenvectors, char *errbuf) {
-	if (!ds || !vidx || !center || !inv_stdev || !g1_init || !eigenvalues || !eigenvectors || n_pcs == 0) {
+	return pgh_pca_sharded(ds, subset, n_var, vidx, center, inv_stdev, n_var, n_pcs, g1_init, nullptr, nullptr,
+	                       eigenvalues, eigenvectors, errbuf);
+}
+
+extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_var, const uint32_t *vidx,
+                               const double *center, const double *inv_stdev, uint64_t n_var_total, uint32_t n_pcs,
+                               const double *g1_init, pgh_allreduce_fn allreduce, void *allreduce_ctx,
+                               double *eigenvalues, double *eigenvectors, char *errbuf) {
+	if (!ds || !g1_init || !eigenvalues || !eigenvectors || n_pcs == 0 ||
+	    (n_var && (!vidx || !center || !inv_stdev))) {
 		SetErr(errbuf, "null or empty argument");
+		return PGH_ERR_ARG;
+	}
+	if (n_var_total < n_var || (!allreduce && n_var_total != n_var)) {
+		SetErr(errbuf, "n_var_total must cover this shard's variants (and equal them without an all-reduce)");
 		return PGH_ERR_ARG;
 	}
 	int rc = CheckSubset(ds, subset, errbuf);
@@ -1151,10 +1164,11 @@ extern "C" int pgh_pca(const pgh_dataset *ds, const pgh_subset *subset, uint32_t
 	}
 	const uint32_t N = ds->sample_ct;
 	const uint32_t n_out = subset ? subset->n_out : N;
-	const uint32_t M = n_var;
+	const uint32_t M = n_var; // this shard's rows of X; every 1/M and the eigenvalue divisor use the total
+	const double m_total = static_cast<double>(n_var_total);
 	const uint32_t k2 = 2 * n_pcs;
 	const uint32_t qq = (n_pcs + 1) * k2;
-	if (M < qq || n_out < qq) {
+	if (n_var_total < qq || n_out < qq) {
 		SetErr(errbuf, "too few variants or samples for the requested number of PCs");
 		return PGH_ERR_ARG;
 	}
@@ -1167,17 +1181,39 @@ extern "C" int pgh_pca(const pgh_dataset *ds, const pgh_subset *subset, uint32_t
 		local[i] = vidx[i] - ds->v_begin;
 	}
 	hipStream_t st = hipStreamPerThread;
+	// Sum a device buffer over the variant shards (X is split by rows, so every X^T(...)
+	// product and every Gram matrix of a tall factor is a sum of per-shard terms).
+	auto all_sum = [&](double *buf, uint64_t count) -> int {
+		if (!allreduce) {
+			return PGH_OK;
+		}
+		if (allreduce(allreduce_ctx, buf, count, st) != 0) {
+			SetErr(errbuf, "pca: the all-reduce callback failed");
+			return PGH_ERR_DEVICE;
+		}
+		return PGH_OK;
+	};
+#define PGH_SUM(buf, count)                                                                                            \
+	do {                                                                                                               \
+		int rc_sum_ = all_sum((buf), (count));                                                                         \
+		if (rc_sum_ != PGH_OK) {                                                                                       \
+			return rc_sum_;                                                                                            \
+		}                                                                                                              \
+	} while (0)
+	const size_t m_alloc = std::max<uint32_t>(M, 1);
 	DevBuf d_vlist, d_center, d_inv, d_ts, d_g1, d_g2, d_qq, d_bb;
-	PGH_HIP(d_vlist.Alloc(sizeof(uint32_t) * M), "hipMalloc(pca)");
-	PGH_HIP(d_center.Alloc(sizeof(double) * M), "hipMalloc(pca)");
-	PGH_HIP(d_inv.Alloc(sizeof(double) * M), "hipMalloc(pca)");
-	PGH_HIP(d_ts.Alloc(32ull * M), "hipMalloc(pca)");
+	PGH_HIP(d_vlist.Alloc(sizeof(uint32_t) * m_alloc), "hipMalloc(pca)");
+	PGH_HIP(d_center.Alloc(sizeof(double) * m_alloc), "hipMalloc(pca)");
+	PGH_HIP(d_inv.Alloc(sizeof(double) * m_alloc), "hipMalloc(pca)");
+	PGH_HIP(d_ts.Alloc(32ull * m_alloc), "hipMalloc(pca)");
 	PGH_HIP(d_g1.Alloc(sizeof(double) * N * k2), "hipMalloc(pca)");
 	PGH_HIP(d_g2.Alloc(sizeof(double) * N * k2), "hipMalloc(pca)");
-	PGH_HIP(d_qq.Alloc(sizeof(double) * static_cast<size_t>(M) * qq), "hipMalloc(pca)");
-	PGH_HIP(hipMemcpy(d_vlist.p, local.data(), sizeof(uint32_t) * M, hipMemcpyHostToDevice), "pca upload");
-	PGH_HIP(hipMemcpy(d_center.p, center, sizeof(double) * M, hipMemcpyHostToDevice), "pca upload");
-	PGH_HIP(hipMemcpy(d_inv.p, inv_stdev, sizeof(double) * M, hipMemcpyHostToDevice), "pca upload");
+	PGH_HIP(d_qq.Alloc(sizeof(double) * m_alloc * qq), "hipMalloc(pca)");
+	if (M) {
+		PGH_HIP(hipMemcpy(d_vlist.p, local.data(), sizeof(uint32_t) * M, hipMemcpyHostToDevice), "pca upload");
+		PGH_HIP(hipMemcpy(d_center.p, center, sizeof(double) * M, hipMemcpyHostToDevice), "pca upload");
+		PGH_HIP(hipMemcpy(d_inv.p, inv_stdev, sizeof(double) * M, hipMemcpyHostToDevice), "pca upload");
+	}
 	{
 		// start matrix in raw-sample rows (excluded samples stay zero)
 		std::vector<double> g1_raw(static_cast<size_t>(N) * k2, 0.0);
@@ -1187,24 +1223,31 @@ extern "C" int pgh_pca(const pgh_dataset *ds, const pgh_subset *subset, uint32_t
 		}
 		PGH_HIP(hipMemcpy(d_g1.p, g1_raw.data(), sizeof(double) * g1_raw.size(), hipMemcpyHostToDevice), "pca upload");
 	}
-	PGH_HIP(pgh::LaunchNormTables(d_center.As<double>(), d_inv.As<double>(), M, d_ts.As<double>(), st), "pca tables");
+	if (M) {
+		PGH_HIP(pgh::LaunchNormTables(d_center.As<double>(), d_inv.As<double>(), M, d_ts.As<double>(), st), "pca tables");
+	}
 	const RowView view = ds->View();
 	double *g1 = d_g1.As<double>();
 	double *g2 = d_g2.As<double>();
 	const uint8_t *mask2 = subset ? subset->d_mask2 : nullptr;
 	for (uint32_t pass = 0; pass <= n_pcs; pass++) {
 		double *y = d_qq.As<double>() + static_cast<size_t>(pass) * k2;
-		// Step A: QQ[:, pass*2k : (pass+1)*2k] = X * G1
-		PGH_HIP(pgh::LaunchVariantReduce(view, d_vlist.As<uint32_t>(), M, d_ts.As<double>(), g1, k2, k2, y, qq, st),
-		        "pca step A");
+		// Step A: QQ[:, pass*2k : (pass+1)*2k] = X * G1   (rows of this shard only)
+		if (M) {
+			PGH_HIP(pgh::LaunchVariantReduce(view, d_vlist.As<uint32_t>(), M, d_ts.As<double>(), g1, k2, k2, y, qq, st),
+			        "pca step A");
+		}
 		if (pass < n_pcs) {
-			// Step B + merge: G1 = X^T Y / M
+			// Step B + merge: G1 = X^T Y / M, summed over shards
 			PGH_HIP(hipMemsetAsync(g2, 0, sizeof(double) * N * k2, st), "pca memset");
-			PGH_HIP(pgh::LaunchTableAccumulate(view, d_vlist.As<uint32_t>(), M, y, qq, k2, d_ts.As<double>(), nullptr,
-			                                   nullptr, false, g2, k2, nullptr, nullptr, st),
-			        "pca step B");
+			if (M) {
+				PGH_HIP(pgh::LaunchTableAccumulate(view, d_vlist.As<uint32_t>(), M, y, qq, k2, d_ts.As<double>(),
+				                                   nullptr, nullptr, false, g2, k2, nullptr, nullptr, st),
+				        "pca step B");
+			}
+			PGH_SUM(g2, static_cast<uint64_t>(N) * k2);
 			PGH_HIP(pgh::LaunchMaskRows(g2, N, k2, k2, mask2, st), "pca mask");
-			PGH_HIP(pgh::LaunchScale(g2, static_cast<uint64_t>(N) * k2, 1.0 / static_cast<double>(M), st), "pca scale");
+			PGH_HIP(pgh::LaunchScale(g2, static_cast<uint64_t>(N) * k2, 1.0 / m_total, st), "pca scale");
 			std::swap(g1, g2);
 		}
 	}
@@ -1218,7 +1261,7 @@ extern "C" int pgh_pca(const pgh_dataset *ds, const pgh_subset *subset, uint32_t
 	{
 		DevBuf d_small, d_tmp;
 		PGH_HIP(d_small.Alloc(sizeof(double) * static_cast<size_t>(qq) * k2), "hipMalloc(pca)");
-		PGH_HIP(d_tmp.Alloc(sizeof(double) * static_cast<size_t>(M) * k2), "hipMalloc(pca)");
+		PGH_HIP(d_tmp.Alloc(sizeof(double) * m_alloc * k2), "hipMalloc(pca)");
 		double *q = d_qq.As<double>();
 		std::vector<double> g(static_cast<size_t>(k2) * k2), lam, vec, t(static_cast<size_t>(k2) * k2);
 		for (uint32_t p = 0; p <= n_pcs; p++) {
@@ -1226,14 +1269,22 @@ extern "C" int pgh_pca(const pgh_dataset *ds, const pgh_subset *subset, uint32_t
 			const uint32_t prev = p * k2;
 			for (int rep = 0; rep < 2 && prev > 0; rep++) {
 				PGH_HIP(hipMemsetAsync(d_small.p, 0, sizeof(double) * prev * k2, st), "pca memset");
-				PGH_HIP(pgh::LaunchTallGram(q, qq, prev, bp, qq, k2, M, d_small.As<double>(), k2, st), "pca gram");
-				PGH_HIP(pgh::LaunchTallTimesSmall(q, qq, prev, d_small.As<double>(), k2, k2, -1.0, 1.0, bp, qq, bp, qq, M,
-				                                  st),
-				        "pca project");
+				if (M) {
+					PGH_HIP(pgh::LaunchTallGram(q, qq, prev, bp, qq, k2, M, d_small.As<double>(), k2, st), "pca gram");
+				}
+				PGH_SUM(d_small.As<double>(), static_cast<uint64_t>(prev) * k2);
+				if (M) {
+					PGH_HIP(pgh::LaunchTallTimesSmall(q, qq, prev, d_small.As<double>(), k2, k2, -1.0, 1.0, bp, qq, bp, qq,
+					                                  M, st),
+					        "pca project");
+				}
 			}
 			for (int rep = 0; rep < 2; rep++) {
 				PGH_HIP(hipMemsetAsync(d_small.p, 0, sizeof(double) * k2 * k2, st), "pca memset");
-				PGH_HIP(pgh::LaunchTallGram(bp, qq, k2, bp, qq, k2, M, d_small.As<double>(), k2, st), "pca gram");
+				if (M) {
+					PGH_HIP(pgh::LaunchTallGram(bp, qq, k2, bp, qq, k2, M, d_small.As<double>(), k2, st), "pca gram");
+				}
+				PGH_SUM(d_small.As<double>(), static_cast<uint64_t>(k2) * k2);
 				PGH_HIP(hipMemcpyAsync(g.data(), d_small.p, sizeof(double) * k2 * k2, hipMemcpyDeviceToHost, st),
 				        "pca download");
 				PGH_HIP(hipStreamSynchronize(st), "pca sync");
@@ -1247,10 +1298,12 @@ extern "C" int pgh_pca(const pgh_dataset *ds, const pgh_subset *subset, uint32_t
 				}
 				PGH_HIP(hipMemcpyAsync(d_small.p, t.data(), sizeof(double) * k2 * k2, hipMemcpyHostToDevice, st),
 				        "pca upload");
-				PGH_HIP(pgh::LaunchTallTimesSmall(bp, qq, k2, d_small.As<double>(), k2, k2, 1.0, 0.0, nullptr, 0,
-				                                  d_tmp.As<double>(), k2, M, st),
-				        "pca orthonormalise");
-				PGH_HIP(pgh::LaunchCopyCols(d_tmp.As<double>(), k2, bp, qq, k2, M, st), "pca copy");
+				if (M) {
+					PGH_HIP(pgh::LaunchTallTimesSmall(bp, qq, k2, d_small.As<double>(), k2, k2, 1.0, 0.0, nullptr, 0,
+					                                  d_tmp.As<double>(), k2, M, st),
+					        "pca orthonormalise");
+					PGH_HIP(pgh::LaunchCopyCols(d_tmp.As<double>(), k2, bp, qq, k2, M, st), "pca copy");
+				}
 				PGH_HIP(hipStreamSynchronize(st), "pca sync"); // t is reused by the next repetition
 			}
 		}
@@ -1258,9 +1311,13 @@ extern "C" int pgh_pca(const pgh_dataset *ds, const pgh_subset *subset, uint32_t
 	// Phase 3: BB = X^T U   (src/plink_pca.cpp:664-676)
 	PGH_HIP(d_bb.Alloc(sizeof(double) * static_cast<size_t>(N) * qq), "hipMalloc(pca)");
 	PGH_HIP(hipMemsetAsync(d_bb.p, 0, sizeof(double) * static_cast<size_t>(N) * qq, st), "pca memset");
-	PGH_HIP(pgh::LaunchTableAccumulate(view, d_vlist.As<uint32_t>(), M, d_qq.As<double>(), qq, qq, d_ts.As<double>(),
-	                                   nullptr, nullptr, false, d_bb.As<double>(), qq, nullptr, nullptr, st),
-	        "pca phase 3");
+	if (M) {
+		PGH_HIP(pgh::LaunchTableAccumulate(view, d_vlist.As<uint32_t>(), M, d_qq.As<double>(), qq, qq,
+		                                   d_ts.As<double>(), nullptr, nullptr, false, d_bb.As<double>(), qq, nullptr,
+		                                   nullptr, st),
+		        "pca phase 3");
+	}
+	PGH_SUM(d_bb.As<double>(), static_cast<uint64_t>(N) * qq);
 	PGH_HIP(pgh::LaunchMaskRows(d_bb.As<double>(), N, qq, qq, mask2, st), "pca mask");
 	// Final SVD of BB (src/plink_pca.cpp:700-720) through its qq x qq Gram matrix:
 	// BB^T BB = V S^2 V^T gives the eigenvalues S^2 / M directly and U_k = BB V_k S_k^-1.
@@ -1285,7 +1342,7 @@ extern "C" int pgh_pca(const pgh_dataset *ds, const pgh_subset *subset, uint32_t
 		std::vector<double> vk(static_cast<size_t>(qq) * n_pcs);
 		for (uint32_t pc = 0; pc < n_pcs; pc++) {
 			const double l = lam[pc] > 0.0 ? lam[pc] : 0.0;
-			eigenvalues[pc] = l / static_cast<double>(M);
+			eigenvalues[pc] = l / m_total;
 			const double inv_s = l > 0.0 ? 1.0 / std::sqrt(l) : 0.0;
 			for (uint32_t i = 0; i < qq; i++) {
 				vk[static_cast<size_t>(i) * n_pcs + pc] = vec[static_cast<size_t>(i) * qq + pc] * inv_s;
@@ -1302,6 +1359,7 @@ extern "C" int pgh_pca(const pgh_dataset *ds, const pgh_subset *subset, uint32_t
 		Compact<double>(subset, uk_raw.data(), n_pcs, eigenvectors, N);
 	}
 	return PGH_OK;
+#undef PGH_SUM
 }
 
 // ---------------------------------------------------------------------------

@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     "pgh_close", "pgh_subset_create", "pgh_subset_size", "pgh_subset_destroy", "pgh_counts_range",
     "pgh_counts_range_dev", "pgh_freq_from_counts_dev", "pgh_fused_tally_dev", "pgh_missing_per_sample", "pgh_missing_per_sample_dev", "pgh_unpack_range",
     "pgh_unpack_range_dev", "pgh_score", "pgh_score_dev", "pgh_score_plan_create", "pgh_score_run_dev",
-    "pgh_score_plan_destroy", "pgh_pca", "pgh_reader_create", "pgh_reader_destroy",
+    "pgh_score_plan_destroy", "pgh_pca", "pgh_pca_sharded", "pgh_reader_create", "pgh_reader_destroy",
     "pgh_get_2bit", "pgh_get_counts", "pgh_get_missingness", "pgh_get_int8", "pgh_get_dosage_f64", "pgh_get_phased",
     "pgh_reader_error", "pgh_hwe_lnp", "pgh_hwe_xchr_lnp", "pgh_hwe_lnp_batch", "pgh_hwe_lnp_batch_dev",
 ]
@@ -39,6 +39,10 @@ class PghInfo(C.Structure):
         ("max_record_bytes", C.c_uint32), ("record_bytes", C.c_uint32), ("pitch_bytes", C.c_uint64),
         ("vrtype_hist", C.c_uint32 * 8), ("device", C.c_int32),
     ]
+
+
+# pgh_allreduce_fn(ctx, d_buf, count, stream) -> 0 on success
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
 
 
 class PghError(IOError):
@@ -93,6 +97,7 @@ def _load():
         "pgh_score_run_dev": (C.c_int, [vp, vp, vp, vp, vp, cp]),
         "pgh_score_plan_destroy": (None, [vp]),
         "pgh_pca": (C.c_int, [vp, vp, u32, vp, vp, vp, u32, vp, vp, vp, cp]),
+        "pgh_pca_sharded": (C.c_int, [vp, vp, u32, vp, vp, vp, C.c_uint64, u32, vp, ALLREDUCE_FN, vp, vp, vp, cp]),
         "pgh_reader_create": (C.c_int, [vp, vp, C.POINTER(vp), cp]),
         "pgh_reader_destroy": (None, [vp]),
         "pgh_get_2bit": (C.c_int, [vp, u32, vp]),
@@ -390,6 +395,38 @@ class Dataset:
         eb = _errbuf()
         _check(_lib.pgh_pca(self._h, subset._h if subset else None, len(vidx), _ptr(vidx), _ptr(center),
                             _ptr(inv_stdev), n_pcs, _ptr(g1), _ptr(ev), _ptr(vecs), eb), eb)
+        return ev, vecs
+
+    def pca_sharded(self, vidx, center, inv_stdev, n_var_total: int, n_pcs: int, g1_init, allreduce,
+                    subset: Subset | None = None):
+        """pgh_pca_sharded: this rank's effective variants + `allreduce(d_ptr, count, stream)`, a
+        callable that sums `count` doubles at device pointer `d_ptr` in place over all ranks
+        (see sharding.device_allreduce for the torch.distributed one)."""
+        vidx = np.ascontiguousarray(vidx, dtype=np.uint32)
+        center = np.ascontiguousarray(center, dtype=np.float64)
+        inv_stdev = np.ascontiguousarray(inv_stdev, dtype=np.float64)
+        g1 = np.ascontiguousarray(g1_init, dtype=np.float64)
+        n_out = subset.size if subset else self.n_samples
+        assert g1.shape == (n_out, 2 * n_pcs)
+        ev = np.zeros(n_pcs, dtype=np.float64)
+        vecs = np.zeros((n_out, n_pcs), dtype=np.float64)
+        failure = []
+
+        def trampoline(_ctx, d_buf, count, stream):
+            try:
+                allreduce(int(d_buf), int(count), int(stream or 0))
+                return 0
+            except BaseException as exc:  # an exception must not unwind through the C frames
+                failure.append(exc)
+                return 1
+
+        cb = ALLREDUCE_FN(trampoline)
+        eb = _errbuf()
+        rc = _lib.pgh_pca_sharded(self._h, subset._h if subset else None, len(vidx), _ptr(vidx), _ptr(center),
+                                  _ptr(inv_stdev), n_var_total, n_pcs, _ptr(g1), cb, None, _ptr(ev), _ptr(vecs), eb)
+        if failure:
+            raise failure[0]
+        _check(rc, eb)
         return ev, vecs
 
     def reader(self, subset: Subset | None = None) -> "Reader":

@@ -2,7 +2,8 @@
 
 plink_freq / plink_hardy / plink_missing(variant) / read_pgen shard by contiguous
 variant ranges with no data-path collective; plink_missing(sample)
-and plink_score additionally sum their per-sample partials with one reduce."""
+and plink_score additionally sum their per-sample partials with one reduce;
+plink_pca all-reduces G2 / the Krylov Gram blocks / BB once per pass."""
 
 from __future__ import annotations
 
@@ -40,3 +41,28 @@ def max_over_ranks(dist, seconds: float, device=None) -> float:
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+class _DeviceDoubles:
+    """A span of doubles at a raw device pointer, in the shape torch.as_tensor adopts without a copy."""
+
+    def __init__(self, ptr: int, count: int):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+def device_allreduce(dist, group=None):
+    """The `allreduce(d_ptr, count, stream)` callable Dataset.pca_sharded wants, over a
+    torch.distributed process group (nccl == RCCL over xGMI on a multi-GPU node; gloo stages
+    through the host).  The library enqueued its kernels on its own stream, torch reduces on
+    torch's: fence both sides with a device synchronize — a handful of calls per PCA."""
+    import torch
+
+    def allreduce(d_ptr: int, count: int, stream: int):
+        if count == 0:
+            return
+        torch.cuda.synchronize()
+        t = torch.as_tensor(_DeviceDoubles(d_ptr, count), device="cuda")
+        dist.all_reduce(t, group=group)
+        torch.cuda.synchronize()
+
+    return allreduce

@@ -122,3 +122,114 @@ def test_two_ranks_on_the_gpu_equal_one_rank(tmp_path, gpu_lib):
     s, d, ac = whole.score(np.arange(m), w)
     assert np.array_equal(np.load(tmp_path / "ac.npy").astype(np.uint32), ac)
     assert np.allclose(np.load(tmp_path / "score.npy"), s, rtol=1e-9, atol=1e-9)
+
+
+# ---- plink_pca over variant shards -------------------------------------------------
+
+def _norms_from_counts(counts):
+    """Effective variants + (center, inv_stdev), as the shell's bind does (src/plink_pca.cpp:392-416)."""
+    c = counts.astype(np.float64)
+    obs = c[:, 0] + c[:, 1] + c[:, 2]
+    af = np.where(obs > 0, (c[:, 1] + 2 * c[:, 2]) / np.maximum(2 * obs, 1), 0.0)
+    keep = np.flatnonzero((obs > 0) & (af > 0) & (af < 1))
+    return keep, 2 * af[keep], 1.0 / np.sqrt(2 * af[keep] * (1 - af[keep]))
+
+
+def _cpu_pca_worker(rank, world, port, out_dir):
+    """numpy restatement of the sharded iteration: the same sums the HIP path all-reduces."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(3)
+    m, n, k = 600, 80, 2
+    x = rng.standard_normal((m, n))  # stands for the normalised genotype matrix
+    g1 = rng.standard_normal((n, 2 * k))
+    v0, v1 = sharding.shard_range(rank, world, m, "strong")
+    xs = x[v0:v1]
+
+    def all_sum(a):
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        dist.all_reduce(t)
+        return t.numpy()
+
+    blocks = []
+    for p in range(k + 1):
+        y = xs @ g1
+        blocks.append(y)
+        if p < k:
+            g1 = all_sum(xs.T @ y) / m
+    q = np.concatenate(blocks, axis=1)
+    k2 = 2 * k
+    for p in range(k + 1):  # block Gram-Schmidt through all-reduced Gram matrices
+        bp = q[:, p * k2:(p + 1) * k2]
+        for _ in range(2):
+            if p:
+                prev = q[:, :p * k2]
+                bp -= prev @ all_sum(prev.T @ bp)
+        for _ in range(2):
+            lam, vec = np.linalg.eigh(all_sum(bp.T @ bp))
+            bp[:] = bp @ (vec / np.sqrt(lam))
+    bb = all_sum(xs.T @ q)
+    ev = np.sort(np.linalg.eigvalsh(bb.T @ bb))[::-1][:k] / m
+    gram = all_sum(q.T @ q)  # every rank takes part in every all-reduce
+    if rank == 0:
+        np.save(os.path.join(out_dir, "ev.npy"), ev)
+        np.save(os.path.join(out_dir, "gram.npy"), gram)
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_pca_sums_equal_the_whole(tmp_path):
+    mp.spawn(_cpu_pca_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    rng = np.random.default_rng(3)
+    m, n, k = 600, 80, 2
+    x = rng.standard_normal((m, n))
+    g1 = rng.standard_normal((n, 2 * k))
+    blocks = []
+    for p in range(k + 1):
+        y = x @ g1
+        blocks.append(y)
+        if p < k:
+            g1 = x.T @ y / m
+    u, _, _ = np.linalg.svd(np.concatenate(blocks, axis=1), full_matrices=False)
+    s = np.linalg.svd(x.T @ u, compute_uv=False)
+    assert np.allclose(np.load(tmp_path / "ev.npy"), s[:k] ** 2 / m, rtol=1e-9)
+    assert np.allclose(np.load(tmp_path / "gram.npy"), np.eye(2 * k * (k + 1)), atol=1e-10)
+
+
+def _gpu_pca_worker(rank, world, port, out_dir, m, n, seed, k):
+    import sys
+    sys.path.insert(0, ROOT)
+    import plinking_duck_amd.lib as L
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    L.set_device(0)
+    v0, v1 = sharding.shard_range(rank, world, m, "strong")
+    ds = L.Dataset.synth(v0, v1, n, seed, 0.03)
+    keep, center, inv = _norms_from_counts(ds.counts_range())
+    total = torch.tensor([len(keep)], dtype=torch.int64)
+    dist.all_reduce(total)
+    g1 = np.random.default_rng(11).standard_normal((n, 2 * k))
+    ev, vecs = ds.pca_sharded(keep + v0, center, inv, int(total.item()), k, g1, sharding.device_allreduce(dist))
+    np.save(os.path.join(out_dir, f"ev{rank}.npy"), ev)
+    np.save(os.path.join(out_dir, f"vecs{rank}.npy"), vecs)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_pca_equals_one_rank(tmp_path, gpu_lib):
+    m, n, seed, k, world = 3000, 1501, 31, 3, 2
+    mp.spawn(_gpu_pca_worker, args=(world, _free_port(), str(tmp_path), m, n, seed, k), nprocs=world, join=True)
+    whole = gpu_lib.Dataset.synth(0, m, n, seed, 0.03)
+    keep, center, inv = _norms_from_counts(whole.counts_range())
+    g1 = np.random.default_rng(11).standard_normal((n, 2 * k))
+    ev, vecs = whole.pca(keep, center, inv, k, g1)
+    for rank in range(world):
+        assert np.allclose(np.load(tmp_path / f"ev{rank}.npy"), ev, rtol=1e-9)
+        got = np.load(tmp_path / f"vecs{rank}.npy")
+        for pc in range(k):
+            sign = np.sign(np.dot(got[:, pc], vecs[:, pc]))
+            assert np.allclose(got[:, pc] * sign, vecs[:, pc], atol=1e-7)
+    # world size 1 through the sharded entry point: the callback is called and changes nothing
+    ev1, _ = whole.pca_sharded(keep, center, inv, len(keep), k, g1, lambda p, c, s: None)
+    assert np.allclose(ev1, ev, rtol=1e-12)
