@@ -3,6 +3,7 @@
 #include "../../include/pgenhip.h"
 
 #include "hwe_core.hpp"
+#include "decode.hpp"
 #include "kernels.hpp"
 #include "linalg.hpp"
 #include "pgen_file.hpp"
@@ -17,6 +18,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -219,6 +221,66 @@ extern "C" int pgh_probe(const char *pgen_path, const char *pgi_path, pgh_info *
 	return PGH_OK;
 }
 
+// pgh_open's staging buffers (2 pinned + 2 device, 64 MB each) cost ~40 ms to allocate, more
+// than a small file takes to ingest: one set per device is parked here between opens.
+struct StageSet {
+	uint8_t *pinned[2] = {nullptr, nullptr};
+	uint8_t *device[2] = {nullptr, nullptr};
+	uint64_t bytes = 0;
+	int device_id = -1;
+	void Free() {
+		for (int i = 0; i < 2; i++) {
+			if (pinned[i]) {
+				(void)hipHostFree(pinned[i]);
+			}
+			if (device[i]) {
+				(void)hipFree(device[i]);
+			}
+			pinned[i] = device[i] = nullptr;
+		}
+		bytes = 0;
+	}
+};
+static std::mutex g_stage_mutex;
+static StageSet g_parked_stage;
+
+static hipError_t AcquireStage(uint64_t bytes, int device_id, bool want_device, StageSet &out) {
+	{
+		std::lock_guard<std::mutex> lock(g_stage_mutex);
+		if (g_parked_stage.bytes >= bytes && g_parked_stage.device_id == device_id) {
+			out = g_parked_stage;
+			g_parked_stage = StageSet();
+		}
+	}
+	out.device_id = device_id;
+	hipError_t e = hipSuccess;
+	for (int i = 0; i < 2 && e == hipSuccess; i++) {
+		if (!out.pinned[i]) {
+			e = hipHostMalloc(reinterpret_cast<void **>(&out.pinned[i]), bytes, hipHostMallocDefault);
+		}
+		if (e == hipSuccess && want_device && !out.device[i]) {
+			e = hipMalloc(reinterpret_cast<void **>(&out.device[i]), std::max(bytes, out.bytes));
+		}
+	}
+	out.bytes = std::max(bytes, out.bytes);
+	if (e != hipSuccess) {
+		out.Free();
+	}
+	return e;
+}
+
+static void ReleaseStage(StageSet &set) {
+	{
+		std::lock_guard<std::mutex> lock(g_stage_mutex);
+		if (g_parked_stage.bytes == 0 && set.bytes <= (64ull << 20) + 8192) {
+			g_parked_stage = set;
+			set = StageSet();
+			return;
+		}
+	}
+	set.Free();
+}
+
 // pread is the ceiling of the plain-record ingest path (one thread moves ~6 GB/s out of the
 // page cache); split a stage across a few threads.
 static bool ReadParallel(const pgh::RecordFile &file, uint64_t offset, size_t bytes, uint8_t *dst, std::string &err) {
@@ -332,8 +394,13 @@ extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t va
 		return rc;
 	}
 
-	// Stream the body through two pinned staging buffers: the host normaliser
-	// fills one while the previous one is in flight to HBM.
+	// Stream the body through two pinned staging buffers, three ways per run of records:
+	//   plain   a long run of literal 2-bit records is already the row image: pread into the
+	//           pinned buffer, re-pitch on the copy engine;
+	//   device  anything else: the records' file bytes go up as they are and
+	//           k_decode_records expands them in HBM (decode.hip);
+	//   host    an LD run whose base lies before the opened range (or PGH_HOST_NORMALIZE=1):
+	//           the host normaliser expands rows, which are then copied.
 	pgh::RecordFile file;
 	if (!file.Open(pgen_path, err)) {
 		SetErr(errbuf, err);
@@ -341,30 +408,63 @@ extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t va
 		return PGH_ERR_OPEN;
 	}
 	pgh::Normalizer norm(ix, file);
-	const uint64_t stage_bytes = 64ull << 20;
-	uint32_t rows_per_stage = static_cast<uint32_t>(std::max<uint64_t>(1, stage_bytes / ds->pitch));
-	uint8_t *stage[2] = {nullptr, nullptr};
+	const char *trace_env = std::getenv("PGH_TRACE_OPEN");
+	const bool trace = trace_env && *trace_env && *trace_env != '0';
+	const auto t_start = std::chrono::steady_clock::now();
+	auto lap = [&](const char *what) {
+		if (trace) {
+			std::fprintf(stderr, "pgh_open: %-14s +%.2f ms\n", what,
+			             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+		}
+	};
+	const char *force_host = std::getenv("PGH_HOST_NORMALIZE");
+	const bool host_only = force_host && *force_host && *force_host != '0';
+	const uint32_t rb = ds->record_bytes;
+	auto is_ld = [&](uint32_t r) { return (ix.vrtype[r] & 6u) == 2u; }; // types 2 and 3
+	auto is_plain = [&](uint32_t r) { return ix.vrtype[r] == 0 && ix.offset[r + 1] - ix.offset[r] == rb; };
+	// plain_run[i]: length of the run of plain records starting at variant_begin + i
+	const uint32_t range = variant_end - variant_begin;
+	std::vector<uint32_t> plain_run(static_cast<size_t>(range) + 1, 0);
+	bool any_encoded = false;
+	for (uint32_t i = range; i-- > 0;) {
+		plain_run[i] = is_plain(variant_begin + i) ? plain_run[i + 1] + 1 : 0;
+		any_encoded |= plain_run[i] == 0;
+	}
+	constexpr uint32_t kMinPlainRun = 256; // shorter plain runs ride along with their encoded neighbours
+	const uint64_t stage_bytes = std::max<uint64_t>(64ull << 20, ds->pitch + 4096);
+	const uint32_t rows_per_stage = static_cast<uint32_t>(std::max<uint64_t>(1, stage_bytes / ds->pitch));
+	StageSet staging;
+	int *d_error = nullptr;
 	hipEvent_t done[2] = {nullptr, nullptr};
 	hipStream_t stream = nullptr;
 	auto cleanup = [&]() {
+		ReleaseStage(staging);
 		for (int i = 0; i < 2; i++) {
-			if (stage[i]) {
-				(void)hipHostFree(stage[i]);
-			}
 			if (done[i]) {
 				(void)hipEventDestroy(done[i]);
 			}
+		}
+		if (d_error) {
+			(void)hipFree(d_error);
 		}
 		if (stream) {
 			(void)hipStreamDestroy(stream);
 		}
 	};
+	const bool device_decode = any_encoded && !host_only;
 	hipError_t e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+	if (e == hipSuccess) {
+		e = AcquireStage(stage_bytes, ds->device, device_decode, staging);
+	}
 	for (int i = 0; i < 2 && e == hipSuccess; i++) {
-		e = hipHostMalloc(reinterpret_cast<void **>(&stage[i]), static_cast<size_t>(rows_per_stage) * ds->pitch,
-		                  hipHostMallocDefault);
+		e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+	}
+	uint8_t *const *stage = staging.pinned;
+	uint8_t *const *d_stage = staging.device;
+	if (e == hipSuccess && device_decode) {
+		e = hipMalloc(reinterpret_cast<void **>(&d_error), sizeof(int));
 		if (e == hipSuccess) {
-			e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+			e = hipMemsetAsync(d_error, 0, sizeof(int), stream);
 		}
 	}
 	if (e != hipSuccess) {
@@ -372,33 +472,33 @@ extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t va
 		pgh_close(ds.release());
 		return DeviceFail(errbuf, "staging setup", e);
 	}
+	lap("staging ready");
+	auto fail = [&](int code, const std::string &msg) {
+		(void)hipStreamSynchronize(stream);
+		cleanup();
+		SetErr(errbuf, msg);
+		pgh_close(ds.release());
+		return code;
+	};
 	int which = 0;
 	bool used[2] = {false, false};
-	const uint32_t rb = ds->record_bytes;
-	for (uint32_t v = variant_begin; v < variant_end; v += rows_per_stage) {
-		const uint32_t stop = std::min<uint64_t>(variant_end, static_cast<uint64_t>(v) + rows_per_stage);
+	int64_t last_base = -1; // most recent non-LD variant inside the opened range
+	uint32_t v = variant_begin;
+	while (v < variant_end) {
 		if (used[which]) {
 			e = hipEventSynchronize(done[which]);
 			if (e != hipSuccess) {
 				break;
 			}
 		}
-		// Fast path: a run of plain 2-bit records without aux tracks is already the row
-		// image, ceil(N/4) bytes apart in the file -- read it straight into the pinned
-		// buffer and let the copy engine re-pitch it; stray bits past N are cleared on
-		// the device.  Anything else goes through the host normaliser.
-		bool plain = true;
-		for (uint32_t r = v; r < stop && plain; r++) {
-			plain = ix.vrtype[r] == 0 && ix.offset[r + 1] - ix.offset[r] == rb;
-		}
 		uint8_t *d_dst = ds->d_rows + static_cast<uint64_t>(v - variant_begin) * ds->pitch;
-		if (plain) {
+		const uint32_t room = std::min<uint64_t>(rows_per_stage, variant_end - v);
+		const uint32_t run = plain_run[v - variant_begin];
+		uint32_t stop = v;
+		if (!host_only && run > 0 && (run >= kMinPlainRun || run >= variant_end - v)) {
+			stop = v + std::min(run, room);
 			if (!ReadParallel(file, ix.offset[v], static_cast<size_t>(stop - v) * rb, stage[which], err)) {
-				(void)hipStreamSynchronize(stream);
-				cleanup();
-				SetErr(errbuf, err);
-				pgh_close(ds.release());
-				return PGH_ERR_OPEN;
+				return fail(PGH_ERR_OPEN, err);
 			}
 			e = hipMemsetAsync(d_dst, 0, static_cast<size_t>(stop - v) * ds->pitch, stream);
 			if (e == hipSuccess) {
@@ -407,16 +507,93 @@ extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t va
 			if (e == hipSuccess) {
 				e = pgh::LaunchSanitizeTail(d_dst, ds->pitch, ds->sample_ct, stop - v, stream);
 			}
+			last_base = static_cast<int64_t>(stop) - 1;
 		} else {
-			if (!ExpandParallel(ix, file, norm, v, stop, stage[which], ds->pitch, err)) {
-				(void)hipStreamSynchronize(stream);
-				cleanup();
-				SetErr(errbuf, err);
-				pgh_close(ds.release());
-				return PGH_ERR_FORMAT;
+			// how many records fit as raw bytes + their tables?
+			uint32_t n = 0;
+			uint64_t raw = 0;
+			if (!host_only && !(is_ld(v) && last_base < 0)) {
+				// the stage holds file bytes here, not rows: only its byte budget limits the run
+				const uint32_t left = variant_end - v;
+				while (n < left) {
+					const uint32_t r = v + n;
+					if (n > 0 && plain_run[r - variant_begin] >= kMinPlainRun) {
+						break;
+					}
+					const uint64_t len = ix.offset[r + 1] - ix.offset[r];
+					if (raw + len + 64 + 13ull * (n + 2) > stage_bytes) {
+						break;
+					}
+					raw += len;
+					n++;
+				}
 			}
-			e = hipMemcpyAsync(d_dst, stage[which], static_cast<size_t>(stop - v) * ds->pitch, hipMemcpyHostToDevice,
-			                   stream);
+			if (n == 0) {
+				// host rows: everything under PGH_HOST_NORMALIZE, an LD run without a resident base,
+				// or one record too large to stage
+				stop = v + 1;
+				if (host_only) {
+					stop = v + room;
+				} else {
+					while (stop < v + room && is_ld(stop) && last_base < 0) {
+						stop++;
+					}
+				}
+				if (!ExpandParallel(ix, file, norm, v, stop, stage[which], ds->pitch, err)) {
+					return fail(PGH_ERR_FORMAT, err);
+				}
+				e = hipMemcpyAsync(d_dst, stage[which], static_cast<size_t>(stop - v) * ds->pitch,
+				                   hipMemcpyHostToDevice, stream);
+				for (uint32_t r = v; r < stop; r++) {
+					if (!is_ld(r)) {
+						last_base = r;
+					}
+				}
+			} else {
+				stop = v + n;
+				uint8_t *h = stage[which];
+				if (!ReadParallel(file, ix.offset[v], raw, h, err)) {
+					return fail(PGH_ERR_OPEN, err);
+				}
+				const uint64_t tables = (raw + 16 + 15) & ~15ull; // 16 zero bytes the kernel may read past the end
+				std::memset(h + raw, 0, tables - raw);
+				uint64_t *rec_begin = reinterpret_cast<uint64_t *>(h + tables);
+				uint32_t *ld_row = reinterpret_cast<uint32_t *>(rec_begin + (n + 1));
+				uint8_t *vrtype = reinterpret_cast<uint8_t *>(ld_row + n);
+				bool any_ld = false;
+				for (uint32_t i = 0; i < n; i++) {
+					const uint32_t r = v + i;
+					rec_begin[i] = ix.offset[r] - ix.offset[v];
+					vrtype[i] = ix.vrtype[r];
+					if (is_ld(r)) {
+						any_ld = true;
+						ld_row[i] = last_base < 0 ? 0xffffffffu : static_cast<uint32_t>(last_base - variant_begin);
+					} else {
+						ld_row[i] = 0;
+						last_base = r;
+					}
+				}
+				rec_begin[n] = raw;
+				const uint64_t used_bytes = tables + 8ull * (n + 1) + 4ull * n + n;
+				e = hipMemcpyAsync(d_stage[which], h, used_bytes, hipMemcpyHostToDevice, stream);
+				if (e == hipSuccess) {
+					pgh::DecodeBatch batch;
+					batch.bytes = d_stage[which];
+					batch.bytes_len = raw;
+					batch.rec_begin = reinterpret_cast<const uint64_t *>(d_stage[which] + tables);
+					batch.ld_row = reinterpret_cast<const uint32_t *>(batch.rec_begin + (n + 1));
+					batch.vrtype = reinterpret_cast<const uint8_t *>(batch.ld_row + n);
+					batch.rows = ds->d_rows;
+					batch.pitch = ds->pitch;
+					batch.row0 = v - variant_begin;
+					batch.variant0 = v;
+					batch.n = n;
+					batch.sample_ct = ds->sample_ct;
+					batch.id_bytes = ix.sample_id_bytes;
+					batch.error = d_error;
+					e = pgh::LaunchDecodeRecords(batch, any_ld, stream);
+				}
+			}
 		}
 		if (e == hipSuccess) {
 			e = hipEventRecord(done[which], stream);
@@ -426,14 +603,27 @@ extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t va
 		}
 		used[which] = true;
 		which ^= 1;
+		v = stop;
+	}
+	lap("runs enqueued");
+	int bad_variant = 0;
+	if (e == hipSuccess && d_error) {
+		e = hipMemcpyAsync(&bad_variant, d_error, sizeof(int), hipMemcpyDeviceToHost, stream);
 	}
 	if (e == hipSuccess) {
 		e = hipStreamSynchronize(stream);
 	}
+	lap("stream drained");
 	cleanup();
+	lap("staging freed");
 	if (e != hipSuccess) {
 		pgh_close(ds.release());
 		return DeviceFail(errbuf, "genotype upload", e);
+	}
+	if (bad_variant != 0) {
+		SetErr(errbuf, "malformed variant record " + std::to_string(bad_variant - 1));
+		pgh_close(ds.release());
+		return PGH_ERR_FORMAT;
 	}
 	*out = ds.release();
 	return PGH_OK;

@@ -1,0 +1,165 @@
+"""Test-side .pgen writer producing every hardcall record type (0, 1, 2, 3, 4, 6, 7).
+
+plink2 is not available to generate fixtures with long difflists (the reference's own
+fixtures have N <= 256, so every difflist there is a single group with 1-byte sample
+ids).  This writer builds records from a genotype matrix so the product's device
+decoder, its host normaliser and the oracle's decoder can be compared on multi-group
+difflists and 2/3-byte sample ids.  It is written from the same reading of the format
+as the decoders, so it checks them against EACH OTHER, not against pgenlib: those
+record shapes are "parity unpinned" (DESIGN.md section 4).
+
+Genotype codes: 0 hom-ref, 1 het, 2 hom-alt, 3 missing."""
+
+from __future__ import annotations
+
+import numpy as np
+
+
+def _varint(x: int) -> bytes:
+    out = bytearray()
+    while x >= 0x80:
+        out.append((x & 0x7F) | 0x80)
+        x >>= 7
+    out.append(x)
+    return bytes(out)
+
+
+def _varints(values: np.ndarray) -> bytes:
+    """Concatenated varints of a whole array (vectorised: difflists can hold millions of gaps)."""
+    d = values.astype(np.uint64)
+    if d.size == 0:
+        return b""
+    nb = np.ones(d.size, dtype=np.int64)
+    for j in range(1, 5):
+        nb += d >= (1 << (7 * j))
+    start = np.cumsum(nb) - nb
+    out = np.zeros(int(nb.sum()), dtype=np.uint8)
+    for j in range(5):
+        sel = nb > j
+        if not sel.any():
+            break
+        byte = ((d[sel] >> np.uint64(7 * j)) & np.uint64(0x7F)).astype(np.uint8)
+        byte |= ((nb[sel] > j + 1).astype(np.uint8) << 7)
+        out[start[sel] + j] = byte
+    return out.tobytes()
+
+
+def _pack2(codes: np.ndarray) -> bytes:
+    n = len(codes)
+    pad = (-n) % 4
+    c = np.concatenate([codes.astype(np.uint8), np.zeros(pad, dtype=np.uint8)]).reshape(-1, 4)
+    return (c[:, 0] | (c[:, 1] << 2) | (c[:, 2] << 4) | (c[:, 3] << 6)).astype(np.uint8).tobytes()
+
+
+def _id_bytes(n: int) -> int:
+    return 1 if n < 0x100 else 2 if n < 0x10000 else 3 if n < 0x1000000 else 4
+
+
+def _difflist(ids: np.ndarray, vals: np.ndarray, n_samples: int) -> bytes:
+    ln = len(ids)
+    out = bytearray(_varint(ln))
+    if ln == 0:
+        return bytes(out)
+    w = _id_bytes(n_samples)
+    groups = (ln + 63) // 64
+    gaps = []
+    for g in range(groups):
+        chunk = ids[g * 64:(g + 1) * 64]
+        out += int(chunk[0]).to_bytes(w, "little")
+        gaps.append(_varints(np.diff(chunk)))
+    for g in range(groups - 1):
+        out.append((len(gaps[g]) - 63) & 0xFF)  # gap-section byte length, biased; decoders here skip it
+    out += _pack2(vals)
+    for g in gaps:
+        out += g
+    return bytes(out)
+
+
+_INV = np.array([2, 1, 0, 3], dtype=np.uint8)
+
+
+def encode_record(kind: int, g: np.ndarray, base: np.ndarray | None) -> bytes:
+    n = len(g)
+    if kind == 0:
+        return _pack2(g)
+    if kind == 1:
+        counts = np.bincount(g, minlength=4)
+        low, high = sorted(np.argsort(-counts, kind="stable")[:2].tolist())
+        code = low * 4 + (high - low)
+        bits = np.packbits((g == high).astype(np.uint8), bitorder="little").tobytes()
+        diff = np.flatnonzero((g != low) & (g != high))
+        return bytes([code]) + bits + _difflist(diff, g[diff], n)
+    if kind in (4, 6, 7):
+        const = {4: 0, 6: 2, 7: 3}[kind]
+        diff = np.flatnonzero(g != const)
+        return _difflist(diff, g[diff], n)
+    if kind in (2, 3):
+        assert base is not None
+        target = g if kind == 2 else _INV[g]  # type 3 is patched first, then inverted
+        diff = np.flatnonzero(target != base)
+        return _difflist(diff, target[diff], n)
+    raise ValueError(kind)
+
+
+def choose_kinds(geno: np.ndarray, rng: np.random.Generator) -> list[int]:
+    """A legal, varied assignment: LD types only after a non-LD record."""
+    kinds = []
+    have_base = False
+    for row in geno:
+        options = [0, 1, 4, 6, 7] + ([2, 3] if have_base else [])
+        k = int(rng.choice(options))
+        kinds.append(k)
+        have_base |= k not in (2, 3)
+    return kinds
+
+
+def write_pgen(path: str, geno: np.ndarray, kinds: list[int]) -> None:
+    """geno: [M][N] codes.  Writes mode 0x10 with 8-bit vrtypes and 4-byte record lengths."""
+    m, n = geno.shape
+    records = []
+    base = None
+    for v in range(m):
+        g = geno[v].astype(np.uint8)
+        k = kinds[v]
+        records.append(encode_record(k, g, base))
+        if k not in (2, 3):
+            base = g
+    blocks = (m + 65535) // 65536
+    head = bytearray([0x6C, 0x1B, 0x10]) + int(m).to_bytes(4, "little") + int(n).to_bytes(4, "little")
+    head.append(0x40 | 4 | 3)  # no nonref flags; 8-bit vrtypes; 4-byte record lengths
+    tables = bytearray()
+    table_len = blocks * 8 + sum(min(65536, m - b * 65536) * 5 for b in range(blocks))
+    body_at = len(head) + table_len
+    offsets = []
+    fp = body_at
+    for b in range(blocks):
+        offsets.append(fp)
+        lo, hi = b * 65536, min(m, (b + 1) * 65536)
+        tables += bytes(kinds[lo:hi])
+        for v in range(lo, hi):
+            tables += len(records[v]).to_bytes(4, "little")
+            fp += len(records[v])
+    with open(path, "wb") as f:
+        f.write(head)
+        for o in offsets:
+            f.write(int(o).to_bytes(8, "little"))
+        f.write(tables)
+        for r in records:
+            f.write(r)
+
+
+def rare_matrix(m: int, n: int, rng: np.random.Generator) -> np.ndarray:
+    """Mostly-constant rows with a spread of minor-value rates so difflists span 0..many groups."""
+    geno = np.empty((m, n), dtype=np.uint8)
+    for v in range(m):
+        major = int(rng.choice([0, 0, 0, 2, 3]))
+        rate = float(rng.choice([0.0, 0.0005, 0.01, 0.05, 0.3]))
+        row = np.full(n, major, dtype=np.uint8)
+        hit = rng.random(n) < rate
+        row[hit] = rng.integers(0, 4, hit.sum(), dtype=np.uint8)
+        if v and rng.random() < 0.4:  # near-copies of the previous row make LD records worthwhile
+            row = geno[v - 1].copy()
+            flip = rng.random(n) < rate / 4
+            row[flip] = rng.integers(0, 4, flip.sum(), dtype=np.uint8)
+        geno[v] = row
+    return geno

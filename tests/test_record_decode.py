@@ -1,0 +1,130 @@
+"""Every hardcall record type through the three decoders: the oracle, the product's
+host normaliser, and the device decoder that pgh_open uses (decode.hip).
+
+Fixtures from the reference pin types 0/1/2/3/4/6/7 with single-group difflists
+(N <= 256).  Multi-group difflists and 2/3-byte sample ids come from
+tests/pgen_writer.py; for those the three decoders are checked against each other
+and against the matrix the writer encoded ("parity unpinned" against pgenlib)."""
+
+import os
+
+import numpy as np
+import pytest
+
+from conftest import data_path
+import pgen_writer as W
+
+
+def _pack_rows(geno):
+    m, n = geno.shape
+    pad = (-n) % 4
+    c = np.concatenate([geno.astype(np.uint8), np.zeros((m, pad), dtype=np.uint8)], axis=1).reshape(m, -1, 4)
+    return (c[:, :, 0] | (c[:, :, 1] << 2) | (c[:, :, 2] << 4) | (c[:, :, 3] << 6)).astype(np.uint8)
+
+
+CASES = [  # (variants, samples, seed): 1-, 2- and 3-byte sample ids, ragged tails
+    (60, 7, 1), (300, 255, 2), (300, 256, 3), (200, 1000, 4), (120, 5003, 5), (40, 70001, 6),
+]
+
+
+@pytest.fixture(scope="module")
+def written(tmp_path_factory):
+    out = {}
+    root = tmp_path_factory.mktemp("pgen_writer")
+    for m, n, seed in CASES:
+        rng = np.random.default_rng(seed)
+        geno = W.rare_matrix(m, n, rng)
+        kinds = W.choose_kinds(geno, rng)
+        path = str(root / f"w_{m}_{n}.pgen")
+        W.write_pgen(path, geno, kinds)
+        out[(m, n)] = (path, geno, kinds)
+    return out
+
+
+@pytest.mark.parametrize("m,n,seed", CASES)
+def test_writer_roundtrips_through_oracle_and_host_normaliser(written, oracle, lib, m, n, seed):
+    path, geno, kinds = written[(m, n)]
+    assert set(kinds) >= {0, 1, 2, 3, 4, 6, 7} or m < 100
+    pg = oracle.Pgen(path)
+    assert (pg.M, pg.N) == (m, n)
+    assert [pg.vrtype(v) & 7 for v in range(m)] == kinds
+    for v in range(m):
+        got = pg.geno(v).astype(np.int16)
+        got[got == -9] = 3
+        assert np.array_equal(got, geno[v]), (v, kinds[v])
+    assert np.array_equal(lib.normalize_range_host(path), _pack_rows(geno))
+    # a range that starts inside an LD run resolves its base by walking back
+    first_ld = next((v for v in range(1, m) if kinds[v] in (2, 3)), None)
+    if first_ld is not None:
+        assert np.array_equal(lib.normalize_range_host(path, first_ld, m), _pack_rows(geno[first_ld:]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,n,seed", CASES)
+def test_device_decode_equals_host_normaliser(written, gpu_lib, m, n, seed):
+    path, geno, kinds = written[(m, n)]
+    want = _pack_rows(geno)
+    ds = gpu_lib.Dataset.open(path)
+    assert np.array_equal(ds.copy_rows_to_host(0, m), want)
+    counts = ds.counts_range()
+    assert np.array_equal(counts, np.stack([(geno == c).sum(axis=1) for c in range(4)], axis=1).astype(np.uint32))
+    ds.close()
+    # shards: one that starts on an LD record (host rows for the leading run), one that ends early
+    first_ld = next((v for v in range(1, m) if kinds[v] in (2, 3)), None)
+    for v0, v1 in [(first_ld or 1, m), (0, m // 2), (m // 3, 2 * m // 3)]:
+        part = gpu_lib.Dataset.open(path, variant_begin=v0, variant_end=v1)
+        assert np.array_equal(part.copy_rows_to_host(v0, v1), want[v0:v1]), (v0, v1)
+        part.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["pca_example", "rare_small", "streaming_example", "all_missing", "phased_example",
+                                  "dosage_example", "large_example"])
+def test_device_decode_on_reference_fixtures(gpu_lib, oracle, name, monkeypatch):
+    path = data_path(name + ".pgen")
+    pg = oracle.Pgen(path)
+    host = gpu_lib.normalize_range_host(path)
+    ds = gpu_lib.Dataset.open(path)
+    assert np.array_equal(ds.copy_rows_to_host(0, pg.M), host)
+    ds.close()
+    monkeypatch.setenv("PGH_HOST_NORMALIZE", "1")
+    ds = gpu_lib.Dataset.open(path)
+    assert np.array_equal(ds.copy_rows_to_host(0, pg.M), host)
+    ds.close()
+    step = max(1, pg.M // 97)
+    for v in range(0, pg.M, step):
+        g = pg.geno(v).astype(np.int16)
+        g[g == -9] = 3
+        row = host[v]
+        got = (row[np.arange(pg.N) // 4] >> (2 * (np.arange(pg.N) % 4))) & 3
+        assert np.array_equal(got, g)
+
+
+@pytest.mark.gpu
+def test_malformed_records_are_reported_not_followed(written, gpu_lib, tmp_path):
+    path, geno, kinds = written[(200, 1000)]
+    blob = bytearray(open(path, "rb").read())
+    m = 200
+    # find a type-4 record with a difflist and claim more entries than samples
+    pg_off = 12 + 8 + m * 5
+    lens = [int.from_bytes(blob[12 + 8 + m + 4 * v:12 + 8 + m + 4 * v + 4], "little") for v in range(m)]
+    starts = np.concatenate([[pg_off], pg_off + np.cumsum(lens)])
+    victim = next(v for v in range(m) if kinds[v] == 4 and lens[v] > 3)
+    bad = bytearray(blob)
+    bad[starts[victim]] = 0xFF      # varint continues ...
+    bad[starts[victim] + 1] = 0x7F  # ... to a length far above N
+    p = str(tmp_path / "bad_len.pgen")
+    open(p, "wb").write(bad)
+    with pytest.raises(gpu_lib.PghError) as e:
+        gpu_lib.Dataset.open(p)
+    assert f"malformed variant record {victim}" in str(e.value)
+    # a sample id past N in a group's first-id slot
+    victim = next(v for v in range(m) if kinds[v] == 6 and lens[v] > 6 and (geno[v] != 2).sum() >= 2)
+    bad = bytearray(blob)
+    at = starts[victim] + 1  # one-byte length, then the first group's 2-byte id
+    bad[at:at + 2] = (60000).to_bytes(2, "little")
+    p = str(tmp_path / "bad_id.pgen")
+    open(p, "wb").write(bad)
+    with pytest.raises(gpu_lib.PghError) as e:
+        gpu_lib.Dataset.open(p)
+    assert f"malformed variant record {victim}" in str(e.value)
