@@ -282,7 +282,7 @@ def main():
                 # per-sample partials of the variant shards: RCCL reduce over xGMI
                 sharding.reduce_partials(dist, [d_score, d_dos, d_ac])
 
-        kernel_name = "k_accumulate_mfma"
+        kernel_name = "k_score_gemv_pairs" if ncol == 1 else ("k_accumulate_mfma" if ncol >= 3 else "k_score_accumulate")
         metric = f"plink_score genotypes/s ({ncol} weight columns)"
         dtype = "f64"
 

@@ -885,28 +885,89 @@ __global__ __launch_bounds__(256) void k_score_accumulate(const uint8_t *__restr
 }
 
 // GEMV form (one weight column, the reference's SQL contract): 2 flop per call, so the
-// contraction is not matrix-core work -- plain FP64 adds would cost more than the HBM
-// stream.  "Four Russians" instead: for every group of 4 scored variants the workgroup
-// tabulates the 256 possible (score, dosage) sums of one sample's 4 calls in LDS, and a
-// lane then needs one 16-byte LDS lookup + 2 FP64 adds per 4 calls.  The 8-bit pattern
-// of sample j is assembled from the 4 rows' words with a 2-bit field transposition
-// (even / odd fields -> nibbles -> bytes).  16 variants (4 tables) per barrier, tables
-// double-buffered; variant slices combine by FP64 atomics.
+// contraction is not matrix-core work.  Table lookups instead ("four Russians"): the
+// workgroup tabulates, per small group of scored variants, the possible (score, dosage)
+// sums of one sample's calls in LDS, and a lane then needs one 16-byte LDS lookup + 2 FP64
+// adds per group.  Variant slices combine by FP64 atomics.
 struct alignas(16) ScorePair {
 	double score;
 	double dosage;
 };
 
-__global__ __launch_bounds__(256) void k_score_gemv(const uint8_t *__restrict__ rows, uint64_t pitch,
-                                                    uint32_t sample_ct, const uint32_t *__restrict__ vlist,
-                                                    uint32_t n_var, uint32_t slice_len,
-                                                    const double *__restrict__ weights, uint32_t w_stride,
-                                                    const double *__restrict__ ts, const double *__restrict__ td,
-                                                    double *__restrict__ score, uint32_t out_stride,
-                                                    double *__restrict__ dosage_sum) {
-	constexpr uint32_t kGroups = 4; // 4-variant groups per stage
-	__shared__ ScorePair s_tab[2][kGroups][256];
-	const uint32_t d = blockIdx.x * 256u + threadIdx.x;   // this lane's 4-byte column: samples 16d .. 16d+15
+// Groups are PAIRS of variants: a 16-entry table of 16-byte entries is exactly one 256-byte
+// LDS bank row, so two lanes on the same bank group hold the same entry (a broadcast) and
+// ds_read_b128 lookups are conflict-free for ANY pattern.  (Groups of four -- 256-entry
+// tables, half the lookups -- collided ~3.5 ways: SQ_LDS_BANK_CONFLICT 72 % of the LDS cycles,
+// 85 ms per 1M x 500k against 44 ms here; replicating those tables per bank group cost more in
+// stores than it saved.)  16 variants = 8 pair tables (2 KB) per barrier, double-buffered.
+// (byte B of x) & mask in one VALU op (SDWA byte select); mask lives in a register
+#define PGH_BYTE_AND(B)                                                                                                \
+	__device__ __forceinline__ uint32_t ByteAnd##B(uint32_t x, uint32_t mask) {                                       \
+		uint32_t r;                                                                                                    \
+		asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_" #B " src1_sel:DWORD"        \
+		    : "=v"(r)                                                                                                  \
+		    : "v"(x), "v"(mask));                                                                                      \
+		return r;                                                                                                      \
+	}
+PGH_BYTE_AND(0)
+PGH_BYTE_AND(1)
+PGH_BYTE_AND(2)
+PGH_BYTE_AND(3)
+#undef PGH_BYTE_AND
+
+constexpr uint32_t kGemvPairs = 8; // pair tables per stage (16 variants)
+
+// One stage: 8 pair tables at a compile-time LDS offset (the lookups then use the
+// instruction's immediate offset), 16 words of this lane's 16 samples.
+template <int BUF>
+__device__ __forceinline__ void GemvPairsStage(const ScorePair (*tabs)[kGemvPairs][16], const uint32_t *w,
+                                               double *acc_s, double *acc_d) {
+	const uint32_t kF0 = 0xf0u;
+#pragma unroll
+	for (uint32_t pr = 0; pr < kGemvPairs; pr++) {
+		const uint32_t w0 = w[2 * pr], w1 = w[2 * pr + 1];
+		// nibble k of `even` / `odd` = 4-bit pattern (row0 | row1 << 2) of sample 2k / 2k+1
+		const uint32_t kE = 0x33333333u;
+		const uint32_t even = (w0 & kE) | ((w1 & kE) << 2);
+		const uint32_t odd = ((w0 >> 2) & kE) | (w1 & ~kE);
+		// byte offset of an entry = pattern * 16: the high nibble of a byte already is that,
+		// the low nibbles come from the same words shifted up by 4
+		const uint32_t even_lo = even << 4, odd_lo = odd << 4;
+		const char *tab = reinterpret_cast<const char *>(tabs[BUF][pr]);
+#define PGH_LOOKUP(B)                                                                                                  \
+	{                                                                                                                  \
+		const ScorePair e0 = *reinterpret_cast<const ScorePair *>(tab + ByteAnd##B(even_lo, kF0));                    \
+		const ScorePair e1 = *reinterpret_cast<const ScorePair *>(tab + ByteAnd##B(odd_lo, kF0));                     \
+		const ScorePair e2 = *reinterpret_cast<const ScorePair *>(tab + ByteAnd##B(even, kF0));                       \
+		const ScorePair e3 = *reinterpret_cast<const ScorePair *>(tab + ByteAnd##B(odd, kF0));                        \
+		acc_s[4 * B] += e0.score;                                                                                      \
+		acc_d[4 * B] += e0.dosage;                                                                                     \
+		acc_s[4 * B + 1] += e1.score;                                                                                  \
+		acc_d[4 * B + 1] += e1.dosage;                                                                                 \
+		acc_s[4 * B + 2] += e2.score;                                                                                  \
+		acc_d[4 * B + 2] += e2.dosage;                                                                                 \
+		acc_s[4 * B + 3] += e3.score;                                                                                  \
+		acc_d[4 * B + 3] += e3.dosage;                                                                                 \
+	}
+		PGH_LOOKUP(0)
+		PGH_LOOKUP(1)
+		PGH_LOOKUP(2)
+		PGH_LOOKUP(3)
+#undef PGH_LOOKUP
+	}
+}
+
+__global__ __launch_bounds__(256, 4) void k_score_gemv_pairs(const uint8_t *__restrict__ rows, uint64_t pitch,
+                                                          uint32_t sample_ct, const uint32_t *__restrict__ vlist,
+                                                          uint32_t n_var, uint32_t slice_len,
+                                                          const double *__restrict__ weights, uint32_t w_stride,
+                                                          const double *__restrict__ ts,
+                                                          const double *__restrict__ td, double *__restrict__ score,
+                                                          uint32_t out_stride, double *__restrict__ dosage_sum) {
+	constexpr uint32_t kPairs = kGemvPairs;
+	constexpr uint32_t kStage = kPairs * 2;
+	__shared__ ScorePair s_tab[2][kPairs][16];
+	const uint32_t d = blockIdx.x * 256u + threadIdx.x; // this lane's 4-byte column: samples 16d .. 16d+15
 	const uint32_t n_dwords = (sample_ct + 15) / 16;
 	const bool live = d < n_dwords;
 	const uint32_t i_begin = blockIdx.y * slice_len;
@@ -917,29 +978,28 @@ __global__ __launch_bounds__(256) void k_score_gemv(const uint8_t *__restrict__ 
 		acc_s[j] = 0.0;
 		acc_d[j] = 0.0;
 	}
-	// entry `threadIdx.x` of the 4 tables of the stage starting at scored-variant index base
+	// threads 0..127: entry (t & 15) of pair table (t >> 4) for the stage starting at `base`
 	auto build = [&](uint32_t base, uint32_t buf) {
-#pragma unroll
-		for (uint32_t grp = 0; grp < kGroups; grp++) {
+		if (threadIdx.x < kPairs * 16) {
+			const uint32_t pair = threadIdx.x >> 4, pat = threadIdx.x & 15u;
 			double sc = 0.0, ds = 0.0;
 #pragma unroll
-			for (uint32_t q = 0; q < 4; q++) {
-				const uint32_t i = base + grp * 4u + q;
-				if (i < i_end) { // uniform
-					const uint32_t g = (threadIdx.x >> (2 * q)) & 3u;
-					const double w = weights[static_cast<uint64_t>(i) * w_stride];
-					sc += w * ts[4 * static_cast<uint64_t>(i) + g];
+			for (uint32_t q = 0; q < 2; q++) {
+				const uint32_t i = base + pair * 2u + q;
+				if (i < i_end) {
+					const uint32_t g = (pat >> (2 * q)) & 3u;
+					sc += weights[static_cast<uint64_t>(i) * w_stride] * ts[4 * static_cast<uint64_t>(i) + g];
 					if (td) {
 						ds += td[4 * static_cast<uint64_t>(i) + g];
 					}
 				}
 			}
-			s_tab[buf][grp][threadIdx.x] = ScorePair {sc, ds};
+			s_tab[buf][pair][pat] = ScorePair {sc, ds};
 		}
 	};
-	auto load_words = [&](uint32_t base, uint32_t w[kGroups * 4]) {
+	auto load_words = [&](uint32_t base, uint32_t w[kStage]) {
 #pragma unroll
-		for (uint32_t k = 0; k < kGroups * 4; k++) {
+		for (uint32_t k = 0; k < kStage; k++) {
 			const uint32_t i = base + k;
 			w[k] = (live && i < i_end)
 			           ? __builtin_nontemporal_load(
@@ -947,52 +1007,29 @@ __global__ __launch_bounds__(256) void k_score_gemv(const uint8_t *__restrict__ 
 			           : 0u;
 		}
 	};
-	uint32_t w_cur[kGroups * 4], w_next[kGroups * 4];
+	uint32_t w_a[kStage], w_b[kStage];
 	if (i_begin < i_end) {
-		load_words(i_begin, w_cur);
+		load_words(i_begin, w_a);
 		build(i_begin, 0);
 	}
 	__syncthreads();
-	uint32_t buf = 0;
-	for (uint32_t base = i_begin; base < i_end; base += kGroups * 4, buf ^= 1u) {
-		const bool more = base + kGroups * 4 < i_end;
-		if (more) {
-			load_words(base + kGroups * 4, w_next);
-			build(base + kGroups * 4, buf ^ 1u);
+	// two stages per trip, so each half works on a compile-time table buffer
+	for (uint32_t base = i_begin; base < i_end; base += 2 * kStage) {
+		const bool more_b = base + kStage < i_end;
+		if (more_b) {
+			load_words(base + kStage, w_b);
+			build(base + kStage, 1);
 		}
-#pragma unroll
-		for (uint32_t grp = 0; grp < kGroups; grp++) {
-			const uint32_t w0 = w_cur[4 * grp], w1 = w_cur[4 * grp + 1], w2 = w_cur[4 * grp + 2],
-			               w3 = w_cur[4 * grp + 3];
-			// 2-bit field transposition: byte b of pat[r] = 8-bit pattern of sample 4b + {0,2,1,3}[r]
-			const uint32_t kE = 0x33333333u, kN = 0x0f0f0f0fu;
-			const uint32_t t01 = (w0 & kE) | ((w1 & kE) << 2);
-			const uint32_t t23 = (w2 & kE) | ((w3 & kE) << 2);
-			const uint32_t u01 = ((w0 >> 2) & kE) | (w1 & ~kE);
-			const uint32_t u23 = ((w2 >> 2) & kE) | (w3 & ~kE);
-			uint32_t pat[4];
-			pat[0] = (t01 & kN) | ((t23 & kN) << 4);   // samples 0, 4, 8, 12
-			pat[1] = ((t01 >> 4) & kN) | (t23 & ~kN);  // samples 2, 6, 10, 14
-			pat[2] = (u01 & kN) | ((u23 & kN) << 4);   // samples 1, 5, 9, 13
-			pat[3] = ((u01 >> 4) & kN) | (u23 & ~kN);  // samples 3, 7, 11, 15
-			const ScorePair *tab = s_tab[buf][grp];
-#pragma unroll
-			for (int r = 0; r < 4; r++) {
-				const int within = r == 0 ? 0 : (r == 1 ? 2 : (r == 2 ? 1 : 3));
-#pragma unroll
-				for (int b = 0; b < 4; b++) {
-					const ScorePair e = tab[(pat[r] >> (8 * b)) & 0xffu];
-					acc_s[4 * b + within] += e.score;
-					acc_d[4 * b + within] += e.dosage;
-				}
-			}
+		GemvPairsStage<0>(s_tab, w_a, acc_s, acc_d);
+		__syncthreads();
+		if (!more_b) {
+			break;
 		}
-		if (more) {
-#pragma unroll
-			for (uint32_t k = 0; k < kGroups * 4; k++) {
-				w_cur[k] = w_next[k];
-			}
+		if (base + 2 * kStage < i_end) {
+			load_words(base + 2 * kStage, w_a);
+			build(base + 2 * kStage, 0);
 		}
+		GemvPairsStage<1>(s_tab, w_b, acc_s, acc_d);
 		__syncthreads();
 	}
 	if (live) {
@@ -1881,7 +1918,7 @@ hipError_t LaunchTableAccumulate(const RowView &view, const uint32_t *vlist, uin
 			slice_len = ((n_var + slices - 1) / slices + 15) / 16 * 16;
 			slices = (n_var + slice_len - 1) / slice_len;
 		}
-		hipLaunchKernelGGL(k_score_gemv, dim3(col_blocks, slices), dim3(256), 0, stream, view.rows, view.pitch,
+		hipLaunchKernelGGL(k_score_gemv_pairs, dim3(col_blocks, slices), dim3(256), 0, stream, view.rows, view.pitch,
 		                   view.sample_ct, vlist, n_var, slice_len, weights, w_stride, ts, td, out, out_stride,
 		                   dosage_sum);
 		return hipGetLastError();

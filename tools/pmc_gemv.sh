@@ -1,0 +1,18 @@
+#!/bin/bash
+# PMC passes over the one-column score kernel (run on the GPU box through gpurun).
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+V=${1:-5}
+rm -rf gpurun_out/gemv_pmc
+for c in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "SQ_WAIT_INST_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_ANY SQ_WAVES"; do
+  tag=$(echo $c | tr ' ' '_')
+  PGH_GEMV_VARIANT=$V rocprofv3 --pmc $c --output-format csv -d gpurun_out/gemv_pmc/v${V}_$tag -- python3 bench.py --workload score --score-cols 1 --variants 100000 --steps 1 --warmup 0 --cpu-seconds 0 > /dev/null 2> gpurun_out/gemv_pmc_err.txt || { tail -5 gpurun_out/gemv_pmc_err.txt; exit 1; }
+done
+python3 - <<'PY'
+import csv, glob, collections
+for f in sorted(glob.glob('gpurun_out/gemv_pmc/*/*/*counter_collection.csv')):
+    acc=collections.defaultdict(float)
+    for r in csv.DictReader(open(f)):
+        if 'k_score_gemv' in r['Kernel_Name']:
+            acc[r['Counter_Name']]+=float(r['Counter_Value'])
+    print({k: f"{v:.4g}" for k, v in acc.items()})
+PY
