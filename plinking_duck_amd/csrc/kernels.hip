@@ -1059,8 +1059,14 @@ __global__ __launch_bounds__(256, 4) void k_score_gemv_pairs(const uint8_t *__re
 // lanes cover 128-byte row segments.
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-template <int NCT, bool TRACK_DOSAGE>
-__global__ __launch_bounds__(256, NCT == 1 ? 4 : 2) void k_accumulate_mfma(const uint8_t *__restrict__ rows, uint64_t pitch,
+// NQ (0..3) extra QUARTER tiles of 4 columns ride on v_mfma_f64_4x4x4_4b_f64 (4 independent 4x4x4
+// blocks, 16 cycles against the 16x16x4's 64): with block b = samples 4b..4b+3 its A operand has
+// the very layout of the big tile (lane 16k + 4b + i = 16k + sample), so the looked-up a[t] feeds
+// both; B is lane 16k + 4b + j -> W[v_k][col j] (the same 4 columns in every block) and D is lane
+// 16i + 4b + j (layout measured with tools/mfma_probe.hip).  plink_pca's 2k = 20 columns are one
+// tile + one quarter: 80 matrix-pipe cycles per group instead of the 128 of two padded tiles.
+template <int NCT, int NQ, bool TRACK_DOSAGE>
+__global__ __launch_bounds__(256, (NCT == 1 && NQ == 0) ? 4 : 2) void k_accumulate_mfma(const uint8_t *__restrict__ rows, uint64_t pitch,
                                                          uint32_t sample_ct, const uint32_t *__restrict__ vlist,
                                                          uint32_t n_var, uint32_t slice_len,
                                                          const double *__restrict__ weights, uint32_t w_stride,
@@ -1068,7 +1074,8 @@ __global__ __launch_bounds__(256, NCT == 1 ? 4 : 2) void k_accumulate_mfma(const
                                                          double *__restrict__ out, uint32_t out_stride,
                                                          double *__restrict__ dosage_sum) {
 	constexpr uint32_t kStage = 64;
-	constexpr uint32_t kCols = 16 * NCT;
+	constexpr uint32_t kCols = 16 * NCT + 4 * NQ;
+	constexpr uint32_t kQ = NQ > 0 ? NQ : 1; // array extents (unused when NQ == 0)
 	constexpr uint32_t kWPerThread = kStage * kCols / 256; // weight doubles each thread stages
 	// double-buffered stage: tables / weights / row offsets of 64 variants
 	__shared__ double s_ts[2][kStage][4];
@@ -1091,6 +1098,14 @@ __global__ __launch_bounds__(256, NCT == 1 ? 4 : 2) void k_accumulate_mfma(const
 #pragma unroll
 		for (int c = 0; c < NCT; c++) {
 			acc[t][c] = f64x4 {0.0, 0.0, 0.0, 0.0};
+		}
+	}
+	double accq[4][kQ];
+#pragma unroll
+	for (int t = 0; t < 4; t++) {
+#pragma unroll
+		for (int q = 0; q < static_cast<int>(kQ); q++) {
+			accq[t][q] = 0.0;
 		}
 	}
 	double dsum[4] = {0.0, 0.0, 0.0, 0.0};
@@ -1142,10 +1157,14 @@ __global__ __launch_bounds__(256, NCT == 1 ? 4 : 2) void k_accumulate_mfma(const
 			const uint32_t groups = (cnt + 3) / 4;
 			// two-deep software pipeline: while group g is on the matrix pipe, group g+1's
 			// operands are being looked up in LDS and the row loads of g+2..g+4 are in flight
-			auto operands = [&](uint32_t k, const uint4 &w, double a[4], double b[NCT]) {
+			auto operands = [&](uint32_t k, const uint4 &w, double a[4], double b[NCT + kQ]) {
 #pragma unroll
 				for (int c = 0; c < NCT; c++) {
 					b[c] = s_w[buf][k][16 * c + li];
+				}
+#pragma unroll
+				for (int q = 0; q < NQ; q++) {
+					b[NCT + q] = s_w[buf][k][16 * NCT + 4 * q + (lane & 3u)];
 				}
 				const uint32_t wt[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
@@ -1156,7 +1175,7 @@ __global__ __launch_bounds__(256, NCT == 1 ? 4 : 2) void k_accumulate_mfma(const
 			auto row_load = [&](uint32_t g) {
 				return *reinterpret_cast<const uint4 *>(col_ptr + s_off[buf][g * 4u + lk]);
 			};
-			auto multiply = [&](const double a[4], const double b[NCT]) {
+			auto multiply = [&](const double a[4], const double b[NCT + kQ]) {
 #pragma unroll
 				for (int t = 0; t < 4; t++) {
 					if (TRACK_DOSAGE) {
@@ -1165,6 +1184,10 @@ __global__ __launch_bounds__(256, NCT == 1 ? 4 : 2) void k_accumulate_mfma(const
 #pragma unroll
 					for (int c = 0; c < NCT; c++) {
 						acc[t][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], b[c], acc[t][c], 0, 0, 0);
+					}
+#pragma unroll
+					for (int q = 0; q < NQ; q++) {
+						accq[t][q] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[t], b[NCT + q], accq[t][q], 0, 0, 0);
 					}
 				}
 			};
@@ -1177,7 +1200,7 @@ __global__ __launch_bounds__(256, NCT == 1 ? 4 : 2) void k_accumulate_mfma(const
 				for (uint32_t j = 0; j < kRing; j++) {
 					w[j] = row_load(j);
 				}
-				double a[2][4], b[2][NCT];
+				double a[2][4], b[2][NCT + kQ];
 				operands(lk, w[0], a[0], b[0]);
 #pragma unroll
 				for (uint32_t g4 = 0; g4 < kStage / 4; g4++) {
@@ -1192,7 +1215,7 @@ __global__ __launch_bounds__(256, NCT == 1 ? 4 : 2) void k_accumulate_mfma(const
 			} else {
 				// ragged last stage of a slice
 				for (uint32_t g4 = 0; g4 < groups; g4++) {
-					double a[4], b[NCT];
+					double a[4], b[NCT + kQ];
 					operands(g4 * 4u + lk, row_load(g4), a, b);
 					multiply(a, b);
 				}
@@ -1219,6 +1242,15 @@ __global__ __launch_bounds__(256, NCT == 1 ? 4 : 2) void k_accumulate_mfma(const
 				if (s < sample_ct && col < n_cols) {
 					unsafeAtomicAdd(out + static_cast<uint64_t>(s) * out_stride + col, acc[t][c][r]);
 				}
+			}
+		}
+#pragma unroll
+		for (int q = 0; q < NQ; q++) {
+			// D of the 4-block form: lane = 16 i + 4 b + j -> sample 4b + i, column j
+			const uint32_t s = sample_base + 16u * t + 4u * ((lane >> 2) & 3u) + (lane >> 4);
+			const uint32_t col = 16u * NCT + 4u * q + (lane & 3u);
+			if (s < sample_ct && col < n_cols) {
+				unsafeAtomicAdd(out + static_cast<uint64_t>(s) * out_stride + col, accq[t][q]);
 			}
 		}
 		if (TRACK_DOSAGE) {
@@ -1359,7 +1391,9 @@ __global__ __launch_bounds__(256) void k_variant_reduce(const uint8_t *__restric
 // 32 bytes of the chunk (the 4 lane groups of a variant share the load) and peels sample
 // 4q + k at step q with a per-lane constant shift.  No atomics: a variant's whole sum
 // lives in one wave.
-template <int NCT>
+// NQ quarter tiles: as in k_accumulate_mfma, 4 more columns on v_mfma_f64_4x4x4_4b_f64 with the
+// big tile's A operand (block b = variants 4b..4b+3 of the tile).
+template <int NCT, int NQ>
 __global__ __launch_bounds__(256) void k_variant_reduce_mfma(const uint8_t *__restrict__ rows, uint64_t pitch,
                                                              uint32_t sample_ct, const uint32_t *__restrict__ vlist,
                                                              uint32_t n_var, const double *__restrict__ ts,
@@ -1367,7 +1401,8 @@ __global__ __launch_bounds__(256) void k_variant_reduce_mfma(const uint8_t *__re
                                                              uint32_t n_cols, double *__restrict__ out,
                                                              uint32_t out_stride) {
 	constexpr uint32_t kChunk = 128;           // samples per LDS chunk
-	constexpr uint32_t kCols = 16 * NCT;
+	constexpr uint32_t kCols = 16 * NCT + 4 * NQ;
+	constexpr uint32_t kQ = NQ > 0 ? NQ : 1;
 	constexpr uint32_t kGPerThread = kChunk * kCols / 256;
 	constexpr uint32_t kVT = 2;                // variant tiles per wave
 	__shared__ double s_g[kChunk][kCols];
@@ -1396,6 +1431,14 @@ __global__ __launch_bounds__(256) void k_variant_reduce_mfma(const uint8_t *__re
 #pragma unroll
 		for (int c = 0; c < NCT; c++) {
 			acc[t][c] = f64x4 {0.0, 0.0, 0.0, 0.0};
+		}
+	}
+	double accq[kVT][kQ];
+#pragma unroll
+	for (uint32_t t = 0; t < kVT; t++) {
+#pragma unroll
+		for (uint32_t qq = 0; qq < kQ; qq++) {
+			accq[t][qq] = 0.0;
 		}
 	}
 	double r_g[kGPerThread];
@@ -1441,10 +1484,14 @@ __global__ __launch_bounds__(256) void k_variant_reduce_mfma(const uint8_t *__re
 		}
 #pragma unroll
 		for (uint32_t q = 0; q < kChunk / 4; q++) {
-			double b[NCT];
+			double b[NCT], bq[kQ];
 #pragma unroll
 			for (int c = 0; c < NCT; c++) {
 				b[c] = s_g[4u * q + lk][16 * c + li];
+			}
+#pragma unroll
+			for (int qq = 0; qq < NQ; qq++) {
+				bq[qq] = s_g[4u * q + lk][16 * NCT + 4 * qq + (lane & 3u)];
 			}
 #pragma unroll
 			for (uint32_t t = 0; t < kVT; t++) {
@@ -1453,6 +1500,10 @@ __global__ __launch_bounds__(256) void k_variant_reduce_mfma(const uint8_t *__re
 #pragma unroll
 				for (int c = 0; c < NCT; c++) {
 					acc[t][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[c], acc[t][c], 0, 0, 0);
+				}
+#pragma unroll
+				for (int qq = 0; qq < NQ; qq++) {
+					accq[t][qq] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, bq[qq], accq[t][qq], 0, 0, 0);
 				}
 			}
 		}
@@ -1468,6 +1519,15 @@ __global__ __launch_bounds__(256) void k_variant_reduce_mfma(const uint8_t *__re
 				if (v < n_var && col < n_cols) {
 					out[static_cast<uint64_t>(v) * out_stride + col] = acc[t][c][r];
 				}
+			}
+		}
+#pragma unroll
+		for (int qq = 0; qq < NQ; qq++) {
+			// D of the 4-block form: lane = 16 i + 4 b + j -> variant 4b + i of the tile, column j
+			const uint32_t v = v_wg + (wave * kVT + t) * 16u + 4u * ((lane >> 2) & 3u) + (lane >> 4);
+			const uint32_t col = 16u * NCT + 4u * qq + (lane & 3u);
+			if (v < n_var && col < n_cols) {
+				out[static_cast<uint64_t>(v) * out_stride + col] = accq[t][qq];
 			}
 		}
 	}
@@ -1837,7 +1897,7 @@ static hipError_t LaunchAccumulateN(const RowView &view, const uint32_t *vlist, 
 	return hipGetLastError();
 }
 
-template <int NCT>
+template <int NCT, int NQ>
 static hipError_t LaunchAccumulateMfma(const RowView &view, const uint32_t *vlist, uint32_t n_var,
                                        const double *weights, uint32_t w_stride, uint32_t n_cols, const double *ts,
                                        bool track_dosage, double *out, uint32_t out_stride, double *dosage_sum,
@@ -1858,11 +1918,11 @@ static hipError_t LaunchAccumulateMfma(const RowView &view, const uint32_t *vlis
 		slices = (n_var + slice_len - 1) / slice_len;
 	}
 	if (track_dosage) {
-		hipLaunchKernelGGL((k_accumulate_mfma<NCT, true>), dim3(sample_blocks, slices), dim3(256), 0, stream,
+		hipLaunchKernelGGL((k_accumulate_mfma<NCT, NQ, true>), dim3(sample_blocks, slices), dim3(256), 0, stream,
 		                   view.rows, view.pitch, view.sample_ct, vlist, n_var, slice_len, weights, w_stride, n_cols,
 		                   ts, out, out_stride, dosage_sum);
 	} else {
-		hipLaunchKernelGGL((k_accumulate_mfma<NCT, false>), dim3(sample_blocks, slices), dim3(256), 0, stream,
+		hipLaunchKernelGGL((k_accumulate_mfma<NCT, NQ, false>), dim3(sample_blocks, slices), dim3(256), 0, stream,
 		                   view.rows, view.pitch, view.sample_ct, vlist, n_var, slice_len, weights, w_stride, n_cols,
 		                   ts, out, out_stride, dosage_sum);
 	}
@@ -1890,15 +1950,23 @@ hipError_t LaunchTableAccumulate(const RowView &view, const uint32_t *vlist, uin
 		while (c0 < n_cols && e == hipSuccess) {
 			const uint32_t left = n_cols - c0;
 			const bool track = c0 == 0 && track_dosage && dosage_sum != nullptr;
-			if (left > 16) {
-				e = LaunchAccumulateMfma<2>(view, vlist, n_var, weights + c0, w_stride, left < 32 ? left : 32, ts, track,
-				                            out + c0, out_stride, dosage_sum, stream);
-				c0 += 32;
+#define PGH_ACC(NCT, NQ, WIDTH)                                                                                        \
+	e = LaunchAccumulateMfma<NCT, NQ>(view, vlist, n_var, weights + c0, w_stride, left < (WIDTH) ? left : (WIDTH), ts, \
+	                                  track, out + c0, out_stride, dosage_sum, stream);                                \
+	c0 += (WIDTH)
+			// full 32-column passes, then the tail as one tile + the quarter tiles it needs
+			if (left >= 32 || left > 28) {
+				PGH_ACC(2, 0, 32);
+			} else if (left > 24) {
+				PGH_ACC(1, 3, 28);
+			} else if (left > 20) {
+				PGH_ACC(1, 2, 24);
+			} else if (left > 16) {
+				PGH_ACC(1, 1, 20);
 			} else {
-				e = LaunchAccumulateMfma<1>(view, vlist, n_var, weights + c0, w_stride, left, ts, track, out + c0,
-				                            out_stride, dosage_sum, stream);
-				c0 += 16;
+				PGH_ACC(1, 0, 16);
 			}
+#undef PGH_ACC
 		}
 		return e;
 	}
@@ -1997,16 +2065,23 @@ hipError_t LaunchVariantReduce(const RowView &view, const uint32_t *vlist, uint3
 		const uint32_t left = n_cols - c0;
 		if (mfma_ok) {
 			const uint32_t blocks = (n_var + 127) / 128;
-			if (left > 16) {
-				hipLaunchKernelGGL((k_variant_reduce_mfma<2>), dim3(blocks), dim3(256), 0, stream, view.rows, view.pitch,
-				                   view.sample_ct, vlist, n_var, ts, G + c0, g_stride, left < 32 ? left : 32, out + c0,
-				                   out_stride);
-				c0 += 32;
+#define PGH_VR(NCT, NQ, WIDTH)                                                                                         \
+	hipLaunchKernelGGL((k_variant_reduce_mfma<NCT, NQ>), dim3(blocks), dim3(256), 0, stream, view.rows, view.pitch,    \
+	                   view.sample_ct, vlist, n_var, ts, G + c0, g_stride, left < (WIDTH) ? left : (WIDTH), out + c0,  \
+	                   out_stride);                                                                                    \
+	c0 += (WIDTH)
+			if (left > 28) {
+				PGH_VR(2, 0, 32);
+			} else if (left > 24) {
+				PGH_VR(1, 3, 28);
+			} else if (left > 20) {
+				PGH_VR(1, 2, 24);
+			} else if (left > 16) {
+				PGH_VR(1, 1, 20);
 			} else {
-				hipLaunchKernelGGL((k_variant_reduce_mfma<1>), dim3(blocks), dim3(256), 0, stream, view.rows, view.pitch,
-				                   view.sample_ct, vlist, n_var, ts, G + c0, g_stride, left, out + c0, out_stride);
-				c0 += 16;
+				PGH_VR(1, 0, 16);
 			}
+#undef PGH_VR
 			e = hipGetLastError();
 		} else if (left >= 8) {
 			e = LaunchVariantReduceN<8>(view, vlist, n_var, ts, G + c0, g_stride, out + c0, out_stride, stream);

@@ -260,9 +260,10 @@ def test_score_matches_oracle(gpu_lib, oracle, mode, ncols):
         assert np.allclose(d, ed, rtol=REL, atol=1e-9)
 
 
-@pytest.mark.parametrize("ncols", [2, 3, 5, 15, 17, 33])
+@pytest.mark.parametrize("ncols", [2, 3, 5, 15, 17, 20, 21, 24, 25, 28, 29, 33, 52])
 def test_score_any_number_of_columns(gpu_lib, oracle, ncols):
-    """1-2 columns run as FMAs, >= 3 on FP64 MFMA tiles (16/32 columns per pass, ragged tails)."""
+    """1 column: pair-table lookups; 2: FMAs; >= 3: FP64 MFMA tiles -- 32 columns per pass, the tail as
+    one 16-column tile plus up to three 4-column quarter tiles (v_mfma_f64_4x4x4_4b_f64)."""
     m, n = 150, 1500
     host = np.stack([gpu_lib.synth_record_host(v, n, SEED + 3, 0.05) for v in range(m)])
     ds = gpu_lib.Dataset.from_host_rows(host, n)
@@ -276,6 +277,30 @@ def test_score_any_number_of_columns(gpu_lib, oracle, ncols):
     scale = np.abs(w).sum(axis=0) * 2.0
     assert np.all(np.abs(s - es) <= REL * np.maximum(np.abs(es), 1e-9 * scale))
     assert np.allclose(d, ed, rtol=REL, atol=1e-9)
+
+
+@pytest.mark.parametrize("n_pcs", [2, 9, 10, 11, 13])
+def test_pca_matches_oracle_on_wide_rows(gpu_lib, oracle, n_pcs):
+    """pgh_pca against the numpy restatement with rows wide enough (>= 512 B) for the MFMA Step A;
+    2k = 4, 18, 20, 22, 26 columns cover a bare tile and 1, 2 and 3 quarter tiles."""
+    m, n = 700, 2100
+    host = np.stack([gpu_lib.synth_record_host(v, n, SEED + 11, 0.03) for v in range(m)])
+    ds = gpu_lib.Dataset.from_host_rows(host, n)
+    pg = oracle.Pgen(mem=mem_pgen(host, n))
+    ev, vecs, m_eff = oracle.pca(pg, n_pcs)
+    c = ds.counts_range().astype(np.float64)
+    obs = c[:, 0] + c[:, 1] + c[:, 2]
+    af = np.where(obs > 0, (c[:, 1] + 2 * c[:, 2]) / np.maximum(2 * obs, 1), 0.0)
+    keep = np.flatnonzero((obs > 0) & (af > 0) & (af < 1))
+    assert len(keep) == m_eff
+    g1 = oracle.fill_g1(n, 2 * n_pcs)
+    got_ev, got_vecs = ds.pca(keep, 2 * af[keep], 1.0 / np.sqrt(2 * af[keep] * (1 - af[keep])), n_pcs, g1)
+    assert np.allclose(got_ev, ev, rtol=1e-6)
+    # unstructured data: the leading eigenvalues are close together, so single eigenvectors are
+    # ill-conditioned; the spanned subspace is not (compare the projectors)
+    assert np.allclose(got_vecs.T @ got_vecs, np.eye(n_pcs), atol=1e-8)
+    if n_pcs == 2:
+        assert np.allclose(got_vecs @ got_vecs.T @ vecs, vecs, atol=1e-5)
 
 
 def test_hwe_batch_matches_oracle(gpu_lib, oracle):
