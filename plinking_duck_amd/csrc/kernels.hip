@@ -1399,7 +1399,7 @@ __global__ __launch_bounds__(256) void k_variant_reduce_mfma(const uint8_t *__re
                                                              uint32_t n_var, const double *__restrict__ ts,
                                                              const double *__restrict__ G, uint32_t g_stride,
                                                              uint32_t n_cols, double *__restrict__ out,
-                                                             uint32_t out_stride) {
+                                                             uint32_t out_stride, uint32_t chunks_per_split) {
 	constexpr uint32_t kChunk = 128;           // samples per LDS chunk
 	constexpr uint32_t kCols = 16 * NCT + 4 * NQ;
 	constexpr uint32_t kQ = NQ > 0 ? NQ : 1;
@@ -1457,10 +1457,18 @@ __global__ __launch_bounds__(256) void k_variant_reduce_mfma(const uint8_t *__re
 			s_g[e / kCols][e % kCols] = r_g[j];
 		}
 	};
-	const uint32_t n_chunks = (sample_ct + kChunk - 1) / kChunk;
+	// blockIdx.y picks a run of sample chunks; with more than one run the partial sums of a
+	// variant meet in `out` (zeroed by the launcher) through FP64 atomics
+	const uint32_t all_chunks = (sample_ct + kChunk - 1) / kChunk;
+	const uint32_t ch_begin = blockIdx.y * chunks_per_split;
+	const uint32_t n_chunks = min(all_chunks, ch_begin + chunks_per_split);
+	const bool split = gridDim.y > 1;
 	const uint32_t lane_shift = 2u * lk; // sample 4q + k sits at bit 2*(4*(q&3) + k) of word q >> 2
-	fetch(0);
-	for (uint32_t ch = 0; ch < n_chunks; ch++) {
+	if (ch_begin >= n_chunks) {
+		return;
+	}
+	fetch(ch_begin * kChunk);
+	for (uint32_t ch = ch_begin; ch < n_chunks; ch++) {
 		__syncthreads(); // everyone is done reading the previous chunk
 		commit();
 		__syncthreads();
@@ -1517,7 +1525,12 @@ __global__ __launch_bounds__(256) void k_variant_reduce_mfma(const uint8_t *__re
 				const uint32_t v = v_wg + (wave * kVT + t) * 16u + lk + 4u * r;
 				const uint32_t col = 16u * c + li;
 				if (v < n_var && col < n_cols) {
-					out[static_cast<uint64_t>(v) * out_stride + col] = acc[t][c][r];
+					double *dst = out + static_cast<uint64_t>(v) * out_stride + col;
+					if (split) {
+						unsafeAtomicAdd(dst, acc[t][c][r]);
+					} else {
+						*dst = acc[t][c][r];
+					}
 				}
 			}
 		}
@@ -1527,7 +1540,12 @@ __global__ __launch_bounds__(256) void k_variant_reduce_mfma(const uint8_t *__re
 			const uint32_t v = v_wg + (wave * kVT + t) * 16u + 4u * ((lane >> 2) & 3u) + (lane >> 4);
 			const uint32_t col = 16u * NCT + 4u * qq + (lane & 3u);
 			if (v < n_var && col < n_cols) {
-				out[static_cast<uint64_t>(v) * out_stride + col] = accq[t][qq];
+				double *dst = out + static_cast<uint64_t>(v) * out_stride + col;
+				if (split) {
+					unsafeAtomicAdd(dst, accq[t][qq]);
+				} else {
+					*dst = accq[t][qq];
+				}
 			}
 		}
 	}
@@ -2064,11 +2082,27 @@ hipError_t LaunchVariantReduce(const RowView &view, const uint32_t *vlist, uint3
 	while (c0 < n_cols && e == hipSuccess) {
 		const uint32_t left = n_cols - c0;
 		if (mfma_ok) {
+			// One workgroup per 128 variants is too coarse for a few hundred thousand variants
+			// (781 workgroups on 256 CUs leave a quarter of the matrix pipes idle at the end):
+			// split the sample axis until there are >= ~12 workgroups per CU.
 			const uint32_t blocks = (n_var + 127) / 128;
+			const uint32_t all_chunks = (view.sample_ct + 127) / 128;
+			uint32_t splits = blocks >= 3072 ? 1 : (3072 + blocks - 1) / blocks;
+			splits = std::min(splits, std::max(1u, all_chunks / 64)); // keep >= 64 chunks (8192 samples) per run
+			const uint32_t chunks_per_split = (all_chunks + splits - 1) / splits;
+			splits = (all_chunks + chunks_per_split - 1) / chunks_per_split;
+			const uint32_t width = left > 28 ? 32 : (left > 24 ? 28 : (left > 20 ? 24 : (left > 16 ? 20 : 16)));
+			if (splits > 1) {
+				e = hipMemset2DAsync(out + c0, sizeof(double) * out_stride, 0, sizeof(double) * std::min(left, width),
+				                     n_var, stream);
+				if (e != hipSuccess) {
+					break;
+				}
+			}
 #define PGH_VR(NCT, NQ, WIDTH)                                                                                         \
-	hipLaunchKernelGGL((k_variant_reduce_mfma<NCT, NQ>), dim3(blocks), dim3(256), 0, stream, view.rows, view.pitch,    \
-	                   view.sample_ct, vlist, n_var, ts, G + c0, g_stride, left < (WIDTH) ? left : (WIDTH), out + c0,  \
-	                   out_stride);                                                                                    \
+	hipLaunchKernelGGL((k_variant_reduce_mfma<NCT, NQ>), dim3(blocks, splits), dim3(256), 0, stream, view.rows,        \
+	                   view.pitch, view.sample_ct, vlist, n_var, ts, G + c0, g_stride,                                 \
+	                   left < (WIDTH) ? left : (WIDTH), out + c0, out_stride, chunks_per_split);                       \
 	c0 += (WIDTH)
 			if (left > 28) {
 				PGH_VR(2, 0, 32);

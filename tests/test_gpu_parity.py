@@ -279,11 +279,12 @@ def test_score_any_number_of_columns(gpu_lib, oracle, ncols):
     assert np.allclose(d, ed, rtol=REL, atol=1e-9)
 
 
-@pytest.mark.parametrize("n_pcs", [2, 9, 10, 11, 13])
-def test_pca_matches_oracle_on_wide_rows(gpu_lib, oracle, n_pcs):
+@pytest.mark.parametrize("n_pcs,m,n", [(2, 700, 2100), (9, 700, 2100), (10, 700, 2100), (11, 700, 2100),
+                                       (13, 700, 2100), (2, 300, 20000), (10, 900, 20000)])
+def test_pca_matches_oracle_on_wide_rows(gpu_lib, oracle, n_pcs, m, n):
     """pgh_pca against the numpy restatement with rows wide enough (>= 512 B) for the MFMA Step A;
-    2k = 4, 18, 20, 22, 26 columns cover a bare tile and 1, 2 and 3 quarter tiles."""
-    m, n = 700, 2100
+    2k = 4, 18, 20, 22, 26 columns cover a bare tile and 1, 2 and 3 quarter tiles; N = 20,000 makes
+    Step A split the sample axis over two workgroups per variant tile (atomic combine)."""
     host = np.stack([gpu_lib.synth_record_host(v, n, SEED + 11, 0.03) for v in range(m)])
     ds = gpu_lib.Dataset.from_host_rows(host, n)
     pg = oracle.Pgen(mem=mem_pgen(host, n))
