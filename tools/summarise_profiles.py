@@ -1,0 +1,92 @@
+"""gpurun_out/profiles/ (written by tools/collect_profiles.sh on the GPU box) -> profiles/rNN_*.
+
+    python3 tools/summarise_profiles.py --round 1
+"""
+import argparse
+import collections
+import csv
+import json
+import os
+import re
+import shutil
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "profiles")
+DST = os.path.join(ROOT, "profiles")
+
+DOMINANT = {"freq": "k_counts_block", "fused": "k_fused_tally", "unpack": "k_unpack_wide"}
+
+
+def short(name):
+    m = re.search(r"k_\w+(<[^>]*>)?", name)
+    return m.group(0) if m else name.split("(")[0]
+
+
+def pmc_means(path):
+    acc = collections.OrderedDict()
+    for r in csv.DictReader(open(path)):
+        key = (short(r["Kernel_Name"]), r["Counter_Name"])
+        s = acc.setdefault(key, [0, 0.0])
+        s[0] += 1
+        s[1] += float(r["Counter_Value"])
+    return acc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--round", type=int, required=True)
+    args = ap.parse_args()
+    tag = f"r{args.round:02d}"
+    for name in ("freq", "fused", "unpack", "score", "score1", "pca"):
+        src = os.path.join(SRC, f"bench_{name}.json")
+        if os.path.exists(src):
+            line = [ln for ln in open(src).read().splitlines() if ln.startswith("{")][-1]
+            json.loads(line)
+            with open(os.path.join(DST, f"{tag}_bench_{name}_n1.json"), "w") as f:
+                f.write(line + "\n")
+    for name in ("freq", "fused", "unpack", "score", "pca"):
+        src = os.path.join(SRC, f"{name}_kernel_stats.csv")
+        if os.path.exists(src):
+            shutil.copy(src, os.path.join(DST, f"{tag}_{name}_kernel_stats.csv"))
+    traffic = {
+        "_method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/collect_profiles.sh) over "
+                   "`python3 bench.py [--workload W] --steps 3 --warmup 1 --cpu-seconds 0`; FETCH_SIZE (KiB) doubled as "
+                   "MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads on gfx950, WRITE_SIZE (KiB) as is; mean "
+                   "over the dominant kernel's dispatches. Per-counter means: profiles/rNN_*_pmc_*.csv "
+                   "(tools/summarise_profiles.py).",
+    }
+    for name, kernel in DOMINANT.items():
+        raw = {}
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            src = os.path.join(SRC, f"{name}_{ctr}.csv")
+            if not os.path.exists(src):
+                continue
+            means = pmc_means(src)
+            with open(os.path.join(DST, f"{tag}_{name}_pmc_{ctr}.csv"), "w") as f:
+                f.write("kernel,counter,dispatches,mean_value,unit\n")
+                for (k, c), (n, total) in means.items():
+                    f.write(f"\"{k}\",{c},{n},{total / n:.3f},KiB\n")
+                    if k.startswith(kernel):
+                        raw[ctr] = (n, total / n)
+        if len(raw) == 2:
+            bench = json.loads(open(os.path.join(DST, f"{tag}_bench_{name}_n1.json")).read())
+            traffic[name] = {
+                "kernel": kernel,
+                "variants": bench["config"]["variants_per_rank"],
+                "samples": bench["config"]["samples"],
+                "fetch_size_kib_raw": raw["FETCH_SIZE"][1],
+                "write_size_kib_raw": raw["WRITE_SIZE"][1],
+                "dispatches": raw["FETCH_SIZE"][0],
+                "hbm_bytes_per_launch": (2 * raw["FETCH_SIZE"][1] + raw["WRITE_SIZE"][1]) * 1024,
+                "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
+            }
+    with open(os.path.join(DST, "traffic.json"), "w") as f:
+        json.dump(traffic, f, indent=1)
+        f.write("\n")
+    for name, e in traffic.items():
+        if isinstance(e, dict):
+            print(name, e["kernel"], f"traffic/algorithmic = {e['hbm_bytes_per_launch'] / e['algorithmic_bytes_per_launch']:.4f}")
+
+
+if __name__ == "__main__":
+    main()
