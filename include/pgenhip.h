@@ -203,6 +203,17 @@ int pgh_score_run_dev(const pgh_score_plan *plan, void *d_score_sum, void *d_dos
                       void *stream, char *errbuf);
 void pgh_score_plan_destroy(pgh_score_plan *plan);
 
+/* plink_ld's per-pair sums (src/plink_ld.cpp:52-84, ComputeLdStats' sample loop): for each
+ * pair p of variants (vidx_a[p], vidx_b[p]) over the samples at which both calls are present
+ * (and which the subset keeps),
+ *   sums[p] = {n, sum_a, sum_b, sum_ab, sum_a2, sum_b2}
+ * as exact integers; r2 / D' follow from them in the caller (the reference's double arithmetic
+ * on the same values).  The two rows are reduced with popcounts on the packed planes -- no
+ * PgrGet + per-sample decode.  Pairs that share an anchor and walk consecutive partners (the
+ * windowed scan's order) read the anchor row once per four partners. */
+int pgh_ld_pairs(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_pairs, const uint32_t *vidx_a,
+                 const uint32_t *vidx_b, uint32_t (*sums)[6], char *errbuf);
+
 /* plink_pca's randomized subspace iteration (src/plink_pca.cpp:630-1080): n_pcs + 1
  * passes of Y = X G1 (Step A) and G1 = X^T Y / M (Step B) over the n_var effective
  * variants, thin SVD of the M x (n_pcs+1)*2*n_pcs Krylov block, then B = X^T U and

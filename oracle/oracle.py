@@ -45,6 +45,7 @@ def _load():
     L.pgo_vrtype.argtypes = [vp, u32]
     L.pgo_get_geno.argtypes = [vp, u32, vp, vp]
     L.pgo_get_raw.argtypes = [vp, u32, vp]
+    L.pgo_ld_sums.argtypes = [vp, u32, u32, vp, vp]
     L.pgo_get_counts.argtypes = [vp, u32, vp, vp]
     L.pgo_get_missingness.argtypes = [vp, u32, vp, vp]
     L.pgo_get_phase.argtypes = [vp, u32, vp, vp, vp, vp]
@@ -129,6 +130,14 @@ class Pgen:
         out = np.zeros(self.N, dtype=np.uint8)
         if _L.pgo_get_raw(self._h, v, _p(out)) != 0:
             raise IOError(f"oracle decode failed for variant {v}")
+        return out
+
+    def ld_sums(self, va, vb, include=None):
+        """{n, sum_a, sum_b, sum_ab, sum_a2, sum_b2} of plink_ld's sample loop."""
+        inc = self._inc(include)
+        out = np.zeros(6, dtype=np.uint64)
+        if _L.pgo_ld_sums(self._h, va, vb, _p(inc), _p(out)) != 0:
+            raise IOError(f"oracle decode failed for variants {va}, {vb}")
         return out
 
     def counts(self, v, include=None):
@@ -361,6 +370,31 @@ def score(pg: Pgen, vidx, weights, flip=None, mode="default", include=None):
             dosage_sum += scored
             allele_ct += 2
     return score_sum, dosage_sum, allele_ct
+
+
+def ld_stats(sums):
+    """ComputeLdStats after its sample loop (src/plink_ld.cpp:86-134) -> (r2, d_prime, obs_ct), r2/d_prime
+    None when the pair has < 2 observations or a monomorphic side."""
+    n = int(sums[0])
+    if n < 2:
+        return None, None, n
+    sum_a, sum_b, sum_ab, sum_a2, sum_b2 = (float(x) for x in sums[1:6])
+    dn = float(n)
+    mean_a, mean_b = sum_a / dn, sum_b / dn
+    cov_ab = sum_ab / dn - mean_a * mean_b
+    var_a = sum_a2 / dn - mean_a * mean_a
+    var_b = sum_b2 / dn - mean_b * mean_b
+    if var_a < 1e-15 or var_b < 1e-15:
+        return None, None, n
+    r2 = (cov_ab * cov_ab) / (var_a * var_b)
+    d = cov_ab / 4.0
+    p_a, p_b = sum_a / (2.0 * dn), sum_b / (2.0 * dn)
+    if d >= 0:
+        d_max = min(p_a * (1.0 - p_b), (1.0 - p_a) * p_b)
+    else:
+        d_max = max(-p_a * p_b, -(1.0 - p_a) * (1.0 - p_b))
+    d_prime = 0.0 if abs(d_max) < 1e-15 else d / d_max
+    return r2, d_prime, n
 
 
 def variant_norm(alt_freq):

@@ -472,6 +472,39 @@ int pgo_get_geno(const pgo_file *h, uint32_t v, const uint8_t *include, int8_t *
 	return rc;
 }
 
+/* plink_ld's sample loop (src/plink_ld.cpp:52-84): over the included samples at which
+ * neither call is missing, out = {n, sum_a, sum_b, sum_ab, sum_a2, sum_b2}.  The reference
+ * accumulates these in doubles; every one is an integer below 2^53, so uint64 is the same. */
+int pgo_ld_sums(const pgo_file *h, uint32_t va, uint32_t vb, const uint8_t *include, uint64_t out[6]) {
+	if (va >= h->M || vb >= h->M) {
+		return -1;
+	}
+	uint8_t *ga = scratch_g(h);
+	uint8_t *gb = scratch_g(h);
+	int rc = decode_main(h, va, ga, NULL);
+	if (!rc) {
+		rc = decode_main(h, vb, gb, NULL);
+	}
+	if (!rc) {
+		memset(out, 0, 6 * sizeof(uint64_t));
+		for (uint32_t s = 0; s < h->N; s++) {
+			if ((include && !include[s]) || ga[s] == 3 || gb[s] == 3) {
+				continue;
+			}
+			uint64_t a = ga[s], b = gb[s];
+			out[0]++;
+			out[1] += a;
+			out[2] += b;
+			out[3] += a * b;
+			out[4] += a * a;
+			out[5] += b * b;
+		}
+	}
+	free(ga);
+	free(gb);
+	return rc;
+}
+
 /* raw 2-bit codes (0..3), one byte per raw sample, no subsetting */
 int pgo_get_raw(const pgo_file *h, uint32_t v, uint8_t *out) {
 	if (v >= h->M) {

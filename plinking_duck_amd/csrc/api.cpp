@@ -5,6 +5,7 @@
 #include "hwe_core.hpp"
 #include "decode.hpp"
 #include "kernels.hpp"
+#include "ld.hpp"
 #include "linalg.hpp"
 #include "pgen_file.hpp"
 #include "synth.hpp"
@@ -1550,6 +1551,68 @@ extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, 
 	}
 	return PGH_OK;
 #undef PGH_SUM
+}
+
+// ---------------------------------------------------------------------------
+// plink_ld
+// ---------------------------------------------------------------------------
+
+extern "C" int pgh_ld_pairs(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_pairs, const uint32_t *vidx_a,
+                            const uint32_t *vidx_b, uint32_t (*sums)[6], char *errbuf) {
+	if (!ds || (n_pairs && (!vidx_a || !vidx_b || !sums))) {
+		SetErr(errbuf, "null argument");
+		return PGH_ERR_ARG;
+	}
+	int rc = CheckSubset(ds, subset, errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	if (n_pairs == 0) {
+		return PGH_OK;
+	}
+	// runs of pairs that share the anchor and step through consecutive partners become one
+	// task of up to four partners (the windowed scan produces exactly such runs)
+	std::vector<pgh::LdTask> tasks;
+	tasks.reserve(n_pairs / 2 + 1);
+	for (uint32_t p = 0; p < n_pairs; p++) {
+		const uint32_t a = vidx_a[p], b = vidx_b[p];
+		if (a < ds->v_begin || a >= ds->v_end || b < ds->v_begin || b >= ds->v_end) {
+			SetErr(errbuf, "variant index outside the resident range");
+			return PGH_ERR_ARG;
+		}
+		if (!tasks.empty()) {
+			pgh::LdTask &last = tasks.back();
+			if (last.n_b < 4 && last.a_row == a - ds->v_begin && last.b_row + last.n_b == b - ds->v_begin) {
+				last.n_b++;
+				continue;
+			}
+		}
+		tasks.push_back(pgh::LdTask {a - ds->v_begin, b - ds->v_begin, 1u, p});
+	}
+	hipStream_t st = hipStreamPerThread;
+	void *d_tasks = nullptr, *d_out = nullptr;
+	PGH_HIP(hipMallocAsync(&d_tasks, sizeof(pgh::LdTask) * tasks.size(), st), "ld scratch");
+	hipError_t e = hipMallocAsync(&d_out, 24ull * n_pairs, st);
+	if (e == hipSuccess) {
+		e = hipMemcpyAsync(d_tasks, tasks.data(), sizeof(pgh::LdTask) * tasks.size(), hipMemcpyHostToDevice, st);
+	}
+	if (e == hipSuccess) {
+		e = pgh::LaunchLdPairs(ds->View(), static_cast<const pgh::LdTask *>(d_tasks),
+		                       static_cast<uint32_t>(tasks.size()), subset ? subset->d_mask2 : nullptr,
+		                       static_cast<uint32_t(*)[6]>(d_out), st);
+	}
+	if (e == hipSuccess) {
+		e = hipMemcpyAsync(sums, d_out, 24ull * n_pairs, hipMemcpyDeviceToHost, st);
+	}
+	if (e == hipSuccess) {
+		e = hipStreamSynchronize(st); // `tasks` and `sums` are host memory of this frame / the caller
+	}
+	(void)hipFreeAsync(d_tasks, st);
+	if (d_out) {
+		(void)hipFreeAsync(d_out, st);
+	}
+	PGH_HIP(e, "ld pair kernel");
+	return PGH_OK;
 }
 
 // ---------------------------------------------------------------------------

@@ -21,6 +21,7 @@ void RegisterPlinkHardy(ExtensionLoader &loader);
 void RegisterPlinkMissing(ExtensionLoader &loader);
 void RegisterPlinkScore(ExtensionLoader &loader);
 void RegisterPlinkPca(ExtensionLoader &loader);
+void RegisterPlinkLd(ExtensionLoader &loader);
 
 static void LoadInternal(ExtensionLoader &loader) {
 	RegisterPgenReader(loader);
@@ -29,6 +30,7 @@ static void LoadInternal(ExtensionLoader &loader) {
 	RegisterPlinkMissing(loader);
 	RegisterPlinkScore(loader);
 	RegisterPlinkPca(loader);
+	RegisterPlinkLd(loader);
 }
 
 namespace {
@@ -215,9 +217,21 @@ string RunQuery(const string &request) {
 			projected.push_back(i);
 		}
 	}
-	init_input.column_ids.assign(projected.begin(), projected.end());
-	vector<LogicalType> out_types;
+	// A function without projection_pushdown always fills every column; DuckDB projects above it.
+	vector<idx_t> scanned = projected;
+	if (!tf.projection_pushdown) {
+		scanned.clear();
+		for (idx_t i = 0; i < names.size(); i++) {
+			scanned.push_back(i);
+		}
+	}
+	vector<idx_t> emit; // positions inside the scanned chunk that the caller asked for
 	for (auto c : projected) {
+		emit.push_back(static_cast<idx_t>(std::find(scanned.begin(), scanned.end(), c) - scanned.begin()));
+	}
+	init_input.column_ids.assign(scanned.begin(), scanned.end());
+	vector<LogicalType> out_types;
+	for (auto c : scanned) {
 		out_types.push_back(return_types[c]);
 	}
 
@@ -247,11 +261,11 @@ string RunQuery(const string &request) {
 				string rows;
 				for (idx_t r = 0; r < chunk.size(); r++) {
 					rows += rows.empty() ? "[" : ",[";
-					for (size_t c = 0; c < chunk.data.size(); c++) {
+					for (size_t c = 0; c < emit.size(); c++) {
 						if (c) {
 							rows += ',';
 						}
-						CellToJson(rows, chunk.data[c], r);
+						CellToJson(rows, chunk.data[emit[c]], r);
 					}
 					rows += ']';
 				}

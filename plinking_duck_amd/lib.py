@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     "pgh_close", "pgh_subset_create", "pgh_subset_size", "pgh_subset_destroy", "pgh_counts_range",
     "pgh_counts_range_dev", "pgh_freq_from_counts_dev", "pgh_fused_tally_dev", "pgh_missing_per_sample", "pgh_missing_per_sample_dev", "pgh_unpack_range",
     "pgh_unpack_range_dev", "pgh_score", "pgh_score_dev", "pgh_score_plan_create", "pgh_score_run_dev",
-    "pgh_score_plan_destroy", "pgh_pca", "pgh_pca_sharded", "pgh_reader_create", "pgh_reader_destroy",
+    "pgh_score_plan_destroy", "pgh_pca", "pgh_pca_sharded", "pgh_ld_pairs", "pgh_reader_create", "pgh_reader_destroy",
     "pgh_get_2bit", "pgh_get_counts", "pgh_get_missingness", "pgh_get_int8", "pgh_get_dosage_f64", "pgh_get_phased",
     "pgh_reader_error", "pgh_hwe_lnp", "pgh_hwe_xchr_lnp", "pgh_hwe_lnp_batch", "pgh_hwe_lnp_batch_dev",
 ]
@@ -97,6 +97,7 @@ def _load():
         "pgh_score_run_dev": (C.c_int, [vp, vp, vp, vp, vp, cp]),
         "pgh_score_plan_destroy": (None, [vp]),
         "pgh_pca": (C.c_int, [vp, vp, u32, vp, vp, vp, u32, vp, vp, vp, cp]),
+        "pgh_ld_pairs": (C.c_int, [vp, vp, u32, vp, vp, vp, cp]),
         "pgh_pca_sharded": (C.c_int, [vp, vp, u32, vp, vp, vp, C.c_uint64, u32, vp, ALLREDUCE_FN, vp, vp, vp, cp]),
         "pgh_reader_create": (C.c_int, [vp, vp, C.POINTER(vp), cp]),
         "pgh_reader_destroy": (None, [vp]),
@@ -396,6 +397,16 @@ class Dataset:
         _check(_lib.pgh_pca(self._h, subset._h if subset else None, len(vidx), _ptr(vidx), _ptr(center),
                             _ptr(inv_stdev), n_pcs, _ptr(g1), _ptr(ev), _ptr(vecs), eb), eb)
         return ev, vecs
+
+    def ld_pairs(self, vidx_a, vidx_b, subset: Subset | None = None) -> np.ndarray:
+        """uint32[n_pairs][6] = {n, sum_a, sum_b, sum_ab, sum_a2, sum_b2} per pair."""
+        a = np.ascontiguousarray(vidx_a, dtype=np.uint32)
+        b = np.ascontiguousarray(vidx_b, dtype=np.uint32)
+        assert a.shape == b.shape and a.ndim == 1
+        out = np.zeros((len(a), 6), dtype=np.uint32)
+        eb = _errbuf()
+        _check(_lib.pgh_ld_pairs(self._h, subset._h if subset else None, len(a), _ptr(a), _ptr(b), _ptr(out), eb), eb)
+        return out
 
     def pca_sharded(self, vidx, center, inv_stdev, n_var_total: int, n_pcs: int, g1_init, allreduce,
                     subset: Subset | None = None):

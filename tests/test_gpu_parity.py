@@ -380,3 +380,30 @@ def test_full_width_rows_properties(gpu_lib, oracle):
     s1, _, _ = ds.score(vidx[:200], np.ones(200))
     s2, _, _ = ds.score(vidx[200:], np.ones(312))
     assert np.allclose(s1 + s2, s, rtol=1e-9)
+
+
+@pytest.mark.parametrize("n", [1, 63, 1000, 4097, 16385, 70001])
+def test_ld_pair_sums_match_oracle(gpu_lib, oracle, n):
+    """pgh_ld_pairs: exact integer sums, wave form (short rows) and workgroup form (rows >= 4 KiB),
+    ragged tails, subsets, anchors with 1..9 consecutive partners, repeated and reversed pairs."""
+    m = 40
+    host = np.stack([gpu_lib.synth_record_host(v, n, SEED + 5, 0.08) for v in range(m)])
+    host[3] = 0xFF  # all missing
+    host[4] = 0x00  # monomorphic
+    ds = gpu_lib.Dataset.from_host_rows(host, n)
+    pg = oracle.Pgen(mem=mem_pgen(host, n))
+    rng = np.random.default_rng(n)
+    a, b = [], []
+    for anchor in range(0, 30, 3):
+        span = int(rng.integers(1, 10))
+        for j in range(anchor + 1, min(m, anchor + 1 + span)):
+            a.append(anchor)
+            b.append(j)
+    a += [7, 9, 9, 39, 3]
+    b += [7, 2, 9, 0, 4]
+    for mask in (None, rng.random(n) < 0.5):
+        ss = None if mask is None else ds.subset(mask)
+        inc = None if mask is None else mask.astype(np.uint8)
+        got = ds.ld_pairs(a, b, subset=ss)
+        want = np.stack([pg.ld_sums(x, y, include=inc) for x, y in zip(a, b)])
+        assert np.array_equal(got.astype(np.uint64), want)

@@ -252,3 +252,25 @@ def test_hwe_extremes(oracle):
     assert -50 < lp <= 0.0
     assert oracle.hwe_lnp(0, 0, 0) == 0.0
     assert math.isinf(oracle.hwe_lnp(100000, 200000, 200000))
+
+
+def test_ld_known_answers(oracle):
+    """plink_ld.test:19-62, 121-137: r2 / D' / OBS_CT of the pgen_example pairs."""
+    ka = KA["plink_ld"]
+    pg = oracle.Pgen(data_path("pgen_example.pgen"))
+    idx = {"rs1": 0, "rs2": 1, "rs3": 2, "rs4": 3}
+    for a, b, r2, dp, n in ka["pairwise"]:
+        got = oracle.ld_stats(pg.ld_sums(idx[a], idx[b]))
+        assert got[0] == pytest.approx(r2, rel=1e-12) and got[2] == n
+        if dp is not None:
+            assert got[1] == pytest.approx(dp, rel=1e-12)
+    for a, r2, n in ka["self"]:
+        got = oracle.ld_stats(pg.ld_sums(idx[a], idx[a]))
+        assert got[0] == pytest.approx(r2, rel=1e-12) and got[2] == n
+    inc = np.array([1, 1, 0, 0], dtype=np.uint8)
+    assert list(oracle.ld_stats(pg.ld_sums(0, 1, include=inc))) == ka["subset_s1_s2"]
+    am = oracle.Pgen(data_path("all_missing.pgen"))
+    assert list(oracle.ld_stats(am.ld_sums(0, 1))) == ka["all_missing"]
+    big = oracle.Pgen(data_path("large_example.pgen"))
+    r2s = {round(oracle.ld_stats(big.ld_sums(a, b))[0], 12) for a in range(10) for b in range(a + 1, 10)}
+    assert r2s == {1.0}

@@ -15,8 +15,8 @@ W = [1.0, 0.5, -0.5, 2.0]
 
 
 def test_registered_functions():
-    assert sorted(F.functions()) == ["plink_freq", "plink_hardy", "plink_missing", "plink_pca", "plink_score",
-                                     "read_pgen"]
+    assert sorted(F.functions()) == ["plink_freq", "plink_hardy", "plink_ld", "plink_missing", "plink_pca",
+                                     "plink_score", "read_pgen"]
 
 
 def err(fn, *args, exc=F.InvalidInputException, **kw):
@@ -177,3 +177,22 @@ def test_max_threads_follow_the_reference_formulas():
     assert len(ids) == 50000 and len(set(ids)) == 50000  # no duplicate rows from thread races
     assert F.query("read_pgen", big, columns=["ID"], threads=64).threads == 16
     assert F.query("plink_missing", big, columns=["ID"], threads=5).threads == 5
+
+
+def test_plink_ld_bind_errors():
+    """plink_ld_negative.test"""
+    assert "plink_ld" in err("plink_ld", "nonexistent.pgen", variant1="rs1", variant2="rs2")
+    assert "not found in .pvar" in err("plink_ld", EX, variant1="NOSUCHVARIANT", variant2="rs2")
+    assert "not found in .pvar" in err("plink_ld", EX, variant1="rs1", variant2="NOSUCHVARIANT")
+    assert "both variant1 and variant2" in err("plink_ld", EX, variant1="rs1")
+    assert "both variant1 and variant2" in err("plink_ld", EX, variant2="rs2")
+    assert "r2_threshold" in err("plink_ld", EX, r2_threshold=-0.1)
+    assert "r2_threshold" in err("plink_ld", EX, r2_threshold=1.5)
+    assert "window_kb" in err("plink_ld", EX, window_kb=-1)
+    assert "not found" in err("plink_ld", EX, variant1="rs1", variant2="rs2", samples=["NOSUCHSAMPLE"])
+    assert "region" in err("plink_ld", EX, region="invalid_region", variant1="rs1", variant2="rs2")
+    # a region with fewer than two variants has no pairs and never touches the device
+    assert len(F.query("plink_ld", EX, region="2:15000-15000", r2_threshold=0.0)) == 0
+    assert len(F.query("plink_ld", EX, region="99:1-100", r2_threshold=0.0)) == 0
+    r = F.query("plink_ld", EX, region="99:1-100")
+    assert r.all_names == ["CHROM_A", "POS_A", "ID_A", "CHROM_B", "POS_B", "ID_B", "R2", "D_PRIME", "OBS_CT"]

@@ -448,3 +448,95 @@ def test_pca_matches_oracle_with_subset(gpu_lib, oracle):
     ev_got = F.query("plink_pca", path, n_pcs=2, mode="pcs",
                      samples=[names[i] for i in np.flatnonzero(mask)]).sorted("PC")
     assert [row[1] for row in ev_got] == pytest.approx(list(ev), rel=1e-6)
+
+
+# ---- plink_ld (plink_ld.test, plink_ld_window.test) ------------------------------------------
+
+def test_ld_pairwise_known_answers():
+    ka = KA["plink_ld"]
+    for a, b, r2, dp, n in ka["pairwise"]:
+        r = F.query("plink_ld", EX, variant1=a, variant2=b)
+        assert len(r) == 1
+        row = dict(zip(r.names, r.rows[0]))
+        assert (row["ID_A"], row["ID_B"], row["OBS_CT"]) == (a, b, n) and row["R2"] == pytest.approx(r2, rel=1e-12)
+        if dp is not None:
+            assert row["D_PRIME"] == pytest.approx(dp, rel=1e-12)
+    r = F.query("plink_ld", EX, variant1="rs1", variant2="rs2")
+    assert r.rows[0][:6] == ("1", 10000, "rs1", "1", 20000, "rs2") and r.rows[0][8] == 3
+    assert r.rows[0][6:8] == pytest.approx((0.75, 0.5), rel=1e-12)  # sqllogictest's R columns compare to ~1e-10 too
+    assert r.types == ["VARCHAR", "INTEGER", "VARCHAR", "VARCHAR", "INTEGER", "VARCHAR", "DOUBLE", "DOUBLE", "INTEGER"]
+    r = F.query("plink_ld", EX, variant1="rs1", variant2="rs4", columns=["ID_A", "CHROM_A", "ID_B", "CHROM_B", "R2", "OBS_CT"])
+    assert r.rows[0][:4] == ("rs1", "1", "rs4", "2") and r.rows[0][4:] == pytest.approx((0.75, 3))
+    for a, r2, n in ka["self"]:
+        assert F.query("plink_ld", EX, variant1=a, variant2=a, columns=["R2", "OBS_CT"]).rows[0] == pytest.approx((r2, n))
+    for samples in (["SAMPLE1", "SAMPLE2"], [0, 1]):
+        r = F.query("plink_ld", EX, variant1="rs1", variant2="rs2", samples=samples, columns=["R2", "D_PRIME", "OBS_CT"])
+        assert list(r.rows[0]) == ka["subset_s1_s2"]
+    r = F.query("plink_ld", data_path("all_missing.pgen"), variant1="rs_miss1", variant2="rs_miss2",
+                columns=["R2", "D_PRIME", "OBS_CT"])
+    assert list(r.rows[0]) == ka["all_missing"]
+    for kw in (dict(pvar=data_path("pgen_example.pvar"), psam=data_path("pgen_example.psam")),
+               dict(pvar=data_path("pgen_example.bim"))):
+        assert F.query("plink_ld", EX, variant1="rs1", variant2="rs2", columns=["R2", "OBS_CT"],
+                       **kw).rows[0] == pytest.approx((0.75, 3))
+
+
+def test_ld_windowed_known_answers():
+    ka = KA["plink_ld"]
+    cols = ["ID_A", "ID_B", "R2", "D_PRIME", "OBS_CT"]
+    r = F.query("plink_ld", EX, window_kb=1000, r2_threshold=0.0, columns=cols)
+    for got, want in zip(r.sorted("ID_A", "ID_B"), ka["window_1000kb_r2_0"]):
+        assert got[:2] == tuple(want[:2]) and got[2:] == pytest.approx(want[2:], rel=1e-12)
+    pairs = lambda **kw: [list(x) for x in F.query("plink_ld", EX, columns=["ID_A", "ID_B"], **kw).sorted("ID_A", "ID_B")]
+    assert pairs(window_kb=15, r2_threshold=0.0) == ka["window_15kb_pairs"]
+    assert len(pairs(window_kb=5, r2_threshold=0.0)) == ka["window_5kb_count"]
+    r = F.query("plink_ld", EX, window_kb=10000, r2_threshold=0.0, columns=["CHROM_A", "CHROM_B"])
+    assert all(a == b for a, b in r.rows)
+    r = F.query("plink_ld", EX, window_kb=10000, r2_threshold=0.0, inter_chr=True, columns=["CHROM_A", "CHROM_B"])
+    assert len(r) == ka["inter_chr_count"] and sum(a != b for a, b in r.rows) == ka["inter_chr_cross_count"]
+    assert pairs(window_kb=15, r2_threshold=0.0, inter_chr=True) == ka["inter_chr_15kb_pairs"]
+    assert len(pairs(window_kb=1000, r2_threshold=0.5)) == ka["threshold_counts"]["0.5"]
+    assert pairs(window_kb=1000, r2_threshold=0.5) == [["rs1", "rs2"], ["rs1", "rs3"]]
+    assert len(pairs(window_kb=1000, r2_threshold=0.8)) == ka["threshold_counts"]["0.8"]
+    assert len(pairs(window_kb=1000)) == ka["threshold_counts"]["default"]
+    r = F.query("plink_ld", EX, region="1:10000-20000", r2_threshold=0.0, columns=["ID_A", "ID_B", "R2"])
+    assert r.rows[0][:2] == ("rs1", "rs2") and r.rows[0][2] == pytest.approx(0.75, rel=1e-12)
+    r = F.query("plink_ld", EX, window_kb=1000, r2_threshold=0.0, columns=["POS_A", "POS_B", "CHROM_A", "CHROM_B"])
+    assert all(pa < pb for pa, pb, ca, cb in r.rows if ca == cb)
+    big = data_path("large_example.pgen")
+    exp = ka["large_example_region_1_100_1000_window_1kb"]
+    r = F.query("plink_ld", big, region="1:100-1000", window_kb=1, r2_threshold=0.0, columns=["ID_A", "ID_B", "R2"])
+    assert len(r) == exp["pairs"] and sorted(set(round(x, 12) for x in r.column("R2"))) == exp["distinct_r2"]
+    assert len(set((a, b) for a, b, _ in r.rows)) == exp["pairs"]
+
+
+def test_ld_windowed_matches_oracle_across_threads(oracle):
+    """pca_example: 500 variants x 250 samples with missing calls; every pair inside a window vs the oracle."""
+    path = data_path("pca_example.pgen")
+    pg = oracle.Pgen(path)
+    pv = oracle.load_pvar(data_path("pca_example.pvar"))
+    want = {}
+    kb = 50
+    for a in range(pg.M):
+        for b in range(a + 1, pg.M):
+            if pv["chrom"][a] != pv["chrom"][b] or pv["pos"][b] - pv["pos"][a] > kb * 1000:
+                break
+            r2, dp, n = oracle.ld_stats(pg.ld_sums(a, b))
+            if r2 is not None and r2 >= 0.05:
+                want[(pv["id"][a], pv["id"][b])] = (r2, dp, n)
+    assert len(want) > 50
+    for threads in (1, 5):
+        r = F.query("plink_ld", path, window_kb=kb, r2_threshold=0.05, threads=threads,
+                    columns=["ID_A", "ID_B", "R2", "D_PRIME", "OBS_CT"])
+        got = {(a, b): (r2, dp, n) for a, b, r2, dp, n in r.rows}
+        assert got.keys() == want.keys()
+        for k, (r2, dp, n) in want.items():
+            assert got[k][2] == n and got[k][0] == r2 and got[k][1] == dp  # same sums, same double arithmetic
+    mask = np.random.default_rng(8).random(pg.N) < 0.6
+    names = oracle.load_psam(data_path("pca_example.psam"))["iid"]
+    r = F.query("plink_ld", path, window_kb=20, r2_threshold=0.0, samples=[names[i] for i in np.flatnonzero(mask)],
+                columns=["ID_A", "ID_B", "R2", "OBS_CT"])
+    idx = {v: i for i, v in enumerate(pv["id"])}
+    for a, b, r2, n in r.rows[:200]:
+        e_r2, _, e_n = oracle.ld_stats(pg.ld_sums(idx[a], idx[b], include=mask.astype(np.uint8)))
+        assert (r2, n) == (e_r2, e_n)
