@@ -203,6 +203,14 @@ int pgh_score_run_dev(const pgh_score_plan *plan, void *d_score_sum, void *d_dos
                       void *stream, char *errbuf);
 void pgh_score_plan_destroy(pgh_score_plan *plan);
 
+/* read_pfile's sample-orient aggregate (src/pfile_reader.cpp:3308-3400, the streaming
+ * accumulate_dense loop): counts[k] = {hom_ref, het, hom_alt, missing} of output sample k over
+ * the variants [variant_begin, variant_begin + n_var) or, with vidx != NULL, the n_var listed
+ * variants.  Three column-tally passes over the packed rows (het, hom-alt, missing), hom-ref by
+ * subtraction as the reference derives it at emit time. */
+int pgh_sample_counts(const pgh_dataset *ds, const pgh_subset *subset, uint32_t variant_begin, uint32_t n_var,
+                      const uint32_t *vidx, uint32_t (*counts)[4], char *errbuf);
+
 /* plink_ld's per-pair sums (src/plink_ld.cpp:52-84, ComputeLdStats' sample loop): for each
  * pair p of variants (vidx_a[p], vidx_b[p]) over the samples at which both calls are present
  * (and which the subset keeps),

@@ -132,6 +132,20 @@ class Pgen:
             raise IOError(f"oracle decode failed for variant {v}")
         return out
 
+    def sample_counts(self, vidx=None, include=None):
+        """read_pfile's sample-orient aggregate (src/pfile_reader.cpp:3330-3355): per included sample
+        {hom_ref, het, hom_alt, missing} over the listed variants (default: all)."""
+        vidx = range(self.M) if vidx is None else vidx
+        n = self._n_out(include)
+        out = np.zeros((n, 4), dtype=np.uint32)
+        for v in vidx:
+            g = self.geno(v, include)
+            out[:, 1] += g == 1
+            out[:, 2] += g == 2
+            out[:, 3] += g == -9
+        out[:, 0] = len(vidx) - out[:, 1] - out[:, 2] - out[:, 3]  # hom_ref is derived at emit time
+        return out
+
     def ld_sums(self, va, vb, include=None):
         """{n, sum_a, sum_b, sum_ab, sum_a2, sum_b2} of plink_ld's sample loop."""
         inc = self._inc(include)

@@ -1063,6 +1063,67 @@ extern "C" int pgh_missing_per_sample(const pgh_dataset *ds, const pgh_subset *s
 	return PGH_OK;
 }
 
+extern "C" int pgh_sample_counts(const pgh_dataset *ds, const pgh_subset *subset, uint32_t variant_begin,
+                                 uint32_t n_var, const uint32_t *vidx, uint32_t (*counts)[4], char *errbuf) {
+	if (!ds || !counts) {
+		SetErr(errbuf, "null argument");
+		return PGH_ERR_ARG;
+	}
+	int rc = CheckSubset(ds, subset, errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	std::vector<uint32_t> local;
+	if (vidx) {
+		local.resize(n_var);
+		for (uint32_t i = 0; i < n_var; i++) {
+			if (vidx[i] < ds->v_begin || vidx[i] >= ds->v_end) {
+				SetErr(errbuf, "variant index outside the resident range");
+				return PGH_ERR_ARG;
+			}
+			local[i] = vidx[i] - ds->v_begin;
+		}
+	} else {
+		rc = CheckRange(ds, variant_begin, variant_begin + n_var, errbuf);
+		if (rc != PGH_OK) {
+			return rc;
+		}
+	}
+	const uint32_t N = ds->sample_ct;
+	const uint32_t n_out = subset ? subset->n_out : N;
+	const uint32_t padded = (N + 63) / 64 * 64;
+	hipStream_t st = hipStreamPerThread;
+	DevBuf d_cls, d_list, d_scratch;
+	PGH_HIP(d_cls.Alloc(sizeof(uint32_t) * 3ull * padded), "hipMalloc(sample counts)");
+	const size_t scratch_bytes = pgh::MissingPerSampleScratchBytes(ds->record_bytes, n_var);
+	PGH_HIP(d_scratch.Alloc(scratch_bytes ? scratch_bytes : 16), "hipMalloc(sample counts)");
+	if (vidx && n_var) {
+		PGH_HIP(d_list.Alloc(sizeof(uint32_t) * n_var), "hipMalloc(sample counts)");
+		PGH_HIP(hipMemcpyAsync(d_list.p, local.data(), sizeof(uint32_t) * n_var, hipMemcpyHostToDevice, st),
+		        "sample counts upload");
+	}
+	// one column-tally pass per class (het, hom-alt, missing); hom-ref is what is left
+	for (int cls = 1; cls <= 3; cls++) {
+		PGH_HIP(pgh::LaunchClassPerSample(ds->View(), cls, vidx ? 0 : variant_begin - ds->v_begin,
+		                                  vidx ? d_list.As<uint32_t>() : nullptr, n_var, nullptr,
+		                                  d_scratch.As<uint32_t>(), d_cls.As<uint32_t>() + (cls - 1) * padded, st),
+		        "sample counts kernel");
+	}
+	std::vector<uint32_t> raw(3ull * padded);
+	PGH_HIP(hipMemcpyAsync(raw.data(), d_cls.p, sizeof(uint32_t) * raw.size(), hipMemcpyDeviceToHost, st),
+	        "sample counts copy");
+	PGH_HIP(hipStreamSynchronize(st), "sample counts sync");
+	for (uint32_t k = 0; k < n_out; k++) {
+		const uint32_t s = subset ? subset->sel[k] : k;
+		const uint32_t het = raw[s], alt = raw[padded + s], miss = raw[2ull * padded + s];
+		counts[k][0] = n_var - het - alt - miss;
+		counts[k][1] = het;
+		counts[k][2] = alt;
+		counts[k][3] = miss;
+	}
+	return PGH_OK;
+}
+
 extern "C" int pgh_unpack_range_dev(const pgh_dataset *ds, const pgh_subset *subset, uint32_t v_begin, uint32_t v_end,
                                     void *d_out, size_t out_pitch, void *d_validity, int missing_code, void *stream,
                                     char *errbuf) {

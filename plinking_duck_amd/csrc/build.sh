@@ -20,7 +20,7 @@ echo "built $(cd .. && pwd)/libpgenhip.so"
 
 # host-side table-function shells (plain C++; link against the C ABI only)
 CXX=${CXX:-g++}
-SHELL_SRCS="plink_common pgen_reader plink_freq plink_hardy plink_missing plink_score plink_pca plink_ld extension"
+SHELL_SRCS="plink_common pgen_reader plink_freq plink_hardy plink_missing plink_score plink_pca plink_ld pfile_reader extension"
 objs=""
 for n in $SHELL_SRCS; do
 	o=build/shell_$n.o

@@ -280,6 +280,20 @@ __device__ __forceinline__ void Fold8To32(MissAcc &acc) {
 	}
 }
 
+// CLASS: which genotype code is tallied -- 3 missing (plink_missing, plink_score), 1 het,
+// 2 hom-alt (read_pfile's sample-orient counts)
+template <int CLASS>
+__device__ __forceinline__ uint32_t ClassBits(uint32_t w) {
+	if (CLASS == 3) {
+		return w & (w >> 1) & 0x55555555u;
+	}
+	if (CLASS == 1) {
+		return w & ~(w >> 1) & 0x55555555u;
+	}
+	return (w >> 1) & ~w & 0x55555555u;
+}
+
+template <int CLASS>
 __global__ __launch_bounds__(256) void k_missing_cols(const uint8_t *__restrict__ rows, uint64_t pitch,
                                                       uint32_t chunks, uint32_t v_first,
                                                       const uint32_t *__restrict__ vlist, uint32_t v_count,
@@ -333,14 +347,14 @@ __global__ __launch_bounds__(256) void k_missing_cols(const uint8_t *__restrict_
 		const uint4 w4 = LoadStream(row_ptr(i + 4));
 		const uint4 w5 = LoadStream(row_ptr(i + 5));
 		uint32_t a[4], b[4];
-		a[0] = MissBits(w0.x) + MissBits(w1.x) + MissBits(w2.x);
-		a[1] = MissBits(w0.y) + MissBits(w1.y) + MissBits(w2.y);
-		a[2] = MissBits(w0.z) + MissBits(w1.z) + MissBits(w2.z);
-		a[3] = MissBits(w0.w) + MissBits(w1.w) + MissBits(w2.w);
-		b[0] = MissBits(w3.x) + MissBits(w4.x) + MissBits(w5.x);
-		b[1] = MissBits(w3.y) + MissBits(w4.y) + MissBits(w5.y);
-		b[2] = MissBits(w3.z) + MissBits(w4.z) + MissBits(w5.z);
-		b[3] = MissBits(w3.w) + MissBits(w4.w) + MissBits(w5.w);
+		a[0] = ClassBits<CLASS>(w0.x) + ClassBits<CLASS>(w1.x) + ClassBits<CLASS>(w2.x);
+		a[1] = ClassBits<CLASS>(w0.y) + ClassBits<CLASS>(w1.y) + ClassBits<CLASS>(w2.y);
+		a[2] = ClassBits<CLASS>(w0.z) + ClassBits<CLASS>(w1.z) + ClassBits<CLASS>(w2.z);
+		a[3] = ClassBits<CLASS>(w0.w) + ClassBits<CLASS>(w1.w) + ClassBits<CLASS>(w2.w);
+		b[0] = ClassBits<CLASS>(w3.x) + ClassBits<CLASS>(w4.x) + ClassBits<CLASS>(w5.x);
+		b[1] = ClassBits<CLASS>(w3.y) + ClassBits<CLASS>(w4.y) + ClassBits<CLASS>(w5.y);
+		b[2] = ClassBits<CLASS>(w3.z) + ClassBits<CLASS>(w4.z) + ClassBits<CLASS>(w5.z);
+		b[3] = ClassBits<CLASS>(w3.w) + ClassBits<CLASS>(w4.w) + ClassBits<CLASS>(w5.w);
 		fold(a, 3);
 		fold(b, 3);
 		i += 6;
@@ -348,7 +362,7 @@ __global__ __launch_bounds__(256) void k_missing_cols(const uint8_t *__restrict_
 	while (i < i_end) {
 		if (!row_flags || (row_flags[i] & 0xffu)) { // wave-uniform
 			const uint4 w0 = LoadStream(row_ptr(i));
-			uint32_t a[4] = {MissBits(w0.x), MissBits(w0.y), MissBits(w0.z), MissBits(w0.w)};
+			uint32_t a[4] = {ClassBits<CLASS>(w0.x), ClassBits<CLASS>(w0.y), ClassBits<CLASS>(w0.z), ClassBits<CLASS>(w0.w)};
 			fold(a, 1);
 		}
 		i += 1;
@@ -1794,6 +1808,12 @@ size_t MissingPerSampleScratchBytes(uint32_t record_bytes, uint32_t v_count) {
 
 hipError_t LaunchMissingPerSample(const RowView &view, uint32_t v_first, const uint32_t *vlist, uint32_t v_count,
                                   const uint32_t *row_flags, uint32_t *scratch, uint32_t *out, hipStream_t stream) {
+	return LaunchClassPerSample(view, 3, v_first, vlist, v_count, row_flags, scratch, out, stream);
+}
+
+hipError_t LaunchClassPerSample(const RowView &view, int genotype_class, uint32_t v_first, const uint32_t *vlist,
+                                uint32_t v_count, const uint32_t *row_flags, uint32_t *scratch, uint32_t *out,
+                                hipStream_t stream) {
 	if (v_count == 0) {
 		return hipMemsetAsync(out, 0, sizeof(uint32_t) * view.sample_ct, stream);
 	}
@@ -1802,8 +1822,17 @@ hipError_t LaunchMissingPerSample(const RowView &view, uint32_t v_first, const u
 	uint32_t slice_len, slices;
 	MissingPerSamplePlan(view.record_bytes, v_count, &slice_len, &slices);
 	const uint32_t stride = chunks * 64u;
-	hipLaunchKernelGGL(k_missing_cols, dim3(col_blocks, slices), dim3(256), 0, stream, view.rows, view.pitch, chunks,
-	                   v_first, vlist, v_count, slice_len, row_flags, scratch, stride);
+#define PGH_COLS(CLASS)                                                                                                \
+	hipLaunchKernelGGL(k_missing_cols<CLASS>, dim3(col_blocks, slices), dim3(256), 0, stream, view.rows, view.pitch,   \
+	                   chunks, v_first, vlist, v_count, slice_len, row_flags, scratch, stride)
+	if (genotype_class == 1) {
+		PGH_COLS(1);
+	} else if (genotype_class == 2) {
+		PGH_COLS(2);
+	} else {
+		PGH_COLS(3);
+	}
+#undef PGH_COLS
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) {
 		return e;

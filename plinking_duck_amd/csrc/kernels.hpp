@@ -46,6 +46,11 @@ size_t MissingPerSampleScratchBytes(uint32_t record_bytes, uint32_t v_count);
 hipError_t LaunchMissingPerSample(const RowView &view, uint32_t v_first, const uint32_t *vlist, uint32_t v_count,
                                   const uint32_t *row_flags, uint32_t *scratch, uint32_t *out, hipStream_t stream);
 
+// The same column tally for any one genotype code: 1 het, 2 hom-alt, 3 missing.
+hipError_t LaunchClassPerSample(const RowView &view, int genotype_class, uint32_t v_first, const uint32_t *vlist,
+                                uint32_t v_count, const uint32_t *row_flags, uint32_t *scratch, uint32_t *out,
+                                hipStream_t stream);
+
 // Both reductions in one pass over [v_first, v_first + v_count): counts[i] = class tallies
 // of row i (all samples), missing_per_sample[s] as above.  Same scratch size as
 // LaunchMissingPerSample.

@@ -22,6 +22,7 @@ void RegisterPlinkMissing(ExtensionLoader &loader);
 void RegisterPlinkScore(ExtensionLoader &loader);
 void RegisterPlinkPca(ExtensionLoader &loader);
 void RegisterPlinkLd(ExtensionLoader &loader);
+void RegisterPfileReader(ExtensionLoader &loader);
 
 static void LoadInternal(ExtensionLoader &loader) {
 	RegisterPgenReader(loader);
@@ -31,6 +32,7 @@ static void LoadInternal(ExtensionLoader &loader) {
 	RegisterPlinkScore(loader);
 	RegisterPlinkPca(loader);
 	RegisterPlinkLd(loader);
+	RegisterPfileReader(loader);
 }
 
 namespace {

@@ -11,59 +11,27 @@
 // 'columns' / 'struct' lay the same unpacked bytes out as one scalar column (or
 // struct field) per sample (src/pgen_reader.cpp:386-433, 781-845); `variants :=`
 // scans a caller-ordered list of variant indices (src/pgen_reader.cpp:304-312).
-#include "variant_scan.hpp"
+#include "pgen_reader.hpp"
 
 #include <cmath>
 #include <limits>
 
 namespace duckdb {
 
-static constexpr idx_t COL_GENOTYPES = 5;
-static constexpr uint32_t kUnpackSpan = 2048; // variants unpacked per launch (one output vector)
-
-struct PgenBindData : public TableFunctionData {
-	PgenBindCommon c;
-	bool include_dosages = false;
-	bool include_phased = false;
-	GenotypeMode genotype_mode = GenotypeMode::ARRAY;
-	CountFilter count_filter;
-	GenotypeRangeFilter genotype_filter;
-	uint32_t output_sample_ct = 0;
-	bool has_variant_list = false;
-	vector<uint32_t> variant_indices; // `variants :=`, caller order
-	vector<string> genotype_column_names; // columns / struct modes: IIDs in ascending file order
-};
-
-struct PgenGlobalState : public GlobalTableFunctionState {
-	VariantScanGlobal scan;
-	vector<column_t> column_ids;
-	bool need_genotypes = false;
-	bool need_counts = false;
-	uint32_t max_threads_config = 0;
-	idx_t MaxThreads() const override {
-		uint32_t total = scan.has_variant_list ? static_cast<uint32_t>(scan.variant_list.size())
-		                                       : scan.end_variant_idx - scan.start_variant_idx;
-		return ApplyMaxThreadsCap(total / 1000 + 1, max_threads_config);
-	}
-};
-
-struct PgenLocalState : public LocalTableFunctionState {
-	VariantScanLocal scan;
-	pgh_reader *reader = nullptr;
-	vector<int8_t> bytes;       // unpacked span [rows][n_out]
-	vector<uint64_t> validity;  // [rows][ceil(n_out/64)]
-	vector<double> dosage_doubles;
-	vector<uint64_t> genovec, phasepresent, phaseinfo;
-	~PgenLocalState() override {
-		if (reader) {
-			pgh_reader_destroy(reader);
-		}
-	}
-};
-
 static unique_ptr<FunctionData> PgenBind(ClientContext &context, TableFunctionBindInput &input,
                                          vector<LogicalType> &return_types, vector<string> &names) {
+	return PgenBindNamed(context, input, return_types, names, "read_pgen", false);
+}
+
+unique_ptr<FunctionData> PgenBindNamed(ClientContext &context, TableFunctionBindInput &input,
+                                       vector<LogicalType> &return_types, vector<string> &names, const string &func,
+                                       bool with_region) {
 	auto bind_data = make_uniq<PgenBindData>();
+	bind_data->func = func;
+	const char *fn = bind_data->func.c_str();
+	if (!with_region && input.named_parameters.count("region")) {
+		throw BinderException("Invalid named parameter \"region\" for function %s", fn);
+	}
 	for (auto &kv : input.named_parameters) {
 		if (kv.first == "dosages") {
 			bind_data->include_dosages = kv.second.GetValue<bool>();
@@ -76,55 +44,64 @@ static unique_ptr<FunctionData> PgenBind(ClientContext &context, TableFunctionBi
 				ch = static_cast<char>(std::tolower(static_cast<unsigned char>(ch)));
 			}
 			if (lower != "variant") {
-				throw InvalidInputException("read_pgen: orient := '%s' is not supported "
+				throw InvalidInputException("%s: orient := '%s' is not supported "
 				                            "(read_pgen only supports orient := 'variant'; "
-				                            "use read_pfile for orient := 'genotype' or 'sample')",
+				                            "use read_pfile for orient := 'genotype' or 'sample')", fn,
 				                            v);
 			}
 		}
 	}
 	if (bind_data->include_dosages && bind_data->include_phased) {
-		throw InvalidInputException("read_pgen: dosages and phased cannot both be true");
+		throw InvalidInputException("%s: dosages and phased cannot both be true", fn);
 	}
 	auto &c = bind_data->c;
-	c.Bind(context, input, "read_pgen", false);
+	c.Bind(context, input, bind_data->func, false);
 	uint32_t output_sample_ct = c.effective_sample_ct;
 	bind_data->output_sample_ct = output_sample_ct;
 
 	auto variants_it = input.named_parameters.find("variants");
 	if (variants_it != input.named_parameters.end()) {
 		bind_data->variant_indices =
-		    ResolveVariantsParameter(variants_it->second, c.variants, c.raw_variant_ct, "read_pgen");
+		    ResolveVariantsParameter(variants_it->second, c.variants, c.raw_variant_ct, bind_data->func);
 		bind_data->has_variant_list = true;
+		if (c.variant_range.has_filter) {
+			// read_pfile: region and variants intersect
+			vector<uint32_t> kept;
+			for (auto v : bind_data->variant_indices) {
+				if (v >= c.RangeStart() && v < c.RangeEnd()) {
+					kept.push_back(v);
+				}
+			}
+			bind_data->variant_indices.swap(kept);
+		}
 	}
 
 	auto af_it = input.named_parameters.find("af_range");
 	if (af_it != input.named_parameters.end()) {
-		bind_data->count_filter.af_filter = ParseRangeFilter(af_it->second, "af_range", 0.0, 1.0, "read_pgen");
+		bind_data->count_filter.af_filter = ParseRangeFilter(af_it->second, "af_range", 0.0, 1.0, bind_data->func);
 	}
 	auto ac_it = input.named_parameters.find("ac_range");
 	if (ac_it != input.named_parameters.end()) {
 		bind_data->count_filter.ac_filter =
-		    ParseRangeFilter(ac_it->second, "ac_range", 0.0, static_cast<double>(2 * output_sample_ct), "read_pgen");
+		    ParseRangeFilter(ac_it->second, "ac_range", 0.0, static_cast<double>(2 * output_sample_ct), bind_data->func);
 	}
 	auto ig_it = input.named_parameters.find("include_genotypes");
 	auto gr_it = input.named_parameters.find("genotype_range");
 	bool has_ig = ig_it != input.named_parameters.end();
 	bool has_gr = gr_it != input.named_parameters.end();
 	if (has_ig && has_gr) {
-		throw InvalidInputException(
-		    "read_pgen: specify only one of include_genotypes or genotype_range (genotype_range is the numeric "
-		    "alias of include_genotypes)");
+		throw InvalidInputException("%s: specify only one of include_genotypes or genotype_range (genotype_range is the numeric "
+		    "alias of include_genotypes)", fn);
 	}
 	if ((has_ig || has_gr) && bind_data->include_dosages) {
-		throw InvalidInputException("read_pgen: %s is incompatible with dosages := true",
+		throw InvalidInputException("%s: %s is incompatible with dosages := true", fn,
 		                            has_ig ? "include_genotypes" : "genotype_range");
 	}
 	if (has_ig) {
-		ParseIncludeGenotypes(ig_it->second, bind_data->genotype_filter, "read_pgen");
+		ParseIncludeGenotypes(ig_it->second, bind_data->genotype_filter, bind_data->func);
 	} else if (has_gr) {
 		bool inc_missing = false;
-		RangeFilter range = ParseRangeFilter(gr_it->second, "genotype_range", 0.0, 2.0, "read_pgen", &inc_missing);
+		RangeFilter range = ParseRangeFilter(gr_it->second, "genotype_range", 0.0, 2.0, bind_data->func, &inc_missing);
 		bind_data->genotype_filter.SetFromRange(range, inc_missing);
 	}
 
@@ -133,22 +110,22 @@ static unique_ptr<FunctionData> PgenBind(ClientContext &context, TableFunctionBi
 	if (genotypes_it != input.named_parameters.end()) {
 		genotypes_str = genotypes_it->second.GetValue<string>();
 	}
-	bind_data->genotype_mode = ResolveGenotypeMode(genotypes_str, output_sample_ct, "read_pgen");
+	bind_data->genotype_mode = ResolveGenotypeMode(genotypes_str, output_sample_ct, bind_data->func);
 	if (IsAggregateGenotypeMode(bind_data->genotype_mode)) {
 		const char *label = bind_data->genotype_mode == GenotypeMode::COUNTS ? "counts" : "stats";
 		if (bind_data->include_phased) {
-			throw InvalidInputException("read_pgen: genotypes := '%s' is incompatible with phased := true", label);
+			throw InvalidInputException("%s: genotypes := '%s' is incompatible with phased := true", fn, label);
 		}
 		if (bind_data->include_dosages) {
-			throw InvalidInputException("read_pgen: genotypes := '%s' is incompatible with dosages := true", label);
+			throw InvalidInputException("%s: genotypes := '%s' is incompatible with dosages := true", fn, label);
 		}
 	}
 	const bool per_sample_names =
 	    bind_data->genotype_mode == GenotypeMode::COLUMNS || bind_data->genotype_mode == GenotypeMode::STRUCT;
 	if (per_sample_names) {
 		if (!c.has_sample_info) {
-			throw InvalidInputException("read_pgen: genotypes := '%s' requires a .psam/.fam file for sample IDs "
-			                            "(no companion file found)",
+			throw InvalidInputException("%s: genotypes := '%s' requires a .psam/.fam file for sample IDs "
+			                            "(no companion file found)", fn,
 			                            bind_data->genotype_mode == GenotypeMode::COLUMNS ? "columns" : "struct");
 		}
 		// the subset is a mask, so fields come out in ascending file order whatever order was asked for
@@ -194,11 +171,12 @@ static unique_ptr<FunctionData> PgenBind(ClientContext &context, TableFunctionBi
 	return std::move(bind_data);
 }
 
-static unique_ptr<GlobalTableFunctionState> PgenInitGlobal(ClientContext &context, TableFunctionInitInput &input) {
+unique_ptr<GlobalTableFunctionState> PgenInitGlobal(ClientContext &context, TableFunctionInitInput &input) {
 	auto &bind_data = input.bind_data->Cast<PgenBindData>();
 	auto state = make_uniq<PgenGlobalState>();
-	state->scan.start_variant_idx = 0;
-	state->scan.end_variant_idx = bind_data.c.raw_variant_ct;
+	state->scan.start_variant_idx = bind_data.c.RangeStart(); // the whole file unless read_pfile passed a region
+	state->scan.end_variant_idx = bind_data.c.RangeEnd();
+	state->scan.next_variant_idx.store(state->scan.start_variant_idx);
 	state->scan.effective_sample_ct = bind_data.c.effective_sample_ct;
 	state->column_ids = input.column_ids;
 	state->max_threads_config = GetPlinkingMaxThreads(context);
@@ -217,18 +195,19 @@ static unique_ptr<GlobalTableFunctionState> PgenInitGlobal(ClientContext &contex
 	                     (state->need_genotypes && IsAggregateGenotypeMode(bind_data.genotype_mode));
 	state->scan.want_counts = state->need_counts;
 	if (state->need_genotypes || state->need_counts) {
-		state->scan.dataset = DeviceDataset::Acquire(bind_data.c.pgen_path, "read_pgen");
+		state->scan.dataset = DeviceDataset::Acquire(bind_data.c.pgen_path, bind_data.func);
 		if (bind_data.c.has_sample_subset) {
 			state->scan.subset =
-			    make_uniq<DeviceSubset>(*state->scan.dataset, bind_data.c.sample_subset->sample_include, "read_pgen");
+			    make_uniq<DeviceSubset>(*state->scan.dataset, bind_data.c.sample_subset->sample_include, bind_data.func);
 		}
 	}
 	return std::move(state);
 }
 
-static unique_ptr<LocalTableFunctionState> PgenInitLocal(ExecutionContext &, TableFunctionInitInput &input,
-                                                         GlobalTableFunctionState *global_state) {
+unique_ptr<LocalTableFunctionState> PgenInitLocal(ExecutionContext &, TableFunctionInitInput &input,
+                                                  GlobalTableFunctionState *global_state) {
 	auto &bind_data = input.bind_data->Cast<PgenBindData>();
+	const char *fn = bind_data.func.c_str();
 	auto &gstate = global_state->Cast<PgenGlobalState>();
 	auto state = make_uniq<PgenLocalState>();
 	const bool phased_out = bind_data.include_phased && bind_data.genotype_mode != GenotypeMode::COLUMNS;
@@ -237,7 +216,7 @@ static unique_ptr<LocalTableFunctionState> PgenInitLocal(ExecutionContext &, Tab
 		int rc = pgh_reader_create(gstate.scan.dataset->handle, gstate.scan.subset ? gstate.scan.subset->handle : nullptr,
 		                           &state->reader, errbuf);
 		if (rc != PGH_OK) {
-			throw IOException("read_pgen: thread init failed: %s", string(errbuf));
+			throw IOException("%s: thread init failed: %s", fn, string(errbuf));
 		}
 		uint32_t n = bind_data.output_sample_ct;
 		state->dosage_doubles.resize(n);
@@ -275,8 +254,9 @@ Vector &GenotypeChild(const PgenBindData &bind_data, Vector &vec) {
 
 } // namespace
 
-static void PgenScan(ClientContext &, TableFunctionInput &data_p, DataChunk &output) {
+void PgenScan(ClientContext &, TableFunctionInput &data_p, DataChunk &output) {
 	auto &bind_data = data_p.bind_data->Cast<PgenBindData>();
+	const char *fn = bind_data.func.c_str();
 	auto &gstate = data_p.global_state->Cast<PgenGlobalState>();
 	auto &lstate = data_p.local_state->Cast<PgenLocalState>();
 	auto &column_ids = gstate.column_ids;
@@ -299,7 +279,7 @@ static void PgenScan(ClientContext &, TableFunctionInput &data_p, DataChunk &out
 		    (lstate.scan.BatchDrained() || (!listed && vidx + 1 - plan.front().vidx >= kUnpackSpan))) {
 			break; // the next Scan call continues
 		}
-		if (!lstate.scan.Next(gstate.scan, "read_pgen", no_strata, vidx)) {
+		if (!lstate.scan.Next(gstate.scan, bind_data.func, no_strata, vidx)) {
 			break;
 		}
 		bool all_pass = true;
@@ -339,7 +319,7 @@ static void PgenScan(ClientContext &, TableFunctionInput &data_p, DataChunk &out
 			rc = pgh_unpack_range(ds, ss, span_begin, span_end, lstate.bytes.data(), lstate.validity.data(), 0, errbuf);
 		}
 		if (rc != PGH_OK) {
-			throw IOException("read_pgen: PgrGet failed for variants [%u, %u): %s", span_begin, span_end,
+			throw IOException("%s: PgrGet failed for variants [%u, %u): %s", fn, span_begin, span_end,
 			                  string(errbuf));
 		}
 	}
@@ -395,12 +375,12 @@ static void PgenScan(ClientContext &, TableFunctionInput &data_p, DataChunk &out
 		if (per_variant_decode) {
 			if (bind_data.include_dosages) {
 				if (pgh_get_dosage_f64(lstate.reader, v, lstate.dosage_doubles.data()) != PGH_OK) {
-					throw IOException("read_pgen: PgrGetD failed for variant %u: %s", v,
+					throw IOException("%s: PgrGetD failed for variant %u: %s", fn, v,
 					                  string(pgh_reader_error(lstate.reader)));
 				}
 			} else if (pgh_get_phased(lstate.reader, v, lstate.genovec.data(), lstate.phasepresent.data(),
 			                          lstate.phaseinfo.data()) != PGH_OK) {
-				throw IOException("read_pgen: PgrGetP failed for variant %u: %s", v,
+				throw IOException("%s: PgrGetP failed for variant %u: %s", fn, v,
 				                  string(pgh_reader_error(lstate.reader)));
 			}
 		}

@@ -1,0 +1,63 @@
+// pgen_reader.hpp -- the variant-oriented genotype scan, shared by read_pgen and by
+// read_pfile's orient := 'variant' (pfile_reader.cpp), which differ only in how the three
+// file paths are found and in the name that error messages carry.
+#pragma once
+
+#include "variant_scan.hpp"
+
+namespace duckdb {
+
+static constexpr idx_t COL_GENOTYPES = 5;
+static constexpr uint32_t kUnpackSpan = 2048; // variants unpacked per launch (one output vector)
+
+struct PgenBindData : public TableFunctionData {
+	string func = "read_pgen"; // name in error messages
+	PgenBindCommon c;
+	bool include_dosages = false;
+	bool include_phased = false;
+	GenotypeMode genotype_mode = GenotypeMode::ARRAY;
+	CountFilter count_filter;
+	GenotypeRangeFilter genotype_filter;
+	uint32_t output_sample_ct = 0;
+	bool has_variant_list = false;
+	vector<uint32_t> variant_indices; // `variants :=`, caller order
+	vector<string> genotype_column_names; // columns / struct modes: IIDs in ascending file order
+};
+
+struct PgenGlobalState : public GlobalTableFunctionState {
+	VariantScanGlobal scan;
+	vector<column_t> column_ids;
+	bool need_genotypes = false;
+	bool need_counts = false;
+	uint32_t max_threads_config = 0;
+	idx_t MaxThreads() const override {
+		uint32_t total = scan.has_variant_list ? static_cast<uint32_t>(scan.variant_list.size())
+		                                       : scan.end_variant_idx - scan.start_variant_idx;
+		return ApplyMaxThreadsCap(total / 1000 + 1, max_threads_config);
+	}
+};
+
+struct PgenLocalState : public LocalTableFunctionState {
+	VariantScanLocal scan;
+	pgh_reader *reader = nullptr;
+	vector<int8_t> bytes;       // unpacked span [rows][n_out]
+	vector<uint64_t> validity;  // [rows][ceil(n_out/64)]
+	vector<double> dosage_doubles;
+	vector<uint64_t> genovec, phasepresent, phaseinfo;
+	~PgenLocalState() override {
+		if (reader) {
+			pgh_reader_destroy(reader);
+		}
+	}
+};
+
+//! `func`: "read_pgen" or "read_pfile"; with_region: accept `region :=` (read_pfile only).
+unique_ptr<FunctionData> PgenBindNamed(ClientContext &context, TableFunctionBindInput &input,
+                                       vector<LogicalType> &return_types, vector<string> &names, const string &func,
+                                       bool with_region);
+unique_ptr<GlobalTableFunctionState> PgenInitGlobal(ClientContext &context, TableFunctionInitInput &input);
+unique_ptr<LocalTableFunctionState> PgenInitLocal(ExecutionContext &context, TableFunctionInitInput &input,
+                                                  GlobalTableFunctionState *global_state);
+void PgenScan(ClientContext &context, TableFunctionInput &data_p, DataChunk &output);
+
+} // namespace duckdb

@@ -272,6 +272,7 @@ SampleInfo LoadSampleMetadata(ClientContext &, const string &path) {
 		if (iid_f == kNone) {
 			throw InvalidInputException("'%s' missing required IID column", path);
 		}
+		info.column_names = fields;
 		li++;
 	} else {
 		// .fam: FID IID PAT MAT SEX PHENO1
@@ -279,6 +280,7 @@ SampleInfo LoadSampleMetadata(ClientContext &, const string &path) {
 		fid_f = 0;
 		iid_f = 1;
 		sex_f = 4;
+		info.column_names = {"FID", "IID", "PAT", "MAT", "SEX", "PHENO1"};
 	}
 	for (; li < lines.size(); li++) {
 		if (lines[li].empty()) {
@@ -290,6 +292,7 @@ SampleInfo LoadSampleMetadata(ClientContext &, const string &path) {
 			                            static_cast<unsigned long long>(li + 1));
 		}
 		info.iids.push_back(f[iid_f]);
+		info.rows.push_back(f);
 		if (fid_f != kNone) {
 			info.fids.push_back(fid_f < f.size() ? f[fid_f] : "");
 		}

@@ -48,6 +48,10 @@ struct SampleInfo {
 	vector<string> fids;   // empty when the file has no FID column
 	vector<uint8_t> sexes; // 1 male, 2 female, 0 unknown; empty when no SEX column
 	idx_t sample_ct = 0;
+	// the whole table, for read_pfile's sample-oriented rows (src/pfile_reader.cpp:241-330):
+	// header names without the '#' (.fam: FID IID PAT MAT SEX PHENO1) and every field as text
+	vector<string> column_names;
+	vector<vector<string>> rows;
 	std::unordered_map<string, idx_t> iid_to_idx;
 	void EnsureIidMap(const string &source_label = "sample file");
 };

@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     "pgh_close", "pgh_subset_create", "pgh_subset_size", "pgh_subset_destroy", "pgh_counts_range",
     "pgh_counts_range_dev", "pgh_freq_from_counts_dev", "pgh_fused_tally_dev", "pgh_missing_per_sample", "pgh_missing_per_sample_dev", "pgh_unpack_range",
     "pgh_unpack_range_dev", "pgh_score", "pgh_score_dev", "pgh_score_plan_create", "pgh_score_run_dev",
-    "pgh_score_plan_destroy", "pgh_pca", "pgh_pca_sharded", "pgh_ld_pairs", "pgh_reader_create", "pgh_reader_destroy",
+    "pgh_score_plan_destroy", "pgh_pca", "pgh_pca_sharded", "pgh_ld_pairs", "pgh_sample_counts", "pgh_reader_create", "pgh_reader_destroy",
     "pgh_get_2bit", "pgh_get_counts", "pgh_get_missingness", "pgh_get_int8", "pgh_get_dosage_f64", "pgh_get_phased",
     "pgh_reader_error", "pgh_hwe_lnp", "pgh_hwe_xchr_lnp", "pgh_hwe_lnp_batch", "pgh_hwe_lnp_batch_dev",
 ]
@@ -98,6 +98,7 @@ def _load():
         "pgh_score_plan_destroy": (None, [vp]),
         "pgh_pca": (C.c_int, [vp, vp, u32, vp, vp, vp, u32, vp, vp, vp, cp]),
         "pgh_ld_pairs": (C.c_int, [vp, vp, u32, vp, vp, vp, cp]),
+        "pgh_sample_counts": (C.c_int, [vp, vp, u32, u32, vp, vp, cp]),
         "pgh_pca_sharded": (C.c_int, [vp, vp, u32, vp, vp, vp, C.c_uint64, u32, vp, ALLREDUCE_FN, vp, vp, vp, cp]),
         "pgh_reader_create": (C.c_int, [vp, vp, C.POINTER(vp), cp]),
         "pgh_reader_destroy": (None, [vp]),
@@ -397,6 +398,21 @@ class Dataset:
         _check(_lib.pgh_pca(self._h, subset._h if subset else None, len(vidx), _ptr(vidx), _ptr(center),
                             _ptr(inv_stdev), n_pcs, _ptr(g1), _ptr(ev), _ptr(vecs), eb), eb)
         return ev, vecs
+
+    def sample_counts(self, v_begin: int | None = None, v_end: int | None = None, vidx=None,
+                      subset: Subset | None = None) -> np.ndarray:
+        """uint32[n_out][4] = {hom_ref, het, hom_alt, missing} per sample over a variant range or list."""
+        n_out = subset.size if subset else self.n_samples
+        out = np.zeros((n_out, 4), dtype=np.uint32)
+        eb = _errbuf()
+        if vidx is not None:
+            v = np.ascontiguousarray(vidx, dtype=np.uint32)
+            _check(_lib.pgh_sample_counts(self._h, subset._h if subset else None, 0, len(v), _ptr(v), _ptr(out), eb), eb)
+        else:
+            v0 = self.v_begin if v_begin is None else v_begin
+            v1 = self.v_end if v_end is None else v_end
+            _check(_lib.pgh_sample_counts(self._h, subset._h if subset else None, v0, v1 - v0, None, _ptr(out), eb), eb)
+        return out
 
     def ld_pairs(self, vidx_a, vidx_b, subset: Subset | None = None) -> np.ndarray:
         """uint32[n_pairs][6] = {n, sum_a, sum_b, sum_ab, sum_a2, sum_b2} per pair."""

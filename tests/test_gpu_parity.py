@@ -407,3 +407,20 @@ def test_ld_pair_sums_match_oracle(gpu_lib, oracle, n):
         got = ds.ld_pairs(a, b, subset=ss)
         want = np.stack([pg.ld_sums(x, y, include=inc) for x, y in zip(a, b)])
         assert np.array_equal(got.astype(np.uint64), want)
+
+
+@pytest.mark.parametrize("n", [5, 1000, 70001])
+def test_sample_counts_match_oracle(gpu_lib, oracle, n):
+    m = 300
+    host = np.stack([gpu_lib.synth_record_host(v, n, SEED + 9, 0.06) for v in range(m)])
+    ds = gpu_lib.Dataset.from_host_rows(host, n)
+    pg = oracle.Pgen(mem=mem_pgen(host, n))
+    rng = np.random.default_rng(n)
+    assert np.array_equal(ds.sample_counts(), pg.sample_counts())
+    assert np.array_equal(ds.sample_counts(40, 40), pg.sample_counts(vidx=[]))
+    pick = np.sort(rng.choice(m, size=77, replace=False))
+    mask = rng.random(n) < 0.4
+    mask[0] = True
+    assert np.array_equal(ds.sample_counts(vidx=pick, subset=ds.subset(mask)),
+                          pg.sample_counts(vidx=[int(v) for v in pick], include=mask.astype(np.uint8)))
+    assert np.array_equal(ds.sample_counts(10, 200), pg.sample_counts(vidx=range(10, 200)))

@@ -274,3 +274,15 @@ def test_ld_known_answers(oracle):
     big = oracle.Pgen(data_path("large_example.pgen"))
     r2s = {round(oracle.ld_stats(big.ld_sums(a, b))[0], 12) for a in range(10) for b in range(a + 1, 10)}
     assert r2s == {1.0}
+
+
+def test_sample_counts_known_answers(oracle):
+    """read_pfile_genotypes_counts.test:50-63, read_pfile_sample_counts_sparse.test:10-14."""
+    ka = KA["read_pfile"]
+    pg = oracle.Pgen(data_path("pgen_example.pgen"))
+    got = pg.sample_counts()
+    assert [list(map(int, r)) for r in got] == [ka["sample_counts"][f"SAMPLE{i}"] for i in range(1, 5)]
+    rare = oracle.Pgen(data_path("rare_small.pgen"))
+    tot = rare.sample_counts().sum(axis=0, dtype=np.int64)
+    t = ka["rare_small_totals"]
+    assert [int(x) for x in tot] == [t["hom_ref"], t["het"], t["hom_alt"], t["missing"]]

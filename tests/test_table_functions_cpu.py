@@ -16,7 +16,7 @@ W = [1.0, 0.5, -0.5, 2.0]
 
 def test_registered_functions():
     assert sorted(F.functions()) == ["plink_freq", "plink_hardy", "plink_ld", "plink_missing", "plink_pca",
-                                     "plink_score", "read_pgen"]
+                                     "plink_score", "read_pfile", "read_pgen"]
 
 
 def err(fn, *args, exc=F.InvalidInputException, **kw):
@@ -196,3 +196,30 @@ def test_plink_ld_bind_errors():
     assert len(F.query("plink_ld", EX, region="99:1-100", r2_threshold=0.0)) == 0
     r = F.query("plink_ld", EX, region="99:1-100")
     assert r.all_names == ["CHROM_A", "POS_A", "ID_A", "CHROM_B", "POS_B", "ID_B", "R2", "D_PRIME", "OBS_CT"]
+
+
+def test_read_pfile_bind():
+    PFX = data_path("pgen_example")
+    r = F.query("read_pfile", PFX, columns=["ID", "POS"])
+    assert sorted(r.rows) == [("rs1", 10000), ("rs2", 20000), ("rs3", 30000), ("rs4", 15000)]
+    assert r.all_names == ["CHROM", "POS", "ID", "REF", "ALT", "genotypes"]
+    # explicit paths instead of a prefix; a full .pgen path as the prefix
+    assert len(F.query("read_pfile", EX, columns=["ID"])) == 4
+    assert len(F.query("read_pfile", None, pgen=EX, columns=["ID"])) == 4
+    assert F.query("read_pfile", PFX, region="1:10000-20000", columns=["ID"]).column("ID") == ["rs1", "rs2"]
+    assert F.query("read_pfile", PFX, region="1:10000-20000", variants=["rs2", "rs4"], columns=["ID"]).column("ID") == ["rs2"]
+    s = F.query("read_pfile", PFX, orient="sample", genotypes="counts", columns=["IID", "SEX"])
+    assert s.all_names == ["IID", "SEX", "genotypes"]
+    assert sorted(s.rows) == [(f"SAMPLE{i}", None) for i in range(1, 5)]
+    assert F.query("read_pfile", PFX, orient="sample", genotypes="stats", columns=["IID"]).all_names[-1] == "genotypes"
+    assert "cannot find .pgen file for prefix" in err("read_pfile", data_path("no_such_prefix"))
+    assert "no .pgen file path provided" in err("read_pfile", None)
+    assert "invalid orient value" in err("read_pfile", PFX, orient="diagonal")
+    assert "not compatible with orient := 'genotype'" in err("read_pfile", PFX, orient="genotype", genotypes="counts")
+    assert "incompatible with phased" in err("read_pfile", PFX, orient="sample", genotypes="counts", phased=True)
+    assert "incompatible with dosages" in err("read_pfile", PFX, orient="sample", genotypes="stats", dosages=True)
+    assert "dosages and phased cannot both be true" in err("read_pfile", PFX, dosages=True, phased=True)
+    assert "read_pfile: invalid genotypes value" in err("read_pfile", PFX, genotypes="matrix")
+    assert "not available in this build" in err("read_pfile", PFX, orient="sample")
+    assert "not available in this build" in err("read_pfile", [PFX, PFX])
+    assert "Invalid named parameter" in err("read_pgen", EX, region="1:1-2", exc=F.BinderException)

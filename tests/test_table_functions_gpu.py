@@ -540,3 +540,74 @@ def test_ld_windowed_matches_oracle_across_threads(oracle):
     for a, b, r2, n in r.rows[:200]:
         e_r2, _, e_n = oracle.ld_stats(pg.ld_sums(idx[a], idx[b], include=mask.astype(np.uint8)))
         assert (r2, n) == (e_r2, e_n)
+
+
+# ---- read_pfile (read_pfile_genotypes_counts.test, read_pfile_sample_counts_sparse.test) ----------
+
+def test_read_pfile_counts_known_answers():
+    ka = KA["read_pfile"]
+    PFX = data_path("pgen_example")
+    cts = lambda g: [g["hom_ref"], g["het"], g["hom_alt"], g["missing"]]
+    r = F.query("read_pfile", PFX, genotypes="counts", columns=["ID", "genotypes"])
+    assert r.types[1] == "STRUCT(hom_ref UINTEGER, het UINTEGER, hom_alt UINTEGER, missing UINTEGER)"
+    assert {vid: cts(g) for vid, g in r.rows} == ka["variant_counts"]
+    r = F.query("read_pfile", PFX, genotypes="counts", samples=["SAMPLE1", "SAMPLE3"], columns=["ID", "genotypes"])
+    assert {vid: cts(g) for vid, g in r.rows} == ka["variant_counts_subset_s1_s3"]
+    r = F.query("read_pfile", PFX, orient="sample", genotypes="counts", columns=["IID", "genotypes"])
+    assert {iid: cts(g) for iid, g in r.rows} == ka["sample_counts"]
+    v = F.query("read_pfile", PFX, genotypes="counts", columns=["genotypes"])
+    assert sum(g["het"] + g["hom_alt"] for (g,) in v.rows) == sum(g["het"] + g["hom_alt"] for _, g in r.rows)
+    r = F.query("read_pfile", PFX, genotypes="counts", af_range={"max": 0.4}, columns=["ID", "genotypes"])
+    assert [(vid, cts(g)) for vid, g in r.rows] == [("rs4", [2, 1, 1, 0])]
+    r = F.query("read_pfile", PFX, genotypes="counts", variants=["rs1", "rs2"], columns=["ID", "genotypes"])
+    assert {vid: cts(g) for vid, g in r.rows} == {k: ka["variant_counts"][k] for k in ("rs1", "rs2")}
+    # sample orient under the same filters: per-sample tallies over the surviving variants only
+    r = F.query("read_pfile", PFX, orient="sample", genotypes="counts", af_range={"max": 0.4}, columns=["IID", "genotypes"])
+    assert {iid: cts(g) for iid, g in r.rows} == {"SAMPLE1": [1, 0, 0, 0], "SAMPLE2": [1, 0, 0, 0],
+                                                  "SAMPLE3": [0, 1, 0, 0], "SAMPLE4": [0, 0, 1, 0]}
+    r = F.query("read_pfile", PFX, orient="sample", genotypes="counts", samples=[3, 0], region="1:10000-20000",
+                columns=["IID", "genotypes"])
+    assert [(iid, cts(g)) for iid, g in r.sorted("IID")] == [("SAMPLE1", [1, 1, 0, 0]), ("SAMPLE4", [0, 0, 1, 1])]
+
+
+def test_read_pfile_sample_counts_on_rare_small(oracle):
+    ka = KA["read_pfile"]
+    PFX = data_path("rare_small")
+    for threads in (1, 4):
+        r = F.query("read_pfile", PFX, orient="sample", genotypes="counts", columns=["IID", "genotypes"], threads=threads)
+        assert len(r) == 256
+        tot = {k: sum(g[k] for _, g in r.rows) for k in ("hom_ref", "het", "hom_alt", "missing")}
+        assert tot == ka["rare_small_totals"]
+    pg = oracle.Pgen(PFX + ".pgen")
+    want = pg.sample_counts()
+    names = oracle.load_psam(PFX + ".psam")["iid"]
+    got = dict(r.rows)
+    for k, iid in enumerate(names):
+        g = got[iid]
+        assert [g["hom_ref"], g["het"], g["hom_alt"], g["missing"]] == [int(x) for x in want[k]]
+    s = F.query("read_pfile", PFX, orient="sample", genotypes="stats", columns=["genotypes"])
+    st = ka["rare_small_stats"]
+    n = sum(g["n"] for (g,) in s.rows)
+    assert n == st["sum_n"] and sum(g["carrier_count"] for (g,) in s.rows) == st["sum_carrier_count"]
+    assert round(sum(g["het"] for (g,) in s.rows) / n, 6) == st["het_over_n_6dp"]
+    one = s.rows[0][0]
+    assert one["af"] == pytest.approx((one["het"] + 2 * one["hom_alt"]) / (2 * one["n"]))
+    r = F.query("read_pfile", PFX, orient="sample", genotypes="counts", include_genotypes=["het", "hom_alt"], columns=["IID"])
+    assert len(r) == ka["rare_small_include_het_homalt_rows"]
+    carriers = int(((want[:, 1] + want[:, 2]) > 0).sum())
+    assert carriers == 256
+    r = F.query("read_pfile", PFX, orient="sample", genotypes="counts", include_genotypes=["hom_alt"], columns=["IID"])
+    assert len(r) == int((want[:, 2] > 0).sum())
+    e = ka["rare_small_empty_region"]
+    r = F.query("read_pfile", PFX, orient="sample", genotypes="counts", region="chrZ:1-2", columns=["genotypes"])
+    assert (len(r), sum(g["het"] for (g,) in r.rows), sum(g["hom_ref"] for (g,) in r.rows)) == (e["rows"], e["het"], e["hom_ref"])
+
+
+def test_read_pfile_variant_orient_is_the_read_pgen_scan():
+    exp = [[(None if g == -9 else g) for g in row] for row in KA["pgen_example_genotypes"]["matrix"]]
+    r = F.query("read_pfile", data_path("pgen_example"), columns=["ID", "genotypes"])
+    assert [g for _, g in r.sorted("ID")] == exp
+    r = F.query("read_pfile", data_path("pgen_example"), region="1:20000-30000", genotypes="list", columns=["ID", "genotypes"])
+    assert r.types[1] == "TINYINT[]" and dict(r.rows) == {"rs2": exp[1], "rs3": exp[2]}
+    big = F.query("read_pfile", data_path("large_example"), region="2:1-100000", columns=["CHROM", "genotypes"], threads=3)
+    assert len(big) == 1000 and set(big.column("CHROM")) == {"2"}
