@@ -798,10 +798,25 @@ extern "C" int pgh_synth_write_files(const char *prefix, uint32_t variant_ct, ui
 		}
 	}
 	bool ok = std::fwrite(head.data(), 1, head.size(), f) == head.size();
-	std::vector<uint8_t> rec(rb);
-	for (uint32_t v = 0; ok && v < variant_ct; v++) {
-		pgh_synth_record_host(v, sample_ct, seed, missing_rate, rec.data());
-		ok = std::fwrite(rec.data(), 1, rb, f) == rb;
+	// records are generated on the host (no GPU needed to make a fixture), a block of rows at a
+	// time over a few threads
+	const uint32_t workers = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+	const uint32_t block_rows = static_cast<uint32_t>(std::max<uint64_t>(workers, (32ull << 20) / rb));
+	std::vector<uint8_t> block(static_cast<size_t>(block_rows) * rb);
+	for (uint32_t v0 = 0; ok && v0 < variant_ct; v0 += block_rows) {
+		const uint32_t n = std::min(block_rows, variant_ct - v0);
+		std::vector<std::thread> pool;
+		for (uint32_t t = 0; t < workers; t++) {
+			pool.emplace_back([&, t] {
+				for (uint32_t i = t; i < n; i += workers) {
+					pgh_synth_record_host(v0 + i, sample_ct, seed, missing_rate, block.data() + static_cast<size_t>(i) * rb);
+				}
+			});
+		}
+		for (auto &th : pool) {
+			th.join();
+		}
+		ok = std::fwrite(block.data(), 1, static_cast<size_t>(n) * rb, f) == static_cast<size_t>(n) * rb;
 	}
 	ok = (std::fclose(f) == 0) && ok;
 	if (!ok) {

@@ -611,3 +611,70 @@ def test_read_pfile_variant_orient_is_the_read_pgen_scan():
     assert r.types[1] == "TINYINT[]" and dict(r.rows) == {"rs2": exp[1], "rs3": exp[2]}
     big = F.query("read_pfile", data_path("large_example"), region="2:1-100000", columns=["CHROM", "genotypes"], threads=3)
     assert len(big) == 1000 and set(big.column("CHROM")) == {"2"}
+
+
+# ---- every function over a file that spans several device batches, against the C ABI ---------------
+
+@pytest.fixture(scope="module")
+def midsize(tmp_path_factory, gpu_lib):
+    """40,000 variants x 3,001 samples (3 device batches of 16,384; ragged row tail), 22 chromosomes."""
+    prefix = str(tmp_path_factory.mktemp("midsize") / "mid")
+    gpu_lib.synth_write_files(prefix, 40_000, 3001, 20260807, 0.03)
+    ds = gpu_lib.Dataset.open(prefix + ".pgen")
+    return prefix, ds
+
+
+@pytest.mark.parametrize("threads", [1, 6])
+def test_shells_agree_with_the_library_across_device_batches(midsize, gpu_lib, threads):
+    prefix, ds = midsize
+    path = prefix + ".pgen"
+    m, n = 40_000, 3001
+    counts = ds.counts_range().astype(np.int64)
+    pos_key = lambda chrom, pos: (int(chrom) - 1) * ((m + 21) // 22) + pos // 100 - 1  # variant index from the pvar text
+    r = F.query("plink_freq", path, counts=True, threads=threads,
+                columns=["CHROM", "POS", "HOM_REF_CT", "HET_CT", "HOM_ALT_CT", "MISSING_CT", "OBS_CT", "ALT_FREQ"])
+    assert len(r) == m
+    got = np.zeros((m, 4), dtype=np.int64)
+    seen = np.zeros(m, dtype=bool)
+    for chrom, pos, a, b, c, d, obs, af in r.rows:
+        v = pos_key(chrom, pos)
+        got[v] = (a, b, c, d)
+        seen[v] = True
+        assert obs == 2 * (a + b + c) and af == (b + 2 * c) / (2 * (a + b + c))
+    assert seen.all() and np.array_equal(got, counts)
+    r = F.query("plink_missing", path, threads=threads, columns=["CHROM", "POS", "MISSING_CT", "OBS_CT"])
+    assert len(r) == m and all(counts[pos_key(c, p), 3] == mc and oc == n - mc for c, p, mc, oc in r.rows)
+    r = F.query("plink_missing", path, mode="sample", threads=threads, columns=["IID", "MISSING_CT", "OBS_CT"])
+    miss = ds.missing_per_sample()
+    assert len(r) == n and all(miss[int(iid[1:])] == mc and oc == m - mc for iid, mc, oc in r.rows)
+    r = F.query("plink_hardy", path, threads=threads, region="7:1-100000000",
+                columns=["POS", "HOM_REF_CT", "HET_CT", "HOM_ALT_CT", "P_HWE"])
+    per = (m + 21) // 22
+    assert len(r) == per
+    lnp = gpu_lib.hwe_lnp_batch(ds.counts_range(6 * per, 7 * per), False)
+    for pos, a, b, c, p in r.rows:
+        i = pos // 100 - 1
+        assert (a, b, c) == tuple(counts[6 * per + i, :3]) and p == pytest.approx(min(1.0, np.exp(lnp[i])), rel=1e-9)
+    r = F.query("read_pgen", path, genotypes="counts", ac_range={"min": 3000}, threads=threads, columns=["POS", "CHROM", "genotypes"])
+    keep = np.flatnonzero(counts[:, 1] + 2 * counts[:, 2] >= 3000)
+    assert len(r) == len(keep)
+    assert sorted(pos_key(c, p) for p, c, _ in r.rows) == list(keep)
+    r = F.query("read_pfile", prefix, orient="sample", genotypes="counts", threads=threads, columns=["IID", "genotypes"])
+    sc = ds.sample_counts()
+    assert all([g["hom_ref"], g["het"], g["hom_alt"], g["missing"]] == [int(x) for x in sc[int(iid[1:])]] for iid, g in r.rows)
+    w = np.linspace(-1.0, 1.0, m)
+    r = F.query("plink_score", path, weights=[float(x) for x in w], threads=threads, columns=["IID", "ALLELE_CT", "SCORE_SUM"])
+    s, d, ac = ds.score(np.arange(m), w)
+    for iid, a, ssum in r.rows[::37]:
+        k = int(iid[1:])
+        assert a == ac[k] and ssum == pytest.approx(s[k, 0], rel=1e-9, abs=1e-9)
+    r = F.query("plink_ld", path, region="3:100-3000", window_kb=1, r2_threshold=0.0, threads=threads,
+                columns=["POS_A", "POS_B", "OBS_CT"])
+    base = 2 * per
+    pairs = [(base + a, base + b) for a in range(30) for b in range(a + 1, min(30, a + 11))]
+    sums = ds.ld_pairs([p[0] for p in pairs], [p[1] for p in pairs])
+    got_n = {(pa // 100 - 1 + base, pb // 100 - 1 + base): n_obs for pa, pb, n_obs in r.rows}
+    valid = {p: int(s6[0]) for p, s6 in zip(pairs, sums) if s6[0] >= 2}
+    # rows exist only for pairs with a defined r2 (neither side monomorphic among the shared calls)
+    assert set(got_n) <= set(valid) and len(got_n) >= 0.9 * len(valid)
+    assert all(valid[p] == nn for p, nn in got_n.items())
