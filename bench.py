@@ -127,7 +127,9 @@ def main():
     torch.cuda.set_device(local_rank)
     L.set_device(local_rank)
     dist = None
-    if world > 1:
+    # under torch.distributed.run the process group comes up even for one rank, so the
+    # collective path of the N-rank run is the path that runs (and is rehearsed on one GPU)
+    if world > 1 or "RANK" in os.environ:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
