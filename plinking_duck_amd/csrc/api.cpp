@@ -1,5 +1,5 @@
 // api.cpp -- the C ABI of libpgenhip (include/pgenhip.h): handles, HBM residency,
-// launches.  Host code only; the kernels live in kernels.hip.
+// launches.  Host code only; the kernels live in the *.hip files next to it.
 #include "../../include/pgenhip.h"
 
 #include "hwe_core.hpp"

@@ -1,4 +1,4 @@
-// kernels.hpp -- launch wrappers of the gfx950 kernels (definitions in kernels.hip).
+// kernels.hpp -- launch wrappers of the gfx950 kernels (definitions in tally.hip, unpack.hip, score.hip, pca.hip).
 // All pointers are device pointers unless named h_*.  Every wrapper only
 // enqueues work on `stream` and returns the hipError_t of the launch.
 #pragma once

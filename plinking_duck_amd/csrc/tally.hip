@@ -1,0 +1,774 @@
+// tally.hip -- the HBM-bound reductions over the packed rows (gfx950): per-variant genotype-class
+// tallies (PgrGetCounts), per-sample column tallies, the fused row+column pass, the
+// plink_freq / plink_hardy epilogues and the synthetic generator.
+//
+// Data layout: the genotype matrix is variant-major; row v holds ceil(N/4)
+// bytes of packed 2-bit calls (00 hom-ref, 01 het, 10 hom-alt, 11 missing;
+// sample s in bits 2*(s%4) of byte s/4) followed by zero bytes up to `pitch`
+// (a multiple of 16, so every row can be streamed as whole 16-byte lanes and
+// the pad decodes as hom-ref, which every kernel cancels against N).
+//
+// 16 B per lane coalesced loads, v_bcnt_u32_b32 tallies with its free accumulate operand, wave
+// reductions by shuffles, LDS only for the cross-wave step.
+#include "device_utils.hpp"
+#include "kernels.hpp"
+
+#include "hwe_core.hpp"
+#include "synth.hpp"
+
+namespace pgh {
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// synthetic generator
+// ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_synth_fill(uint8_t *rows, uint64_t pitch, uint32_t sample_ct,
+                                                    uint32_t variant_begin, uint32_t variant_ct, uint64_t seed,
+                                                    uint32_t miss_threshold) {
+	const uint32_t dwords = static_cast<uint32_t>(pitch / 4);
+	const uint32_t d = blockIdx.x * 256u + threadIdx.x;
+	if (d >= dwords) {
+		return;
+	}
+	for (uint32_t r = blockIdx.y; r < variant_ct; r += gridDim.y) {
+		const SynthVariant sv = SynthVariantParams(seed, variant_begin + r);
+		uint32_t w = 0;
+		const uint32_t s0 = d * 16u;
+#pragma unroll 4
+		for (uint32_t j = 0; j < 16; j++) {
+			const uint32_t s = s0 + j;
+			if (s < sample_ct) {
+				w |= SynthGenotype(sv, s, miss_threshold) << (2 * j);
+			}
+		}
+		reinterpret_cast<uint32_t *>(rows + static_cast<uint64_t>(r) * pitch)[d] = w;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_sanitize_tail(uint8_t *rows, uint64_t pitch, uint32_t sample_ct,
+                                                       uint32_t variant_ct) {
+	// one thread per (row, pad byte); rows are short on pad so this is tiny
+	const uint32_t record_bytes = (sample_ct + 3) / 4;
+	const uint32_t pad = static_cast<uint32_t>(pitch - record_bytes) + 1; // + the last data byte
+	const uint64_t idx = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x;
+	const uint64_t total = static_cast<uint64_t>(variant_ct) * pad;
+	if (idx >= total) {
+		return;
+	}
+	const uint32_t r = static_cast<uint32_t>(idx / pad);
+	const uint32_t k = static_cast<uint32_t>(idx % pad);
+	uint8_t *row = rows + static_cast<uint64_t>(r) * pitch;
+	if (k == 0) {
+		const uint32_t rem = sample_ct & 3;
+		if (rem) {
+			row[record_bytes - 1] &= static_cast<uint8_t>((1u << (2 * rem)) - 1);
+		}
+	} else {
+		row[record_bytes - 1 + k] = 0;
+	}
+}
+
+// ---------------------------------------------------------------------------
+// genotype-class tally
+// ---------------------------------------------------------------------------
+
+struct Tally {
+	uint32_t lo = 0;   // slots with the low bit set  (het + missing)
+	uint32_t hi = 0;   // slots with the high bit set (hom-alt + missing)
+	uint32_t both = 0; // missing
+};
+
+template <bool MASKED>
+__device__ __forceinline__ void TallyWord(Tally &t, uint32_t w, uint32_t m) {
+	const uint32_t sel = MASKED ? m : kLow;
+	const uint32_t lo = w & sel;
+	const uint32_t hi = (w >> 1) & sel;
+	t.lo += __popc(lo);
+	t.hi += __popc(hi);
+	t.both += __popc(lo & hi);
+}
+
+template <bool MASKED>
+__device__ __forceinline__ void TallyQuad(Tally &t, const uint4 &w, const uint4 &m) {
+	TallyWord<MASKED>(t, w.x, m.x);
+	TallyWord<MASKED>(t, w.y, m.y);
+	TallyWord<MASKED>(t, w.z, m.z);
+	TallyWord<MASKED>(t, w.w, m.w);
+}
+
+// One 256-thread workgroup per variant row: for long rows (>= 4 KiB).
+template <bool MASKED>
+__global__ __launch_bounds__(256) void k_counts_block(const uint8_t *__restrict__ rows, uint64_t pitch,
+                                                      uint32_t chunks, uint32_t v_first,
+                                                      const uint32_t *__restrict__ vlist, uint32_t v_count,
+                                                      const uint4 *__restrict__ mask2, uint32_t n_eff,
+                                                      uint4 *__restrict__ out) {
+	__shared__ uint32_t part[4][3];
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wave = threadIdx.x >> 6;
+	for (uint32_t i = blockIdx.x; i < v_count; i += gridDim.x) {
+		const uint32_t v = vlist ? vlist[i] : v_first + i;
+		const uint4 *row = reinterpret_cast<const uint4 *>(rows + static_cast<uint64_t>(v) * pitch);
+		Tally t;
+		uint32_t c = threadIdx.x;
+		// 4 independent 16-byte loads in flight per lane
+		for (; c + 768u < chunks; c += 1024u) {
+			const uint4 w0 = LoadStream(row + c);
+			const uint4 w1 = LoadStream(row + c + 256u);
+			const uint4 w2 = LoadStream(row + c + 512u);
+			const uint4 w3 = LoadStream(row + c + 768u);
+			uint4 m0 = {0, 0, 0, 0}, m1 = m0, m2 = m0, m3 = m0;
+			if (MASKED) {
+				m0 = mask2[c];
+				m1 = mask2[c + 256u];
+				m2 = mask2[c + 512u];
+				m3 = mask2[c + 768u];
+			}
+			TallyQuad<MASKED>(t, w0, m0);
+			TallyQuad<MASKED>(t, w1, m1);
+			TallyQuad<MASKED>(t, w2, m2);
+			TallyQuad<MASKED>(t, w3, m3);
+		}
+		for (; c < chunks; c += 256u) {
+			const uint4 w = LoadStream(row + c);
+			uint4 m = {0, 0, 0, 0};
+			if (MASKED) {
+				m = mask2[c];
+			}
+			TallyQuad<MASKED>(t, w, m);
+		}
+		const uint32_t lo = WaveSum(t.lo);
+		const uint32_t hi = WaveSum(t.hi);
+		const uint32_t both = WaveSum(t.both);
+		if (lane == 0) {
+			part[wave][0] = lo;
+			part[wave][1] = hi;
+			part[wave][2] = both;
+		}
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			const uint32_t l = part[0][0] + part[1][0] + part[2][0] + part[3][0];
+			const uint32_t h = part[0][1] + part[1][1] + part[2][1] + part[3][1];
+			const uint32_t b = part[0][2] + part[1][2] + part[2][2] + part[3][2];
+			uint4 r;
+			r.y = l - b;                 // het
+			r.z = h - b;                 // hom-alt
+			r.w = b;                     // missing
+			r.x = n_eff - r.y - r.z - b; // hom-ref (zero pad cancels here)
+			out[i] = r;
+		}
+		__syncthreads();
+	}
+}
+
+// One wave per variant row: short rows.  4 rows per 256-thread workgroup.
+template <bool MASKED>
+__global__ __launch_bounds__(256) void k_counts_wave(const uint8_t *__restrict__ rows, uint64_t pitch,
+                                                     uint32_t chunks, uint32_t v_first,
+                                                     const uint32_t *__restrict__ vlist, uint32_t v_count,
+                                                     const uint4 *__restrict__ mask2, uint32_t n_eff,
+                                                     uint4 *__restrict__ out) {
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wave = threadIdx.x >> 6;
+	for (uint32_t i = blockIdx.x * 4u + wave; i < v_count; i += gridDim.x * 4u) {
+		const uint32_t v = vlist ? vlist[i] : v_first + i;
+		const uint4 *row = reinterpret_cast<const uint4 *>(rows + static_cast<uint64_t>(v) * pitch);
+		Tally t;
+		for (uint32_t c = lane; c < chunks; c += 64u) {
+			const uint4 w = LoadStream(row + c);
+			uint4 m = {0, 0, 0, 0};
+			if (MASKED) {
+				m = mask2[c];
+			}
+			TallyQuad<MASKED>(t, w, m);
+		}
+		const uint32_t lo = WaveSum(t.lo);
+		const uint32_t hi = WaveSum(t.hi);
+		const uint32_t both = WaveSum(t.both);
+		if (lane == 0) {
+			uint4 r;
+			r.y = lo - both;
+			r.z = hi - both;
+			r.w = both;
+			r.x = n_eff - r.y - r.z - both;
+			out[i] = r;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------
+// per-sample missing tally (column sums of the missing indicator)
+// ---------------------------------------------------------------------------
+//
+// A lane owns one 16-byte column (64 samples) and walks down a slice of rows.
+// The indicator m = w & (w>>1) & 0x5555.. has one bit per 2-bit slot, so it is
+// added SWAR-style: 2-bit fields (<=3 rows) -> 4-bit fields (<=15) -> 8-bit
+// fields (<=255) -> 64 uint32 registers.  Each slice writes its totals to its
+// own slab row with plain stores; k_sum_slabs adds the slices.  No atomics: a
+// lane's 64 counters sit 256 B apart from its neighbour's, the worst shape for
+// the memory-side atomic units.
+
+struct MissAcc {
+	uint32_t a4[8];
+	uint32_t a8[16];
+	uint32_t a32[64];
+};
+
+__device__ __forceinline__ void Fold2To4(MissAcc &acc, const uint32_t a2[4]) {
+#pragma unroll
+	for (int j = 0; j < 4; j++) {
+		acc.a4[2 * j] += a2[j] & 0x33333333u;
+		acc.a4[2 * j + 1] += (a2[j] >> 2) & 0x33333333u;
+	}
+}
+
+__device__ __forceinline__ void Fold4To8(MissAcc &acc) {
+#pragma unroll
+	for (int j = 0; j < 4; j++) {
+		acc.a8[4 * j + 0] += acc.a4[2 * j] & 0x0f0f0f0fu;
+		acc.a8[4 * j + 1] += (acc.a4[2 * j] >> 4) & 0x0f0f0f0fu;
+		acc.a8[4 * j + 2] += acc.a4[2 * j + 1] & 0x0f0f0f0fu;
+		acc.a8[4 * j + 3] += (acc.a4[2 * j + 1] >> 4) & 0x0f0f0f0fu;
+		acc.a4[2 * j] = 0;
+		acc.a4[2 * j + 1] = 0;
+	}
+}
+
+__device__ __forceinline__ void Fold8To32(MissAcc &acc) {
+	// a8[4j+q] byte b counts sample 16j + 4b + {0,2,1,3}[q]
+#pragma unroll
+	for (int j = 0; j < 4; j++) {
+#pragma unroll
+		for (int q = 0; q < 4; q++) {
+			const uint32_t word = acc.a8[4 * j + q];
+			acc.a8[4 * j + q] = 0;
+			const int within = (q == 0) ? 0 : (q == 1 ? 2 : (q == 2 ? 1 : 3));
+#pragma unroll
+			for (int b = 0; b < 4; b++) {
+				acc.a32[16 * j + 4 * b + within] += (word >> (8 * b)) & 0xffu;
+			}
+		}
+	}
+}
+
+// CLASS: which genotype code is tallied -- 3 missing (plink_missing, plink_score), 1 het,
+// 2 hom-alt (read_pfile's sample-orient counts)
+template <int CLASS>
+__device__ __forceinline__ uint32_t ClassBits(uint32_t w) {
+	if (CLASS == 3) {
+		return w & (w >> 1) & 0x55555555u;
+	}
+	if (CLASS == 1) {
+		return w & ~(w >> 1) & 0x55555555u;
+	}
+	return (w >> 1) & ~w & 0x55555555u;
+}
+
+template <int CLASS>
+__global__ __launch_bounds__(256) void k_missing_cols(const uint8_t *__restrict__ rows, uint64_t pitch,
+                                                      uint32_t chunks, uint32_t v_first,
+                                                      const uint32_t *__restrict__ vlist, uint32_t v_count,
+                                                      uint32_t slice_len, const uint32_t *__restrict__ row_flags,
+                                                      uint32_t *__restrict__ slabs, uint32_t slab_stride) {
+	// row_flags (optional): rows whose low byte is zero are not counted (skipped scored variants)
+	const uint32_t col = blockIdx.x * 256u + threadIdx.x;
+	if (col >= chunks) {
+		return;
+	}
+	const uint32_t i_begin = blockIdx.y * slice_len;
+	const uint32_t i_end = min(i_begin + slice_len, v_count);
+	MissAcc acc;
+#pragma unroll
+	for (int j = 0; j < 8; j++) {
+		acc.a4[j] = 0;
+	}
+#pragma unroll
+	for (int j = 0; j < 16; j++) {
+		acc.a8[j] = 0;
+	}
+#pragma unroll
+	for (int j = 0; j < 64; j++) {
+		acc.a32[j] = 0;
+	}
+	uint32_t n4 = 0, n8 = 0; // rows folded into the 4-bit / 8-bit fields so far
+	uint32_t i = i_begin;
+	auto row_ptr = [&](uint32_t idx) {
+		const uint32_t v = vlist ? vlist[idx] : v_first + idx;
+		return reinterpret_cast<const uint4 *>(rows + static_cast<uint64_t>(v) * pitch) + col;
+	};
+	auto fold = [&](const uint32_t a2[4], uint32_t take) {
+		Fold2To4(acc, a2);
+		n4 += take;
+		if (n4 + 3 > 15) {
+			Fold4To8(acc);
+			n8 += n4;
+			n4 = 0;
+			if (n8 + 15 > 255) {
+				Fold8To32(acc);
+				n8 = 0;
+			}
+		}
+	};
+	// main loop: six independent 16-byte loads in flight per lane
+	while (!row_flags && i + 6 <= i_end) {
+		const uint4 w0 = LoadStream(row_ptr(i));
+		const uint4 w1 = LoadStream(row_ptr(i + 1));
+		const uint4 w2 = LoadStream(row_ptr(i + 2));
+		const uint4 w3 = LoadStream(row_ptr(i + 3));
+		const uint4 w4 = LoadStream(row_ptr(i + 4));
+		const uint4 w5 = LoadStream(row_ptr(i + 5));
+		uint32_t a[4], b[4];
+		a[0] = ClassBits<CLASS>(w0.x) + ClassBits<CLASS>(w1.x) + ClassBits<CLASS>(w2.x);
+		a[1] = ClassBits<CLASS>(w0.y) + ClassBits<CLASS>(w1.y) + ClassBits<CLASS>(w2.y);
+		a[2] = ClassBits<CLASS>(w0.z) + ClassBits<CLASS>(w1.z) + ClassBits<CLASS>(w2.z);
+		a[3] = ClassBits<CLASS>(w0.w) + ClassBits<CLASS>(w1.w) + ClassBits<CLASS>(w2.w);
+		b[0] = ClassBits<CLASS>(w3.x) + ClassBits<CLASS>(w4.x) + ClassBits<CLASS>(w5.x);
+		b[1] = ClassBits<CLASS>(w3.y) + ClassBits<CLASS>(w4.y) + ClassBits<CLASS>(w5.y);
+		b[2] = ClassBits<CLASS>(w3.z) + ClassBits<CLASS>(w4.z) + ClassBits<CLASS>(w5.z);
+		b[3] = ClassBits<CLASS>(w3.w) + ClassBits<CLASS>(w4.w) + ClassBits<CLASS>(w5.w);
+		fold(a, 3);
+		fold(b, 3);
+		i += 6;
+	}
+	while (i < i_end) {
+		if (!row_flags || (row_flags[i] & 0xffu)) { // wave-uniform
+			const uint4 w0 = LoadStream(row_ptr(i));
+			uint32_t a[4] = {ClassBits<CLASS>(w0.x), ClassBits<CLASS>(w0.y), ClassBits<CLASS>(w0.z), ClassBits<CLASS>(w0.w)};
+			fold(a, 1);
+		}
+		i += 1;
+	}
+	Fold4To8(acc);
+	Fold8To32(acc);
+	uint4 *dst = reinterpret_cast<uint4 *>(slabs + static_cast<uint64_t>(blockIdx.y) * slab_stride + col * 64u);
+#pragma unroll
+	for (int k = 0; k < 16; k++) {
+		dst[k] = make_uint4(acc.a32[4 * k], acc.a32[4 * k + 1], acc.a32[4 * k + 2], acc.a32[4 * k + 3]);
+	}
+}
+
+// ---------------------------------------------------------------------------
+// fused pass: per-variant class tallies AND per-sample missing tallies
+// ---------------------------------------------------------------------------
+//
+// plink_freq + plink_hardy + plink_missing (both modes) need the row sums and the
+// column sums of the same matrix; this kernel reads every byte once for both.
+// Ownership is by column (as k_missing_cols): a lane keeps its 64 samples' missing
+// counters in registers.  The row sums cross lanes: each lane's per-row popcounts
+// go through an LDS tile [12 rows][256 lanes] (packed 10-bit fields), a 16-lane
+// shuffle tree finishes the row, and 36 lanes add the workgroup's partials to the
+// per-variant totals with one coalesced atomic instruction per 12 rows.
+constexpr uint32_t kFusedRows = 12;
+
+// column counters of the fused kernel: as MissAcc but the last level is 16-bit
+// (<= 65535 rows per slice), which keeps the kernel under 168 VGPRs
+struct MissAcc16 {
+	uint32_t a4[8];
+	uint32_t a8[16];
+	uint32_t a16[32];
+};
+
+__device__ __forceinline__ void Fold8To16(MissAcc16 &acc) {
+	// a16[2i + e] half h <- byte 2h + e of a8[i]
+#pragma unroll
+	for (int i = 0; i < 16; i++) {
+		acc.a16[2 * i] += acc.a8[i] & 0x00ff00ffu;
+		acc.a16[2 * i + 1] += (acc.a8[i] >> 8) & 0x00ff00ffu;
+		acc.a8[i] = 0;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_fused_tally(const uint8_t *__restrict__ rows, uint64_t pitch,
+                                                     uint32_t chunks, uint32_t v_first, uint32_t v_count,
+                                                     uint32_t slice_len, uint32_t *__restrict__ tallies,
+                                                     uint32_t *__restrict__ slabs, uint32_t slab_stride) {
+	__shared__ uint32_t s_p[kFusedRows][256];
+	__shared__ uint32_t s_res[kFusedRows][3];
+	const uint32_t col = blockIdx.x * 256u + threadIdx.x;
+	const bool live = col < chunks;
+	const uint32_t i_begin = blockIdx.y * slice_len;
+	const uint32_t i_end = min(i_begin + slice_len, v_count);
+	MissAcc16 acc;
+#pragma unroll
+	for (int j = 0; j < 8; j++) {
+		acc.a4[j] = 0;
+	}
+#pragma unroll
+	for (int j = 0; j < 16; j++) {
+		acc.a8[j] = 0;
+	}
+#pragma unroll
+	for (int j = 0; j < 32; j++) {
+		acc.a16[j] = 0;
+	}
+	uint32_t n4 = 0, n8 = 0;
+	auto fold = [&](const uint32_t a2[4], uint32_t take) {
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			acc.a4[2 * j] += a2[j] & 0x33333333u;
+			acc.a4[2 * j + 1] += (a2[j] >> 2) & 0x33333333u;
+		}
+		n4 += take;
+		if (n4 + 3 > 15) {
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				acc.a8[4 * j + 0] += acc.a4[2 * j] & 0x0f0f0f0fu;
+				acc.a8[4 * j + 1] += (acc.a4[2 * j] >> 4) & 0x0f0f0f0fu;
+				acc.a8[4 * j + 2] += acc.a4[2 * j + 1] & 0x0f0f0f0fu;
+				acc.a8[4 * j + 3] += (acc.a4[2 * j + 1] >> 4) & 0x0f0f0f0fu;
+				acc.a4[2 * j] = 0;
+				acc.a4[2 * j + 1] = 0;
+			}
+			n8 += n4;
+			n4 = 0;
+			if (n8 + 15 > 255) {
+				Fold8To16(acc);
+				n8 = 0;
+			}
+		}
+	};
+	// one row: class popcounts packed as lo | hi << 10 | both << 20, missing bits into a2
+	auto one_row = [&](const uint4 &w, uint32_t a2[4]) -> uint32_t {
+		const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+		uint32_t lo_ct = 0, hi_ct = 0, both_ct = 0;
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			const uint32_t lo = ws[j] & kLow;
+			const uint32_t hi = (ws[j] >> 1) & kLow;
+			const uint32_t both = lo & hi;
+			lo_ct += __popc(lo);
+			hi_ct += __popc(hi);
+			both_ct += __popc(both);
+			a2[j] += both;
+		}
+		return lo_ct | (hi_ct << 10) | (both_ct << 20);
+	};
+	const uint4 zero4 = make_uint4(0, 0, 0, 0);
+	auto load_row = [&](uint32_t idx) {
+		return live ? LoadStream(reinterpret_cast<const uint4 *>(rows + static_cast<uint64_t>(v_first + idx) * pitch) +
+		                         col)
+		            : zero4;
+	};
+	for (uint32_t i = i_begin; i < i_end; i += kFusedRows) {
+		const uint32_t nb = min(kFusedRows, i_end - i);
+		if (nb == kFusedRows) {
+#pragma unroll
+			for (uint32_t h = 0; h < kFusedRows; h += 6) {
+				const uint4 w0 = load_row(i + h), w1 = load_row(i + h + 1), w2 = load_row(i + h + 2);
+				const uint4 w3 = load_row(i + h + 3), w4 = load_row(i + h + 4), w5 = load_row(i + h + 5);
+				uint32_t a[4] = {0, 0, 0, 0};
+				s_p[h + 0][threadIdx.x] = one_row(w0, a);
+				s_p[h + 1][threadIdx.x] = one_row(w1, a);
+				s_p[h + 2][threadIdx.x] = one_row(w2, a);
+				fold(a, 3);
+				uint32_t b[4] = {0, 0, 0, 0};
+				s_p[h + 3][threadIdx.x] = one_row(w3, b);
+				s_p[h + 4][threadIdx.x] = one_row(w4, b);
+				s_p[h + 5][threadIdx.x] = one_row(w5, b);
+				fold(b, 3);
+			}
+		} else {
+			for (uint32_t r = 0; r < nb; r++) {
+				const uint4 w = load_row(i + r);
+				uint32_t a[4] = {0, 0, 0, 0};
+				s_p[r][threadIdx.x] = one_row(w, a);
+				fold(a, 1);
+			}
+		}
+		__syncthreads();
+		// row sums: lane t -> (row t >> 4, sixteenth t & 15) sums 16 packed lanes (8 + 8 so the
+		// 10-bit fields cannot overflow), then a 16-lane shuffle tree
+		{
+			const uint32_t row = threadIdx.x >> 4, part = threadIdx.x & 15u;
+			uint32_t lo = 0, hi = 0, both = 0;
+			if (row < nb) {
+				const uint4 *src = reinterpret_cast<const uint4 *>(&s_p[row][part * 16u]);
+				const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+				const uint32_t p0 = q0.x + q0.y + q0.z + q0.w + q1.x + q1.y + q1.z + q1.w;
+				const uint32_t p1 = q2.x + q2.y + q2.z + q2.w + q3.x + q3.y + q3.z + q3.w;
+				lo = (p0 & 0x3ffu) + (p1 & 0x3ffu);
+				hi = ((p0 >> 10) & 0x3ffu) + ((p1 >> 10) & 0x3ffu);
+				both = (p0 >> 20) + (p1 >> 20);
+			}
+#pragma unroll
+			for (int off = 8; off > 0; off >>= 1) {
+				lo += __shfl_xor(lo, off, 64);
+				hi += __shfl_xor(hi, off, 64);
+				both += __shfl_xor(both, off, 64);
+			}
+			if (part == 0 && row < nb) {
+				s_res[row][0] = lo;
+				s_res[row][1] = hi;
+				s_res[row][2] = both;
+			}
+		}
+		__syncthreads();
+		if (threadIdx.x < nb * 3u) {
+			const uint32_t r = threadIdx.x / 3u, f = threadIdx.x % 3u;
+			atomicAdd(tallies + 4ull * (i + r) + 1u + f, s_res[r][f]);
+		}
+	}
+	if (live) {
+		// drain the narrow levels, then unscramble: a16[2(4j+q)+e] half h counts sample
+		// 16j + 8h + 4e + {0,2,1,3}[q]
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			acc.a8[4 * j + 0] += acc.a4[2 * j] & 0x0f0f0f0fu;
+			acc.a8[4 * j + 1] += (acc.a4[2 * j] >> 4) & 0x0f0f0f0fu;
+			acc.a8[4 * j + 2] += acc.a4[2 * j + 1] & 0x0f0f0f0fu;
+			acc.a8[4 * j + 3] += (acc.a4[2 * j + 1] >> 4) & 0x0f0f0f0fu;
+		}
+		Fold8To16(acc);
+		uint32_t *dst = slabs + static_cast<uint64_t>(blockIdx.y) * slab_stride + col * 64u;
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+#pragma unroll
+			for (int h = 0; h < 2; h++) {
+#pragma unroll
+				for (int e = 0; e < 2; e++) {
+					// samples 16j + 8h + 4e + {0,1,2,3}  <-  q = {0,2,1,3}
+					uint4 o;
+					o.x = (acc.a16[2 * (4 * j + 0) + e] >> (16 * h)) & 0xffffu;
+					o.y = (acc.a16[2 * (4 * j + 2) + e] >> (16 * h)) & 0xffffu;
+					o.z = (acc.a16[2 * (4 * j + 1) + e] >> (16 * h)) & 0xffffu;
+					o.w = (acc.a16[2 * (4 * j + 3) + e] >> (16 * h)) & 0xffffu;
+					reinterpret_cast<uint4 *>(dst)[4 * j + 2 * h + e] = o;
+				}
+			}
+		}
+	}
+}
+
+// (., lo, hi, both) -> (hom_ref, het, hom_alt, missing)
+__global__ __launch_bounds__(256) void k_finish_tallies(uint4 *__restrict__ tallies, uint32_t n, uint32_t n_eff) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) {
+		return;
+	}
+	const uint4 t = tallies[i];
+	uint4 r;
+	r.y = t.y - t.w;
+	r.z = t.z - t.w;
+	r.w = t.w;
+	r.x = n_eff - r.y - r.z - r.w;
+	tallies[i] = r;
+}
+
+// out[s] = sum over slices of slabs[slice][s]
+__global__ __launch_bounds__(256) void k_sum_slabs(const uint32_t *__restrict__ slabs, uint32_t slab_stride,
+                                                   uint32_t n_slabs, uint32_t n, uint32_t *__restrict__ out) {
+	const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+	if (s >= n) {
+		return;
+	}
+	uint32_t acc = 0;
+	for (uint32_t k = 0; k < n_slabs; k++) {
+		acc += slabs[static_cast<uint64_t>(k) * slab_stride + s];
+	}
+	out[s] = acc;
+}
+
+// ---------------------------------------------------------------------------
+// plink_freq epilogue
+// ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_freq_from_counts(const uint4 *__restrict__ counts, uint32_t n,
+                                                          double *__restrict__ alt_freq, int32_t *__restrict__ obs_ct) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) {
+		return;
+	}
+	const uint4 c = counts[i];
+	const uint32_t obs = c.x + c.y + c.z;
+	// src/plink_freq.cpp:541-543
+	alt_freq[i] = obs ? (static_cast<double>(c.y) + 2.0 * static_cast<double>(c.z)) / (2.0 * static_cast<double>(obs))
+	                  : __builtin_nan("");
+	obs_ct[i] = static_cast<int32_t>(2u * obs);
+}
+
+// ---------------------------------------------------------------------------
+// HWE
+// ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(64) void k_hwe_batch(const uint32_t *__restrict__ counts, uint32_t n, uint32_t midp,
+                                                  double *__restrict__ ln_p) {
+	const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+	if (i >= n) {
+		return;
+	}
+	ln_p[i] = HweLnP(static_cast<int32_t>(counts[4 * i + 1]), static_cast<int32_t>(counts[4 * i]),
+	                 static_cast<int32_t>(counts[4 * i + 2]), midp);
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------
+// launch wrappers
+// ---------------------------------------------------------------------------
+
+hipError_t LaunchSynthFill(uint8_t *rows, uint64_t pitch, uint32_t sample_ct, uint32_t variant_begin,
+                           uint32_t variant_ct, uint64_t seed, uint32_t miss_threshold, hipStream_t stream) {
+	if (variant_ct == 0) {
+		return hipSuccess;
+	}
+	const uint32_t dwords = static_cast<uint32_t>(pitch / 4);
+	dim3 grid((dwords + 255) / 256, variant_ct < 65535u ? variant_ct : 65535u);
+	hipLaunchKernelGGL(k_synth_fill, grid, dim3(256), 0, stream, rows, pitch, sample_ct, variant_begin, variant_ct,
+	                   seed, miss_threshold);
+	return hipGetLastError();
+}
+
+hipError_t LaunchSanitizeTail(uint8_t *rows, uint64_t pitch, uint32_t sample_ct, uint32_t variant_ct,
+                              hipStream_t stream) {
+	if (variant_ct == 0) {
+		return hipSuccess;
+	}
+	const uint32_t record_bytes = (sample_ct + 3) / 4;
+	const uint64_t total = static_cast<uint64_t>(variant_ct) * (pitch - record_bytes + 1);
+	const uint64_t blocks = (total + 255) / 256;
+	hipLaunchKernelGGL(k_sanitize_tail, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, stream, rows, pitch,
+	                   sample_ct, variant_ct);
+	return hipGetLastError();
+}
+
+hipError_t LaunchCounts(const RowView &view, uint32_t v_first, const uint32_t *vlist, uint32_t v_count,
+                        const uint8_t *mask2, uint32_t n_eff, uint32_t *out, hipStream_t stream) {
+	if (v_count == 0) {
+		return hipSuccess;
+	}
+	const uint32_t chunks = static_cast<uint32_t>((static_cast<uint64_t>(view.record_bytes) + 15) / 16);
+	const uint4 *m = reinterpret_cast<const uint4 *>(mask2);
+	uint4 *o = reinterpret_cast<uint4 *>(out);
+	if (chunks >= 256) {
+		// 256 CUs x 8 resident workgroups; beyond that the grid strides
+		const uint32_t grid = v_count < (1u << 20) ? v_count : (1u << 20);
+		if (mask2) {
+			hipLaunchKernelGGL(k_counts_block<true>, dim3(grid), dim3(256), 0, stream, view.rows, view.pitch, chunks,
+			                   v_first, vlist, v_count, m, n_eff, o);
+		} else {
+			hipLaunchKernelGGL(k_counts_block<false>, dim3(grid), dim3(256), 0, stream, view.rows, view.pitch, chunks,
+			                   v_first, vlist, v_count, m, n_eff, o);
+		}
+	} else {
+		const uint32_t blocks = (v_count + 3) / 4;
+		const uint32_t grid = blocks < (1u << 20) ? blocks : (1u << 20);
+		if (mask2) {
+			hipLaunchKernelGGL(k_counts_wave<true>, dim3(grid), dim3(256), 0, stream, view.rows, view.pitch, chunks,
+			                   v_first, vlist, v_count, m, n_eff, o);
+		} else {
+			hipLaunchKernelGGL(k_counts_wave<false>, dim3(grid), dim3(256), 0, stream, view.rows, view.pitch, chunks,
+			                   v_first, vlist, v_count, m, n_eff, o);
+		}
+	}
+	return hipGetLastError();
+}
+
+hipError_t LaunchFreqFromCounts(const uint32_t *counts, uint32_t n, double *alt_freq, int32_t *obs_ct,
+                                hipStream_t stream) {
+	if (n == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_freq_from_counts, dim3((n + 255) / 256), dim3(256), 0, stream,
+	                   reinterpret_cast<const uint4 *>(counts), n, alt_freq, obs_ct);
+	return hipGetLastError();
+}
+
+void MissingPerSamplePlan(uint32_t record_bytes, uint32_t v_count, uint32_t *slice_len_out, uint32_t *slices_out) {
+	const uint32_t chunks = (record_bytes + 15) / 16;
+	const uint32_t col_blocks = (chunks + 255) / 256;
+	// enough row slices for >= ~2048 workgroups (256 CUs x 4 resident x 2), each a multiple of 6 rows
+	uint32_t want_slices = (2048 + col_blocks - 1) / col_blocks;
+	if (want_slices > 1024) {
+		want_slices = 1024;
+	}
+	uint32_t slice_len = (v_count + want_slices - 1) / want_slices;
+	slice_len = ((slice_len + 5) / 6) * 6;
+	if (slice_len < 96) {
+		slice_len = 96;
+	}
+	if (slice_len > 65280u) {
+		slice_len = 65280u; // the fused kernel keeps 16-bit column counters; 65280 = 12 * 5440
+	}
+	*slice_len_out = slice_len;
+	*slices_out = v_count ? (v_count + slice_len - 1) / slice_len : 0;
+}
+
+size_t MissingPerSampleScratchBytes(uint32_t record_bytes, uint32_t v_count) {
+	uint32_t slice_len, slices;
+	MissingPerSamplePlan(record_bytes, v_count, &slice_len, &slices);
+	const uint64_t stride = static_cast<uint64_t>((record_bytes + 15) / 16) * 64;
+	return static_cast<size_t>(slices) * stride * sizeof(uint32_t);
+}
+
+hipError_t LaunchMissingPerSample(const RowView &view, uint32_t v_first, const uint32_t *vlist, uint32_t v_count,
+                                  const uint32_t *row_flags, uint32_t *scratch, uint32_t *out, hipStream_t stream) {
+	return LaunchClassPerSample(view, 3, v_first, vlist, v_count, row_flags, scratch, out, stream);
+}
+
+hipError_t LaunchClassPerSample(const RowView &view, int genotype_class, uint32_t v_first, const uint32_t *vlist,
+                                uint32_t v_count, const uint32_t *row_flags, uint32_t *scratch, uint32_t *out,
+                                hipStream_t stream) {
+	if (v_count == 0) {
+		return hipMemsetAsync(out, 0, sizeof(uint32_t) * view.sample_ct, stream);
+	}
+	const uint32_t chunks = static_cast<uint32_t>((static_cast<uint64_t>(view.record_bytes) + 15) / 16);
+	const uint32_t col_blocks = (chunks + 255) / 256;
+	uint32_t slice_len, slices;
+	MissingPerSamplePlan(view.record_bytes, v_count, &slice_len, &slices);
+	const uint32_t stride = chunks * 64u;
+#define PGH_COLS(CLASS)                                                                                                \
+	hipLaunchKernelGGL(k_missing_cols<CLASS>, dim3(col_blocks, slices), dim3(256), 0, stream, view.rows, view.pitch,   \
+	                   chunks, v_first, vlist, v_count, slice_len, row_flags, scratch, stride)
+	if (genotype_class == 1) {
+		PGH_COLS(1);
+	} else if (genotype_class == 2) {
+		PGH_COLS(2);
+	} else {
+		PGH_COLS(3);
+	}
+#undef PGH_COLS
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess) {
+		return e;
+	}
+	hipLaunchKernelGGL(k_sum_slabs, dim3((view.sample_ct + 255) / 256), dim3(256), 0, stream, scratch, stride, slices,
+	                   view.sample_ct, out);
+	return hipGetLastError();
+}
+
+hipError_t LaunchFusedTally(const RowView &view, uint32_t v_first, uint32_t v_count, uint32_t *scratch,
+                            uint32_t *counts, uint32_t *missing_per_sample, hipStream_t stream) {
+	if (v_count == 0) {
+		return hipMemsetAsync(missing_per_sample, 0, sizeof(uint32_t) * view.sample_ct, stream);
+	}
+	const uint32_t chunks = static_cast<uint32_t>((static_cast<uint64_t>(view.record_bytes) + 15) / 16);
+	const uint32_t col_blocks = (chunks + 255) / 256;
+	uint32_t slice_len, slices;
+	MissingPerSamplePlan(view.record_bytes, v_count, &slice_len, &slices);
+	slice_len = (slice_len + kFusedRows - 1) / kFusedRows * kFusedRows; // <= 65280, so never more slices
+	slices = (v_count + slice_len - 1) / slice_len;
+	const uint32_t stride = chunks * 64u;
+	hipError_t e = hipMemsetAsync(counts, 0, 16ull * v_count, stream);
+	if (e != hipSuccess) {
+		return e;
+	}
+	hipLaunchKernelGGL(k_fused_tally, dim3(col_blocks, slices), dim3(256), 0, stream, view.rows, view.pitch, chunks,
+	                   v_first, v_count, slice_len, counts, scratch, stride);
+	hipLaunchKernelGGL(k_finish_tallies, dim3((v_count + 255) / 256), dim3(256), 0, stream,
+	                   reinterpret_cast<uint4 *>(counts), v_count, view.sample_ct);
+	hipLaunchKernelGGL(k_sum_slabs, dim3((view.sample_ct + 255) / 256), dim3(256), 0, stream, scratch, stride, slices,
+	                   view.sample_ct, missing_per_sample);
+	return hipGetLastError();
+}
+
+hipError_t LaunchHweBatch(const uint32_t *counts, uint32_t n, uint32_t midp, double *ln_p, hipStream_t stream) {
+	if (n == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_hwe_batch, dim3((n + 63) / 64), dim3(64), 0, stream, counts, n, midp, ln_p);
+	return hipGetLastError();
+}
+
+} // namespace pgh
