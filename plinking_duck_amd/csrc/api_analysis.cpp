@@ -1,0 +1,734 @@
+// api_analysis.cpp -- the batched analysis entry points: tallies, unpack, plink_score,
+// plink_pca (single GPU and sharded), plink_ld.
+#include "api_internal.hpp"
+
+// ---------------------------------------------------------------------------
+// batched device calls
+// ---------------------------------------------------------------------------
+
+extern "C" int pgh_counts_range_dev(const pgh_dataset *ds, const pgh_subset *subset, uint32_t v_begin, uint32_t v_end,
+                                    void *d_out, void *stream, char *errbuf) {
+	int rc = CheckRange(ds, v_begin, v_end, errbuf);
+	if (rc == PGH_OK) {
+		rc = CheckSubset(ds, subset, errbuf);
+	}
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	PGH_HIP(pgh::LaunchCounts(ds->View(), v_begin - ds->v_begin, nullptr, v_end - v_begin,
+	                          subset ? subset->d_mask2 : nullptr, subset ? subset->n_out : ds->sample_ct,
+	                          static_cast<uint32_t *>(d_out), static_cast<hipStream_t>(stream)),
+	        "counts kernel");
+	return PGH_OK;
+}
+
+extern "C" int pgh_counts_range(const pgh_dataset *ds, const pgh_subset *subset, uint32_t v_begin, uint32_t v_end,
+                                uint32_t (*out)[4], char *errbuf) {
+	int rc = CheckRange(ds, v_begin, v_end, errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	const size_t n = v_end - v_begin;
+	if (n == 0) {
+		return PGH_OK;
+	}
+	DevBuf buf;
+	PGH_HIP(buf.Alloc(n * 16), "hipMalloc(counts)");
+	rc = pgh_counts_range_dev(ds, subset, v_begin, v_end, buf.p, hipStreamPerThread, errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	PGH_HIP(hipMemcpyAsync(out, buf.p, n * 16, hipMemcpyDeviceToHost, hipStreamPerThread), "counts copy");
+	PGH_HIP(hipStreamSynchronize(hipStreamPerThread), "counts sync");
+	return PGH_OK;
+}
+
+extern "C" int pgh_freq_from_counts_dev(const void *d_counts, uint32_t n, void *d_alt_freq, void *d_obs_ct,
+                                        void *stream, char *errbuf) {
+	if (n && (!d_counts || !d_alt_freq || !d_obs_ct)) {
+		SetErr(errbuf, "null argument");
+		return PGH_ERR_ARG;
+	}
+	PGH_HIP(pgh::LaunchFreqFromCounts(static_cast<const uint32_t *>(d_counts), n, static_cast<double *>(d_alt_freq),
+	                                  static_cast<int32_t *>(d_obs_ct), static_cast<hipStream_t>(stream)),
+	        "freq kernel");
+	return PGH_OK;
+}
+
+extern "C" int pgh_missing_per_sample_dev(const pgh_dataset *ds, uint32_t v_begin, uint32_t v_end, void *d_out,
+                                          void *stream, char *errbuf) {
+	int rc = CheckRange(ds, v_begin, v_end, errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	// per-slice partial rows: a few MB, stream-ordered so the call stays enqueue-only
+	const size_t scratch_bytes = pgh::MissingPerSampleScratchBytes(ds->record_bytes, v_end - v_begin);
+	void *scratch = nullptr;
+	PGH_HIP(hipMallocAsync(&scratch, scratch_bytes ? scratch_bytes : 16, st), "missing scratch");
+	hipError_t e = pgh::LaunchMissingPerSample(ds->View(), v_begin - ds->v_begin, nullptr, v_end - v_begin, nullptr,
+	                                           static_cast<uint32_t *>(scratch), static_cast<uint32_t *>(d_out), st);
+	(void)hipFreeAsync(scratch, st);
+	PGH_HIP(e, "missing-per-sample kernel");
+	return PGH_OK;
+}
+
+extern "C" int pgh_fused_tally_dev(const pgh_dataset *ds, uint32_t v_begin, uint32_t v_end, void *d_counts,
+                                   void *d_missing, void *stream, char *errbuf) {
+	int rc = CheckRange(ds, v_begin, v_end, errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	if (!d_counts || !d_missing) {
+		SetErr(errbuf, "null argument");
+		return PGH_ERR_ARG;
+	}
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	const size_t scratch_bytes = pgh::MissingPerSampleScratchBytes(ds->record_bytes, v_end - v_begin);
+	void *scratch = nullptr;
+	PGH_HIP(hipMallocAsync(&scratch, scratch_bytes ? scratch_bytes : 16, st), "fused scratch");
+	hipError_t e = pgh::LaunchFusedTally(ds->View(), v_begin - ds->v_begin, v_end - v_begin,
+	                                     static_cast<uint32_t *>(scratch), static_cast<uint32_t *>(d_counts),
+	                                     static_cast<uint32_t *>(d_missing), st);
+	(void)hipFreeAsync(scratch, st);
+	PGH_HIP(e, "fused tally kernel");
+	return PGH_OK;
+}
+
+extern "C" int pgh_missing_per_sample(const pgh_dataset *ds, const pgh_subset *subset, uint32_t v_begin,
+                                      uint32_t v_end, uint32_t *out, char *errbuf) {
+	int rc = CheckRange(ds, v_begin, v_end, errbuf);
+	if (rc == PGH_OK) {
+		rc = CheckSubset(ds, subset, errbuf);
+	}
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	const uint32_t N = ds->sample_ct;
+	const uint32_t padded = (N + 63) / 64 * 64;
+	DevBuf buf;
+	PGH_HIP(buf.Alloc(sizeof(uint32_t) * padded), "hipMalloc(missing)");
+	rc = pgh_missing_per_sample_dev(ds, v_begin, v_end, buf.p, hipStreamPerThread, errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	std::vector<uint32_t> raw(N);
+	PGH_HIP(hipMemcpyAsync(raw.data(), buf.p, sizeof(uint32_t) * N, hipMemcpyDeviceToHost, hipStreamPerThread),
+	        "missing copy");
+	PGH_HIP(hipStreamSynchronize(hipStreamPerThread), "missing sync");
+	Compact<uint32_t>(subset, raw.data(), 1, out, N);
+	return PGH_OK;
+}
+
+extern "C" int pgh_sample_counts(const pgh_dataset *ds, const pgh_subset *subset, uint32_t variant_begin,
+                                 uint32_t n_var, const uint32_t *vidx, uint32_t (*counts)[4], char *errbuf) {
+	if (!ds || !counts) {
+		SetErr(errbuf, "null argument");
+		return PGH_ERR_ARG;
+	}
+	int rc = CheckSubset(ds, subset, errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	std::vector<uint32_t> local;
+	if (vidx) {
+		local.resize(n_var);
+		for (uint32_t i = 0; i < n_var; i++) {
+			if (vidx[i] < ds->v_begin || vidx[i] >= ds->v_end) {
+				SetErr(errbuf, "variant index outside the resident range");
+				return PGH_ERR_ARG;
+			}
+			local[i] = vidx[i] - ds->v_begin;
+		}
+	} else {
+		rc = CheckRange(ds, variant_begin, variant_begin + n_var, errbuf);
+		if (rc != PGH_OK) {
+			return rc;
+		}
+	}
+	const uint32_t N = ds->sample_ct;
+	const uint32_t n_out = subset ? subset->n_out : N;
+	const uint32_t padded = (N + 63) / 64 * 64;
+	hipStream_t st = hipStreamPerThread;
+	DevBuf d_cls, d_list, d_scratch;
+	PGH_HIP(d_cls.Alloc(sizeof(uint32_t) * 3ull * padded), "hipMalloc(sample counts)");
+	const size_t scratch_bytes = pgh::MissingPerSampleScratchBytes(ds->record_bytes, n_var);
+	PGH_HIP(d_scratch.Alloc(scratch_bytes ? scratch_bytes : 16), "hipMalloc(sample counts)");
+	if (vidx && n_var) {
+		PGH_HIP(d_list.Alloc(sizeof(uint32_t) * n_var), "hipMalloc(sample counts)");
+		PGH_HIP(hipMemcpyAsync(d_list.p, local.data(), sizeof(uint32_t) * n_var, hipMemcpyHostToDevice, st),
+		        "sample counts upload");
+	}
+	// one column-tally pass per class (het, hom-alt, missing); hom-ref is what is left
+	for (int cls = 1; cls <= 3; cls++) {
+		PGH_HIP(pgh::LaunchClassPerSample(ds->View(), cls, vidx ? 0 : variant_begin - ds->v_begin,
+		                                  vidx ? d_list.As<uint32_t>() : nullptr, n_var, nullptr,
+		                                  d_scratch.As<uint32_t>(), d_cls.As<uint32_t>() + (cls - 1) * padded, st),
+		        "sample counts kernel");
+	}
+	std::vector<uint32_t> raw(3ull * padded);
+	PGH_HIP(hipMemcpyAsync(raw.data(), d_cls.p, sizeof(uint32_t) * raw.size(), hipMemcpyDeviceToHost, st),
+	        "sample counts copy");
+	PGH_HIP(hipStreamSynchronize(st), "sample counts sync");
+	for (uint32_t k = 0; k < n_out; k++) {
+		const uint32_t s = subset ? subset->sel[k] : k;
+		const uint32_t het = raw[s], alt = raw[padded + s], miss = raw[2ull * padded + s];
+		counts[k][0] = n_var - het - alt - miss;
+		counts[k][1] = het;
+		counts[k][2] = alt;
+		counts[k][3] = miss;
+	}
+	return PGH_OK;
+}
+
+extern "C" int pgh_unpack_range_dev(const pgh_dataset *ds, const pgh_subset *subset, uint32_t v_begin, uint32_t v_end,
+                                    void *d_out, size_t out_pitch, void *d_validity, int missing_code, void *stream,
+                                    char *errbuf) {
+	int rc = CheckRange(ds, v_begin, v_end, errbuf);
+	if (rc == PGH_OK) {
+		rc = CheckSubset(ds, subset, errbuf);
+	}
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	const uint32_t n_out = subset ? subset->n_out : ds->sample_ct;
+	if (d_out && (out_pitch % 16 != 0 || out_pitch < (static_cast<size_t>(n_out) + 15) / 16 * 16)) {
+		SetErr(errbuf, "out_pitch must be a multiple of 16 covering the row");
+		return PGH_ERR_ARG;
+	}
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	if (subset) {
+		PGH_HIP(pgh::LaunchUnpackSubset(ds->View(), v_begin - ds->v_begin, v_end - v_begin, subset->d_sel, n_out,
+		                                static_cast<int8_t *>(d_out), out_pitch, static_cast<uint64_t *>(d_validity),
+		                                static_cast<int8_t>(missing_code), st),
+		        "unpack kernel");
+	} else {
+		PGH_HIP(pgh::LaunchUnpack(ds->View(), v_begin - ds->v_begin, v_end - v_begin, static_cast<int8_t *>(d_out),
+		                          out_pitch, static_cast<uint64_t *>(d_validity), static_cast<int8_t>(missing_code),
+		                          st),
+		        "unpack kernel");
+	}
+	return PGH_OK;
+}
+
+extern "C" int pgh_unpack_range(const pgh_dataset *ds, const pgh_subset *subset, uint32_t v_begin, uint32_t v_end,
+                                int8_t *out, uint64_t *validity, int missing_code, char *errbuf) {
+	int rc = CheckRange(ds, v_begin, v_end, errbuf);
+	if (rc == PGH_OK) {
+		rc = CheckSubset(ds, subset, errbuf);
+	}
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	const uint32_t n_out = subset ? subset->n_out : ds->sample_ct;
+	const size_t rows = v_end - v_begin;
+	if (rows == 0 || n_out == 0) {
+		return PGH_OK;
+	}
+	const size_t out_pitch = (static_cast<size_t>(n_out) + 15) / 16 * 16;
+	const size_t val_words = (n_out + 63) / 64;
+	// chunk the range so the device staging stays bounded (output is 4x the input)
+	const size_t max_rows = std::max<size_t>(1, (512ull << 20) / out_pitch);
+	DevBuf d_out, d_val;
+	const size_t chunk_rows = std::min(rows, max_rows);
+	if (out) {
+		PGH_HIP(d_out.Alloc(chunk_rows * out_pitch), "hipMalloc(unpack)");
+	}
+	if (validity) {
+		PGH_HIP(d_val.Alloc(chunk_rows * val_words * 8), "hipMalloc(validity)");
+	}
+	for (size_t r0 = 0; r0 < rows; r0 += chunk_rows) {
+		const size_t r1 = std::min(rows, r0 + chunk_rows);
+		rc = pgh_unpack_range_dev(ds, subset, v_begin + static_cast<uint32_t>(r0), v_begin + static_cast<uint32_t>(r1),
+		                          d_out.p, out_pitch, d_val.p, missing_code, hipStreamPerThread, errbuf);
+		if (rc != PGH_OK) {
+			return rc;
+		}
+		if (out) {
+			PGH_HIP(hipMemcpy2DAsync(out + r0 * n_out, n_out, d_out.p, out_pitch, n_out, r1 - r0,
+			                         hipMemcpyDeviceToHost, hipStreamPerThread),
+			        "unpack copy");
+		}
+		if (validity) {
+			PGH_HIP(hipMemcpyAsync(validity + r0 * val_words, d_val.p, (r1 - r0) * val_words * 8,
+			                       hipMemcpyDeviceToHost, hipStreamPerThread),
+			        "validity copy");
+		}
+		PGH_HIP(hipStreamSynchronize(hipStreamPerThread), "unpack sync");
+	}
+	return PGH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// plink_score
+// ---------------------------------------------------------------------------
+
+struct pgh_score_plan {
+	const pgh_dataset *ds = nullptr;
+	uint32_t n_scored = 0, n_cols = 0;
+	int mode = 0;
+	void *d_vlist = nullptr, *d_weights = nullptr, *d_flip = nullptr, *d_counts = nullptr, *d_ts = nullptr,
+	     *d_td = nullptr, *d_ac = nullptr;
+};
+
+extern "C" void pgh_score_plan_destroy(pgh_score_plan *plan) {
+	if (!plan) {
+		return;
+	}
+	for (void *p : {plan->d_vlist, plan->d_weights, plan->d_flip, plan->d_counts, plan->d_ts, plan->d_td, plan->d_ac}) {
+		if (p) {
+			(void)hipFree(p);
+		}
+	}
+	delete plan;
+}
+
+extern "C" int pgh_score_plan_create(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_scored,
+                                     const uint32_t *vidx, const double *weights, const uint8_t *flip, uint32_t n_cols,
+                                     int mode, pgh_score_plan **out, char *errbuf) {
+	if (!ds || !out || (n_scored && (!vidx || !weights))) {
+		SetErr(errbuf, "null argument");
+		return PGH_ERR_ARG;
+	}
+	*out = nullptr;
+	if (mode < 0 || mode > 2) {
+		SetErr(errbuf, "unknown score mode");
+		return PGH_ERR_ARG;
+	}
+	if (n_cols == 0 || n_cols > 4096) {
+		SetErr(errbuf, "n_cols must be between 1 and 4096");
+		return PGH_ERR_ARG;
+	}
+	int rc = CheckSubset(ds, subset, errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	std::vector<uint32_t> local(n_scored);
+	for (uint32_t i = 0; i < n_scored; i++) {
+		if (vidx[i] < ds->v_begin || vidx[i] >= ds->v_end) {
+			SetErr(errbuf, "scored variant index outside the resident range");
+			return PGH_ERR_ARG;
+		}
+		local[i] = vidx[i] - ds->v_begin;
+	}
+	std::unique_ptr<pgh_score_plan, void (*)(pgh_score_plan *)> plan(new pgh_score_plan(), pgh_score_plan_destroy);
+	plan->ds = ds;
+	plan->n_scored = n_scored;
+	plan->n_cols = n_cols;
+	plan->mode = mode;
+	if (n_scored) {
+		const uint32_t N = ds->sample_ct;
+		hipStream_t st = hipStreamPerThread;
+		PGH_HIP(hipMalloc(&plan->d_vlist, sizeof(uint32_t) * n_scored), "hipMalloc(score)");
+		PGH_HIP(hipMalloc(&plan->d_weights, sizeof(double) * n_scored * n_cols), "hipMalloc(score)");
+		PGH_HIP(hipMalloc(&plan->d_counts, 16ull * n_scored), "hipMalloc(score)");
+		PGH_HIP(hipMalloc(&plan->d_ts, 32ull * n_scored), "hipMalloc(score)");
+		PGH_HIP(hipMalloc(&plan->d_td, 32ull * n_scored), "hipMalloc(score)");
+		PGH_HIP(hipMalloc(&plan->d_ac, 4ull * n_scored), "hipMalloc(score)");
+		PGH_HIP(hipMemcpyAsync(plan->d_vlist, local.data(), sizeof(uint32_t) * n_scored, hipMemcpyHostToDevice, st),
+		        "score upload");
+		PGH_HIP(hipMemcpyAsync(plan->d_weights, weights, sizeof(double) * n_scored * n_cols, hipMemcpyHostToDevice, st),
+		        "score upload");
+		if (flip) {
+			PGH_HIP(hipMalloc(&plan->d_flip, n_scored), "hipMalloc(score)");
+			PGH_HIP(hipMemcpyAsync(plan->d_flip, flip, n_scored, hipMemcpyHostToDevice, st), "score upload");
+		}
+		// per-variant statistics and contribution tables depend on the data only: once per plan
+		PGH_HIP(pgh::LaunchCounts(ds->View(), 0, static_cast<uint32_t *>(plan->d_vlist), n_scored,
+		                          subset ? subset->d_mask2 : nullptr, subset ? subset->n_out : N,
+		                          static_cast<uint32_t *>(plan->d_counts), st),
+		        "score counts kernel");
+		PGH_HIP(pgh::LaunchScoreTables(static_cast<uint32_t *>(plan->d_counts), static_cast<uint8_t *>(plan->d_flip),
+		                               n_scored, mode, static_cast<double *>(plan->d_ts),
+		                               static_cast<double *>(plan->d_td), static_cast<uint32_t *>(plan->d_ac), st),
+		        "score table kernel");
+		PGH_HIP(hipStreamSynchronize(st), "score plan sync"); // host staging vectors die with this frame
+	}
+	*out = plan.release();
+	return PGH_OK;
+}
+
+extern "C" int pgh_score_run_dev(const pgh_score_plan *plan, void *d_score_sum, void *d_dosage_sum, void *d_allele_ct,
+                                 void *stream, char *errbuf) {
+	if (!plan || !d_score_sum || !d_dosage_sum || !d_allele_ct) {
+		SetErr(errbuf, "null argument");
+		return PGH_ERR_ARG;
+	}
+	const pgh_dataset *ds = plan->ds;
+	const uint32_t N = ds->sample_ct;
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	PGH_HIP(hipMemsetAsync(d_score_sum, 0, sizeof(double) * N * plan->n_cols, st), "score memset");
+	PGH_HIP(hipMemsetAsync(d_dosage_sum, 0, sizeof(double) * N, st), "score memset");
+	if (plan->n_scored == 0) {
+		PGH_HIP(hipMemsetAsync(d_allele_ct, 0, sizeof(uint32_t) * N, st), "score memset");
+		return PGH_OK;
+	}
+	PGH_HIP(pgh::LaunchScoreAccumulate(ds->View(), static_cast<uint32_t *>(plan->d_vlist), plan->n_scored,
+	                                   static_cast<double *>(plan->d_weights), plan->n_cols,
+	                                   static_cast<double *>(plan->d_ts), static_cast<double *>(plan->d_td),
+	                                   static_cast<uint32_t *>(plan->d_ac), plan->mode != PGH_SCORE_CENTER,
+	                                   static_cast<double *>(d_score_sum), static_cast<double *>(d_dosage_sum),
+	                                   static_cast<uint32_t *>(d_allele_ct), st),
+	        "score accumulate kernel");
+	// ALLELE_CT is integer bookkeeping: 2 per scored, non-skipped variant, minus 2 per such
+	// variant at which the sample is missing unless missing calls are mean-imputed
+	// (src/plink_score.cpp:632-651).
+	if (plan->mode == PGH_SCORE_MEAN_IMPUTE) {
+		PGH_HIP(pgh::LaunchAlleleCt(static_cast<uint32_t *>(plan->d_ac), plan->n_scored, nullptr, N,
+		                            static_cast<uint32_t *>(d_allele_ct), st),
+		        "allele count kernel");
+	} else {
+		const size_t scratch_bytes = pgh::MissingPerSampleScratchBytes(ds->record_bytes, plan->n_scored);
+		void *scratch = nullptr, *miss = nullptr;
+		PGH_HIP(hipMallocAsync(&scratch, scratch_bytes ? scratch_bytes : 16, st), "score scratch");
+		PGH_HIP(hipMallocAsync(&miss, sizeof(uint32_t) * ((N + 63) / 64 * 64), st), "score scratch");
+		hipError_t e = pgh::LaunchMissingPerSample(ds->View(), 0, static_cast<uint32_t *>(plan->d_vlist),
+		                                           plan->n_scored, static_cast<uint32_t *>(plan->d_ac),
+		                                           static_cast<uint32_t *>(scratch), static_cast<uint32_t *>(miss), st);
+		if (e == hipSuccess) {
+			e = pgh::LaunchAlleleCt(static_cast<uint32_t *>(plan->d_ac), plan->n_scored, static_cast<uint32_t *>(miss),
+			                        N, static_cast<uint32_t *>(d_allele_ct), st);
+		}
+		(void)hipFreeAsync(scratch, st);
+		(void)hipFreeAsync(miss, st);
+		PGH_HIP(e, "allele count kernels");
+	}
+	return PGH_OK;
+}
+
+extern "C" int pgh_score_dev(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_scored, const uint32_t *vidx,
+                             const double *weights, const uint8_t *flip, uint32_t n_cols, int mode, void *d_score_sum,
+                             void *d_dosage_sum, void *d_allele_ct, void *stream, char *errbuf) {
+	pgh_score_plan *plan = nullptr;
+	int rc = pgh_score_plan_create(ds, subset, n_scored, vidx, weights, flip, n_cols, mode, &plan, errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	rc = pgh_score_run_dev(plan, d_score_sum, d_dosage_sum, d_allele_ct, stream, errbuf);
+	if (rc == PGH_OK) {
+		hipError_t e = hipStreamSynchronize(static_cast<hipStream_t>(stream)); // the plan's buffers are freed next
+		if (e != hipSuccess) {
+			rc = DeviceFail(errbuf, "score sync", e);
+		}
+	}
+	pgh_score_plan_destroy(plan);
+	return rc;
+}
+
+extern "C" int pgh_score(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_scored, const uint32_t *vidx,
+                         const double *weights, const uint8_t *flip, uint32_t n_cols, int mode, double *score_sum,
+                         double *dosage_sum, uint32_t *allele_ct, char *errbuf) {
+	if (!ds) {
+		SetErr(errbuf, "null dataset");
+		return PGH_ERR_ARG;
+	}
+	const uint32_t N = ds->sample_ct;
+	DevBuf d_score, d_dos, d_ac;
+	PGH_HIP(d_score.Alloc(sizeof(double) * N * std::max<uint32_t>(1, n_cols)), "hipMalloc(score out)");
+	PGH_HIP(d_dos.Alloc(sizeof(double) * N), "hipMalloc(score out)");
+	PGH_HIP(d_ac.Alloc(sizeof(uint32_t) * N), "hipMalloc(score out)");
+	int rc = pgh_score_dev(ds, subset, n_scored, vidx, weights, flip, n_cols, mode, d_score.p, d_dos.p, d_ac.p,
+	                       hipStreamPerThread, errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	std::vector<double> h_score(static_cast<size_t>(N) * n_cols), h_dos(N);
+	std::vector<uint32_t> h_ac(N);
+	PGH_HIP(hipMemcpy(h_score.data(), d_score.p, sizeof(double) * N * n_cols, hipMemcpyDeviceToHost), "score copy");
+	PGH_HIP(hipMemcpy(h_dos.data(), d_dos.p, sizeof(double) * N, hipMemcpyDeviceToHost), "score copy");
+	PGH_HIP(hipMemcpy(h_ac.data(), d_ac.p, sizeof(uint32_t) * N, hipMemcpyDeviceToHost), "score copy");
+	Compact<double>(subset, h_score.data(), n_cols, score_sum, N);
+	Compact<double>(subset, h_dos.data(), 1, dosage_sum, N);
+	Compact<uint32_t>(subset, h_ac.data(), 1, allele_ct, N);
+	return PGH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// plink_pca
+// ---------------------------------------------------------------------------
+
+extern "C" int pgh_pca(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_var, const uint32_t *vidx,
+                       const double *center, const double *inv_stdev, uint32_t n_pcs, const double *g1_init,
+                       double *eigenvalues, double *eigenvectors, char *errbuf) {
+	return pgh_pca_sharded(ds, subset, n_var, vidx, center, inv_stdev, n_var, n_pcs, g1_init, nullptr, nullptr,
+	                       eigenvalues, eigenvectors, errbuf);
+}
+
+extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_var, const uint32_t *vidx,
+                               const double *center, const double *inv_stdev, uint64_t n_var_total, uint32_t n_pcs,
+                               const double *g1_init, pgh_allreduce_fn allreduce, void *allreduce_ctx,
+                               double *eigenvalues, double *eigenvectors, char *errbuf) {
+	if (!ds || !g1_init || !eigenvalues || !eigenvectors || n_pcs == 0 ||
+	    (n_var && (!vidx || !center || !inv_stdev))) {
+		SetErr(errbuf, "null or empty argument");
+		return PGH_ERR_ARG;
+	}
+	if (n_var_total < n_var || (!allreduce && n_var_total != n_var)) {
+		SetErr(errbuf, "n_var_total must cover this shard's variants (and equal them without an all-reduce)");
+		return PGH_ERR_ARG;
+	}
+	int rc = CheckSubset(ds, subset, errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	const uint32_t N = ds->sample_ct;
+	const uint32_t n_out = subset ? subset->n_out : N;
+	const uint32_t M = n_var; // this shard's rows of X; every 1/M and the eigenvalue divisor use the total
+	const double m_total = static_cast<double>(n_var_total);
+	const uint32_t k2 = 2 * n_pcs;
+	const uint32_t qq = (n_pcs + 1) * k2;
+	if (n_var_total < qq || n_out < qq) {
+		SetErr(errbuf, "too few variants or samples for the requested number of PCs");
+		return PGH_ERR_ARG;
+	}
+	std::vector<uint32_t> local(M);
+	for (uint32_t i = 0; i < M; i++) {
+		if (vidx[i] < ds->v_begin || vidx[i] >= ds->v_end) {
+			SetErr(errbuf, "effective variant index outside the resident range");
+			return PGH_ERR_ARG;
+		}
+		local[i] = vidx[i] - ds->v_begin;
+	}
+	hipStream_t st = hipStreamPerThread;
+	// Sum a device buffer over the variant shards (X is split by rows, so every X^T(...)
+	// product and every Gram matrix of a tall factor is a sum of per-shard terms).
+	auto all_sum = [&](double *buf, uint64_t count) -> int {
+		if (!allreduce) {
+			return PGH_OK;
+		}
+		if (allreduce(allreduce_ctx, buf, count, st) != 0) {
+			SetErr(errbuf, "pca: the all-reduce callback failed");
+			return PGH_ERR_DEVICE;
+		}
+		return PGH_OK;
+	};
+#define PGH_SUM(buf, count)                                                                                            \
+	do {                                                                                                               \
+		int rc_sum_ = all_sum((buf), (count));                                                                         \
+		if (rc_sum_ != PGH_OK) {                                                                                       \
+			return rc_sum_;                                                                                            \
+		}                                                                                                              \
+	} while (0)
+	const size_t m_alloc = std::max<uint32_t>(M, 1);
+	DevBuf d_vlist, d_center, d_inv, d_ts, d_g1, d_g2, d_qq, d_bb;
+	PGH_HIP(d_vlist.Alloc(sizeof(uint32_t) * m_alloc), "hipMalloc(pca)");
+	PGH_HIP(d_center.Alloc(sizeof(double) * m_alloc), "hipMalloc(pca)");
+	PGH_HIP(d_inv.Alloc(sizeof(double) * m_alloc), "hipMalloc(pca)");
+	PGH_HIP(d_ts.Alloc(32ull * m_alloc), "hipMalloc(pca)");
+	PGH_HIP(d_g1.Alloc(sizeof(double) * N * k2), "hipMalloc(pca)");
+	PGH_HIP(d_g2.Alloc(sizeof(double) * N * k2), "hipMalloc(pca)");
+	PGH_HIP(d_qq.Alloc(sizeof(double) * m_alloc * qq), "hipMalloc(pca)");
+	if (M) {
+		PGH_HIP(hipMemcpy(d_vlist.p, local.data(), sizeof(uint32_t) * M, hipMemcpyHostToDevice), "pca upload");
+		PGH_HIP(hipMemcpy(d_center.p, center, sizeof(double) * M, hipMemcpyHostToDevice), "pca upload");
+		PGH_HIP(hipMemcpy(d_inv.p, inv_stdev, sizeof(double) * M, hipMemcpyHostToDevice), "pca upload");
+	}
+	{
+		// start matrix in raw-sample rows (excluded samples stay zero)
+		std::vector<double> g1_raw(static_cast<size_t>(N) * k2, 0.0);
+		for (uint32_t k = 0; k < n_out; k++) {
+			const uint32_t s = subset ? subset->sel[k] : k;
+			std::memcpy(&g1_raw[static_cast<size_t>(s) * k2], g1_init + static_cast<size_t>(k) * k2, sizeof(double) * k2);
+		}
+		PGH_HIP(hipMemcpy(d_g1.p, g1_raw.data(), sizeof(double) * g1_raw.size(), hipMemcpyHostToDevice), "pca upload");
+	}
+	if (M) {
+		PGH_HIP(pgh::LaunchNormTables(d_center.As<double>(), d_inv.As<double>(), M, d_ts.As<double>(), st), "pca tables");
+	}
+	const RowView view = ds->View();
+	double *g1 = d_g1.As<double>();
+	double *g2 = d_g2.As<double>();
+	const uint8_t *mask2 = subset ? subset->d_mask2 : nullptr;
+	for (uint32_t pass = 0; pass <= n_pcs; pass++) {
+		double *y = d_qq.As<double>() + static_cast<size_t>(pass) * k2;
+		// Step A: QQ[:, pass*2k : (pass+1)*2k] = X * G1   (rows of this shard only)
+		if (M) {
+			PGH_HIP(pgh::LaunchVariantReduce(view, d_vlist.As<uint32_t>(), M, d_ts.As<double>(), g1, k2, k2, y, qq, st),
+			        "pca step A");
+		}
+		if (pass < n_pcs) {
+			// Step B + merge: G1 = X^T Y / M, summed over shards
+			PGH_HIP(hipMemsetAsync(g2, 0, sizeof(double) * N * k2, st), "pca memset");
+			if (M) {
+				PGH_HIP(pgh::LaunchTableAccumulate(view, d_vlist.As<uint32_t>(), M, y, qq, k2, d_ts.As<double>(),
+				                                   nullptr, nullptr, false, g2, k2, nullptr, nullptr, st),
+				        "pca step B");
+			}
+			PGH_SUM(g2, static_cast<uint64_t>(N) * k2);
+			PGH_HIP(pgh::LaunchMaskRows(g2, N, k2, k2, mask2, st), "pca mask");
+			PGH_HIP(pgh::LaunchScale(g2, static_cast<uint64_t>(N) * k2, 1.0 / m_total, st), "pca scale");
+			std::swap(g1, g2);
+		}
+	}
+	// Orthonormal basis of the Krylov block's column space, on the device.  The
+	// reference takes the left singular vectors of QQ (src/plink_pca.cpp:683-697); the
+	// only thing phase 3 uses of them is that they are an orthonormal basis of that
+	// space (singular values of B = X^T U do not change under a rotation of U), so a
+	// block Gram-Schmidt does the same job without an M x qq SVD on the host:
+	// per block of 2k columns, project out the finished blocks twice (BCGS2), then
+	// orthonormalise inside the block twice through its 2k x 2k Gram matrix.
+	{
+		DevBuf d_small, d_tmp;
+		PGH_HIP(d_small.Alloc(sizeof(double) * static_cast<size_t>(qq) * k2), "hipMalloc(pca)");
+		PGH_HIP(d_tmp.Alloc(sizeof(double) * m_alloc * k2), "hipMalloc(pca)");
+		double *q = d_qq.As<double>();
+		std::vector<double> g(static_cast<size_t>(k2) * k2), lam, vec, t(static_cast<size_t>(k2) * k2);
+		for (uint32_t p = 0; p <= n_pcs; p++) {
+			double *bp = q + static_cast<size_t>(p) * k2;
+			const uint32_t prev = p * k2;
+			for (int rep = 0; rep < 2 && prev > 0; rep++) {
+				PGH_HIP(hipMemsetAsync(d_small.p, 0, sizeof(double) * prev * k2, st), "pca memset");
+				if (M) {
+					PGH_HIP(pgh::LaunchTallGram(q, qq, prev, bp, qq, k2, M, d_small.As<double>(), k2, st), "pca gram");
+				}
+				PGH_SUM(d_small.As<double>(), static_cast<uint64_t>(prev) * k2);
+				if (M) {
+					PGH_HIP(pgh::LaunchTallTimesSmall(q, qq, prev, d_small.As<double>(), k2, k2, -1.0, 1.0, bp, qq, bp, qq,
+					                                  M, st),
+					        "pca project");
+				}
+			}
+			for (int rep = 0; rep < 2; rep++) {
+				PGH_HIP(hipMemsetAsync(d_small.p, 0, sizeof(double) * k2 * k2, st), "pca memset");
+				if (M) {
+					PGH_HIP(pgh::LaunchTallGram(bp, qq, k2, bp, qq, k2, M, d_small.As<double>(), k2, st), "pca gram");
+				}
+				PGH_SUM(d_small.As<double>(), static_cast<uint64_t>(k2) * k2);
+				PGH_HIP(hipMemcpyAsync(g.data(), d_small.p, sizeof(double) * k2 * k2, hipMemcpyDeviceToHost, st),
+				        "pca download");
+				PGH_HIP(hipStreamSynchronize(st), "pca sync");
+				pgh::SymmetricEigen(g, k2, lam, vec);
+				const double floor = lam[0] * 1e-13; // below this a direction is rounding noise
+				for (uint32_t i = 0; i < k2; i++) {
+					for (uint32_t j = 0; j < k2; j++) {
+						t[static_cast<size_t>(i) * k2 + j] =
+						    lam[j] > floor && lam[j] > 0.0 ? vec[static_cast<size_t>(i) * k2 + j] / std::sqrt(lam[j]) : 0.0;
+					}
+				}
+				PGH_HIP(hipMemcpyAsync(d_small.p, t.data(), sizeof(double) * k2 * k2, hipMemcpyHostToDevice, st),
+				        "pca upload");
+				if (M) {
+					PGH_HIP(pgh::LaunchTallTimesSmall(bp, qq, k2, d_small.As<double>(), k2, k2, 1.0, 0.0, nullptr, 0,
+					                                  d_tmp.As<double>(), k2, M, st),
+					        "pca orthonormalise");
+					PGH_HIP(pgh::LaunchCopyCols(d_tmp.As<double>(), k2, bp, qq, k2, M, st), "pca copy");
+				}
+				PGH_HIP(hipStreamSynchronize(st), "pca sync"); // t is reused by the next repetition
+			}
+		}
+	}
+	// Phase 3: BB = X^T U   (src/plink_pca.cpp:664-676)
+	PGH_HIP(d_bb.Alloc(sizeof(double) * static_cast<size_t>(N) * qq), "hipMalloc(pca)");
+	PGH_HIP(hipMemsetAsync(d_bb.p, 0, sizeof(double) * static_cast<size_t>(N) * qq, st), "pca memset");
+	if (M) {
+		PGH_HIP(pgh::LaunchTableAccumulate(view, d_vlist.As<uint32_t>(), M, d_qq.As<double>(), qq, qq,
+		                                   d_ts.As<double>(), nullptr, nullptr, false, d_bb.As<double>(), qq, nullptr,
+		                                   nullptr, st),
+		        "pca phase 3");
+	}
+	PGH_SUM(d_bb.As<double>(), static_cast<uint64_t>(N) * qq);
+	PGH_HIP(pgh::LaunchMaskRows(d_bb.As<double>(), N, qq, qq, mask2, st), "pca mask");
+	// Final SVD of BB (src/plink_pca.cpp:700-720) through its qq x qq Gram matrix:
+	// BB^T BB = V S^2 V^T gives the eigenvalues S^2 / M directly and U_k = BB V_k S_k^-1.
+	{
+		DevBuf d_g, d_vk, d_uk;
+		PGH_HIP(d_g.Alloc(sizeof(double) * static_cast<size_t>(qq) * qq), "hipMalloc(pca)");
+		PGH_HIP(d_vk.Alloc(sizeof(double) * static_cast<size_t>(qq) * n_pcs), "hipMalloc(pca)");
+		PGH_HIP(d_uk.Alloc(sizeof(double) * static_cast<size_t>(N) * n_pcs), "hipMalloc(pca)");
+		PGH_HIP(hipMemsetAsync(d_g.p, 0, sizeof(double) * static_cast<size_t>(qq) * qq, st), "pca memset");
+		PGH_HIP(pgh::LaunchTallGram(d_bb.As<double>(), qq, qq, d_bb.As<double>(), qq, qq, N, d_g.As<double>(), qq, st),
+		        "pca gram");
+		std::vector<double> g(static_cast<size_t>(qq) * qq), lam, vec;
+		PGH_HIP(hipMemcpyAsync(g.data(), d_g.p, sizeof(double) * g.size(), hipMemcpyDeviceToHost, st), "pca download");
+		PGH_HIP(hipStreamSynchronize(st), "pca sync");
+		for (uint32_t i = 0; i < qq; i++) { // symmetrise away the atomics' rounding asymmetry
+			for (uint32_t j = i + 1; j < qq; j++) {
+				const double avg = 0.5 * (g[static_cast<size_t>(i) * qq + j] + g[static_cast<size_t>(j) * qq + i]);
+				g[static_cast<size_t>(i) * qq + j] = g[static_cast<size_t>(j) * qq + i] = avg;
+			}
+		}
+		pgh::SymmetricEigen(g, qq, lam, vec);
+		std::vector<double> vk(static_cast<size_t>(qq) * n_pcs);
+		for (uint32_t pc = 0; pc < n_pcs; pc++) {
+			const double l = lam[pc] > 0.0 ? lam[pc] : 0.0;
+			eigenvalues[pc] = l / m_total;
+			const double inv_s = l > 0.0 ? 1.0 / std::sqrt(l) : 0.0;
+			for (uint32_t i = 0; i < qq; i++) {
+				vk[static_cast<size_t>(i) * n_pcs + pc] = vec[static_cast<size_t>(i) * qq + pc] * inv_s;
+			}
+		}
+		PGH_HIP(hipMemcpyAsync(d_vk.p, vk.data(), sizeof(double) * vk.size(), hipMemcpyHostToDevice, st), "pca upload");
+		PGH_HIP(pgh::LaunchTallTimesSmall(d_bb.As<double>(), qq, qq, d_vk.As<double>(), n_pcs, n_pcs, 1.0, 0.0, nullptr, 0,
+		                                  d_uk.As<double>(), n_pcs, N, st),
+		        "pca eigenvectors");
+		std::vector<double> uk_raw(static_cast<size_t>(N) * n_pcs);
+		PGH_HIP(hipMemcpyAsync(uk_raw.data(), d_uk.p, sizeof(double) * uk_raw.size(), hipMemcpyDeviceToHost, st),
+		        "pca download");
+		PGH_HIP(hipStreamSynchronize(st), "pca sync");
+		Compact<double>(subset, uk_raw.data(), n_pcs, eigenvectors, N);
+	}
+	return PGH_OK;
+#undef PGH_SUM
+}
+
+// ---------------------------------------------------------------------------
+// plink_ld
+// ---------------------------------------------------------------------------
+
+extern "C" int pgh_ld_pairs(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_pairs, const uint32_t *vidx_a,
+                            const uint32_t *vidx_b, uint32_t (*sums)[6], char *errbuf) {
+	if (!ds || (n_pairs && (!vidx_a || !vidx_b || !sums))) {
+		SetErr(errbuf, "null argument");
+		return PGH_ERR_ARG;
+	}
+	int rc = CheckSubset(ds, subset, errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	if (n_pairs == 0) {
+		return PGH_OK;
+	}
+	// runs of pairs that share the anchor and step through consecutive partners become one
+	// task of up to four partners (the windowed scan produces exactly such runs)
+	std::vector<pgh::LdTask> tasks;
+	tasks.reserve(n_pairs / 2 + 1);
+	for (uint32_t p = 0; p < n_pairs; p++) {
+		const uint32_t a = vidx_a[p], b = vidx_b[p];
+		if (a < ds->v_begin || a >= ds->v_end || b < ds->v_begin || b >= ds->v_end) {
+			SetErr(errbuf, "variant index outside the resident range");
+			return PGH_ERR_ARG;
+		}
+		if (!tasks.empty()) {
+			pgh::LdTask &last = tasks.back();
+			if (last.n_b < 4 && last.a_row == a - ds->v_begin && last.b_row + last.n_b == b - ds->v_begin) {
+				last.n_b++;
+				continue;
+			}
+		}
+		tasks.push_back(pgh::LdTask {a - ds->v_begin, b - ds->v_begin, 1u, p});
+	}
+	hipStream_t st = hipStreamPerThread;
+	void *d_tasks = nullptr, *d_out = nullptr;
+	PGH_HIP(hipMallocAsync(&d_tasks, sizeof(pgh::LdTask) * tasks.size(), st), "ld scratch");
+	hipError_t e = hipMallocAsync(&d_out, 24ull * n_pairs, st);
+	if (e == hipSuccess) {
+		e = hipMemcpyAsync(d_tasks, tasks.data(), sizeof(pgh::LdTask) * tasks.size(), hipMemcpyHostToDevice, st);
+	}
+	if (e == hipSuccess) {
+		e = pgh::LaunchLdPairs(ds->View(), static_cast<const pgh::LdTask *>(d_tasks),
+		                       static_cast<uint32_t>(tasks.size()), subset ? subset->d_mask2 : nullptr,
+		                       static_cast<uint32_t(*)[6]>(d_out), st);
+	}
+	if (e == hipSuccess) {
+		e = hipMemcpyAsync(sums, d_out, 24ull * n_pairs, hipMemcpyDeviceToHost, st);
+	}
+	if (e == hipSuccess) {
+		e = hipStreamSynchronize(st); // `tasks` and `sums` are host memory of this frame / the caller
+	}
+	(void)hipFreeAsync(d_tasks, st);
+	if (d_out) {
+		(void)hipFreeAsync(d_out, st);
+	}
+	PGH_HIP(e, "ld pair kernel");
+	return PGH_OK;
+}

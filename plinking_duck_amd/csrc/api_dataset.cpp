@@ -1,0 +1,798 @@
+// api_dataset.cpp -- library/device entry points, datasets (open = header parse + staged ingest
+// with device record decode), synthetic data, sample subsets.
+#include "api_internal.hpp"
+
+// ---------------------------------------------------------------------------
+// library / device
+// ---------------------------------------------------------------------------
+
+extern "C" const char *pgh_version(void) {
+	return "pgenhip 1 gfx950";
+}
+
+extern "C" int pgh_device_count(void) {
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) {
+		return 0;
+	}
+	return n;
+}
+
+extern "C" int pgh_set_device(int device, char *errbuf) {
+	PGH_HIP(hipSetDevice(device), "hipSetDevice");
+	return PGH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// dataset lifecycle
+// ---------------------------------------------------------------------------
+
+static void FillInfo(const PgenIndex &ix, pgh_info *out) {
+	std::memset(out, 0, sizeof *out);
+	out->raw_variant_ct = ix.variant_ct;
+	out->raw_sample_ct = ix.sample_ct;
+	out->variant_begin = 0;
+	out->variant_end = ix.variant_ct;
+	out->has_dosage = ix.has_dosage;
+	out->has_phase = ix.has_phase;
+	out->max_record_bytes = ix.max_record_bytes;
+	out->record_bytes = ix.RecordBytes();
+	out->pitch_bytes = ChoosePitch(ix.RecordBytes());
+	for (int i = 0; i < 8; i++) {
+		out->vrtype_hist[i] = ix.vrtype_hist[i];
+	}
+	out->device = -1;
+}
+
+extern "C" int pgh_probe(const char *pgen_path, const char *pgi_path, pgh_info *out, char *errbuf) {
+	if (!pgen_path || !out) {
+		SetErr(errbuf, "null argument");
+		return PGH_ERR_ARG;
+	}
+	PgenIndex ix;
+	std::string err;
+	if (!pgh::ParsePgenIndex(pgen_path, pgi_path ? pgi_path : "", ix, err)) {
+		SetErr(errbuf, err);
+		return err.find("cannot open") != std::string::npos ? PGH_ERR_OPEN : PGH_ERR_FORMAT;
+	}
+	FillInfo(ix, out);
+	return PGH_OK;
+}
+
+// pgh_open's staging buffers (2 pinned + 2 device, 64 MB each) cost ~40 ms to allocate, more
+// than a small file takes to ingest: one set per device is parked here between opens.
+struct StageSet {
+	uint8_t *pinned[2] = {nullptr, nullptr};
+	uint8_t *device[2] = {nullptr, nullptr};
+	uint64_t bytes = 0;
+	int device_id = -1;
+	void Free() {
+		for (int i = 0; i < 2; i++) {
+			if (pinned[i]) {
+				(void)hipHostFree(pinned[i]);
+			}
+			if (device[i]) {
+				(void)hipFree(device[i]);
+			}
+			pinned[i] = device[i] = nullptr;
+		}
+		bytes = 0;
+	}
+};
+static std::mutex g_stage_mutex;
+static StageSet g_parked_stage;
+
+static hipError_t AcquireStage(uint64_t bytes, int device_id, bool want_device, StageSet &out) {
+	{
+		std::lock_guard<std::mutex> lock(g_stage_mutex);
+		if (g_parked_stage.bytes >= bytes && g_parked_stage.device_id == device_id) {
+			out = g_parked_stage;
+			g_parked_stage = StageSet();
+		}
+	}
+	out.device_id = device_id;
+	hipError_t e = hipSuccess;
+	for (int i = 0; i < 2 && e == hipSuccess; i++) {
+		if (!out.pinned[i]) {
+			e = hipHostMalloc(reinterpret_cast<void **>(&out.pinned[i]), bytes, hipHostMallocDefault);
+		}
+		if (e == hipSuccess && want_device && !out.device[i]) {
+			e = hipMalloc(reinterpret_cast<void **>(&out.device[i]), std::max(bytes, out.bytes));
+		}
+	}
+	out.bytes = std::max(bytes, out.bytes);
+	if (e != hipSuccess) {
+		out.Free();
+	}
+	return e;
+}
+
+static void ReleaseStage(StageSet &set) {
+	{
+		std::lock_guard<std::mutex> lock(g_stage_mutex);
+		if (g_parked_stage.bytes == 0 && set.bytes <= (64ull << 20) + 8192) {
+			g_parked_stage = set;
+			set = StageSet();
+			return;
+		}
+	}
+	set.Free();
+}
+
+// pread is the ceiling of the plain-record ingest path (one thread moves ~6 GB/s out of the
+// page cache); split a stage across a few threads.
+static bool ReadParallel(const pgh::RecordFile &file, uint64_t offset, size_t bytes, uint8_t *dst, std::string &err) {
+	constexpr size_t kMinSlice = 4u << 20;
+	const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+	const unsigned parts = static_cast<unsigned>(std::min<size_t>(std::min(8u, hw), std::max<size_t>(1, bytes / kMinSlice)));
+	if (parts <= 1) {
+		return file.ReadAt(offset, bytes, dst, err);
+	}
+	std::vector<std::thread> pool;
+	std::vector<std::string> errs(parts);
+	std::vector<char> ok(parts, 1);
+	const size_t slice = (bytes + parts - 1) / parts;
+	for (unsigned t = 0; t < parts; t++) {
+		const size_t lo = std::min(bytes, static_cast<size_t>(t) * slice);
+		const size_t hi = std::min(bytes, lo + slice);
+		pool.emplace_back([&, t, lo, hi] { ok[t] = file.ReadAt(offset + lo, hi - lo, dst + lo, errs[t]) ? 1 : 0; });
+	}
+	for (auto &th : pool) {
+		th.join();
+	}
+	for (unsigned t = 0; t < parts; t++) {
+		if (!ok[t]) {
+			err = errs[t];
+			return false;
+		}
+	}
+	return true;
+}
+
+// Host normalisation of compressed records, split over a few threads.  Each worker owns a
+// Normalizer (LD-base scratch) and a contiguous sub-range; a sub-range that starts inside an
+// LD run resolves its base by walking back, exactly as a range that starts mid-file does.
+static bool ExpandParallel(const pgh::PgenIndex &ix, const pgh::RecordFile &file, pgh::Normalizer &first,
+                           uint32_t v_begin, uint32_t v_end, uint8_t *dst, size_t pitch, std::string &err) {
+	constexpr uint32_t kMinRows = 64;
+	const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+	const uint32_t rows = v_end - v_begin;
+	const unsigned parts = std::min<unsigned>(std::min(8u, hw), std::max<uint32_t>(1, rows / kMinRows));
+	if (parts <= 1) {
+		return first.ExpandRange(v_begin, v_end, dst, pitch, err);
+	}
+	std::vector<std::thread> pool;
+	std::vector<std::string> errs(parts);
+	std::vector<char> ok(parts, 1);
+	const uint32_t slice = (rows + parts - 1) / parts;
+	for (unsigned t = 0; t < parts; t++) {
+		const uint32_t lo = std::min<uint64_t>(v_end, static_cast<uint64_t>(v_begin) + static_cast<uint64_t>(t) * slice);
+		const uint32_t hi = std::min<uint64_t>(v_end, static_cast<uint64_t>(lo) + slice);
+		pool.emplace_back([&, t, lo, hi] {
+			if (lo >= hi) {
+				return;
+			}
+			uint8_t *out = dst + static_cast<size_t>(lo - v_begin) * pitch;
+			if (t == 0) {
+				ok[t] = first.ExpandRange(lo, hi, out, pitch, errs[t]) ? 1 : 0;
+			} else {
+				pgh::Normalizer mine(ix, file);
+				ok[t] = mine.ExpandRange(lo, hi, out, pitch, errs[t]) ? 1 : 0;
+			}
+		});
+	}
+	for (auto &th : pool) {
+		th.join();
+	}
+	for (unsigned t = 0; t < parts; t++) {
+		if (!ok[t]) {
+			err = errs[t];
+			return false;
+		}
+	}
+	return true;
+}
+
+extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t variant_begin, uint32_t variant_end,
+                        pgh_dataset **out, char *errbuf) {
+	if (!pgen_path || !out) {
+		SetErr(errbuf, "null argument");
+		return PGH_ERR_ARG;
+	}
+	*out = nullptr;
+	std::unique_ptr<pgh_dataset> ds(new pgh_dataset());
+	std::string err;
+	if (!pgh::ParsePgenIndex(pgen_path, pgi_path ? pgi_path : "", ds->index, err)) {
+		SetErr(errbuf, err);
+		return err.find("cannot open") != std::string::npos ? PGH_ERR_OPEN : PGH_ERR_FORMAT;
+	}
+	const PgenIndex &ix = ds->index;
+	if (ix.has_multiallelic) {
+		SetErr(errbuf, "multiallelic hardcall tracks are not supported");
+		return PGH_ERR_UNSUPPORTED;
+	}
+	if (variant_end == UINT32_MAX) {
+		variant_end = ix.variant_ct;
+	}
+	if (variant_begin > variant_end || variant_end > ix.variant_ct) {
+		SetErr(errbuf, "variant range out of bounds");
+		return PGH_ERR_ARG;
+	}
+	ds->has_file = true;
+	ds->pgen_path = pgen_path;
+	ds->raw_variant_ct = ix.variant_ct;
+	ds->sample_ct = ix.sample_ct;
+	ds->record_bytes = ix.RecordBytes();
+	ds->pitch = ChoosePitch(ds->record_bytes);
+	ds->v_begin = variant_begin;
+	ds->v_end = variant_end;
+	PGH_HIP(hipGetDevice(&ds->device), "hipGetDevice");
+	int rc = AllocRows(ds.get(), errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+
+	// Stream the body through two pinned staging buffers, three ways per run of records:
+	//   plain   a long run of literal 2-bit records is already the row image: pread into the
+	//           pinned buffer, re-pitch on the copy engine;
+	//   device  anything else: the records' file bytes go up as they are and
+	//           k_decode_records expands them in HBM (decode.hip);
+	//   host    an LD run whose base lies before the opened range (or PGH_HOST_NORMALIZE=1):
+	//           the host normaliser expands rows, which are then copied.
+	pgh::RecordFile file;
+	if (!file.Open(pgen_path, err)) {
+		SetErr(errbuf, err);
+		pgh_close(ds.release());
+		return PGH_ERR_OPEN;
+	}
+	pgh::Normalizer norm(ix, file);
+	const char *trace_env = std::getenv("PGH_TRACE_OPEN");
+	const bool trace = trace_env && *trace_env && *trace_env != '0';
+	const auto t_start = std::chrono::steady_clock::now();
+	auto lap = [&](const char *what) {
+		if (trace) {
+			std::fprintf(stderr, "pgh_open: %-14s +%.2f ms\n", what,
+			             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+		}
+	};
+	const char *force_host = std::getenv("PGH_HOST_NORMALIZE");
+	const bool host_only = force_host && *force_host && *force_host != '0';
+	const uint32_t rb = ds->record_bytes;
+	auto is_ld = [&](uint32_t r) { return (ix.vrtype[r] & 6u) == 2u; }; // types 2 and 3
+	auto is_plain = [&](uint32_t r) { return ix.vrtype[r] == 0 && ix.offset[r + 1] - ix.offset[r] == rb; };
+	// plain_run[i]: length of the run of plain records starting at variant_begin + i
+	const uint32_t range = variant_end - variant_begin;
+	std::vector<uint32_t> plain_run(static_cast<size_t>(range) + 1, 0);
+	bool any_encoded = false;
+	for (uint32_t i = range; i-- > 0;) {
+		plain_run[i] = is_plain(variant_begin + i) ? plain_run[i + 1] + 1 : 0;
+		any_encoded |= plain_run[i] == 0;
+	}
+	constexpr uint32_t kMinPlainRun = 256; // shorter plain runs ride along with their encoded neighbours
+	const uint64_t stage_bytes = std::max<uint64_t>(64ull << 20, ds->pitch + 4096);
+	const uint32_t rows_per_stage = static_cast<uint32_t>(std::max<uint64_t>(1, stage_bytes / ds->pitch));
+	StageSet staging;
+	int *d_error = nullptr;
+	hipEvent_t done[2] = {nullptr, nullptr};
+	hipStream_t stream = nullptr;
+	auto cleanup = [&]() {
+		ReleaseStage(staging);
+		for (int i = 0; i < 2; i++) {
+			if (done[i]) {
+				(void)hipEventDestroy(done[i]);
+			}
+		}
+		if (d_error) {
+			(void)hipFree(d_error);
+		}
+		if (stream) {
+			(void)hipStreamDestroy(stream);
+		}
+	};
+	const bool device_decode = any_encoded && !host_only;
+	hipError_t e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+	if (e == hipSuccess) {
+		e = AcquireStage(stage_bytes, ds->device, device_decode, staging);
+	}
+	for (int i = 0; i < 2 && e == hipSuccess; i++) {
+		e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+	}
+	uint8_t *const *stage = staging.pinned;
+	uint8_t *const *d_stage = staging.device;
+	if (e == hipSuccess && device_decode) {
+		e = hipMalloc(reinterpret_cast<void **>(&d_error), sizeof(int));
+		if (e == hipSuccess) {
+			e = hipMemsetAsync(d_error, 0, sizeof(int), stream);
+		}
+	}
+	if (e != hipSuccess) {
+		cleanup();
+		pgh_close(ds.release());
+		return DeviceFail(errbuf, "staging setup", e);
+	}
+	lap("staging ready");
+	auto fail = [&](int code, const std::string &msg) {
+		(void)hipStreamSynchronize(stream);
+		cleanup();
+		SetErr(errbuf, msg);
+		pgh_close(ds.release());
+		return code;
+	};
+	int which = 0;
+	bool used[2] = {false, false};
+	int64_t last_base = -1; // most recent non-LD variant inside the opened range
+	uint32_t v = variant_begin;
+	while (v < variant_end) {
+		if (used[which]) {
+			e = hipEventSynchronize(done[which]);
+			if (e != hipSuccess) {
+				break;
+			}
+		}
+		uint8_t *d_dst = ds->d_rows + static_cast<uint64_t>(v - variant_begin) * ds->pitch;
+		const uint32_t room = std::min<uint64_t>(rows_per_stage, variant_end - v);
+		const uint32_t run = plain_run[v - variant_begin];
+		uint32_t stop = v;
+		if (!host_only && run > 0 && (run >= kMinPlainRun || run >= variant_end - v)) {
+			stop = v + std::min(run, room);
+			if (!ReadParallel(file, ix.offset[v], static_cast<size_t>(stop - v) * rb, stage[which], err)) {
+				return fail(PGH_ERR_OPEN, err);
+			}
+			e = hipMemsetAsync(d_dst, 0, static_cast<size_t>(stop - v) * ds->pitch, stream);
+			if (e == hipSuccess) {
+				e = hipMemcpy2DAsync(d_dst, ds->pitch, stage[which], rb, rb, stop - v, hipMemcpyHostToDevice, stream);
+			}
+			if (e == hipSuccess) {
+				e = pgh::LaunchSanitizeTail(d_dst, ds->pitch, ds->sample_ct, stop - v, stream);
+			}
+			last_base = static_cast<int64_t>(stop) - 1;
+		} else {
+			// how many records fit as raw bytes + their tables?
+			uint32_t n = 0;
+			uint64_t raw = 0;
+			if (!host_only && !(is_ld(v) && last_base < 0)) {
+				// the stage holds file bytes here, not rows: only its byte budget limits the run
+				const uint32_t left = variant_end - v;
+				while (n < left) {
+					const uint32_t r = v + n;
+					if (n > 0 && plain_run[r - variant_begin] >= kMinPlainRun) {
+						break;
+					}
+					const uint64_t len = ix.offset[r + 1] - ix.offset[r];
+					if (raw + len + 64 + 13ull * (n + 2) > stage_bytes) {
+						break;
+					}
+					raw += len;
+					n++;
+				}
+			}
+			if (n == 0) {
+				// host rows: everything under PGH_HOST_NORMALIZE, an LD run without a resident base,
+				// or one record too large to stage
+				stop = v + 1;
+				if (host_only) {
+					stop = v + room;
+				} else {
+					while (stop < v + room && is_ld(stop) && last_base < 0) {
+						stop++;
+					}
+				}
+				if (!ExpandParallel(ix, file, norm, v, stop, stage[which], ds->pitch, err)) {
+					return fail(PGH_ERR_FORMAT, err);
+				}
+				e = hipMemcpyAsync(d_dst, stage[which], static_cast<size_t>(stop - v) * ds->pitch,
+				                   hipMemcpyHostToDevice, stream);
+				for (uint32_t r = v; r < stop; r++) {
+					if (!is_ld(r)) {
+						last_base = r;
+					}
+				}
+			} else {
+				stop = v + n;
+				uint8_t *h = stage[which];
+				if (!ReadParallel(file, ix.offset[v], raw, h, err)) {
+					return fail(PGH_ERR_OPEN, err);
+				}
+				const uint64_t tables = (raw + 16 + 15) & ~15ull; // 16 zero bytes the kernel may read past the end
+				std::memset(h + raw, 0, tables - raw);
+				uint64_t *rec_begin = reinterpret_cast<uint64_t *>(h + tables);
+				uint32_t *ld_row = reinterpret_cast<uint32_t *>(rec_begin + (n + 1));
+				uint8_t *vrtype = reinterpret_cast<uint8_t *>(ld_row + n);
+				bool any_ld = false;
+				for (uint32_t i = 0; i < n; i++) {
+					const uint32_t r = v + i;
+					rec_begin[i] = ix.offset[r] - ix.offset[v];
+					vrtype[i] = ix.vrtype[r];
+					if (is_ld(r)) {
+						any_ld = true;
+						ld_row[i] = last_base < 0 ? 0xffffffffu : static_cast<uint32_t>(last_base - variant_begin);
+					} else {
+						ld_row[i] = 0;
+						last_base = r;
+					}
+				}
+				rec_begin[n] = raw;
+				const uint64_t used_bytes = tables + 8ull * (n + 1) + 4ull * n + n;
+				e = hipMemcpyAsync(d_stage[which], h, used_bytes, hipMemcpyHostToDevice, stream);
+				if (e == hipSuccess) {
+					pgh::DecodeBatch batch;
+					batch.bytes = d_stage[which];
+					batch.bytes_len = raw;
+					batch.rec_begin = reinterpret_cast<const uint64_t *>(d_stage[which] + tables);
+					batch.ld_row = reinterpret_cast<const uint32_t *>(batch.rec_begin + (n + 1));
+					batch.vrtype = reinterpret_cast<const uint8_t *>(batch.ld_row + n);
+					batch.rows = ds->d_rows;
+					batch.pitch = ds->pitch;
+					batch.row0 = v - variant_begin;
+					batch.variant0 = v;
+					batch.n = n;
+					batch.sample_ct = ds->sample_ct;
+					batch.id_bytes = ix.sample_id_bytes;
+					batch.error = d_error;
+					e = pgh::LaunchDecodeRecords(batch, any_ld, stream);
+				}
+			}
+		}
+		if (e == hipSuccess) {
+			e = hipEventRecord(done[which], stream);
+		}
+		if (e != hipSuccess) {
+			break;
+		}
+		used[which] = true;
+		which ^= 1;
+		v = stop;
+	}
+	lap("runs enqueued");
+	int bad_variant = 0;
+	if (e == hipSuccess && d_error) {
+		e = hipMemcpyAsync(&bad_variant, d_error, sizeof(int), hipMemcpyDeviceToHost, stream);
+	}
+	if (e == hipSuccess) {
+		e = hipStreamSynchronize(stream);
+	}
+	lap("stream drained");
+	cleanup();
+	lap("staging freed");
+	if (e != hipSuccess) {
+		pgh_close(ds.release());
+		return DeviceFail(errbuf, "genotype upload", e);
+	}
+	if (bad_variant != 0) {
+		SetErr(errbuf, "malformed variant record " + std::to_string(bad_variant - 1));
+		pgh_close(ds.release());
+		return PGH_ERR_FORMAT;
+	}
+	*out = ds.release();
+	return PGH_OK;
+}
+
+extern "C" int pgh_normalize_range_host(const char *pgen_path, const char *pgi_path, uint32_t variant_begin,
+                                        uint32_t variant_end, uint8_t *rows, size_t row_stride, char *errbuf) {
+	if (!pgen_path || (!rows && variant_end > variant_begin)) {
+		SetErr(errbuf, "null argument");
+		return PGH_ERR_ARG;
+	}
+	PgenIndex ix;
+	std::string err;
+	if (!pgh::ParsePgenIndex(pgen_path, pgi_path ? pgi_path : "", ix, err)) {
+		SetErr(errbuf, err);
+		return err.find("cannot open") != std::string::npos ? PGH_ERR_OPEN : PGH_ERR_FORMAT;
+	}
+	if (variant_end == UINT32_MAX) {
+		variant_end = ix.variant_ct;
+	}
+	if (variant_begin > variant_end || variant_end > ix.variant_ct || row_stride < ix.RecordBytes()) {
+		SetErr(errbuf, "variant range or row_stride out of bounds");
+		return PGH_ERR_ARG;
+	}
+	pgh::RecordFile file;
+	if (!file.Open(pgen_path, err)) {
+		SetErr(errbuf, err);
+		return PGH_ERR_OPEN;
+	}
+	pgh::Normalizer norm(ix, file);
+	if (!norm.ExpandRange(variant_begin, variant_end, rows, row_stride, err)) {
+		SetErr(errbuf, err);
+		return PGH_ERR_FORMAT;
+	}
+	return PGH_OK;
+}
+
+extern "C" int pgh_from_host_rows(const uint8_t *rows, size_t row_stride, uint32_t variant_ct, uint32_t sample_ct,
+                                  pgh_dataset **out, char *errbuf) {
+	if (!out || (!rows && variant_ct) || sample_ct == 0) {
+		SetErr(errbuf, "bad argument");
+		return PGH_ERR_ARG;
+	}
+	*out = nullptr;
+	std::unique_ptr<pgh_dataset> ds(new pgh_dataset());
+	ds->raw_variant_ct = variant_ct;
+	ds->sample_ct = sample_ct;
+	ds->record_bytes = (sample_ct + 3) / 4;
+	ds->pitch = ChoosePitch(ds->record_bytes);
+	ds->v_begin = 0;
+	ds->v_end = variant_ct;
+	if (row_stride < ds->record_bytes) {
+		SetErr(errbuf, "row_stride smaller than ceil(N/4)");
+		return PGH_ERR_ARG;
+	}
+	PGH_HIP(hipGetDevice(&ds->device), "hipGetDevice");
+	int rc = AllocRows(ds.get(), errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	if (variant_ct) {
+		hipError_t e = hipMemset(ds->d_rows, 0, static_cast<size_t>(variant_ct) * ds->pitch);
+		if (e == hipSuccess) {
+			e = hipMemcpy2D(ds->d_rows, ds->pitch, rows, row_stride, ds->record_bytes, variant_ct,
+			                hipMemcpyHostToDevice);
+		}
+		if (e == hipSuccess) {
+			e = pgh::LaunchSanitizeTail(ds->d_rows, ds->pitch, sample_ct, variant_ct, nullptr);
+		}
+		if (e == hipSuccess) {
+			e = hipDeviceSynchronize();
+		}
+		if (e != hipSuccess) {
+			pgh_close(ds.release());
+			return DeviceFail(errbuf, "row upload", e);
+		}
+	}
+	*out = ds.release();
+	return PGH_OK;
+}
+
+extern "C" int pgh_synth_create(uint32_t variant_begin, uint32_t variant_end, uint32_t sample_ct, uint64_t seed,
+                                double missing_rate, pgh_dataset **out, char *errbuf) {
+	if (!out || variant_begin > variant_end || sample_ct == 0) {
+		SetErr(errbuf, "bad argument");
+		return PGH_ERR_ARG;
+	}
+	*out = nullptr;
+	std::unique_ptr<pgh_dataset> ds(new pgh_dataset());
+	ds->raw_variant_ct = variant_end;
+	ds->sample_ct = sample_ct;
+	ds->record_bytes = (sample_ct + 3) / 4;
+	ds->pitch = ChoosePitch(ds->record_bytes);
+	ds->v_begin = variant_begin;
+	ds->v_end = variant_end;
+	PGH_HIP(hipGetDevice(&ds->device), "hipGetDevice");
+	int rc = AllocRows(ds.get(), errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	hipError_t e = pgh::LaunchSynthFill(ds->d_rows, ds->pitch, sample_ct, variant_begin, variant_end - variant_begin,
+	                                    seed, pgh::SynthMissThreshold(missing_rate), nullptr);
+	if (e == hipSuccess) {
+		e = hipDeviceSynchronize();
+	}
+	if (e != hipSuccess) {
+		pgh_close(ds.release());
+		return DeviceFail(errbuf, "synthetic fill", e);
+	}
+	*out = ds.release();
+	return PGH_OK;
+}
+
+extern "C" int pgh_synth_record_host(uint32_t v, uint32_t sample_ct, uint64_t seed, double missing_rate,
+                                     uint8_t *out) {
+	if (!out || sample_ct == 0) {
+		return PGH_ERR_ARG;
+	}
+	const uint32_t thr = pgh::SynthMissThreshold(missing_rate);
+	const pgh::SynthVariant sv = pgh::SynthVariantParams(seed, v);
+	std::memset(out, 0, (static_cast<size_t>(sample_ct) + 3) / 4);
+	for (uint32_t s = 0; s < sample_ct; s++) {
+		out[s >> 2] |= static_cast<uint8_t>(pgh::SynthGenotype(sv, s, thr) << (2 * (s & 3)));
+	}
+	return PGH_OK;
+}
+
+extern "C" int pgh_synth_write_files(const char *prefix, uint32_t variant_ct, uint32_t sample_ct, uint64_t seed,
+                                     double missing_rate, char *errbuf) {
+	if (!prefix || sample_ct == 0) {
+		SetErr(errbuf, "bad argument");
+		return PGH_ERR_ARG;
+	}
+	const std::string base(prefix);
+	const uint32_t rb = (sample_ct + 3) / 4;
+	if (rb > 0xffffffu) {
+		SetErr(errbuf, "sample count too large for 3-byte record lengths");
+		return PGH_ERR_ARG;
+	}
+	FILE *f = std::fopen((base + ".pgen").c_str(), "wb");
+	if (!f) {
+		SetErr(errbuf, "cannot create '" + base + ".pgen'");
+		return PGH_ERR_OPEN;
+	}
+	// mode 0x10; ctrl: 4-bit vrtypes + the narrowest record-length width, nonref mode 1
+	const uint32_t len_bytes = rb < 0x100 ? 1 : (rb < 0x10000 ? 2 : 3);
+	const uint8_t ctrl = static_cast<uint8_t>(0x40 | (len_bytes - 1));
+	std::vector<uint8_t> head = {0x6c, 0x1b, 0x10};
+	auto put = [&](uint64_t v, int n) {
+		for (int i = 0; i < n; i++) {
+			head.push_back(static_cast<uint8_t>(v >> (8 * i)));
+		}
+	};
+	put(variant_ct, 4);
+	put(sample_ct, 4);
+	head.push_back(ctrl);
+	const uint32_t blocks = (variant_ct + 65535) / 65536;
+	uint64_t table_bytes = 12 + 8ull * blocks;
+	for (uint32_t b = 0; b < blocks; b++) {
+		const uint32_t cnt = std::min<uint32_t>(65536, variant_ct - b * 65536u);
+		table_bytes += (cnt + 1) / 2 + static_cast<uint64_t>(cnt) * len_bytes;
+	}
+	for (uint32_t b = 0; b < blocks; b++) {
+		put(table_bytes + static_cast<uint64_t>(b) * 65536ull * rb, 8);
+	}
+	for (uint32_t b = 0; b < blocks; b++) {
+		const uint32_t cnt = std::min<uint32_t>(65536, variant_ct - b * 65536u);
+		head.insert(head.end(), (cnt + 1) / 2, 0); // vrtype 0
+		for (uint32_t i = 0; i < cnt; i++) {
+			put(rb, static_cast<int>(len_bytes));
+		}
+	}
+	bool ok = std::fwrite(head.data(), 1, head.size(), f) == head.size();
+	// records are generated on the host (no GPU needed to make a fixture), a block of rows at a
+	// time over a few threads
+	const uint32_t workers = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+	const uint32_t block_rows = static_cast<uint32_t>(std::max<uint64_t>(workers, (32ull << 20) / rb));
+	std::vector<uint8_t> block(static_cast<size_t>(block_rows) * rb);
+	for (uint32_t v0 = 0; ok && v0 < variant_ct; v0 += block_rows) {
+		const uint32_t n = std::min(block_rows, variant_ct - v0);
+		std::vector<std::thread> pool;
+		for (uint32_t t = 0; t < workers; t++) {
+			pool.emplace_back([&, t] {
+				for (uint32_t i = t; i < n; i += workers) {
+					pgh_synth_record_host(v0 + i, sample_ct, seed, missing_rate, block.data() + static_cast<size_t>(i) * rb);
+				}
+			});
+		}
+		for (auto &th : pool) {
+			th.join();
+		}
+		ok = std::fwrite(block.data(), 1, static_cast<size_t>(n) * rb, f) == static_cast<size_t>(n) * rb;
+	}
+	ok = (std::fclose(f) == 0) && ok;
+	if (!ok) {
+		SetErr(errbuf, "write failed on '" + base + ".pgen'");
+		return PGH_ERR_OPEN;
+	}
+	f = std::fopen((base + ".pvar").c_str(), "w");
+	if (!f) {
+		SetErr(errbuf, "cannot create '" + base + ".pvar'");
+		return PGH_ERR_OPEN;
+	}
+	std::fprintf(f, "#CHROM\tPOS\tID\tREF\tALT\n");
+	for (uint32_t v = 0; v < variant_ct; v++) {
+		// 22 autosomes, equal-sized runs, ascending positions
+		const uint32_t per_chrom = (variant_ct + 21) / 22;
+		std::fprintf(f, "%u\t%u\tsv%u\tA\tG\n", v / per_chrom + 1, (v % per_chrom + 1) * 100, v);
+	}
+	std::fclose(f);
+	f = std::fopen((base + ".psam").c_str(), "w");
+	if (!f) {
+		SetErr(errbuf, "cannot create '" + base + ".psam'");
+		return PGH_ERR_OPEN;
+	}
+	std::fprintf(f, "#FID\tIID\tSEX\n");
+	for (uint32_t s = 0; s < sample_ct; s++) {
+		std::fprintf(f, "F%u\tS%u\t%u\n", s / 4, s, 1 + (s & 1));
+	}
+	std::fclose(f);
+	return PGH_OK;
+}
+
+extern "C" int pgh_copy_rows_to_host(const pgh_dataset *ds, uint32_t v_begin, uint32_t v_end, uint8_t *rows,
+                                     size_t row_stride, char *errbuf) {
+	int rc = CheckRange(ds, v_begin, v_end, errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	if (v_end == v_begin) {
+		return PGH_OK;
+	}
+	if (!rows || row_stride < ds->record_bytes) {
+		SetErr(errbuf, "bad destination");
+		return PGH_ERR_ARG;
+	}
+	PGH_HIP(hipMemcpy2D(rows, row_stride, ds->d_rows + static_cast<uint64_t>(v_begin - ds->v_begin) * ds->pitch,
+	                    ds->pitch, ds->record_bytes, v_end - v_begin, hipMemcpyDeviceToHost),
+	        "row download");
+	return PGH_OK;
+}
+
+extern "C" int pgh_get_info(const pgh_dataset *ds, pgh_info *out) {
+	if (!ds || !out) {
+		return PGH_ERR_ARG;
+	}
+	if (ds->has_file) {
+		FillInfo(ds->index, out);
+	} else {
+		std::memset(out, 0, sizeof *out);
+		out->raw_variant_ct = ds->raw_variant_ct;
+		out->raw_sample_ct = ds->sample_ct;
+		out->record_bytes = ds->record_bytes;
+		out->max_record_bytes = ds->record_bytes;
+		out->vrtype_hist[0] = ds->v_end - ds->v_begin;
+	}
+	out->variant_begin = ds->v_begin;
+	out->variant_end = ds->v_end;
+	out->pitch_bytes = ds->pitch;
+	out->device = ds->device;
+	return PGH_OK;
+}
+
+extern "C" const void *pgh_device_rows(const pgh_dataset *ds) {
+	return ds ? ds->d_rows : nullptr;
+}
+
+extern "C" void pgh_close(pgh_dataset *ds) {
+	if (!ds) {
+		return;
+	}
+	if (ds->d_rows) {
+		(void)hipFree(ds->d_rows);
+	}
+	delete ds;
+}
+
+// ---------------------------------------------------------------------------
+// sample subsets
+// ---------------------------------------------------------------------------
+
+extern "C" int pgh_subset_create(const pgh_dataset *ds, const uint64_t *sample_include, pgh_subset **out,
+                                 char *errbuf) {
+	if (!ds || !sample_include || !out) {
+		SetErr(errbuf, "null argument");
+		return PGH_ERR_ARG;
+	}
+	*out = nullptr;
+	std::unique_ptr<pgh_subset> ss(new pgh_subset());
+	ss->ds = ds;
+	const uint32_t N = ds->sample_ct;
+	ss->include.assign(sample_include, sample_include + (N + 63) / 64);
+	std::vector<uint8_t> mask2(ds->pitch, 0);
+	for (uint32_t s = 0; s < N; s++) {
+		if ((ss->include[s >> 6] >> (s & 63)) & 1ull) {
+			ss->sel.push_back(s);
+			mask2[s >> 2] |= static_cast<uint8_t>(1u << (2 * (s & 3)));
+		}
+	}
+	ss->n_out = static_cast<uint32_t>(ss->sel.size());
+	hipError_t e = hipMalloc(reinterpret_cast<void **>(&ss->d_mask2), ds->pitch);
+	if (e == hipSuccess) {
+		e = hipMemcpy(ss->d_mask2, mask2.data(), ds->pitch, hipMemcpyHostToDevice);
+	}
+	if (e == hipSuccess) {
+		e = hipMalloc(reinterpret_cast<void **>(&ss->d_sel), sizeof(uint32_t) * std::max<uint32_t>(1, ss->n_out));
+	}
+	if (e == hipSuccess && ss->n_out) {
+		e = hipMemcpy(ss->d_sel, ss->sel.data(), sizeof(uint32_t) * ss->n_out, hipMemcpyHostToDevice);
+	}
+	if (e != hipSuccess) {
+		pgh_subset_destroy(ss.release());
+		return DeviceFail(errbuf, "subset upload", e);
+	}
+	*out = ss.release();
+	return PGH_OK;
+}
+
+extern "C" uint32_t pgh_subset_size(const pgh_subset *ss) {
+	return ss ? ss->n_out : 0;
+}
+
+extern "C" void pgh_subset_destroy(pgh_subset *ss) {
+	if (!ss) {
+		return;
+	}
+	if (ss->d_mask2) {
+		(void)hipFree(ss->d_mask2);
+	}
+	if (ss->d_sel) {
+		(void)hipFree(ss->d_sel);
+	}
+	delete ss;
+}

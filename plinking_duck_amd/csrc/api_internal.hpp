@@ -1,0 +1,169 @@
+// api_internal.hpp -- handle types and small helpers shared by the api_*.cpp files (the C ABI
+// of include/pgenhip.h).  Host code only; the kernels live in the *.hip files.
+#pragma once
+
+#include "../../include/pgenhip.h"
+
+#include "hwe_core.hpp"
+#include "decode.hpp"
+#include "kernels.hpp"
+#include "ld.hpp"
+#include "linalg.hpp"
+#include "pgen_file.hpp"
+#include "synth.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <chrono>
+#include <thread>
+#include <vector>
+
+using pgh::PgenIndex;
+using pgh::RowView;
+
+// ---------------------------------------------------------------------------
+// handle types
+// ---------------------------------------------------------------------------
+
+struct pgh_dataset {
+	int device = 0;
+	bool has_file = false;
+	std::string pgen_path;
+	PgenIndex index; // valid when has_file
+	uint32_t raw_variant_ct = 0;
+	uint32_t sample_ct = 0;
+	uint32_t record_bytes = 0;
+	uint32_t v_begin = 0; // resident range
+	uint32_t v_end = 0;
+	uint64_t pitch = 0;
+	uint8_t *d_rows = nullptr;
+
+	RowView View() const {
+		return RowView {d_rows, pitch, sample_ct, record_bytes};
+	}
+};
+
+struct pgh_subset {
+	const pgh_dataset *ds = nullptr;
+	uint32_t n_out = 0;
+	std::vector<uint64_t> include; // ceil(N/64) words
+	std::vector<uint32_t> sel;     // raw index of each included sample, ascending
+	uint8_t *d_mask2 = nullptr;    // one pitched row of 01 slots
+	uint32_t *d_sel = nullptr;
+};
+
+struct pgh_reader {
+	const pgh_dataset *ds = nullptr;
+	const pgh_subset *subset = nullptr;
+	hipStream_t stream = nullptr;
+	// counts window: one launch serves the next kWindow per-variant calls
+	static constexpr uint32_t kWindow = 128; // the reference's claim batch (src/plink_freq.cpp:413)
+	uint32_t win_begin = 0, win_end = 0;
+	uint32_t *d_counts = nullptr;
+	uint32_t *h_counts = nullptr; // pinned
+	uint8_t *h_row = nullptr;     // pinned, pitch bytes
+	std::unique_ptr<pgh::RecordFile> file;
+	std::unique_ptr<pgh::Normalizer> norm;
+	std::string err;
+};
+
+namespace {
+
+[[maybe_unused]] void SetErr(char *errbuf, const std::string &msg) {
+	if (errbuf) {
+		std::snprintf(errbuf, PGH_ERRBUF_LEN, "%s", msg.c_str());
+	}
+}
+
+[[maybe_unused]] int DeviceFail(char *errbuf, const char *what, hipError_t e) {
+	SetErr(errbuf, std::string(what) + ": " + hipGetErrorString(e));
+	return PGH_ERR_DEVICE;
+}
+
+#define PGH_HIP(call, what)                                                                                            \
+	do {                                                                                                               \
+		hipError_t e_ = (call);                                                                                        \
+		if (e_ != hipSuccess) {                                                                                        \
+			return DeviceFail(errbuf, what, e_);                                                                       \
+		}                                                                                                              \
+	} while (0)
+
+[[maybe_unused]] uint64_t ChoosePitch(uint32_t record_bytes) {
+	// whole 16-byte lanes always; 128-byte (cache line) aligned rows once rows are long
+	const uint64_t align = record_bytes >= 512 ? 128 : 16;
+	uint64_t p = (static_cast<uint64_t>(record_bytes) + align - 1) / align * align;
+	return p ? p : align;
+}
+
+// RAII device buffer for the host-output entry points
+struct DevBuf {
+	void *p = nullptr;
+	~DevBuf() {
+		if (p) {
+			(void)hipFree(p);
+		}
+	}
+	hipError_t Alloc(size_t bytes) {
+		return hipMalloc(&p, bytes ? bytes : 16);
+	}
+	template <class T>
+	T *As() {
+		return static_cast<T *>(p);
+	}
+};
+
+[[maybe_unused]] int CheckRange(const pgh_dataset *ds, uint32_t v_begin, uint32_t v_end, char *errbuf) {
+	if (!ds) {
+		SetErr(errbuf, "null dataset");
+		return PGH_ERR_ARG;
+	}
+	if (v_begin > v_end || v_begin < ds->v_begin || v_end > ds->v_end) {
+		char msg[160];
+		std::snprintf(msg, sizeof msg, "variant range [%u, %u) is outside the resident range [%u, %u)", v_begin, v_end,
+		              ds->v_begin, ds->v_end);
+		SetErr(errbuf, msg);
+		return PGH_ERR_ARG;
+	}
+	return PGH_OK;
+}
+
+[[maybe_unused]] int CheckSubset(const pgh_dataset *ds, const pgh_subset *ss, char *errbuf) {
+	if (ss && ss->ds != ds) {
+		SetErr(errbuf, "sample subset belongs to a different dataset");
+		return PGH_ERR_ARG;
+	}
+	return PGH_OK;
+}
+
+// compact `raw` (one value per raw sample) to the included samples
+template <class T>
+[[maybe_unused]] void Compact(const pgh_subset *ss, const T *raw, size_t stride, T *out, uint32_t n_raw) {
+	if (!ss) {
+		for (uint32_t s = 0; s < n_raw; s++) {
+			std::memcpy(out + static_cast<size_t>(s) * stride, raw + static_cast<size_t>(s) * stride,
+			            sizeof(T) * stride);
+		}
+		return;
+	}
+	for (uint32_t k = 0; k < ss->n_out; k++) {
+		std::memcpy(out + static_cast<size_t>(k) * stride, raw + static_cast<size_t>(ss->sel[k]) * stride,
+		            sizeof(T) * stride);
+	}
+}
+
+[[maybe_unused]] int AllocRows(pgh_dataset *ds, char *errbuf) {
+	const uint64_t rows = ds->v_end - ds->v_begin;
+	const uint64_t bytes = rows * ds->pitch;
+	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_rows), bytes ? bytes : 16), "hipMalloc(genotype rows)");
+	return PGH_OK;
+}
+
+} // namespace
+

@@ -1,0 +1,312 @@
+// api_reader.cpp -- the per-variant reader calls that mirror pgenlib (PgrGetCounts, PgrGet, ...)
+// and the exact-test entry points.
+#include "api_internal.hpp"
+
+// ---------------------------------------------------------------------------
+// per-variant reader
+// ---------------------------------------------------------------------------
+
+extern "C" int pgh_reader_create(const pgh_dataset *ds, const pgh_subset *subset, pgh_reader **out, char *errbuf) {
+	if (!ds || !out) {
+		SetErr(errbuf, "null argument");
+		return PGH_ERR_ARG;
+	}
+	*out = nullptr;
+	int rc = CheckSubset(ds, subset, errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	std::unique_ptr<pgh_reader> rd(new pgh_reader());
+	rd->ds = ds;
+	rd->subset = subset;
+	hipError_t e = hipStreamCreateWithFlags(&rd->stream, hipStreamNonBlocking);
+	if (e == hipSuccess) {
+		e = hipMalloc(reinterpret_cast<void **>(&rd->d_counts), 16 * pgh_reader::kWindow);
+	}
+	if (e == hipSuccess) {
+		e = hipHostMalloc(reinterpret_cast<void **>(&rd->h_counts), 16 * pgh_reader::kWindow, hipHostMallocDefault);
+	}
+	if (e == hipSuccess) {
+		e = hipHostMalloc(reinterpret_cast<void **>(&rd->h_row), ds->pitch, hipHostMallocDefault);
+	}
+	if (e != hipSuccess) {
+		pgh_reader_destroy(rd.release());
+		return DeviceFail(errbuf, "reader setup", e);
+	}
+	if (ds->has_file && (ds->index.has_dosage || ds->index.has_phase)) {
+		rd->file.reset(new pgh::RecordFile());
+		std::string err;
+		if (!rd->file->Open(ds->pgen_path, err)) {
+			SetErr(errbuf, err);
+			pgh_reader_destroy(rd.release());
+			return PGH_ERR_OPEN;
+		}
+		rd->norm.reset(new pgh::Normalizer(ds->index, *rd->file));
+	}
+	*out = rd.release();
+	return PGH_OK;
+}
+
+extern "C" void pgh_reader_destroy(pgh_reader *rd) {
+	if (!rd) {
+		return;
+	}
+	if (rd->stream) {
+		(void)hipStreamSynchronize(rd->stream);
+	}
+	if (rd->d_counts) {
+		(void)hipFree(rd->d_counts);
+	}
+	if (rd->h_counts) {
+		(void)hipHostFree(rd->h_counts);
+	}
+	if (rd->h_row) {
+		(void)hipHostFree(rd->h_row);
+	}
+	if (rd->stream) {
+		(void)hipStreamDestroy(rd->stream);
+	}
+	delete rd;
+}
+
+extern "C" const char *pgh_reader_error(const pgh_reader *rd) {
+	return rd ? rd->err.c_str() : "null reader";
+}
+
+namespace {
+
+int ReaderFail(pgh_reader *rd, int code, const std::string &msg) {
+	rd->err = msg;
+	return code;
+}
+
+int ReaderCheck(pgh_reader *rd, uint32_t vidx) {
+	if (!rd) {
+		return PGH_ERR_ARG;
+	}
+	if (vidx < rd->ds->v_begin || vidx >= rd->ds->v_end) {
+		return ReaderFail(rd, PGH_ERR_ARG, "variant index " + std::to_string(vidx) + " outside the resident range");
+	}
+	return PGH_OK;
+}
+
+// raw 2-bit row of one variant -> pinned host buffer
+int FetchRow(pgh_reader *rd, uint32_t vidx) {
+	const pgh_dataset *ds = rd->ds;
+	hipError_t e = hipMemcpyAsync(rd->h_row, ds->d_rows + static_cast<uint64_t>(vidx - ds->v_begin) * ds->pitch,
+	                              ds->record_bytes, hipMemcpyDeviceToHost, rd->stream);
+	if (e == hipSuccess) {
+		e = hipStreamSynchronize(rd->stream);
+	}
+	if (e != hipSuccess) {
+		return ReaderFail(rd, PGH_ERR_DEVICE, std::string("row fetch: ") + hipGetErrorString(e));
+	}
+	return PGH_OK;
+}
+
+inline uint32_t RowCode(const uint8_t *row, uint32_t s) {
+	return (row[s >> 2] >> (2 * (s & 3))) & 3u;
+}
+
+template <class Fn>
+void ForEachIncluded(const pgh_reader *rd, Fn &&fn) {
+	if (rd->subset) {
+		for (uint32_t k = 0; k < rd->subset->n_out; k++) {
+			fn(k, rd->subset->sel[k]);
+		}
+	} else {
+		for (uint32_t s = 0; s < rd->ds->sample_ct; s++) {
+			fn(s, s);
+		}
+	}
+}
+
+} // namespace
+
+extern "C" int pgh_get_counts(pgh_reader *rd, uint32_t vidx, uint32_t out[4]) {
+	int rc = ReaderCheck(rd, vidx);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	if (vidx < rd->win_begin || vidx >= rd->win_end) {
+		const pgh_dataset *ds = rd->ds;
+		const uint32_t stop = std::min<uint64_t>(ds->v_end, static_cast<uint64_t>(vidx) + pgh_reader::kWindow);
+		char errbuf[PGH_ERRBUF_LEN];
+		rc = pgh_counts_range_dev(ds, rd->subset, vidx, stop, rd->d_counts, rd->stream, errbuf);
+		if (rc != PGH_OK) {
+			return ReaderFail(rd, rc, errbuf);
+		}
+		hipError_t e = hipMemcpyAsync(rd->h_counts, rd->d_counts, 16ull * (stop - vidx), hipMemcpyDeviceToHost,
+		                              rd->stream);
+		if (e == hipSuccess) {
+			e = hipStreamSynchronize(rd->stream);
+		}
+		if (e != hipSuccess) {
+			rd->win_begin = rd->win_end = 0;
+			return ReaderFail(rd, PGH_ERR_DEVICE, std::string("counts fetch: ") + hipGetErrorString(e));
+		}
+		rd->win_begin = vidx;
+		rd->win_end = stop;
+	}
+	std::memcpy(out, rd->h_counts + 4 * static_cast<size_t>(vidx - rd->win_begin), 16);
+	return PGH_OK;
+}
+
+extern "C" int pgh_get_2bit(pgh_reader *rd, uint32_t vidx, uint64_t *genovec) {
+	int rc = ReaderCheck(rd, vidx);
+	if (rc == PGH_OK) {
+		rc = FetchRow(rd, vidx);
+	}
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	const uint32_t n_out = rd->subset ? rd->subset->n_out : rd->ds->sample_ct;
+	std::memset(genovec, 0, sizeof(uint64_t) * ((n_out + 31) / 32));
+	ForEachIncluded(rd, [&](uint32_t k, uint32_t s) {
+		genovec[k >> 5] |= static_cast<uint64_t>(RowCode(rd->h_row, s)) << (2 * (k & 31));
+	});
+	return PGH_OK;
+}
+
+extern "C" int pgh_get_missingness(pgh_reader *rd, uint32_t vidx, uint64_t *bits) {
+	int rc = ReaderCheck(rd, vidx);
+	if (rc == PGH_OK) {
+		rc = FetchRow(rd, vidx);
+	}
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	const uint32_t n_out = rd->subset ? rd->subset->n_out : rd->ds->sample_ct;
+	std::memset(bits, 0, sizeof(uint64_t) * ((n_out + 63) / 64));
+	ForEachIncluded(rd, [&](uint32_t k, uint32_t s) {
+		if (RowCode(rd->h_row, s) == 3u) {
+			bits[k >> 6] |= 1ull << (k & 63);
+		}
+	});
+	return PGH_OK;
+}
+
+extern "C" int pgh_get_int8(pgh_reader *rd, uint32_t vidx, int8_t *out) {
+	int rc = ReaderCheck(rd, vidx);
+	if (rc == PGH_OK) {
+		rc = FetchRow(rd, vidx);
+	}
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	ForEachIncluded(rd, [&](uint32_t k, uint32_t s) {
+		const uint32_t c = RowCode(rd->h_row, s);
+		out[k] = c == 3u ? static_cast<int8_t>(-9) : static_cast<int8_t>(c);
+	});
+	return PGH_OK;
+}
+
+extern "C" int pgh_get_phased(pgh_reader *rd, uint32_t vidx, uint64_t *genovec, uint64_t *phasepresent,
+                              uint64_t *phaseinfo) {
+	int rc = ReaderCheck(rd, vidx);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	const pgh_dataset *ds = rd->ds;
+	const uint32_t n_out = rd->subset ? rd->subset->n_out : ds->sample_ct;
+	std::memset(phasepresent, 0, sizeof(uint64_t) * ((n_out + 63) / 64));
+	std::memset(phaseinfo, 0, sizeof(uint64_t) * ((n_out + 63) / 64));
+	if (!(rd->norm && (ds->index.vrtype[vidx] & 0x10))) {
+		return pgh_get_2bit(rd, vidx, genovec);
+	}
+	std::vector<uint8_t> row, pp, pi;
+	std::string err;
+	if (!rd->norm->DecodePhase(vidx, row, pp, pi, err)) {
+		return ReaderFail(rd, PGH_ERR_FORMAT, err);
+	}
+	std::memset(genovec, 0, sizeof(uint64_t) * ((n_out + 31) / 32));
+	ForEachIncluded(rd, [&](uint32_t k, uint32_t s) {
+		genovec[k >> 5] |= static_cast<uint64_t>(RowCode(row.data(), s)) << (2 * (k & 31));
+		if (pp[s]) {
+			phasepresent[k >> 6] |= 1ull << (k & 63);
+		}
+		if (pi[s]) {
+			phaseinfo[k >> 6] |= 1ull << (k & 63);
+		}
+	});
+	return PGH_OK;
+}
+
+extern "C" int pgh_get_dosage_f64(pgh_reader *rd, uint32_t vidx, double *out) {
+	int rc = ReaderCheck(rd, vidx);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	const pgh_dataset *ds = rd->ds;
+	if (rd->norm && (ds->index.vrtype[vidx] & 0x60)) {
+		// explicit dosage track: decoded on the host from the record
+		std::vector<uint8_t> row;
+		std::vector<uint16_t> dos;
+		std::string err;
+		if (!rd->norm->DecodeDosage(vidx, row, dos, err)) {
+			return ReaderFail(rd, PGH_ERR_FORMAT, err);
+		}
+		ForEachIncluded(rd, [&](uint32_t k, uint32_t s) {
+			if (dos[s] != 0xffff) {
+				out[k] = static_cast<double>(dos[s]) / 16384.0;
+			} else {
+				const uint32_t c = RowCode(row.data(), s);
+				out[k] = c == 3u ? -9.0 : static_cast<double>(c);
+			}
+		});
+		return PGH_OK;
+	}
+	rc = FetchRow(rd, vidx);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	ForEachIncluded(rd, [&](uint32_t k, uint32_t s) {
+		const uint32_t c = RowCode(rd->h_row, s);
+		out[k] = c == 3u ? -9.0 : static_cast<double>(c);
+	});
+	return PGH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// HWE
+// ---------------------------------------------------------------------------
+
+extern "C" double pgh_hwe_lnp(int32_t obs_hets, int32_t obs_hom1, int32_t obs_hom2, uint32_t midp) {
+	return pgh::HweLnP(obs_hets, obs_hom1, obs_hom2, midp);
+}
+
+extern "C" double pgh_hwe_xchr_lnp(int32_t female_hets, int32_t female_hom1, int32_t female_hom2, int32_t male1,
+                                   int32_t male2, uint32_t midp) {
+	return pgh::HweXchrLnP(female_hets, female_hom1, female_hom2, male1, male2, midp);
+}
+
+extern "C" int pgh_hwe_lnp_batch_dev(const void *d_counts, uint32_t n, uint32_t midp, void *d_ln_p, void *stream,
+                                     char *errbuf) {
+	if (n && (!d_counts || !d_ln_p)) {
+		SetErr(errbuf, "null argument");
+		return PGH_ERR_ARG;
+	}
+	PGH_HIP(pgh::LaunchHweBatch(static_cast<const uint32_t *>(d_counts), n, midp, static_cast<double *>(d_ln_p),
+	                            static_cast<hipStream_t>(stream)),
+	        "hwe kernel");
+	return PGH_OK;
+}
+
+extern "C" int pgh_hwe_lnp_batch(const uint32_t (*counts)[4], uint32_t n, uint32_t midp, double *ln_p, char *errbuf) {
+	if (n == 0) {
+		return PGH_OK;
+	}
+	if (!counts || !ln_p) {
+		SetErr(errbuf, "null argument");
+		return PGH_ERR_ARG;
+	}
+	DevBuf d_counts, d_lnp;
+	PGH_HIP(d_counts.Alloc(16ull * n), "hipMalloc(hwe)");
+	PGH_HIP(d_lnp.Alloc(8ull * n), "hipMalloc(hwe)");
+	PGH_HIP(hipMemcpyAsync(d_counts.p, counts, 16ull * n, hipMemcpyHostToDevice, hipStreamPerThread), "hwe upload");
+	PGH_HIP(pgh::LaunchHweBatch(d_counts.As<uint32_t>(), n, midp, d_lnp.As<double>(), hipStreamPerThread),
+	        "hwe kernel");
+	PGH_HIP(hipMemcpyAsync(ln_p, d_lnp.p, 8ull * n, hipMemcpyDeviceToHost, hipStreamPerThread), "hwe copy");
+	PGH_HIP(hipStreamSynchronize(hipStreamPerThread), "hwe sync");
+	return PGH_OK;
+}
