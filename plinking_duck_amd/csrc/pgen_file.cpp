@@ -212,12 +212,22 @@ bool ParsePgenIndex(const std::string &pgen_path, const std::string &pgi_path, P
 		return false;
 	}
 	out.sample_id_bytes = N < (1u << 8) ? 1 : (N < (1u << 16) ? 2 : (N < (1u << 24) ? 3 : 4));
-	out.vrtype.assign(M, 0);
-	out.offset.assign(static_cast<size_t>(M) + 1, 0);
+	// The counts come from the file: nothing is sized by them until the file has been shown to be
+	// long enough to hold what they imply (a corrupt count must not turn into a 30 GB allocation).
+	uint64_t index_size = body_size;
+	if (mode == 0x20 && ::stat(index_path.c_str(), &st) == 0) {
+		index_size = static_cast<uint64_t>(st.st_size);
+	}
 
 	if (mode == 0x02) {
 		// fixed-width 2-bit records directly after the 12-byte header
 		const uint64_t w = out.RecordBytes();
+		if (12 + static_cast<uint64_t>(M) * w > body_size) {
+			err = "'" + pgen_path + "': variant records run past the end of the file";
+			return false;
+		}
+		out.vrtype.assign(M, 0);
+		out.offset.assign(static_cast<size_t>(M) + 1, 0);
 		for (uint64_t v = 0; v <= M; v++) {
 			out.offset[v] = 12 + v * w;
 		}
@@ -231,12 +241,16 @@ bool ParsePgenIndex(const std::string &pgen_path, const std::string &pgi_path, P
 		const uint32_t len_bytes = (width_code & 3) + 1;
 		const uint32_t allele_ct_bytes = (out.ctrl >> 4) & 3;
 		const bool nonref_flags = ((out.ctrl >> 6) & 3) == 3;
-		const uint32_t blocks = (M + 65535) / 65536;
+		const uint32_t blocks = static_cast<uint32_t>((static_cast<uint64_t>(M) + 65535) / 65536); // M + 65535 can wrap
 		uint64_t table_bytes = 12 + 8ull * blocks;
 		for (uint32_t b = 0; b < blocks; b++) {
 			uint32_t cnt = (M - b * 65536u) < 65536u ? (M - b * 65536u) : 65536u;
 			table_bytes += (type_bits == 4 ? (cnt + 1) / 2 : cnt) + static_cast<uint64_t>(cnt) * len_bytes +
 			               static_cast<uint64_t>(cnt) * allele_ct_bytes + (nonref_flags ? (cnt + 7) / 8 : 0);
+		}
+		if (table_bytes > index_size) {
+			err = "'" + index_path + "': truncated variant-record tables";
+			return false;
 		}
 		std::vector<uint8_t> tab;
 		if (!SlurpFile(index_path, tab, table_bytes, err)) {
@@ -246,11 +260,18 @@ bool ParsePgenIndex(const std::string &pgen_path, const std::string &pgi_path, P
 			err = "'" + index_path + "': truncated variant-record tables";
 			return false;
 		}
+		out.vrtype.assign(M, 0);
+		out.offset.assign(static_cast<size_t>(M) + 1, 0);
 		uint64_t pos = 12 + 8ull * blocks;
+		uint64_t floor_at = mode == 0x10 ? table_bytes : 0; // records never start inside the tables or go backwards
 		for (uint32_t b = 0; b < blocks; b++) {
 			const uint32_t v0 = b * 65536u;
 			const uint32_t cnt = (M - v0) < 65536u ? (M - v0) : 65536u;
 			uint64_t at = LoadLe64(tab.data() + 12 + 8ull * b);
+			if (at < floor_at || at > body_size) {
+				err = "'" + index_path + "': variant block offset out of range";
+				return false;
+			}
 			const uint8_t *types = tab.data() + pos;
 			pos += type_bits == 4 ? (cnt + 1) / 2 : cnt;
 			const uint8_t *lens = tab.data() + pos;
@@ -265,7 +286,12 @@ bool ParsePgenIndex(const std::string &pgen_path, const std::string &pgi_path, P
 				out.offset[v0 + i] = at;
 				at += LoadLe(lens + static_cast<size_t>(i) * len_bytes, len_bytes);
 			}
+			if (at > body_size) {
+				err = "'" + pgen_path + "': variant records run past the end of the file";
+				return false;
+			}
 			out.offset[v0 + cnt] = at;
+			floor_at = at;
 		}
 	} else {
 		char buf[64];
