@@ -18,7 +18,9 @@
 // struct output, multi-file lists, combine_samples, parquet companions.
 #include "pgen_reader.hpp"
 
+#include <cerrno>
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 #include <mutex>
 
@@ -31,6 +33,47 @@ string Lowered(string s) {
 		ch = static_cast<char>(std::tolower(static_cast<unsigned char>(ch)));
 	}
 	return s;
+}
+
+//! read_pfile's own region grammar (src/pfile_reader.cpp:43-95): 'chr', 'chr:start-' and
+//! 'chr:start-end'; returns the closed form the shared ParseRegion takes.
+string CanonicalRegion(const string &region_str) {
+	const long kOpenEnd = 2147483647L;
+	auto colon = region_str.find(':');
+	if (colon == string::npos) {
+		return region_str + ":0-" + std::to_string(kOpenEnd); // the whole chromosome
+	}
+	if (colon == 0) {
+		throw InvalidInputException("read_pfile: invalid region format '%s' (empty chromosome)", region_str);
+	}
+	const string range = region_str.substr(colon + 1);
+	auto dash = range.find('-');
+	if (dash == string::npos) {
+		throw InvalidInputException("read_pfile: invalid region format '%s' (expected chr:start-end)", region_str);
+	}
+	const string start_str = range.substr(0, dash), end_str = range.substr(dash + 1);
+	if (start_str.empty()) {
+		throw InvalidInputException("read_pfile: invalid region format '%s' (empty start position)", region_str);
+	}
+	char *tail = nullptr;
+	errno = 0;
+	long start = std::strtol(start_str.c_str(), &tail, 10);
+	if (tail == start_str.c_str() || *tail != '\0' || errno != 0 || start < 0) {
+		throw InvalidInputException("read_pfile: invalid region start '%s' in '%s'", start_str, region_str);
+	}
+	long end = kOpenEnd;
+	if (!end_str.empty()) {
+		errno = 0;
+		end = std::strtol(end_str.c_str(), &tail, 10);
+		if (tail == end_str.c_str() || *tail != '\0' || errno != 0 || end < 0) {
+			throw InvalidInputException("read_pfile: invalid region end '%s' in '%s'", end_str, region_str);
+		}
+	}
+	if (start > end) {
+		throw InvalidInputException("read_pfile: region start (%lld) > end (%lld) in '%s'", static_cast<long long>(start),
+		                            static_cast<long long>(end), region_str);
+	}
+	return region_str.substr(0, colon) + ":" + std::to_string(start) + "-" + std::to_string(std::min(end, kOpenEnd));
 }
 
 bool PsamMissing(const string &v) {
@@ -133,7 +176,9 @@ static unique_ptr<FunctionData> PfileBind(ClientContext &context, TableFunctionB
 	TableFunctionBindInput inner;
 	inner.inputs.push_back(Value::VARCHAR(pgen_path));
 	for (auto &kv : input.named_parameters) {
-		if (kv.first != "pgen" && kv.first != "orient") {
+		if (kv.first == "region") {
+			inner.named_parameters[kv.first] = Value::VARCHAR(CanonicalRegion(kv.second.GetValue<string>()));
+		} else if (kv.first != "pgen" && kv.first != "orient") {
 			inner.named_parameters[kv.first] = kv.second;
 		}
 	}

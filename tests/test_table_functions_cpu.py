@@ -223,3 +223,10 @@ def test_read_pfile_bind():
     assert "not available in this build" in err("read_pfile", PFX, orient="sample")
     assert "not available in this build" in err("read_pfile", [PFX, PFX])
     assert "Invalid named parameter" in err("read_pgen", EX, region="1:1-2", exc=F.BinderException)
+    # read_pfile_negative.test:113-131 and the open forms of its region grammar
+    assert "invalid region" in err("read_pfile", PFX, region="invalid:abc-def")
+    assert "empty chromosome" in err("read_pfile", PFX, region=":100-200")
+    assert "region start (30000) > end (10000)" in err("read_pfile", PFX, region="1:30000-10000")
+    assert F.query("read_pfile", PFX, region="2", columns=["ID"]).column("ID") == ["rs4"]
+    assert F.query("read_pfile", PFX, region="1:20000-", columns=["ID"]).column("ID") == ["rs2", "rs3"]
+    assert len(F.query("read_pfile", PFX, region="99:1-100", columns=["ID"])) == 0
