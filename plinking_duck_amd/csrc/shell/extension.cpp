@@ -176,7 +176,13 @@ string RunQuery(const string &request) {
 	}
 	if (const Json *st = req.Get("settings")) {
 		for (auto &kv : st->obj) {
-			context.settings[kv.first] = JsonToValue(kv.second);
+			Value v = JsonToValue(kv.second);
+			// the SET-time check of the option (src/plinking_duck_extension.cpp:37-42)
+			if (kv.first == "plinking_max_threads" && !v.IsNull() && v.GetValue<int64_t>() < 0) {
+				return ErrorJson(InvalidInputException::Kind(),
+				                 "plinking_max_threads must be non-negative (0 = default, >0 = cap)");
+			}
+			context.settings[kv.first] = v;
 		}
 	}
 	TableFunctionBindInput bind_input;

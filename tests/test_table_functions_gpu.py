@@ -678,3 +678,68 @@ def test_shells_agree_with_the_library_across_device_batches(midsize, gpu_lib, t
     # rows exist only for pairs with a defined r2 (neither side monomorphic among the shared calls)
     assert set(got_n) <= set(valid) and len(got_n) >= 0.9 * len(valid)
     assert all(valid[p] == nn for p, nn in got_n.items())
+
+
+# ---- read_pgen_filter.test, mirrored query by query ---------------------------------------------
+
+def test_read_pgen_filter_test_mirror():
+    q = lambda cols, **kw: F.query("read_pgen", EX, columns=cols, **kw)
+    ids = lambda **kw: q(["ID"], **kw).column("ID")
+    assert ids(af_range={"max": 0.4}) == ["rs4"]
+    assert len(ids(af_range={"min": 0.5, "max": 0.5})) == 3
+    assert ids(af_range={"min": 0.9}) == []
+    assert ids(ac_range={"min": 4}) == ["rs2"]
+    assert len(ids(ac_range={"max": 3})) == 3
+    assert ids(af_range={"max": 0.4}, ac_range={"min": 3}) == ["rs4"]
+    assert q(["ID", "genotypes"], af_range={"max": 0.4}).rows == [("rs4", [0, 0, 1, 2])]
+    N = None
+    g = lambda **kw: dict(q(["ID", "genotypes"], **kw).rows)
+    assert g(genotype_range={"min": 1}) == {"rs1": [N, 1, 2, N], "rs2": [1, 1, N, 2], "rs3": [2, N, 1, N], "rs4": [N, N, 1, 2]}
+    assert g(genotype_range={"min": 1, "max": 1}) == {"rs1": [N, 1, N, N], "rs2": [1, 1, N, N], "rs3": [N, N, 1, N],
+                                                      "rs4": [N, N, 1, N]}
+    assert g(genotype_range={"min": 2, "max": 2}) == {"rs1": [N, N, 2, N], "rs2": [N, N, N, 2], "rs3": [2, N, N, N],
+                                                      "rs4": [N, N, N, 2]}
+    assert g(af_range={"max": 0.4}, genotype_range={"min": 1}) == {"rs4": [N, N, 1, 2]}
+    assert len(F.query("read_pgen", data_path("all_missing.pgen"), genotype_range={"min": 0, "max": 2}, columns=["ID"])) == 0
+    assert g(include_genotypes=["het", "hom_alt"]) == g(genotype_range={"min": 1})
+    assert g(include_genotypes=["hom_ref", "hom_alt"]) == {"rs1": [0, N, 2, N], "rs2": [N, N, 0, 2], "rs3": [2, N, N, 0],
+                                                           "rs4": [0, 0, N, 2]}
+    for kw, msg in [(dict(af_range={"min": 0.8, "max": 0.2}), "min (0.8) > max (0.2)"),
+                    (dict(af_range={"max": 1.5}), "out of range"), (dict(ac_range={"min": -1}), "out of range"),
+                    (dict(af_range={"minimum": 0.1}), "unknown field 'minimum'"),
+                    (dict(genotype_range={"min": 2, "max": 0}), "min (2) > max (0)"),
+                    (dict(genotype_range={"max": 3}), "out of range"),
+                    (dict(genotype_range={"min": 1}, dosages=True), "genotype_range is incompatible with dosages"),
+                    (dict(include_genotypes=["het"], genotype_range={"min": 1}),
+                     "specify only one of include_genotypes or genotype_range"),
+                    (dict(include_genotypes=["het"], dosages=True), "incompatible with dosages"),
+                    (dict(include_genotypes=["carrier"]), "unknown category 'carrier'")]:
+        with pytest.raises(F.InvalidInputException) as e:
+            q(["ID"], **kw)
+        assert msg in str(e.value), (kw, str(e.value))
+
+
+# ---- plinking_max_threads.test ---------------------------------------------------------------
+
+@pytest.mark.parametrize("cap", [1, 2, 0, None])
+def test_plinking_max_threads_test_mirror(cap):
+    big, pfx = data_path("large_example.pgen"), data_path("large_example")
+    st = {} if cap is None else {"plinking_max_threads": cap}
+    r = F.query("read_pfile", pfx, columns=["ID"], settings=st, threads=8)
+    assert len(r) == 3000 and len(set(r.column("ID"))) == 3000
+    assert len(F.query("read_pgen", big, columns=["ID"], settings=st, threads=8)) == 3000
+    fr = F.query("plink_freq", big, columns=["ALT_FREQ"], settings=st, threads=8)
+    assert len(fr) == 3000 and all(0.0 <= x <= 1.0 for x in fr.column("ALT_FREQ"))
+    assert len(F.query("plink_hardy", big, columns=["ID"], settings=st, threads=8)) == 3000
+    mv = F.query("plink_missing", big, columns=["MISSING_CT"], settings=st, threads=8)
+    ms = F.query("plink_missing", big, mode="sample", columns=["MISSING_CT"], settings=st, threads=8)
+    assert len(mv) == 3000 and len(ms) == 8
+    assert sum(mv.column("MISSING_CT")) == sum(ms.column("MISSING_CT"))  # cross-function consistency under the cap
+    if cap:
+        assert r.threads <= cap
+
+
+def test_negative_thread_cap_is_rejected():
+    with pytest.raises(F.InvalidInputException) as e:
+        F.query("plink_freq", EX, columns=["ID"], settings={"plinking_max_threads": -1})
+    assert "plinking_max_threads must be non-negative" in str(e.value)
