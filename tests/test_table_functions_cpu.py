@@ -230,3 +230,14 @@ def test_read_pfile_bind():
     assert F.query("read_pfile", PFX, region="2", columns=["ID"]).column("ID") == ["rs4"]
     assert F.query("read_pfile", PFX, region="1:20000-", columns=["ID"]).column("ID") == ["rs2", "rs3"]
     assert len(F.query("read_pfile", PFX, region="99:1-100", columns=["ID"])) == 0
+
+
+def test_null_list_params_test_mirror():
+    """null_list_params.test: NULL / typed-NULL list parameters."""
+    PFX = data_path("pgen_example")
+    assert "samples list must not be empty" in err("read_pfile", PFX, samples=None)
+    assert "samples list must not be empty" in err("read_pfile", PFX, samples=[])
+    assert "samples list must not be empty" in err("plink_freq", EX, samples=None)
+    assert "variants must not be NULL" in err("read_pfile", PFX, variants=None)
+    assert len(F.query("read_pfile", PFX, include_genotypes=None, columns=["ID"])) == 4
+    assert "weights must not be NULL" in err("plink_score", EX, weights=None)
