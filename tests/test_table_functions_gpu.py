@@ -743,3 +743,22 @@ def test_negative_thread_cap_is_rejected():
     with pytest.raises(F.InvalidInputException) as e:
         F.query("plink_freq", EX, columns=["ID"], settings={"plinking_max_threads": -1})
     assert "plinking_max_threads must be non-negative" in str(e.value)
+
+
+def test_read_pgen_genotypes_test_mirror():
+    """read_pgen_genotypes.test: mode names are case-insensitive, ARRAY == LIST element for element,
+    orphan files and explicit companions."""
+    for mode, typ in (("LIST", "TINYINT[]"), ("Auto", "TINYINT[4]"), ("ARRAY", "TINYINT[4]")):
+        assert F.query("read_pgen", EX, genotypes=mode, columns=["genotypes"]).types == [typ]
+    for path, kw in ((EX, {}), (data_path("large_example.pgen"), {}), (EX, {"samples": [0, 2]})):
+        a = dict(F.query("read_pgen", path, genotypes="array", columns=["ID", "genotypes"], **kw).rows)
+        l = dict(F.query("read_pgen", path, genotypes="list", columns=["ID", "genotypes"], **kw).rows)
+        assert a == l and len(a) in (4, 3000)
+    assert dict(F.query("read_pgen", EX, genotypes="list", samples=[3], columns=["ID", "genotypes"]).rows)["rs2"] == [2]
+    orphan = data_path("pgen_orphan.pgen")
+    assert F.query("read_pgen", orphan, genotypes="list", columns=["genotypes"]).types == ["TINYINT[]"]
+    assert F.query("read_pgen", orphan, genotypes="array", columns=["genotypes"]).types == ["TINYINT[4]"]
+    assert len(F.query("read_pgen", orphan, genotypes="list", samples=[0, 2], columns=["genotypes"]).rows[0][0]) == 2
+    for kw in (dict(pvar=data_path("pgen_example.pvar"), psam=data_path("pgen_example.psam")),
+               dict(pvar=data_path("pgen_example.bim"))):
+        assert dict(F.query("read_pgen", EX, genotypes="list", columns=["ID", "genotypes"], **kw).rows)["rs1"] == [0, 1, 2, None]
