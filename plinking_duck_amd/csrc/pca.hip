@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void k_variant_reduce_mfma(const uint8_t *__re
 			}
 #pragma unroll
 			for (uint32_t t = 0; t < kVT; t++) {
-				const uint32_t g = (w[t][q >> 2] >> (8u * (q & 3u) + lane_shift)) & 3u;
+				const uint32_t g = __builtin_amdgcn_ubfe(w[t][q >> 2], 8u * (q & 3u) + lane_shift, 2u);
 				const double a = s_t[t_base[t]][g];
 #pragma unroll
 				for (int c = 0; c < NCT; c++) {

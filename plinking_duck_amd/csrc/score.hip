@@ -338,20 +338,27 @@ __global__ __launch_bounds__(256, (NCT == 1 && NQ == 0) ? 4 : 2) void k_accumula
 	constexpr uint32_t kCols = 16 * NCT + 4 * NQ;
 	constexpr uint32_t kQ = NQ > 0 ? NQ : 1; // array extents (unused when NQ == 0)
 	constexpr uint32_t kWPerThread = kStage * kCols / 256; // weight doubles each thread stages
-	// double-buffered stage: tables / weights / row offsets of 64 variants
+	// double-buffered stage of 64 variants: their tables, their weights and the workgroup's
+	// 64 bytes (256 samples) of each of their rows.  The whole stage is fetched into registers
+	// while the previous one is being multiplied, so the multiply loop touches no global memory
+	// and an HBM miss has a full stage (16 groups x 4 MFMAs per wave) to land.
 	__shared__ double s_ts[2][kStage][4];
 	__shared__ double s_w[2][kStage][kCols];
-	__shared__ uint64_t s_off[2][kStage];
+	__shared__ uint4 s_geno[2][kStage][4];
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = threadIdx.x >> 6;
 	const uint32_t li = lane & 15u; // sample within tile (A), column within tile (B, D)
 	const uint32_t lk = lane >> 4;  // variant within the group of 4 (A, B); row group (D)
 	const uint32_t sample_base = (blockIdx.x * 4u + wave) * 64u;
 	const bool wave_live = sample_base < sample_ct; // wave-uniform
-	const uint8_t *col_ptr = rows + (sample_base >> 2);
 	const uint32_t shift = 2u * li;
 	const uint32_t i_begin = blockIdx.y * slice_len;
 	const uint32_t i_end = min(i_begin + slice_len, n_var);
+	// staging role of this thread: 16-byte piece (tid & 3) -- the 64 samples of wave (tid & 3) --
+	// of stage variant (tid >> 2)
+	const uint32_t piece = threadIdx.x & 3u;
+	const bool piece_live = (blockIdx.x * 4u + piece) * 64u < sample_ct;
+	const uint8_t *piece_ptr = rows + (static_cast<uint64_t>(blockIdx.x) * 4u + piece) * 16u;
 
 	f64x4 acc[4][NCT];
 #pragma unroll
@@ -371,34 +378,31 @@ __global__ __launch_bounds__(256, (NCT == 1 && NQ == 0) ? 4 : 2) void k_accumula
 	}
 	double dsum[4] = {0.0, 0.0, 0.0, 0.0};
 
-	// staging registers: the next stage is fetched from global memory while the
-	// current one is being multiplied, then dropped into the other LDS buffer
 	double r_ts = 0.0;
 	double r_w[kWPerThread];
-	uint64_t r_off = 0;
+	uint4 r_geno = make_uint4(0, 0, 0, 0);
 	auto fetch = [&](uint32_t base) {
 		const uint32_t cnt = min(kStage, i_end - base);
 		const uint32_t k = threadIdx.x; // kStage * 4 == 256
 		r_ts = (k >> 2) < cnt ? ts[4 * static_cast<uint64_t>(base) + k] : 0.0;
+		r_geno = make_uint4(0, 0, 0, 0);
+		if ((k >> 2) < cnt && piece_live) {
+			r_geno = *reinterpret_cast<const uint4 *>(piece_ptr + static_cast<uint64_t>(vlist[base + (k >> 2)]) * pitch);
+		}
 #pragma unroll
 		for (uint32_t j = 0; j < kWPerThread; j++) {
 			const uint32_t e = threadIdx.x + 256u * j;
 			const uint32_t v = e / kCols, c = e % kCols;
 			r_w[j] = (v < cnt && c < n_cols) ? weights[static_cast<uint64_t>(base + v) * w_stride + c] : 0.0;
 		}
-		if (threadIdx.x < kStage) {
-			r_off = static_cast<uint64_t>(vlist[base + (threadIdx.x < cnt ? threadIdx.x : 0)]) * pitch;
-		}
 	};
 	auto commit = [&](uint32_t buf) {
 		s_ts[buf][threadIdx.x >> 2][threadIdx.x & 3] = r_ts;
+		s_geno[buf][threadIdx.x >> 2][threadIdx.x & 3] = r_geno;
 #pragma unroll
 		for (uint32_t j = 0; j < kWPerThread; j++) {
 			const uint32_t e = threadIdx.x + 256u * j;
 			s_w[buf][e / kCols][e % kCols] = r_w[j];
-		}
-		if (threadIdx.x < kStage) {
-			s_off[buf][threadIdx.x] = r_off;
 		}
 	};
 
@@ -416,9 +420,11 @@ __global__ __launch_bounds__(256, (NCT == 1 && NQ == 0) ? 4 : 2) void k_accumula
 		}
 		if (wave_live) {
 			const uint32_t groups = (cnt + 3) / 4;
-			// two-deep software pipeline: while group g is on the matrix pipe, group g+1's
-			// operands are being looked up in LDS and the row loads of g+2..g+4 are in flight
-			auto operands = [&](uint32_t k, const uint4 &w, double a[4], double b[NCT + kQ]) {
+			// operands of group g: the 16 bytes of variant 4g + lk that hold this wave's 64 samples
+			// (one broadcast LDS read per 16 lanes), four table lookups, the weight entries
+			auto operands = [&](uint32_t g, double a[4], double b[NCT + kQ]) {
+				const uint32_t k = g * 4u + lk;
+				const uint4 w = s_geno[buf][k][wave];
 #pragma unroll
 				for (int c = 0; c < NCT; c++) {
 					b[c] = s_w[buf][k][16 * c + li];
@@ -430,11 +436,8 @@ __global__ __launch_bounds__(256, (NCT == 1 && NQ == 0) ? 4 : 2) void k_accumula
 				const uint32_t wt[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
 				for (int t = 0; t < 4; t++) {
-					a[t] = s_ts[buf][k][(wt[t] >> shift) & 3u];
+					a[t] = s_ts[buf][k][__builtin_amdgcn_ubfe(wt[t], shift, 2u)]; // one v_bfe_u32, not shift + and
 				}
-			};
-			auto row_load = [&](uint32_t g) {
-				return *reinterpret_cast<const uint4 *>(col_ptr + s_off[buf][g * 4u + lk]);
 			};
 			auto multiply = [&](const double a[4], const double b[NCT + kQ]) {
 #pragma unroll
@@ -453,23 +456,14 @@ __global__ __launch_bounds__(256, (NCT == 1 && NQ == 0) ? 4 : 2) void k_accumula
 				}
 			};
 			if (groups == kStage / 4) {
-				// full stage, fully unrolled so the ring of 4 row loads and the operand
-				// double buffer are plain register renaming (no moves, no early waits)
-				constexpr uint32_t kRing = 3; // row loads in flight (3 keeps NCT = 1 at 128 VGPRs = 4 waves/SIMD)
-				uint4 w[kRing];
-#pragma unroll
-				for (uint32_t j = 0; j < kRing; j++) {
-					w[j] = row_load(j);
-				}
+				// full stage, fully unrolled: while group g is on the matrix pipe the operands of
+				// g + 1 are being read out of LDS (double-buffered in registers)
 				double a[2][4], b[2][NCT + kQ];
-				operands(lk, w[0], a[0], b[0]);
+				operands(0, a[0], b[0]);
 #pragma unroll
 				for (uint32_t g4 = 0; g4 < kStage / 4; g4++) {
-					if (g4 + kRing < kStage / 4) {
-						w[g4 % kRing] = row_load(g4 + kRing); // slot of group g4, already turned into operands
-					}
 					if (g4 + 1 < kStage / 4) {
-						operands((g4 + 1u) * 4u + lk, w[(g4 + 1) % kRing], a[(g4 + 1) % 2], b[(g4 + 1) % 2]);
+						operands(g4 + 1u, a[(g4 + 1) % 2], b[(g4 + 1) % 2]);
 					}
 					multiply(a[g4 % 2], b[g4 % 2]);
 				}
@@ -477,7 +471,7 @@ __global__ __launch_bounds__(256, (NCT == 1 && NQ == 0) ? 4 : 2) void k_accumula
 				// ragged last stage of a slice
 				for (uint32_t g4 = 0; g4 < groups; g4++) {
 					double a[4], b[NCT + kQ];
-					operands(g4 * 4u + lk, row_load(g4), a, b);
+					operands(g4, a, b);
 					multiply(a, b);
 				}
 			}
