@@ -5,15 +5,21 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -mllvm -amdgpu-mfma-vgpr-form"
 mkdir -p build
+pids=()
 for f in tally.hip unpack.hip score.hip pca.hip decode.hip ld.hip api_dataset.cpp api_analysis.cpp api_reader.cpp pgen_file.cpp linalg.cpp; do
 	o=build/${f%.*}.o
 	if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ -n "$(find . -maxdepth 1 -name '*.hpp' -newer "$o")" ] || [ ../../include/pgenhip.h -nt "$o" ]; then
+		# translation units are independent: compile them side by side
 		if [ "${f##*.}" = "hip" ]; then
-			$HIPCC $FLAGS -c "$f" -o "$o"
+			$HIPCC $FLAGS -c "$f" -o "$o" &
 		else
-			$HIPCC $FLAGS -x hip -c "$f" -o "$o"
+			$HIPCC $FLAGS -x hip -c "$f" -o "$o" &
 		fi
+		pids+=($!)
 	fi
+done
+for p in "${pids[@]}"; do
+	wait "$p"
 done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libpgenhip.so build/tally.o build/unpack.o build/score.o build/pca.o build/decode.o build/ld.o build/api_dataset.o build/api_analysis.o build/api_reader.o build/pgen_file.o build/linalg.o
 echo "built $(cd .. && pwd)/libpgenhip.so"
