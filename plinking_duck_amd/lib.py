@@ -62,6 +62,16 @@ def _load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with plinking_duck_amd/csrc/build.sh "
             "(python -c 'import __graft_entry__ as g; g.build()').  There is no CPU fallback.")
+    # PyTorch-ROCm wheels bundle their own HIP runtime (torch/lib/libamdhip64.so).  A process that
+    # ends up with two HIP runtimes -- this library bound to /opt/rocm first, torch's loaded later --
+    # leaves the second one without a device ("No HIP GPUs are available").  Loading torch first makes
+    # both bind the same runtime, so do that whenever torch is installed; the library itself needs
+    # neither torch nor Python.
+    if os.environ.get("PGH_NO_TORCH_PRELOAD", "") in ("", "0"):
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(LIB_PATH)
     vp, u32, u64, i32, cp = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32, C.c_char_p
     sigs = {

@@ -424,3 +424,36 @@ def test_sample_counts_match_oracle(gpu_lib, oracle, n):
     assert np.array_equal(ds.sample_counts(vidx=pick, subset=ds.subset(mask)),
                           pg.sample_counts(vidx=[int(v) for v in pick], include=mask.astype(np.uint8)))
     assert np.array_equal(ds.sample_counts(10, 200), pg.sample_counts(vidx=range(10, 200)))
+
+
+def test_full_size_matrix_properties(gpu_lib):
+    """BASELINE configs 2/3 at full size -- 1,000,000 x 500,000 resident in HBM (125 GB) -- through
+    properties that need no second implementation: every row tallies to N; the fused pass equals the
+    two separate passes; per-sample and per-variant missing tallies are two reductions of one matrix;
+    shards of the variant axis add up; unpack of a slice agrees with its tallies."""
+    torch = pytest.importorskip("torch")
+    free, _ = torch.cuda.mem_get_info()
+    m, n = 1_000_000, 500_000
+    if free < 135e9:
+        pytest.skip("needs 135 GB of free HBM")
+    ds = gpu_lib.Dataset.synth(0, m, n, SEED, 0.02)
+    counts = ds.counts_range()
+    assert counts.shape == (m, 4) and (counts.sum(axis=1, dtype=np.int64) == n).all()
+    assert 0.019 < counts[:, 3].sum(dtype=np.int64) / (m * n) < 0.021
+    st = torch.cuda.current_stream().cuda_stream
+    d_counts = torch.zeros((m, 4), dtype=torch.int32, device="cuda")
+    d_miss = torch.zeros((n + 63) // 64 * 64, dtype=torch.int32, device="cuda")
+    ds.fused_tally_dev(0, m, d_counts.data_ptr(), d_miss.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_counts.cpu().numpy().astype(np.uint32), counts)
+    miss = ds.missing_per_sample()
+    assert np.array_equal(d_miss[:n].cpu().numpy().astype(np.uint32), miss)
+    assert int(miss.sum(dtype=np.int64)) == int(counts[:, 3].sum(dtype=np.int64))
+    cut = 611_111
+    assert np.array_equal(ds.missing_per_sample(0, cut) + ds.missing_per_sample(cut, m), miss)
+    sc = ds.sample_counts(cut, cut + 4096)
+    assert (sc.sum(axis=1) == 4096).all() and int(sc[:, 3].sum()) == int(counts[cut:cut + 4096, 3].sum())
+    geno, _ = ds.unpack_range(cut, cut + 8)
+    for r in range(8):
+        row = np.where(geno[r] == -9, 3, geno[r])
+        assert [int((row == c).sum()) for c in range(4)] == [int(x) for x in counts[cut + r]]
