@@ -289,6 +289,12 @@ double pgh_hwe_xchr_lnp(int32_t female_hets, int32_t female_hom1, int32_t female
 /* Batch of autosomal tests on the device, straight from a counts array:
  * ln_p[i] from counts[i] = {hom_ref, het, hom_alt, missing}. */
 int pgh_hwe_lnp_batch(const uint32_t (*counts)[4], uint32_t n, uint32_t midp, double *ln_p, char *errbuf);
+
+/* plink2::HweXchrLnP (src/plink_hardy.cpp:94) for n variants at once, one workgroup per variant:
+ * strata[i] = {female_hets, female_hom1, female_hom2, male1, male2}.  The host form
+ * pgh_hwe_xchr_lnp costs ~0.1 s per variant at 500k samples; this is what the plink_hardy shell
+ * calls for the chrX variants of a device batch. */
+int pgh_hwe_xchr_lnp_batch(const int32_t (*strata)[5], uint32_t n, uint32_t midp, double *ln_p, char *errbuf);
 /* Same with device buffers: d_counts uint32[n][4] -> d_ln_p double[n]. */
 int pgh_hwe_lnp_batch_dev(const void *d_counts, uint32_t n, uint32_t midp, void *d_ln_p, void *stream, char *errbuf);
 

@@ -310,3 +310,23 @@ extern "C" int pgh_hwe_lnp_batch(const uint32_t (*counts)[4], uint32_t n, uint32
 	PGH_HIP(hipStreamSynchronize(hipStreamPerThread), "hwe sync");
 	return PGH_OK;
 }
+
+extern "C" int pgh_hwe_xchr_lnp_batch(const int32_t (*strata)[5], uint32_t n, uint32_t midp, double *ln_p,
+                                      char *errbuf) {
+	if (n == 0) {
+		return PGH_OK;
+	}
+	if (!strata || !ln_p) {
+		SetErr(errbuf, "null argument");
+		return PGH_ERR_ARG;
+	}
+	DevBuf d_strata, d_lnp;
+	PGH_HIP(d_strata.Alloc(20ull * n), "hipMalloc(hwe)");
+	PGH_HIP(d_lnp.Alloc(8ull * n), "hipMalloc(hwe)");
+	PGH_HIP(hipMemcpyAsync(d_strata.p, strata, 20ull * n, hipMemcpyHostToDevice, hipStreamPerThread), "hwe upload");
+	PGH_HIP(pgh::LaunchHweXchrBatch(d_strata.As<int32_t>(), n, midp, d_lnp.As<double>(), hipStreamPerThread),
+	        "chrX hwe kernel");
+	PGH_HIP(hipMemcpyAsync(ln_p, d_lnp.p, 8ull * n, hipMemcpyDeviceToHost, hipStreamPerThread), "hwe copy");
+	PGH_HIP(hipStreamSynchronize(hipStreamPerThread), "hwe sync");
+	return PGH_OK;
+}

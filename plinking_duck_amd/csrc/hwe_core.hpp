@@ -149,7 +149,7 @@ PGH_HD inline double HweLnP(int32_t obs_hets, int32_t obs_hom1, int32_t obs_hom2
 // allele, relative to its modal table: calls fn(k, rel) for every het count k
 // whose relative probability is not negligible, and returns the sum of rel.
 template <class Fn>
-inline double HweWalk(int64_t n, int64_t a, Fn &&fn) {
+PGH_HD inline double HweWalk(int64_t n, int64_t a, Fn &&fn) {
 	const int64_t b = 2 * n - a;
 	const int64_t rare = a < b ? a : b;
 	const int64_t common = 2 * n - rare;
@@ -262,6 +262,82 @@ inline double HweXchrLnP(int32_t female_hets, int32_t female_hom1, int32_t femal
 	}
 	delete[] lh;
 	return result;
+}
+
+// ---- chrX, one variant per workgroup (device) ---------------------------------------------
+// The same rule as HweXchrLnP above with the table columns (mA) spread over the lanes.  The
+// hypergeometric column weights come from lgamma instead of a running log-ratio, so no per-call
+// array is needed: ln H(m) = ln C(nm, m) + ln C(2 nf, nA - m)  (the common denominator cancels
+// against the column of the maximum).
+
+PGH_HD inline double LnChoose(double n, double k) {
+	return lgamma(n + 1.0) - lgamma(k + 1.0) - lgamma(n - k + 1.0);
+}
+
+struct XchrShape {
+	int64_t nf, nm, nA, m_lo, m_hi;
+	double lh_max;
+};
+
+PGH_HD inline double XchrColumnLog(const XchrShape &x, int64_t m) {
+	return LnChoose(static_cast<double>(x.nm), static_cast<double>(m)) +
+	       LnChoose(static_cast<double>(2 * x.nf), static_cast<double>(x.nA - m));
+}
+
+PGH_HD inline XchrShape MakeXchrShape(int32_t female_hets, int32_t female_hom1, int32_t female_hom2, int32_t male1,
+                                      int32_t male2) {
+	XchrShape x;
+	x.nf = static_cast<int64_t>(female_hets) + female_hom1 + female_hom2;
+	x.nm = static_cast<int64_t>(male1) + male2;
+	x.nA = 2 * static_cast<int64_t>(female_hom1) + female_hets + male1;
+	x.m_lo = x.nA - 2 * x.nf > 0 ? x.nA - 2 * x.nf : 0;
+	x.m_hi = x.nA < x.nm ? x.nA : x.nm;
+	// mode of the hypergeometric split, then its neighbours (the closed form can be off by one)
+	const double nt = static_cast<double>(x.nm + 2 * x.nf);
+	int64_t mode = static_cast<int64_t>((static_cast<double>(x.nA) + 1.0) * (static_cast<double>(x.nm) + 1.0) / (nt + 2.0));
+	mode = mode < x.m_lo ? x.m_lo : (mode > x.m_hi ? x.m_hi : mode);
+	x.lh_max = XchrColumnLog(x, mode);
+	for (int64_t d = -2; d <= 2; d++) {
+		const int64_t m = mode + d;
+		if (m >= x.m_lo && m <= x.m_hi) {
+			const double v = XchrColumnLog(x, m);
+			x.lh_max = v > x.lh_max ? v : x.lh_max;
+		}
+	}
+	return x;
+}
+
+// probability of the observed table relative to the column of the maximum (0 if it underflows)
+PGH_HD inline double XchrObserved(const XchrShape &x, int32_t female_hets, int32_t male1) {
+	double w_obs = 0.0;
+	const double t_obs = HweWalk(x.nf, x.nA - male1, [&](int64_t k, double rel) {
+		if (k == female_hets) {
+			w_obs = rel;
+		}
+	});
+	return exp(XchrColumnLog(x, male1) - x.lh_max) * w_obs / t_obs;
+}
+
+// one column's share of {total, tail, ties}
+PGH_HD inline void XchrColumn(const XchrShape &x, int64_t m, double lo, double hi, double &total, double &tail,
+                              double &ties) {
+	const double h = exp(XchrColumnLog(x, m) - x.lh_max);
+	total += h;
+	if (h <= lo) {
+		tail += h; // every table of this column is less likely than the observed one
+		return;
+	}
+	const double t = HweWalk(x.nf, x.nA - m, [](int64_t, double) {});
+	const double scale = h / t;
+	HweWalk(x.nf, x.nA - m, [&](int64_t, double rel) {
+		const double joint = rel * scale;
+		if (joint <= hi) {
+			tail += joint;
+			if (joint >= lo) {
+				ties += joint;
+			}
+		}
+	});
 }
 
 } // namespace pgh

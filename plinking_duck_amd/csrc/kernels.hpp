@@ -120,5 +120,7 @@ hipError_t LaunchCopyCols(const double *src, uint32_t ld_src, double *dst, uint3
 
 // ---- HWE --------------------------------------------------------------------
 hipError_t LaunchHweBatch(const uint32_t *counts, uint32_t n, uint32_t midp, double *ln_p, hipStream_t stream);
+// chrX: strata[i] = {female_hets, female_hom1, female_hom2, male1, male2}; one workgroup per variant
+hipError_t LaunchHweXchrBatch(const int32_t *strata, uint32_t n, uint32_t midp, double *ln_p, hipStream_t stream);
 
 } // namespace pgh

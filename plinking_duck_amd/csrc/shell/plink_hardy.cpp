@@ -1,8 +1,9 @@
 // plink_hardy.cpp -- plink_hardy(path, pvar, psam, samples, region, midp, build)
 //
 // Surface of the reference's src/plink_hardy.cpp; counts come from the batched
-// device tally, the exact tests from libpgenhip's HWE routines (pgh_hwe_lnp /
-// pgh_hwe_xchr_lnp, the replacements for plink2::HweLnP / HweXchrLnP).
+// device tally, and the exact tests of a whole device batch from two more launches
+// (pgh_hwe_lnp_batch / pgh_hwe_xchr_lnp_batch, the replacements for one
+// plink2::HweLnP / HweXchrLnP call per variant).
 #include "variant_scan.hpp"
 
 #include <cmath>
@@ -27,25 +28,6 @@ static double LnPToPvalue(double ln_p) {
 	return p < 0.0 ? 0.0 : (p > 1.0 ? 1.0 : p);
 }
 
-//! src/plink_hardy.cpp:67-79
-static double HweExactTestAutosomal(int32_t obs_hom_ref, int32_t obs_hets, int32_t obs_hom_alt, bool midp) {
-	if (obs_hom_ref < 0 || obs_hets < 0 || obs_hom_alt < 0 || obs_hom_ref + obs_hets + obs_hom_alt == 0) {
-		return 1.0;
-	}
-	return LnPToPvalue(pgh_hwe_lnp(obs_hets, obs_hom_ref, obs_hom_alt, midp ? 1U : 0U));
-}
-
-//! src/plink_hardy.cpp:83-95
-static double HweExactTestXchr(int32_t female_hom_ref, int32_t female_hets, int32_t female_hom_alt, int32_t male_ref,
-                               int32_t male_alt, bool midp) {
-	if (female_hom_ref < 0 || female_hets < 0 || female_hom_alt < 0 || male_ref < 0 || male_alt < 0 ||
-	    female_hom_ref + female_hets + female_hom_alt + male_ref + male_alt == 0) {
-		return 1.0;
-	}
-	return LnPToPvalue(
-	    pgh_hwe_xchr_lnp(female_hets, female_hom_ref, female_hom_alt, male_ref, male_alt, midp ? 1U : 0U));
-}
-
 struct PlinkHardyBindData : public TableFunctionData {
 	PgenBindCommon c;
 	bool midp = false;
@@ -57,6 +39,7 @@ struct PlinkHardyGlobalState : public GlobalTableFunctionState {
 	VariantScanGlobal scan;
 	vector<column_t> column_ids;
 	bool need_genotype_counts = false;
+	bool need_p_hwe = false;
 	uint32_t max_threads_config = 0;
 	idx_t MaxThreads() const override {
 		uint32_t range = scan.end_variant_idx - scan.start_variant_idx;
@@ -66,6 +49,9 @@ struct PlinkHardyGlobalState : public GlobalTableFunctionState {
 
 struct PlinkHardyLocalState : public LocalTableFunctionState {
 	VariantScanLocal scan;
+	// ln p of every variant of the claimed device batch (autosomal rule; chrX rows overwritten)
+	uint32_t lnp_batch_begin = UINT32_MAX;
+	vector<double> lnp;
 };
 
 static unique_ptr<FunctionData> PlinkHardyBind(ClientContext &context, TableFunctionBindInput &input,
@@ -102,8 +88,8 @@ static unique_ptr<GlobalTableFunctionState> PlinkHardyInitGlobal(ClientContext &
 	for (auto col_id : input.column_ids) {
 		if (col_id != COLUMN_IDENTIFIER_ROW_ID && col_id >= COL_HOM_REF_CT && col_id <= COL_P_HWE) {
 			state->need_genotype_counts = true;
-			break;
 		}
+		state->need_p_hwe |= col_id == COL_P_HWE;
 	}
 	if (state->need_genotype_counts) {
 		state->scan.dataset = DeviceDataset::Acquire(bind_data.c.pgen_path, "plink_hardy");
@@ -122,6 +108,57 @@ static unique_ptr<GlobalTableFunctionState> PlinkHardyInitGlobal(ClientContext &
 static unique_ptr<LocalTableFunctionState> PlinkHardyInitLocal(ExecutionContext &, TableFunctionInitInput &,
                                                                GlobalTableFunctionState *) {
 	return make_uniq<PlinkHardyLocalState>();
+}
+
+//! The exact tests of the batch the thread has just claimed: the autosomal rule for every row in
+//! one launch, then the chrX rule for the rows it applies to (females' genotypes + males' alleles).
+static void PrepareBatchTests(const PlinkHardyBindData &bind_data, PlinkHardyLocalState &lstate) {
+	auto &scan = lstate.scan;
+	auto &variants = bind_data.c.variants;
+	const uint32_t n = scan.batch_end - scan.batch_begin;
+	lstate.lnp_batch_begin = scan.batch_begin;
+	lstate.lnp.assign(n, 0.0);
+	char errbuf[PGH_ERRBUF_LEN] = {0};
+	if (pgh_hwe_lnp_batch(reinterpret_cast<const uint32_t(*)[4]>(scan.counts.data()), n, bind_data.midp ? 1u : 0u,
+	                      lstate.lnp.data(), errbuf) != PGH_OK) {
+		throw IOException("plink_hardy: exact tests failed for variants [%u, %u): %s", scan.batch_begin,
+		                  scan.batch_end, string(errbuf));
+	}
+	if (!scan.have_strata) {
+		return;
+	}
+	vector<int32_t> strata;
+	vector<uint32_t> where;
+	for (uint32_t v = scan.batch_begin; v < scan.batch_end; v++) {
+		ChromPloidy ploidy = ClassifyChromPloidy(variants.GetChrom(v), variants.GetPos(v), bind_data.par_bounds);
+		if (ploidy == ChromPloidy::AUTOSOMAL) {
+			continue;
+		}
+		SexAwareCounts sac = SexAwareFromStrata(ploidy, scan.Counts(v), scan.MaleCounts(v), scan.FemaleCounts(v),
+		                                        bind_data.have_sex);
+		if (sac.sex_unavailable || !sac.hwe_defined) {
+			continue;
+		}
+		// males contribute only to geno_hom_* (het -> missing), females to both
+		where.push_back(v - scan.batch_begin);
+		strata.push_back(static_cast<int32_t>(sac.hwe_het));
+		strata.push_back(static_cast<int32_t>(sac.hwe_hom_ref));
+		strata.push_back(static_cast<int32_t>(sac.hwe_hom_alt));
+		strata.push_back(static_cast<int32_t>(sac.geno_hom_ref) - static_cast<int32_t>(sac.hwe_hom_ref));
+		strata.push_back(static_cast<int32_t>(sac.geno_hom_alt) - static_cast<int32_t>(sac.hwe_hom_alt));
+	}
+	if (where.empty()) {
+		return;
+	}
+	vector<double> x_lnp(where.size());
+	if (pgh_hwe_xchr_lnp_batch(reinterpret_cast<const int32_t(*)[5]>(strata.data()), static_cast<uint32_t>(where.size()),
+	                           bind_data.midp ? 1u : 0u, x_lnp.data(), errbuf) != PGH_OK) {
+		throw IOException("plink_hardy: chrX exact tests failed for variants [%u, %u): %s", scan.batch_begin,
+		                  scan.batch_end, string(errbuf));
+	}
+	for (size_t k = 0; k < where.size(); k++) {
+		lstate.lnp[where[k]] = x_lnp[k];
+	}
 }
 
 static void PlinkHardyScan(ClientContext &, TableFunctionInput &data_p, DataChunk &output) {
@@ -147,7 +184,13 @@ static void PlinkHardyScan(ClientContext &, TableFunctionInput &data_p, DataChun
 		ChromPloidy ploidy = ChromPloidy::AUTOSOMAL;
 		if (gstate.need_genotype_counts) {
 			ploidy = ClassifyChromPloidy(variants.GetChrom(vidx), variants.GetPos(vidx), bind_data.par_bounds);
+			if (gstate.need_p_hwe && lstate.lnp_batch_begin != lstate.scan.batch_begin) {
+				PrepareBatchTests(bind_data, lstate);
+			}
 		}
+		const double batch_lnp = gstate.need_p_hwe && gstate.need_genotype_counts
+		                             ? lstate.lnp[vidx - lstate.scan.batch_begin]
+		                             : 0.0;
 		const bool sex_aware = ploidy != ChromPloidy::AUTOSOMAL;
 		uint32_t genocounts[4] = {0, 0, 0, 0};
 		SexAwareCounts sac;
@@ -186,7 +229,8 @@ static void PlinkHardyScan(ClientContext &, TableFunctionInput &data_p, DataChun
 					// males contribute only to geno_hom_* (het -> missing), females to both
 					int32_t male_ref = static_cast<int32_t>(sac.geno_hom_ref) - static_cast<int32_t>(sac.hwe_hom_ref);
 					int32_t male_alt = static_cast<int32_t>(sac.geno_hom_alt) - static_cast<int32_t>(sac.hwe_hom_alt);
-					p_hwe = HweExactTestXchr(out_hom_ref, out_het, out_hom_alt, male_ref, male_alt, bind_data.midp);
+					// HweExactTestXchr's guards (src/plink_hardy.cpp:83-95), the test itself from the batch
+					p_hwe = (male_ref < 0 || male_alt < 0) ? 1.0 : LnPToPvalue(batch_lnp);
 				}
 			} else {
 				out_hom_ref = static_cast<int32_t>(sac.geno_hom_ref);
@@ -205,7 +249,7 @@ static void PlinkHardyScan(ClientContext &, TableFunctionInput &data_p, DataChun
 				o_het = static_cast<double>(het) / static_cast<double>(obs);
 				double p = (2.0 * hom_ref + het) / (2.0 * obs);
 				e_het = 2.0 * p * (1.0 - p);
-				p_hwe = HweExactTestAutosomal(out_hom_ref, out_het, out_hom_alt, bind_data.midp);
+				p_hwe = LnPToPvalue(batch_lnp); // HweExactTestAutosomal (src/plink_hardy.cpp:67-79), batched
 			}
 		}
 

@@ -602,6 +602,65 @@ __global__ __launch_bounds__(64) void k_hwe_batch(const uint32_t *__restrict__ c
 	                 static_cast<int32_t>(counts[4 * i + 2]), midp);
 }
 
+// chrX exact test, one workgroup per variant: lanes share out the table columns (male A-allele
+// counts), each walks the female het distribution of its columns, and the three sums meet in a
+// block reduction.  strata[i] = {female_hets, female_hom1, female_hom2, male1, male2}.
+__global__ __launch_bounds__(256) void k_hwe_xchr_batch(const int32_t *__restrict__ strata, uint32_t n, uint32_t midp,
+                                                        double *__restrict__ ln_p) {
+	__shared__ double s_obs;
+	__shared__ double s_part[4][3];
+	const uint32_t i = blockIdx.x;
+	const int32_t fh = strata[5 * i], f1 = strata[5 * i + 1], f2 = strata[5 * i + 2], m1 = strata[5 * i + 3],
+	              m2 = strata[5 * i + 4];
+	const XchrShape x = MakeXchrShape(fh, f1, f2, m1, m2);
+	if (x.nf + x.nm <= 0) {
+		if (threadIdx.x == 0) {
+			ln_p[i] = 0.0;
+		}
+		return;
+	}
+	if (threadIdx.x == 0) {
+		s_obs = XchrObserved(x, fh, m1);
+	}
+	__syncthreads();
+	const double p_obs = s_obs;
+	if (!(p_obs > 0.0)) {
+		if (threadIdx.x == 0) {
+			ln_p[i] = -INFINITY;
+		}
+		return;
+	}
+	const double hi = p_obs * (1.0 + kHweTieEps);
+	const double lo = p_obs * (1.0 - kHweTieEps);
+	double total = 0.0, tail = 0.0, ties = 0.0;
+	for (int64_t m = x.m_lo + threadIdx.x; m <= x.m_hi; m += 256) {
+		XchrColumn(x, m, lo, hi, total, tail, ties);
+	}
+	double v[3] = {total, tail, ties};
+#pragma unroll
+	for (int k = 0; k < 3; k++) {
+		for (int d = 32; d > 0; d >>= 1) {
+			v[k] += __shfl_xor(v[k], d, 64);
+		}
+	}
+	if ((threadIdx.x & 63u) == 0) {
+		s_part[threadIdx.x >> 6][0] = v[0];
+		s_part[threadIdx.x >> 6][1] = v[1];
+		s_part[threadIdx.x >> 6][2] = v[2];
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		total = s_part[0][0] + s_part[1][0] + s_part[2][0] + s_part[3][0];
+		tail = s_part[0][1] + s_part[1][1] + s_part[2][1] + s_part[3][1];
+		ties = s_part[0][2] + s_part[1][2] + s_part[2][2] + s_part[3][2];
+		if (midp) {
+			tail -= 0.5 * ties;
+		}
+		double pv = tail / total;
+		ln_p[i] = log(pv > 1.0 ? 1.0 : pv);
+	}
+}
+
 } // namespace
 
 // ---------------------------------------------------------------------------
@@ -768,6 +827,14 @@ hipError_t LaunchHweBatch(const uint32_t *counts, uint32_t n, uint32_t midp, dou
 		return hipSuccess;
 	}
 	hipLaunchKernelGGL(k_hwe_batch, dim3((n + 63) / 64), dim3(64), 0, stream, counts, n, midp, ln_p);
+	return hipGetLastError();
+}
+
+hipError_t LaunchHweXchrBatch(const int32_t *strata, uint32_t n, uint32_t midp, double *ln_p, hipStream_t stream) {
+	if (n == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_hwe_xchr_batch, dim3(n), dim3(256), 0, stream, strata, n, midp, ln_p);
 	return hipGetLastError();
 }
 

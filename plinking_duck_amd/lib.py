@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "pgh_unpack_range_dev", "pgh_score", "pgh_score_dev", "pgh_score_plan_create", "pgh_score_run_dev",
     "pgh_score_plan_destroy", "pgh_pca", "pgh_pca_sharded", "pgh_ld_pairs", "pgh_sample_counts", "pgh_reader_create", "pgh_reader_destroy",
     "pgh_get_2bit", "pgh_get_counts", "pgh_get_missingness", "pgh_get_int8", "pgh_get_dosage_f64", "pgh_get_phased",
-    "pgh_reader_error", "pgh_hwe_lnp", "pgh_hwe_xchr_lnp", "pgh_hwe_lnp_batch", "pgh_hwe_lnp_batch_dev",
+    "pgh_reader_error", "pgh_hwe_lnp", "pgh_hwe_xchr_lnp", "pgh_hwe_lnp_batch", "pgh_hwe_lnp_batch_dev", "pgh_hwe_xchr_lnp_batch",
 ]
 
 
@@ -108,6 +108,7 @@ def _load():
         "pgh_score_plan_destroy": (None, [vp]),
         "pgh_pca": (C.c_int, [vp, vp, u32, vp, vp, vp, u32, vp, vp, vp, cp]),
         "pgh_ld_pairs": (C.c_int, [vp, vp, u32, vp, vp, vp, cp]),
+        "pgh_hwe_xchr_lnp_batch": (C.c_int, [vp, u32, u32, vp, cp]),
         "pgh_sample_counts": (C.c_int, [vp, vp, u32, u32, vp, vp, cp]),
         "pgh_pca_sharded": (C.c_int, [vp, vp, u32, vp, vp, vp, C.c_uint64, u32, vp, ALLREDUCE_FN, vp, vp, vp, cp]),
         "pgh_reader_create": (C.c_int, [vp, vp, C.POINTER(vp), cp]),
@@ -188,6 +189,16 @@ def normalize_range_host(path: str, v_begin: int = 0, v_end: int | None = None, 
 
 def hwe_lnp(hets: int, hom1: int, hom2: int, midp: bool = False) -> float:
     return _lib.pgh_hwe_lnp(hets, hom1, hom2, 1 if midp else 0)
+
+
+def hwe_xchr_lnp_batch(strata, midp: bool = False) -> np.ndarray:
+    """strata: int32[n][5] = {female_hets, female_hom1, female_hom2, male1, male2} -> ln p per variant (device)."""
+    st = np.ascontiguousarray(strata, dtype=np.int32)
+    assert st.ndim == 2 and st.shape[1] == 5
+    out = np.zeros(len(st), dtype=np.float64)
+    eb = _errbuf()
+    _check(_lib.pgh_hwe_xchr_lnp_batch(_ptr(st), len(st), 1 if midp else 0, _ptr(out), eb), eb)
+    return out
 
 
 def hwe_xchr_lnp(fhets: int, fhom1: int, fhom2: int, male1: int, male2: int, midp: bool = False) -> float:

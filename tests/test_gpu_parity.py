@@ -457,3 +457,35 @@ def test_full_size_matrix_properties(gpu_lib):
     for r in range(8):
         row = np.where(geno[r] == -9, 3, geno[r])
         assert [int((row == c).sum()) for c in range(4)] == [int(x) for x in counts[cut + r]]
+
+
+def test_hwe_xchr_batch_matches_host_and_oracle(gpu_lib, oracle):
+    """The device chrX exact test (one workgroup per variant) against the library's host routine
+    (same rule, running log-ratios instead of lgamma) and, for small tables, the oracle's full enumeration."""
+    rng = np.random.default_rng(41)
+    rows = []
+    for _ in range(120):
+        nf, nm = int(rng.integers(0, 4000)), int(rng.integers(0, 4000))
+        p = rng.uniform(0.02, 0.98)
+        f = rng.uniform(-0.1, 0.2)
+        pr = np.clip([p * p + f * p * (1 - p), 2 * p * (1 - p) * (1 - f), (1 - p) ** 2 + f * p * (1 - p)], 0, None)
+        hom1, het, hom2 = rng.multinomial(nf, pr / pr.sum())
+        male1 = int(rng.binomial(nm, min(1.0, max(0.0, p + rng.uniform(-0.05, 0.05)))))
+        rows.append([het, hom1, hom2, male1, nm - male1])
+    rows += [[0, 0, 0, 0, 0], [0, 0, 0, 5, 7], [3, 2, 1, 0, 0], [1, 1, 1, 1, 1], [0, 10, 0, 10, 0], [200000, 150000, 70000, 130000, 90000]]
+    strata = np.array(rows, dtype=np.int32)
+    for midp in (False, True):
+        got = gpu_lib.hwe_xchr_lnp_batch(strata, midp)
+        for i, (fh, f1, f2, m1, m2) in enumerate(rows[:-1]):
+            host = gpu_lib.hwe_xchr_lnp(fh, f1, f2, m1, m2, midp)
+            if np.isinf(host):
+                assert got[i] < -700
+            else:
+                assert abs(got[i] - host) < 1e-8, (rows[i], midp, got[i], host)
+        for i in range(0, 40):
+            fh, f1, f2, m1, m2 = rows[i]
+            if fh + f1 + f2 + m1 + m2 <= 1500:
+                exp = oracle.hwe_xchr_lnp(fh, f1, f2, m1, m2, midp)
+                assert abs(got[i] - exp) < 1e-6 or (np.isinf(exp) and got[i] < -700)
+    # biobank-sized strata finish (the host routine takes ~0.1 s for this one table)
+    assert np.isfinite(got[-1]) or got[-1] < -700
