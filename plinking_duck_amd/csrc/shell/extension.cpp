@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <mutex>
+#include <chrono>
 #include <thread>
 
 namespace duckdb {
@@ -206,7 +207,9 @@ string RunQuery(const string &request) {
 
 	vector<LogicalType> return_types;
 	vector<string> names;
+	const auto t_bind0 = std::chrono::steady_clock::now();
 	auto bind_data = tf.bind(context, bind_input, return_types, names);
+	const auto t_bind1 = std::chrono::steady_clock::now();
 
 	// projection pushdown: "columns": [names] or absent for all
 	TableFunctionInitInput init_input;
@@ -243,7 +246,9 @@ string RunQuery(const string &request) {
 		out_types.push_back(return_types[c]);
 	}
 
+	const auto t_init0 = std::chrono::steady_clock::now();
 	auto gstate = tf.init_global(context, init_input);
+	const auto t_init1 = std::chrono::steady_clock::now();
 	idx_t n_threads = std::max<idx_t>(1, std::min<idx_t>(gstate->MaxThreads(), context.db_threads));
 
 	std::mutex result_mutex;
@@ -309,6 +314,10 @@ string RunQuery(const string &request) {
 	for (auto &t : threads) {
 		t.join();
 	}
+	const auto t_scan1 = std::chrono::steady_clock::now();
+	auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+		return std::chrono::duration<double, std::milli>(b - a).count();
+	};
 	if (!first_error.empty()) {
 		return ErrorJson(first_error_kind.c_str(), first_error);
 	}
@@ -334,7 +343,10 @@ string RunQuery(const string &request) {
 		}
 		pdkjson::EscapeTo(out, names[i]);
 	}
-	out += "],\"threads\":" + std::to_string(n_threads) + ",\"row_count\":" + std::to_string(total_rows) + ",\"rows\":[";
+	// phase times of this call (bind = companions + header probe, init = device residency, scan = threads)
+	out += "],\"bind_ms\":" + std::to_string(ms(t_bind0, t_bind1)) + ",\"init_ms\":" + std::to_string(ms(t_init0, t_init1)) +
+	       ",\"scan_ms\":" + std::to_string(ms(t_init1, t_scan1));
+	out += ",\"threads\":" + std::to_string(n_threads) + ",\"row_count\":" + std::to_string(total_rows) + ",\"rows\":[";
 	bool first = true;
 	for (auto &rc : row_chunks) {
 		if (!first) {

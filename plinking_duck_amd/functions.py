@@ -54,6 +54,7 @@ class Result:
         self.types = doc["types"]
         self.all_names = doc["all_names"]
         self.threads = doc["threads"]
+        self.timing_ms = {k: doc.get(k + "_ms") for k in ("bind", "init", "scan")}
         self.rows = [tuple(r) for r in doc["rows"]]
 
     def __len__(self):
