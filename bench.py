@@ -49,7 +49,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--variants", type=int, default=1_000_000, help="variants per rank (weak) or in total (strong)")
     ap.add_argument("--samples", type=int, default=500_000)
-    ap.add_argument("--workload", choices=["freq", "fused", "unpack", "score", "pca"], default="freq")
+    ap.add_argument("--ld-variants", type=int, default=20000, help="anchors of the ld workload")
+    ap.add_argument("--ld-window", type=int, default=64, help="partners per anchor of the ld workload")
+    ap.add_argument("--workload", choices=["freq", "fused", "unpack", "score", "pca", "ld", "samplecounts"], default="freq")
     ap.add_argument("--n-pcs", type=int, default=10)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 disables)")
@@ -215,6 +217,55 @@ def main():
         kernel_name = "k_unpack"
         metric = "read_pgen genotypes/s"
         dtype = "u8"
+    elif args.workload == "samplecounts":
+        # read_pfile orient := 'sample', genotypes := 'counts': per-sample {het, hom_alt, missing}
+        # tallies over every variant (hom_ref by subtraction) -- three column-tally passes
+        padded = (n + 63) // 64 * 64
+        d_cls = torch.empty((3, padded), dtype=torch.int32, device=dev)
+        h_cls = torch.empty((3, padded), dtype=torch.int32, pin_memory=True)
+        algo_bytes = 3 * m * record_bytes
+
+        def step(timed):
+            if timed:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+            ds.sample_counts_dev(v_begin, v_end, d_cls.data_ptr(), st)
+            if timed:
+                e1.record(stream)
+                kernel_events.append((e0, e1))
+            h_cls.copy_(d_cls, non_blocking=True)
+
+        kernel_name = "k_missing_cols<1..3> x3 + k_sum_slabs"
+        metric = "read_pfile sample-orient counts genotypes/s"
+    elif args.workload == "ld":
+        # plink_ld windowed shape: every anchor of the first --ld-variants rows against its next
+        # --ld-window variants; one launch for all pairs, six integer sums per pair
+        mv = min(m, args.ld_variants)
+        wdw = args.ld_window
+        p_a = np.repeat(np.arange(mv - wdw, dtype=np.uint32), wdw) + np.uint32(v_begin)
+        p_b = p_a + np.tile(np.arange(1, wdw + 1, dtype=np.uint32), mv - wdw)
+        n_pairs = len(p_a)
+        d_sums = torch.empty((n_pairs, 6), dtype=torch.int32, device=dev)
+        h_sums = torch.empty((n_pairs, 6), dtype=torch.int32, pin_memory=True)
+        units_per_step = n_pairs * n  # sample pairs
+        # an anchor row is read once per four partners: 1.25 rows per pair (repeats of a row by later
+        # anchors come out of L2/MALL; roofline.traffic would show the HBM share)
+        algo_bytes = int(n_pairs * 1.25 * record_bytes)
+
+        def step(timed):
+            if timed:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+            ds.ld_pairs_dev(p_a, p_b, d_sums.data_ptr(), st)
+            if timed:
+                e1.record(stream)
+                kernel_events.append((e0, e1))
+            h_sums.copy_(d_sums, non_blocking=True)
+
+        kernel_name = "k_ld_pairs"
+        metric = f"plink_ld sample pairs/s ({wdw} partners per anchor)"
     elif args.workload == "pca":
         # BASELINE config 5 shape: plink_pca, k = n_pcs (qq = (k+1)*2k), all passes + orthonormalisation
         k = args.n_pcs
@@ -307,6 +358,8 @@ def main():
     kernel_ms = [a.elapsed_time(b) for a, b in kernel_events]
     kern_avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
     total_units = sharding.total_variants(world, args.variants, args.scaling) * n
+    if args.workload == "ld":
+        total_units = units_per_step * (world if args.scaling == "weak" else 1)  # sample pairs, every rank the same shape
     value = total_units * args.steps / elapsed
 
     if algo_flops is not None and (args.workload == "pca" or args.score_cols >= 3):
@@ -329,7 +382,7 @@ def main():
         line = {
             "metric": metric,
             "value": value,
-            "unit": "genotypes/s",
+            "unit": "sample pairs/s" if args.workload == "ld" else "genotypes/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,

@@ -210,6 +210,10 @@ void pgh_score_plan_destroy(pgh_score_plan *plan);
  * subtraction as the reference derives it at emit time. */
 int pgh_sample_counts(const pgh_dataset *ds, const pgh_subset *subset, uint32_t variant_begin, uint32_t n_var,
                       const uint32_t *vidx, uint32_t (*counts)[4], char *errbuf);
+/* Enqueue-only form over all raw samples: d_classes = uint32[3][ceil(N/64)*64] receives the het,
+ * hom-alt and missing tallies (hom-ref = variants - the three). */
+int pgh_sample_counts_dev(const pgh_dataset *ds, uint32_t variant_begin, uint32_t variant_end, void *d_classes,
+                          void *stream, char *errbuf);
 
 /* plink_ld's per-pair sums (src/plink_ld.cpp:52-84, ComputeLdStats' sample loop): for each
  * pair p of variants (vidx_a[p], vidx_b[p]) over the samples at which both calls are present
@@ -221,6 +225,10 @@ int pgh_sample_counts(const pgh_dataset *ds, const pgh_subset *subset, uint32_t 
  * windowed scan's order) read the anchor row once per four partners. */
 int pgh_ld_pairs(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_pairs, const uint32_t *vidx_a,
                  const uint32_t *vidx_b, uint32_t (*sums)[6], char *errbuf);
+/* Device-output form: sums land in d_sums (uint32[n_pairs][6]) on `stream`; vidx_a / vidx_b stay
+ * host arrays (the task list is built from them and uploaded stream-ordered). */
+int pgh_ld_pairs_dev(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_pairs, const uint32_t *vidx_a,
+                     const uint32_t *vidx_b, void *d_sums, void *stream, char *errbuf);
 
 /* plink_pca's randomized subspace iteration (src/plink_pca.cpp:630-1080): n_pcs + 1
  * passes of Y = X G1 (Step A) and G1 = X^T Y / M (Step B) over the n_var effective

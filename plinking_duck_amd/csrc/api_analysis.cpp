@@ -120,6 +120,32 @@ extern "C" int pgh_missing_per_sample(const pgh_dataset *ds, const pgh_subset *s
 	return PGH_OK;
 }
 
+extern "C" int pgh_sample_counts_dev(const pgh_dataset *ds, uint32_t v_begin, uint32_t v_end, void *d_classes,
+                                     void *stream, char *errbuf) {
+	int rc = CheckRange(ds, v_begin, v_end, errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	if (!d_classes) {
+		SetErr(errbuf, "null argument");
+		return PGH_ERR_ARG;
+	}
+	const uint32_t padded = (ds->sample_ct + 63) / 64 * 64;
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	const size_t scratch_bytes = pgh::MissingPerSampleScratchBytes(ds->record_bytes, v_end - v_begin);
+	void *scratch = nullptr;
+	PGH_HIP(hipMallocAsync(&scratch, scratch_bytes ? scratch_bytes : 16, st), "sample counts scratch");
+	hipError_t e = hipSuccess;
+	for (int cls = 1; cls <= 3 && e == hipSuccess; cls++) {
+		e = pgh::LaunchClassPerSample(ds->View(), cls, v_begin - ds->v_begin, nullptr, v_end - v_begin, nullptr,
+		                              static_cast<uint32_t *>(scratch),
+		                              static_cast<uint32_t *>(d_classes) + static_cast<size_t>(cls - 1) * padded, st);
+	}
+	(void)hipFreeAsync(scratch, st);
+	PGH_HIP(e, "sample counts kernel");
+	return PGH_OK;
+}
+
 extern "C" int pgh_sample_counts(const pgh_dataset *ds, const pgh_subset *subset, uint32_t variant_begin,
                                  uint32_t n_var, const uint32_t *vidx, uint32_t (*counts)[4], char *errbuf) {
 	if (!ds || !counts) {
@@ -675,9 +701,10 @@ extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, 
 // plink_ld
 // ---------------------------------------------------------------------------
 
-extern "C" int pgh_ld_pairs(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_pairs, const uint32_t *vidx_a,
-                            const uint32_t *vidx_b, uint32_t (*sums)[6], char *errbuf) {
-	if (!ds || (n_pairs && (!vidx_a || !vidx_b || !sums))) {
+extern "C" int pgh_ld_pairs_dev(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_pairs,
+                                const uint32_t *vidx_a, const uint32_t *vidx_b, void *d_sums, void *stream,
+                                char *errbuf) {
+	if (!ds || (n_pairs && (!vidx_a || !vidx_b || !d_sums))) {
 		SetErr(errbuf, "null argument");
 		return PGH_ERR_ARG;
 	}
@@ -707,28 +734,37 @@ extern "C" int pgh_ld_pairs(const pgh_dataset *ds, const pgh_subset *subset, uin
 		}
 		tasks.push_back(pgh::LdTask {a - ds->v_begin, b - ds->v_begin, 1u, p});
 	}
-	hipStream_t st = hipStreamPerThread;
-	void *d_tasks = nullptr, *d_out = nullptr;
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	void *d_tasks = nullptr;
 	PGH_HIP(hipMallocAsync(&d_tasks, sizeof(pgh::LdTask) * tasks.size(), st), "ld scratch");
-	hipError_t e = hipMallocAsync(&d_out, 24ull * n_pairs, st);
-	if (e == hipSuccess) {
-		e = hipMemcpyAsync(d_tasks, tasks.data(), sizeof(pgh::LdTask) * tasks.size(), hipMemcpyHostToDevice, st);
-	}
+	// pageable source: the copy is staged before the call returns, so `tasks` may die with this frame
+	hipError_t e = hipMemcpyAsync(d_tasks, tasks.data(), sizeof(pgh::LdTask) * tasks.size(), hipMemcpyHostToDevice, st);
 	if (e == hipSuccess) {
 		e = pgh::LaunchLdPairs(ds->View(), static_cast<const pgh::LdTask *>(d_tasks),
 		                       static_cast<uint32_t>(tasks.size()), subset ? subset->d_mask2 : nullptr,
-		                       static_cast<uint32_t(*)[6]>(d_out), st);
-	}
-	if (e == hipSuccess) {
-		e = hipMemcpyAsync(sums, d_out, 24ull * n_pairs, hipMemcpyDeviceToHost, st);
-	}
-	if (e == hipSuccess) {
-		e = hipStreamSynchronize(st); // `tasks` and `sums` are host memory of this frame / the caller
+		                       static_cast<uint32_t(*)[6]>(d_sums), st);
 	}
 	(void)hipFreeAsync(d_tasks, st);
-	if (d_out) {
-		(void)hipFreeAsync(d_out, st);
-	}
 	PGH_HIP(e, "ld pair kernel");
+	return PGH_OK;
+}
+
+extern "C" int pgh_ld_pairs(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_pairs, const uint32_t *vidx_a,
+                            const uint32_t *vidx_b, uint32_t (*sums)[6], char *errbuf) {
+	if (n_pairs && !sums) {
+		SetErr(errbuf, "null argument");
+		return PGH_ERR_ARG;
+	}
+	if (n_pairs == 0) {
+		return PGH_OK;
+	}
+	DevBuf d_out;
+	PGH_HIP(d_out.Alloc(24ull * n_pairs), "hipMalloc(ld)");
+	int rc = pgh_ld_pairs_dev(ds, subset, n_pairs, vidx_a, vidx_b, d_out.p, hipStreamPerThread, errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	PGH_HIP(hipMemcpyAsync(sums, d_out.p, 24ull * n_pairs, hipMemcpyDeviceToHost, hipStreamPerThread), "ld copy");
+	PGH_HIP(hipStreamSynchronize(hipStreamPerThread), "ld sync");
 	return PGH_OK;
 }

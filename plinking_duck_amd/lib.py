@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     "pgh_close", "pgh_subset_create", "pgh_subset_size", "pgh_subset_destroy", "pgh_counts_range",
     "pgh_counts_range_dev", "pgh_freq_from_counts_dev", "pgh_fused_tally_dev", "pgh_missing_per_sample", "pgh_missing_per_sample_dev", "pgh_unpack_range",
     "pgh_unpack_range_dev", "pgh_score", "pgh_score_dev", "pgh_score_plan_create", "pgh_score_run_dev",
-    "pgh_score_plan_destroy", "pgh_pca", "pgh_pca_sharded", "pgh_ld_pairs", "pgh_sample_counts", "pgh_reader_create", "pgh_reader_destroy",
+    "pgh_score_plan_destroy", "pgh_pca", "pgh_pca_sharded", "pgh_ld_pairs", "pgh_ld_pairs_dev", "pgh_sample_counts", "pgh_sample_counts_dev", "pgh_reader_create", "pgh_reader_destroy",
     "pgh_get_2bit", "pgh_get_counts", "pgh_get_missingness", "pgh_get_int8", "pgh_get_dosage_f64", "pgh_get_phased",
     "pgh_reader_error", "pgh_hwe_lnp", "pgh_hwe_xchr_lnp", "pgh_hwe_lnp_batch", "pgh_hwe_lnp_batch_dev", "pgh_hwe_xchr_lnp_batch",
 ]
@@ -110,6 +110,8 @@ def _load():
         "pgh_ld_pairs": (C.c_int, [vp, vp, u32, vp, vp, vp, cp]),
         "pgh_hwe_xchr_lnp_batch": (C.c_int, [vp, u32, u32, vp, cp]),
         "pgh_sample_counts": (C.c_int, [vp, vp, u32, u32, vp, vp, cp]),
+        "pgh_sample_counts_dev": (C.c_int, [vp, u32, u32, vp, vp, cp]),
+        "pgh_ld_pairs_dev": (C.c_int, [vp, vp, u32, vp, vp, vp, vp, cp]),
         "pgh_pca_sharded": (C.c_int, [vp, vp, u32, vp, vp, vp, C.c_uint64, u32, vp, ALLREDUCE_FN, vp, vp, vp, cp]),
         "pgh_reader_create": (C.c_int, [vp, vp, C.POINTER(vp), cp]),
         "pgh_reader_destroy": (None, [vp]),
@@ -434,6 +436,17 @@ class Dataset:
             v1 = self.v_end if v_end is None else v_end
             _check(_lib.pgh_sample_counts(self._h, subset._h if subset else None, v0, v1 - v0, None, _ptr(out), eb), eb)
         return out
+
+    def sample_counts_dev(self, v_begin, v_end, d_classes: int, stream: int = 0):
+        eb = _errbuf()
+        _check(_lib.pgh_sample_counts_dev(self._h, v_begin, v_end, d_classes, stream, eb), eb)
+
+    def ld_pairs_dev(self, vidx_a: np.ndarray, vidx_b: np.ndarray, d_sums: int, stream: int = 0,
+                     subset: Subset | None = None):
+        """vidx_a / vidx_b: contiguous uint32 host arrays (kept by the caller); sums land in d_sums."""
+        eb = _errbuf()
+        _check(_lib.pgh_ld_pairs_dev(self._h, subset._h if subset else None, len(vidx_a), _ptr(vidx_a), _ptr(vidx_b),
+                                     d_sums, stream, eb), eb)
 
     def ld_pairs(self, vidx_a, vidx_b, subset: Subset | None = None) -> np.ndarray:
         """uint32[n_pairs][6] = {n, sum_a, sum_b, sum_ab, sum_a2, sum_b2} per pair."""
