@@ -219,11 +219,11 @@ def main():
         dtype = "u8"
     elif args.workload == "samplecounts":
         # read_pfile orient := 'sample', genotypes := 'counts': per-sample {het, hom_alt, missing}
-        # tallies over every variant (hom_ref by subtraction) -- three column-tally passes
+        # tallies over every variant (hom_ref by subtraction) -- one pass, three counter sets per lane
         padded = (n + 63) // 64 * 64
         d_cls = torch.empty((3, padded), dtype=torch.int32, device=dev)
         h_cls = torch.empty((3, padded), dtype=torch.int32, pin_memory=True)
-        algo_bytes = 3 * m * record_bytes
+        algo_bytes = m * record_bytes
 
         def step(timed):
             if timed:
@@ -236,7 +236,7 @@ def main():
                 kernel_events.append((e0, e1))
             h_cls.copy_(d_cls, non_blocking=True)
 
-        kernel_name = "k_missing_cols<1..3> x3 + k_sum_slabs"
+        kernel_name = "k_class_cols3 + k_sum_class_bytes"
         metric = "read_pfile sample-orient counts genotypes/s"
     elif args.workload == "ld":
         # plink_ld windowed shape: every anchor of the first --ld-variants rows against its next

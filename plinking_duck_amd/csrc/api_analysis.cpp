@@ -132,15 +132,11 @@ extern "C" int pgh_sample_counts_dev(const pgh_dataset *ds, uint32_t v_begin, ui
 	}
 	const uint32_t padded = (ds->sample_ct + 63) / 64 * 64;
 	hipStream_t st = static_cast<hipStream_t>(stream);
-	const size_t scratch_bytes = pgh::MissingPerSampleScratchBytes(ds->record_bytes, v_end - v_begin);
+	const size_t scratch_bytes = pgh::ClassCounts3ScratchBytes(ds->record_bytes);
 	void *scratch = nullptr;
-	PGH_HIP(hipMallocAsync(&scratch, scratch_bytes ? scratch_bytes : 16, st), "sample counts scratch");
-	hipError_t e = hipSuccess;
-	for (int cls = 1; cls <= 3 && e == hipSuccess; cls++) {
-		e = pgh::LaunchClassPerSample(ds->View(), cls, v_begin - ds->v_begin, nullptr, v_end - v_begin, nullptr,
-		                              static_cast<uint32_t *>(scratch),
-		                              static_cast<uint32_t *>(d_classes) + static_cast<size_t>(cls - 1) * padded, st);
-	}
+	PGH_HIP(hipMallocAsync(&scratch, scratch_bytes, st), "sample counts scratch");
+	hipError_t e = pgh::LaunchClassCounts3(ds->View(), v_begin - ds->v_begin, nullptr, v_end - v_begin,
+	                                       static_cast<uint8_t *>(scratch), static_cast<uint32_t *>(d_classes), padded, st);
 	(void)hipFreeAsync(scratch, st);
 	PGH_HIP(e, "sample counts kernel");
 	return PGH_OK;
@@ -178,20 +174,17 @@ extern "C" int pgh_sample_counts(const pgh_dataset *ds, const pgh_subset *subset
 	hipStream_t st = hipStreamPerThread;
 	DevBuf d_cls, d_list, d_scratch;
 	PGH_HIP(d_cls.Alloc(sizeof(uint32_t) * 3ull * padded), "hipMalloc(sample counts)");
-	const size_t scratch_bytes = pgh::MissingPerSampleScratchBytes(ds->record_bytes, n_var);
-	PGH_HIP(d_scratch.Alloc(scratch_bytes ? scratch_bytes : 16), "hipMalloc(sample counts)");
+	PGH_HIP(d_scratch.Alloc(pgh::ClassCounts3ScratchBytes(ds->record_bytes)), "hipMalloc(sample counts)");
 	if (vidx && n_var) {
 		PGH_HIP(d_list.Alloc(sizeof(uint32_t) * n_var), "hipMalloc(sample counts)");
 		PGH_HIP(hipMemcpyAsync(d_list.p, local.data(), sizeof(uint32_t) * n_var, hipMemcpyHostToDevice, st),
 		        "sample counts upload");
 	}
-	// one column-tally pass per class (het, hom-alt, missing); hom-ref is what is left
-	for (int cls = 1; cls <= 3; cls++) {
-		PGH_HIP(pgh::LaunchClassPerSample(ds->View(), cls, vidx ? 0 : variant_begin - ds->v_begin,
-		                                  vidx ? d_list.As<uint32_t>() : nullptr, n_var, nullptr,
-		                                  d_scratch.As<uint32_t>(), d_cls.As<uint32_t>() + (cls - 1) * padded, st),
-		        "sample counts kernel");
-	}
+	// het, hom-alt and missing column tallies in one pass; hom-ref is what is left
+	PGH_HIP(pgh::LaunchClassCounts3(ds->View(), vidx ? 0 : variant_begin - ds->v_begin,
+	                                vidx ? d_list.As<uint32_t>() : nullptr, n_var, d_scratch.As<uint8_t>(),
+	                                d_cls.As<uint32_t>(), padded, st),
+	        "sample counts kernel");
 	std::vector<uint32_t> raw(3ull * padded);
 	PGH_HIP(hipMemcpyAsync(raw.data(), d_cls.p, sizeof(uint32_t) * raw.size(), hipMemcpyDeviceToHost, st),
 	        "sample counts copy");

@@ -51,6 +51,12 @@ hipError_t LaunchClassPerSample(const RowView &view, int genotype_class, uint32_
                                 uint32_t v_count, const uint32_t *row_flags, uint32_t *scratch, uint32_t *out,
                                 hipStream_t stream);
 
+// All three non-reference codes in ONE pass: out[c * out_stride + s] for c = het, hom-alt, missing.
+// scratch: ClassCounts3ScratchBytes() bytes of device memory (byte-counter slabs).
+size_t ClassCounts3ScratchBytes(uint32_t record_bytes);
+hipError_t LaunchClassCounts3(const RowView &view, uint32_t v_first, const uint32_t *vlist, uint32_t v_count,
+                              uint8_t *scratch, uint32_t *out, uint32_t out_stride, hipStream_t stream);
+
 // Both reductions in one pass over [v_first, v_first + v_count): counts[i] = class tallies
 // of row i (all samples), missing_per_sample[s] as above.  Same scratch size as
 // LaunchMissingPerSample.

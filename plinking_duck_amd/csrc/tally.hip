@@ -10,6 +10,8 @@
 //
 // 16 B per lane coalesced loads, v_bcnt_u32_b32 tallies with its free accumulate operand, wave
 // reductions by shuffles, LDS only for the cross-wave step.
+#include <algorithm>
+
 #include "device_utils.hpp"
 #include "kernels.hpp"
 
@@ -347,6 +349,158 @@ __global__ __launch_bounds__(256) void k_missing_cols(const uint8_t *__restrict_
 	for (int k = 0; k < 16; k++) {
 		dst[k] = make_uint4(acc.a32[4 * k], acc.a32[4 * k + 1], acc.a32[4 * k + 2], acc.a32[4 * k + 3]);
 	}
+}
+
+// ---------------------------------------------------------------------------
+// per-sample tallies of all three non-reference codes in one pass
+// ---------------------------------------------------------------------------
+//
+// read_pfile's sample-orient counts need het, hom-alt and missing per sample; three passes of
+// k_missing_cols read the matrix three times.  One pass keeps three sets of SWAR counters per
+// lane, which only fits the register file if the last level stays 8-bit: a workgroup therefore
+// takes a slice of at most 252 rows and writes its 3 x 64 byte counters per lane raw (the a8
+// layout: word 4j+q, byte b counts sample 16j + 4b + {0,2,1,3}[q]); k_sum_class_bytes undoes the
+// layout and adds the slices.  The byte slabs are 3 B per sample per 252 rows, +1 % of the read.
+constexpr uint32_t kCols3Rows = 252;   // rows per slice: a multiple of 6, <= 255
+constexpr uint32_t kCols3Super = 256;  // slices per launch (bounds the slab scratch to ~0.4 GB at N = 500k)
+
+struct ClassAcc8 {
+	uint32_t a4[8];
+	uint32_t a8[16];
+};
+
+__device__ __forceinline__ void Fold2To4(ClassAcc8 &acc, const uint32_t a2[4]) {
+#pragma unroll
+	for (int j = 0; j < 4; j++) {
+		acc.a4[2 * j] += a2[j] & 0x33333333u;
+		acc.a4[2 * j + 1] += (a2[j] >> 2) & 0x33333333u;
+	}
+}
+
+__device__ __forceinline__ void Fold4To8(ClassAcc8 &acc) {
+#pragma unroll
+	for (int j = 0; j < 4; j++) {
+		acc.a8[4 * j + 0] += acc.a4[2 * j] & 0x0f0f0f0fu;
+		acc.a8[4 * j + 1] += (acc.a4[2 * j] >> 4) & 0x0f0f0f0fu;
+		acc.a8[4 * j + 2] += acc.a4[2 * j + 1] & 0x0f0f0f0fu;
+		acc.a8[4 * j + 3] += (acc.a4[2 * j + 1] >> 4) & 0x0f0f0f0fu;
+		acc.a4[2 * j] = 0;
+		acc.a4[2 * j + 1] = 0;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_class_cols3(const uint8_t *__restrict__ rows, uint64_t pitch, uint32_t chunks,
+                                                     uint32_t v_first, const uint32_t *__restrict__ vlist,
+                                                     uint32_t v_count, uint8_t *__restrict__ slabs,
+                                                     uint64_t slab_stride) {
+	const uint32_t col = blockIdx.x * 256u + threadIdx.x;
+	if (col >= chunks) {
+		return;
+	}
+	const uint32_t i_begin = blockIdx.y * kCols3Rows;
+	const uint32_t i_end = min(i_begin + kCols3Rows, v_count);
+	ClassAcc8 acc[3]; // het, hom-alt, missing
+#pragma unroll
+	for (int c = 0; c < 3; c++) {
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			acc[c].a4[j] = 0;
+		}
+#pragma unroll
+		for (int j = 0; j < 16; j++) {
+			acc[c].a8[j] = 0;
+		}
+	}
+	auto row_ptr = [&](uint32_t idx) {
+		const uint32_t v = vlist ? vlist[idx] : v_first + idx;
+		return reinterpret_cast<const uint4 *>(rows + static_cast<uint64_t>(v) * pitch) + col;
+	};
+	// indicator words of the three codes of one data word, added into a2[class][word]
+	auto add_word = [&](uint32_t w, uint32_t a2[3][4], int k) {
+		const uint32_t lo = w & kLow, hi = (w >> 1) & kLow;
+		const uint32_t both = lo & hi;
+		a2[0][k] += lo ^ both;
+		a2[1][k] += hi ^ both;
+		a2[2][k] += both;
+	};
+	auto add_row = [&](const uint4 &w, uint32_t a2[3][4]) {
+		add_word(w.x, a2, 0);
+		add_word(w.y, a2, 1);
+		add_word(w.z, a2, 2);
+		add_word(w.w, a2, 3);
+	};
+	uint32_t n4 = 0; // rows folded into the 4-bit fields since the last 4 -> 8 fold
+	auto fold = [&](uint32_t a2[3][4], uint32_t take) {
+#pragma unroll
+		for (int c = 0; c < 3; c++) {
+			Fold2To4(acc[c], a2[c]);
+		}
+		n4 += take;
+		if (n4 + 3 > 15) {
+#pragma unroll
+			for (int c = 0; c < 3; c++) {
+				Fold4To8(acc[c]);
+			}
+			n4 = 0;
+		}
+	};
+	uint32_t i = i_begin;
+	while (i + 6 <= i_end) {
+		const uint4 w0 = LoadStream(row_ptr(i));
+		const uint4 w1 = LoadStream(row_ptr(i + 1));
+		const uint4 w2 = LoadStream(row_ptr(i + 2));
+		const uint4 w3 = LoadStream(row_ptr(i + 3));
+		const uint4 w4 = LoadStream(row_ptr(i + 4));
+		const uint4 w5 = LoadStream(row_ptr(i + 5));
+		uint32_t a[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+		add_row(w0, a);
+		add_row(w1, a);
+		add_row(w2, a);
+		fold(a, 3);
+		uint32_t b[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+		add_row(w3, b);
+		add_row(w4, b);
+		add_row(w5, b);
+		fold(b, 3);
+		i += 6;
+	}
+	while (i < i_end) {
+		const uint4 w0 = LoadStream(row_ptr(i));
+		uint32_t a[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+		add_row(w0, a);
+		fold(a, 1);
+		i += 1;
+	}
+#pragma unroll
+	for (int c = 0; c < 3; c++) {
+		Fold4To8(acc[c]);
+		uint4 *dst = reinterpret_cast<uint4 *>(slabs + (static_cast<uint64_t>(blockIdx.y) * 3u + c) * slab_stride +
+		                                       static_cast<uint64_t>(col) * 64u);
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			dst[k] = make_uint4(acc[c].a8[4 * k], acc[c].a8[4 * k + 1], acc[c].a8[4 * k + 2], acc[c].a8[4 * k + 3]);
+		}
+	}
+}
+
+// out[c][s] (+)= sum over the slices of sample s's byte counter of class c
+__global__ __launch_bounds__(256) void k_sum_class_bytes(const uint8_t *__restrict__ slabs, uint64_t slab_stride,
+                                                         uint32_t n_slices, uint32_t n, uint32_t out_stride,
+                                                         uint32_t accumulate, uint32_t *__restrict__ out) {
+	const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+	const uint32_t c = blockIdx.y;
+	if (s >= n) {
+		return;
+	}
+	// where k_class_cols3 left sample s: lane column s / 64; inside it word 4j + q, byte b
+	const uint32_t t = s & 63u, j = t >> 4, r = t & 15u, b = r >> 2, within = r & 3u;
+	const uint32_t q = within == 0 ? 0u : (within == 1 ? 2u : (within == 2 ? 1u : 3u));
+	const uint64_t at = static_cast<uint64_t>(s >> 6) * 64u + (4u * j + q) * 4u + b;
+	uint32_t acc = accumulate ? out[static_cast<uint64_t>(c) * out_stride + s] : 0u;
+	for (uint32_t y = 0; y < n_slices; y++) {
+		acc += slabs[(static_cast<uint64_t>(y) * 3u + c) * slab_stride + at];
+	}
+	out[static_cast<uint64_t>(c) * out_stride + s] = acc;
 }
 
 // ---------------------------------------------------------------------------
@@ -795,6 +949,39 @@ hipError_t LaunchClassPerSample(const RowView &view, int genotype_class, uint32_
 	hipLaunchKernelGGL(k_sum_slabs, dim3((view.sample_ct + 255) / 256), dim3(256), 0, stream, scratch, stride, slices,
 	                   view.sample_ct, out);
 	return hipGetLastError();
+}
+
+size_t ClassCounts3ScratchBytes(uint32_t record_bytes) {
+	const uint64_t chunks = (static_cast<uint64_t>(record_bytes) + 15) / 16;
+	return static_cast<size_t>(kCols3Super) * 3u * chunks * 64u;
+}
+
+hipError_t LaunchClassCounts3(const RowView &view, uint32_t v_first, const uint32_t *vlist, uint32_t v_count,
+                              uint8_t *scratch, uint32_t *out, uint32_t out_stride, hipStream_t stream) {
+	if (v_count == 0) {
+		return hipMemsetAsync(out, 0, sizeof(uint32_t) * 3ull * out_stride, stream);
+	}
+	const uint32_t chunks = static_cast<uint32_t>((static_cast<uint64_t>(view.record_bytes) + 15) / 16);
+	const uint32_t col_blocks = (chunks + 255) / 256;
+	const uint64_t slab_stride = static_cast<uint64_t>(chunks) * 64u;
+	const uint32_t rows_per_launch = kCols3Super * kCols3Rows;
+	for (uint32_t done = 0; done < v_count; done += rows_per_launch) {
+		const uint32_t n_rows = std::min(rows_per_launch, v_count - done);
+		const uint32_t slices = (n_rows + kCols3Rows - 1) / kCols3Rows;
+		hipLaunchKernelGGL(k_class_cols3, dim3(col_blocks, slices), dim3(256), 0, stream, view.rows, view.pitch, chunks,
+		                   v_first + done, vlist ? vlist + done : nullptr, n_rows, scratch, slab_stride);
+		hipError_t e = hipGetLastError();
+		if (e != hipSuccess) {
+			return e;
+		}
+		hipLaunchKernelGGL(k_sum_class_bytes, dim3((view.sample_ct + 255) / 256, 3), dim3(256), 0, stream, scratch,
+		                   slab_stride, slices, view.sample_ct, out_stride, done ? 1u : 0u, out);
+		e = hipGetLastError();
+		if (e != hipSuccess) {
+			return e;
+		}
+	}
+	return hipSuccess;
 }
 
 hipError_t LaunchFusedTally(const RowView &view, uint32_t v_first, uint32_t v_count, uint32_t *scratch,
