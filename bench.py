@@ -57,6 +57,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 disables)")
     ap.add_argument("--cpu-sample-variants", type=int, default=8192)
     ap.add_argument("--score-cols", type=int, default=16)
+    ap.add_argument("--score-no-dosage-sum", action="store_true",
+                    help="score workload without NAMED_ALLELE_DOSAGE_SUM (what SELECT IID, SCORE_SUM projects)")
     return ap.parse_args()
 
 
@@ -327,16 +329,16 @@ def main():
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
-            plan.run_dev(d_score.data_ptr(), d_dos.data_ptr(), d_ac.data_ptr(), st)
+            plan.run_dev(d_score.data_ptr(), 0 if args.score_no_dosage_sum else d_dos.data_ptr(), d_ac.data_ptr(), st)
             if timed:
                 e1.record(stream)
                 kernel_events.append((e0, e1))
             if dist is not None:
                 # per-sample partials of the variant shards: RCCL reduce over xGMI
-                sharding.reduce_partials(dist, [d_score, d_dos, d_ac])
+                sharding.reduce_partials(dist, [d_score, d_ac] if args.score_no_dosage_sum else [d_score, d_dos, d_ac])
 
         kernel_name = "k_score_gemv_pairs" if ncol == 1 else ("k_accumulate_mfma" if ncol >= 3 else "k_score_accumulate")
-        metric = f"plink_score genotypes/s ({ncol} weight columns)"
+        metric = f"plink_score genotypes/s ({ncol} weight columns{', no dosage sum' if args.score_no_dosage_sum else ''})"
         dtype = "f64"
 
     def barrier():

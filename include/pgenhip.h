@@ -180,7 +180,10 @@ int pgh_unpack_range_dev(const pgh_dataset *ds, const pgh_subset *subset, uint32
  *   flip[i]      scored allele is REF (dosage 2 - alt)      (may be NULL)
  *   mode         PGH_SCORE_MEAN_IMPUTE | _NO_MEAN_IMPUTATION | _CENTER
  * Outputs over the included samples (ascending file order):
- *   score_sum    [n_out][n_cols], dosage_sum [n_out], allele_ct [n_out]. */
+ *   score_sum    [n_out][n_cols], dosage_sum [n_out], allele_ct [n_out].
+ * dosage_sum (d_dosage_sum in the device forms) may be NULL when NAMED_ALLELE_DOSAGE_SUM is not
+ * wanted: the one-column kernel then looks up 8-byte instead of 16-byte entries and does half
+ * the adds (the reference always accumulates it; skipping it is projection pushdown). */
 enum { PGH_SCORE_MEAN_IMPUTE = 0, PGH_SCORE_NO_MEAN_IMPUTATION = 1, PGH_SCORE_CENTER = 2 };
 int pgh_score(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_scored, const uint32_t *vidx,
               const double *weights, const uint8_t *flip, uint32_t n_cols, int mode, double *score_sum,

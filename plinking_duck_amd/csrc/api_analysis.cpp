@@ -369,7 +369,7 @@ extern "C" int pgh_score_plan_create(const pgh_dataset *ds, const pgh_subset *su
 
 extern "C" int pgh_score_run_dev(const pgh_score_plan *plan, void *d_score_sum, void *d_dosage_sum, void *d_allele_ct,
                                  void *stream, char *errbuf) {
-	if (!plan || !d_score_sum || !d_dosage_sum || !d_allele_ct) {
+	if (!plan || !d_score_sum || !d_allele_ct) { // d_dosage_sum == NULL: the dosage sum is not wanted
 		SetErr(errbuf, "null argument");
 		return PGH_ERR_ARG;
 	}
@@ -377,7 +377,9 @@ extern "C" int pgh_score_run_dev(const pgh_score_plan *plan, void *d_score_sum, 
 	const uint32_t N = ds->sample_ct;
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	PGH_HIP(hipMemsetAsync(d_score_sum, 0, sizeof(double) * N * plan->n_cols, st), "score memset");
-	PGH_HIP(hipMemsetAsync(d_dosage_sum, 0, sizeof(double) * N, st), "score memset");
+	if (d_dosage_sum) {
+		PGH_HIP(hipMemsetAsync(d_dosage_sum, 0, sizeof(double) * N, st), "score memset");
+	}
 	if (plan->n_scored == 0) {
 		PGH_HIP(hipMemsetAsync(d_allele_ct, 0, sizeof(uint32_t) * N, st), "score memset");
 		return PGH_OK;
@@ -385,7 +387,8 @@ extern "C" int pgh_score_run_dev(const pgh_score_plan *plan, void *d_score_sum, 
 	PGH_HIP(pgh::LaunchScoreAccumulate(ds->View(), static_cast<uint32_t *>(plan->d_vlist), plan->n_scored,
 	                                   static_cast<double *>(plan->d_weights), plan->n_cols,
 	                                   static_cast<double *>(plan->d_ts), static_cast<double *>(plan->d_td),
-	                                   static_cast<uint32_t *>(plan->d_ac), plan->mode != PGH_SCORE_CENTER,
+	                                   static_cast<uint32_t *>(plan->d_ac),
+	                                   plan->mode != PGH_SCORE_CENTER && d_dosage_sum != nullptr,
 	                                   static_cast<double *>(d_score_sum), static_cast<double *>(d_dosage_sum),
 	                                   static_cast<uint32_t *>(d_allele_ct), st),
 	        "score accumulate kernel");
@@ -444,7 +447,9 @@ extern "C" int pgh_score(const pgh_dataset *ds, const pgh_subset *subset, uint32
 	const uint32_t N = ds->sample_ct;
 	DevBuf d_score, d_dos, d_ac;
 	PGH_HIP(d_score.Alloc(sizeof(double) * N * std::max<uint32_t>(1, n_cols)), "hipMalloc(score out)");
-	PGH_HIP(d_dos.Alloc(sizeof(double) * N), "hipMalloc(score out)");
+	if (dosage_sum) {
+		PGH_HIP(d_dos.Alloc(sizeof(double) * N), "hipMalloc(score out)");
+	}
 	PGH_HIP(d_ac.Alloc(sizeof(uint32_t) * N), "hipMalloc(score out)");
 	int rc = pgh_score_dev(ds, subset, n_scored, vidx, weights, flip, n_cols, mode, d_score.p, d_dos.p, d_ac.p,
 	                       hipStreamPerThread, errbuf);
@@ -454,10 +459,14 @@ extern "C" int pgh_score(const pgh_dataset *ds, const pgh_subset *subset, uint32
 	std::vector<double> h_score(static_cast<size_t>(N) * n_cols), h_dos(N);
 	std::vector<uint32_t> h_ac(N);
 	PGH_HIP(hipMemcpy(h_score.data(), d_score.p, sizeof(double) * N * n_cols, hipMemcpyDeviceToHost), "score copy");
-	PGH_HIP(hipMemcpy(h_dos.data(), d_dos.p, sizeof(double) * N, hipMemcpyDeviceToHost), "score copy");
+	if (dosage_sum) {
+		PGH_HIP(hipMemcpy(h_dos.data(), d_dos.p, sizeof(double) * N, hipMemcpyDeviceToHost), "score copy");
+	}
 	PGH_HIP(hipMemcpy(h_ac.data(), d_ac.p, sizeof(uint32_t) * N, hipMemcpyDeviceToHost), "score copy");
 	Compact<double>(subset, h_score.data(), n_cols, score_sum, N);
-	Compact<double>(subset, h_dos.data(), 1, dosage_sum, N);
+	if (dosage_sum) {
+		Compact<double>(subset, h_dos.data(), 1, dosage_sum, N);
+	}
 	Compact<uint32_t>(subset, h_ac.data(), 1, allele_ct, N);
 	return PGH_OK;
 }

@@ -181,7 +181,9 @@ constexpr uint32_t kGemvPairs = 8; // pair tables per stage (16 variants)
 
 // One stage: 8 pair tables at a compile-time LDS offset (the lookups then use the
 // instruction's immediate offset), 16 words of this lane's 16 samples.
-template <int BUF>
+// TRACK: the dosage half of an entry is wanted too (16-byte lookups and two adds per pair; without it
+// 8-byte lookups of the same table and one add -- half the LDS cycles and half the FP64 adds)
+template <int BUF, bool TRACK>
 __device__ __forceinline__ void GemvPairsStage(const ScorePair (*tabs)[kGemvPairs][16], const uint32_t *w,
                                                double *acc_s, double *acc_d) {
 	const uint32_t kF0 = 0xf0u;
@@ -197,7 +199,7 @@ __device__ __forceinline__ void GemvPairsStage(const ScorePair (*tabs)[kGemvPair
 		const uint32_t even_lo = even << 4, odd_lo = odd << 4;
 		const char *tab = reinterpret_cast<const char *>(tabs[BUF][pr]);
 #define PGH_LOOKUP(B)                                                                                                  \
-	{                                                                                                                  \
+	if (TRACK) {                                                                                                       \
 		const ScorePair e0 = *reinterpret_cast<const ScorePair *>(tab + ByteAnd##B(even_lo, kF0));                    \
 		const ScorePair e1 = *reinterpret_cast<const ScorePair *>(tab + ByteAnd##B(odd_lo, kF0));                     \
 		const ScorePair e2 = *reinterpret_cast<const ScorePair *>(tab + ByteAnd##B(even, kF0));                       \
@@ -210,6 +212,11 @@ __device__ __forceinline__ void GemvPairsStage(const ScorePair (*tabs)[kGemvPair
 		acc_d[4 * B + 2] += e2.dosage;                                                                                 \
 		acc_s[4 * B + 3] += e3.score;                                                                                  \
 		acc_d[4 * B + 3] += e3.dosage;                                                                                 \
+	} else {                                                                                                           \
+		acc_s[4 * B] += *reinterpret_cast<const double *>(tab + ByteAnd##B(even_lo, kF0));                            \
+		acc_s[4 * B + 1] += *reinterpret_cast<const double *>(tab + ByteAnd##B(odd_lo, kF0));                         \
+		acc_s[4 * B + 2] += *reinterpret_cast<const double *>(tab + ByteAnd##B(even, kF0));                           \
+		acc_s[4 * B + 3] += *reinterpret_cast<const double *>(tab + ByteAnd##B(odd, kF0));                            \
 	}
 		PGH_LOOKUP(0)
 		PGH_LOOKUP(1)
@@ -219,6 +226,7 @@ __device__ __forceinline__ void GemvPairsStage(const ScorePair (*tabs)[kGemvPair
 	}
 }
 
+template <bool TRACK>
 __global__ __launch_bounds__(256, 4) void k_score_gemv_pairs(const uint8_t *__restrict__ rows, uint64_t pitch,
                                                           uint32_t sample_ct, const uint32_t *__restrict__ vlist,
                                                           uint32_t n_var, uint32_t slice_len,
@@ -282,7 +290,7 @@ __global__ __launch_bounds__(256, 4) void k_score_gemv_pairs(const uint8_t *__re
 			load_words(base + kStage, w_b);
 			build(base + kStage, 1);
 		}
-		GemvPairsStage<0>(s_tab, w_a, acc_s, acc_d);
+		GemvPairsStage<0, TRACK>(s_tab, w_a, acc_s, acc_d);
 		__syncthreads();
 		if (!more_b) {
 			break;
@@ -291,7 +299,7 @@ __global__ __launch_bounds__(256, 4) void k_score_gemv_pairs(const uint8_t *__re
 			load_words(base + 2 * kStage, w_a);
 			build(base + 2 * kStage, 0);
 		}
-		GemvPairsStage<1>(s_tab, w_b, acc_s, acc_d);
+		GemvPairsStage<1, TRACK>(s_tab, w_b, acc_s, acc_d);
 		__syncthreads();
 	}
 	if (live) {
@@ -300,7 +308,7 @@ __global__ __launch_bounds__(256, 4) void k_score_gemv_pairs(const uint8_t *__re
 			const uint32_t s0 = d * 16u + j;
 			if (s0 < sample_ct) {
 				unsafeAtomicAdd(score + static_cast<uint64_t>(s0) * out_stride, acc_s[j]);
-				if (dosage_sum) {
+				if (TRACK && dosage_sum) {
 					unsafeAtomicAdd(dosage_sum + s0, acc_d[j]);
 				}
 			}
@@ -668,9 +676,15 @@ hipError_t LaunchTableAccumulate(const RowView &view, const uint32_t *vlist, uin
 			slice_len = ((n_var + slices - 1) / slices + 15) / 16 * 16;
 			slices = (n_var + slice_len - 1) / slice_len;
 		}
-		hipLaunchKernelGGL(k_score_gemv_pairs, dim3(col_blocks, slices), dim3(256), 0, stream, view.rows, view.pitch,
-		                   view.sample_ct, vlist, n_var, slice_len, weights, w_stride, ts, td, out, out_stride,
-		                   dosage_sum);
+		if (td && dosage_sum) {
+			hipLaunchKernelGGL(k_score_gemv_pairs<true>, dim3(col_blocks, slices), dim3(256), 0, stream, view.rows,
+			                   view.pitch, view.sample_ct, vlist, n_var, slice_len, weights, w_stride, ts, td, out,
+			                   out_stride, dosage_sum);
+		} else {
+			hipLaunchKernelGGL(k_score_gemv_pairs<false>, dim3(col_blocks, slices), dim3(256), 0, stream, view.rows,
+			                   view.pitch, view.sample_ct, vlist, n_var, slice_len, weights, w_stride, ts, nullptr, out,
+			                   out_stride, nullptr);
+		}
 		return hipGetLastError();
 	}
 	// 2 columns: plain FP64 FMAs

@@ -41,6 +41,7 @@ struct PlinkScoreGlobalState : public GlobalTableFunctionState {
 	vector<uint32_t> allele_cts;
 	std::mutex phase1_mutex;
 	bool scoring_done = false;
+	bool need_dosage_sum = false; // NAMED_ALLELE_DOSAGE_SUM projected: only then is it accumulated
 	std::atomic<uint32_t> next_sample_idx {0};
 	uint32_t total_samples = 0;
 	uint32_t scored_variant_count = 0;
@@ -193,6 +194,7 @@ static unique_ptr<GlobalTableFunctionState> PlinkScoreInitGlobal(ClientContext &
 		if (col_id != COLUMN_IDENTIFIER_ROW_ID && col_id >= COL_ALLELE_CT) {
 			need_scores = true;
 		}
+		state->need_dosage_sum |= col_id == COL_NAMED_ALLELE_DOSAGE_SUM;
 	}
 	if (need_scores && !bind_data.scored_variants.empty()) {
 		state->dataset = DeviceDataset::Acquire(bind_data.c.pgen_path, "plink_score");
@@ -300,7 +302,8 @@ static void PlinkScoreScan(ClientContext &, TableFunctionInput &data_p, DataChun
 					char errbuf[PGH_ERRBUF_LEN] = {0};
 					int rc = pgh_score(gstate.dataset->handle, gstate.subset ? gstate.subset->handle : nullptr,
 					                   static_cast<uint32_t>(n_scored), vidx.data(), weights.data(), flip.data(), 1, mode,
-					                   gstate.score_sums.data(), gstate.named_allele_dosage_sums.data(),
+					                   gstate.score_sums.data(),
+					                   gstate.need_dosage_sum ? gstate.named_allele_dosage_sums.data() : nullptr,
 					                   gstate.allele_cts.data(), errbuf);
 					if (rc != PGH_OK) {
 						throw IOException("plink_score: scoring failed: %s", string(errbuf));

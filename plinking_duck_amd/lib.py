@@ -377,7 +377,8 @@ class Dataset:
         _check(_lib.pgh_unpack_range_dev(self._h, subset._h if subset else None, v_begin, v_end, d_out, out_pitch,
                                          d_validity, missing_code, stream, eb), eb)
 
-    def score(self, vidx, weights, flip=None, mode: int = SCORE_MEAN_IMPUTE, subset: Subset | None = None):
+    def score(self, vidx, weights, flip=None, mode: int = SCORE_MEAN_IMPUTE, subset: Subset | None = None,
+              want_dosage_sum: bool = True):
         vidx = np.ascontiguousarray(vidx, dtype=np.uint32)
         weights = np.ascontiguousarray(weights, dtype=np.float64)
         if weights.ndim == 1:
@@ -387,7 +388,7 @@ class Dataset:
         flip_a = None if flip is None else np.ascontiguousarray(flip, dtype=np.uint8)
         n_out = subset.size if subset else self.n_samples
         score = np.zeros((n_out, n_cols), dtype=np.float64)
-        dos = np.zeros(n_out, dtype=np.float64)
+        dos = np.zeros(n_out, dtype=np.float64) if want_dosage_sum else None
         ac = np.zeros(n_out, dtype=np.uint32)
         eb = _errbuf()
         _check(_lib.pgh_score(self._h, subset._h if subset else None, n_scored, _ptr(vidx), _ptr(weights), _ptr(flip_a),

@@ -258,6 +258,10 @@ def test_score_matches_oracle(gpu_lib, oracle, mode, ncols):
         scale = np.abs(w).sum(axis=0) * 2.0  # magnitude of the terms being summed
         assert np.all(np.abs(s - es) <= REL * np.maximum(np.abs(es), 1e-9 * scale))
         assert np.allclose(d, ed, rtol=REL, atol=1e-9)
+        # without the dosage sum (projection pushdown of NAMED_ALLELE_DOSAGE_SUM) the rest is unchanged
+        s2, d2, ac2 = ds.score(vidx, w, flip=flip, mode=code, subset=ss, want_dosage_sum=False)
+        assert d2 is None and np.array_equal(ac2, ac)
+        assert np.all(np.abs(s2 - es) <= REL * np.maximum(np.abs(es), 1e-9 * scale))
 
 
 @pytest.mark.parametrize("ncols", [2, 3, 5, 15, 17, 20, 21, 24, 25, 28, 29, 33, 52])
