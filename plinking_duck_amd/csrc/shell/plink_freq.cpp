@@ -152,160 +152,147 @@ static void PlinkFreqScan(ClientContext &, TableFunctionInput &data_p, DataChunk
 		return false;
 	};
 
-	idx_t rows_emitted = 0;
-	uint32_t vidx;
-	while (rows_emitted < STANDARD_VECTOR_SIZE && lstate.scan.Next(gstate.scan, "plink_freq", needs_strata, vidx)) {
-		ChromPloidy ploidy = ChromPloidy::AUTOSOMAL;
-		if (gstate.need_frequencies) {
-			ploidy = ClassifyChromPloidy(variants.GetChrom(vidx), variants.GetPos(vidx), bind_data.par_bounds);
-		}
-		const bool sex_aware = ploidy != ChromPloidy::AUTOSOMAL;
-
-		uint32_t genocounts[4] = {0, 0, 0, 0};
-		uint64_t all_dosages[2] = {0, 0};
+	// Two steps per chunk, the columnar way round: first the derived values of every row the
+	// chunk will hold (the tallies are already there, batch by batch), then one tight loop per
+	// projected column.
+	struct FreqRow {
+		uint32_t vidx;
+		uint32_t obs_ct = 0;
+		double alt_freq = 0.0;
 		double imp_r2 = 0.0;
-		SexAwareCounts sac;
-		if (gstate.need_frequencies) {
-			std::memcpy(genocounts, lstate.scan.Counts(vidx), sizeof genocounts);
-			if (sex_aware) {
-				static const uint32_t zero[4] = {0, 0, 0, 0};
-				const bool strata = lstate.scan.have_strata;
-				sac = SexAwareFromStrata(ploidy, genocounts, strata ? lstate.scan.MaleCounts(vidx) : zero,
-				                         strata ? lstate.scan.FemaleCounts(vidx) : zero, bind_data.have_sex);
-			} else if (bind_data.include_dosage) {
-				static constexpr uint64_t kDosageMid = 16384;
-				if (lstate.reader) {
-					// PgrGetDCounts: dosage-weighted sums + MaCH r2, decoded per variant
-					if (pgh_get_dosage_f64(lstate.reader, vidx, lstate.dosage_doubles.data()) != PGH_OK) {
-						throw IOException("plink_freq: PgrGetDCounts failed for variant %u: %s", vidx,
-						                  string(pgh_reader_error(lstate.reader)));
-					}
-					uint64_t sum = 0, ssq = 0;
-					uint32_t nm = 0;
-					for (double d : lstate.dosage_doubles) {
-						if (d == -9.0) {
-							continue;
-						}
-						uint64_t u = static_cast<uint64_t>(std::llround(d * 16384.0));
+		int32_t counts[4] = {0, 0, 0, 0};
+		bool freq_is_null = false, counts_are_null = false, r2_is_null = false;
+	};
+	static constexpr uint64_t kDosageMid = 16384;
+	vector<FreqRow> rows;
+	rows.reserve(STANDARD_VECTOR_SIZE);
+	uint32_t vidx;
+	while (rows.size() < STANDARD_VECTOR_SIZE && lstate.scan.Next(gstate.scan, "plink_freq", needs_strata, vidx)) {
+		FreqRow row;
+		row.vidx = vidx;
+		if (!gstate.need_frequencies) {
+			rows.push_back(row);
+			continue;
+		}
+		const ChromPloidy ploidy = ClassifyChromPloidy(variants.GetChrom(vidx), variants.GetPos(vidx), bind_data.par_bounds);
+		const uint32_t *gc = lstate.scan.Counts(vidx);
+		for (int k = 0; k < 4; k++) {
+			row.counts[k] = static_cast<int32_t>(gc[k]);
+		}
+		const uint32_t observed = gc[0] + gc[1] + gc[2];
+		if (ploidy != ChromPloidy::AUTOSOMAL) {
+			// chrX / chrY / chrMT: ploidy-aware allele counts from the sex strata
+			// (ComputeSexAwareCounts, src/plink_freq.cpp:463-472); IMP_R2 is not defined here
+			static const uint32_t zero[4] = {0, 0, 0, 0};
+			const bool strata = lstate.scan.have_strata;
+			SexAwareCounts sac = SexAwareFromStrata(ploidy, gc, strata ? lstate.scan.MaleCounts(vidx) : zero,
+			                                        strata ? lstate.scan.FemaleCounts(vidx) : zero, bind_data.have_sex);
+			row.r2_is_null = true;
+			row.counts_are_null = sac.sex_unavailable;
+			row.freq_is_null = sac.sex_unavailable || sac.obs_allele_ct == 0;
+			if (!row.freq_is_null) {
+				row.alt_freq = static_cast<double>(sac.alt_allele_ct) / static_cast<double>(sac.obs_allele_ct);
+				row.obs_ct = sac.obs_allele_ct;
+			}
+			row.counts[0] = static_cast<int32_t>(sac.geno_hom_ref);
+			row.counts[1] = static_cast<int32_t>(sac.geno_het);
+			row.counts[2] = static_cast<int32_t>(sac.geno_hom_alt);
+			row.counts[3] = static_cast<int32_t>(sac.geno_missing);
+		} else if (bind_data.include_dosage) {
+			// dosage-weighted allele sums (PgrGetDCounts, src/plink_freq.cpp:525-535)
+			uint64_t alt_sum, ref_sum;
+			row.r2_is_null = !bind_data.c.file_has_dosage;
+			if (lstate.reader) {
+				if (pgh_get_dosage_f64(lstate.reader, vidx, lstate.dosage_doubles.data()) != PGH_OK) {
+					throw IOException("plink_freq: PgrGetDCounts failed for variant %u: %s", vidx,
+					                  string(pgh_reader_error(lstate.reader)));
+				}
+				uint64_t sum = 0, ssq = 0;
+				uint32_t nm = 0;
+				for (double d : lstate.dosage_doubles) {
+					if (d != -9.0) {
+						const uint64_t u = static_cast<uint64_t>(std::llround(d * 16384.0));
 						sum += u;
 						ssq += u * u;
 						nm++;
 					}
-					all_dosages[1] = sum;
-					all_dosages[0] = static_cast<uint64_t>(nm) * 2 * kDosageMid - sum;
-					if (nm) {
-						double sumd = static_cast<double>(sum);
-						double avg = sumd / static_cast<double>(nm);
-						double var = static_cast<double>(ssq) - sumd * avg;
-						imp_r2 = 2.0 * var / (sumd * (32768.0 - avg));
-					}
-				} else {
-					uint32_t obs = genocounts[0] + genocounts[1] + genocounts[2];
-					all_dosages[1] = (static_cast<uint64_t>(genocounts[1]) + 2ull * genocounts[2]) * kDosageMid;
-					all_dosages[0] = 2ull * obs * kDosageMid - all_dosages[1];
 				}
-			}
-		}
-
-		static constexpr uint64_t kDosageMid = 16384;
-		uint32_t hardcall_obs_sample_ct = genocounts[0] + genocounts[1] + genocounts[2];
-		uint32_t obs_ct;
-		double alt_freq;
-		bool freq_is_null = false;
-		int32_t out_hom_ref = static_cast<int32_t>(genocounts[0]);
-		int32_t out_het = static_cast<int32_t>(genocounts[1]);
-		int32_t out_hom_alt = static_cast<int32_t>(genocounts[2]);
-		int32_t out_missing = static_cast<int32_t>(genocounts[3]);
-		bool counts_are_null = false;
-
-		if (sex_aware) {
-			if (sac.sex_unavailable || sac.obs_allele_ct == 0) {
-				freq_is_null = true;
-				alt_freq = 0.0;
-				obs_ct = 0;
-				counts_are_null = sac.sex_unavailable;
+				alt_sum = sum;
+				ref_sum = static_cast<uint64_t>(nm) * 2 * kDosageMid - sum;
+				if (nm) { // MaCH r2 = popvar(d) / (2 p (1 - p)) on the 16384 scale
+					const double sumd = static_cast<double>(sum);
+					const double avg = sumd / static_cast<double>(nm);
+					row.imp_r2 = 2.0 * (static_cast<double>(ssq) - sumd * avg) / (sumd * (32768.0 - avg));
+				}
 			} else {
-				alt_freq = static_cast<double>(sac.alt_allele_ct) / static_cast<double>(sac.obs_allele_ct);
-				obs_ct = sac.obs_allele_ct;
+				alt_sum = (static_cast<uint64_t>(gc[1]) + 2ull * gc[2]) * kDosageMid;
+				ref_sum = 2ull * observed * kDosageMid - alt_sum;
 			}
-			out_hom_ref = static_cast<int32_t>(sac.geno_hom_ref);
-			out_het = static_cast<int32_t>(sac.geno_het);
-			out_hom_alt = static_cast<int32_t>(sac.geno_hom_alt);
-			out_missing = static_cast<int32_t>(sac.geno_missing);
-		} else if (bind_data.include_dosage) {
-			uint64_t total_dosage = all_dosages[0] + all_dosages[1];
-			if (total_dosage == 0) {
-				freq_is_null = true;
-				alt_freq = 0.0;
-				obs_ct = 0;
-			} else {
-				alt_freq = static_cast<double>(all_dosages[1]) / static_cast<double>(total_dosage);
-				obs_ct = static_cast<uint32_t>(total_dosage / kDosageMid);
+			const uint64_t total = alt_sum + ref_sum;
+			row.freq_is_null = total == 0;
+			if (total) {
+				row.alt_freq = static_cast<double>(alt_sum) / static_cast<double>(total);
+				row.obs_ct = static_cast<uint32_t>(total / kDosageMid);
 			}
-		} else if (hardcall_obs_sample_ct == 0) {
-			freq_is_null = true;
-			alt_freq = 0.0;
-			obs_ct = 0;
 		} else {
-			obs_ct = 2 * hardcall_obs_sample_ct;
-			alt_freq = (static_cast<double>(genocounts[1]) + 2.0 * static_cast<double>(genocounts[2])) /
-			           (2.0 * static_cast<double>(hardcall_obs_sample_ct));
-		}
-
-		for (idx_t out_col = 0; out_col < column_ids.size(); out_col++) {
-			auto file_col = column_ids[out_col];
-			if (file_col == COLUMN_IDENTIFIER_ROW_ID) {
-				continue;
-			}
-			auto &vec = output.data[out_col];
-			if (bind_data.include_dosage && file_col == bind_data.imp_r2_col_idx) {
-				if (sex_aware || !bind_data.c.file_has_dosage) {
-					FlatVector::SetNull(vec, rows_emitted, true);
-				} else {
-					FlatVector::GetData<double>(vec)[rows_emitted] = imp_r2;
-				}
-				continue;
-			}
-			if (FillVariantMetadataColumn(variants, file_col, vidx, vec, rows_emitted)) {
-				continue;
-			}
-			auto put_count = [&](int32_t v) {
-				if (counts_are_null) {
-					FlatVector::SetNull(vec, rows_emitted, true);
-				} else {
-					FlatVector::GetData<int32_t>(vec)[rows_emitted] = v;
-				}
-			};
-			switch (file_col) {
-			case COL_ALT_FREQ:
-				if (freq_is_null) {
-					FlatVector::SetNull(vec, rows_emitted, true);
-				} else {
-					FlatVector::GetData<double>(vec)[rows_emitted] = alt_freq;
-				}
-				break;
-			case COL_OBS_CT:
-				FlatVector::GetData<int32_t>(vec)[rows_emitted] = static_cast<int32_t>(obs_ct);
-				break;
-			case COL_HOM_REF_CT:
-				put_count(out_hom_ref);
-				break;
-			case COL_HET_CT:
-				put_count(out_het);
-				break;
-			case COL_HOM_ALT_CT:
-				put_count(out_hom_alt);
-				break;
-			case COL_MISSING_CT:
-				put_count(out_missing);
-				break;
-			default:
-				break;
+			// src/plink_freq.cpp:536-544: OBS_CT counts alleles; no observation -> NULL frequency, OBS_CT 0
+			row.freq_is_null = observed == 0;
+			if (observed) {
+				row.obs_ct = 2 * observed;
+				row.alt_freq = (static_cast<double>(gc[1]) + 2.0 * static_cast<double>(gc[2])) /
+				               (2.0 * static_cast<double>(observed));
 			}
 		}
-		rows_emitted++;
+		rows.push_back(row);
 	}
-	CompatSetOutputCardinality(output, rows_emitted);
+
+	const idx_t n_rows = rows.size();
+	for (idx_t out_col = 0; out_col < column_ids.size(); out_col++) {
+		const auto file_col = column_ids[out_col];
+		if (file_col == COLUMN_IDENTIFIER_ROW_ID) {
+			continue;
+		}
+		auto &vec = output.data[out_col];
+		if (bind_data.include_dosage && file_col == bind_data.imp_r2_col_idx) {
+			auto *dst = FlatVector::GetData<double>(vec);
+			for (idx_t r = 0; r < n_rows; r++) {
+				if (rows[r].r2_is_null) {
+					FlatVector::SetNull(vec, r, true);
+				} else {
+					dst[r] = rows[r].imp_r2;
+				}
+			}
+		} else if (file_col < COL_ALT_FREQ) {
+			for (idx_t r = 0; r < n_rows; r++) {
+				FillVariantMetadataColumn(variants, file_col, rows[r].vidx, vec, r);
+			}
+		} else if (file_col == COL_ALT_FREQ) {
+			auto *dst = FlatVector::GetData<double>(vec);
+			for (idx_t r = 0; r < n_rows; r++) {
+				if (rows[r].freq_is_null) {
+					FlatVector::SetNull(vec, r, true);
+				} else {
+					dst[r] = rows[r].alt_freq;
+				}
+			}
+		} else if (file_col == COL_OBS_CT) {
+			auto *dst = FlatVector::GetData<int32_t>(vec);
+			for (idx_t r = 0; r < n_rows; r++) {
+				dst[r] = static_cast<int32_t>(rows[r].obs_ct);
+			}
+		} else if (file_col >= COL_HOM_REF_CT && file_col <= COL_MISSING_CT) {
+			const int which = static_cast<int>(file_col - COL_HOM_REF_CT);
+			auto *dst = FlatVector::GetData<int32_t>(vec);
+			for (idx_t r = 0; r < n_rows; r++) {
+				if (rows[r].counts_are_null) {
+					FlatVector::SetNull(vec, r, true);
+				} else {
+					dst[r] = rows[r].counts[which];
+				}
+			}
+		}
+	}
+	CompatSetOutputCardinality(output, n_rows);
 }
 
 void RegisterPlinkFreq(ExtensionLoader &loader) {
