@@ -121,48 +121,49 @@ static unique_ptr<LocalTableFunctionState> PlinkMissingInitLocal(ExecutionContex
 	return make_uniq<PlinkMissingLocalState>();
 }
 
+// Variant mode, columnar: the chunk's variants first, then one loop per projected column.
+// MISSING_CT is column 3 of the batched tally; OBS_CT = samples - MISSING_CT; F_MISS over the
+// effective sample count (src/plink_missing.cpp:486-490).
 static void PlinkMissingScanVariant(const PlinkMissingBindData &bind_data, PlinkMissingGlobalState &gstate,
                                     PlinkMissingLocalState &lstate, DataChunk &output) {
-	auto &column_ids = gstate.column_ids;
-	uint32_t sample_ct = bind_data.c.effective_sample_ct;
+	const uint32_t sample_ct = bind_data.c.effective_sample_ct;
 	auto no_strata = [](uint32_t, uint32_t) { return false; };
-	idx_t rows_emitted = 0;
+	uint32_t vids[STANDARD_VECTOR_SIZE], missing[STANDARD_VECTOR_SIZE];
+	idx_t n_rows = 0;
 	uint32_t vidx;
-	while (rows_emitted < STANDARD_VECTOR_SIZE && lstate.scan.Next(gstate.scan, "plink_missing", no_strata, vidx)) {
-		uint32_t missing_ct = gstate.need_missingness ? lstate.scan.Counts(vidx)[3] : 0;
-		uint32_t obs_ct = sample_ct - missing_ct;
-		double f_miss = sample_ct > 0 ? static_cast<double>(missing_ct) / static_cast<double>(sample_ct) : 0.0;
-		for (idx_t out_col = 0; out_col < column_ids.size(); out_col++) {
-			auto file_col = column_ids[out_col];
-			if (file_col == COLUMN_IDENTIFIER_ROW_ID) {
-				continue;
+	while (n_rows < STANDARD_VECTOR_SIZE && lstate.scan.Next(gstate.scan, "plink_missing", no_strata, vidx)) {
+		vids[n_rows] = vidx;
+		missing[n_rows] = gstate.need_missingness ? lstate.scan.Counts(vidx)[3] : 0;
+		n_rows++;
+	}
+	for (idx_t out_col = 0; out_col < gstate.column_ids.size(); out_col++) {
+		const auto file_col = gstate.column_ids[out_col];
+		if (file_col == COLUMN_IDENTIFIER_ROW_ID) {
+			continue;
+		}
+		auto &vec = output.data[out_col];
+		if (file_col < VCOL_MISSING_CT) {
+			for (idx_t r = 0; r < n_rows; r++) {
+				FillVariantMetadataColumn(bind_data.c.variants, file_col, vids[r], vec, r);
 			}
-			auto &vec = output.data[out_col];
-			if (FillVariantMetadataColumn(bind_data.c.variants, file_col, vidx, vec, rows_emitted)) {
-				continue;
+		} else if (file_col == VCOL_F_MISS) {
+			auto *dst = FlatVector::GetData<double>(vec);
+			for (idx_t r = 0; r < n_rows; r++) {
+				dst[r] = sample_ct > 0 ? static_cast<double>(missing[r]) / static_cast<double>(sample_ct) : 0.0;
 			}
-			switch (file_col) {
-			case VCOL_MISSING_CT:
-				FlatVector::GetData<int32_t>(vec)[rows_emitted] = static_cast<int32_t>(missing_ct);
-				break;
-			case VCOL_OBS_CT:
-				FlatVector::GetData<int32_t>(vec)[rows_emitted] = static_cast<int32_t>(obs_ct);
-				break;
-			case VCOL_F_MISS:
-				FlatVector::GetData<double>(vec)[rows_emitted] = f_miss;
-				break;
-			default:
-				break;
+		} else {
+			auto *dst = FlatVector::GetData<int32_t>(vec);
+			for (idx_t r = 0; r < n_rows; r++) {
+				dst[r] = static_cast<int32_t>(file_col == VCOL_MISSING_CT ? missing[r] : sample_ct - missing[r]);
 			}
 		}
-		rows_emitted++;
 	}
-	CompatSetOutputCardinality(output, rows_emitted);
+	CompatSetOutputCardinality(output, n_rows);
 }
 
 static void PlinkMissingScanSample(const PlinkMissingBindData &bind_data, PlinkMissingGlobalState &gstate,
                                    DataChunk &output) {
-	uint32_t sample_ct = bind_data.c.effective_sample_ct;
+	const uint32_t sample_ct = bind_data.c.effective_sample_ct;
 	{
 		// Phase 1: one device launch covers the whole variant range, so the first
 		// thread in does it; later threads find it done and go straight to phase 2.
@@ -181,56 +182,39 @@ static void PlinkMissingScanSample(const PlinkMissingBindData &bind_data, PlinkM
 			gstate.variant_scan_done = true;
 		}
 	}
-	// Phase 2: emit sample rows (ascending file order within the subset)
-	auto &column_ids = gstate.column_ids;
-	uint32_t total_variant_ct = gstate.total_variant_ct;
-	idx_t rows_emitted = 0;
-	while (rows_emitted < STANDARD_VECTOR_SIZE) {
-		uint32_t sidx = gstate.next_sample_idx.fetch_add(1);
-		if (sidx >= sample_ct) {
-			break;
+	// Phase 2: a run of output samples per call (ascending file order within the subset); the
+	// denominator is the number of variants in the region (src/plink_missing.cpp:643-646)
+	const uint32_t first = gstate.next_sample_idx.fetch_add(STANDARD_VECTOR_SIZE);
+	const idx_t n_rows = first < sample_ct ? std::min<idx_t>(STANDARD_VECTOR_SIZE, sample_ct - first) : 0;
+	const uint32_t variant_ct = gstate.total_variant_ct;
+	auto file_index = [&](idx_t r) {
+		const uint32_t sidx = first + static_cast<uint32_t>(r);
+		return bind_data.c.has_sample_subset ? bind_data.c.sample_subset->sorted_indices[sidx] : sidx;
+	};
+	auto missing_of = [&](idx_t r) { return gstate.need_missingness ? gstate.sample_missing_counts[first + r] : 0u; };
+	for (idx_t out_col = 0; out_col < gstate.column_ids.size(); out_col++) {
+		const auto file_col = gstate.column_ids[out_col];
+		if (file_col == COLUMN_IDENTIFIER_ROW_ID) {
+			continue;
 		}
-		uint32_t missing_ct = gstate.need_missingness ? gstate.sample_missing_counts[sidx] : 0;
-		uint32_t obs_ct = total_variant_ct - missing_ct;
-		double f_miss =
-		    total_variant_ct > 0 ? static_cast<double>(missing_ct) / static_cast<double>(total_variant_ct) : 0.0;
-		uint32_t orig_idx = bind_data.c.has_sample_subset ? bind_data.c.sample_subset->sorted_indices[sidx] : sidx;
-		for (idx_t out_col = 0; out_col < column_ids.size(); out_col++) {
-			auto file_col = column_ids[out_col];
-			if (file_col == COLUMN_IDENTIFIER_ROW_ID) {
-				continue;
+		auto &vec = output.data[out_col];
+		if (file_col == SCOL_FID || file_col == SCOL_IID) {
+			for (idx_t r = 0; r < n_rows; r++) {
+				FillSampleIdColumn(bind_data.c.sample_info, file_col == SCOL_FID, file_index(r), vec, r);
 			}
-			auto &vec = output.data[out_col];
-			switch (file_col) {
-			case SCOL_FID: {
-				auto &fids = bind_data.c.sample_info.fids;
-				if (!fids.empty() && orig_idx < fids.size() && !fids[orig_idx].empty()) {
-					FlatVector::GetData<string_t>(vec)[rows_emitted] = StringVector::AddString(vec, fids[orig_idx]);
-				} else {
-					FlatVector::SetNull(vec, rows_emitted, true);
-				}
-				break;
+		} else if (file_col == SCOL_F_MISS) {
+			auto *dst = FlatVector::GetData<double>(vec);
+			for (idx_t r = 0; r < n_rows; r++) {
+				dst[r] = variant_ct > 0 ? static_cast<double>(missing_of(r)) / static_cast<double>(variant_ct) : 0.0;
 			}
-			case SCOL_IID:
-				FlatVector::GetData<string_t>(vec)[rows_emitted] =
-				    StringVector::AddString(vec, bind_data.c.sample_info.iids[orig_idx]);
-				break;
-			case SCOL_MISSING_CT:
-				FlatVector::GetData<int32_t>(vec)[rows_emitted] = static_cast<int32_t>(missing_ct);
-				break;
-			case SCOL_OBS_CT:
-				FlatVector::GetData<int32_t>(vec)[rows_emitted] = static_cast<int32_t>(obs_ct);
-				break;
-			case SCOL_F_MISS:
-				FlatVector::GetData<double>(vec)[rows_emitted] = f_miss;
-				break;
-			default:
-				break;
+		} else {
+			auto *dst = FlatVector::GetData<int32_t>(vec);
+			for (idx_t r = 0; r < n_rows; r++) {
+				dst[r] = static_cast<int32_t>(file_col == SCOL_MISSING_CT ? missing_of(r) : variant_ct - missing_of(r));
 			}
 		}
-		rows_emitted++;
 	}
-	CompatSetOutputCardinality(output, rows_emitted);
+	CompatSetOutputCardinality(output, n_rows);
 }
 
 static void PlinkMissingScan(ClientContext &, TableFunctionInput &data_p, DataChunk &output) {

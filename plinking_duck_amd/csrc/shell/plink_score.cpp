@@ -62,6 +62,84 @@ struct PlinkScoreGlobalState : public GlobalTableFunctionState {
 
 struct PlinkScoreLocalState : public LocalTableFunctionState {};
 
+//! `weights :=` -> the scored variants, ascending by variant index, zero weights dropped
+//! (src/plink_score.cpp:329-427).  Two shapes:
+//!   LIST(DOUBLE)                         one weight per variant of the region, positionally
+//!   LIST(STRUCT(id, allele, weight))     keyed by variant ID; `allele` picks ALT (as is) or REF
+//!                                        (flipped: 2 - dosage); unknown IDs / alleles are skipped
+static vector<ScoredVariant> ResolveWeights(const Value &weights, const VariantMetadataIndex &variants,
+                                            uint32_t range_start, uint32_t range_end) {
+	if (weights.IsNull()) {
+		throw InvalidInputException("plink_score: weights must not be NULL");
+	}
+	if (weights.type().id() != LogicalTypeId::LIST) {
+		throw InvalidInputException("plink_score: weights must be a list (LIST(DOUBLE) for positional mode, "
+		                            "or LIST(STRUCT(id, allele, weight)) for ID-keyed mode)");
+	}
+	const auto &items = ListValue::GetChildren(weights);
+	if (items.empty()) {
+		throw InvalidInputException("plink_score: weights list is empty");
+	}
+	vector<ScoredVariant> scored;
+	const auto &item_type = ListType::GetChildType(weights.type());
+	if (item_type.id() != LogicalTypeId::STRUCT) {
+		const uint32_t expected = range_end - range_start;
+		if (items.size() != expected) {
+			throw InvalidInputException("plink_score: weights list length (%llu) must match variant count (%u)",
+			                            static_cast<unsigned long long>(items.size()), expected);
+		}
+		for (uint32_t i = 0; i < expected; i++) {
+			const double w = items[i].GetValue<double>();
+			if (w != 0.0) {
+				scored.push_back({range_start + i, w, false});
+			}
+		}
+		return scored;
+	}
+	// positions of the three fields inside each struct value
+	int field_of[3] = {-1, -1, -1}; // id, allele, weight
+	const auto &fields = StructType::GetChildTypes(item_type);
+	for (idx_t f = 0; f < fields.size(); f++) {
+		static const char *const kNames[3] = {"id", "allele", "weight"};
+		for (int k = 0; k < 3; k++) {
+			if (fields[f].first == kNames[k]) {
+				field_of[k] = static_cast<int>(f);
+			}
+		}
+	}
+	if (field_of[0] < 0 || field_of[1] < 0 || field_of[2] < 0) {
+		throw InvalidInputException("plink_score: ID-keyed weights must be "
+		                            "LIST(STRUCT(id VARCHAR, allele VARCHAR, weight DOUBLE))");
+	}
+	// IDs of the region; of two variants with one ID the later one is the one that gets scored
+	std::unordered_map<string, uint32_t> by_id;
+	for (uint32_t v = range_start; v < range_end; v++) {
+		if (!variants.ids[v].empty()) {
+			by_id[variants.ids[v]] = v;
+		}
+	}
+	for (const auto &item : items) {
+		const auto &vals = StructValue::GetChildren(item);
+		auto hit = by_id.find(vals[field_of[0]].GetValue<string>());
+		if (hit == by_id.end()) {
+			continue;
+		}
+		const uint32_t v = hit->second;
+		const string allele = vals[field_of[1]].GetValue<string>();
+		const bool is_alt = allele == variants.GetAlt(v);
+		if (!is_alt && allele != variants.GetRef(v)) {
+			continue;
+		}
+		const double w = vals[field_of[2]].GetValue<double>();
+		if (w != 0.0) {
+			scored.push_back({v, w, !is_alt});
+		}
+	}
+	std::stable_sort(scored.begin(), scored.end(),
+	                 [](const ScoredVariant &x, const ScoredVariant &y) { return x.variant_idx < y.variant_idx; });
+	return scored;
+}
+
 static unique_ptr<FunctionData> PlinkScoreBind(ClientContext &context, TableFunctionBindInput &input,
                                                vector<LogicalType> &return_types, vector<string> &names) {
 	auto bind_data = make_uniq<PlinkScoreBindData>();
@@ -90,85 +168,7 @@ static unique_ptr<FunctionData> PlinkScoreBind(ClientContext &context, TableFunc
 	if (weights_it == input.named_parameters.end()) {
 		throw InvalidInputException("plink_score: weights parameter is required");
 	}
-	auto &weights_val = weights_it->second;
-	if (weights_val.IsNull()) {
-		throw InvalidInputException("plink_score: weights must not be NULL");
-	}
-	auto &weights_type = weights_val.type();
-	uint32_t range_start = c.RangeStart();
-	uint32_t range_end = c.RangeEnd();
-	uint32_t variant_count = range_end - range_start;
-
-	if (weights_type.id() != LogicalTypeId::LIST) {
-		throw InvalidInputException("plink_score: weights must be a list (LIST(DOUBLE) for positional mode, "
-		                            "or LIST(STRUCT(id, allele, weight)) for ID-keyed mode)");
-	}
-	auto &child_type = ListType::GetChildType(weights_type);
-	auto &children = ListValue::GetChildren(weights_val);
-	if (children.empty()) {
-		throw InvalidInputException("plink_score: weights list is empty");
-	}
-	if (child_type.id() == LogicalTypeId::STRUCT) {
-		// ID-keyed mode: LIST(STRUCT(id VARCHAR, allele VARCHAR, weight DOUBLE))
-		auto &struct_children = StructType::GetChildTypes(child_type);
-		constexpr idx_t kNone = static_cast<idx_t>(-1);
-		idx_t id_idx = kNone, allele_idx = kNone, weight_idx = kNone;
-		for (idx_t i = 0; i < struct_children.size(); i++) {
-			if (struct_children[i].first == "id") {
-				id_idx = i;
-			} else if (struct_children[i].first == "allele") {
-				allele_idx = i;
-			} else if (struct_children[i].first == "weight") {
-				weight_idx = i;
-			}
-		}
-		if (id_idx == kNone || allele_idx == kNone || weight_idx == kNone) {
-			throw InvalidInputException("plink_score: ID-keyed weights must be "
-			                            "LIST(STRUCT(id VARCHAR, allele VARCHAR, weight DOUBLE))");
-		}
-		// variant ID -> index, restricted to the region; duplicate IDs: last one wins
-		std::unordered_map<string, uint32_t> variant_id_map;
-		for (uint32_t v = range_start; v < range_end; v++) {
-			if (!c.variants.ids[v].empty()) {
-				variant_id_map[c.variants.ids[v]] = v;
-			}
-		}
-		for (auto &entry : children) {
-			auto &struct_vals = StructValue::GetChildren(entry);
-			string id = struct_vals[id_idx].GetValue<string>();
-			string allele = struct_vals[allele_idx].GetValue<string>();
-			double weight = struct_vals[weight_idx].GetValue<double>();
-			auto it = variant_id_map.find(id);
-			if (it == variant_id_map.end()) {
-				continue; // unmatched IDs are skipped silently
-			}
-			uint32_t vidx = it->second;
-			bool flip;
-			if (allele == c.variants.GetAlt(vidx)) {
-				flip = false;
-			} else if (allele == c.variants.GetRef(vidx)) {
-				flip = true;
-			} else {
-				continue; // unmatched allele
-			}
-			if (weight != 0.0) {
-				bind_data->scored_variants.push_back({vidx, weight, flip});
-			}
-		}
-		std::sort(bind_data->scored_variants.begin(), bind_data->scored_variants.end(),
-		          [](const ScoredVariant &a, const ScoredVariant &b) { return a.variant_idx < b.variant_idx; });
-	} else {
-		if (static_cast<uint32_t>(children.size()) != variant_count) {
-			throw InvalidInputException("plink_score: weights list length (%llu) must match variant count (%u)",
-			                            static_cast<unsigned long long>(children.size()), variant_count);
-		}
-		for (idx_t i = 0; i < children.size(); i++) {
-			double w = children[i].GetValue<double>();
-			if (w != 0.0) {
-				bind_data->scored_variants.push_back({range_start + static_cast<uint32_t>(i), w, false});
-			}
-		}
-	}
+	bind_data->scored_variants = ResolveWeights(weights_it->second, c.variants, c.RangeStart(), c.RangeEnd());
 
 	names = {"FID", "IID", "ALLELE_CT", "DENOM", "NAMED_ALLELE_DOSAGE_SUM", "SCORE_SUM", "SCORE_AVG"};
 	return_types = {LogicalType::VARCHAR, LogicalType::VARCHAR, LogicalType::INTEGER, LogicalType::INTEGER,
@@ -315,58 +315,40 @@ static void PlinkScoreScan(ClientContext &, TableFunctionInput &data_p, DataChun
 	}
 
 	// Phase 2: one row per sample
-	auto &column_ids = gstate.column_ids;
-	bool has_fid = !bind_data.c.sample_info.fids.empty();
-	idx_t rows_emitted = 0;
-	while (rows_emitted < STANDARD_VECTOR_SIZE) {
-		uint32_t sidx = gstate.next_sample_idx.fetch_add(1);
-		if (sidx >= gstate.total_samples) {
-			break;
+	// Phase 2: a run of output samples per call, one loop per projected column.  ALLELE_CT and
+	// DENOM are the same number; SCORE_AVG = SCORE_SUM / ALLELE_CT (src/plink_score.cpp:686-699).
+	const uint32_t first = gstate.next_sample_idx.fetch_add(STANDARD_VECTOR_SIZE);
+	const idx_t n_rows =
+	    first < gstate.total_samples ? std::min<idx_t>(STANDARD_VECTOR_SIZE, gstate.total_samples - first) : 0;
+	for (idx_t out_col = 0; out_col < gstate.column_ids.size(); out_col++) {
+		const auto file_col = gstate.column_ids[out_col];
+		if (file_col == COLUMN_IDENTIFIER_ROW_ID) {
+			continue;
 		}
-		uint32_t orig_idx = bind_data.sample_output_order[sidx];
-		uint32_t allele_ct = gstate.allele_cts[sidx];
-		double score_sum = gstate.score_sums[sidx];
-		double dosage_sum = gstate.named_allele_dosage_sums[sidx];
-		double score_avg = allele_ct > 0 ? score_sum / static_cast<double>(allele_ct) : 0.0;
-		for (idx_t out_col = 0; out_col < column_ids.size(); out_col++) {
-			auto file_col = column_ids[out_col];
-			if (file_col == COLUMN_IDENTIFIER_ROW_ID) {
-				continue;
+		auto &vec = output.data[out_col];
+		if (file_col == COL_FID || file_col == COL_IID) {
+			for (idx_t r = 0; r < n_rows; r++) {
+				FillSampleIdColumn(bind_data.c.sample_info, file_col == COL_FID, bind_data.sample_output_order[first + r],
+				                   vec, r, false);
 			}
-			auto &vec = output.data[out_col];
-			switch (file_col) {
-			case COL_FID:
-				if (has_fid) {
-					FlatVector::GetData<string_t>(vec)[rows_emitted] =
-					    StringVector::AddString(vec, bind_data.c.sample_info.fids[orig_idx]);
-				} else {
-					FlatVector::SetNull(vec, rows_emitted, true);
-				}
-				break;
-			case COL_IID:
-				FlatVector::GetData<string_t>(vec)[rows_emitted] =
-				    StringVector::AddString(vec, bind_data.c.sample_info.iids[orig_idx]);
-				break;
-			case COL_ALLELE_CT:
-			case COL_DENOM:
-				FlatVector::GetData<int32_t>(vec)[rows_emitted] = static_cast<int32_t>(allele_ct);
-				break;
-			case COL_NAMED_ALLELE_DOSAGE_SUM:
-				FlatVector::GetData<double>(vec)[rows_emitted] = dosage_sum;
-				break;
-			case COL_SCORE_SUM:
-				FlatVector::GetData<double>(vec)[rows_emitted] = score_sum;
-				break;
-			case COL_SCORE_AVG:
-				FlatVector::GetData<double>(vec)[rows_emitted] = score_avg;
-				break;
-			default:
-				break;
+		} else if (file_col == COL_ALLELE_CT || file_col == COL_DENOM) {
+			auto *dst = FlatVector::GetData<int32_t>(vec);
+			for (idx_t r = 0; r < n_rows; r++) {
+				dst[r] = static_cast<int32_t>(gstate.allele_cts[first + r]);
+			}
+		} else {
+			auto *dst = FlatVector::GetData<double>(vec);
+			for (idx_t r = 0; r < n_rows; r++) {
+				const double sum = gstate.score_sums[first + r];
+				const uint32_t allele_ct = gstate.allele_cts[first + r];
+				dst[r] = file_col == COL_NAMED_ALLELE_DOSAGE_SUM ? gstate.named_allele_dosage_sums[first + r]
+				         : file_col == COL_SCORE_SUM             ? sum
+				         : allele_ct > 0                         ? sum / static_cast<double>(allele_ct)
+				                                                 : 0.0;
 			}
 		}
-		rows_emitted++;
 	}
-	CompatSetOutputCardinality(output, rows_emitted);
+	CompatSetOutputCardinality(output, n_rows);
 }
 
 void RegisterPlinkScore(ExtensionLoader &loader) {

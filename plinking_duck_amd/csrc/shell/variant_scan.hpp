@@ -196,6 +196,18 @@ inline bool FillVariantMetadataColumn(const VariantMetadataIndex &variants, idx_
 	}
 }
 
+//! FID / IID of one output row of the per-sample functions: FID is NULL when the file has no FID
+//! column and, for plink_missing (src/plink_missing.cpp:651-664), when the field is empty.
+inline void FillSampleIdColumn(const SampleInfo &info, bool fid, uint32_t file_idx, Vector &vec, idx_t row,
+                               bool empty_fid_is_null = true) {
+	const auto &ids = fid ? info.fids : info.iids;
+	if (file_idx < ids.size() && !(fid && empty_fid_is_null && ids[file_idx].empty())) {
+		FlatVector::GetData<string_t>(vec)[row] = StringVector::AddString(vec, ids[file_idx]);
+	} else {
+		FlatVector::SetNull(vec, row, true);
+	}
+}
+
 //! Common bind work: companions, header probe, metadata, count checks, samples, region.
 struct PgenBindCommon {
 	string pgen_path, pvar_path, psam_path;
