@@ -228,86 +228,65 @@ static void PlinkPcaScan(ClientContext &, TableFunctionInput &data_p, DataChunk 
 		}
 	}
 	auto &column_ids = gs.column_ids;
-	bool has_fid = !bind_data.c.sample_info.fids.empty();
 	idx_t rows_emitted = 0;
 
 	if (bind_data.mode == PcaMode::SAMPLES) {
-		while (rows_emitted < STANDARD_VECTOR_SIZE) {
-			uint32_t sidx = gs.next_emit_idx.fetch_add(1);
-			if (sidx >= gs.N) {
-				break;
+		// a run of output samples per call, one loop per projected column
+		const uint32_t first = gs.next_emit_idx.fetch_add(STANDARD_VECTOR_SIZE);
+		rows_emitted = first < gs.N ? std::min<idx_t>(STANDARD_VECTOR_SIZE, gs.N - first) : 0;
+		for (idx_t out_col = 0; out_col < column_ids.size(); out_col++) {
+			const auto file_col = column_ids[out_col];
+			if (file_col == COLUMN_IDENTIFIER_ROW_ID) {
+				continue;
 			}
-			uint32_t orig_idx = bind_data.sample_output_order[sidx];
-			for (idx_t out_col = 0; out_col < column_ids.size(); out_col++) {
-				auto file_col = column_ids[out_col];
-				if (file_col == COLUMN_IDENTIFIER_ROW_ID) {
-					continue;
+			auto &vec = output.data[out_col];
+			if (file_col < SCOL_PC_START) {
+				for (idx_t r = 0; r < rows_emitted; r++) {
+					FillSampleIdColumn(bind_data.c.sample_info, file_col == SCOL_FID,
+					                   bind_data.sample_output_order[first + r], vec, r, false);
 				}
-				auto &vec = output.data[out_col];
-				if (file_col == SCOL_FID) {
-					if (has_fid) {
-						FlatVector::GetData<string_t>(vec)[rows_emitted] =
-						    StringVector::AddString(vec, bind_data.c.sample_info.fids[orig_idx]);
-					} else {
-						FlatVector::SetNull(vec, rows_emitted, true);
-					}
-				} else if (file_col == SCOL_IID) {
-					FlatVector::GetData<string_t>(vec)[rows_emitted] =
-					    StringVector::AddString(vec, bind_data.c.sample_info.iids[orig_idx]);
-				} else if (file_col >= SCOL_PC_START && file_col < SCOL_PC_START + bind_data.n_pcs) {
-					uint32_t pc = static_cast<uint32_t>(file_col - SCOL_PC_START);
-					FlatVector::GetData<double>(vec)[rows_emitted] =
-					    gs.eigenvectors[static_cast<size_t>(sidx) * gs.n_pcs + pc];
+			} else if (file_col < SCOL_PC_START + bind_data.n_pcs) {
+				const size_t pc = file_col - SCOL_PC_START;
+				auto *dst = FlatVector::GetData<double>(vec);
+				for (idx_t r = 0; r < rows_emitted; r++) {
+					dst[r] = gs.eigenvectors[static_cast<size_t>(first + r) * gs.n_pcs + pc];
 				}
 			}
-			rows_emitted++;
 		}
 	} else if (bind_data.mode == PcaMode::PCS) {
 		// proportions are over the k reported eigenvalues only (src/plink_pca.cpp:777-796)
-		double total_variance = 0.0;
+		const uint32_t first = gs.next_emit_idx.fetch_add(STANDARD_VECTOR_SIZE);
+		rows_emitted = first < gs.n_pcs ? std::min<idx_t>(STANDARD_VECTOR_SIZE, gs.n_pcs - first) : 0;
+		double total_variance = 0.0, running = 0.0;
 		for (uint32_t i = 0; i < gs.n_pcs; i++) {
 			total_variance += gs.eigenvalues[i];
 		}
-		while (rows_emitted < STANDARD_VECTOR_SIZE) {
-			uint32_t pc_idx = gs.next_emit_idx.fetch_add(1);
-			if (pc_idx >= gs.n_pcs) {
-				break;
-			}
-			double eigenvalue = gs.eigenvalues[pc_idx];
-			double var_prop = total_variance > 0.0 ? eigenvalue / total_variance : 0.0;
-			double cum_var = 0.0;
-			for (uint32_t i = 0; i <= pc_idx; i++) {
-				cum_var += gs.eigenvalues[i];
-			}
-			cum_var = total_variance > 0.0 ? cum_var / total_variance : 0.0;
+		for (uint32_t i = 0; i < first; i++) {
+			running += gs.eigenvalues[i];
+		}
+		for (idx_t r = 0; r < rows_emitted; r++) {
+			const double eigenvalue = gs.eigenvalues[first + r];
+			running += eigenvalue;
 			for (idx_t out_col = 0; out_col < column_ids.size(); out_col++) {
-				auto file_col = column_ids[out_col];
+				const auto file_col = column_ids[out_col];
 				if (file_col == COLUMN_IDENTIFIER_ROW_ID) {
 					continue;
 				}
 				auto &vec = output.data[out_col];
-				switch (file_col) {
-				case PCOL_PC:
-					FlatVector::GetData<int32_t>(vec)[rows_emitted] = static_cast<int32_t>(pc_idx + 1);
-					break;
-				case PCOL_EIGENVALUE:
-					FlatVector::GetData<double>(vec)[rows_emitted] = eigenvalue;
-					break;
-				case PCOL_VARIANCE_PROPORTION:
-					FlatVector::GetData<double>(vec)[rows_emitted] = var_prop;
-					break;
-				case PCOL_CUMULATIVE_VARIANCE:
-					FlatVector::GetData<double>(vec)[rows_emitted] = cum_var;
-					break;
-				default:
-					break;
+				if (file_col == PCOL_PC) {
+					FlatVector::GetData<int32_t>(vec)[r] = static_cast<int32_t>(first + r + 1);
+				} else {
+					const double share = file_col == PCOL_EIGENVALUE ? eigenvalue
+					                     : total_variance <= 0.0    ? 0.0
+					                     : (file_col == PCOL_VARIANCE_PROPORTION ? eigenvalue : running) / total_variance;
+					FlatVector::GetData<double>(vec)[r] = share;
 				}
 			}
-			rows_emitted++;
 		}
 	} else {
 		// 'both': one row {EIGENVEC: LIST(STRUCT(FID, IID, PC1..)), EIGENVAL: LIST(DOUBLE)}
 		if (gs.next_emit_idx.fetch_add(1) == 0) {
+			const bool has_fid = !bind_data.c.sample_info.fids.empty();
 			vector<Value> eigenvec_entries;
 			for (uint32_t sidx = 0; sidx < gs.N; sidx++) {
 				uint32_t orig_idx = bind_data.sample_output_order[sidx];
