@@ -178,133 +178,101 @@ static void PlinkHardyScan(ClientContext &, TableFunctionInput &data_p, DataChun
 		return false;
 	};
 
-	idx_t rows_emitted = 0;
+	// The chunk's rows first (counts of the HWE-test stratum, heterozygosities, the batch's exact
+	// test), then one loop per projected column.
+	struct HardyRow {
+		uint32_t vidx;
+		int32_t counts[3] = {0, 0, 0}; // HOM_REF_CT, HET_CT, HOM_ALT_CT of the tested stratum
+		double stats[3] = {0.0, 0.0, 1.0}; // O_HET, E_HET, P_HWE
+		bool counts_are_null = false, stats_are_null = true;
+	};
+	vector<HardyRow> rows;
+	rows.reserve(STANDARD_VECTOR_SIZE);
 	uint32_t vidx;
-	while (rows_emitted < STANDARD_VECTOR_SIZE && lstate.scan.Next(gstate.scan, "plink_hardy", needs_strata, vidx)) {
-		ChromPloidy ploidy = ChromPloidy::AUTOSOMAL;
-		if (gstate.need_genotype_counts) {
-			ploidy = ClassifyChromPloidy(variants.GetChrom(vidx), variants.GetPos(vidx), bind_data.par_bounds);
-			if (gstate.need_p_hwe && lstate.lnp_batch_begin != lstate.scan.batch_begin) {
-				PrepareBatchTests(bind_data, lstate);
-			}
+	while (rows.size() < STANDARD_VECTOR_SIZE && lstate.scan.Next(gstate.scan, "plink_hardy", needs_strata, vidx)) {
+		HardyRow row;
+		row.vidx = vidx;
+		if (!gstate.need_genotype_counts) {
+			rows.push_back(row);
+			continue;
 		}
-		const double batch_lnp = gstate.need_p_hwe && gstate.need_genotype_counts
-		                             ? lstate.lnp[vidx - lstate.scan.batch_begin]
-		                             : 0.0;
-		const bool sex_aware = ploidy != ChromPloidy::AUTOSOMAL;
-		uint32_t genocounts[4] = {0, 0, 0, 0};
-		SexAwareCounts sac;
-		if (gstate.need_genotype_counts) {
-			std::memcpy(genocounts, lstate.scan.Counts(vidx), sizeof genocounts);
-			if (sex_aware) {
-				static const uint32_t zero[4] = {0, 0, 0, 0};
-				const bool strata = lstate.scan.have_strata;
-				sac = SexAwareFromStrata(ploidy, genocounts, strata ? lstate.scan.MaleCounts(vidx) : zero,
-				                         strata ? lstate.scan.FemaleCounts(vidx) : zero, bind_data.have_sex);
-			}
+		if (gstate.need_p_hwe && lstate.lnp_batch_begin != lstate.scan.batch_begin) {
+			PrepareBatchTests(bind_data, lstate);
 		}
-
-		// Reported HOM/HET counts are the HWE-test stratum: females on chrX,
-		// haploid carriers (HET = 0) on chrY / chrMT.
-		int32_t out_hom_ref = 0, out_het = 0, out_hom_alt = 0;
-		double o_het = 0.0, e_het = 0.0, p_hwe = 1.0;
-		bool stats_are_null;
-		bool counts_are_null = false;
-		if (sex_aware) {
-			if (sac.sex_unavailable) {
-				counts_are_null = true;
-				stats_are_null = true;
-			} else if (sac.hwe_defined) {
-				out_hom_ref = static_cast<int32_t>(sac.hwe_hom_ref);
-				out_het = static_cast<int32_t>(sac.hwe_het);
-				out_hom_alt = static_cast<int32_t>(sac.hwe_hom_alt);
-				uint32_t fobs = sac.hwe_hom_ref + sac.hwe_het + sac.hwe_hom_alt;
-				if (fobs == 0) {
-					stats_are_null = true;
-				} else {
-					stats_are_null = false;
-					o_het = static_cast<double>(sac.hwe_het) / static_cast<double>(fobs);
-					double p = (2.0 * sac.hwe_hom_ref + sac.hwe_het) / (2.0 * fobs);
-					e_het = 2.0 * p * (1.0 - p);
-					// males contribute only to geno_hom_* (het -> missing), females to both
-					int32_t male_ref = static_cast<int32_t>(sac.geno_hom_ref) - static_cast<int32_t>(sac.hwe_hom_ref);
-					int32_t male_alt = static_cast<int32_t>(sac.geno_hom_alt) - static_cast<int32_t>(sac.hwe_hom_alt);
-					// HweExactTestXchr's guards (src/plink_hardy.cpp:83-95), the test itself from the batch
-					p_hwe = (male_ref < 0 || male_alt < 0) ? 1.0 : LnPToPvalue(batch_lnp);
-				}
-			} else {
-				out_hom_ref = static_cast<int32_t>(sac.geno_hom_ref);
-				out_het = static_cast<int32_t>(sac.geno_het);
-				out_hom_alt = static_cast<int32_t>(sac.geno_hom_alt);
-				stats_are_null = true;
+		const double ln_p = gstate.need_p_hwe ? lstate.lnp[vidx - lstate.scan.batch_begin] : 0.0;
+		const ChromPloidy ploidy = ClassifyChromPloidy(variants.GetChrom(vidx), variants.GetPos(vidx), bind_data.par_bounds);
+		const uint32_t *gc = lstate.scan.Counts(vidx);
+		// O_HET / E_HET of a diploid stratum (src/plink_hardy.cpp:575-588)
+		auto diploid_stats = [&](uint32_t hom_ref, uint32_t het, uint32_t hom_alt, bool test_ok) {
+			const uint32_t obs = hom_ref + het + hom_alt;
+			row.counts[0] = static_cast<int32_t>(hom_ref);
+			row.counts[1] = static_cast<int32_t>(het);
+			row.counts[2] = static_cast<int32_t>(hom_alt);
+			row.stats_are_null = obs == 0;
+			if (obs) {
+				const double p = (2.0 * hom_ref + het) / (2.0 * obs);
+				row.stats[0] = static_cast<double>(het) / static_cast<double>(obs);
+				row.stats[1] = 2.0 * p * (1.0 - p);
+				row.stats[2] = test_ok ? LnPToPvalue(ln_p) : 1.0;
 			}
+		};
+		if (ploidy == ChromPloidy::AUTOSOMAL) {
+			diploid_stats(gc[0], gc[1], gc[2], true);
 		} else {
-			uint32_t hom_ref = genocounts[0], het = genocounts[1], hom_alt = genocounts[2];
-			uint32_t obs = hom_ref + het + hom_alt;
-			out_hom_ref = static_cast<int32_t>(hom_ref);
-			out_het = static_cast<int32_t>(het);
-			out_hom_alt = static_cast<int32_t>(hom_alt);
-			stats_are_null = (obs == 0);
-			if (!stats_are_null) {
-				o_het = static_cast<double>(het) / static_cast<double>(obs);
-				double p = (2.0 * hom_ref + het) / (2.0 * obs);
-				e_het = 2.0 * p * (1.0 - p);
-				p_hwe = LnPToPvalue(batch_lnp); // HweExactTestAutosomal (src/plink_hardy.cpp:67-79), batched
+			static const uint32_t zero[4] = {0, 0, 0, 0};
+			const bool strata = lstate.scan.have_strata;
+			SexAwareCounts sac = SexAwareFromStrata(ploidy, gc, strata ? lstate.scan.MaleCounts(vidx) : zero,
+			                                        strata ? lstate.scan.FemaleCounts(vidx) : zero, bind_data.have_sex);
+			if (sac.sex_unavailable) {
+				row.counts_are_null = true;
+			} else if (sac.hwe_defined) {
+				// chrX: the females are the tested stratum; the males enter the exact test as allele counts
+				// (geno_hom_* minus the females'), which must not come out negative
+				const bool males_ok = sac.geno_hom_ref >= sac.hwe_hom_ref && sac.geno_hom_alt >= sac.hwe_hom_alt;
+				diploid_stats(sac.hwe_hom_ref, sac.hwe_het, sac.hwe_hom_alt, males_ok);
+			} else {
+				// chrY / chrMT: haploid carriers, HET_CT = 0, no test
+				row.counts[0] = static_cast<int32_t>(sac.geno_hom_ref);
+				row.counts[1] = static_cast<int32_t>(sac.geno_het);
+				row.counts[2] = static_cast<int32_t>(sac.geno_hom_alt);
 			}
 		}
-
-		for (idx_t out_col = 0; out_col < column_ids.size(); out_col++) {
-			auto file_col = column_ids[out_col];
-			if (file_col == COLUMN_IDENTIFIER_ROW_ID) {
-				continue;
-			}
-			auto &vec = output.data[out_col];
-			if (FillVariantMetadataColumn(variants, file_col, vidx, vec, rows_emitted)) {
-				continue;
-			}
-			auto put_count = [&](int32_t v) {
-				if (counts_are_null) {
-					FlatVector::SetNull(vec, rows_emitted, true);
-				} else {
-					FlatVector::GetData<int32_t>(vec)[rows_emitted] = v;
-				}
-			};
-			auto put_stat = [&](double v) {
-				if (stats_are_null) {
-					FlatVector::SetNull(vec, rows_emitted, true);
-				} else {
-					FlatVector::GetData<double>(vec)[rows_emitted] = v;
-				}
-			};
-			switch (file_col) {
-			case COL_A1: // tested allele = ALT
-				FillVariantMetadataColumn(variants, 4, vidx, vec, rows_emitted);
-				break;
-			case COL_HOM_REF_CT:
-				put_count(out_hom_ref);
-				break;
-			case COL_HET_CT:
-				put_count(out_het);
-				break;
-			case COL_HOM_ALT_CT:
-				put_count(out_hom_alt);
-				break;
-			case COL_O_HET:
-				put_stat(o_het);
-				break;
-			case COL_E_HET:
-				put_stat(e_het);
-				break;
-			case COL_P_HWE:
-				put_stat(p_hwe);
-				break;
-			default:
-				break;
-			}
-		}
-		rows_emitted++;
+		rows.push_back(row);
 	}
-	CompatSetOutputCardinality(output, rows_emitted);
+
+	const idx_t n_rows = rows.size();
+	for (idx_t out_col = 0; out_col < column_ids.size(); out_col++) {
+		const auto file_col = column_ids[out_col];
+		if (file_col == COLUMN_IDENTIFIER_ROW_ID) {
+			continue;
+		}
+		auto &vec = output.data[out_col];
+		if (file_col <= COL_A1) {
+			const idx_t source = file_col == COL_A1 ? 4 : file_col; // the tested allele A1 is ALT
+			for (idx_t r = 0; r < n_rows; r++) {
+				FillVariantMetadataColumn(variants, source, rows[r].vidx, vec, r);
+			}
+		} else if (file_col <= COL_HOM_ALT_CT) {
+			auto *dst = FlatVector::GetData<int32_t>(vec);
+			for (idx_t r = 0; r < n_rows; r++) {
+				if (rows[r].counts_are_null) {
+					FlatVector::SetNull(vec, r, true);
+				} else {
+					dst[r] = rows[r].counts[file_col - COL_HOM_REF_CT];
+				}
+			}
+		} else if (file_col <= COL_P_HWE) {
+			auto *dst = FlatVector::GetData<double>(vec);
+			for (idx_t r = 0; r < n_rows; r++) {
+				if (rows[r].stats_are_null) {
+					FlatVector::SetNull(vec, r, true);
+				} else {
+					dst[r] = rows[r].stats[file_col - COL_O_HET];
+				}
+			}
+		}
+	}
+	CompatSetOutputCardinality(output, n_rows);
 }
 
 void RegisterPlinkHardy(ExtensionLoader &loader) {
