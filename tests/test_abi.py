@@ -163,3 +163,25 @@ def test_no_gpu_means_loud_failure(lib):
         lib.Dataset.open(data_path("pgen_example.pgen"))
     with pytest.raises(IOError):
         lib.Dataset.synth(0, 4, 16, 1, 0.0)
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/pgenhip.h is the boundary: it must compile as C99 (what cgo / JNI / ctypes generators
+    consume) and as C++, and a C program must link against libpgenhip.so with nothing but the header."""
+    import subprocess
+    src = tmp_path / "host.c"
+    src.write_text('#include "pgenhip.h"\n#include <stdio.h>\n'
+                   'int main(void) { pgh_info info; char err[PGH_ERRBUF_LEN];\n'
+                   '  int rc = pgh_probe("/nonexistent.pgen", 0, &info, err);\n'
+                   '  printf("%s rc=%d %s\\n", pgh_version(), rc, err); return rc == PGH_OK; }\n')
+    inc = os.path.join(ROOT, "include")
+    libdir = os.path.join(ROOT, "plinking_duck_amd")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-c", str(src),
+                    "-o", str(tmp_path / "host_c.o")], check=True, capture_output=True)
+    subprocess.run(["g++", "-std=c++11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-x", "c++", "-c",
+                    str(src), "-o", str(tmp_path / "host_cpp.o")], check=True, capture_output=True)
+    exe = tmp_path / "host"
+    subprocess.run(["gcc", str(tmp_path / "host_c.o"), "-o", str(exe), "-L", libdir, "-lpgenhip",
+                    "-Wl,-rpath," + libdir], check=True, capture_output=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and "pgenhip" in r.stdout and "cannot open" in r.stdout
