@@ -185,3 +185,15 @@ def test_header_is_plain_c_and_links(tmp_path):
                     "-Wl,-rpath," + libdir], check=True, capture_output=True)
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0 and "pgenhip" in r.stdout and "cannot open" in r.stdout
+
+
+def test_rccl_host_example_compiles(tmp_path):
+    """tests/abi/rccl_host.cpp -- the RCCL all-reduce callback a C++ host hands to pgh_pca_sharded --
+    compiles against pgenhip.h + rccl.h (hipcc cross-compiles without a GPU)."""
+    import subprocess
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    subprocess.run([hipcc, "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c",
+                    os.path.join(ROOT, "tests", "abi", "rccl_host.cpp"), "-o", str(tmp_path / "rccl_host.o")],
+                   check=True, capture_output=True)
