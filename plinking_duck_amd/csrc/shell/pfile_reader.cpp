@@ -2,8 +2,9 @@
 //                                variants, af_range, ac_range, include_genotypes, genotype_range,
 //                                dosages, phased)
 //
-// The part of the reference's src/pfile_reader.cpp that sits on the genotype hot path, for ONE
-// fileset (a prefix or explicit pgen/pvar/psam paths):
+// The part of the reference's src/pfile_reader.cpp that sits on the genotype hot path, for one
+// fileset (a prefix or explicit pgen/pvar/psam paths) or a LIST of prefixes that share their
+// samples and are concatenated along the variant axis (shards):
 //   orient := 'variant'  one row per variant -- the read_pgen scan (pgen_reader.cpp) under
 //                        read_pfile's name, plus `region`;
 //   orient := 'sample' with genotypes := 'counts' | 'stats'
@@ -15,7 +16,7 @@
 //                        column-tally launches) by whichever thread scans first; phase 2 emits rows.
 // Not carried over (they materialise a variant x sample matrix on the host or fan variants out
 // to tidy rows -- no device work): orient := 'genotype', sample-oriented array/list/columns/
-// struct output, multi-file lists, combine_samples, parquet companions.
+// struct output, combine_samples other than the implicit one, parquet companions.
 #include "pgen_reader.hpp"
 
 #include <cerrno>
@@ -82,17 +83,23 @@ bool PsamMissing(const string &v) {
 
 } // namespace
 
+//! One fileset of the call.
+struct PfileSource {
+	string pgen_path;
+	TableFunctionBindInput inner;          // (pgen path; pvar, psam, samples, region, ...) for the shared binds
+	unique_ptr<FunctionData> variant_bind; // orient := 'variant': the read_pgen bind under read_pfile's name
+	PgenBindCommon c;                      // orient := 'sample'
+	bool has_variant_list = false;
+	vector<uint32_t> variant_indices;
+};
+
 struct PfileBindData : public TableFunctionData {
 	bool sample_orient = false;
-	// orient := 'variant': the read_pgen bind under read_pfile's name
-	unique_ptr<FunctionData> variant_bind;
+	vector<PfileSource> sources; // row-concatenated in list order; all share source 0's samples
 	// orient := 'sample' aggregate
-	PgenBindCommon c;
 	GenotypeMode genotype_mode = GenotypeMode::COUNTS;
 	CountFilter count_filter;
 	GenotypeRangeFilter genotype_filter;
-	bool has_variant_list = false;
-	vector<uint32_t> variant_indices;
 	idx_t genotypes_col = 0;
 	idx_t sex_col = static_cast<idx_t>(-1);
 	vector<idx_t> parent_cols;
@@ -100,14 +107,15 @@ struct PfileBindData : public TableFunctionData {
 };
 
 struct PfileGlobalState : public GlobalTableFunctionState {
-	// orient := 'variant'
-	unique_ptr<GlobalTableFunctionState> variant_state;
+	// orient := 'variant': one read_pgen scan state per source
+	vector<unique_ptr<GlobalTableFunctionState>> variant_states;
+	uint64_t total_variants = 0;
 	// orient := 'sample'
 	vector<column_t> column_ids;
 	bool need_genotypes = false;
 	uint32_t max_threads_config = 0;
-	shared_ptr<DeviceDataset> dataset;
-	unique_ptr<DeviceSubset> subset;
+	vector<shared_ptr<DeviceDataset>> datasets;
+	vector<unique_ptr<DeviceSubset>> subsets;
 	std::mutex phase1_mutex;
 	bool phase1_done = false;
 	vector<uint32_t> counts;     // [output sample][4]
@@ -118,8 +126,8 @@ struct PfileGlobalState : public GlobalTableFunctionState {
 	std::atomic<uint32_t> next_idx {0};
 
 	idx_t MaxThreads() const override {
-		if (variant_state) {
-			return variant_state->MaxThreads();
+		if (!variant_states.empty()) {
+			return ApplyMaxThreadsCap(total_variants / 1000 + 1, max_threads_config);
 		}
 		// src/pfile_reader.cpp:576-581: phase 1 is parallel over variants in the reference
 		uint32_t work = std::max<uint32_t>(static_cast<uint32_t>(counts.size() / 4), candidate_variants);
@@ -128,42 +136,26 @@ struct PfileGlobalState : public GlobalTableFunctionState {
 };
 
 struct PfileLocalState : public LocalTableFunctionState {
-	unique_ptr<LocalTableFunctionState> variant_state;
+	// orient := 'variant': this thread's read_pgen scan state per source, and the source it is draining
+	vector<unique_ptr<LocalTableFunctionState>> variant_states;
+	size_t current = 0;
 };
 
-static unique_ptr<FunctionData> PfileBind(ClientContext &context, TableFunctionBindInput &input,
-                                          vector<LogicalType> &return_types, vector<string> &names) {
-	auto bind_data = make_uniq<PfileBindData>();
-	if (input.inputs[0].type().id() == LogicalTypeId::LIST) {
-		throw InvalidInputException("read_pfile: multi-file lists are not available in this build "
-		                            "(pass one prefix per call)");
-	}
-	const string prefix = input.inputs[0].IsNull() ? string() : input.inputs[0].GetValue<string>();
-	string pgen_path, orient_str = "variant";
-	for (auto &kv : input.named_parameters) {
-		if (kv.first == "pgen") {
-			pgen_path = kv.second.GetValue<string>();
-		} else if (kv.first == "orient") {
-			orient_str = Lowered(kv.second.GetValue<string>());
-		} else if (kv.first == "combine_samples") {
-			throw InvalidInputException("read_pfile: combine_samples needs a multi-file list, which is not available "
-			                            "in this build");
-		}
-	}
-	if (orient_str != "variant" && orient_str != "sample" && orient_str != "genotype") {
-		throw InvalidInputException("read_pfile: invalid orient value '%s' (expected 'variant', 'genotype', or 'sample')",
-		                            orient_str);
-	}
-	// --- the three paths (src/pfile_reader.cpp:670-760) ---
+//! Paths of one fileset (src/pfile_reader.cpp:670-760): `prefix`.pgen or a full .pgen path, the
+//! companions next to it unless named explicitly; returns the (pgen; named...) input the shared binds take.
+static PfileSource ResolveSource(const string &prefix, const string &pgen_override, const TableFunctionBindInput &input,
+                                 bool take_pvar_override) {
+	PfileSource src;
+	src.pgen_path = pgen_override;
 	string eff_prefix = prefix;
-	if (pgen_path.empty()) {
+	if (src.pgen_path.empty()) {
 		if (prefix.empty()) {
 			throw InvalidInputException("read_pfile: no .pgen file path provided");
 		}
 		if (FileExists(prefix + ".pgen")) {
-			pgen_path = prefix + ".pgen";
+			src.pgen_path = prefix + ".pgen";
 		} else if (FileExists(prefix)) {
-			pgen_path = prefix; // a full .pgen path given as the prefix
+			src.pgen_path = prefix; // a full .pgen path given as the prefix
 			if (prefix.size() > 5 && prefix.compare(prefix.size() - 5, 5, ".pgen") == 0) {
 				eff_prefix = prefix.substr(0, prefix.size() - 5);
 			}
@@ -172,31 +164,91 @@ static unique_ptr<FunctionData> PfileBind(ClientContext &context, TableFunctionB
 			                            prefix + ".pgen");
 		}
 	}
-	// the shared bind takes (pgen path; pvar, psam, ...): drop what only read_pfile knows
-	TableFunctionBindInput inner;
-	inner.inputs.push_back(Value::VARCHAR(pgen_path));
+	src.inner.inputs.push_back(Value::VARCHAR(src.pgen_path));
 	for (auto &kv : input.named_parameters) {
 		if (kv.first == "region") {
-			inner.named_parameters[kv.first] = Value::VARCHAR(CanonicalRegion(kv.second.GetValue<string>()));
-		} else if (kv.first != "pgen" && kv.first != "orient") {
-			inner.named_parameters[kv.first] = kv.second;
+			src.inner.named_parameters[kv.first] = Value::VARCHAR(CanonicalRegion(kv.second.GetValue<string>()));
+		} else if (kv.first == "pvar" && !take_pvar_override) {
+			continue;
+		} else if (kv.first != "pgen" && kv.first != "orient" && kv.first != "combine_samples") {
+			src.inner.named_parameters[kv.first] = kv.second;
 		}
 	}
-	if (!inner.named_parameters.count("pvar") && !eff_prefix.empty()) {
-		for (const char *ext : {".pvar", ".bim"}) {
+	auto companion = [&](const char *param, std::initializer_list<const char *> exts) {
+		if (src.inner.named_parameters.count(param) || eff_prefix.empty()) {
+			return;
+		}
+		for (const char *ext : exts) {
 			if (FileExists(eff_prefix + ext)) {
-				inner.named_parameters["pvar"] = Value::VARCHAR(eff_prefix + ext);
-				break;
+				src.inner.named_parameters[param] = Value::VARCHAR(eff_prefix + ext);
+				return;
 			}
+		}
+	};
+	companion("pvar", {".pvar", ".bim"});
+	companion("psam", {".psam", ".fam"});
+	return src;
+}
+
+static unique_ptr<FunctionData> PfileBind(ClientContext &context, TableFunctionBindInput &input,
+                                          vector<LogicalType> &return_types, vector<string> &names) {
+	auto bind_data = make_uniq<PfileBindData>();
+	string pgen_override, orient_str = "variant", combine = "implicit";
+	for (auto &kv : input.named_parameters) {
+		if (kv.first == "pgen") {
+			pgen_override = kv.second.GetValue<string>();
+		} else if (kv.first == "orient") {
+			orient_str = Lowered(kv.second.GetValue<string>());
+		} else if (kv.first == "combine_samples") {
+			combine = Lowered(kv.second.GetValue<string>());
 		}
 	}
-	if (!inner.named_parameters.count("psam") && !eff_prefix.empty()) {
-		for (const char *ext : {".psam", ".fam"}) {
-			if (FileExists(eff_prefix + ext)) {
-				inner.named_parameters["psam"] = Value::VARCHAR(eff_prefix + ext);
-				break;
+	// --- the prefix, or the list of prefixes (ResolvePathList, src/plink_common.cpp:460-483) ---
+	vector<string> prefixes;
+	const Value &first = input.inputs[0];
+	if (first.IsNull()) {
+		if (pgen_override.empty()) { // a NULL positional with pgen := stands for the no-positional call
+			throw InvalidInputException("read_pfile: empty file list provided");
+		}
+		prefixes.push_back(string());
+	} else if (first.type().id() == LogicalTypeId::LIST) {
+		for (auto &item : ListValue::GetChildren(first)) {
+			if (!item.IsNull()) {
+				prefixes.push_back(item.GetValue<string>());
 			}
 		}
+		if (prefixes.empty()) {
+			throw InvalidInputException("read_pfile: empty file list provided");
+		}
+	} else {
+		prefixes.push_back(first.GetValue<string>());
+	}
+	const bool multi_file = prefixes.size() > 1;
+	if (orient_str != "variant" && orient_str != "sample" && orient_str != "genotype") {
+		throw InvalidInputException("read_pfile: invalid orient value '%s' (expected 'variant', 'genotype', or 'sample')",
+		                            orient_str);
+	}
+	if (combine != "implicit" && combine != "identical") {
+		if (combine == "union" || combine == "intersect" || combine == "concatenate") {
+			throw InvalidInputException("read_pfile: combine_samples := '%s' is not yet implemented "
+			                            "(only 'implicit' and 'identical' are supported)",
+			                            combine);
+		}
+		throw InvalidInputException("read_pfile: unknown combine_samples '%s'", combine);
+	}
+	if (multi_file) {
+		if (!pgen_override.empty() || input.named_parameters.count("pvar")) {
+			throw InvalidInputException(
+			    "read_pfile: pgen/pvar overrides cannot be combined with a multi-file list (pgen is the per-shard "
+			    "input and pvar differs per shard). A psam override is allowed — it applies to every shard.");
+		}
+		if (input.named_parameters.count("variants")) {
+			throw InvalidInputException("read_pfile: variants := [...] with a multi-file list is not yet supported; "
+			                            "use region := for selection across files");
+		}
+	}
+	for (size_t i = 0; i < prefixes.size(); i++) {
+		bind_data->sources.push_back(ResolveSource(prefixes[i], i == 0 ? pgen_override : string(), input, !multi_file));
 	}
 
 	string genotypes_str = "auto";
@@ -204,8 +256,29 @@ static unique_ptr<FunctionData> PfileBind(ClientContext &context, TableFunctionB
 	if (genotypes_it != input.named_parameters.end()) {
 		genotypes_str = Lowered(genotypes_it->second.GetValue<string>());
 	}
+	auto same_samples = [&](uint32_t have, uint32_t want, const PfileSource &src) {
+		if (have != want) {
+			throw InvalidInputException(
+			    "read_pfile: sample count mismatch across files: '%s' has %u samples, but expected %u "
+			    "(from '%s'). All listed pfiles must share the same samples.",
+			    src.pgen_path, have, want, bind_data->sources[0].pgen_path);
+		}
+	};
 	if (orient_str == "variant") {
-		bind_data->variant_bind = PgenBindNamed(context, inner, return_types, names, "read_pfile", true);
+		// every source binds as a read_pgen scan; the schema is source 0's
+		uint32_t want = 0;
+		for (size_t i = 0; i < bind_data->sources.size(); i++) {
+			auto &src = bind_data->sources[i];
+			vector<LogicalType> types_i;
+			vector<string> names_i;
+			src.variant_bind = PgenBindNamed(context, src.inner, i ? types_i : return_types, i ? names_i : names,
+			                                 "read_pfile", true);
+			const uint32_t have = src.variant_bind->Cast<PgenBindData>().c.raw_sample_ct;
+			if (i == 0) {
+				want = have;
+			}
+			same_samples(have, want, src);
+		}
 		return std::move(bind_data);
 	}
 	if (orient_str == "genotype") {
@@ -231,9 +304,15 @@ static unique_ptr<FunctionData> PfileBind(ClientContext &context, TableFunctionB
 	if (dosages && phased) {
 		throw InvalidInputException("read_pfile: dosages and phased cannot both be true");
 	}
-	auto &c = bind_data->c;
-	c.Bind(context, inner, "read_pfile", true);
-	bind_data->genotype_mode = ResolveGenotypeMode(genotypes_str, c.raw_variant_ct, "read_pfile");
+	uint64_t total_variants = 0;
+	for (size_t i = 0; i < bind_data->sources.size(); i++) {
+		auto &src = bind_data->sources[i];
+		src.c.Bind(context, src.inner, "read_pfile", i == 0);
+		same_samples(src.c.raw_sample_ct, bind_data->sources[0].c.raw_sample_ct, src);
+		total_variants += src.c.raw_variant_ct;
+	}
+	auto &c = bind_data->sources[0].c;
+	bind_data->genotype_mode = ResolveGenotypeMode(genotypes_str, static_cast<uint32_t>(total_variants), "read_pfile");
 	if (!IsAggregateGenotypeMode(bind_data->genotype_mode)) {
 		throw InvalidInputException("read_pfile: orient := 'sample' with genotypes := '%s' is not available in this "
 		                            "build (the sample-oriented matrix is assembled on the host; use genotypes := "
@@ -248,10 +327,11 @@ static unique_ptr<FunctionData> PfileBind(ClientContext &context, TableFunctionB
 		throw InvalidInputException("read_pfile: genotypes := '%s' is incompatible with dosages := true", label);
 	}
 	auto variants_it = input.named_parameters.find("variants");
-	if (variants_it != input.named_parameters.end()) {
-		bind_data->variant_indices = ResolveVariantsParameter(variants_it->second, c.variants, c.raw_variant_ct, "read_pfile");
-		std::sort(bind_data->variant_indices.begin(), bind_data->variant_indices.end());
-		bind_data->has_variant_list = true;
+	if (variants_it != input.named_parameters.end()) { // single source only (guarded above)
+		auto &src = bind_data->sources[0];
+		src.variant_indices = ResolveVariantsParameter(variants_it->second, c.variants, c.raw_variant_ct, "read_pfile");
+		std::sort(src.variant_indices.begin(), src.variant_indices.end());
+		src.has_variant_list = true;
 	}
 	auto af_it = input.named_parameters.find("af_range");
 	if (af_it != input.named_parameters.end()) {
@@ -281,7 +361,7 @@ static unique_ptr<FunctionData> PfileBind(ClientContext &context, TableFunctionB
 			bind_data->output_samples.push_back(s);
 		}
 	}
-	// schema: every psam column (SEX is INTEGER, the rest VARCHAR), then the aggregate struct
+	// schema: every psam column of source 0 (SEX is INTEGER, the rest VARCHAR), then the aggregate struct
 	for (idx_t i = 0; i < c.sample_info.column_names.size(); i++) {
 		const string &name = c.sample_info.column_names[i];
 		names.push_back(name);
@@ -305,28 +385,38 @@ static unique_ptr<FunctionData> PfileBind(ClientContext &context, TableFunctionB
 static unique_ptr<GlobalTableFunctionState> PfileInitGlobal(ClientContext &context, TableFunctionInitInput &input) {
 	auto &bind_data = input.bind_data->Cast<PfileBindData>();
 	auto state = make_uniq<PfileGlobalState>();
+	state->max_threads_config = GetPlinkingMaxThreads(context);
 	if (!bind_data.sample_orient) {
-		TableFunctionInitInput inner = input;
-		inner.bind_data = bind_data.variant_bind.get();
-		state->variant_state = PgenInitGlobal(context, inner);
+		for (auto &src : bind_data.sources) {
+			TableFunctionInitInput inner = input;
+			inner.bind_data = src.variant_bind.get();
+			state->variant_states.push_back(PgenInitGlobal(context, inner));
+			auto &scan = state->variant_states.back()->Cast<PgenGlobalState>().scan;
+			state->total_variants += scan.has_variant_list ? scan.variant_list.size()
+			                                               : scan.end_variant_idx - scan.start_variant_idx;
+		}
 		return std::move(state);
 	}
 	state->column_ids = input.column_ids;
-	state->max_threads_config = GetPlinkingMaxThreads(context);
 	for (auto col_id : input.column_ids) {
 		if (col_id == bind_data.genotypes_col) {
 			state->need_genotypes = true;
 		}
 	}
-	const auto &c = bind_data.c;
-	state->candidate_variants = bind_data.has_variant_list ? static_cast<uint32_t>(bind_data.variant_indices.size())
-	                                                       : c.RangeEnd() - c.RangeStart();
+	for (auto &src : bind_data.sources) {
+		state->candidate_variants += src.has_variant_list ? static_cast<uint32_t>(src.variant_indices.size())
+		                                                  : src.c.RangeEnd() - src.c.RangeStart();
+	}
 	state->counts.assign(4 * bind_data.output_samples.size(), 0);
 	// a row filter needs the tallies even when the struct itself is not projected
 	if (state->need_genotypes || bind_data.genotype_filter.active) {
-		state->dataset = DeviceDataset::Acquire(c.pgen_path, "read_pfile");
-		if (c.has_sample_subset) {
-			state->subset = make_uniq<DeviceSubset>(*state->dataset, c.sample_subset->sample_include, "read_pfile");
+		for (auto &src : bind_data.sources) {
+			state->datasets.push_back(DeviceDataset::Acquire(src.c.pgen_path, "read_pfile"));
+			state->subsets.push_back(nullptr);
+			if (bind_data.sources[0].c.has_sample_subset) {
+				state->subsets.back() = make_uniq<DeviceSubset>(
+				    *state->datasets.back(), bind_data.sources[0].c.sample_subset->sample_include, "read_pfile");
+			}
 		}
 	}
 	return std::move(state);
@@ -337,70 +427,71 @@ static unique_ptr<LocalTableFunctionState> PfileInitLocal(ExecutionContext &cont
 	auto &bind_data = input.bind_data->Cast<PfileBindData>();
 	auto state = make_uniq<PfileLocalState>();
 	if (!bind_data.sample_orient) {
-		TableFunctionInitInput inner = input;
-		inner.bind_data = bind_data.variant_bind.get();
-		state->variant_state = PgenInitLocal(context, inner, global_state->Cast<PfileGlobalState>().variant_state.get());
+		auto &gstate = global_state->Cast<PfileGlobalState>();
+		for (size_t i = 0; i < bind_data.sources.size(); i++) {
+			TableFunctionInitInput inner = input;
+			inner.bind_data = bind_data.sources[i].variant_bind.get();
+			state->variant_states.push_back(PgenInitLocal(context, inner, gstate.variant_states[i].get()));
+		}
 	}
 	return std::move(state);
 }
 
-//! Phase 1: the effective variants (region, variants, af/ac filters) and every sample's tallies.
+//! Phase 1: per source, the effective variants (region, variants, af/ac filters) and every sample's
+//! tallies over them; the sources share their samples, so the tallies simply add.
 static void RunSamplePhase1(const PfileBindData &bind_data, PfileGlobalState &gstate) {
-	const auto &c = bind_data.c;
-	pgh_dataset *ds = gstate.dataset->handle;
-	pgh_subset *ss = gstate.subset ? gstate.subset->handle : nullptr;
 	char errbuf[PGH_ERRBUF_LEN] = {0};
-	vector<uint32_t> list;
-	if (bind_data.has_variant_list) {
-		for (auto v : bind_data.variant_indices) {
-			if (!c.variant_range.has_filter || (v >= c.RangeStart() && v < c.RangeEnd())) {
-				list.push_back(v);
-			}
-		}
-	}
-	const bool listed = bind_data.has_variant_list;
-	uint32_t begin = c.RangeStart(), n_var = listed ? static_cast<uint32_t>(list.size()) : c.RangeEnd() - c.RangeStart();
-	if (bind_data.count_filter.HasFilter() && n_var) {
-		// per-variant tallies of the candidates decide which of them stay
-		vector<uint32_t> vc(4 * static_cast<size_t>(n_var));
-		vector<uint32_t> kept;
-		auto consider = [&](uint32_t v, const uint32_t *gc) {
-			GenotypeRangeFilter none;
-			if (!CheckPreDecompFilters(bind_data.count_filter, none, gc, c.effective_sample_ct).skip) {
-				kept.push_back(v);
-			}
-		};
+	vector<uint32_t> part(gstate.counts.size());
+	gstate.effective_variants = 0;
+	for (size_t si = 0; si < bind_data.sources.size(); si++) {
+		const auto &src = bind_data.sources[si];
+		const auto &c = src.c;
+		pgh_dataset *ds = gstate.datasets[si]->handle;
+		pgh_subset *ss = gstate.subsets[si] ? gstate.subsets[si]->handle : nullptr;
+		vector<uint32_t> list;
+		bool listed = src.has_variant_list;
 		if (listed) {
-			for (uint32_t i = 0; i < n_var; i++) {
-				if (pgh_counts_range(ds, ss, list[i], list[i] + 1, reinterpret_cast<uint32_t(*)[4]>(vc.data() + 4 * i),
-				                     errbuf) != PGH_OK) {
-					throw IOException("read_pfile: PgrGetCounts failed for variant %u: %s", list[i], string(errbuf));
+			for (auto v : src.variant_indices) {
+				if (!c.variant_range.has_filter || (v >= c.RangeStart() && v < c.RangeEnd())) {
+					list.push_back(v);
 				}
-				consider(list[i], vc.data() + 4 * i);
 			}
-		} else {
-			if (pgh_counts_range(ds, ss, begin, begin + n_var, reinterpret_cast<uint32_t(*)[4]>(vc.data()), errbuf) !=
-			    PGH_OK) {
-				throw IOException("read_pfile: PgrGetCounts failed for variants [%u, %u): %s", begin, begin + n_var,
-				                  string(errbuf));
+		}
+		const uint32_t begin = c.RangeStart();
+		uint32_t n_var = listed ? static_cast<uint32_t>(list.size()) : c.RangeEnd() - c.RangeStart();
+		if (bind_data.count_filter.HasFilter() && n_var) {
+			// per-variant tallies of the candidates decide which of them stay
+			vector<uint32_t> vc(4 * static_cast<size_t>(n_var));
+			vector<uint32_t> kept;
+			const GenotypeRangeFilter none;
+			auto consider = [&](uint32_t v, const uint32_t *gc) {
+				if (!CheckPreDecompFilters(bind_data.count_filter, none, gc, bind_data.sources[0].c.effective_sample_ct)
+				         .skip) {
+					kept.push_back(v);
+				}
+			};
+			for (uint32_t i = 0; i < (listed ? n_var : 1u); i++) {
+				const uint32_t v0 = listed ? list[i] : begin, v1 = listed ? list[i] + 1 : begin + n_var;
+				if (pgh_counts_range(ds, ss, v0, v1, reinterpret_cast<uint32_t(*)[4]>(vc.data() + 4 * static_cast<size_t>(i)),
+				                     errbuf) != PGH_OK) {
+					throw IOException("read_pfile: PgrGetCounts failed for variants [%u, %u): %s", v0, v1, string(errbuf));
+				}
 			}
 			for (uint32_t i = 0; i < n_var; i++) {
-				consider(begin + i, vc.data() + 4 * i);
+				consider(listed ? list[i] : begin + i, vc.data() + 4 * static_cast<size_t>(i));
 			}
+			list.swap(kept);
+			listed = true;
+			n_var = static_cast<uint32_t>(list.size());
 		}
-		list.swap(kept);
-		n_var = static_cast<uint32_t>(list.size());
-		gstate.effective_variants = n_var;
-		if (pgh_sample_counts(ds, ss, 0, n_var, list.data(), reinterpret_cast<uint32_t(*)[4]>(gstate.counts.data()),
-		                      errbuf) != PGH_OK) {
-			throw IOException("read_pfile: PgrGet failed during sample-orient aggregation: %s", string(errbuf));
-		}
-	} else {
-		gstate.effective_variants = n_var;
 		if (pgh_sample_counts(ds, ss, listed ? 0 : begin, n_var, listed ? list.data() : nullptr,
-		                      reinterpret_cast<uint32_t(*)[4]>(gstate.counts.data()), errbuf) != PGH_OK) {
+		                      reinterpret_cast<uint32_t(*)[4]>(part.data()), errbuf) != PGH_OK) {
 			throw IOException("read_pfile: PgrGet failed during sample-orient aggregation: %s", string(errbuf));
 		}
+		for (size_t k = 0; k < part.size(); k++) {
+			gstate.counts[k] += part[k];
+		}
+		gstate.effective_variants += n_var;
 	}
 	if (bind_data.genotype_filter.active) {
 		// keep a sample if any of its calls is allowed (src/pfile_reader.cpp:3452-3462)
@@ -423,90 +514,90 @@ static void PfileScan(ClientContext &context, TableFunctionInput &data_p, DataCh
 	auto &bind_data = data_p.bind_data->Cast<PfileBindData>();
 	auto &gstate = data_p.global_state->Cast<PfileGlobalState>();
 	if (!bind_data.sample_orient) {
-		TableFunctionInput inner = data_p;
-		inner.bind_data = bind_data.variant_bind.get();
-		inner.global_state = gstate.variant_state.get();
-		inner.local_state = data_p.local_state->Cast<PfileLocalState>().variant_state.get();
-		PgenScan(context, inner, output);
+		// drain the sources in list order; a thread moves on when the source has nothing left for it
+		auto &lstate = data_p.local_state->Cast<PfileLocalState>();
+		while (lstate.current < bind_data.sources.size()) {
+			TableFunctionInput inner = data_p;
+			inner.bind_data = bind_data.sources[lstate.current].variant_bind.get();
+			inner.global_state = gstate.variant_states[lstate.current].get();
+			inner.local_state = lstate.variant_states[lstate.current].get();
+			PgenScan(context, inner, output);
+			if (output.size() > 0) {
+				return;
+			}
+			lstate.current++;
+			output.Reset();
+		}
+		CompatSetOutputCardinality(output, 0);
 		return;
 	}
-	if (gstate.dataset) {
+	if (!gstate.datasets.empty()) {
 		std::lock_guard<std::mutex> lock(gstate.phase1_mutex);
 		if (!gstate.phase1_done) {
 			RunSamplePhase1(bind_data, gstate);
 			gstate.phase1_done = true;
 		}
 	}
-	const auto &info = bind_data.c.sample_info;
+	const auto &info = bind_data.sources[0].c.sample_info;
 	const uint32_t total = gstate.use_keep ? static_cast<uint32_t>(gstate.keep.size())
 	                                       : static_cast<uint32_t>(bind_data.output_samples.size());
-	idx_t rows = 0;
-	while (rows < STANDARD_VECTOR_SIZE) {
-		uint32_t claim = static_cast<uint32_t>(std::min<idx_t>(128, STANDARD_VECTOR_SIZE - rows));
-		uint32_t first = gstate.next_idx.fetch_add(claim);
-		if (first >= total) {
-			break;
+	// a run of output rows per call, one loop per projected column
+	const uint32_t first = gstate.next_idx.fetch_add(STANDARD_VECTOR_SIZE);
+	const idx_t n_rows = first < total ? std::min<idx_t>(STANDARD_VECTOR_SIZE, total - first) : 0;
+	auto position = [&](idx_t r) { return gstate.use_keep ? gstate.keep[first + r] : first + static_cast<uint32_t>(r); };
+	for (idx_t out_col = 0; out_col < gstate.column_ids.size(); out_col++) {
+		const auto file_col = gstate.column_ids[out_col];
+		if (file_col == COLUMN_IDENTIFIER_ROW_ID) {
+			continue;
 		}
-		uint32_t last = std::min(first + claim, total);
-		for (uint32_t idx = first; idx < last; idx++, rows++) {
-			const uint32_t pos = gstate.use_keep ? gstate.keep[idx] : idx;
-			const uint32_t file_idx = bind_data.output_samples[pos];
-			for (idx_t out_col = 0; out_col < gstate.column_ids.size(); out_col++) {
-				auto file_col = gstate.column_ids[out_col];
-				if (file_col == COLUMN_IDENTIFIER_ROW_ID) {
-					continue;
-				}
-				auto &vec = output.data[out_col];
-				if (file_col < bind_data.genotypes_col) {
-					// FillSampleMetadataValue (src/pfile_reader.cpp:2846-2885)
-					const auto &row = info.rows[file_idx];
-					const string val = file_col < row.size() ? row[file_col] : string();
-					if (file_col == bind_data.sex_col) {
-						int32_t sex = 0;
-						if (!PsamMissing(val)) {
-							char *end = nullptr;
-							long parsed = std::strtol(val.c_str(), &end, 10);
-							sex = end != val.c_str() ? static_cast<int32_t>(parsed) : 0;
-						}
-						if (sex == 0) {
-							FlatVector::SetNull(vec, rows, true);
-						} else {
-							FlatVector::GetData<int32_t>(vec)[rows] = sex;
-						}
-						continue;
-					}
-					bool is_parent = std::find(bind_data.parent_cols.begin(), bind_data.parent_cols.end(), file_col) !=
-					                 bind_data.parent_cols.end();
-					if (PsamMissing(val) || (is_parent && val == "0")) {
-						FlatVector::SetNull(vec, rows, true);
+		auto &vec = output.data[out_col];
+		if (file_col < bind_data.genotypes_col) {
+			// FillSampleMetadataValue (src/pfile_reader.cpp:2846-2885): SEX is an integer with 0 / NA -> NULL,
+			// PAT / MAT "0" -> NULL, the usual missing tokens -> NULL
+			const bool is_sex = file_col == bind_data.sex_col;
+			const bool is_parent = std::find(bind_data.parent_cols.begin(), bind_data.parent_cols.end(), file_col) !=
+			                       bind_data.parent_cols.end();
+			for (idx_t r = 0; r < n_rows; r++) {
+				const auto &fields = info.rows[bind_data.output_samples[position(r)]];
+				const string val = file_col < fields.size() ? fields[file_col] : string();
+				if (is_sex) {
+					char *end = nullptr;
+					const long parsed = PsamMissing(val) ? 0 : std::strtol(val.c_str(), &end, 10);
+					if (parsed == 0 || end == val.c_str()) {
+						FlatVector::SetNull(vec, r, true);
 					} else {
-						FlatVector::GetData<string_t>(vec)[rows] = StringVector::AddString(vec, val);
+						FlatVector::GetData<int32_t>(vec)[r] = static_cast<int32_t>(parsed);
 					}
-					continue;
-				}
-				const uint32_t *sc = gstate.counts.data() + 4 * static_cast<size_t>(pos);
-				auto &entries = StructVector::GetEntries(vec);
-				for (int k = 0; k < 4; k++) {
-					FlatVector::GetData<uint32_t>(*entries[k])[rows] = sc[k];
-				}
-				if (bind_data.genotype_mode == GenotypeMode::STATS) {
-					const double nan = std::numeric_limits<double>::quiet_NaN();
-					const uint32_t n = sc[0] + sc[1] + sc[2];
-					const uint32_t all = n + sc[3];
-					FlatVector::GetData<uint32_t>(*entries[4])[rows] = n;
-					const double af = n ? (static_cast<double>(sc[1]) + 2.0 * sc[2]) / (2.0 * n) : nan;
-					FlatVector::GetData<double>(*entries[5])[rows] = af;
-					FlatVector::GetData<double>(*entries[6])[rows] = n ? std::min(af, 1.0 - af) : nan;
-					FlatVector::GetData<double>(*entries[7])[rows] =
-					    all ? static_cast<double>(sc[3]) / static_cast<double>(all) : nan;
-					FlatVector::GetData<uint32_t>(*entries[8])[rows] = sc[1] + sc[2];
-					FlatVector::GetData<double>(*entries[9])[rows] =
-					    n ? static_cast<double>(sc[1]) / static_cast<double>(n) : nan;
+				} else if (PsamMissing(val) || (is_parent && val == "0")) {
+					FlatVector::SetNull(vec, r, true);
+				} else {
+					FlatVector::GetData<string_t>(vec)[r] = StringVector::AddString(vec, val);
 				}
 			}
+			continue;
+		}
+		auto &entries = StructVector::GetEntries(vec);
+		const double nan = std::numeric_limits<double>::quiet_NaN();
+		for (idx_t r = 0; r < n_rows; r++) {
+			const uint32_t *sc = gstate.counts.data() + 4 * static_cast<size_t>(position(r));
+			for (int k = 0; k < 4; k++) {
+				FlatVector::GetData<uint32_t>(*entries[k])[r] = sc[k];
+			}
+			if (bind_data.genotype_mode != GenotypeMode::STATS) {
+				continue;
+			}
+			const uint32_t n = sc[0] + sc[1] + sc[2];
+			const uint32_t all = n + sc[3];
+			const double af = n ? (static_cast<double>(sc[1]) + 2.0 * sc[2]) / (2.0 * n) : nan;
+			FlatVector::GetData<uint32_t>(*entries[4])[r] = n;
+			FlatVector::GetData<double>(*entries[5])[r] = af;
+			FlatVector::GetData<double>(*entries[6])[r] = n ? std::min(af, 1.0 - af) : nan;
+			FlatVector::GetData<double>(*entries[7])[r] = all ? static_cast<double>(sc[3]) / static_cast<double>(all) : nan;
+			FlatVector::GetData<uint32_t>(*entries[8])[r] = sc[1] + sc[2];
+			FlatVector::GetData<double>(*entries[9])[r] = n ? static_cast<double>(sc[1]) / static_cast<double>(n) : nan;
 		}
 	}
-	CompatSetOutputCardinality(output, rows);
+	CompatSetOutputCardinality(output, n_rows);
 }
 
 void RegisterPfileReader(ExtensionLoader &loader) {

@@ -198,6 +198,37 @@ def test_plink_ld_bind_errors():
     assert r.all_names == ["CHROM_A", "POS_A", "ID_A", "CHROM_B", "POS_B", "ID_B", "R2", "D_PRIME", "OBS_CT"]
 
 
+def test_read_pfile_file_lists_bind():
+    """read_pfile_list.test, read_pfile_list_shards.test sections 1, 5, 7 (variants), 8: metadata only, no device."""
+    PFX = data_path("pgen_example")
+    assert len(F.query("read_pfile", [PFX, PFX], columns=["ID"])) == 8
+    assert len(set(F.query("read_pfile", [PFX, PFX], columns=["POS"]).column("POS"))) == 4
+    assert len(F.query("read_pfile", [PFX], columns=["ID"])) == 4
+    shards = [data_path("shard%d" % i) for i in (1, 2, 3)]
+    whole = data_path("large_example")
+    for threads in (1, 4):
+        got = F.query("read_pfile", shards, columns=["CHROM", "POS", "ID"], threads=threads)
+        assert sorted(got.rows) == sorted(F.query("read_pfile", whole, columns=["CHROM", "POS", "ID"]).rows)
+    got = F.query("read_pfile", shards, region="1:5000-50000", columns=["CHROM", "ID"])
+    assert len(got) == 451 and set(got.column("CHROM")) == {"1"}
+    assert sorted(got.column("ID")) == sorted(F.query("read_pfile", whole, region="1:5000-50000", columns=["ID"]).column("ID"))
+    r = F.query("read_pfile", [whole, data_path("streaming_example")], columns=["CHROM"])
+    assert len(r) == 53000 and len(set(r.column("CHROM"))) == 3
+    assert len(F.query("read_pfile", shards[0], variants=[0, 1], columns=["ID"])) == 2
+    assert len(F.query("read_pfile", shards[:1], columns=["ID"])) == 1000
+    # a psam override applies to every shard
+    assert len(F.query("read_pfile", shards, psam=shards[0] + ".psam", columns=["ID"])) == 3000
+    assert "sample count mismatch across files" in err("read_pfile", [PFX, whole])
+    assert "sample count mismatch across files" in err("read_pfile", [shards[0], PFX], orient="sample", genotypes="counts")
+    assert "overrides cannot be combined with a multi-file list" in err("read_pfile", [PFX, PFX], pvar=PFX + ".pvar")
+    assert "overrides cannot be combined with a multi-file list" in err("read_pfile", [PFX, PFX], pgen=PFX + ".pgen")
+    assert "variants := [...] with a multi-file list is not yet supported" in err("read_pfile", shards[:2], variants=["var1"])
+    assert "not yet supported" in err("read_pfile", shards[:2], variants=[0, 1])
+    assert "empty file list provided" in err("read_pfile", [])
+    assert "cannot find .pgen file for prefix '%s'" % data_path("does_not_exist") in err(
+        "read_pfile", [shards[0], data_path("does_not_exist")])
+
+
 def test_read_pfile_bind():
     PFX = data_path("pgen_example")
     r = F.query("read_pfile", PFX, columns=["ID", "POS"])
@@ -213,7 +244,8 @@ def test_read_pfile_bind():
     assert sorted(s.rows) == [(f"SAMPLE{i}", None) for i in range(1, 5)]
     assert F.query("read_pfile", PFX, orient="sample", genotypes="stats", columns=["IID"]).all_names[-1] == "genotypes"
     assert "cannot find .pgen file for prefix" in err("read_pfile", data_path("no_such_prefix"))
-    assert "no .pgen file path provided" in err("read_pfile", None)
+    assert "no .pgen file path provided" in err("read_pfile", "")
+    assert "empty file list provided" in err("read_pfile", None)  # null_list_params.test:30-33
     assert "invalid orient value" in err("read_pfile", PFX, orient="diagonal")
     assert "not compatible with orient := 'genotype'" in err("read_pfile", PFX, orient="genotype", genotypes="counts")
     assert "incompatible with phased" in err("read_pfile", PFX, orient="sample", genotypes="counts", phased=True)
@@ -221,7 +253,6 @@ def test_read_pfile_bind():
     assert "dosages and phased cannot both be true" in err("read_pfile", PFX, dosages=True, phased=True)
     assert "read_pfile: invalid genotypes value" in err("read_pfile", PFX, genotypes="matrix")
     assert "not available in this build" in err("read_pfile", PFX, orient="sample")
-    assert "not available in this build" in err("read_pfile", [PFX, PFX])
     assert "Invalid named parameter" in err("read_pgen", EX, region="1:1-2", exc=F.BinderException)
     # read_pfile_negative.test:113-131 and the open forms of its region grammar
     assert "invalid region" in err("read_pfile", PFX, region="invalid:abc-def")

@@ -613,6 +613,56 @@ def test_read_pfile_variant_orient_is_the_read_pgen_scan():
     assert len(big) == 1000 and set(big.column("CHROM")) == {"2"}
 
 
+@pytest.mark.parametrize("threads", [1, 4])
+def test_read_pfile_shards_reproduce_the_whole_file(threads):
+    """read_pfile_list_shards.test sections 2, 4, 5, 6, 7 and read_pfile_list.test: three variant-disjoint
+    shards of large_example, read as a list, give the whole file's rows in every genotype mode."""
+    shards = [data_path("shard%d" % i) for i in (1, 2, 3)]
+    whole = data_path("large_example")
+    for kw in ({}, {"genotypes": "list"}, {"genotypes": "counts"}, {"genotypes": "stats"}, {"dosages": True},
+               {"phased": True}, {"region": "1:5000-50000"}, {"samples": ["SAMP7", "SAMP2"]},
+               {"psam": shards[1] + ".psam", "genotypes": "counts"}):
+        mf = F.query("read_pfile", shards, columns=["ID", "genotypes"], threads=threads, **kw)
+        wf = F.query("read_pfile", whole, columns=["ID", "genotypes"], threads=threads, **kw)
+        assert len(mf) == len(wf) == (451 if "region" in kw else 3000), kw
+        assert sorted(mf.rows, key=lambda r: r[0]) == sorted(wf.rows, key=lambda r: r[0]), kw
+    cols = ["ID"] + ["SAMP%d" % i for i in range(1, 9)]
+    mf = F.query("read_pfile", shards, genotypes="columns", columns=cols, threads=threads)
+    wf = F.query("read_pfile", whole, genotypes="columns", columns=cols, threads=threads)
+    assert len(mf) == 3000 and sorted(mf.rows) == sorted(wf.rows)
+    # filters fire on every shard (AF = 0.5, AC = 6 throughout this fixture)
+    for kw, n in (({"af_range": {"max": 0.5}}, 3000), ({"af_range": {"min": 0.6}}, 0),
+                  ({"ac_range": {"min": 2, "max": 10}}, 3000), ({"ac_range": {"min": 12}}, 0)):
+        assert len(F.query("read_pfile", shards, columns=["ID", "genotypes"], threads=threads, **kw)) == n, kw
+    # the same file twice: every row twice, values intact across the source boundary
+    ex = data_path("pgen_example")
+    twice = F.query("read_pfile", [ex, ex], columns=["ID", "genotypes"], threads=threads)
+    once = F.query("read_pfile", ex, columns=["ID", "genotypes"])
+    assert sorted(twice.rows) == sorted(once.rows + once.rows)
+    assert len(F.query("read_pfile", [ex, ex], genotypes="columns", columns=["SAMPLE1"], threads=threads)) == 8
+    assert len(F.query("read_pfile", [ex, ex], af_range={"max": 0.5}, columns=["genotypes"], threads=threads)) == 8
+    big2 = F.query("read_pfile", [whole, whole], genotypes="counts", columns=["ID", "genotypes"], threads=threads)
+    one = dict(F.query("read_pfile", whole, genotypes="counts", columns=["ID", "genotypes"]).rows)
+    assert len(big2) == 6000 and all(g is not None and g == one[i] for i, g in big2.rows)
+
+
+def test_read_pfile_sample_orient_counts_add_up_over_shards():
+    """read_pfile_list.test:97-107 for the aggregate modes: the sources' variants concatenate, so every
+    sample's tallies over the shards are its tallies over the whole file."""
+    shards = [data_path("shard%d" % i) for i in (1, 2, 3)]
+    whole = data_path("large_example")
+    for kw in ({"genotypes": "counts"}, {"genotypes": "stats"}, {"genotypes": "counts", "region": "1:5000-50000"},
+               {"genotypes": "counts", "samples": ["SAMP7", "SAMP2"]}, {"genotypes": "counts", "af_range": {"max": 0.5}},
+               {"genotypes": "counts", "af_range": {"min": 0.6}}, {"genotypes": "counts", "include_genotypes": ["missing"]}):
+        mf = F.query("read_pfile", shards, orient="sample", columns=["IID", "genotypes"], threads=3, **kw)
+        wf = F.query("read_pfile", whole, orient="sample", columns=["IID", "genotypes"], **kw)
+        assert sorted(mf.rows, key=lambda r: r[0]) == sorted(wf.rows, key=lambda r: r[0]), kw
+    ex = data_path("pgen_example")
+    twice = dict(F.query("read_pfile", [ex, ex], orient="sample", genotypes="counts", columns=["IID", "genotypes"]).rows)
+    once = dict(F.query("read_pfile", ex, orient="sample", genotypes="counts", columns=["IID", "genotypes"]).rows)
+    assert len(twice) == 4 and all({k: 2 * v for k, v in once[i].items()} == twice[i] for i in once)
+
+
 # ---- every function over a file that spans several device batches, against the C ABI ---------------
 
 @pytest.fixture(scope="module")
