@@ -206,6 +206,31 @@ int pgh_score_run_dev(const pgh_score_plan *plan, void *d_score_sum, void *d_dos
                       void *stream, char *errbuf);
 void pgh_score_plan_destroy(pgh_score_plan *plan);
 
+/* ---- dosage tracks ------------------------------------------------------------
+ * A file's explicit dosages (vrtype bits 0x20 / 0x40 / 0x60) are brought to one resident form at
+ * pgh_open: a presence bit per sample and the present samples' uint16 values, 16384 per ALT copy.
+ * A sample without an explicit dosage takes its hardcall (0 / 16384 / 32768); one with neither is
+ * missing.  pgh_score scores dosage-bearing variants from these values as the reference does
+ * through PgrGetD (src/plink_score.cpp:586-652).
+ *
+ * pgh_dosage_sums: PgrGetDCounts (src/plink_freq.cpp:475-480, :525-535): per variant
+ *   sums[i] = {sum of dosages, sum of squared dosages, samples with a dosage or a call}
+ * on the 16384 scale over the included samples: alt dosage sum = sums[0], ref = 2*16384*sums[2] - sums[0],
+ * MaCH r2 from the first two moments.  Variants: [variant_begin, variant_begin + n_variants), or the
+ * n_variants listed in vidx when vidx != NULL.
+ *
+ * pgh_dosage_unpack: PgrGetD + Dosage16ToDoublesMinus9 (src/pgen_reader.cpp:694-705): out[i][k] =
+ * dosage of output sample k at variant i as a double, -9.0 when missing; rows of n_out doubles. */
+int pgh_dosage_sums(const pgh_dataset *ds, const pgh_subset *subset, uint32_t variant_begin, uint32_t n_variants,
+                    const uint32_t *vidx, uint64_t (*sums)[3], char *errbuf);
+int pgh_dosage_unpack(const pgh_dataset *ds, const pgh_subset *subset, uint32_t variant_begin, uint32_t n_variants,
+                      const uint32_t *vidx, double *out, char *errbuf);
+/* Enqueue-only forms over [v_begin, v_end): d_sums = uint64[n][3]; d_out = double rows of out_stride elements. */
+int pgh_dosage_sums_dev(const pgh_dataset *ds, const pgh_subset *subset, uint32_t v_begin, uint32_t v_end,
+                        void *d_sums, void *stream, char *errbuf);
+int pgh_dosage_unpack_dev(const pgh_dataset *ds, const pgh_subset *subset, uint32_t v_begin, uint32_t v_end,
+                          void *d_out, size_t out_stride, void *stream, char *errbuf);
+
 /* read_pfile's sample-orient aggregate (src/pfile_reader.cpp:3308-3400, the streaming
  * accumulate_dense loop): counts[k] = {hom_ref, het, hom_alt, missing} of output sample k over
  * the variants [variant_begin, variant_begin + n_var) or, with vidx != NULL, the n_var listed
@@ -282,7 +307,8 @@ int pgh_get_counts(pgh_reader *rd, uint32_t vidx, uint32_t out[4]);
 int pgh_get_missingness(pgh_reader *rd, uint32_t vidx, uint64_t *bits);
 /* PgrGet + GenoarrToBytesMinus9 (src/plink_freq.cpp:463-469): {0,1,2,-9}. */
 int pgh_get_int8(pgh_reader *rd, uint32_t vidx, int8_t *out);
-/* PgrGetD + Dosage16ToDoublesMinus9 (src/plink_score.cpp:586-596): -9.0 = missing. */
+/* PgrGetD + Dosage16ToDoublesMinus9 (src/plink_score.cpp:586-596): -9.0 = missing.  One row of
+ * pgh_dosage_unpack through the reader's stream. */
 int pgh_get_dosage_f64(pgh_reader *rd, uint32_t vidx, double *out);
 /* PgrGetP (src/pgen_reader.cpp:715): genovec as pgh_get_2bit plus the
  * phasepresent / phaseinfo bitarrays (ceil(n_out/64) words each, zero for

@@ -279,22 +279,148 @@ extern "C" int pgh_unpack_range(const pgh_dataset *ds, const pgh_subset *subset,
 }
 
 // ---------------------------------------------------------------------------
+// dosage tracks
+// ---------------------------------------------------------------------------
+
+//! Local variant indices of [v_begin, v_begin + n) or of vidx[0..n) on the device; NULL when the run is contiguous.
+static int UploadVariantList(const pgh_dataset *ds, uint32_t v_begin, uint32_t n, const uint32_t *vidx, DevBuf &d_list,
+                             hipStream_t st, std::vector<uint32_t> &local, char *errbuf) {
+	if (!vidx) {
+		return CheckRange(ds, v_begin, v_begin + n, errbuf);
+	}
+	local.resize(n);
+	for (uint32_t i = 0; i < n; i++) {
+		if (vidx[i] < ds->v_begin || vidx[i] >= ds->v_end) {
+			SetErr(errbuf, "variant index outside the resident range");
+			return PGH_ERR_ARG;
+		}
+		local[i] = vidx[i] - ds->v_begin;
+	}
+	PGH_HIP(d_list.Alloc(sizeof(uint32_t) * n), "hipMalloc(variant list)");
+	PGH_HIP(hipMemcpyAsync(d_list.p, local.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, st), "variant list upload");
+	return PGH_OK;
+}
+
+extern "C" int pgh_dosage_sums_dev(const pgh_dataset *ds, const pgh_subset *subset, uint32_t v_begin, uint32_t v_end,
+                                   void *d_sums, void *stream, char *errbuf) {
+	int rc = CheckRange(ds, v_begin, v_end, errbuf);
+	if (rc == PGH_OK) {
+		rc = CheckSubset(ds, subset, errbuf);
+	}
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	if (!d_sums && v_end > v_begin) {
+		SetErr(errbuf, "null argument");
+		return PGH_ERR_ARG;
+	}
+	PGH_HIP(pgh::LaunchDosageSums(ds->View(), ds->Dosage(), v_begin - ds->v_begin, nullptr, v_end - v_begin,
+	                              subset ? subset->d_include : nullptr, static_cast<uint64_t *>(d_sums),
+	                              static_cast<hipStream_t>(stream)),
+	        "dosage sums kernel");
+	return PGH_OK;
+}
+
+extern "C" int pgh_dosage_sums(const pgh_dataset *ds, const pgh_subset *subset, uint32_t variant_begin,
+                               uint32_t n_variants, const uint32_t *vidx, uint64_t (*sums)[3], char *errbuf) {
+	if (!ds || (n_variants && !sums)) {
+		SetErr(errbuf, "null argument");
+		return PGH_ERR_ARG;
+	}
+	int rc = CheckSubset(ds, subset, errbuf);
+	if (rc != PGH_OK || n_variants == 0) {
+		return rc;
+	}
+	hipStream_t st = hipStreamPerThread;
+	DevBuf d_list, d_sums;
+	std::vector<uint32_t> local;
+	rc = UploadVariantList(ds, variant_begin, n_variants, vidx, d_list, st, local, errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	PGH_HIP(d_sums.Alloc(24ull * n_variants), "hipMalloc(dosage sums)");
+	PGH_HIP(pgh::LaunchDosageSums(ds->View(), ds->Dosage(), vidx ? 0 : variant_begin - ds->v_begin, d_list.As<uint32_t>(),
+	                              n_variants, subset ? subset->d_include : nullptr, d_sums.As<uint64_t>(), st),
+	        "dosage sums kernel");
+	PGH_HIP(hipMemcpyAsync(sums, d_sums.p, 24ull * n_variants, hipMemcpyDeviceToHost, st), "dosage sums copy");
+	PGH_HIP(hipStreamSynchronize(st), "dosage sums sync");
+	return PGH_OK;
+}
+
+extern "C" int pgh_dosage_unpack_dev(const pgh_dataset *ds, const pgh_subset *subset, uint32_t v_begin, uint32_t v_end,
+                                     void *d_out, size_t out_stride, void *stream, char *errbuf) {
+	int rc = CheckRange(ds, v_begin, v_end, errbuf);
+	if (rc == PGH_OK) {
+		rc = CheckSubset(ds, subset, errbuf);
+	}
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	const uint32_t n_out = subset ? subset->n_out : ds->sample_ct;
+	if (v_end > v_begin && (!d_out || out_stride < n_out)) {
+		SetErr(errbuf, "out_stride must cover the row");
+		return PGH_ERR_ARG;
+	}
+	PGH_HIP(pgh::LaunchDosageUnpack(ds->View(), ds->Dosage(), v_begin - ds->v_begin, nullptr, v_end - v_begin,
+	                                subset ? subset->d_sel : nullptr, n_out, static_cast<double *>(d_out), out_stride,
+	                                static_cast<hipStream_t>(stream)),
+	        "dosage unpack kernel");
+	return PGH_OK;
+}
+
+extern "C" int pgh_dosage_unpack(const pgh_dataset *ds, const pgh_subset *subset, uint32_t variant_begin,
+                                 uint32_t n_variants, const uint32_t *vidx, double *out, char *errbuf) {
+	if (!ds || (n_variants && !out)) {
+		SetErr(errbuf, "null argument");
+		return PGH_ERR_ARG;
+	}
+	int rc = CheckSubset(ds, subset, errbuf);
+	const uint32_t n_out = subset ? subset->n_out : ds->sample_ct;
+	if (rc != PGH_OK || n_variants == 0 || n_out == 0) {
+		return rc;
+	}
+	hipStream_t st = hipStreamPerThread;
+	DevBuf d_list, d_out;
+	std::vector<uint32_t> local;
+	rc = UploadVariantList(ds, variant_begin, n_variants, vidx, d_list, st, local, errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	// 8 bytes per sample leave the device: chunk the run so the staging stays bounded
+	const uint32_t chunk = static_cast<uint32_t>(std::min<uint64_t>(n_variants, std::max<uint64_t>(1, (512ull << 20) / (8ull * n_out))));
+	PGH_HIP(d_out.Alloc(8ull * chunk * n_out), "hipMalloc(dosage unpack)");
+	for (uint32_t r0 = 0; r0 < n_variants; r0 += chunk) {
+		const uint32_t cnt = std::min(chunk, n_variants - r0);
+		PGH_HIP(pgh::LaunchDosageUnpack(ds->View(), ds->Dosage(), vidx ? 0 : variant_begin - ds->v_begin + r0,
+		                                vidx ? d_list.As<uint32_t>() + r0 : nullptr, cnt, subset ? subset->d_sel : nullptr,
+		                                n_out, d_out.As<double>(), n_out, st),
+		        "dosage unpack kernel");
+		PGH_HIP(hipMemcpyAsync(out + static_cast<uint64_t>(r0) * n_out, d_out.p, 8ull * cnt * n_out, hipMemcpyDeviceToHost, st),
+		        "dosage unpack copy");
+		PGH_HIP(hipStreamSynchronize(st), "dosage unpack sync");
+	}
+	return PGH_OK;
+}
+
+// ---------------------------------------------------------------------------
 // plink_score
 // ---------------------------------------------------------------------------
 
 struct pgh_score_plan {
 	const pgh_dataset *ds = nullptr;
 	uint32_t n_scored = 0, n_cols = 0;
+	uint32_t n_hard = 0; // the first n_hard entries have hardcalls only; the rest carry dosage tracks
 	int mode = 0;
 	void *d_vlist = nullptr, *d_weights = nullptr, *d_flip = nullptr, *d_counts = nullptr, *d_ts = nullptr,
-	     *d_td = nullptr, *d_ac = nullptr;
+	     *d_td = nullptr, *d_ac = nullptr, *d_lin = nullptr;
 };
 
 extern "C" void pgh_score_plan_destroy(pgh_score_plan *plan) {
 	if (!plan) {
 		return;
 	}
-	for (void *p : {plan->d_vlist, plan->d_weights, plan->d_flip, plan->d_counts, plan->d_ts, plan->d_td, plan->d_ac}) {
+	for (void *p : {plan->d_vlist, plan->d_weights, plan->d_flip, plan->d_counts, plan->d_ts, plan->d_td, plan->d_ac,
+	                plan->d_lin}) {
 		if (p) {
 			(void)hipFree(p);
 		}
@@ -330,37 +456,89 @@ extern "C" int pgh_score_plan_create(const pgh_dataset *ds, const pgh_subset *su
 		}
 		local[i] = vidx[i] - ds->v_begin;
 	}
+	// Variants that carry dosage tracks are scored by their own kernel (dosage.hip); they go to the back
+	// of the list so each kernel sees one contiguous run.  Per-sample sums do not depend on the order.
+	std::vector<uint32_t> order(n_scored);
+	uint32_t n_hard = n_scored;
+	if (ds->dos_rows) {
+		n_hard = 0;
+		for (uint32_t i = 0; i < n_scored; i++) {
+			if (ds->dos_row_of[local[i]] < 0) {
+				order[n_hard++] = i;
+			}
+		}
+		uint32_t at = n_hard;
+		for (uint32_t i = 0; i < n_scored; i++) {
+			if (ds->dos_row_of[local[i]] >= 0) {
+				order[at++] = i;
+			}
+		}
+	} else {
+		for (uint32_t i = 0; i < n_scored; i++) {
+			order[i] = i;
+		}
+	}
+	std::vector<uint32_t> p_local(n_scored);
+	std::vector<double> p_weights(static_cast<size_t>(n_scored) * n_cols);
+	std::vector<uint8_t> p_flip(flip ? n_scored : 0);
+	for (uint32_t k = 0; k < n_scored; k++) {
+		p_local[k] = local[order[k]];
+		std::memcpy(&p_weights[static_cast<size_t>(k) * n_cols], weights + static_cast<size_t>(order[k]) * n_cols,
+		            sizeof(double) * n_cols);
+		if (flip) {
+			p_flip[k] = flip[order[k]];
+		}
+	}
 	std::unique_ptr<pgh_score_plan, void (*)(pgh_score_plan *)> plan(new pgh_score_plan(), pgh_score_plan_destroy);
 	plan->ds = ds;
 	plan->n_scored = n_scored;
+	plan->n_hard = n_hard;
 	plan->n_cols = n_cols;
 	plan->mode = mode;
 	if (n_scored) {
 		const uint32_t N = ds->sample_ct;
+		const uint32_t n_dos = n_scored - n_hard;
 		hipStream_t st = hipStreamPerThread;
 		PGH_HIP(hipMalloc(&plan->d_vlist, sizeof(uint32_t) * n_scored), "hipMalloc(score)");
 		PGH_HIP(hipMalloc(&plan->d_weights, sizeof(double) * n_scored * n_cols), "hipMalloc(score)");
-		PGH_HIP(hipMalloc(&plan->d_counts, 16ull * n_scored), "hipMalloc(score)");
+		PGH_HIP(hipMalloc(&plan->d_counts, 24ull * n_scored), "hipMalloc(score)"); // counts[4] u32, or dosage sums[3] u64
 		PGH_HIP(hipMalloc(&plan->d_ts, 32ull * n_scored), "hipMalloc(score)");
 		PGH_HIP(hipMalloc(&plan->d_td, 32ull * n_scored), "hipMalloc(score)");
 		PGH_HIP(hipMalloc(&plan->d_ac, 4ull * n_scored), "hipMalloc(score)");
-		PGH_HIP(hipMemcpyAsync(plan->d_vlist, local.data(), sizeof(uint32_t) * n_scored, hipMemcpyHostToDevice, st),
+		PGH_HIP(hipMemcpyAsync(plan->d_vlist, p_local.data(), sizeof(uint32_t) * n_scored, hipMemcpyHostToDevice, st),
 		        "score upload");
-		PGH_HIP(hipMemcpyAsync(plan->d_weights, weights, sizeof(double) * n_scored * n_cols, hipMemcpyHostToDevice, st),
+		PGH_HIP(hipMemcpyAsync(plan->d_weights, p_weights.data(), sizeof(double) * n_scored * n_cols,
+		                       hipMemcpyHostToDevice, st),
 		        "score upload");
 		if (flip) {
 			PGH_HIP(hipMalloc(&plan->d_flip, n_scored), "hipMalloc(score)");
-			PGH_HIP(hipMemcpyAsync(plan->d_flip, flip, n_scored, hipMemcpyHostToDevice, st), "score upload");
+			PGH_HIP(hipMemcpyAsync(plan->d_flip, p_flip.data(), n_scored, hipMemcpyHostToDevice, st), "score upload");
 		}
 		// per-variant statistics and contribution tables depend on the data only: once per plan
-		PGH_HIP(pgh::LaunchCounts(ds->View(), 0, static_cast<uint32_t *>(plan->d_vlist), n_scored,
-		                          subset ? subset->d_mask2 : nullptr, subset ? subset->n_out : N,
-		                          static_cast<uint32_t *>(plan->d_counts), st),
-		        "score counts kernel");
-		PGH_HIP(pgh::LaunchScoreTables(static_cast<uint32_t *>(plan->d_counts), static_cast<uint8_t *>(plan->d_flip),
-		                               n_scored, mode, static_cast<double *>(plan->d_ts),
-		                               static_cast<double *>(plan->d_td), static_cast<uint32_t *>(plan->d_ac), st),
-		        "score table kernel");
+		uint32_t *vlist = static_cast<uint32_t *>(plan->d_vlist);
+		uint8_t *d_flip = static_cast<uint8_t *>(plan->d_flip);
+		if (n_hard) {
+			PGH_HIP(pgh::LaunchCounts(ds->View(), 0, vlist, n_hard, subset ? subset->d_mask2 : nullptr,
+			                          subset ? subset->n_out : N, static_cast<uint32_t *>(plan->d_counts), st),
+			        "score counts kernel");
+			PGH_HIP(pgh::LaunchScoreTables(static_cast<uint32_t *>(plan->d_counts), d_flip, n_hard, mode,
+			                               static_cast<double *>(plan->d_ts), static_cast<double *>(plan->d_td),
+			                               static_cast<uint32_t *>(plan->d_ac), st),
+			        "score table kernel");
+		}
+		if (n_dos) {
+			PGH_HIP(hipMalloc(&plan->d_lin, 32ull * n_dos), "hipMalloc(score)");
+			uint64_t *sums = reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(plan->d_counts) + 16ull * n_hard);
+			PGH_HIP(pgh::LaunchDosageSums(ds->View(), ds->Dosage(), 0, vlist + n_hard, n_dos,
+			                              subset ? subset->d_include : nullptr, sums, st),
+			        "dosage sums kernel");
+			PGH_HIP(pgh::LaunchScoreTablesDosage(sums, d_flip ? d_flip + n_hard : nullptr, n_dos, mode,
+			                                     static_cast<double *>(plan->d_ts) + 4ull * n_hard,
+			                                     static_cast<double *>(plan->d_td) + 4ull * n_hard,
+			                                     static_cast<double *>(plan->d_lin),
+			                                     static_cast<uint32_t *>(plan->d_ac) + n_hard, st),
+			        "score table kernel");
+		}
 		PGH_HIP(hipStreamSynchronize(st), "score plan sync"); // host staging vectors die with this frame
 	}
 	*out = plan.release();
@@ -384,37 +562,54 @@ extern "C" int pgh_score_run_dev(const pgh_score_plan *plan, void *d_score_sum, 
 		PGH_HIP(hipMemsetAsync(d_allele_ct, 0, sizeof(uint32_t) * N, st), "score memset");
 		return PGH_OK;
 	}
-	PGH_HIP(pgh::LaunchScoreAccumulate(ds->View(), static_cast<uint32_t *>(plan->d_vlist), plan->n_scored,
-	                                   static_cast<double *>(plan->d_weights), plan->n_cols,
-	                                   static_cast<double *>(plan->d_ts), static_cast<double *>(plan->d_td),
-	                                   static_cast<uint32_t *>(plan->d_ac),
-	                                   plan->mode != PGH_SCORE_CENTER && d_dosage_sum != nullptr,
-	                                   static_cast<double *>(d_score_sum), static_cast<double *>(d_dosage_sum),
-	                                   static_cast<uint32_t *>(d_allele_ct), st),
-	        "score accumulate kernel");
+	uint32_t *vlist = static_cast<uint32_t *>(plan->d_vlist);
+	double *weights = static_cast<double *>(plan->d_weights);
+	double *ts = static_cast<double *>(plan->d_ts);
+	uint32_t *ac = static_cast<uint32_t *>(plan->d_ac);
+	const uint32_t n_hard = plan->n_hard, n_dos = plan->n_scored - plan->n_hard;
+	if (n_hard) {
+		PGH_HIP(pgh::LaunchScoreAccumulate(ds->View(), vlist, n_hard, weights, plan->n_cols, ts,
+		                                   static_cast<double *>(plan->d_td), ac,
+		                                   plan->mode != PGH_SCORE_CENTER && d_dosage_sum != nullptr,
+		                                   static_cast<double *>(d_score_sum), static_cast<double *>(d_dosage_sum),
+		                                   static_cast<uint32_t *>(d_allele_ct), st),
+		        "score accumulate kernel");
+	}
 	// ALLELE_CT is integer bookkeeping: 2 per scored, non-skipped variant, minus 2 per such
 	// variant at which the sample is missing unless missing calls are mean-imputed
-	// (src/plink_score.cpp:632-651).
-	if (plan->mode == PGH_SCORE_MEAN_IMPUTE) {
-		PGH_HIP(pgh::LaunchAlleleCt(static_cast<uint32_t *>(plan->d_ac), plan->n_scored, nullptr, N,
-		                            static_cast<uint32_t *>(d_allele_ct), st),
-		        "allele count kernel");
-	} else {
-		const size_t scratch_bytes = pgh::MissingPerSampleScratchBytes(ds->record_bytes, plan->n_scored);
-		void *scratch = nullptr, *miss = nullptr;
+	// (src/plink_score.cpp:632-651).  Under a dosage track "missing" means no dosage and no call.
+	const bool count_missing = plan->mode != PGH_SCORE_MEAN_IMPUTE;
+	void *scratch = nullptr, *miss = nullptr;
+	hipError_t e = hipSuccess;
+	if (count_missing) {
+		const size_t scratch_bytes = pgh::MissingPerSampleScratchBytes(ds->record_bytes, std::max(n_hard, 1u));
+		const size_t miss_bytes = sizeof(uint32_t) * ((N + 63) / 64 * 64);
 		PGH_HIP(hipMallocAsync(&scratch, scratch_bytes ? scratch_bytes : 16, st), "score scratch");
-		PGH_HIP(hipMallocAsync(&miss, sizeof(uint32_t) * ((N + 63) / 64 * 64), st), "score scratch");
-		hipError_t e = pgh::LaunchMissingPerSample(ds->View(), 0, static_cast<uint32_t *>(plan->d_vlist),
-		                                           plan->n_scored, static_cast<uint32_t *>(plan->d_ac),
-		                                           static_cast<uint32_t *>(scratch), static_cast<uint32_t *>(miss), st);
-		if (e == hipSuccess) {
-			e = pgh::LaunchAlleleCt(static_cast<uint32_t *>(plan->d_ac), plan->n_scored, static_cast<uint32_t *>(miss),
-			                        N, static_cast<uint32_t *>(d_allele_ct), st);
+		PGH_HIP(hipMallocAsync(&miss, miss_bytes, st), "score scratch");
+		e = hipMemsetAsync(miss, 0, miss_bytes, st);
+		if (e == hipSuccess && n_hard) {
+			e = pgh::LaunchMissingPerSample(ds->View(), 0, vlist, n_hard, ac, static_cast<uint32_t *>(scratch),
+			                                static_cast<uint32_t *>(miss), st);
 		}
-		(void)hipFreeAsync(scratch, st);
-		(void)hipFreeAsync(miss, st);
-		PGH_HIP(e, "allele count kernels");
 	}
+	if (e == hipSuccess && n_dos) {
+		e = pgh::LaunchScoreDosage(ds->View(), ds->Dosage(), vlist + n_hard, n_dos,
+		                           weights + static_cast<uint64_t>(n_hard) * plan->n_cols, plan->n_cols, plan->n_cols,
+		                           ts + 4ull * n_hard, static_cast<double *>(plan->d_lin), ac + n_hard, plan->mode,
+		                           static_cast<double *>(d_score_sum), plan->n_cols, static_cast<double *>(d_dosage_sum),
+		                           static_cast<uint32_t *>(miss), st);
+	}
+	if (e == hipSuccess) {
+		e = pgh::LaunchAlleleCt(ac, plan->n_scored, static_cast<uint32_t *>(miss), N,
+		                        static_cast<uint32_t *>(d_allele_ct), st);
+	}
+	if (scratch) {
+		(void)hipFreeAsync(scratch, st);
+	}
+	if (miss) {
+		(void)hipFreeAsync(miss, st);
+	}
+	PGH_HIP(e, "score kernels");
 	return PGH_OK;
 }
 

@@ -193,6 +193,115 @@ static bool ExpandParallel(const pgh::PgenIndex &ix, const pgh::RecordFile &file
 	return true;
 }
 
+// Dosage tracks -> the resident bit-array form (dosage.hpp:DosageView).  The tracks are
+// parsed on the host, a few threads over chunks of variants (each worker owns a
+// Normalizer: finding a track means walking the record's main and phase tracks first);
+// presence bits and packed values go up chunk by chunk and the rank table is built on the
+// device.  Dense 0x40 tracks drop their 65535 "no dosage" entries, so downstream kernels
+// never meet that sentinel.
+static int LoadDosageTracks(pgh_dataset *ds, const pgh::RecordFile &file, char *errbuf) {
+	const PgenIndex &ix = ds->index;
+	const uint32_t range = ds->v_end - ds->v_begin;
+	const uint32_t N = ds->sample_ct;
+	const uint32_t words = (N + 63) / 64;
+	ds->dos_row_of.assign(range, -1);
+	uint64_t capacity = 0;
+	std::vector<uint32_t> carriers;
+	for (uint32_t i = 0; i < range; i++) {
+		const uint32_t v = ds->v_begin + i;
+		if (ix.vrtype[v] & 0x60) {
+			ds->dos_row_of[i] = static_cast<int32_t>(carriers.size());
+			carriers.push_back(v);
+			capacity += std::min<uint64_t>(N, (ix.offset[v + 1] - ix.offset[v]) / 2); // a value is two record bytes
+		}
+	}
+	if (carriers.empty()) {
+		ds->dos_row_of.clear();
+		return PGH_OK;
+	}
+	const uint32_t rows = static_cast<uint32_t>(carriers.size());
+	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_dos_row_of), sizeof(int32_t) * range), "hipMalloc(dosage)");
+	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_dos_present), 8ull * rows * words), "hipMalloc(dosage)");
+	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_dos_rank), 4ull * rows * words), "hipMalloc(dosage)");
+	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_dos_val_off), 8ull * rows), "hipMalloc(dosage)");
+	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_dos_values), 2 * std::max<uint64_t>(capacity, 8)),
+	        "hipMalloc(dosage)");
+	PGH_HIP(hipMemcpy(ds->d_dos_row_of, ds->dos_row_of.data(), sizeof(int32_t) * range, hipMemcpyHostToDevice),
+	        "dosage upload");
+	std::vector<uint64_t> val_off(rows);
+	uint64_t filled = 0;
+	const uint32_t chunk_rows = std::max<uint32_t>(8, static_cast<uint32_t>((64ull << 20) / (2ull * N + 8ull * words)));
+	const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+	std::vector<uint64_t> h_present;
+	std::vector<std::vector<uint16_t>> h_values;
+	std::vector<uint16_t> packed;
+	for (uint32_t r0 = 0; r0 < rows; r0 += chunk_rows) {
+		const uint32_t r1 = std::min(rows, r0 + chunk_rows);
+		const uint32_t cnt = r1 - r0;
+		h_present.assign(static_cast<size_t>(cnt) * words, 0);
+		h_values.assign(cnt, {});
+		const unsigned parts = std::min<unsigned>(std::min(8u, hw), std::max<uint32_t>(1, cnt / 8));
+		std::vector<std::thread> pool;
+		std::vector<std::string> errs(parts);
+		const uint32_t slice = (cnt + parts - 1) / parts;
+		for (unsigned t = 0; t < parts; t++) {
+			pool.emplace_back([&, t] {
+				pgh::Normalizer norm(ix, file);
+				std::vector<uint8_t> row2bit;
+				std::vector<uint16_t> dos16;
+				const uint32_t lo = std::min(cnt, t * slice), hi = std::min(cnt, lo + slice);
+				for (uint32_t k = lo; k < hi; k++) {
+					if (!norm.DecodeDosage(carriers[r0 + k], row2bit, dos16, errs[t])) {
+						return;
+					}
+					uint64_t *bits = h_present.data() + static_cast<size_t>(k) * words;
+					for (uint32_t s = 0; s < N; s++) {
+						if (dos16[s] != 0xffff) {
+							if (dos16[s] > 32768) {
+								errs[t] = "dosage above 2.0 in variant " + std::to_string(carriers[r0 + k]);
+								return;
+							}
+							bits[s >> 6] |= 1ull << (s & 63);
+							h_values[k].push_back(dos16[s]);
+						}
+					}
+				}
+			});
+		}
+		for (auto &th : pool) {
+			th.join();
+		}
+		for (auto &e : errs) {
+			if (!e.empty()) {
+				SetErr(errbuf, e);
+				return PGH_ERR_FORMAT;
+			}
+		}
+		packed.clear();
+		for (uint32_t k = 0; k < cnt; k++) {
+			val_off[r0 + k] = filled + packed.size();
+			packed.insert(packed.end(), h_values[k].begin(), h_values[k].end());
+		}
+		if (filled + packed.size() > std::max<uint64_t>(capacity, 8)) {
+			SetErr(errbuf, "dosage tracks hold more values than their records have bytes for");
+			return PGH_ERR_FORMAT;
+		}
+		PGH_HIP(hipMemcpy(ds->d_dos_present + static_cast<uint64_t>(r0) * words, h_present.data(), 8ull * cnt * words,
+		                  hipMemcpyHostToDevice),
+		        "dosage upload");
+		if (!packed.empty()) {
+			PGH_HIP(hipMemcpy(ds->d_dos_values + filled, packed.data(), 2 * packed.size(), hipMemcpyHostToDevice),
+			        "dosage upload");
+		}
+		filled += packed.size();
+	}
+	PGH_HIP(hipMemcpy(ds->d_dos_val_off, val_off.data(), 8ull * rows, hipMemcpyHostToDevice), "dosage upload");
+	PGH_HIP(pgh::LaunchDosageRank(ds->d_dos_present, rows, words, ds->d_dos_rank, hipStreamPerThread), "dosage rank kernel");
+	PGH_HIP(hipStreamSynchronize(hipStreamPerThread), "dosage rank sync");
+	ds->dos_rows = rows;
+	return PGH_OK;
+}
+
 extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t variant_begin, uint32_t variant_end,
                         pgh_dataset **out, char *errbuf) {
 	if (!pgen_path || !out) {
@@ -462,6 +571,14 @@ extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t va
 		SetErr(errbuf, "malformed variant record " + std::to_string(bad_variant - 1));
 		pgh_close(ds.release());
 		return PGH_ERR_FORMAT;
+	}
+	if (ix.has_dosage) {
+		rc = LoadDosageTracks(ds.get(), file, errbuf);
+		lap("dosage tracks");
+		if (rc != PGH_OK) {
+			pgh_close(ds.release());
+			return rc;
+		}
 	}
 	*out = ds.release();
 	return PGH_OK;
@@ -733,8 +850,12 @@ extern "C" void pgh_close(pgh_dataset *ds) {
 	if (!ds) {
 		return;
 	}
-	if (ds->d_rows) {
-		(void)hipFree(ds->d_rows);
+	for (void *p : {static_cast<void *>(ds->d_rows), static_cast<void *>(ds->d_dos_row_of),
+	                static_cast<void *>(ds->d_dos_present), static_cast<void *>(ds->d_dos_rank),
+	                static_cast<void *>(ds->d_dos_val_off), static_cast<void *>(ds->d_dos_values)}) {
+		if (p) {
+			(void)hipFree(p);
+		}
 	}
 	delete ds;
 }
@@ -772,6 +893,12 @@ extern "C" int pgh_subset_create(const pgh_dataset *ds, const uint64_t *sample_i
 	if (e == hipSuccess && ss->n_out) {
 		e = hipMemcpy(ss->d_sel, ss->sel.data(), sizeof(uint32_t) * ss->n_out, hipMemcpyHostToDevice);
 	}
+	if (e == hipSuccess) {
+		e = hipMalloc(reinterpret_cast<void **>(&ss->d_include), 8 * std::max<size_t>(1, ss->include.size()));
+	}
+	if (e == hipSuccess && !ss->include.empty()) {
+		e = hipMemcpy(ss->d_include, ss->include.data(), 8 * ss->include.size(), hipMemcpyHostToDevice);
+	}
 	if (e != hipSuccess) {
 		pgh_subset_destroy(ss.release());
 		return DeviceFail(errbuf, "subset upload", e);
@@ -793,6 +920,9 @@ extern "C" void pgh_subset_destroy(pgh_subset *ss) {
 	}
 	if (ss->d_sel) {
 		(void)hipFree(ss->d_sel);
+	}
+	if (ss->d_include) {
+		(void)hipFree(ss->d_include);
 	}
 	delete ss;
 }

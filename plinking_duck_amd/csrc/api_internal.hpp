@@ -6,6 +6,7 @@
 
 #include "hwe_core.hpp"
 #include "decode.hpp"
+#include "dosage.hpp"
 #include "kernels.hpp"
 #include "ld.hpp"
 #include "linalg.hpp"
@@ -44,9 +45,27 @@ struct pgh_dataset {
 	uint32_t v_end = 0;
 	uint64_t pitch = 0;
 	uint8_t *d_rows = nullptr;
+	// explicit dosages of the resident range (dosage.hpp:DosageView); dos_rows == 0: hardcalls only
+	uint32_t dos_rows = 0;
+	std::vector<int32_t> dos_row_of;
+	int32_t *d_dos_row_of = nullptr;
+	uint64_t *d_dos_present = nullptr;
+	uint32_t *d_dos_rank = nullptr;
+	uint64_t *d_dos_val_off = nullptr;
+	uint16_t *d_dos_values = nullptr;
 
 	RowView View() const {
 		return RowView {d_rows, pitch, sample_ct, record_bytes};
+	}
+	pgh::DosageView Dosage() const {
+		pgh::DosageView d;
+		d.row_of = d_dos_row_of;
+		d.present = d_dos_present;
+		d.rank = d_dos_rank;
+		d.val_off = d_dos_val_off;
+		d.values = d_dos_values;
+		d.words = (sample_ct + 63) / 64;
+		return d;
 	}
 };
 
@@ -56,6 +75,7 @@ struct pgh_subset {
 	std::vector<uint64_t> include; // ceil(N/64) words
 	std::vector<uint32_t> sel;     // raw index of each included sample, ascending
 	uint8_t *d_mask2 = nullptr;    // one pitched row of 01 slots
+	uint64_t *d_include = nullptr; // the include words, for the kernels that walk samples bit by bit
 	uint32_t *d_sel = nullptr;
 };
 
@@ -69,6 +89,8 @@ struct pgh_reader {
 	uint32_t *d_counts = nullptr;
 	uint32_t *h_counts = nullptr; // pinned
 	uint8_t *h_row = nullptr;     // pinned, pitch bytes
+	double *d_dosage = nullptr;   // one dosage row, allocated by the first pgh_get_dosage_f64
+	double *h_dosage = nullptr;   // pinned
 	std::unique_ptr<pgh::RecordFile> file;
 	std::unique_ptr<pgh::Normalizer> norm;
 	std::string err;

@@ -33,7 +33,7 @@ extern "C" int pgh_reader_create(const pgh_dataset *ds, const pgh_subset *subset
 		pgh_reader_destroy(rd.release());
 		return DeviceFail(errbuf, "reader setup", e);
 	}
-	if (ds->has_file && (ds->index.has_dosage || ds->index.has_phase)) {
+	if (ds->has_file && ds->index.has_phase) { // phase tracks are parsed on the host, per call
 		rd->file.reset(new pgh::RecordFile());
 		std::string err;
 		if (!rd->file->Open(ds->pgen_path, err)) {
@@ -62,6 +62,12 @@ extern "C" void pgh_reader_destroy(pgh_reader *rd) {
 	}
 	if (rd->h_row) {
 		(void)hipHostFree(rd->h_row);
+	}
+	if (rd->d_dosage) {
+		(void)hipFree(rd->d_dosage);
+	}
+	if (rd->h_dosage) {
+		(void)hipHostFree(rd->h_dosage);
 	}
 	if (rd->stream) {
 		(void)hipStreamDestroy(rd->stream);
@@ -237,33 +243,33 @@ extern "C" int pgh_get_dosage_f64(pgh_reader *rd, uint32_t vidx, double *out) {
 	if (rc != PGH_OK) {
 		return rc;
 	}
+	// PgrGetD + Dosage16ToDoublesMinus9: one row of the dosage unpack kernel through the reader's buffers
 	const pgh_dataset *ds = rd->ds;
-	if (rd->norm && (ds->index.vrtype[vidx] & 0x60)) {
-		// explicit dosage track: decoded on the host from the record
-		std::vector<uint8_t> row;
-		std::vector<uint16_t> dos;
-		std::string err;
-		if (!rd->norm->DecodeDosage(vidx, row, dos, err)) {
-			return ReaderFail(rd, PGH_ERR_FORMAT, err);
-		}
-		ForEachIncluded(rd, [&](uint32_t k, uint32_t s) {
-			if (dos[s] != 0xffff) {
-				out[k] = static_cast<double>(dos[s]) / 16384.0;
-			} else {
-				const uint32_t c = RowCode(row.data(), s);
-				out[k] = c == 3u ? -9.0 : static_cast<double>(c);
-			}
-		});
+	const uint32_t n_out = rd->subset ? rd->subset->n_out : ds->sample_ct;
+	if (n_out == 0) {
 		return PGH_OK;
 	}
-	rc = FetchRow(rd, vidx);
-	if (rc != PGH_OK) {
-		return rc;
+	hipError_t e = hipSuccess;
+	if (!rd->d_dosage) {
+		e = hipMalloc(reinterpret_cast<void **>(&rd->d_dosage), sizeof(double) * n_out);
+		if (e == hipSuccess) {
+			e = hipHostMalloc(reinterpret_cast<void **>(&rd->h_dosage), sizeof(double) * n_out, hipHostMallocDefault);
+		}
 	}
-	ForEachIncluded(rd, [&](uint32_t k, uint32_t s) {
-		const uint32_t c = RowCode(rd->h_row, s);
-		out[k] = c == 3u ? -9.0 : static_cast<double>(c);
-	});
+	if (e == hipSuccess) {
+		e = pgh::LaunchDosageUnpack(ds->View(), ds->Dosage(), vidx - ds->v_begin, nullptr, 1,
+		                            rd->subset ? rd->subset->d_sel : nullptr, n_out, rd->d_dosage, n_out, rd->stream);
+	}
+	if (e == hipSuccess) {
+		e = hipMemcpyAsync(rd->h_dosage, rd->d_dosage, sizeof(double) * n_out, hipMemcpyDeviceToHost, rd->stream);
+	}
+	if (e == hipSuccess) {
+		e = hipStreamSynchronize(rd->stream);
+	}
+	if (e != hipSuccess) {
+		return ReaderFail(rd, PGH_ERR_DEVICE, std::string("dosage row: ") + hipGetErrorString(e));
+	}
+	std::memcpy(out, rd->h_dosage, sizeof(double) * n_out);
 	return PGH_OK;
 }
 

@@ -1,0 +1,55 @@
+// dosage.hpp -- resident dosage tracks and the kernels that read them (gfx950).
+#pragma once
+
+#include "kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace pgh {
+
+//! A dataset's explicit dosages in HBM, in the file's own bit-array form (vrtype 0x60;
+//! the 0x20 list and 0x40 dense forms are brought to it at pgh_open): per dosage-bearing
+//! variant a presence bit per sample, and the present samples' 16-bit values (0..32768 =
+//! 0..2 ALT copies) packed in sample order.  `rank` holds the number of presence bits
+//! before each 64-sample word, so any lane finds its value with one popcount.
+struct DosageView {
+	const int32_t *row_of = nullptr;   // per resident variant: row below, or -1 (hardcalls only)
+	const uint64_t *present = nullptr; // rows x words
+	const uint32_t *rank = nullptr;    // rows x words
+	const uint64_t *val_off = nullptr; // rows: where the row's values start
+	const uint16_t *values = nullptr;
+	uint32_t words = 0; // ceil(sample_ct / 64)
+};
+
+//! rank[r][w] = number of presence bits of row r before word w
+hipError_t LaunchDosageRank(const uint64_t *present, uint32_t rows, uint32_t words, uint32_t *rank,
+                            hipStream_t stream);
+
+//! PgrGetDCounts (src/plink_freq.cpp:475): per variant {sum of dosages, sum of squares, samples with a
+//! dosage or a call} on the 16384-per-copy scale, over the included samples; hardcalls count as 0 / 16384 / 32768.
+//! Variants are v0 + i, or vlist[i] when vlist != NULL (indices local to the resident range).
+hipError_t LaunchDosageSums(const RowView &view, const DosageView &dos, uint32_t v0, const uint32_t *vlist,
+                            uint32_t n_var, const uint64_t *include, uint64_t *out, hipStream_t stream);
+
+//! PgrGetD + Dosage16ToDoublesMinus9 (src/pgen_reader.cpp:694, src/plink_score.cpp:587): one double per
+//! output sample, -9 where the sample has neither a dosage nor a call.  sel == NULL: every sample.
+hipError_t LaunchDosageUnpack(const RowView &view, const DosageView &dos, uint32_t v0, const uint32_t *vlist,
+                              uint32_t n_var, const uint32_t *sel, uint32_t n_out, double *out, uint64_t out_stride,
+                              hipStream_t stream);
+
+//! Per scored variant, from LaunchDosageSums' output: the contribution tables of the hardcall codes
+//! (ts / td as LaunchScoreTables writes them, with the mean taken over dosages), the affine map of an
+//! explicit dosage lin = {scale, shift}: contribution = (d * scale + shift), and the ALLELE_CT increment.
+hipError_t LaunchScoreTablesDosage(const uint64_t *sums, const uint8_t *flip, uint32_t n_scored, int mode, double *ts,
+                                   double *td, double *lin, uint32_t *ac, hipStream_t stream);
+
+//! plink_score over variants that carry dosages (src/plink_score.cpp:586-652): adds into score / dosage_sum and
+//! counts, per sample, the scored variants at which it has neither dosage nor call (miss, for ALLELE_CT).
+hipError_t LaunchScoreDosage(const RowView &view, const DosageView &dos, const uint32_t *vlist, uint32_t n_scored,
+                             const double *weights, uint32_t w_stride, uint32_t n_cols, const double *ts,
+                             const double *lin, const uint32_t *ac, int mode, double *score, uint32_t out_stride,
+                             double *dosage_sum, uint32_t *miss, hipStream_t stream);
+
+} // namespace pgh

@@ -601,10 +601,7 @@ bool Normalizer::DecodeDosage(uint32_t v, std::vector<uint8_t> &row2bit, std::ve
 	const uint32_t N = index_.sample_ct;
 	const uint8_t t = index_.vrtype[v];
 	dosage16.assign(N, 0xffff);
-	if (t & 0x80) {
-		err = "phased-dosage track is not supported";
-		return false;
-	}
+	// a phased-dosage track (0x80) follows the dosage track; PgrGetD does not read it either
 	ByteCursor cur {rec.data() + aux, rec.data() + rec.size()};
 	if (t & 0x10) {
 		// step over the phase track

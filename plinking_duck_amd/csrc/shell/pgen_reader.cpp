@@ -264,7 +264,8 @@ void PgenScan(ClientContext &, TableFunctionInput &data_p, DataChunk &output) {
 	const GenotypeMode mode = bind_data.genotype_mode;
 	const bool listed = gstate.scan.has_variant_list;
 	const bool phased_out = bind_data.include_phased && mode != GenotypeMode::COLUMNS;
-	const bool per_variant_decode = gstate.need_genotypes && (bind_data.include_dosages || phased_out);
+	const bool dosage_rows = gstate.need_genotypes && bind_data.include_dosages;
+	const bool per_variant_decode = gstate.need_genotypes && !dosage_rows && phased_out;
 	const bool plain_hardcalls =
 	    gstate.need_genotypes && !IsAggregateGenotypeMode(mode) && !bind_data.include_dosages && !phased_out;
 	auto no_strata = [](uint32_t, uint32_t) { return false; };
@@ -324,10 +325,26 @@ void PgenScan(ClientContext &, TableFunctionInput &data_p, DataChunk &output) {
 		}
 	}
 
+	const double *dose = nullptr; // the current row of the chunk's dosages
+	if (dosage_rows) {
+		// PgrGetD + Dosage16ToDoublesMinus9 for the chunk's variants in one device call
+		vector<uint32_t> chunk_vidx(plan.size());
+		for (size_t r = 0; r < plan.size(); r++) {
+			chunk_vidx[r] = plan[r].vidx;
+		}
+		lstate.dosage_doubles.resize(plan.size() * static_cast<size_t>(n));
+		char errbuf[PGH_ERRBUF_LEN] = {0};
+		if (pgh_dosage_unpack(gstate.scan.dataset->handle, gstate.scan.subset ? gstate.scan.subset->handle : nullptr, 0,
+		                      static_cast<uint32_t>(plan.size()), chunk_vidx.data(), lstate.dosage_doubles.data(),
+		                      errbuf) != PGH_OK) {
+			throw IOException("%s: PgrGetD failed for variants [%u, %u): %s", fn, span_begin, span_end, string(errbuf));
+		}
+	}
+
 	// per-call writers shared by the ARRAY / LIST / STRUCT / COLUMNS layouts: `slot` is the
 	// element index inside `dst` (child offset, or the output row for scalar layouts)
 	auto put_dosage = [&](Vector &dst, idx_t slot, uint32_t s) {
-		double d = lstate.dosage_doubles[s];
+		double d = dose[s];
 		if (d == -9.0) {
 			FlatVector::Validity(dst).SetInvalid(slot);
 			FlatVector::GetData<double>(dst)[slot] = 0.0;
@@ -372,13 +389,9 @@ void PgenScan(ClientContext &, TableFunctionInput &data_p, DataChunk &output) {
 		const size_t src_row = listed ? row : v - span_begin;
 		const int8_t *src = plain_hardcalls ? lstate.bytes.data() + src_row * n : nullptr;
 		const uint64_t *val = plain_hardcalls ? lstate.validity.data() + src_row * val_words : nullptr;
+		dose = dosage_rows ? lstate.dosage_doubles.data() + row * static_cast<size_t>(n) : nullptr;
 		if (per_variant_decode) {
-			if (bind_data.include_dosages) {
-				if (pgh_get_dosage_f64(lstate.reader, v, lstate.dosage_doubles.data()) != PGH_OK) {
-					throw IOException("%s: PgrGetD failed for variant %u: %s", fn, v,
-					                  string(pgh_reader_error(lstate.reader)));
-				}
-			} else if (pgh_get_phased(lstate.reader, v, lstate.genovec.data(), lstate.phasepresent.data(),
+			if (pgh_get_phased(lstate.reader, v, lstate.genovec.data(), lstate.phasepresent.data(),
 			                          lstate.phaseinfo.data()) != PGH_OK) {
 				throw IOException("%s: PgrGetP failed for variant %u: %s", fn, v,
 				                  string(pgh_reader_error(lstate.reader)));

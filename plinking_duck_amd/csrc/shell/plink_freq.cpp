@@ -34,6 +34,7 @@ struct PlinkFreqGlobalState : public GlobalTableFunctionState {
 	bool need_frequencies = false;
 	uint32_t max_threads_config = 0;
 
+	bool dosage_on_device = false; // dosage := true on a file with dosage tracks: moments from pgh_dosage_sums
 	idx_t MaxThreads() const override {
 		uint32_t range = scan.end_variant_idx - scan.start_variant_idx;
 		return ApplyMaxThreadsCap(range / 500 + 1, max_threads_config);
@@ -42,13 +43,6 @@ struct PlinkFreqGlobalState : public GlobalTableFunctionState {
 
 struct PlinkFreqLocalState : public LocalTableFunctionState {
 	VariantScanLocal scan;
-	pgh_reader *reader = nullptr; // per-variant dosage decode (dosage := true on a dosage file)
-	vector<double> dosage_doubles;
-	~PlinkFreqLocalState() override {
-		if (reader) {
-			pgh_reader_destroy(reader);
-		}
-	}
 };
 
 static unique_ptr<FunctionData> PlinkFreqBind(ClientContext &context, TableFunctionBindInput &input,
@@ -114,25 +108,16 @@ static unique_ptr<GlobalTableFunctionState> PlinkFreqInitGlobal(ClientContext &c
 			BuildSexStrata(state->scan, bind_data.c.sample_info, bind_data.c.sample_subset.get(),
 			               bind_data.c.raw_sample_ct, "plink_freq");
 		}
+		state->dosage_on_device = bind_data.include_dosage && bind_data.c.file_has_dosage;
 	}
 	return std::move(state);
 }
 
 static unique_ptr<LocalTableFunctionState> PlinkFreqInitLocal(ExecutionContext &, TableFunctionInitInput &input,
                                                               GlobalTableFunctionState *global_state) {
-	auto &bind_data = input.bind_data->Cast<PlinkFreqBindData>();
-	auto &gstate = global_state->Cast<PlinkFreqGlobalState>();
-	auto state = make_uniq<PlinkFreqLocalState>();
-	if (gstate.need_frequencies && bind_data.include_dosage && bind_data.c.file_has_dosage) {
-		char errbuf[PGH_ERRBUF_LEN] = {0};
-		int rc = pgh_reader_create(gstate.scan.dataset->handle, gstate.scan.subset ? gstate.scan.subset->handle : nullptr,
-		                           &state->reader, errbuf);
-		if (rc != PGH_OK) {
-			throw IOException("plink_freq: thread init failed: %s", string(errbuf));
-		}
-		state->dosage_doubles.resize(bind_data.c.effective_sample_ct);
-	}
-	return std::move(state);
+	(void)input;
+	(void)global_state;
+	return make_uniq<PlinkFreqLocalState>();
 }
 
 static void PlinkFreqScan(ClientContext &, TableFunctionInput &data_p, DataChunk &output) {
@@ -166,6 +151,7 @@ static void PlinkFreqScan(ClientContext &, TableFunctionInput &data_p, DataChunk
 	static constexpr uint64_t kDosageMid = 16384;
 	vector<FreqRow> rows;
 	rows.reserve(STANDARD_VECTOR_SIZE);
+	vector<uint32_t> dosage_rows, dosage_vidx; // rows whose frequency comes from the dosage tracks
 	uint32_t vidx;
 	while (rows.size() < STANDARD_VECTOR_SIZE && lstate.scan.Next(gstate.scan, "plink_freq", needs_strata, vidx)) {
 		FreqRow row;
@@ -202,28 +188,12 @@ static void PlinkFreqScan(ClientContext &, TableFunctionInput &data_p, DataChunk
 			// dosage-weighted allele sums (PgrGetDCounts, src/plink_freq.cpp:525-535)
 			uint64_t alt_sum, ref_sum;
 			row.r2_is_null = !bind_data.c.file_has_dosage;
-			if (lstate.reader) {
-				if (pgh_get_dosage_f64(lstate.reader, vidx, lstate.dosage_doubles.data()) != PGH_OK) {
-					throw IOException("plink_freq: PgrGetDCounts failed for variant %u: %s", vidx,
-					                  string(pgh_reader_error(lstate.reader)));
-				}
-				uint64_t sum = 0, ssq = 0;
-				uint32_t nm = 0;
-				for (double d : lstate.dosage_doubles) {
-					if (d != -9.0) {
-						const uint64_t u = static_cast<uint64_t>(std::llround(d * 16384.0));
-						sum += u;
-						ssq += u * u;
-						nm++;
-					}
-				}
-				alt_sum = sum;
-				ref_sum = static_cast<uint64_t>(nm) * 2 * kDosageMid - sum;
-				if (nm) { // MaCH r2 = popvar(d) / (2 p (1 - p)) on the 16384 scale
-					const double sumd = static_cast<double>(sum);
-					const double avg = sumd / static_cast<double>(nm);
-					row.imp_r2 = 2.0 * (static_cast<double>(ssq) - sumd * avg) / (sumd * (32768.0 - avg));
-				}
+			if (gstate.dosage_on_device) {
+				// the moments come from one device call per chunk, below
+				dosage_rows.push_back(static_cast<uint32_t>(rows.size()));
+				dosage_vidx.push_back(vidx);
+				rows.push_back(row);
+				continue;
 			} else {
 				alt_sum = (static_cast<uint64_t>(gc[1]) + 2ull * gc[2]) * kDosageMid;
 				ref_sum = 2ull * observed * kDosageMid - alt_sum;
@@ -244,6 +214,33 @@ static void PlinkFreqScan(ClientContext &, TableFunctionInput &data_p, DataChunk
 			}
 		}
 		rows.push_back(row);
+	}
+
+	if (!dosage_rows.empty()) {
+		// PgrGetDCounts for the chunk's rows at once (src/plink_freq.cpp:475-480, :525-535)
+		vector<uint64_t> moments(3 * dosage_rows.size());
+		char errbuf[PGH_ERRBUF_LEN] = {0};
+		if (pgh_dosage_sums(gstate.scan.dataset->handle, gstate.scan.subset ? gstate.scan.subset->handle : nullptr, 0,
+		                    static_cast<uint32_t>(dosage_vidx.size()), dosage_vidx.data(),
+		                    reinterpret_cast<uint64_t(*)[3]>(moments.data()), errbuf) != PGH_OK) {
+			throw IOException("plink_freq: PgrGetDCounts failed for variants [%u, %u]: %s", dosage_vidx.front(),
+			                  dosage_vidx.back(), string(errbuf));
+		}
+		for (size_t k = 0; k < dosage_rows.size(); k++) {
+			FreqRow &row = rows[dosage_rows[k]];
+			const uint64_t sum = moments[3 * k], ssq = moments[3 * k + 1], nm = moments[3 * k + 2];
+			if (nm) { // MaCH r2 = popvar(d) / (2 p (1 - p)) on the 16384 scale
+				const double sumd = static_cast<double>(sum);
+				const double avg = sumd / static_cast<double>(nm);
+				row.imp_r2 = 2.0 * (static_cast<double>(ssq) - sumd * avg) / (sumd * (32768.0 - avg));
+			}
+			const uint64_t total = nm * 2 * kDosageMid; // alt + ref dosage
+			row.freq_is_null = total == 0;
+			if (total) {
+				row.alt_freq = static_cast<double>(sum) / static_cast<double>(total);
+				row.obs_ct = static_cast<uint32_t>(total / kDosageMid);
+			}
+		}
 	}
 
 	const idx_t n_rows = rows.size();

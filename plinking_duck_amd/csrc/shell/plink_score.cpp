@@ -211,70 +211,6 @@ static unique_ptr<LocalTableFunctionState> PlinkScoreInitLocal(ExecutionContext 
 	return make_uniq<PlinkScoreLocalState>();
 }
 
-//! Files with explicit dosage tracks: the dosage track is decoded on the host
-//! (pgh_get_dosage_f64 = PgrGetD + Dosage16ToDoublesMinus9), so this mirrors the
-//! reference loop (src/plink_score.cpp:586-652) variant by variant.
-static void ScoreFromDosages(const PlinkScoreBindData &bind_data, PlinkScoreGlobalState &gstate) {
-	char errbuf[PGH_ERRBUF_LEN] = {0};
-	pgh_reader *reader = nullptr;
-	int rc = pgh_reader_create(gstate.dataset->handle, gstate.subset ? gstate.subset->handle : nullptr, &reader, errbuf);
-	if (rc != PGH_OK) {
-		throw IOException("plink_score: thread init failed: %s", string(errbuf));
-	}
-	uint32_t sample_ct = bind_data.c.effective_sample_ct;
-	vector<double> dosage(sample_ct);
-	for (auto &sv : bind_data.scored_variants) {
-		if (pgh_get_dosage_f64(reader, sv.variant_idx, dosage.data()) != PGH_OK) {
-			string msg = pgh_reader_error(reader);
-			pgh_reader_destroy(reader);
-			throw IOException("plink_score: PgrGetD failed for variant %u: %s", sv.variant_idx, msg);
-		}
-		double sum_alt = 0.0;
-		uint32_t non_missing_ct = 0;
-		for (uint32_t s = 0; s < sample_ct; s++) {
-			if (dosage[s] != -9.0) {
-				sum_alt += dosage[s];
-				non_missing_ct++;
-			}
-		}
-		if (non_missing_ct == 0) {
-			continue;
-		}
-		double mean_alt = sum_alt / static_cast<double>(non_missing_ct);
-		if (bind_data.center) {
-			double freq = mean_alt / 2.0;
-			double sd = std::sqrt(2.0 * freq * (1.0 - freq));
-			if (sd == 0.0) {
-				continue;
-			}
-			double mean_scored = sv.flip ? (2.0 - mean_alt) : mean_alt;
-			for (uint32_t s = 0; s < sample_ct; s++) {
-				if (dosage[s] == -9.0) {
-					continue;
-				}
-				double scored = sv.flip ? (2.0 - dosage[s]) : dosage[s];
-				gstate.score_sums[s] += sv.weight * ((scored - mean_scored) / sd);
-				gstate.allele_cts[s] += 2;
-			}
-		} else {
-			for (uint32_t s = 0; s < sample_ct; s++) {
-				double alt = dosage[s];
-				if (alt == -9.0) {
-					if (bind_data.no_mean_imputation) {
-						continue;
-					}
-					alt = mean_alt;
-				}
-				double scored = sv.flip ? (2.0 - alt) : alt;
-				gstate.score_sums[s] += sv.weight * scored;
-				gstate.named_allele_dosage_sums[s] += scored;
-				gstate.allele_cts[s] += 2;
-			}
-		}
-	}
-	pgh_reader_destroy(reader);
-}
-
 static void PlinkScoreScan(ClientContext &, TableFunctionInput &data_p, DataChunk &output) {
 	auto &bind_data = data_p.bind_data->Cast<PlinkScoreBindData>();
 	auto &gstate = data_p.global_state->Cast<PlinkScoreGlobalState>();
@@ -284,9 +220,9 @@ static void PlinkScoreScan(ClientContext &, TableFunctionInput &data_p, DataChun
 		std::lock_guard<std::mutex> lock(gstate.phase1_mutex);
 		if (!gstate.scoring_done) {
 			if (gstate.dataset && !bind_data.scored_variants.empty()) {
-				if (bind_data.c.file_has_dosage) {
-					ScoreFromDosages(bind_data, gstate);
-				} else {
+				{
+					// hardcalls and dosage tracks alike: the library scores a dosage-bearing variant from its
+					// dosages, as PgrGetD hands them to the reference loop (src/plink_score.cpp:586-652)
 					size_t n_scored = bind_data.scored_variants.size();
 					vector<uint32_t> vidx(n_scored);
 					vector<double> weights(n_scored);

@@ -26,7 +26,8 @@ EXPORTED_SYMBOLS = [
     "pgh_close", "pgh_subset_create", "pgh_subset_size", "pgh_subset_destroy", "pgh_counts_range",
     "pgh_counts_range_dev", "pgh_freq_from_counts_dev", "pgh_fused_tally_dev", "pgh_missing_per_sample", "pgh_missing_per_sample_dev", "pgh_unpack_range",
     "pgh_unpack_range_dev", "pgh_score", "pgh_score_dev", "pgh_score_plan_create", "pgh_score_run_dev",
-    "pgh_score_plan_destroy", "pgh_pca", "pgh_pca_sharded", "pgh_ld_pairs", "pgh_ld_pairs_dev", "pgh_sample_counts", "pgh_sample_counts_dev", "pgh_reader_create", "pgh_reader_destroy",
+    "pgh_score_plan_destroy", "pgh_pca", "pgh_pca_sharded", "pgh_ld_pairs", "pgh_ld_pairs_dev", "pgh_sample_counts", "pgh_sample_counts_dev",
+    "pgh_dosage_sums", "pgh_dosage_sums_dev", "pgh_dosage_unpack", "pgh_dosage_unpack_dev", "pgh_reader_create", "pgh_reader_destroy",
     "pgh_get_2bit", "pgh_get_counts", "pgh_get_missingness", "pgh_get_int8", "pgh_get_dosage_f64", "pgh_get_phased",
     "pgh_reader_error", "pgh_hwe_lnp", "pgh_hwe_xchr_lnp", "pgh_hwe_lnp_batch", "pgh_hwe_lnp_batch_dev", "pgh_hwe_xchr_lnp_batch",
 ]
@@ -111,6 +112,10 @@ def _load():
         "pgh_hwe_xchr_lnp_batch": (C.c_int, [vp, u32, u32, vp, cp]),
         "pgh_sample_counts": (C.c_int, [vp, vp, u32, u32, vp, vp, cp]),
         "pgh_sample_counts_dev": (C.c_int, [vp, u32, u32, vp, vp, cp]),
+        "pgh_dosage_sums": (C.c_int, [vp, vp, u32, u32, vp, vp, cp]),
+        "pgh_dosage_sums_dev": (C.c_int, [vp, vp, u32, u32, vp, vp, cp]),
+        "pgh_dosage_unpack": (C.c_int, [vp, vp, u32, u32, vp, vp, cp]),
+        "pgh_dosage_unpack_dev": (C.c_int, [vp, vp, u32, u32, vp, C.c_size_t, vp, cp]),
         "pgh_ld_pairs_dev": (C.c_int, [vp, vp, u32, vp, vp, vp, vp, cp]),
         "pgh_pca_sharded": (C.c_int, [vp, vp, u32, vp, vp, vp, C.c_uint64, u32, vp, ALLREDUCE_FN, vp, vp, vp, cp]),
         "pgh_reader_create": (C.c_int, [vp, vp, C.POINTER(vp), cp]),
@@ -437,6 +442,44 @@ class Dataset:
             v1 = self.v_end if v_end is None else v_end
             _check(_lib.pgh_sample_counts(self._h, subset._h if subset else None, v0, v1 - v0, None, _ptr(out), eb), eb)
         return out
+
+    def _range_or_list(self, v_begin, v_end, vidx):
+        if vidx is not None:
+            v = np.ascontiguousarray(vidx, dtype=np.uint32)
+            return 0, len(v), v
+        v0 = self.v_begin if v_begin is None else v_begin
+        v1 = self.v_end if v_end is None else v_end
+        return v0, v1 - v0, None
+
+    def dosage_sums(self, v_begin: int | None = None, v_end: int | None = None, vidx=None,
+                    subset: Subset | None = None) -> np.ndarray:
+        """uint64[n][3] = {sum, sum of squares, observed samples} of the dosages (16384 per ALT copy)."""
+        v0, n, v = self._range_or_list(v_begin, v_end, vidx)
+        out = np.zeros((n, 3), dtype=np.uint64)
+        eb = _errbuf()
+        _check(_lib.pgh_dosage_sums(self._h, subset._h if subset else None, v0, n, _ptr(v) if v is not None else None,
+                                    _ptr(out), eb), eb)
+        return out
+
+    def dosage_unpack(self, v_begin: int | None = None, v_end: int | None = None, vidx=None,
+                      subset: Subset | None = None) -> np.ndarray:
+        """float64[n][n_out]: dosages, -9 where a sample has neither a dosage nor a call."""
+        v0, n, v = self._range_or_list(v_begin, v_end, vidx)
+        out = np.zeros((n, subset.size if subset else self.n_samples), dtype=np.float64)
+        eb = _errbuf()
+        _check(_lib.pgh_dosage_unpack(self._h, subset._h if subset else None, v0, n, _ptr(v) if v is not None else None,
+                                      _ptr(out), eb), eb)
+        return out
+
+    def dosage_sums_dev(self, v_begin, v_end, d_sums: int, stream: int = 0, subset: Subset | None = None):
+        eb = _errbuf()
+        _check(_lib.pgh_dosage_sums_dev(self._h, subset._h if subset else None, v_begin, v_end, d_sums, stream, eb), eb)
+
+    def dosage_unpack_dev(self, v_begin, v_end, d_out: int, out_stride: int, stream: int = 0,
+                          subset: Subset | None = None):
+        eb = _errbuf()
+        _check(_lib.pgh_dosage_unpack_dev(self._h, subset._h if subset else None, v_begin, v_end, d_out, out_stride,
+                                          stream, eb), eb)
 
     def sample_counts_dev(self, v_begin, v_end, d_classes: int, stream: int = 0):
         eb = _errbuf()

@@ -55,7 +55,8 @@ def _id_bytes(n: int) -> int:
     return 1 if n < 0x100 else 2 if n < 0x10000 else 3 if n < 0x1000000 else 4
 
 
-def _difflist(ids: np.ndarray, vals: np.ndarray, n_samples: int) -> bytes:
+def _difflist(ids: np.ndarray, vals: np.ndarray | None, n_samples: int) -> bytes:
+    """vals None: the id-only form the 0x20 dosage track uses."""
     ln = len(ids)
     out = bytearray(_varint(ln))
     if ln == 0:
@@ -69,7 +70,8 @@ def _difflist(ids: np.ndarray, vals: np.ndarray, n_samples: int) -> bytes:
         gaps.append(_varints(np.diff(chunk)))
     for g in range(groups - 1):
         out.append((len(gaps[g]) - 63) & 0xFF)  # gap-section byte length, biased; decoders here skip it
-    out += _pack2(vals)
+    if vals is not None:
+        out += _pack2(vals)
     for g in gaps:
         out += g
     return bytes(out)
@@ -113,17 +115,55 @@ def choose_kinds(geno: np.ndarray, rng: np.random.Generator) -> list[int]:
     return kinds
 
 
-def write_pgen(path: str, geno: np.ndarray, kinds: list[int]) -> None:
-    """geno: [M][N] codes.  Writes mode 0x10 with 8-bit vrtypes and 4-byte record lengths."""
+def phase_track(g: np.ndarray, rng: np.random.Generator) -> bytes:
+    """vrtype bit 0x10: first bit 0 = every het is phased, then one phaseinfo bit per het; first bit 1 =
+    a phasepresent bit per het, then one phaseinfo bit per phased het."""
+    het_ct = int((g == 1).sum())
+    explicit = bool(rng.integers(0, 2))
+    if not explicit:
+        bits = np.concatenate([[0], rng.integers(0, 2, het_ct)]).astype(np.uint8)
+        return np.packbits(bits, bitorder="little").tobytes()
+    present = rng.integers(0, 2, het_ct).astype(np.uint8)
+    head = np.packbits(np.concatenate([[1], present]).astype(np.uint8), bitorder="little").tobytes()
+    info = rng.integers(0, 2, int(present.sum())).astype(np.uint8)
+    return head + np.packbits(info, bitorder="little").tobytes()
+
+
+def dosage_track(kind: int, dos16: np.ndarray, n: int) -> bytes:
+    """kind 0x20: sample-id list + values; 0x40: one value per sample (65535 = none); 0x60: presence bits + values."""
+    have = np.flatnonzero(dos16 != 0xFFFF)
+    vals = dos16[have].astype("<u2").tobytes()
+    if kind == 0x20:
+        return _difflist(have, None, n) + vals
+    if kind == 0x40:
+        return dos16.astype("<u2").tobytes()
+    if kind == 0x60:
+        return np.packbits((dos16 != 0xFFFF).astype(np.uint8), bitorder="little").tobytes() + vals
+    raise ValueError(kind)
+
+
+def write_pgen(path: str, geno: np.ndarray, kinds: list[int], dosage: np.ndarray | None = None,
+               dosage_kinds: list[int] | None = None, phase_rng: np.random.Generator | None = None) -> None:
+    """geno: [M][N] codes.  Writes mode 0x10 with 8-bit vrtypes and 4-byte record lengths.
+    dosage: [M][N] uint16 (65535 = no explicit dosage), written per variant as dosage_kinds[v] (0 = no track).
+    phase_rng: give every variant with a het a phase track (bit 0x10) of random content."""
     m, n = geno.shape
     records = []
+    kinds = list(kinds)
     base = None
     for v in range(m):
         g = geno[v].astype(np.uint8)
         k = kinds[v]
-        records.append(encode_record(k, g, base))
+        rec = encode_record(k, g, base)
         if k not in (2, 3):
             base = g
+        if phase_rng is not None and (g == 1).any():
+            rec += phase_track(g, phase_rng)
+            kinds[v] |= 0x10
+        if dosage is not None and dosage_kinds[v]:
+            rec += dosage_track(dosage_kinds[v], dosage[v], n)
+            kinds[v] |= dosage_kinds[v]
+        records.append(rec)
     blocks = (m + 65535) // 65536
     head = bytearray([0x6C, 0x1B, 0x10]) + int(m).to_bytes(4, "little") + int(n).to_bytes(4, "little")
     head.append(0x40 | 4 | 3)  # no nonref flags; 8-bit vrtypes; 4-byte record lengths

@@ -1,0 +1,204 @@
+"""Dosage tracks (vrtype bits 0x20 / 0x40 / 0x60) through the resident device form.
+
+The reference's own fixture (dosage_example, 4 x 4) pins the decode and the arithmetic
+(`read_pgen_dosage.test:108-128`, `plink_freq_dosage.test:93-116`; see test_gpu_parity and the
+table-function tests).  Everything larger comes from tests/pgen_writer.py: the three track
+shapes, with and without a phase track in front, over every hardcall record type, so the
+device path is checked against the oracle on multi-word presence arrays and multi-group id
+lists; those shapes are "parity unpinned" against pgenlib."""
+
+import numpy as np
+import pytest
+
+from conftest import data_path
+import pgen_writer as W
+
+CASES = [(40, 7, 11), (150, 257, 12), (120, 1000, 13), (60, 5003, 14)]  # (variants, samples, seed)
+
+
+def make_dosage_file(path, m, n, seed, with_phase):
+    rng = np.random.default_rng(seed)
+    geno = W.rare_matrix(m, n, rng)
+    for v in range(0, m, 5):  # some dense rows so that hets (and a phase track) are common
+        geno[v] = rng.choice(4, size=n, p=[0.45, 0.3, 0.2, 0.05])
+    kinds = W.choose_kinds(geno, rng)
+    dos = np.full((m, n), 0xFFFF, dtype=np.uint16)
+    dkinds = []
+    for v in range(m):
+        k = int(rng.choice([0, 0x20, 0x40, 0x60]))
+        dkinds.append(k)
+        if k == 0:
+            continue
+        rate = float(rng.choice([0.0, 0.002, 0.05, 0.6, 1.0]))
+        hit = rng.random(n) < rate
+        dos[v, hit] = rng.integers(0, 32769, int(hit.sum()), dtype=np.uint16)
+    W.write_pgen(path, geno, kinds, dosage=dos, dosage_kinds=dkinds,
+                 phase_rng=np.random.default_rng(seed + 100) if with_phase else None)
+    want = np.where(dos != 0xFFFF, dos.astype(np.float64) / 16384.0,
+                    np.where(geno == 3, -9.0, geno.astype(np.float64)))
+    return geno, dos, dkinds, want
+
+
+@pytest.fixture(scope="module")
+def files(tmp_path_factory):
+    root = tmp_path_factory.mktemp("dosage_tracks")
+    out = {}
+    for m, n, seed in CASES:
+        for with_phase in (False, True):
+            path = str(root / f"d_{m}_{n}_{int(with_phase)}.pgen")
+            out[(m, n, with_phase)] = (path,) + make_dosage_file(path, m, n, seed, with_phase)
+    return out
+
+
+@pytest.mark.parametrize("m,n,seed", CASES)
+@pytest.mark.parametrize("with_phase", [False, True])
+def test_oracle_reads_the_written_tracks(files, oracle, m, n, seed, with_phase):
+    path, geno, dos, dkinds, want = files[(m, n, with_phase)]
+    pg = oracle.Pgen(path)
+    assert pg.has_dosage and {k for k in dkinds} == {0, 0x20, 0x40, 0x60}
+    for v in range(m):
+        assert pg.vrtype(v) & 0x60 == dkinds[v]
+        assert np.array_equal(pg.dosage(v), want[v]), (v, dkinds[v])
+
+
+def _moments(want_rows):
+    out = np.zeros((len(want_rows), 3), dtype=np.uint64)
+    for i, d in enumerate(want_rows):
+        u = np.rint(d[d != -9.0] * 16384.0).astype(np.uint64)
+        out[i] = (u.sum(), (u * u).sum(), len(u))
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,n,seed", CASES)
+@pytest.mark.parametrize("with_phase", [False, True])
+def test_device_dosages_equal_the_oracle(files, gpu_lib, oracle, m, n, seed, with_phase):
+    path, geno, dos, dkinds, want = files[(m, n, with_phase)]
+    ds = gpu_lib.Dataset.open(path)
+    assert np.array_equal(ds.dosage_unpack(), want)
+    assert np.array_equal(ds.dosage_sums(), _moments(want))
+    rng = np.random.default_rng(seed)
+    mask = rng.random(n) < 0.4
+    mask[0] = True
+    ss = ds.subset(mask)
+    vidx = np.sort(rng.choice(m, size=min(m, 17), replace=False))
+    assert np.array_equal(ds.dosage_unpack(vidx=vidx, subset=ss), want[vidx][:, mask])
+    assert np.array_equal(ds.dosage_sums(vidx=vidx, subset=ss), _moments(want[vidx][:, mask]))
+    assert np.array_equal(ds.dosage_sums(3, 9), _moments(want[3:9]))
+    rd = ds.reader(ss)
+    for v in vidx[:5]:
+        assert np.array_equal(rd.get_dosage_f64(int(v)), want[v][mask])
+    # a shard opened mid-file indexes its tracks from its own first variant
+    part = gpu_lib.Dataset.open(path, variant_begin=m // 3, variant_end=m - 2)
+    assert np.array_equal(part.dosage_unpack(), want[m // 3:m - 2])
+    # the hardcall tallies are untouched by the aux tracks behind them
+    pg = oracle.Pgen(path)
+    assert np.array_equal(ds.counts_range(), np.stack([pg.counts(v) for v in range(m)]))
+
+
+REL = 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["default", "no_mean_imputation", "center"])
+@pytest.mark.parametrize("ncols", [1, 3, 6])
+def test_score_over_dosage_tracks(files, gpu_lib, oracle, mode, ncols):
+    m, n = 120, 1000
+    path, geno, dos, dkinds, want = files[(m, n, True)]
+    ds = gpu_lib.Dataset.open(path)
+    pg = oracle.Pgen(path)
+    rng = np.random.default_rng(ncols)
+    vidx = np.sort(rng.choice(m, size=97, replace=False))
+    w = rng.standard_normal((len(vidx), ncols))
+    flip = (rng.random(len(vidx)) < 0.3).astype(np.uint8)
+    code = {"default": gpu_lib.SCORE_MEAN_IMPUTE, "no_mean_imputation": gpu_lib.SCORE_NO_MEAN_IMPUTATION,
+            "center": gpu_lib.SCORE_CENTER}[mode]
+    for mask in (None, rng.random(n) < 0.5):
+        ss = None if mask is None else ds.subset(mask)
+        inc = None if mask is None else mask.astype(np.uint8)
+        s, d, ac = ds.score(vidx, w, flip=flip, mode=code, subset=ss)
+        es, ed, eac = oracle.score(pg, vidx, w, flip=flip, mode=mode, include=inc)
+        assert np.array_equal(ac, eac)
+        scale = np.abs(w).sum(axis=0) * 2.0
+        assert np.all(np.abs(s - es) <= REL * np.maximum(np.abs(es), 1e-3 * scale))
+        assert np.allclose(d, ed, rtol=REL, atol=1e-9)
+    # only dosage-bearing variants, and only hardcall ones, through the same entry point
+    for pick in ([v for v in range(m) if dkinds[v]][:30], [v for v in range(m) if not dkinds[v]][:30]):
+        wv = rng.standard_normal((len(pick), ncols))
+        s, d, ac = ds.score(pick, wv, mode=code)
+        es, ed, eac = oracle.score(pg, pick, wv, mode=mode)
+        assert np.array_equal(ac, eac) and np.allclose(s, es, rtol=1e-9, atol=1e-9) and np.allclose(d, ed, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_reference_dosage_fixture_through_the_device_form(gpu_lib, oracle):
+    ds = gpu_lib.Dataset.open(data_path("dosage_example.pgen"))
+    pg = oracle.Pgen(data_path("dosage_example.pgen"))
+    got = ds.dosage_unpack()
+    for v in range(pg.M):
+        assert np.array_equal(got[v], pg.dosage(v))
+        counts, dosages, r2 = pg.dcounts(v)
+        sums = ds.dosage_sums(v, v + 1)[0]
+        assert int(sums[0]) == int(dosages[1]) and int(sums[2]) * 32768 - int(sums[0]) == int(dosages[0])
+
+
+def _companions(prefix, m, n):
+    with open(prefix + ".pvar", "w") as f:
+        f.write("#CHROM\tPOS\tID\tREF\tALT\n")
+        for v in range(m):
+            f.write(f"{1 + v * 3 // m}\t{1000 + 10 * v}\tv{v}\tA\tG\n")
+    with open(prefix + ".psam", "w") as f:
+        f.write("#IID\tSEX\n")
+        for s in range(n):
+            f.write(f"S{s}\t{1 + s % 2}\n")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("threads", [1, 5])
+def test_table_functions_over_dosage_tracks(tmp_path, gpu_lib, oracle, threads):
+    """plink_freq(dosage := true), plink_score and read_pgen(dosages := true) on a file whose variants mix the
+    three track shapes: the shells against the oracle's PgrGetDCounts / PgrGetD restatements."""
+    import plinking_duck_amd.functions as F
+    m, n = 2600, 301  # several 2048-row chunks
+    prefix = str(tmp_path / "dz")
+    geno, dos, dkinds, want = make_dosage_file(prefix + ".pgen", m, n, 21, True)
+    _companions(prefix, m, n)
+    pg = oracle.Pgen(prefix + ".pgen")
+    mask = np.zeros(n, dtype=bool)
+    mask[[5, 17, 200, 300] + list(range(40, 140))] = True
+    for samples, inc in ((None, None), ([int(i) for i in np.flatnonzero(mask)], mask.astype(np.uint8))):
+        kw = {} if samples is None else {"samples": samples}
+        r = F.query("plink_freq", prefix + ".pgen", dosage=True, threads=threads,
+                    columns=["ID", "ALT_FREQ", "OBS_CT", "IMP_R2"], **kw)
+        assert len(r) == m
+        for vid, af, obs, r2 in r.rows:
+            v = int(vid[1:])
+            counts, dosages, er2 = pg.dcounts(v, inc)
+            eaf, eobs = oracle.freq_from_dcounts(dosages)
+            assert (af, obs) == (eaf, eobs), v
+            if eobs and not np.isnan(er2):
+                assert r2 == pytest.approx(er2, rel=1e-12, abs=1e-300), v
+        rng = np.random.default_rng(3)
+        w = rng.standard_normal(m)
+        w[rng.random(m) < 0.2] = 0.0
+        for mode, kwm in (("default", {}), ("no_mean_imputation", {"no_mean_imputation": True}), ("center", {"center": True})):
+            r = F.query("plink_score", prefix + ".pgen", weights=[float(x) for x in w], threads=threads,
+                        columns=["IID", "ALLELE_CT", "NAMED_ALLELE_DOSAGE_SUM", "SCORE_SUM"], **kw, **kwm)
+            vidx = np.flatnonzero(w != 0.0)
+            es, ed, eac = oracle.score(pg, vidx, w[vidx], mode=mode, include=inc)
+            names = [f"S{s}" for s in (range(n) if samples is None else samples)]
+            got = {iid: (ac, d, s) for iid, ac, d, s in r.rows}
+            assert sorted(got) == sorted(names)
+            for k, iid in enumerate(names):
+                ac, d, s = got[iid]
+                assert ac == int(eac[k])
+                assert s == pytest.approx(es[k, 0], rel=1e-9, abs=1e-9) and d == pytest.approx(ed[k], rel=1e-9, abs=1e-9)
+    r = F.query("read_pgen", prefix + ".pgen", dosages=True, threads=threads, columns=["ID", "genotypes"])
+    assert len(r) == m
+    for vid, g in r.rows:
+        v = int(vid[1:])
+        assert [(-9.0 if x is None else x) for x in g] == want[v].tolist(), v
+    r = F.query("read_pgen", prefix + ".pgen", dosages=True, genotypes="columns", variants=[7, 2599, 64],
+                samples=["S300", "S5"], columns=["ID", "S5", "S300"])
+    assert [(vid, -9.0 if a is None else a, -9.0 if b is None else b) for vid, a, b in r.rows] == \
+        [(f"v{v}", want[v][5], want[v][300]) for v in (7, 2599, 64)]
