@@ -51,11 +51,13 @@ def parse_args():
     ap.add_argument("--samples", type=int, default=500_000)
     ap.add_argument("--ld-variants", type=int, default=20000, help="anchors of the ld workload")
     ap.add_argument("--ld-window", type=int, default=64, help="partners per anchor of the ld workload")
-    ap.add_argument("--workload", choices=["freq", "fused", "unpack", "score", "pca", "ld", "samplecounts"], default="freq")
+    ap.add_argument("--workload", choices=["freq", "fused", "unpack", "score", "pca", "ld", "samplecounts", "dosagefreq", "dosagescore"], default="freq")
     ap.add_argument("--n-pcs", type=int, default=10)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 disables)")
     ap.add_argument("--cpu-sample-variants", type=int, default=8192)
+    ap.add_argument("--dosage-rate", type=float, default=0.1,
+                    help="dosage workloads: fraction of samples with an explicit dosage per variant")
     ap.add_argument("--score-cols", type=int, default=16)
     ap.add_argument("--score-no-dosage-sum", action="store_true",
                     help="score workload without NAMED_ALLELE_DOSAGE_SUM (what SELECT IID, SCORE_SUM projects)")
@@ -140,6 +142,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     n = args.samples
+    if args.workload.startswith("dosage") and args.variants == 1_000_000:
+        args.variants = 250_000  # rows + presence bits + ranks + values of 1M variants do not fit one GPU
     v_begin, v_end = sharding.shard_range(rank, world, args.variants, args.scaling)
     m = v_end - v_begin
     ds = L.Dataset.synth(v_begin, v_end, n, SEED, MISSING_RATE)
@@ -219,6 +223,57 @@ def main():
         kernel_name = "k_unpack"
         metric = "read_pgen genotypes/s"
         dtype = "u8"
+    elif args.workload in ("dosagefreq", "dosagescore"):
+        # plink_freq(dosage := true) / plink_score over explicit dosages: synthetic 0x60-style tracks on every
+        # variant, --dosage-rate of the samples carrying a value (the rest fall back to their hardcall)
+        ds.synth_add_dosage(args.dosage_rate, SEED + 7)
+        words = (n + 63) // 64
+        # 2-bit record + presence bits + the explicit values; the score's explicit-entry sweep also needs the
+        # per-word ranks and reads the record a second time (hardcall sweep, then the dosage sweep)
+        algo_bytes = m * record_bytes + m * words * 8 + 2 * int(ds.info.dosage_value_ct)
+        if args.workload == "dosagescore":
+            algo_bytes += m * words * 4 + m * record_bytes
+        dtype = "u16"
+        if args.workload == "dosagefreq":
+            d_sums = torch.empty((m, 3), dtype=torch.int64, device=dev)
+            h_sums = torch.empty((m, 3), dtype=torch.int64, pin_memory=True)
+
+            def step(timed):
+                if timed:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e0.record(stream)
+                ds.dosage_sums_dev(v_begin, v_end, d_sums.data_ptr(), st)
+                if timed:
+                    e1.record(stream)
+                    kernel_events.append((e0, e1))
+                h_sums.copy_(d_sums, non_blocking=True)
+
+            kernel_name = "k_dosage_sums"
+            metric = "plink_freq(dosage) genotypes/s"
+        else:
+            rng = np.random.default_rng(SEED + 1)
+            weights = rng.standard_normal((m, 1))
+            plan = ds.score_plan(np.arange(v_begin, v_end, dtype=np.uint32), weights)
+            d_score = torch.empty((n, 1), dtype=torch.float64, device=dev)
+            d_dos = torch.empty(n, dtype=torch.float64, device=dev)
+            d_ac = torch.empty(n, dtype=torch.int32, device=dev)
+            dtype = "f64"
+
+            def step(timed):
+                if timed:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e0.record(stream)
+                plan.run_dev(d_score.data_ptr(), d_dos.data_ptr(), d_ac.data_ptr(), st)
+                if timed:
+                    e1.record(stream)
+                    kernel_events.append((e0, e1))
+                if dist is not None:
+                    dist.reduce(d_score, dst=0)
+
+            kernel_name = "k_score_gemv_pairs + k_score_dosage_fix"
+            metric = "plink_score(dosage) genotypes/s"
     elif args.workload == "samplecounts":
         # read_pfile orient := 'sample', genotypes := 'counts': per-sample {het, hom_alt, missing}
         # tallies over every variant (hom_ref by subtraction) -- one pass, three counter sets per lane
@@ -397,7 +452,9 @@ def main():
             "config": {
                 "workload": f"{args.workload}: {args.variants} variants x {n} samples "
                             f"({'per GPU' if args.scaling == 'weak' else 'total'}), 2-bit hardcalls resident in HBM, "
-                            f"seed {SEED}, {MISSING_RATE:.0%} missing",
+                            f"seed {SEED}, {MISSING_RATE:.0%} missing"
+                            + (f", dosage tracks on every variant with {args.dosage_rate:.0%} of samples explicit"
+                               if args.workload.startswith("dosage") else ""),
                 "variants_per_rank": m,
                 "samples": n,
                 "record_bytes": record_bytes,

@@ -59,6 +59,8 @@ typedef struct pgh_info {
 	uint64_t pitch_bytes;      /* device row stride of one record               */
 	uint32_t vrtype_hist[8];   /* number of records per main-track type (vrtype & 7) */
 	int32_t device;            /* HIP device ordinal                            */
+	uint32_t dosage_variant_ct; /* resident variants that carry a dosage track (vrtype & 0x60) */
+	uint64_t dosage_value_ct;   /* explicit dosages held for them                */
 } pgh_info;
 
 /* ---- library / device --------------------------------------------------- */
@@ -103,6 +105,10 @@ int pgh_from_host_rows(const uint8_t *rows, size_t row_stride, uint32_t variant_
  * ranks that own disjoint variant ranges hold slices of one global matrix. */
 int pgh_synth_create(uint32_t variant_begin, uint32_t variant_end, uint32_t sample_ct, uint64_t seed,
                      double missing_rate, pgh_dataset **out, char *errbuf);
+/* Gives every resident variant of a dataset without dosage tracks a seeded synthetic one:
+ * each sample carries an explicit dosage with probability `rate`, values uniform on 0..32768.
+ * Benchmark input of the shape `plink2 --import-dosage` leaves behind (vrtype 0x60). */
+int pgh_synth_add_dosage(pgh_dataset *ds, double rate, uint64_t seed, char *errbuf);
 /* The same generator on the host: one record (ceil(N/4) bytes) of variant v. */
 int pgh_synth_record_host(uint32_t v, uint32_t sample_ct, uint64_t seed, double missing_rate, uint8_t *out);
 /* Writes <prefix>.pgen (mode 0x10, vrtype-0 records), .pvar and .psam. */

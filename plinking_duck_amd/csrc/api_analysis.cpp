@@ -567,10 +567,15 @@ extern "C" int pgh_score_run_dev(const pgh_score_plan *plan, void *d_score_sum, 
 	double *ts = static_cast<double *>(plan->d_ts);
 	uint32_t *ac = static_cast<uint32_t *>(plan->d_ac);
 	const uint32_t n_hard = plan->n_hard, n_dos = plan->n_scored - plan->n_hard;
-	if (n_hard) {
-		PGH_HIP(pgh::LaunchScoreAccumulate(ds->View(), vlist, n_hard, weights, plan->n_cols, ts,
-		                                   static_cast<double *>(plan->d_td), ac,
-		                                   plan->mode != PGH_SCORE_CENTER && d_dosage_sum != nullptr,
+	// One weight column (the SQL contract): dosage-bearing variants ride the hardcall kernel with their
+	// dosage-mean tables and k_score_dosage_fix adds what the explicit entries change.  More columns:
+	// hardcall-only variants through the MFMA kernel, dosage-bearing ones through k_score_dosage.
+	const bool two_step = plan->n_cols == 1;
+	const uint32_t n_table = two_step ? plan->n_scored : n_hard;
+	const bool track = plan->mode != PGH_SCORE_CENTER && d_dosage_sum != nullptr;
+	if (n_table) {
+		PGH_HIP(pgh::LaunchScoreAccumulate(ds->View(), vlist, n_table, weights, plan->n_cols, ts,
+		                                   static_cast<double *>(plan->d_td), ac, track,
 		                                   static_cast<double *>(d_score_sum), static_cast<double *>(d_dosage_sum),
 		                                   static_cast<uint32_t *>(d_allele_ct), st),
 		        "score accumulate kernel");
@@ -582,22 +587,30 @@ extern "C" int pgh_score_run_dev(const pgh_score_plan *plan, void *d_score_sum, 
 	void *scratch = nullptr, *miss = nullptr;
 	hipError_t e = hipSuccess;
 	if (count_missing) {
-		const size_t scratch_bytes = pgh::MissingPerSampleScratchBytes(ds->record_bytes, std::max(n_hard, 1u));
+		const size_t scratch_bytes = pgh::MissingPerSampleScratchBytes(ds->record_bytes, std::max(n_table, 1u));
 		const size_t miss_bytes = sizeof(uint32_t) * ((N + 63) / 64 * 64);
 		PGH_HIP(hipMallocAsync(&scratch, scratch_bytes ? scratch_bytes : 16, st), "score scratch");
 		PGH_HIP(hipMallocAsync(&miss, miss_bytes, st), "score scratch");
 		e = hipMemsetAsync(miss, 0, miss_bytes, st);
-		if (e == hipSuccess && n_hard) {
-			e = pgh::LaunchMissingPerSample(ds->View(), 0, vlist, n_hard, ac, static_cast<uint32_t *>(scratch),
+		if (e == hipSuccess && n_table) {
+			e = pgh::LaunchMissingPerSample(ds->View(), 0, vlist, n_table, ac, static_cast<uint32_t *>(scratch),
 			                                static_cast<uint32_t *>(miss), st);
 		}
 	}
 	if (e == hipSuccess && n_dos) {
-		e = pgh::LaunchScoreDosage(ds->View(), ds->Dosage(), vlist + n_hard, n_dos,
-		                           weights + static_cast<uint64_t>(n_hard) * plan->n_cols, plan->n_cols, plan->n_cols,
-		                           ts + 4ull * n_hard, static_cast<double *>(plan->d_lin), ac + n_hard, plan->mode,
-		                           static_cast<double *>(d_score_sum), plan->n_cols, static_cast<double *>(d_dosage_sum),
-		                           static_cast<uint32_t *>(miss), st);
+		if (two_step) {
+			e = pgh::LaunchScoreDosageFix(ds->View(), ds->Dosage(), vlist + n_hard, n_dos, weights + n_hard, 1,
+			                              ts + 4ull * n_hard, static_cast<double *>(plan->d_lin), ac + n_hard,
+			                              static_cast<double *>(d_score_sum), 1,
+			                              track ? static_cast<double *>(d_dosage_sum) : nullptr,
+			                              static_cast<uint32_t *>(miss), st);
+		} else {
+			e = pgh::LaunchScoreDosage(ds->View(), ds->Dosage(), vlist + n_hard, n_dos,
+			                           weights + static_cast<uint64_t>(n_hard) * plan->n_cols, plan->n_cols, plan->n_cols,
+			                           ts + 4ull * n_hard, static_cast<double *>(plan->d_lin), ac + n_hard, plan->mode,
+			                           static_cast<double *>(d_score_sum), plan->n_cols,
+			                           static_cast<double *>(d_dosage_sum), static_cast<uint32_t *>(miss), st);
+		}
 	}
 	if (e == hipSuccess) {
 		e = pgh::LaunchAlleleCt(ac, plan->n_scored, static_cast<uint32_t *>(miss), N,

@@ -223,12 +223,12 @@ static int LoadDosageTracks(pgh_dataset *ds, const pgh::RecordFile &file, char *
 	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_dos_row_of), sizeof(int32_t) * range), "hipMalloc(dosage)");
 	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_dos_present), 8ull * rows * words), "hipMalloc(dosage)");
 	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_dos_rank), 4ull * rows * words), "hipMalloc(dosage)");
-	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_dos_val_off), 8ull * rows), "hipMalloc(dosage)");
-	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_dos_values), 2 * std::max<uint64_t>(capacity, 8)),
-	        "hipMalloc(dosage)");
+	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_dos_val_off), 8ull * (rows + 1)), "hipMalloc(dosage)");
+	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_dos_values), 2 * capacity + 32), "hipMalloc(dosage)");
+	PGH_HIP(hipMemset(ds->d_dos_values, 0, 2 * capacity + 32), "dosage memset");
 	PGH_HIP(hipMemcpy(ds->d_dos_row_of, ds->dos_row_of.data(), sizeof(int32_t) * range, hipMemcpyHostToDevice),
 	        "dosage upload");
-	std::vector<uint64_t> val_off(rows);
+	std::vector<uint64_t> val_off(rows + 1);
 	uint64_t filled = 0;
 	const uint32_t chunk_rows = std::max<uint32_t>(8, static_cast<uint32_t>((64ull << 20) / (2ull * N + 8ull * words)));
 	const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
@@ -282,7 +282,7 @@ static int LoadDosageTracks(pgh_dataset *ds, const pgh::RecordFile &file, char *
 			val_off[r0 + k] = filled + packed.size();
 			packed.insert(packed.end(), h_values[k].begin(), h_values[k].end());
 		}
-		if (filled + packed.size() > std::max<uint64_t>(capacity, 8)) {
+		if (filled + packed.size() > capacity) {
 			SetErr(errbuf, "dosage tracks hold more values than their records have bytes for");
 			return PGH_ERR_FORMAT;
 		}
@@ -295,10 +295,12 @@ static int LoadDosageTracks(pgh_dataset *ds, const pgh::RecordFile &file, char *
 		}
 		filled += packed.size();
 	}
-	PGH_HIP(hipMemcpy(ds->d_dos_val_off, val_off.data(), 8ull * rows, hipMemcpyHostToDevice), "dosage upload");
+	val_off[rows] = filled;
+	PGH_HIP(hipMemcpy(ds->d_dos_val_off, val_off.data(), 8ull * (rows + 1), hipMemcpyHostToDevice), "dosage upload");
 	PGH_HIP(pgh::LaunchDosageRank(ds->d_dos_present, rows, words, ds->d_dos_rank, hipStreamPerThread), "dosage rank kernel");
 	PGH_HIP(hipStreamSynchronize(hipStreamPerThread), "dosage rank sync");
 	ds->dos_rows = rows;
+	ds->dos_values = filled;
 	return PGH_OK;
 }
 
@@ -692,6 +694,52 @@ extern "C" int pgh_synth_create(uint32_t variant_begin, uint32_t variant_end, ui
 	return PGH_OK;
 }
 
+extern "C" int pgh_synth_add_dosage(pgh_dataset *ds, double rate, uint64_t seed, char *errbuf) {
+	if (!ds || ds->dos_rows || !(rate >= 0.0 && rate <= 1.0)) {
+		SetErr(errbuf, "bad argument (null dataset, tracks already present, or rate outside [0, 1])");
+		return PGH_ERR_ARG;
+	}
+	const uint32_t rows = ds->v_end - ds->v_begin;
+	const uint32_t words = (ds->sample_ct + 63) / 64;
+	if (rows == 0) {
+		return PGH_OK;
+	}
+	hipStream_t st = hipStreamPerThread;
+	ds->dos_row_of.resize(rows);
+	for (uint32_t i = 0; i < rows; i++) {
+		ds->dos_row_of[i] = static_cast<int32_t>(i);
+	}
+	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_dos_row_of), sizeof(int32_t) * rows), "hipMalloc(dosage)");
+	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_dos_present), 8ull * rows * words), "hipMalloc(dosage)");
+	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_dos_rank), 4ull * rows * words), "hipMalloc(dosage)");
+	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_dos_val_off), 8ull * (rows + 1)), "hipMalloc(dosage)");
+	PGH_HIP(hipMemcpyAsync(ds->d_dos_row_of, ds->dos_row_of.data(), sizeof(int32_t) * rows, hipMemcpyHostToDevice, st),
+	        "dosage upload");
+	PGH_HIP(pgh::LaunchSynthDosageBits(ds->d_dos_present, rows, words, ds->sample_ct, ds->v_begin, seed, rate, st),
+	        "synthetic dosage bits");
+	PGH_HIP(pgh::LaunchDosageRank(ds->d_dos_present, rows, words, ds->d_dos_rank, st), "dosage rank kernel");
+	PGH_HIP(pgh::LaunchDosageRowTotals(ds->d_dos_present, ds->d_dos_rank, rows, words, ds->d_dos_val_off, st),
+	        "dosage totals kernel");
+	std::vector<uint64_t> off(rows + 1);
+	PGH_HIP(hipMemcpyAsync(off.data(), ds->d_dos_val_off, 8ull * rows, hipMemcpyDeviceToHost, st), "dosage totals copy");
+	PGH_HIP(hipStreamSynchronize(st), "dosage totals sync");
+	uint64_t total = 0;
+	for (uint32_t r = 0; r < rows; r++) {
+		const uint64_t c = off[r];
+		off[r] = total;
+		total += c;
+	}
+	off[rows] = total;
+	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_dos_values), 2 * total + 32), "hipMalloc(dosage)");
+	PGH_HIP(hipMemsetAsync(ds->d_dos_values, 0, 2 * total + 32, st), "dosage memset");
+	PGH_HIP(hipMemcpyAsync(ds->d_dos_val_off, off.data(), 8ull * (rows + 1), hipMemcpyHostToDevice, st), "dosage upload");
+	PGH_HIP(pgh::LaunchSynthDosageValues(ds->d_dos_values, total, seed, st), "synthetic dosage values");
+	PGH_HIP(hipStreamSynchronize(st), "synthetic dosage sync");
+	ds->dos_rows = rows;
+	ds->dos_values = total;
+	return PGH_OK;
+}
+
 extern "C" int pgh_synth_record_host(uint32_t v, uint32_t sample_ct, uint64_t seed, double missing_rate,
                                      uint8_t *out) {
 	if (!out || sample_ct == 0) {
@@ -839,6 +887,8 @@ extern "C" int pgh_get_info(const pgh_dataset *ds, pgh_info *out) {
 	out->variant_end = ds->v_end;
 	out->pitch_bytes = ds->pitch;
 	out->device = ds->device;
+	out->dosage_variant_ct = ds->dos_rows;
+	out->dosage_value_ct = ds->dos_values;
 	return PGH_OK;
 }
 

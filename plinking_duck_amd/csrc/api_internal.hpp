@@ -47,6 +47,7 @@ struct pgh_dataset {
 	uint8_t *d_rows = nullptr;
 	// explicit dosages of the resident range (dosage.hpp:DosageView); dos_rows == 0: hardcalls only
 	uint32_t dos_rows = 0;
+	uint64_t dos_values = 0; // explicit dosages held
 	std::vector<int32_t> dos_row_of;
 	int32_t *d_dos_row_of = nullptr;
 	uint64_t *d_dos_present = nullptr;

@@ -11,6 +11,7 @@
 #include "dosage.hpp"
 
 #include "device_utils.hpp"
+#include "synth.hpp"
 
 namespace pgh {
 
@@ -86,6 +87,59 @@ __global__ __launch_bounds__(256) void k_dosage_rank(const uint64_t *__restrict_
 	}
 }
 
+// ---- synthetic tracks for the benchmarks (the file-free twin of LaunchSynthFill) ----------------
+__global__ __launch_bounds__(256) void k_synth_dosage_bits(uint64_t *__restrict__ present, uint32_t words,
+                                                           uint32_t sample_ct, uint32_t variant0, uint64_t seed,
+                                                           uint32_t threshold) {
+	const uint64_t key = Mix64(Mix64(seed) ^ (static_cast<uint64_t>(variant0 + blockIdx.x) << 32) ^ 0x5851f42d4c957f2dULL);
+	for (uint32_t w = threadIdx.x; w < words; w += 256u) {
+		uint64_t bits = 0;
+		for (uint32_t b = 0; b < 64u; b++) {
+			const uint32_t s = 64u * w + b;
+			if (s < sample_ct && static_cast<uint32_t>(Mix64(key ^ s)) < threshold) {
+				bits |= 1ull << b;
+			}
+		}
+		present[static_cast<uint64_t>(blockIdx.x) * words + w] = bits;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_dosage_row_totals(const uint64_t *__restrict__ present,
+                                                           const uint32_t *__restrict__ rank, uint32_t words,
+                                                           uint32_t rows, uint64_t *__restrict__ totals) {
+	const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+	if (r < rows) {
+		const uint64_t last = static_cast<uint64_t>(r) * words + (words - 1);
+		totals[r] = rank[last] + static_cast<uint64_t>(__popcll(present[last]));
+	}
+}
+
+__global__ __launch_bounds__(256) void k_synth_dosage_values(uint16_t *__restrict__ values, uint64_t count,
+                                                             uint64_t seed) {
+	const uint64_t key = Mix64(seed ^ 0x2545f4914f6cdd1dULL);
+	for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < count; i += gridDim.x * 256ull) {
+		values[i] = static_cast<uint16_t>(((Mix64(key ^ i) & 0xffffffffull) * 32769ull) >> 32);
+	}
+}
+
+// 16 presence bits -> one bit in every even position of a 32-bit word (the 01 slot mask of 16 samples)
+__device__ __forceinline__ uint32_t Spread16(uint32_t x) {
+	x = (x | (x << 8)) & 0x00ff00ffu;
+	x = (x | (x << 4)) & 0x0f0f0f0fu;
+	x = (x | (x << 2)) & 0x33333333u;
+	x = (x | (x << 1)) & 0x55555555u;
+	return x;
+}
+
+// One workgroup per variant, two sweeps:
+//   A. the hardcalls of the samples WITHOUT an explicit dosage: a lane takes 64 samples per trip
+//      (16 bytes of the row + their presence word), spreads the presence bits over the 2-bit slots
+//      and counts hets and hom-alts among the rest -- the tally kernel's popcount algebra;
+//   B. the explicit values.  Without a sample subset they are one contiguous run of uint16, streamed
+//      16 bytes per lane with no reference to which sample owns which; with a subset a lane owns a
+//      64-sample word and walks its included presence bits through the rank table.
+// sum = 16384 (hets + 2 hom-alts) + sum of values, and likewise for the squares and the count.
+template <bool HAS_INCLUDE>
 __global__ __launch_bounds__(256) void k_dosage_sums(const uint8_t *__restrict__ rows, uint64_t pitch,
                                                      uint32_t sample_ct, DosageView dos, uint32_t v0,
                                                      const uint32_t *__restrict__ vlist,
@@ -94,22 +148,65 @@ __global__ __launch_bounds__(256) void k_dosage_sums(const uint8_t *__restrict__
 	__shared__ uint64_t s_part[4][3];
 	const uint32_t i = blockIdx.x;
 	const uint32_t lv = vlist ? vlist[i] : v0 + i;
-	const uint32_t *row32 = reinterpret_cast<const uint32_t *>(rows + static_cast<uint64_t>(lv) * pitch);
-	const DosageRow row = RowOf(dos, lv);
+	const uint4 *row128 = reinterpret_cast<const uint4 *>(rows + static_cast<uint64_t>(lv) * pitch);
+	const int32_t r = dos.row_of ? dos.row_of[lv] : -1;
+	const uint64_t *present = r >= 0 ? dos.present + static_cast<uint64_t>(r) * dos.words : nullptr;
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	uint64_t sum = 0, ssq = 0, nm = 0;
-	for (uint32_t w = wave; w < dos.words; w += 4u) {
-		const uint32_t s = 64u * w + lane;
-		if (s >= sample_ct || (include && !((include[w] >> lane) & 1ull))) {
-			continue;
+	uint32_t het = 0, hom_alt = 0, called = 0, n_explicit = 0, vsum = 0;
+	uint64_t vssq = 0;
+	for (uint32_t w = threadIdx.x; w < dos.words; w += 256u) {
+		const uint4 q = LoadStream(row128 + w);
+		const uint64_t e = present ? present[w] : 0ull;
+		const uint32_t live = sample_ct - 64u * w;
+		uint64_t m = live >= 64u ? ~0ull : (1ull << live) - 1ull;
+		if (HAS_INCLUDE) {
+			m &= include[w];
 		}
-		const uint64_t u = DosageOrCall(row, row32, s);
-		if (u != kNoDosage) {
-			sum += u;
-			ssq += u * u;
-			nm++;
+		const uint64_t keep = m & ~e;
+		const uint32_t x[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			const uint32_t kk = Spread16(static_cast<uint32_t>(keep >> (16 * j)) & 0xffffu);
+			const uint32_t lo = x[j] & kLow, hi = (x[j] >> 1) & kLow;
+			het += __popc(lo & ~hi & kk);
+			hom_alt += __popc(hi & ~lo & kk);
+			called += __popc(kk & ~(lo & hi));
+		}
+		if (HAS_INCLUDE) {
+			uint64_t take = e & m;
+			const uint16_t *vals = dos.values + dos.val_off[r] + dos.rank[static_cast<uint64_t>(r) * dos.words + w];
+			while (take) {
+				const uint32_t b = static_cast<uint32_t>(__ffsll(static_cast<long long>(take))) - 1u;
+				const uint32_t u = vals[__popcll(e & ((1ull << b) - 1ull))];
+				vsum += u;
+				vssq += static_cast<uint64_t>(u) * u;
+				n_explicit++;
+				take &= take - 1ull;
+			}
 		}
 	}
+	if (!HAS_INCLUDE && present) {
+		const uint64_t o0 = dos.val_off[r], o1 = dos.val_off[r + 1];
+		for (uint64_t at = (o0 & ~7ull) + 8ull * threadIdx.x; at < o1; at += 8ull * 256u) {
+			const uint4 q = LoadStream(reinterpret_cast<const uint4 *>(dos.values + at));
+			const uint32_t x[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+			for (int j = 0; j < 8; j++) {
+				const uint64_t idx = at + j;
+				const uint32_t u = (x[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+				if (idx >= o0 && idx < o1) {
+					vsum += u;
+					vssq += static_cast<uint64_t>(u) * u;
+				}
+			}
+		}
+		if (threadIdx.x == 0) {
+			n_explicit = static_cast<uint32_t>(o1 - o0);
+		}
+	}
+	uint64_t sum = 16384ull * (het + 2ull * hom_alt) + vsum;
+	uint64_t ssq = 16384ull * 16384ull * (het + 4ull * hom_alt) + vssq;
+	uint64_t nm = static_cast<uint64_t>(called) + n_explicit;
 	sum = WaveSum64(sum);
 	ssq = WaveSum64(ssq);
 	nm = WaveSum64(nm);
@@ -194,14 +291,16 @@ __global__ __launch_bounds__(256) void k_score_tables_dosage(const uint64_t *__r
 	for (int g = 0; g < 4; g++) {
 		ts[4ull * i + g] = s[g];
 		td[4ull * i + g] = d[g];
-		lin[4ull * i + g] = l[g];
+		lin[4ull * i + g] = inc ? l[g] : 0.0; // a skipped variant contributes nothing, dosage or call
 	}
 	ac[i] = inc;
 }
 
 // One lane per sample, a slice of the scored variants per workgroup row (the shape of
 // score.hip:k_score_accumulate); per variant the lane takes its explicit dosage through the
-// affine map, or its call through the code table.
+// affine map, or its call through the code table.  Variants go eight at a time: first every
+// load that does not depend on another (presence word, rank, the 2-bit word), then the eight
+// value loads, then the arithmetic -- the loop is latency-bound otherwise.
 template <int NCOLS>
 __global__ __launch_bounds__(256) void k_score_dosage(const uint8_t *__restrict__ rows, uint64_t pitch,
                                                       uint32_t sample_ct, DosageView dos,
@@ -213,13 +312,20 @@ __global__ __launch_bounds__(256) void k_score_dosage(const uint8_t *__restrict_
                                                       double *__restrict__ score, double *__restrict__ dosage_sum,
                                                       uint32_t *__restrict__ miss) {
 	constexpr uint32_t kStage = 64;
+	constexpr uint32_t kGroup = 8;
 	__shared__ double s_ts[kStage][4];
 	__shared__ double s_lin[kStage][4];
 	__shared__ double s_w[kStage][NCOLS];
-	__shared__ uint32_t s_ac[kStage];
-	__shared__ uint32_t s_v[kStage];
-	const uint32_t s = blockIdx.x * 256u + threadIdx.x;
-	const bool live = s < sample_ct;
+	__shared__ uint64_t s_row[kStage];  // byte offset of the variant's 2-bit row
+	__shared__ uint64_t s_bits[kStage]; // word offset of its presence / rank row
+	__shared__ uint64_t s_vals[kStage]; // where its values start
+	__shared__ uint32_t s_on[kStage];   // ~0: scored and carrying a track; 0 otherwise (presence reads as empty)
+	__shared__ uint32_t s_counts[kStage];
+	const uint32_t s = min(blockIdx.x * 256u + threadIdx.x, sample_ct - 1u);
+	const bool live = blockIdx.x * 256u + threadIdx.x < sample_ct;
+	const uint32_t w = s >> 6, b = s & 63u;
+	const uint64_t below = (1ull << b) - 1ull;
+	const uint32_t shift = 2u * (s & 15u);
 	const uint32_t i_begin = blockIdx.y * slice_len;
 	const uint32_t i_end = min(i_begin + slice_len, n_scored);
 	double acc[NCOLS];
@@ -232,52 +338,63 @@ __global__ __launch_bounds__(256) void k_score_dosage(const uint8_t *__restrict_
 	for (uint32_t base = i_begin; base < i_end; base += kStage) {
 		const uint32_t cnt = min(kStage, i_end - base);
 		__syncthreads();
-		for (uint32_t k = threadIdx.x; k < cnt * 4u; k += 256u) {
-			s_ts[k >> 2][k & 3] = ts[4ull * base + k];
-			s_lin[k >> 2][k & 3] = lin[4ull * base + k];
+		for (uint32_t k = threadIdx.x; k < kStage * 4u; k += 256u) {
+			const bool in = (k >> 2) < cnt;
+			s_ts[k >> 2][k & 3] = in ? ts[4ull * base + k] : 0.0;
+			s_lin[k >> 2][k & 3] = in ? lin[4ull * base + k] : 0.0;
 		}
-		for (uint32_t k = threadIdx.x; k < cnt * NCOLS; k += 256u) {
-			const uint32_t c = k % NCOLS;
-			s_w[k / NCOLS][c] = c < n_cols ? weights[static_cast<uint64_t>(base + k / NCOLS) * w_stride + c] : 0.0;
+		for (uint32_t k = threadIdx.x; k < kStage * NCOLS; k += 256u) {
+			const uint32_t c = k % NCOLS, v = k / NCOLS;
+			s_w[v][c] = (v < cnt && c < n_cols) ? weights[static_cast<uint64_t>(base + v) * w_stride + c] : 0.0;
 		}
-		for (uint32_t k = threadIdx.x; k < cnt; k += 256u) {
-			s_ac[k] = ac[base + k];
-			s_v[k] = vlist[base + k];
+		for (uint32_t k = threadIdx.x; k < kStage; k += 256u) {
+			// entries past the slice read variant 0 with empty tables: they add nothing
+			const uint32_t lv = k < cnt ? vlist[base + k] : vlist[i_begin];
+			const int32_t r = k < cnt ? dos.row_of[lv] : -1;
+			const uint32_t on = k < cnt ? ac[base + k] : 0u;
+			s_row[k] = static_cast<uint64_t>(lv) * pitch;
+			s_bits[k] = static_cast<uint64_t>(r < 0 ? 0 : r) * dos.words;
+			s_vals[k] = r < 0 ? 0ull : dos.val_off[r];
+			s_on[k] = (r >= 0 && on != 0u) ? ~0u : 0u;
+			s_counts[k] = on != 0u;
 		}
 		__syncthreads();
-		if (!live) {
-			continue;
-		}
-		for (uint32_t k = 0; k < cnt; k++) {
-			if (s_ac[k] == 0) {
-				continue; // nobody observed, or no variance under center: the reference skips the variant
+		for (uint32_t k0 = 0; k0 < kStage && k0 < cnt; k0 += kGroup) {
+			uint64_t bits[kGroup];
+			uint32_t rk[kGroup], word[kGroup], u[kGroup];
+#pragma unroll
+			for (uint32_t j = 0; j < kGroup; j++) {
+				const uint32_t k = k0 + j;
+				bits[j] = dos.present[s_bits[k] + w];
+				rk[j] = dos.rank[s_bits[k] + w];
+				word[j] = reinterpret_cast<const uint32_t *>(rows + s_row[k])[s >> 4];
 			}
-			const uint32_t lv = s_v[k];
-			const uint32_t *row32 = reinterpret_cast<const uint32_t *>(rows + static_cast<uint64_t>(lv) * pitch);
-			const DosageRow row = RowOf(dos, lv);
-			double x;
-			bool explicit_dosage = false;
-			uint32_t u = 0;
-			if (row.present) {
-				const uint32_t w = s >> 6, b = s & 63u;
-				const uint64_t bits = row.present[w];
-				if ((bits >> b) & 1ull) {
-					explicit_dosage = true;
-					u = row.values[row.rank[w] + static_cast<uint32_t>(__popcll(bits & ((1ull << b) - 1ull)))];
+#pragma unroll
+			for (uint32_t j = 0; j < kGroup; j++) {
+				const uint32_t k = k0 + j;
+				bits[j] &= static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(s_on[k]))); // all ones or zero
+				u[j] = 0;
+				if ((bits[j] >> b) & 1ull) {
+					u[j] = dos.values[s_vals[k] + rk[j] + static_cast<uint32_t>(__popcll(bits[j] & below))];
 				}
 			}
-			if (explicit_dosage) {
-				const double d = static_cast<double>(u) * 0x1p-14;
-				x = ((s_lin[k][0] * d + s_lin[k][1]) - s_lin[k][2]) * s_lin[k][3];
-			} else {
-				const uint32_t g = (row32[s >> 4] >> (2u * (s & 15u))) & 3u;
-				x = s_ts[k][g];
-				missed += g == 3u;
-			}
-			dsum += x;
 #pragma unroll
-			for (int c = 0; c < NCOLS; c++) {
-				acc[c] = fma(s_w[k][c], x, acc[c]);
+			for (uint32_t j = 0; j < kGroup; j++) {
+				const uint32_t k = k0 + j;
+				const uint32_t g = (word[j] >> shift) & 3u;
+				double x;
+				if ((bits[j] >> b) & 1ull) {
+					const double d = static_cast<double>(u[j]) * 0x1p-14;
+					x = ((s_lin[k][0] * d + s_lin[k][1]) - s_lin[k][2]) * s_lin[k][3];
+				} else {
+					x = s_ts[k][g];
+					missed += (g == 3u) & s_counts[k];
+				}
+				dsum += x;
+#pragma unroll
+				for (int c = 0; c < NCOLS; c++) {
+					acc[c] = fma(s_w[k][c], x, acc[c]);
+				}
 			}
 		}
 	}
@@ -297,6 +414,136 @@ __global__ __launch_bounds__(256) void k_score_dosage(const uint8_t *__restrict_
 	}
 }
 
+// plink_score's single weight column, the fast way round.  A sample's contribution at a variant is
+//     ts[call]                                   without an explicit dosage,
+//     ts[call] + (affine(dosage) - ts[call])     with one,
+// so the dosage-bearing variants first go through the hardcall kernel with their (dosage-mean) tables
+// (score.hip, a few instructions per sample), and this kernel adds the bracket for the explicit
+// entries only.  A lane owns a 64-sample word of a 4096-sample tile and walks its presence bits in
+// order -- the values are consumed in the order they are stored, so no rank arithmetic per entry --
+// and the tile's sums live in LDS (FP64 LDS atomics: lanes of one instruction never share a sample).
+// Work is proportional to the explicit entries: ~30 instructions per entry instead of ~40 per sample.
+template <bool TRACK>
+__global__ __launch_bounds__(1024, 8) void k_score_dosage_fix(const uint8_t *__restrict__ rows, uint64_t pitch,
+                                                           uint32_t sample_ct, DosageView dos,
+                                                           const uint32_t *__restrict__ vlist, uint32_t n_scored,
+                                                           uint32_t slice_len, const double *__restrict__ weights,
+                                                           uint32_t w_stride, const double *__restrict__ ts,
+                                                           const double *__restrict__ lin,
+                                                           const uint32_t *__restrict__ ac,
+                                                           double *__restrict__ score, uint32_t out_stride,
+                                                           double *__restrict__ dosage_sum,
+                                                           uint32_t *__restrict__ miss) {
+	constexpr uint32_t kPad = 65;    // row stride of the tile in LDS: spreads equal bit positions over the banks
+	constexpr uint32_t kWaves = 16;  // sixteen waves share one tile: the loop is a chain of memory latencies
+	constexpr uint32_t kChunk = 128; // variants whose constants are staged in LDS at a time
+	__shared__ double s_acc[64 * kPad];
+	__shared__ double s_dsum[TRACK ? 64 * kPad : 1];
+	__shared__ uint64_t s_row[kChunk], s_bits[kChunk], s_vals[kChunk]; // row bytes / presence row / first value
+	__shared__ double s_wt[kChunk], s_t[kChunk][4], s_l[kChunk][4];
+	__shared__ uint32_t s_on[kChunk];
+	for (uint32_t t = threadIdx.x; t < 64 * kPad; t += 64u * kWaves) {
+		s_acc[t] = 0.0;
+		if (TRACK) {
+			s_dsum[t] = 0.0;
+		}
+	}
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint32_t w = blockIdx.x * 64u + lane;
+	const bool in_row = w < dos.words;
+	const uint32_t i_begin = blockIdx.y * slice_len;
+	const uint32_t i_end = min(i_begin + slice_len, n_scored);
+	for (uint32_t base = i_begin; base < i_end; base += kChunk) {
+		const uint32_t cnt = min(kChunk, i_end - base);
+		__syncthreads();
+		if (threadIdx.x < cnt) {
+			const uint32_t i = base + threadIdx.x;
+			const uint32_t lv = vlist[i];
+			const int32_t r = dos.row_of[lv];
+			s_on[threadIdx.x] = ac[i] != 0u && r >= 0;
+			s_row[threadIdx.x] = static_cast<uint64_t>(lv) * pitch;
+			s_bits[threadIdx.x] = static_cast<uint64_t>(r < 0 ? 0 : r) * dos.words;
+			s_vals[threadIdx.x] = r < 0 ? 0ull : dos.val_off[r];
+			s_wt[threadIdx.x] = weights[static_cast<uint64_t>(i) * w_stride];
+		}
+		for (uint32_t k = threadIdx.x; k < cnt * 4u; k += 64u * kWaves) {
+			s_t[k >> 2][k & 3] = ts[4ull * base + k];
+			s_l[k >> 2][k & 3] = lin[4ull * base + k];
+		}
+		__syncthreads();
+	for (uint32_t k = wave; k < cnt; k += kWaves) {
+		if (!s_on[k]) {
+			continue; // skipped by the reference (nobody observed, or no variance under center)
+		}
+		const uint64_t at = s_bits[k] + w;
+		uint64_t e = in_row ? dos.present[at] : 0ull;
+		const uint32_t rk = in_row ? dos.rank[at] : 0u;
+		uint4 q = make_uint4(0, 0, 0, 0);
+		if (in_row) {
+			q = *reinterpret_cast<const uint4 *>(rows + s_row[k] + 16ull * w);
+		}
+		if (__ballot(e != 0ull) == 0ull) {
+			continue; // no explicit dosage in this tile
+		}
+		const uint16_t *vals = dos.values + s_vals[k] + rk;
+		const double wt = s_wt[k];
+		const double l0 = s_l[k][0], l1 = s_l[k][1], l2 = s_l[k][2], l3 = s_l[k][3];
+#define PGH_DOSAGE_ENTRY(U)                                                                                            \
+	{                                                                                                                  \
+		const uint32_t b = static_cast<uint32_t>(__ffsll(static_cast<long long>(e))) - 1u;                             \
+		e &= e - 1ull;                                                                                                 \
+		const uint32_t word = b < 32u ? (b < 16u ? q.x : q.y) : (b < 48u ? q.z : q.w);                                 \
+		const uint32_t code = (word >> (2u * (b & 15u))) & 3u;                                                         \
+		const double table = s_t[k][code];                                                                             \
+		const double d = static_cast<double>(U) * 0x1p-14;                                                             \
+		const double delta = ((l0 * d + l1) - l2) * l3 - table;                                                        \
+		atomicAdd(&s_acc[lane * kPad + b], wt * delta);                                                                \
+		if (TRACK) {                                                                                                   \
+			atomicAdd(&s_dsum[lane * kPad + b], delta);                                                                \
+		}                                                                                                              \
+		if (miss && code == 3u) {                                                                                      \
+			atomicSub(miss + 64u * w + b, 1u); /* it has a dosage: not missing after all */                            \
+		}                                                                                                              \
+	}
+		// the first eight values of the word are fetched together (one memory latency, not one per entry)
+		const uint32_t have = static_cast<uint32_t>(__popcll(e));
+#define PGH_AHEAD(P, J0, J1)                                                                                           \
+	const uint32_t p##P = ((J0) < have ? vals[J0] : 0u) | (((J1) < have ? vals[J1] : 0u) << 16); /* two per register */
+		PGH_AHEAD(0, 0, 1) PGH_AHEAD(1, 2, 3) PGH_AHEAD(2, 4, 5) PGH_AHEAD(3, 6, 7)
+#undef PGH_AHEAD
+#define PGH_STEP(P)                                                                                                    \
+	if (e) {                                                                                                           \
+		PGH_DOSAGE_ENTRY(p##P & 0xffffu)                                                                               \
+	}                                                                                                                  \
+	if (e) {                                                                                                           \
+		PGH_DOSAGE_ENTRY(p##P >> 16)                                                                                   \
+	}
+		PGH_STEP(0) PGH_STEP(1) PGH_STEP(2) PGH_STEP(3)
+#undef PGH_STEP
+		uint32_t n = 8;
+		while (e) {
+			const uint32_t u = vals[n++];
+			PGH_DOSAGE_ENTRY(u)
+		}
+#undef PGH_DOSAGE_ENTRY
+	}
+	}
+	__syncthreads();
+	for (uint32_t t = threadIdx.x; t < 4096u; t += 64u * kWaves) {
+		const uint32_t s = blockIdx.x * 4096u + t;
+		const uint32_t at = (t >> 6) * kPad + (t & 63u);
+		if (s < sample_ct) {
+			if (s_acc[at] != 0.0) {
+				unsafeAtomicAdd(score + static_cast<uint64_t>(s) * out_stride, s_acc[at]);
+			}
+			if (TRACK && s_dsum[at] != 0.0) {
+				unsafeAtomicAdd(dosage_sum + s, s_dsum[at]);
+			}
+		}
+	}
+}
+
 } // namespace
 
 hipError_t LaunchDosageRank(const uint64_t *present, uint32_t rows, uint32_t words, uint32_t *rank,
@@ -308,13 +555,46 @@ hipError_t LaunchDosageRank(const uint64_t *present, uint32_t rows, uint32_t wor
 	return hipGetLastError();
 }
 
+hipError_t LaunchSynthDosageBits(uint64_t *present, uint32_t rows, uint32_t words, uint32_t sample_ct, uint32_t variant0,
+                                 uint64_t seed, double rate, hipStream_t stream) {
+	if (rows == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_synth_dosage_bits, dim3(rows), dim3(256), 0, stream, present, words, sample_ct, variant0, seed,
+	                   SynthMissThreshold(rate));
+	return hipGetLastError();
+}
+
+hipError_t LaunchDosageRowTotals(const uint64_t *present, const uint32_t *rank, uint32_t rows, uint32_t words,
+                                 uint64_t *totals, hipStream_t stream) {
+	if (rows == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_dosage_row_totals, dim3((rows + 255) / 256), dim3(256), 0, stream, present, rank, words, rows,
+	                   totals);
+	return hipGetLastError();
+}
+
+hipError_t LaunchSynthDosageValues(uint16_t *values, uint64_t count, uint64_t seed, hipStream_t stream) {
+	if (count == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_synth_dosage_values, dim3(4096), dim3(256), 0, stream, values, count, seed);
+	return hipGetLastError();
+}
+
 hipError_t LaunchDosageSums(const RowView &view, const DosageView &dos, uint32_t v0, const uint32_t *vlist,
                             uint32_t n_var, const uint64_t *include, uint64_t *out, hipStream_t stream) {
 	if (n_var == 0) {
 		return hipSuccess;
 	}
-	hipLaunchKernelGGL(k_dosage_sums, dim3(n_var), dim3(256), 0, stream, view.rows, view.pitch, view.sample_ct, dos, v0,
-	                   vlist, include, out);
+	if (include) {
+		hipLaunchKernelGGL(k_dosage_sums<true>, dim3(n_var), dim3(256), 0, stream, view.rows, view.pitch, view.sample_ct,
+		                   dos, v0, vlist, include, out);
+	} else {
+		hipLaunchKernelGGL(k_dosage_sums<false>, dim3(n_var), dim3(256), 0, stream, view.rows, view.pitch, view.sample_ct,
+		                   dos, v0, vlist, include, out);
+	}
 	return hipGetLastError();
 }
 
@@ -373,6 +653,39 @@ hipError_t LaunchScoreDosage(const RowView &view, const DosageView &dos, const u
 			                   view.sample_ct, dos, vlist, n_scored, slice_len, weights + c0, w_stride, cols, out_stride, ts,
 			                   lin, ac, mode, score + c0, dsum, ms);
 		}
+	}
+	return hipGetLastError();
+}
+
+} // namespace pgh
+
+namespace pgh {
+
+hipError_t LaunchScoreDosageFix(const RowView &view, const DosageView &dos, const uint32_t *vlist, uint32_t n_scored,
+                                const double *weights, uint32_t w_stride, const double *ts, const double *lin,
+                                const uint32_t *ac, double *score, uint32_t out_stride, double *dosage_sum,
+                                uint32_t *miss, hipStream_t stream) {
+	if (n_scored == 0) {
+		return hipSuccess;
+	}
+	const uint32_t tiles = (dos.words + 63) / 64;
+	const uint32_t want_slices = (2048 + tiles - 1) / tiles;
+	uint32_t slice_len = (n_scored + want_slices - 1) / want_slices;
+	slice_len = ((slice_len + 127) / 128) * 128;
+	uint32_t slices = (n_scored + slice_len - 1) / slice_len;
+	if (slices > 65535u) {
+		slices = 65535u;
+		slice_len = ((n_scored + slices - 1) / slices + 127) / 128 * 128;
+		slices = (n_scored + slice_len - 1) / slice_len;
+	}
+	if (dosage_sum) {
+		hipLaunchKernelGGL(k_score_dosage_fix<true>, dim3(tiles, slices), dim3(1024), 0, stream, view.rows, view.pitch,
+		                   view.sample_ct, dos, vlist, n_scored, slice_len, weights, w_stride, ts, lin, ac, score, out_stride,
+		                   dosage_sum, miss);
+	} else {
+		hipLaunchKernelGGL(k_score_dosage_fix<false>, dim3(tiles, slices), dim3(1024), 0, stream, view.rows, view.pitch,
+		                   view.sample_ct, dos, vlist, n_scored, slice_len, weights, w_stride, ts, lin, ac, score, out_stride,
+		                   dosage_sum, miss);
 	}
 	return hipGetLastError();
 }

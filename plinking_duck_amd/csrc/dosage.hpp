@@ -18,14 +18,21 @@ struct DosageView {
 	const int32_t *row_of = nullptr;   // per resident variant: row below, or -1 (hardcalls only)
 	const uint64_t *present = nullptr; // rows x words
 	const uint32_t *rank = nullptr;    // rows x words
-	const uint64_t *val_off = nullptr; // rows: where the row's values start
-	const uint16_t *values = nullptr;
+	const uint64_t *val_off = nullptr; // rows + 1: where each row's values start, and where the last one ends
+	const uint16_t *values = nullptr;  // 16-byte aligned, padded by 16 bytes: rows are streamed in aligned 16-byte loads
 	uint32_t words = 0; // ceil(sample_ct / 64)
 };
 
 //! rank[r][w] = number of presence bits of row r before word w
 hipError_t LaunchDosageRank(const uint64_t *present, uint32_t rows, uint32_t words, uint32_t *rank,
                             hipStream_t stream);
+
+//! Seeded synthetic tracks: presence bits Bernoulli(rate) per (variant, sample); row totals; uniform values.
+hipError_t LaunchSynthDosageBits(uint64_t *present, uint32_t rows, uint32_t words, uint32_t sample_ct, uint32_t variant0,
+                                 uint64_t seed, double rate, hipStream_t stream);
+hipError_t LaunchDosageRowTotals(const uint64_t *present, const uint32_t *rank, uint32_t rows, uint32_t words,
+                                 uint64_t *totals, hipStream_t stream);
+hipError_t LaunchSynthDosageValues(uint16_t *values, uint64_t count, uint64_t seed, hipStream_t stream);
 
 //! PgrGetDCounts (src/plink_freq.cpp:475): per variant {sum of dosages, sum of squares, samples with a
 //! dosage or a call} on the 16384-per-copy scale, over the included samples; hardcalls count as 0 / 16384 / 32768.
@@ -51,5 +58,13 @@ hipError_t LaunchScoreDosage(const RowView &view, const DosageView &dos, const u
                              const double *weights, uint32_t w_stride, uint32_t n_cols, const double *ts,
                              const double *lin, const uint32_t *ac, int mode, double *score, uint32_t out_stride,
                              double *dosage_sum, uint32_t *miss, hipStream_t stream);
+
+//! The single-column form in two steps: the caller first runs the hardcall accumulate (LaunchScoreAccumulate)
+//! over the same variants with the same tables; this adds (affine(dosage) - ts[call]) for the explicit entries
+//! and takes the samples that have a dosage but a missing call back out of `miss` (NULL: not tracked).
+hipError_t LaunchScoreDosageFix(const RowView &view, const DosageView &dos, const uint32_t *vlist, uint32_t n_scored,
+                                const double *weights, uint32_t w_stride, const double *ts, const double *lin,
+                                const uint32_t *ac, double *score, uint32_t out_stride, double *dosage_sum,
+                                uint32_t *miss, hipStream_t stream);
 
 } // namespace pgh

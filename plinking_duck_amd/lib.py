@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "pgh_counts_range_dev", "pgh_freq_from_counts_dev", "pgh_fused_tally_dev", "pgh_missing_per_sample", "pgh_missing_per_sample_dev", "pgh_unpack_range",
     "pgh_unpack_range_dev", "pgh_score", "pgh_score_dev", "pgh_score_plan_create", "pgh_score_run_dev",
     "pgh_score_plan_destroy", "pgh_pca", "pgh_pca_sharded", "pgh_ld_pairs", "pgh_ld_pairs_dev", "pgh_sample_counts", "pgh_sample_counts_dev",
-    "pgh_dosage_sums", "pgh_dosage_sums_dev", "pgh_dosage_unpack", "pgh_dosage_unpack_dev", "pgh_reader_create", "pgh_reader_destroy",
+    "pgh_synth_add_dosage", "pgh_dosage_sums", "pgh_dosage_sums_dev", "pgh_dosage_unpack", "pgh_dosage_unpack_dev", "pgh_reader_create", "pgh_reader_destroy",
     "pgh_get_2bit", "pgh_get_counts", "pgh_get_missingness", "pgh_get_int8", "pgh_get_dosage_f64", "pgh_get_phased",
     "pgh_reader_error", "pgh_hwe_lnp", "pgh_hwe_xchr_lnp", "pgh_hwe_lnp_batch", "pgh_hwe_lnp_batch_dev", "pgh_hwe_xchr_lnp_batch",
 ]
@@ -39,6 +39,7 @@ class PghInfo(C.Structure):
         ("variant_end", C.c_uint32), ("has_dosage", C.c_uint32), ("has_phase", C.c_uint32),
         ("max_record_bytes", C.c_uint32), ("record_bytes", C.c_uint32), ("pitch_bytes", C.c_uint64),
         ("vrtype_hist", C.c_uint32 * 8), ("device", C.c_int32),
+        ("dosage_variant_ct", C.c_uint32), ("dosage_value_ct", C.c_uint64),
     ]
 
 
@@ -112,6 +113,7 @@ def _load():
         "pgh_hwe_xchr_lnp_batch": (C.c_int, [vp, u32, u32, vp, cp]),
         "pgh_sample_counts": (C.c_int, [vp, vp, u32, u32, vp, vp, cp]),
         "pgh_sample_counts_dev": (C.c_int, [vp, u32, u32, vp, vp, cp]),
+        "pgh_synth_add_dosage": (C.c_int, [vp, C.c_double, C.c_uint64, cp]),
         "pgh_dosage_sums": (C.c_int, [vp, vp, u32, u32, vp, vp, cp]),
         "pgh_dosage_sums_dev": (C.c_int, [vp, vp, u32, u32, vp, vp, cp]),
         "pgh_dosage_unpack": (C.c_int, [vp, vp, u32, u32, vp, vp, cp]),
@@ -442,6 +444,12 @@ class Dataset:
             v1 = self.v_end if v_end is None else v_end
             _check(_lib.pgh_sample_counts(self._h, subset._h if subset else None, v0, v1 - v0, None, _ptr(out), eb), eb)
         return out
+
+    def synth_add_dosage(self, rate: float, seed: int):
+        """Seeded synthetic dosage tracks on every resident variant (benchmark input)."""
+        eb = _errbuf()
+        _check(_lib.pgh_synth_add_dosage(self._h, rate, seed, eb), eb)
+        _lib.pgh_get_info(self._h, C.byref(self.info))
 
     def _range_or_list(self, v_begin, v_end, vidx):
         if vidx is not None:

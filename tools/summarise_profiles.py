@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "profiles")
 DST = os.path.join(ROOT, "profiles")
 
-DOMINANT = {"freq": "k_counts_block", "fused": "k_fused_tally", "unpack": "k_unpack_wide"}
+DOMINANT = {"freq": "k_counts_block", "fused": "k_fused_tally", "unpack": "k_unpack_wide", "dosagefreq": "k_dosage_sums"}
 
 
 def short(name):
@@ -37,14 +37,14 @@ def main():
     ap.add_argument("--round", type=int, required=True)
     args = ap.parse_args()
     tag = f"r{args.round:02d}"
-    for name in ("freq", "fused", "unpack", "score", "score1", "pca", "ld", "samplecounts"):
+    for name in ("freq", "fused", "unpack", "score", "score1", "pca", "ld", "samplecounts", "dosagefreq", "dosagescore"):
         src = os.path.join(SRC, f"bench_{name}.json")
         if os.path.exists(src):
             line = [ln for ln in open(src).read().splitlines() if ln.startswith("{")][-1]
             json.loads(line)
             with open(os.path.join(DST, f"{tag}_bench_{name}_n1.json"), "w") as f:
                 f.write(line + "\n")
-    for name in ("freq", "fused", "unpack", "score", "pca", "ld", "samplecounts"):
+    for name in ("freq", "fused", "unpack", "score", "pca", "ld", "samplecounts", "dosagefreq", "dosagescore"):
         src = os.path.join(SRC, f"{name}_kernel_stats.csv")
         if os.path.exists(src):
             shutil.copy(src, os.path.join(DST, f"{tag}_{name}_kernel_stats.csv"))
