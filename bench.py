@@ -229,10 +229,10 @@ def main():
         ds.synth_add_dosage(args.dosage_rate, SEED + 7)
         words = (n + 63) // 64
         # 2-bit record + presence bits + the explicit values; the score's explicit-entry sweep also needs the
-        # per-word ranks and reads the record a second time (hardcall sweep, then the dosage sweep)
+        # per-word ranks (its second read of the record, hardcall sweep then dosage sweep, is not counted)
         algo_bytes = m * record_bytes + m * words * 8 + 2 * int(ds.info.dosage_value_ct)
         if args.workload == "dosagescore":
-            algo_bytes += m * words * 4 + m * record_bytes
+            algo_bytes += m * words * 4
         dtype = "u16"
         if args.workload == "dosagefreq":
             d_sums = torch.empty((m, 3), dtype=torch.int64, device=dev)

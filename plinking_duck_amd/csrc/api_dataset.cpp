@@ -540,6 +540,7 @@ extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t va
 					batch.sample_ct = ds->sample_ct;
 					batch.id_bytes = ix.sample_id_bytes;
 					batch.error = d_error;
+					batch.aux_at = nullptr;
 					e = pgh::LaunchDecodeRecords(batch, any_ld, stream);
 				}
 			}

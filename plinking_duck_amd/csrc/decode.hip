@@ -20,41 +20,13 @@
 // launch after every other record of the batch is in place.
 #include "decode.hpp"
 
+#include "decode_device.hpp"
+
 namespace pgh {
 
 namespace {
 
 constexpr int kDecodeThreads = 256;
-
-struct Src {
-	const uint8_t *bytes;
-	uint64_t len; // readable bytes (the staging buffer is padded past this by 16 zero bytes)
-
-	__device__ uint32_t Byte(uint64_t at) const {
-		return at < len ? bytes[at] : 0u;
-	}
-	// little-endian 32-bit word at any byte offset
-	__device__ uint32_t Word(uint64_t at) const {
-		if (at + 4 > len) {
-			return Byte(at) | (Byte(at + 1) << 8) | (Byte(at + 2) << 16) | (Byte(at + 3) << 24);
-		}
-		const uint64_t base = at & ~3ull;
-		const uint32_t sh = static_cast<uint32_t>(at & 3) * 8;
-		const uint32_t lo = *reinterpret_cast<const uint32_t *>(bytes + base);
-		if (sh == 0) {
-			return lo;
-		}
-		const uint32_t hi = *reinterpret_cast<const uint32_t *>(bytes + base + 4); // inside the pad at worst
-		return (lo >> sh) | (hi << (32 - sh));
-	}
-	__device__ uint32_t Le(uint64_t at, uint32_t n) const {
-		uint32_t v = 0;
-		for (uint32_t i = 0; i < n; i++) {
-			v |= Byte(at + i) << (8 * i);
-		}
-		return v;
-	}
-};
 
 // 16 presence bits -> one bit in every even position of a 32-bit word
 __device__ inline uint32_t Spread16(uint32_t x) {
@@ -71,16 +43,6 @@ __device__ inline uint32_t InvertWord(uint32_t x) {
 }
 __device__ inline uint32_t InvertCode(uint32_t g) {
 	return g ^ ((~g & 1u) << 1);
-}
-
-__device__ inline uint32_t InclusiveScan(uint32_t v, uint32_t lane) {
-	for (int d = 1; d < 64; d <<= 1) {
-		uint32_t up = __shfl_up(v, d);
-		if (lane >= static_cast<uint32_t>(d)) {
-			v += up;
-		}
-	}
-	return v;
 }
 
 template <bool LD_PASS>
@@ -176,6 +138,9 @@ __global__ __launch_bounds__(kDecodeThreads) void k_decode_records(DecodeBatch b
 		row[w] = out;
 	}
 	if (kind == 0) {
+		if (b.aux_at && threadIdx.x == 0) {
+			b.aux_at[r] = cur; // aux tracks (phase, dosage) follow the literal bytes
+		}
 		return;
 	}
 	__threadfence();
@@ -186,42 +151,6 @@ __global__ __launch_bounds__(kDecodeThreads) void k_decode_records(DecodeBatch b
 
 	// ---- 2. difflist (wave 0) ----------------------------------------------------------
 	const uint32_t lane = threadIdx.x;
-	bool bad = false;
-	uint32_t len = 0;
-	{
-		uint32_t shift = 0;
-		while (true) {
-			const uint32_t byte = src.Byte(cur++);
-			len |= (byte & 0x7fu) << shift;
-			if (!(byte & 0x80u)) {
-				break;
-			}
-			shift += 7;
-			if (shift > 28 || cur > rec_end) {
-				bad = true;
-				break;
-			}
-		}
-	}
-	if (bad || len > N) {
-		if (lane == 0) {
-			atomicCAS(b.error, 0, static_cast<int>(b.variant0 + r) + 1);
-		}
-		return;
-	}
-	if (len == 0) {
-		return;
-	}
-	const uint32_t groups = (len + 63) / 64;
-	const uint64_t first_ids = cur;
-	const uint64_t values = first_ids + static_cast<uint64_t>(groups) * b.id_bytes + (groups - 1);
-	const uint64_t gaps = values + (len + 3) / 4;
-	if (gaps > rec_end) {
-		if (lane == 0) {
-			atomicCAS(b.error, 0, static_cast<int>(b.variant0 + r) + 1);
-		}
-		return;
-	}
 	// value the base row holds at sample `id`, in the code space of the finished row
 	auto base_code = [&](uint32_t id) -> uint32_t {
 		switch (kind) {
@@ -235,11 +164,9 @@ __global__ __launch_bounds__(kDecodeThreads) void k_decode_records(DecodeBatch b
 			return fill & 3u;
 		}
 	};
-	auto apply = [&](uint32_t entry, uint32_t id) {
-		if (id >= N) {
-			bad = true;
-			return;
-		}
+	// Each entry flips its 2-bit slot with one atomicXor of (base value ^ new value): entries never share
+	// a slot, so no ordering is needed.
+	auto apply = [&](uint32_t entry, uint32_t id, uint64_t values) {
 		uint32_t val = (src.Byte(values + (entry >> 2)) >> (2 * (entry & 3u))) & 3u;
 		if (kind == 3) {
 			val = InvertCode(val); // the reference patches, then inverts the whole row
@@ -249,59 +176,14 @@ __global__ __launch_bounds__(kDecodeThreads) void k_decode_records(DecodeBatch b
 			atomicXor(&row[id >> 4], flip << (2 * (id & 15u)));
 		}
 	};
-	// each group's first entry carries its sample id outright
-	for (uint32_t g = lane; g < groups; g += 64) {
-		apply(g * 64, src.Le(first_ids + static_cast<uint64_t>(g) * b.id_bytes, b.id_bytes));
-	}
-	// the other entries are varint gaps: varint k belongs to group k / 63, entry 64*(k/63) + k%63 + 1
-	const uint32_t n_gaps = len - groups;
-	uint32_t k_base = 0, carry_id = 0;
-	uint64_t pos = gaps;
-	const uint64_t lt_mask = (1ull << lane) - 1ull;
-	while (k_base < n_gaps) {
-		const bool in_rec = pos + lane < rec_end;
-		const uint32_t byte = in_rec ? src.Byte(pos + lane) : 0x80u;
-		const bool term = in_rec && !(byte & 0x80u);
-		const uint64_t terms = __ballot(term);
-		const uint64_t before = terms & lt_mask;
-		const uint32_t rank = static_cast<uint32_t>(__popcll(before));
-		const uint32_t start = before ? 64u - static_cast<uint32_t>(__clzll(before)) : 0u;
-		const uint32_t sh = 7u * (lane - start);
-		const bool take = term && rank < n_gaps - k_base;
-		const uint64_t taken = __ballot(take);
-		if (taken == 0 || __ballot(in_rec && sh > 28u && rank < n_gaps - k_base) != 0) {
-			bad = true; // no complete gap in 64 bytes, or a gap longer than five bytes
-			break;
+	uint32_t len = 0;
+	const bool ok = WalkDifflistIds(src, cur, rec_end, N, b.id_bytes, true, len, apply);
+	if (lane == 0) {
+		if (!ok) {
+			atomicCAS(b.error, 0, static_cast<int>(b.variant0 + r) + 1);
+		} else if (b.aux_at) {
+			b.aux_at[r] = cur;
 		}
-		const uint32_t last = 63u - static_cast<uint32_t>(__clzll(taken));
-		// payload of bytes past the last taken terminator must not leak into the scan of the next trip;
-		// inside this trip they sit above every taken lane, so they never reach one
-		const uint32_t sum = InclusiveScan(sh <= 28u ? (byte & 0x7fu) << sh : 0u, lane);
-		const uint32_t g0 = k_base / 63;
-		const uint32_t in_g0 = 63u * (g0 + 1) - k_base; // gaps of this trip that still belong to g0
-		// running sum at the end of g0's part of this trip (0 when g0 does not end here)
-		const uint64_t edge = __ballot(take && rank + 1 == in_g0);
-		const uint32_t sum_g0 = edge ? __shfl(sum, static_cast<int>(__ffsll(static_cast<long long>(edge)) - 1)) : 0u;
-		uint32_t id = 0;
-		if (take) {
-			const uint32_t k = k_base + rank;
-			const uint32_t g = k / 63;
-			if (g == g0) {
-				const uint32_t from = (k_base % 63 == 0)
-				                          ? src.Le(first_ids + static_cast<uint64_t>(g0) * b.id_bytes, b.id_bytes)
-				                          : carry_id;
-				id = from + sum;
-			} else {
-				id = src.Le(first_ids + static_cast<uint64_t>(g) * b.id_bytes, b.id_bytes) + (sum - sum_g0);
-			}
-			apply(g * 64 + k % 63 + 1, id);
-		}
-		carry_id = __shfl(id, static_cast<int>(last));
-		k_base += static_cast<uint32_t>(__popcll(taken));
-		pos += last + 1;
-	}
-	if (__ballot(bad) != 0 && lane == 0) {
-		atomicCAS(b.error, 0, static_cast<int>(b.variant0 + r) + 1);
 	}
 }
 

@@ -24,6 +24,7 @@ struct DecodeBatch {
 	uint32_t sample_ct;
 	uint32_t id_bytes;         // width of a difflist sample id
 	int *error;                // set (once) to 1 + the variant index of a malformed record
+	uint64_t *aux_at;          // [n] or NULL: offset into bytes of the first byte after each record's main track
 };
 
 // Expands every record of the batch into its row: types 0/1/4/6/7 in one launch, the

@@ -10,6 +10,7 @@
 // loads and the values it touches are one contiguous run.
 #include "dosage.hpp"
 
+#include "decode_device.hpp"
 #include "device_utils.hpp"
 #include "synth.hpp"
 
@@ -84,6 +85,255 @@ __global__ __launch_bounds__(256) void k_dosage_rank(const uint64_t *__restrict_
 			rank[at + w] = before + incl - c;
 		}
 		carry += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+	}
+}
+
+// ---- ingest: dosage tracks out of the staged record bytes ------------------------------------------
+// A record is [main track][phase track if 0x10][dosage track: 0x20 id list / 0x40 dense / 0x60 bit array].
+// The main track's end comes from the record decode (aux_at); the phase track's length depends on the
+// number of hets in the finished row.  Pass 1 (k_dosage_locate) finds the track, writes the presence bits
+// and counts the values; a one-block scan hands out value offsets; k_dosage_rank builds the ranks;
+// pass 2 (k_dosage_values) copies the values -- for the dense 0x40 shape through the ranks, dropping its
+// 65535 "no dosage" entries.
+__device__ __forceinline__ uint32_t BlockSum256(uint32_t x, uint32_t *s_part) {
+	x = WaveSum(x);
+	__syncthreads();
+	if ((threadIdx.x & 63u) == 0) {
+		s_part[threadIdx.x >> 6] = x;
+	}
+	__syncthreads();
+	return s_part[0] + s_part[1] + s_part[2] + s_part[3];
+}
+
+__device__ __forceinline__ void IngestFail(const DosageIngest &b, uint32_t r) {
+	if (threadIdx.x == 0) {
+		atomicCAS(b.error, 0, static_cast<int>(b.variant0 + r) + 1);
+	}
+}
+
+__global__ __launch_bounds__(256) void k_dosage_locate(DosageIngest b) {
+	__shared__ uint32_t s_part[4];
+	__shared__ uint64_t s_cur;
+	__shared__ uint32_t s_len;
+	__shared__ int s_ok;
+	const uint32_t r = blockIdx.x;
+	const int32_t dr = b.dos_row[r];
+	if (dr < 0) {
+		return;
+	}
+	if (threadIdx.x == 0) {
+		b.count[r] = 0;
+		b.track[r] = 0;
+	}
+	const Src src {b.bytes, b.bytes_len};
+	const uint32_t N = b.sample_ct;
+	const uint32_t t = b.vrtype[r];
+	const uint64_t rec_end = b.rec_begin[r + 1];
+	uint64_t cur = b.aux_at[r];
+	if ((t & 0x08u) || cur > rec_end || cur < b.rec_begin[r]) {
+		IngestFail(b, r);
+		return;
+	}
+	if (t & 0x10u) {
+		// phase track: ceil((1 + hets) / 8) bytes; bit 0 set = they are phase-present flags and
+		// ceil(flagged / 8) bytes of phase bits follow
+		const uint32_t *row32 = reinterpret_cast<const uint32_t *>(b.rows + static_cast<uint64_t>(b.row0 + r) * b.pitch);
+		uint32_t hets = 0;
+		for (uint32_t w = threadIdx.x; w < (N + 15) / 16; w += 256u) {
+			const uint32_t x = row32[w]; // slots past N are zero (hom-ref)
+			hets += __popc(x & ~(x >> 1) & kLow);
+		}
+		hets = BlockSum256(hets, s_part);
+		const uint32_t head = (1 + hets + 7) / 8;
+		if (cur + head > rec_end) {
+			IngestFail(b, r);
+			return;
+		}
+		uint32_t flagged = 0;
+		if (src.Byte(cur) & 1u) {
+			for (uint32_t i = threadIdx.x; i < head; i += 256u) {
+				uint32_t byte = src.Byte(cur + i);
+				if (i == 0) {
+					byte &= ~1u;
+				}
+				if (i == head - 1 && ((1 + hets) & 7u)) {
+					byte &= (1u << ((1 + hets) & 7u)) - 1u;
+				}
+				flagged += __popc(byte);
+			}
+			flagged = BlockSum256(flagged, s_part);
+			flagged = (flagged + 7) / 8;
+		}
+		cur += head + flagged;
+		if (cur > rec_end) {
+			IngestFail(b, r);
+			return;
+		}
+	}
+	uint64_t *present = b.present + static_cast<uint64_t>(dr) * b.words;
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const uint32_t kind = t & 0x60u;
+	uint32_t count = 0;
+	uint64_t track = cur;
+	if (kind == 0x60u) {
+		const uint64_t nb = (N + 7) / 8;
+		if (cur + nb > rec_end) {
+			IngestFail(b, r);
+			return;
+		}
+		for (uint32_t w = threadIdx.x; w < b.words; w += 256u) {
+			uint64_t bits = 0;
+			for (uint32_t k = 0; k < 8; k++) {
+				const uint64_t at = 8ull * w + k;
+				if (at < nb) {
+					bits |= static_cast<uint64_t>(src.Byte(cur + at)) << (8 * k);
+				}
+			}
+			const uint32_t live = N - 64u * w;
+			if (live < 64u) {
+				bits &= (1ull << live) - 1ull;
+			}
+			present[w] = bits;
+			count += static_cast<uint32_t>(__popcll(bits));
+		}
+		count = BlockSum256(count, s_part);
+		track = cur + nb;
+	} else if (kind == 0x40u) {
+		if (cur + 2ull * N > rec_end) {
+			IngestFail(b, r);
+			return;
+		}
+		bool bad = false;
+		for (uint32_t w = wave; w < b.words; w += 4u) {
+			const uint32_t s = 64u * w + lane;
+			const uint32_t v = s < N ? src.Le(cur + 2ull * s, 2) : 0xffffu;
+			bad |= v > 32768u && v != 0xffffu;
+			const uint64_t bits = __ballot(v != 0xffffu);
+			if (lane == 0) {
+				present[w] = bits;
+				count += static_cast<uint32_t>(__popcll(bits));
+			}
+		}
+		count = BlockSum256(count, s_part);
+		if (__syncthreads_or(bad)) {
+			IngestFail(b, r);
+			return;
+		}
+	} else { // 0x20: the samples are listed (a difflist without its value section), their values follow in that order
+		if (threadIdx.x == 0) {
+			s_ok = 1;
+		}
+		__syncthreads();
+		if (wave == 0) {
+			uint32_t len = 0;
+			auto apply = [&](uint32_t, uint32_t id, uint64_t) { atomicOr(reinterpret_cast<unsigned long long *>(&present[id >> 6]), 1ull << (id & 63u)); };
+			const bool ok = WalkDifflistIds(src, cur, rec_end, N, b.id_bytes, false, len, apply);
+			if (lane == 0) {
+				s_ok = ok;
+				s_cur = cur;
+				s_len = len;
+			}
+		}
+		__syncthreads();
+		if (!s_ok) {
+			IngestFail(b, r);
+			return;
+		}
+		count = s_len;
+		track = s_cur;
+	}
+	if (track + 2ull * (kind == 0x40u ? N : count) > rec_end) {
+		IngestFail(b, r);
+		return;
+	}
+	if (threadIdx.x == 0) {
+		b.count[r] = count;
+		b.track[r] = track;
+	}
+}
+
+// value offsets of the batch's tracks, in record order, continuing the dataset's running total
+__global__ __launch_bounds__(1024) void k_dosage_offsets(DosageIngest b) {
+	__shared__ uint64_t s_wave[16];
+	__shared__ uint64_t s_carry;
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	if (threadIdx.x == 0) {
+		s_carry = *b.total;
+	}
+	__syncthreads();
+	for (uint32_t base = 0; base < b.n; base += 1024u) {
+		const uint32_t r = base + threadIdx.x;
+		const bool on = r < b.n && b.dos_row[r] >= 0;
+		const uint64_t c = on ? b.count[r] : 0ull;
+		uint64_t incl = c;
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint64_t up = __shfl_up(incl, d);
+			if (lane >= static_cast<uint32_t>(d)) {
+				incl += up;
+			}
+		}
+		if (lane == 63u) {
+			s_wave[wave] = incl;
+		}
+		__syncthreads();
+		uint64_t before = s_carry;
+		for (uint32_t k = 0; k < wave; k++) {
+			before += s_wave[k];
+		}
+		if (on) {
+			b.val_off[b.dos_row[r]] = before + incl - c;
+		}
+		__syncthreads();
+		if (threadIdx.x == 1023u) {
+			s_carry = before + incl;
+		}
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) {
+		*b.total = s_carry;
+		if (s_carry > b.capacity) {
+			atomicCAS(b.error, 0, static_cast<int>(b.variant0) + 1);
+		}
+	}
+}
+
+__global__ __launch_bounds__(256) void k_dosage_values(DosageIngest b) {
+	const uint32_t r = blockIdx.x;
+	const int32_t dr = b.dos_row[r];
+	if (dr < 0 || *b.error != 0 || *b.total > b.capacity) {
+		return;
+	}
+	const Src src {b.bytes, b.bytes_len};
+	const uint32_t N = b.sample_ct;
+	const uint32_t count = b.count[r];
+	const uint64_t track = b.track[r];
+	const uint64_t *present = b.present + static_cast<uint64_t>(dr) * b.words;
+	const uint32_t *rank = b.rank + static_cast<uint64_t>(dr) * b.words;
+	uint16_t *out = b.values + b.val_off[dr];
+	// a list that names a sample twice leaves fewer presence bits than it has values
+	const uint32_t bits_set = rank[b.words - 1] + static_cast<uint32_t>(__popcll(present[b.words - 1]));
+	if (bits_set != count) {
+		IngestFail(b, r);
+		return;
+	}
+	bool bad = false;
+	if ((b.vrtype[r] & 0x60u) == 0x40u) {
+		for (uint32_t s = threadIdx.x; s < N; s += 256u) {
+			const uint64_t bits = present[s >> 6];
+			if ((bits >> (s & 63u)) & 1ull) {
+				out[rank[s >> 6] + static_cast<uint32_t>(__popcll(bits & ((1ull << (s & 63u)) - 1ull)))] =
+				    static_cast<uint16_t>(src.Le(track + 2ull * s, 2));
+			}
+		}
+	} else {
+		for (uint32_t j = threadIdx.x; j < count; j += 256u) {
+			const uint32_t v = src.Le(track + 2ull * j, 2);
+			bad |= v > 32768u;
+			out[j] = static_cast<uint16_t>(v);
+		}
+	}
+	if (bad) {
+		atomicCAS(b.error, 0, static_cast<int>(b.variant0 + r) + 1);
 	}
 }
 
@@ -186,7 +436,8 @@ __global__ __launch_bounds__(256) void k_dosage_sums(const uint8_t *__restrict__
 		}
 	}
 	if (!HAS_INCLUDE && present) {
-		const uint64_t o0 = dos.val_off[r], o1 = dos.val_off[r + 1];
+		const uint64_t last = static_cast<uint64_t>(r) * dos.words + (dos.words - 1);
+		const uint64_t o0 = dos.val_off[r], o1 = o0 + dos.rank[last] + static_cast<uint64_t>(__popcll(dos.present[last]));
 		for (uint64_t at = (o0 & ~7ull) + 8ull * threadIdx.x; at < o1; at += 8ull * 256u) {
 			const uint4 q = LoadStream(reinterpret_cast<const uint4 *>(dos.values + at));
 			const uint32_t x[4] = {q.x, q.y, q.z, q.w};
@@ -552,6 +803,19 @@ hipError_t LaunchDosageRank(const uint64_t *present, uint32_t rows, uint32_t wor
 		return hipSuccess;
 	}
 	hipLaunchKernelGGL(k_dosage_rank, dim3(rows), dim3(256), 0, stream, present, words, rank);
+	return hipGetLastError();
+}
+
+hipError_t LaunchDosageIngest(const DosageIngest &batch, uint32_t first_row, uint32_t n_rows, hipStream_t stream) {
+	if (batch.n == 0 || n_rows == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_dosage_locate, dim3(batch.n), dim3(256), 0, stream, batch);
+	hipLaunchKernelGGL(k_dosage_offsets, dim3(1), dim3(1024), 0, stream, batch);
+	hipLaunchKernelGGL(k_dosage_rank, dim3(n_rows), dim3(256), 0, stream,
+	                   batch.present + static_cast<uint64_t>(first_row) * batch.words, batch.words,
+	                   batch.rank + static_cast<uint64_t>(first_row) * batch.words);
+	hipLaunchKernelGGL(k_dosage_values, dim3(batch.n), dim3(256), 0, stream, batch);
 	return hipGetLastError();
 }
 

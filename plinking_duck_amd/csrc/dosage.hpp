@@ -23,6 +23,34 @@ struct DosageView {
 	uint32_t words = 0; // ceil(sample_ct / 64)
 };
 
+//! One staged run of records (decode.hpp:DecodeBatch) whose dosage tracks go into the resident form.
+//! All pointers are device pointers; the scratch arrays live for the batch only.
+struct DosageIngest {
+	const uint8_t *bytes; // the records' file bytes (16 readable zero bytes follow bytes_len)
+	uint64_t bytes_len;
+	const uint64_t *rec_begin; // [n + 1]
+	const uint8_t *vrtype;     // [n]
+	const uint64_t *aux_at;    // [n] first byte after each record's main track (written by the record decode)
+	const int32_t *dos_row;    // [n] row of the record in the arrays below, or -1: no dosage track
+	const uint8_t *rows;       // the finished 2-bit rows (a phase track's length depends on the het count)
+	uint64_t pitch;
+	uint32_t row0, variant0, n, sample_ct, id_bytes;
+	uint64_t *present; // rows x words, zero-filled
+	uint32_t *rank;
+	uint32_t words;
+	uint64_t *val_off; // [rows]
+	uint16_t *values;
+	uint64_t capacity; // values the allocation holds
+	uint64_t *total;   // running count of stored values (one device counter per dataset)
+	uint32_t *count;   // [n] scratch: explicit dosages of each record
+	uint64_t *track;   // [n] scratch: offset into bytes of each record's value section
+	int *error;        // set (once) to 1 + the variant index of a malformed record
+};
+
+//! Locates every dosage track of the batch behind its record's main (and phase) track, writes presence bits,
+//! ranks, value offsets and values.  first_row / n_rows: the contiguous run of dosage rows the batch fills.
+hipError_t LaunchDosageIngest(const DosageIngest &batch, uint32_t first_row, uint32_t n_rows, hipStream_t stream);
+
 //! rank[r][w] = number of presence bits of row r before word w
 hipError_t LaunchDosageRank(const uint64_t *present, uint32_t rows, uint32_t words, uint32_t *rank,
                             hipStream_t stream);
