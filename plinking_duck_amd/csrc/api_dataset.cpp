@@ -193,51 +193,74 @@ static bool ExpandParallel(const pgh::PgenIndex &ix, const pgh::RecordFile &file
 	return true;
 }
 
-// Dosage tracks -> the resident bit-array form (dosage.hpp:DosageView).  The tracks are
-// parsed on the host, a few threads over chunks of variants (each worker owns a
-// Normalizer: finding a track means walking the record's main and phase tracks first);
-// presence bits and packed values go up chunk by chunk and the rank table is built on the
-// device.  Dense 0x40 tracks drop their 65535 "no dosage" entries, so downstream kernels
-// never meet that sentinel.
-static int LoadDosageTracks(pgh_dataset *ds, const pgh::RecordFile &file, char *errbuf) {
+// Dosage tracks -> the resident bit-array form (dosage.hpp:DosageView).
+//
+// PrepareDosage sizes and allocates the arrays before the body is streamed: a row per dosage-bearing
+// variant of the range, and room for as many values as the records have bytes for.  Records that go
+// through the device decode have their tracks extracted there (LaunchDosageIngest).  The few that are
+// expanded on the host (an LD run whose base lies before the range, PGH_HOST_NORMALIZE=1) are parsed
+// on the host afterwards and appended (AppendDosageTracksHost); value runs need not be in row order.
+struct DosageStaging {
+	uint64_t capacity = 0;
+	uint64_t *d_total = nullptr;       // running count of stored values
+	std::vector<uint32_t> host_parsed; // variants whose track the host parses
+	~DosageStaging() {
+		if (d_total) {
+			(void)hipFree(d_total);
+		}
+	}
+};
+
+static int PrepareDosage(pgh_dataset *ds, DosageStaging &stg, char *errbuf) {
 	const PgenIndex &ix = ds->index;
 	const uint32_t range = ds->v_end - ds->v_begin;
 	const uint32_t N = ds->sample_ct;
 	const uint32_t words = (N + 63) / 64;
 	ds->dos_row_of.assign(range, -1);
-	uint64_t capacity = 0;
-	std::vector<uint32_t> carriers;
+	uint32_t rows = 0;
 	for (uint32_t i = 0; i < range; i++) {
 		const uint32_t v = ds->v_begin + i;
 		if (ix.vrtype[v] & 0x60) {
-			ds->dos_row_of[i] = static_cast<int32_t>(carriers.size());
-			carriers.push_back(v);
-			capacity += std::min<uint64_t>(N, (ix.offset[v + 1] - ix.offset[v]) / 2); // a value is two record bytes
+			ds->dos_row_of[i] = static_cast<int32_t>(rows++);
+			stg.capacity += std::min<uint64_t>(N, (ix.offset[v + 1] - ix.offset[v]) / 2); // a value is two record bytes
 		}
 	}
-	if (carriers.empty()) {
+	if (rows == 0) {
 		ds->dos_row_of.clear();
 		return PGH_OK;
 	}
-	const uint32_t rows = static_cast<uint32_t>(carriers.size());
 	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_dos_row_of), sizeof(int32_t) * range), "hipMalloc(dosage)");
 	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_dos_present), 8ull * rows * words), "hipMalloc(dosage)");
 	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_dos_rank), 4ull * rows * words), "hipMalloc(dosage)");
 	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_dos_val_off), 8ull * (rows + 1)), "hipMalloc(dosage)");
-	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_dos_values), 2 * capacity + 32), "hipMalloc(dosage)");
-	PGH_HIP(hipMemset(ds->d_dos_values, 0, 2 * capacity + 32), "dosage memset");
+	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_dos_values), 2 * stg.capacity + 32), "hipMalloc(dosage)");
+	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&stg.d_total), 8), "hipMalloc(dosage)");
+	PGH_HIP(hipMemset(ds->d_dos_present, 0, 8ull * rows * words), "dosage memset");
+	PGH_HIP(hipMemset(ds->d_dos_rank, 0, 4ull * rows * words), "dosage memset");
+	PGH_HIP(hipMemset(ds->d_dos_val_off, 0, 8ull * (rows + 1)), "dosage memset");
+	PGH_HIP(hipMemset(ds->d_dos_values, 0, 2 * stg.capacity + 32), "dosage memset");
+	PGH_HIP(hipMemset(stg.d_total, 0, 8), "dosage memset");
 	PGH_HIP(hipMemcpy(ds->d_dos_row_of, ds->dos_row_of.data(), sizeof(int32_t) * range, hipMemcpyHostToDevice),
 	        "dosage upload");
-	std::vector<uint64_t> val_off(rows + 1);
-	uint64_t filled = 0;
+	ds->dos_rows = rows;
+	return PGH_OK;
+}
+
+// The host twin of LaunchDosageIngest for `variants` (ascending): a few threads over chunks, each worker
+// with its own Normalizer (finding a track means walking the record's main and phase tracks first).
+// Dense 0x40 tracks drop their 65535 "no dosage" entries, so downstream kernels never meet that sentinel.
+static int AppendDosageTracksHost(pgh_dataset *ds, const pgh::RecordFile &file, const std::vector<uint32_t> &variants,
+                                  uint64_t capacity, uint64_t &filled, char *errbuf) {
+	const PgenIndex &ix = ds->index;
+	const uint32_t N = ds->sample_ct;
+	const uint32_t words = (N + 63) / 64;
+	const uint32_t total = static_cast<uint32_t>(variants.size());
 	const uint32_t chunk_rows = std::max<uint32_t>(8, static_cast<uint32_t>((64ull << 20) / (2ull * N + 8ull * words)));
 	const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
 	std::vector<uint64_t> h_present;
 	std::vector<std::vector<uint16_t>> h_values;
-	std::vector<uint16_t> packed;
-	for (uint32_t r0 = 0; r0 < rows; r0 += chunk_rows) {
-		const uint32_t r1 = std::min(rows, r0 + chunk_rows);
-		const uint32_t cnt = r1 - r0;
+	for (uint32_t r0 = 0; r0 < total; r0 += chunk_rows) {
+		const uint32_t cnt = std::min(total - r0, chunk_rows);
 		h_present.assign(static_cast<size_t>(cnt) * words, 0);
 		h_values.assign(cnt, {});
 		const unsigned parts = std::min<unsigned>(std::min(8u, hw), std::max<uint32_t>(1, cnt / 8));
@@ -251,14 +274,14 @@ static int LoadDosageTracks(pgh_dataset *ds, const pgh::RecordFile &file, char *
 				std::vector<uint16_t> dos16;
 				const uint32_t lo = std::min(cnt, t * slice), hi = std::min(cnt, lo + slice);
 				for (uint32_t k = lo; k < hi; k++) {
-					if (!norm.DecodeDosage(carriers[r0 + k], row2bit, dos16, errs[t])) {
+					if (!norm.DecodeDosage(variants[r0 + k], row2bit, dos16, errs[t])) {
 						return;
 					}
 					uint64_t *bits = h_present.data() + static_cast<size_t>(k) * words;
 					for (uint32_t s = 0; s < N; s++) {
 						if (dos16[s] != 0xffff) {
 							if (dos16[s] > 32768) {
-								errs[t] = "dosage above 2.0 in variant " + std::to_string(carriers[r0 + k]);
+								errs[t] = "dosage above 2.0 in variant " + std::to_string(variants[r0 + k]);
 								return;
 							}
 							bits[s >> 6] |= 1ull << (s & 63);
@@ -277,30 +300,28 @@ static int LoadDosageTracks(pgh_dataset *ds, const pgh::RecordFile &file, char *
 				return PGH_ERR_FORMAT;
 			}
 		}
-		packed.clear();
 		for (uint32_t k = 0; k < cnt; k++) {
-			val_off[r0 + k] = filled + packed.size();
-			packed.insert(packed.end(), h_values[k].begin(), h_values[k].end());
-		}
-		if (filled + packed.size() > capacity) {
-			SetErr(errbuf, "dosage tracks hold more values than their records have bytes for");
-			return PGH_ERR_FORMAT;
-		}
-		PGH_HIP(hipMemcpy(ds->d_dos_present + static_cast<uint64_t>(r0) * words, h_present.data(), 8ull * cnt * words,
-		                  hipMemcpyHostToDevice),
-		        "dosage upload");
-		if (!packed.empty()) {
-			PGH_HIP(hipMemcpy(ds->d_dos_values + filled, packed.data(), 2 * packed.size(), hipMemcpyHostToDevice),
+			const uint32_t row = static_cast<uint32_t>(ds->dos_row_of[variants[r0 + k] - ds->v_begin]);
+			if (filled + h_values[k].size() > capacity) {
+				SetErr(errbuf, "dosage tracks hold more values than their records have bytes for");
+				return PGH_ERR_FORMAT;
+			}
+			PGH_HIP(hipMemcpy(ds->d_dos_present + static_cast<uint64_t>(row) * words,
+			                  h_present.data() + static_cast<size_t>(k) * words, 8ull * words, hipMemcpyHostToDevice),
 			        "dosage upload");
+			PGH_HIP(hipMemcpy(ds->d_dos_val_off + row, &filled, 8, hipMemcpyHostToDevice), "dosage upload");
+			if (!h_values[k].empty()) {
+				PGH_HIP(hipMemcpy(ds->d_dos_values + filled, h_values[k].data(), 2 * h_values[k].size(),
+				                  hipMemcpyHostToDevice),
+				        "dosage upload");
+			}
+			filled += h_values[k].size();
+			PGH_HIP(pgh::LaunchDosageRank(ds->d_dos_present + static_cast<uint64_t>(row) * words, 1, words,
+			                              ds->d_dos_rank + static_cast<uint64_t>(row) * words, hipStreamPerThread),
+			        "dosage rank kernel");
 		}
-		filled += packed.size();
+		PGH_HIP(hipStreamSynchronize(hipStreamPerThread), "dosage rank sync");
 	}
-	val_off[rows] = filled;
-	PGH_HIP(hipMemcpy(ds->d_dos_val_off, val_off.data(), 8ull * (rows + 1), hipMemcpyHostToDevice), "dosage upload");
-	PGH_HIP(pgh::LaunchDosageRank(ds->d_dos_present, rows, words, ds->d_dos_rank, hipStreamPerThread), "dosage rank kernel");
-	PGH_HIP(hipStreamSynchronize(hipStreamPerThread), "dosage rank sync");
-	ds->dos_rows = rows;
-	ds->dos_values = filled;
 	return PGH_OK;
 }
 
@@ -339,9 +360,15 @@ extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t va
 	ds->v_end = variant_end;
 	PGH_HIP(hipGetDevice(&ds->device), "hipGetDevice");
 	int rc = AllocRows(ds.get(), errbuf);
+	DosageStaging dosage;
+	if (rc == PGH_OK && ix.has_dosage) {
+		rc = PrepareDosage(ds.get(), dosage, errbuf);
+	}
 	if (rc != PGH_OK) {
+		pgh_close(ds.release());
 		return rc;
 	}
+	auto has_track = [&](uint32_t r) { return ds->dos_rows != 0 && ds->dos_row_of[r - variant_begin] >= 0; };
 
 	// Stream the body through two pinned staging buffers, three ways per run of records:
 	//   plain   a long run of literal 2-bit records is already the row image: pread into the
@@ -470,7 +497,7 @@ extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t va
 						break;
 					}
 					const uint64_t len = ix.offset[r + 1] - ix.offset[r];
-					if (raw + len + 64 + 13ull * (n + 2) > stage_bytes) {
+					if (raw + len + 64 + 37ull * (n + 2) > stage_bytes) {
 						break;
 					}
 					raw += len;
@@ -497,6 +524,9 @@ extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t va
 					if (!is_ld(r)) {
 						last_base = r;
 					}
+					if (has_track(r)) {
+						dosage.host_parsed.push_back(r);
+					}
 				}
 			} else {
 				stop = v + n;
@@ -506,14 +536,24 @@ extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t va
 				}
 				const uint64_t tables = (raw + 16 + 15) & ~15ull; // 16 zero bytes the kernel may read past the end
 				std::memset(h + raw, 0, tables - raw);
+				// tables behind the bytes: rec_begin u64[n+1] | aux_at u64[n] | track u64[n] | ld_row u32[n] |
+				// dos_row i32[n] | count u32[n] | vrtype u8[n]  (aux_at / track / count are device scratch)
 				uint64_t *rec_begin = reinterpret_cast<uint64_t *>(h + tables);
-				uint32_t *ld_row = reinterpret_cast<uint32_t *>(rec_begin + (n + 1));
-				uint8_t *vrtype = reinterpret_cast<uint8_t *>(ld_row + n);
+				uint32_t *ld_row = reinterpret_cast<uint32_t *>(rec_begin + (n + 1) + 2ull * n);
+				int32_t *dos_row = reinterpret_cast<int32_t *>(ld_row + n);
+				uint8_t *vrtype = reinterpret_cast<uint8_t *>(dos_row + 2ull * n);
 				bool any_ld = false;
+				int64_t first_track = -1;
+				uint32_t n_tracks = 0;
 				for (uint32_t i = 0; i < n; i++) {
 					const uint32_t r = v + i;
 					rec_begin[i] = ix.offset[r] - ix.offset[v];
 					vrtype[i] = ix.vrtype[r];
+					dos_row[i] = has_track(r) ? ds->dos_row_of[r - variant_begin] : -1;
+					if (dos_row[i] >= 0) {
+						first_track = first_track < 0 ? dos_row[i] : first_track;
+						n_tracks++;
+					}
 					if (is_ld(r)) {
 						any_ld = true;
 						ld_row[i] = last_base < 0 ? 0xffffffffu : static_cast<uint32_t>(last_base - variant_begin);
@@ -523,15 +563,19 @@ extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t va
 					}
 				}
 				rec_begin[n] = raw;
-				const uint64_t used_bytes = tables + 8ull * (n + 1) + 4ull * n + n;
+				const uint64_t used_bytes = tables + 8ull * (n + 1) + 16ull * n + 12ull * n + n;
 				e = hipMemcpyAsync(d_stage[which], h, used_bytes, hipMemcpyHostToDevice, stream);
 				if (e == hipSuccess) {
 					pgh::DecodeBatch batch;
 					batch.bytes = d_stage[which];
 					batch.bytes_len = raw;
 					batch.rec_begin = reinterpret_cast<const uint64_t *>(d_stage[which] + tables);
-					batch.ld_row = reinterpret_cast<const uint32_t *>(batch.rec_begin + (n + 1));
-					batch.vrtype = reinterpret_cast<const uint8_t *>(batch.ld_row + n);
+					uint64_t *d_aux = const_cast<uint64_t *>(batch.rec_begin) + (n + 1);
+					uint64_t *d_track = d_aux + n;
+					batch.ld_row = reinterpret_cast<const uint32_t *>(d_track + n);
+					const int32_t *d_dos_row = reinterpret_cast<const int32_t *>(batch.ld_row + n);
+					uint32_t *d_count = reinterpret_cast<uint32_t *>(const_cast<int32_t *>(d_dos_row) + n);
+					batch.vrtype = reinterpret_cast<const uint8_t *>(d_count + n);
 					batch.rows = ds->d_rows;
 					batch.pitch = ds->pitch;
 					batch.row0 = v - variant_begin;
@@ -540,8 +584,35 @@ extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t va
 					batch.sample_ct = ds->sample_ct;
 					batch.id_bytes = ix.sample_id_bytes;
 					batch.error = d_error;
-					batch.aux_at = nullptr;
+					batch.aux_at = n_tracks ? d_aux : nullptr;
 					e = pgh::LaunchDecodeRecords(batch, any_ld, stream);
+					if (e == hipSuccess && n_tracks) {
+						pgh::DosageIngest in;
+						in.bytes = batch.bytes;
+						in.bytes_len = raw;
+						in.rec_begin = batch.rec_begin;
+						in.vrtype = batch.vrtype;
+						in.aux_at = d_aux;
+						in.dos_row = d_dos_row;
+						in.rows = ds->d_rows;
+						in.pitch = ds->pitch;
+						in.row0 = batch.row0;
+						in.variant0 = v;
+						in.n = n;
+						in.sample_ct = ds->sample_ct;
+						in.id_bytes = ix.sample_id_bytes;
+						in.present = ds->d_dos_present;
+						in.rank = ds->d_dos_rank;
+						in.words = (ds->sample_ct + 63) / 64;
+						in.val_off = ds->d_dos_val_off;
+						in.values = ds->d_dos_values;
+						in.capacity = dosage.capacity;
+						in.total = dosage.d_total;
+						in.count = d_count;
+						in.track = d_track;
+						in.error = d_error;
+						e = pgh::LaunchDosageIngest(in, static_cast<uint32_t>(first_track), n_tracks, stream);
+					}
 				}
 			}
 		}
@@ -575,13 +646,22 @@ extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t va
 		pgh_close(ds.release());
 		return PGH_ERR_FORMAT;
 	}
-	if (ix.has_dosage) {
-		rc = LoadDosageTracks(ds.get(), file, errbuf);
-		lap("dosage tracks");
-		if (rc != PGH_OK) {
+	if (ds->dos_rows) {
+		uint64_t filled = 0;
+		hipError_t de = hipMemcpy(&filled, dosage.d_total, 8, hipMemcpyDeviceToHost);
+		if (de != hipSuccess) {
 			pgh_close(ds.release());
-			return rc;
+			return DeviceFail(errbuf, "dosage total", de);
 		}
+		if (!dosage.host_parsed.empty()) {
+			rc = AppendDosageTracksHost(ds.get(), file, dosage.host_parsed, dosage.capacity, filled, errbuf);
+			if (rc != PGH_OK) {
+				pgh_close(ds.release());
+				return rc;
+			}
+		}
+		ds->dos_values = filled;
+		lap("dosage tracks");
 	}
 	*out = ds.release();
 	return PGH_OK;

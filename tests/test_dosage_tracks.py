@@ -72,10 +72,16 @@ def _moments(want_rows):
 @pytest.mark.gpu
 @pytest.mark.parametrize("m,n,seed", CASES)
 @pytest.mark.parametrize("with_phase", [False, True])
-def test_device_dosages_equal_the_oracle(files, gpu_lib, oracle, m, n, seed, with_phase):
+def test_device_dosages_equal_the_oracle(files, gpu_lib, oracle, m, n, seed, with_phase, monkeypatch):
     path, geno, dos, dkinds, want = files[(m, n, with_phase)]
-    ds = gpu_lib.Dataset.open(path)
+    ds = gpu_lib.Dataset.open(path)  # tracks located and extracted on the device (k_dosage_locate / k_dosage_values)
     assert np.array_equal(ds.dosage_unpack(), want)
+    assert ds.info.dosage_variant_ct == sum(1 for k in dkinds if k) and ds.info.dosage_value_ct == int((dos != 0xFFFF).sum())
+    monkeypatch.setenv("PGH_HOST_NORMALIZE", "1")  # the host parser of the same tracks
+    hosted = gpu_lib.Dataset.open(path)
+    monkeypatch.delenv("PGH_HOST_NORMALIZE")
+    assert np.array_equal(hosted.dosage_unpack(), want) and np.array_equal(hosted.dosage_sums(), ds.dosage_sums())
+    assert hosted.info.dosage_value_ct == ds.info.dosage_value_ct
     assert np.array_equal(ds.dosage_sums(), _moments(want))
     rng = np.random.default_rng(seed)
     mask = rng.random(n) < 0.4
@@ -202,3 +208,35 @@ def test_table_functions_over_dosage_tracks(tmp_path, gpu_lib, oracle, threads):
                 samples=["S300", "S5"], columns=["ID", "S5", "S300"])
     assert [(vid, -9.0 if a is None else a, -9.0 if b is None else b) for vid, a, b in r.rows] == \
         [(f"v{v}", want[v][5], want[v][300]) for v in (7, 2599, 64)]
+
+
+@pytest.mark.gpu
+def test_malformed_dosage_tracks_are_reported(files, gpu_lib, tmp_path):
+    """Truncated tracks, a value above 2.0 and a list that runs past the samples: pgh_open says which variant."""
+    path, geno, dos, dkinds, want = files[(120, 1000, False)]
+    raw = bytearray(open(path, "rb").read())
+    pg_m = 120
+    head = 12
+    offs = int.from_bytes(raw[head:head + 8], "little")
+    lens = [int.from_bytes(raw[head + 8 + pg_m + 4 * v:head + 12 + pg_m + 4 * v], "little") for v in range(pg_m)]
+    starts = np.concatenate([[offs], offs + np.cumsum(lens)])
+    for kind in (0x20, 0x40, 0x60):
+        v = next(v for v in range(pg_m) if dkinds[v] == kind and (dos[v] != 0xFFFF).sum() > 3)
+        bad = bytearray(raw)
+        end = int(starts[v + 1])
+        bad[end - 2:end] = (40000).to_bytes(2, "little")  # the last value of the track: above 2.0
+        p = str(tmp_path / f"bad_{kind:x}.pgen")
+        open(p, "wb").write(bad)
+        with pytest.raises(gpu_lib.PghError) as e:
+            gpu_lib.Dataset.open(p)
+        assert f"record {v}" in str(e.value) or f"variant {v}" in str(e.value), str(e.value)
+    # a record cut short: its length field shrunk by 3 bytes (the next record's bytes are then misread too,
+    # but the first malformed variant is the one reported or an earlier one never)
+    v = next(v for v in range(pg_m) if dkinds[v] == 0x60 and (dos[v] != 0xFFFF).sum() > 3)
+    bad = bytearray(raw)
+    at = head + 8 + pg_m + 4 * v
+    bad[at:at + 4] = (lens[v] - 3).to_bytes(4, "little")
+    p = str(tmp_path / "short.pgen")
+    open(p, "wb").write(bad)
+    with pytest.raises(gpu_lib.PghError):
+        gpu_lib.Dataset.open(p)
