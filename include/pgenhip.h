@@ -105,6 +105,10 @@ int pgh_from_host_rows(const uint8_t *rows, size_t row_stride, uint32_t variant_
  * ranks that own disjoint variant ranges hold slices of one global matrix. */
 int pgh_synth_create(uint32_t variant_begin, uint32_t variant_end, uint32_t sample_ct, uint64_t seed,
                      double missing_rate, pgh_dataset **out, char *errbuf);
+/* The same fileset with a dosage track (vrtype 0x60: presence bits + uint16 values) behind every record:
+ * each sample explicit with probability dosage_rate, values uniform on 0..32768.  Ingest benchmark input. */
+int pgh_synth_write_dosage_files(const char *prefix, uint32_t variant_ct, uint32_t sample_ct, uint64_t seed,
+                                 double missing_rate, double dosage_rate, char *errbuf);
 /* Gives every resident variant of a dataset without dosage tracks a seeded synthetic one:
  * each sample carries an explicit dosage with probability `rate`, values uniform on 0..32768.
  * Benchmark input of the shape `plink2 --import-dosage` leaves behind (vrtype 0x60). */

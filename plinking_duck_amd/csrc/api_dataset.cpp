@@ -332,6 +332,15 @@ extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t va
 		return PGH_ERR_ARG;
 	}
 	*out = nullptr;
+	const char *trace_env = std::getenv("PGH_TRACE_OPEN");
+	const bool trace = trace_env && *trace_env && *trace_env != '0';
+	const auto t_start = std::chrono::steady_clock::now();
+	auto lap = [&](const char *what) {
+		if (trace) {
+			std::fprintf(stderr, "pgh_open: %-14s +%.2f ms\n", what,
+			             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+		}
+	};
 	std::unique_ptr<pgh_dataset> ds(new pgh_dataset());
 	std::string err;
 	if (!pgh::ParsePgenIndex(pgen_path, pgi_path ? pgi_path : "", ds->index, err)) {
@@ -359,7 +368,9 @@ extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t va
 	ds->v_begin = variant_begin;
 	ds->v_end = variant_end;
 	PGH_HIP(hipGetDevice(&ds->device), "hipGetDevice");
+	lap("index parsed");
 	int rc = AllocRows(ds.get(), errbuf);
+	lap("rows allocated");
 	DosageStaging dosage;
 	if (rc == PGH_OK && ix.has_dosage) {
 		rc = PrepareDosage(ds.get(), dosage, errbuf);
@@ -368,6 +379,7 @@ extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t va
 		pgh_close(ds.release());
 		return rc;
 	}
+	lap("dosage arrays");
 	auto has_track = [&](uint32_t r) { return ds->dos_rows != 0 && ds->dos_row_of[r - variant_begin] >= 0; };
 
 	// Stream the body through two pinned staging buffers, three ways per run of records:
@@ -384,15 +396,6 @@ extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t va
 		return PGH_ERR_OPEN;
 	}
 	pgh::Normalizer norm(ix, file);
-	const char *trace_env = std::getenv("PGH_TRACE_OPEN");
-	const bool trace = trace_env && *trace_env && *trace_env != '0';
-	const auto t_start = std::chrono::steady_clock::now();
-	auto lap = [&](const char *what) {
-		if (trace) {
-			std::fprintf(stderr, "pgh_open: %-14s +%.2f ms\n", what,
-			             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
-		}
-	};
 	const char *force_host = std::getenv("PGH_HOST_NORMALIZE");
 	const bool host_only = force_host && *force_host && *force_host != '0';
 	const uint32_t rb = ds->record_bytes;
@@ -835,6 +838,117 @@ extern "C" int pgh_synth_record_host(uint32_t v, uint32_t sample_ct, uint64_t se
 	return PGH_OK;
 }
 
+static int WriteSynthCompanions(const std::string &base, uint32_t variant_ct, uint32_t sample_ct, char *errbuf) {
+	FILE *f = std::fopen((base + ".pvar").c_str(), "w");
+	if (!f) {
+		SetErr(errbuf, "cannot create '" + base + ".pvar'");
+		return PGH_ERR_OPEN;
+	}
+	std::fprintf(f, "#CHROM\tPOS\tID\tREF\tALT\n");
+	for (uint32_t v = 0; v < variant_ct; v++) {
+		// 22 autosomes, equal-sized runs, ascending positions
+		const uint32_t per_chrom = (variant_ct + 21) / 22;
+		std::fprintf(f, "%u\t%u\tsv%u\tA\tG\n", v / per_chrom + 1, (v % per_chrom + 1) * 100, v);
+	}
+	std::fclose(f);
+	f = std::fopen((base + ".psam").c_str(), "w");
+	if (!f) {
+		SetErr(errbuf, "cannot create '" + base + ".psam'");
+		return PGH_ERR_OPEN;
+	}
+	std::fprintf(f, "#FID\tIID\tSEX\n");
+	for (uint32_t s = 0; s < sample_ct; s++) {
+		std::fprintf(f, "F%u\tS%u\t%u\n", s / 4, s, 1 + (s & 1));
+	}
+	std::fclose(f);
+	return PGH_OK;
+}
+
+// A synthetic .pgen whose records carry a 0x60 dosage track behind the 2-bit bytes pgh_synth_write_files
+// would write: presence bits Bernoulli(dosage_rate) per sample, values uniform on 0..32768.  Records vary
+// in length, so the header tables are written after the body.
+static int WriteSynthDosagePgen(const std::string &base, uint32_t variant_ct, uint32_t sample_ct, uint64_t seed,
+                                   double missing_rate, double dosage_rate, char *errbuf) {
+	const uint32_t rb = (sample_ct + 3) / 4, pb = (sample_ct + 7) / 8;
+	FILE *f = std::fopen((base + ".pgen").c_str(), "wb");
+	if (!f) {
+		SetErr(errbuf, "cannot create '" + base + ".pgen'");
+		return PGH_ERR_OPEN;
+	}
+	const uint32_t blocks = (variant_ct + 65535) / 65536;
+	const uint64_t table_bytes = 12 + 8ull * blocks + 5ull * variant_ct; // 8-bit vrtypes, 4-byte record lengths
+	std::vector<uint8_t> pad(table_bytes, 0);
+	bool ok = std::fwrite(pad.data(), 1, pad.size(), f) == pad.size();
+	std::vector<uint32_t> lens(variant_ct);
+	const uint32_t threshold = pgh::SynthMissThreshold(dosage_rate);
+	const uint32_t workers = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+	const uint32_t block_rows = std::max<uint32_t>(workers, static_cast<uint32_t>((64ull << 20) / (rb + pb + 2ull * sample_ct)));
+	std::vector<std::vector<uint8_t>> recs(block_rows);
+	for (uint32_t v0 = 0; ok && v0 < variant_ct; v0 += block_rows) {
+		const uint32_t n = std::min(block_rows, variant_ct - v0);
+		std::vector<std::thread> pool;
+		for (uint32_t t = 0; t < workers; t++) {
+			pool.emplace_back([&, t] {
+				for (uint32_t i = t; i < n; i += workers) {
+					const uint32_t v = v0 + i;
+					std::vector<uint8_t> &rec = recs[i];
+					rec.assign(static_cast<size_t>(rb) + pb, 0);
+					pgh_synth_record_host(v, sample_ct, seed, missing_rate, rec.data());
+					const uint64_t key = pgh::Mix64(pgh::Mix64(seed) ^ (static_cast<uint64_t>(v) << 32) ^ 0x5851f42d4c957f2dULL);
+					for (uint32_t s = 0; s < sample_ct; s++) {
+						const uint64_t h = pgh::Mix64(key ^ s);
+						if (static_cast<uint32_t>(h) < threshold) {
+							rec[rb + (s >> 3)] |= static_cast<uint8_t>(1u << (s & 7));
+							const uint32_t val = static_cast<uint32_t>(((h >> 32) * 32769ull) >> 32);
+							rec.push_back(static_cast<uint8_t>(val));
+							rec.push_back(static_cast<uint8_t>(val >> 8));
+						}
+					}
+					lens[v] = static_cast<uint32_t>(rec.size());
+				}
+			});
+		}
+		for (auto &th : pool) {
+			th.join();
+		}
+		for (uint32_t i = 0; ok && i < n; i++) {
+			ok = std::fwrite(recs[i].data(), 1, recs[i].size(), f) == recs[i].size();
+		}
+	}
+	std::vector<uint8_t> head = {0x6c, 0x1b, 0x10};
+	auto put = [&](uint64_t v, int n) {
+		for (int i = 0; i < n; i++) {
+			head.push_back(static_cast<uint8_t>(v >> (8 * i)));
+		}
+	};
+	put(variant_ct, 4);
+	put(sample_ct, 4);
+	head.push_back(0x40 | 4 | 3);
+	uint64_t at = table_bytes;
+	for (uint32_t b = 0; b < blocks; b++) {
+		put(at, 8);
+		const uint32_t lo = b * 65536u, hi = std::min<uint64_t>(variant_ct, (b + 1ull) * 65536u);
+		for (uint32_t v = lo; v < hi; v++) {
+			at += lens[v];
+		}
+	}
+	for (uint32_t b = 0; b < blocks; b++) {
+		const uint32_t lo = b * 65536u, hi = std::min<uint64_t>(variant_ct, (b + 1ull) * 65536u);
+		head.insert(head.end(), hi - lo, 0x60);
+		for (uint32_t v = lo; v < hi; v++) {
+			put(lens[v], 4);
+		}
+	}
+	ok = ok && head.size() == table_bytes && std::fseek(f, 0, SEEK_SET) == 0 &&
+	     std::fwrite(head.data(), 1, head.size(), f) == head.size();
+	ok = (std::fclose(f) == 0) && ok;
+	if (!ok) {
+		SetErr(errbuf, "write failed on '" + base + ".pgen'");
+		return PGH_ERR_OPEN;
+	}
+	return PGH_OK;
+}
+
 extern "C" int pgh_synth_write_files(const char *prefix, uint32_t variant_ct, uint32_t sample_ct, uint64_t seed,
                                      double missing_rate, char *errbuf) {
 	if (!prefix || sample_ct == 0) {
@@ -906,29 +1020,18 @@ extern "C" int pgh_synth_write_files(const char *prefix, uint32_t variant_ct, ui
 		SetErr(errbuf, "write failed on '" + base + ".pgen'");
 		return PGH_ERR_OPEN;
 	}
-	f = std::fopen((base + ".pvar").c_str(), "w");
-	if (!f) {
-		SetErr(errbuf, "cannot create '" + base + ".pvar'");
-		return PGH_ERR_OPEN;
+	return WriteSynthCompanions(base, variant_ct, sample_ct, errbuf);
+}
+
+extern "C" int pgh_synth_write_dosage_files(const char *prefix, uint32_t variant_ct, uint32_t sample_ct, uint64_t seed,
+                                            double missing_rate, double dosage_rate, char *errbuf) {
+	if (!prefix || sample_ct == 0 || !(dosage_rate >= 0.0 && dosage_rate <= 1.0)) {
+		SetErr(errbuf, "bad argument");
+		return PGH_ERR_ARG;
 	}
-	std::fprintf(f, "#CHROM\tPOS\tID\tREF\tALT\n");
-	for (uint32_t v = 0; v < variant_ct; v++) {
-		// 22 autosomes, equal-sized runs, ascending positions
-		const uint32_t per_chrom = (variant_ct + 21) / 22;
-		std::fprintf(f, "%u\t%u\tsv%u\tA\tG\n", v / per_chrom + 1, (v % per_chrom + 1) * 100, v);
-	}
-	std::fclose(f);
-	f = std::fopen((base + ".psam").c_str(), "w");
-	if (!f) {
-		SetErr(errbuf, "cannot create '" + base + ".psam'");
-		return PGH_ERR_OPEN;
-	}
-	std::fprintf(f, "#FID\tIID\tSEX\n");
-	for (uint32_t s = 0; s < sample_ct; s++) {
-		std::fprintf(f, "F%u\tS%u\t%u\n", s / 4, s, 1 + (s & 1));
-	}
-	std::fclose(f);
-	return PGH_OK;
+	const std::string base(prefix);
+	int rc = WriteSynthDosagePgen(base, variant_ct, sample_ct, seed, missing_rate, dosage_rate, errbuf);
+	return rc == PGH_OK ? WriteSynthCompanions(base, variant_ct, sample_ct, errbuf) : rc;
 }
 
 extern "C" int pgh_copy_rows_to_host(const pgh_dataset *ds, uint32_t v_begin, uint32_t v_end, uint8_t *rows,

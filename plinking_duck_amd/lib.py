@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "pgh_counts_range_dev", "pgh_freq_from_counts_dev", "pgh_fused_tally_dev", "pgh_missing_per_sample", "pgh_missing_per_sample_dev", "pgh_unpack_range",
     "pgh_unpack_range_dev", "pgh_score", "pgh_score_dev", "pgh_score_plan_create", "pgh_score_run_dev",
     "pgh_score_plan_destroy", "pgh_pca", "pgh_pca_sharded", "pgh_ld_pairs", "pgh_ld_pairs_dev", "pgh_sample_counts", "pgh_sample_counts_dev",
-    "pgh_synth_add_dosage", "pgh_dosage_sums", "pgh_dosage_sums_dev", "pgh_dosage_unpack", "pgh_dosage_unpack_dev", "pgh_reader_create", "pgh_reader_destroy",
+    "pgh_synth_add_dosage", "pgh_synth_write_dosage_files", "pgh_dosage_sums", "pgh_dosage_sums_dev", "pgh_dosage_unpack", "pgh_dosage_unpack_dev", "pgh_reader_create", "pgh_reader_destroy",
     "pgh_get_2bit", "pgh_get_counts", "pgh_get_missingness", "pgh_get_int8", "pgh_get_dosage_f64", "pgh_get_phased",
     "pgh_reader_error", "pgh_hwe_lnp", "pgh_hwe_xchr_lnp", "pgh_hwe_lnp_batch", "pgh_hwe_lnp_batch_dev", "pgh_hwe_xchr_lnp_batch",
 ]
@@ -114,6 +114,7 @@ def _load():
         "pgh_sample_counts": (C.c_int, [vp, vp, u32, u32, vp, vp, cp]),
         "pgh_sample_counts_dev": (C.c_int, [vp, u32, u32, vp, vp, cp]),
         "pgh_synth_add_dosage": (C.c_int, [vp, C.c_double, C.c_uint64, cp]),
+        "pgh_synth_write_dosage_files": (C.c_int, [cp, u32, u32, C.c_uint64, C.c_double, C.c_double, cp]),
         "pgh_dosage_sums": (C.c_int, [vp, vp, u32, u32, vp, vp, cp]),
         "pgh_dosage_sums_dev": (C.c_int, [vp, vp, u32, u32, vp, vp, cp]),
         "pgh_dosage_unpack": (C.c_int, [vp, vp, u32, u32, vp, vp, cp]),
@@ -243,6 +244,11 @@ def synth_record_host(v: int, n: int, seed: int, missing_rate: float) -> np.ndar
 def synth_write_files(prefix: str, m: int, n: int, seed: int, missing_rate: float):
     eb = _errbuf()
     _check(_lib.pgh_synth_write_files(prefix.encode(), m, n, seed, missing_rate, eb), eb)
+
+
+def synth_write_dosage_files(prefix: str, m: int, n: int, seed: int, missing_rate: float, dosage_rate: float):
+    eb = _errbuf()
+    _check(_lib.pgh_synth_write_dosage_files(prefix.encode(), m, n, seed, missing_rate, dosage_rate, eb), eb)
 
 
 class Subset:
