@@ -240,3 +240,36 @@ def test_malformed_dosage_tracks_are_reported(files, gpu_lib, tmp_path):
     open(p, "wb").write(bad)
     with pytest.raises(gpu_lib.PghError):
         gpu_lib.Dataset.open(p)
+
+
+@pytest.mark.gpu
+def test_device_track_reader_survives_corrupt_bytes(files, gpu_lib, tmp_path):
+    """Random byte damage inside the records (aux tracks included): every open either fails with a
+    PGH_ERR_* or yields tracks whose own bookkeeping is consistent; the kernels' reads stay inside the
+    staged bytes, their writes inside the rows they own."""
+    path, geno, dos, dkinds, want = files[(120, 1000, True)]
+    raw = np.frombuffer(open(path, "rb").read(), dtype=np.uint8)
+    body_at = 12 + 8 + 5 * 120
+    rng = np.random.default_rng(99)
+    opened = failed = 0
+    for trial in range(60):
+        bad = raw.copy()
+        hits = rng.integers(body_at, len(bad), size=int(rng.integers(1, 6)))
+        bad[hits] = rng.integers(0, 256, size=len(hits), dtype=np.uint8)
+        p = str(tmp_path / f"c{trial}.pgen")
+        bad.tofile(p)
+        try:
+            ds = gpu_lib.Dataset.open(p)
+        except gpu_lib.PghError:
+            failed += 1
+            continue
+        opened += 1
+        sums = ds.dosage_sums()
+        d = ds.dosage_unpack()
+        assert int(ds.info.dosage_value_ct) <= int((dos != 0xFFFF).sum()) + 1000 * 120
+        assert ((d == -9.0) | ((d >= 0.0) & (d <= 2.0))).all()
+        assert (sums[:, 2] <= 1000).all()
+        ds.close()
+    assert opened and failed  # both outcomes occur: damage to a value is silent, damage to the structure is not
+    ds = gpu_lib.Dataset.open(path)  # the device is still healthy
+    assert np.array_equal(ds.dosage_unpack(), want)
