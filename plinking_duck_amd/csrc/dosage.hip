@@ -757,22 +757,25 @@ __global__ __launch_bounds__(1024, 8) void k_score_dosage_fix(const uint8_t *__r
 			atomicSub(miss + 64u * w + b, 1u); /* it has a dosage: not missing after all */                            \
 		}                                                                                                              \
 	}
-		// the first eight values of the word are fetched together (one memory latency, not one per entry)
-		const uint32_t have = static_cast<uint32_t>(__popcll(e));
-#define PGH_AHEAD(P, J0, J1)                                                                                           \
-	const uint32_t p##P = ((J0) < have ? vals[J0] : 0u) | (((J1) < have ? vals[J1] : 0u) << 16); /* two per register */
-		PGH_AHEAD(0, 0, 1) PGH_AHEAD(1, 2, 3) PGH_AHEAD(2, 4, 5) PGH_AHEAD(3, 6, 7)
-#undef PGH_AHEAD
+		// The word's first sixteen values arrive in two 16-byte loads (2-byte aligned: the hardware takes
+		// unaligned global loads), so a word costs one memory latency, not one per entry; they may run past
+		// the word's own run, into its neighbours' or the array's padding, and only `have` of them are used.
+		uint4 pa = make_uint4(0, 0, 0, 0), pb = make_uint4(0, 0, 0, 0);
+		if (e) {
+			__builtin_memcpy(&pa, vals, 16);
+			__builtin_memcpy(&pb, vals + 8, 16);
+		}
 #define PGH_STEP(P)                                                                                                    \
 	if (e) {                                                                                                           \
-		PGH_DOSAGE_ENTRY(p##P & 0xffffu)                                                                               \
+		PGH_DOSAGE_ENTRY((P) & 0xffffu)                                                                                \
 	}                                                                                                                  \
 	if (e) {                                                                                                           \
-		PGH_DOSAGE_ENTRY(p##P >> 16)                                                                                   \
+		PGH_DOSAGE_ENTRY((P) >> 16)                                                                                    \
 	}
-		PGH_STEP(0) PGH_STEP(1) PGH_STEP(2) PGH_STEP(3)
+		PGH_STEP(pa.x) PGH_STEP(pa.y) PGH_STEP(pa.z) PGH_STEP(pa.w)
+		PGH_STEP(pb.x) PGH_STEP(pb.y) PGH_STEP(pb.z) PGH_STEP(pb.w)
 #undef PGH_STEP
-		uint32_t n = 8;
+		uint32_t n = 16;
 		while (e) {
 			const uint32_t u = vals[n++];
 			PGH_DOSAGE_ENTRY(u)
