@@ -20,6 +20,7 @@ __device__ __forceinline__ uint32_t WaveSum(uint32_t x) {
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint4 LoadStream(const uint4 *p) {
 	// once-read stream: non-temporal so it does not evict the mask / tables from L2

@@ -356,151 +356,187 @@ __global__ __launch_bounds__(256) void k_missing_cols(const uint8_t *__restrict_
 // ---------------------------------------------------------------------------
 //
 // read_pfile's sample-orient counts need het, hom-alt and missing per sample; three passes of
-// k_missing_cols read the matrix three times.  One pass keeps three sets of SWAR counters per
-// lane, which only fits the register file if the last level stays 8-bit: a workgroup therefore
-// takes a slice of at most 252 rows and writes its 3 x 64 byte counters per lane raw (the a8
-// layout: word 4j+q, byte b counts sample 16j + 4b + {0,2,1,3}[q]); k_sum_class_bytes undoes the
-// layout and adds the slices.  The byte slabs are 3 B per sample per 252 rows, +1 % of the read.
-constexpr uint32_t kCols3Rows = 252;   // rows per slice: a multiple of 6, <= 255
-constexpr uint32_t kCols3Super = 256;  // slices per launch (bounds the slab scratch to ~0.4 GB at N = 500k)
+// k_missing_cols read the matrix three times.  This is a positional population count: how often each
+// BIT POSITION of a lane's 16 bytes is set over the rows.  A 2-bit word needs no unpacking for that --
+//     n_lo[s]   = rows with the low bit of s set   = het + missing
+//     n_hi[s]   = rows with the high bit of s set  = hom-alt + missing
+//     n_both[s] = rows with both set               = missing
+// so a lane's two raw dwords go straight into bit-sliced counters (plane p holds bit p of every position's
+// count) through a Harley-Seal carry-save tree, 16 rows per trip: 15 carry-save adders (5 ops each) per
+// word instead of per-row field arithmetic, and only the `both` stream costs extraction (lo & hi, two
+// dwords packed into one).  A lane owns 8 bytes (32 samples): three counter words x 10 planes + carries
+// keep it near 80 VGPRs, so enough waves are resident to hold sixteen rows in flight each.  Ten planes
+// count to 1023: a workgroup takes a slice of 1008 rows and writes its planes raw (120 B per lane); k_sum_class_bits turns bit positions back into
+// samples, adds the slices and takes the differences.  (The SWAR field-widening form this replaced spent
+// ~70 VALU ops per 16 bytes and streamed at 0.62 of the HBM roofline; this one spends ~50.)
+constexpr uint32_t kCols3Rows = 1008;  // rows per slice: a multiple of 16, <= 1023
+constexpr uint32_t kCols3Super = 256;  // slices per launch (bounds the plane scratch to ~0.5 GB at N = 500k)
+constexpr int kCols3Planes = 10;
+constexpr uint32_t kCols3Words = 3;    // per lane: two raw dwords (lo / hi bits interleaved) + their packed `both` word
 
-struct ClassAcc8 {
-	uint32_t a4[8];
-	uint32_t a8[16];
+__device__ __forceinline__ void Csa(uint32_t &h, uint32_t &l, uint32_t a, uint32_t b, uint32_t c) {
+	const uint32_t u = a ^ b;
+	h = (a & b) | (u & c);
+	l = u ^ c;
+}
+
+// bit-sliced counter of one 32-bit word of indicator bits, fed four rows at a time
+struct BitCounter {
+	uint32_t p[kCols3Planes]; // p[0] ones, p[1] twos, p[2] fours, p[3] eights, p[4] sixteens, ...
+	uint32_t fours_a, eights_a; // carries waiting for their partner inside a 16-row trip
+
+	__device__ __forceinline__ void Clear() {
+#pragma unroll
+		for (int k = 0; k < kCols3Planes; k++) {
+			p[k] = 0;
+		}
+		fours_a = eights_a = 0;
+	}
+	// rows 4g .. 4g+3 of a 16-row trip (g = 0..3, compile-time)
+	template <int G>
+	__device__ __forceinline__ void Add4(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) {
+		uint32_t twos_a, twos_b, fours;
+		Csa(twos_a, p[0], p[0], x0, x1);
+		Csa(twos_b, p[0], p[0], x2, x3);
+		Csa(fours, p[1], p[1], twos_a, twos_b);
+		if (G == 0 || G == 2) {
+			fours_a = fours;
+			return;
+		}
+		uint32_t eights;
+		Csa(eights, p[2], p[2], fours_a, fours);
+		if (G == 1) {
+			eights_a = eights;
+			return;
+		}
+		uint32_t carry;
+		Csa(carry, p[3], p[3], eights_a, eights);
+#pragma unroll
+		for (int k = 4; k < kCols3Planes; k++) { // ripple the sixteens up
+			const uint32_t t = p[k] & carry;
+			p[k] ^= carry;
+			carry = t;
+		}
+	}
 };
-
-__device__ __forceinline__ void Fold2To4(ClassAcc8 &acc, const uint32_t a2[4]) {
-#pragma unroll
-	for (int j = 0; j < 4; j++) {
-		acc.a4[2 * j] += a2[j] & 0x33333333u;
-		acc.a4[2 * j + 1] += (a2[j] >> 2) & 0x33333333u;
-	}
-}
-
-__device__ __forceinline__ void Fold4To8(ClassAcc8 &acc) {
-#pragma unroll
-	for (int j = 0; j < 4; j++) {
-		acc.a8[4 * j + 0] += acc.a4[2 * j] & 0x0f0f0f0fu;
-		acc.a8[4 * j + 1] += (acc.a4[2 * j] >> 4) & 0x0f0f0f0fu;
-		acc.a8[4 * j + 2] += acc.a4[2 * j + 1] & 0x0f0f0f0fu;
-		acc.a8[4 * j + 3] += (acc.a4[2 * j + 1] >> 4) & 0x0f0f0f0fu;
-		acc.a4[2 * j] = 0;
-		acc.a4[2 * j + 1] = 0;
-	}
-}
 
 __global__ __launch_bounds__(256) void k_class_cols3(const uint8_t *__restrict__ rows, uint64_t pitch, uint32_t chunks,
                                                      uint32_t v_first, const uint32_t *__restrict__ vlist,
-                                                     uint32_t v_count, uint8_t *__restrict__ slabs,
+                                                     uint32_t v_count, uint32_t *__restrict__ slabs,
                                                      uint64_t slab_stride) {
-	const uint32_t col = blockIdx.x * 256u + threadIdx.x;
+	const uint32_t col = blockIdx.x * 256u + threadIdx.x; // 8 bytes = 32 samples per lane
 	if (col >= chunks) {
 		return;
 	}
 	const uint32_t i_begin = blockIdx.y * kCols3Rows;
 	const uint32_t i_end = min(i_begin + kCols3Rows, v_count);
-	ClassAcc8 acc[3]; // het, hom-alt, missing
+	BitCounter ctr[kCols3Words];
 #pragma unroll
-	for (int c = 0; c < 3; c++) {
-#pragma unroll
-		for (int j = 0; j < 8; j++) {
-			acc[c].a4[j] = 0;
-		}
-#pragma unroll
-		for (int j = 0; j < 16; j++) {
-			acc[c].a8[j] = 0;
-		}
+	for (uint32_t k = 0; k < kCols3Words; k++) {
+		ctr[k].Clear();
 	}
-	auto row_ptr = [&](uint32_t idx) {
+	// rows past the slice read as all hom-ref: they add nothing to any counter
+	auto load = [&](uint32_t idx) {
+		if (idx >= i_end) {
+			return make_uint2(0, 0);
+		}
 		const uint32_t v = vlist ? vlist[idx] : v_first + idx;
-		return reinterpret_cast<const uint4 *>(rows + static_cast<uint64_t>(v) * pitch) + col;
+		const u32x2 w = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(rows + static_cast<uint64_t>(v) * pitch) + col);
+		return make_uint2(w.x, w.y);
 	};
-	// indicator words of the three codes of one data word, added into a2[class][word]
-	auto add_word = [&](uint32_t w, uint32_t a2[3][4], int k) {
-		const uint32_t lo = w & kLow, hi = (w >> 1) & kLow;
-		const uint32_t both = lo & hi;
-		a2[0][k] += lo ^ both;
-		a2[1][k] += hi ^ both;
-		a2[2][k] += both;
-	};
-	auto add_row = [&](const uint4 &w, uint32_t a2[3][4]) {
-		add_word(w.x, a2, 0);
-		add_word(w.y, a2, 1);
-		add_word(w.z, a2, 2);
-		add_word(w.w, a2, 3);
-	};
-	uint32_t n4 = 0; // rows folded into the 4-bit fields since the last 4 -> 8 fold
-	auto fold = [&](uint32_t a2[3][4], uint32_t take) {
-#pragma unroll
-		for (int c = 0; c < 3; c++) {
-			Fold2To4(acc[c], a2[c]);
-		}
-		n4 += take;
-		if (n4 + 3 > 15) {
-#pragma unroll
-			for (int c = 0; c < 3; c++) {
-				Fold4To8(acc[c]);
-			}
-			n4 = 0;
-		}
-	};
-	uint32_t i = i_begin;
-	while (i + 6 <= i_end) {
-		const uint4 w0 = LoadStream(row_ptr(i));
-		const uint4 w1 = LoadStream(row_ptr(i + 1));
-		const uint4 w2 = LoadStream(row_ptr(i + 2));
-		const uint4 w3 = LoadStream(row_ptr(i + 3));
-		const uint4 w4 = LoadStream(row_ptr(i + 4));
-		const uint4 w5 = LoadStream(row_ptr(i + 5));
-		uint32_t a[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-		add_row(w0, a);
-		add_row(w1, a);
-		add_row(w2, a);
-		fold(a, 3);
-		uint32_t b[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-		add_row(w3, b);
-		add_row(w4, b);
-		add_row(w5, b);
-		fold(b, 3);
-		i += 6;
+	// samples with both bits set: those of dword x at even positions, those of dword y at odd ones
+	auto both = [](const uint2 &r) { return (r.x & (r.x >> 1) & kLow) | ((r.y & (r.y << 1)) & ~kLow); };
+#define PGH_COLS3_GROUP(G, R0, R1, R2, R3)                                                                             \
+	ctr[0].Add4<G>(R0.x, R1.x, R2.x, R3.x);                                                                            \
+	ctr[1].Add4<G>(R0.y, R1.y, R2.y, R3.y);                                                                            \
+	ctr[2].Add4<G>(both(R0), both(R1), both(R2), both(R3));
+	for (uint32_t i = i_begin; i < i_end; i += 16u) {
+		// sixteen rows per trip, all in flight before the first is used
+		const uint2 r0 = load(i), r1 = load(i + 1), r2 = load(i + 2), r3 = load(i + 3);
+		const uint2 r4 = load(i + 4), r5 = load(i + 5), r6 = load(i + 6), r7 = load(i + 7);
+		const uint2 r8 = load(i + 8), r9 = load(i + 9), r10 = load(i + 10), r11 = load(i + 11);
+		const uint2 r12 = load(i + 12), r13 = load(i + 13), r14 = load(i + 14), r15 = load(i + 15);
+		PGH_COLS3_GROUP(0, r0, r1, r2, r3)
+		PGH_COLS3_GROUP(1, r4, r5, r6, r7)
+		PGH_COLS3_GROUP(2, r8, r9, r10, r11)
+		PGH_COLS3_GROUP(3, r12, r13, r14, r15)
 	}
-	while (i < i_end) {
-		const uint4 w0 = LoadStream(row_ptr(i));
-		uint32_t a[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-		add_row(w0, a);
-		fold(a, 1);
-		i += 1;
-	}
+#undef PGH_COLS3_GROUP
+	// planes of word k: slabs[slice][k][plane][col]  (a wave writes 256 contiguous bytes per plane)
+	uint32_t *dst = slabs + static_cast<uint64_t>(blockIdx.y) * slab_stride + col;
 #pragma unroll
-	for (int c = 0; c < 3; c++) {
-		Fold4To8(acc[c]);
-		uint4 *dst = reinterpret_cast<uint4 *>(slabs + (static_cast<uint64_t>(blockIdx.y) * 3u + c) * slab_stride +
-		                                       static_cast<uint64_t>(col) * 64u);
+	for (uint32_t k = 0; k < kCols3Words; k++) {
 #pragma unroll
-		for (int k = 0; k < 4; k++) {
-			dst[k] = make_uint4(acc[c].a8[4 * k], acc[c].a8[4 * k + 1], acc[c].a8[4 * k + 2], acc[c].a8[4 * k + 3]);
+		for (int pl = 0; pl < kCols3Planes; pl++) {
+			dst[(static_cast<uint64_t>(k) * kCols3Planes + pl) * chunks] = ctr[k].p[pl];
 		}
 	}
 }
 
-// out[c][s] (+)= sum over the slices of sample s's byte counter of class c
-__global__ __launch_bounds__(256) void k_sum_class_bytes(const uint8_t *__restrict__ slabs, uint64_t slab_stride,
-                                                         uint32_t n_slices, uint32_t n, uint32_t out_stride,
-                                                         uint32_t accumulate, uint32_t *__restrict__ out) {
-	const uint32_t s = blockIdx.x * 256u + threadIdx.x;
-	const uint32_t c = blockIdx.y;
-	if (s >= n) {
+// out[c][s] += class c of sample s summed over the slices: c = 0 het, 1 hom-alt, 2 missing.
+// A lane owns one column of k_class_cols3 (32 samples) and a run of slices: it adds the slices' 10-plane
+// numbers in bit-sliced form (a ripple-carry adder over planes, ~75 ops per word per slice, every plane word
+// read once and coalesced) and only at the end turns bit positions into samples:
+// raw dword j holds sample 16j + k's low bit at 2k and high bit at 2k + 1, the packed `both` word its
+// both-bit at 2k + j.
+constexpr int kCols3SumPlanes = 18;        // kCols3Super * kCols3Rows < 2^18
+constexpr uint32_t kCols3SumGroup = 64;    // slices per lane: the rest of the parallelism comes from grid.y
+__global__ __launch_bounds__(256) void k_sum_class_bits(const uint32_t *__restrict__ slabs, uint64_t slab_stride,
+                                                        uint32_t chunks, uint32_t n_slices, uint32_t n,
+                                                        uint32_t out_stride, uint32_t *__restrict__ out) {
+	const uint32_t col = blockIdx.x * 256u + threadIdx.x;
+	if (col >= chunks) {
 		return;
 	}
-	// where k_class_cols3 left sample s: lane column s / 64; inside it word 4j + q, byte b
-	const uint32_t t = s & 63u, j = t >> 4, r = t & 15u, b = r >> 2, within = r & 3u;
-	const uint32_t q = within == 0 ? 0u : (within == 1 ? 2u : (within == 2 ? 1u : 3u));
-	const uint64_t at = static_cast<uint64_t>(s >> 6) * 64u + (4u * j + q) * 4u + b;
-	uint32_t acc = accumulate ? out[static_cast<uint64_t>(c) * out_stride + s] : 0u;
-	for (uint32_t y = 0; y < n_slices; y++) {
-		acc += slabs[(static_cast<uint64_t>(y) * 3u + c) * slab_stride + at];
+	uint32_t acc[kCols3Words][kCols3SumPlanes];
+#pragma unroll
+	for (uint32_t k = 0; k < kCols3Words; k++) {
+#pragma unroll
+		for (int pl = 0; pl < kCols3SumPlanes; pl++) {
+			acc[k][pl] = 0;
+		}
 	}
-	out[static_cast<uint64_t>(c) * out_stride + s] = acc;
+	const uint32_t y_begin = blockIdx.y * kCols3SumGroup;
+	const uint32_t y_end = min(y_begin + kCols3SumGroup, n_slices);
+	for (uint32_t y = y_begin; y < y_end; y++) {
+		const uint32_t *sl = slabs + static_cast<uint64_t>(y) * slab_stride + col;
+		uint32_t x[kCols3Words * kCols3Planes]; // the slice's thirty plane words, all in flight together
+#pragma unroll
+		for (uint32_t q = 0; q < kCols3Words * kCols3Planes; q++) {
+			x[q] = __builtin_nontemporal_load(sl + static_cast<uint64_t>(q) * chunks);
+		}
+#pragma unroll
+		for (uint32_t k = 0; k < kCols3Words; k++) {
+			uint32_t carry = 0;
+#pragma unroll
+			for (int pl = 0; pl < kCols3Planes; pl++) {
+				Csa(carry, acc[k][pl], acc[k][pl], x[k * kCols3Planes + pl], carry);
+			}
+#pragma unroll
+			for (int pl = kCols3Planes; pl < kCols3SumPlanes; pl++) {
+				const uint32_t t = acc[k][pl] & carry;
+				acc[k][pl] ^= carry;
+				carry = t;
+			}
+		}
+	}
+#pragma unroll
+	for (uint32_t t = 0; t < 32; t++) {
+		const uint32_t s = 32u * col + t;
+		const uint32_t j = t >> 4, k = t & 15u;
+		uint32_t n_lo = 0, n_hi = 0, n_both = 0;
+#pragma unroll
+		for (int pl = 0; pl < kCols3SumPlanes; pl++) {
+			n_lo += ((acc[j][pl] >> (2 * k)) & 1u) << pl;
+			n_hi += ((acc[j][pl] >> (2 * k + 1)) & 1u) << pl;
+			n_both += ((acc[2][pl] >> (2 * k + j)) & 1u) << pl;
+		}
+		if (s < n) {
+			atomicAdd(out + s, n_lo - n_both);
+			atomicAdd(out + static_cast<uint64_t>(out_stride) + s, n_hi - n_both);
+			atomicAdd(out + 2ull * out_stride + s, n_both);
+		}
+	}
 }
 
 // ---------------------------------------------------------------------------
@@ -952,8 +988,8 @@ hipError_t LaunchClassPerSample(const RowView &view, int genotype_class, uint32_
 }
 
 size_t ClassCounts3ScratchBytes(uint32_t record_bytes) {
-	const uint64_t chunks = (static_cast<uint64_t>(record_bytes) + 15) / 16;
-	return static_cast<size_t>(kCols3Super) * 3u * chunks * 64u;
+	const uint64_t chunks = (static_cast<uint64_t>(record_bytes) + 7) / 8;
+	return static_cast<size_t>(kCols3Super) * kCols3Words * kCols3Planes * chunks * 4u;
 }
 
 hipError_t LaunchClassCounts3(const RowView &view, uint32_t v_first, const uint32_t *vlist, uint32_t v_count,
@@ -961,21 +997,26 @@ hipError_t LaunchClassCounts3(const RowView &view, uint32_t v_first, const uint3
 	if (v_count == 0) {
 		return hipMemsetAsync(out, 0, sizeof(uint32_t) * 3ull * out_stride, stream);
 	}
-	const uint32_t chunks = static_cast<uint32_t>((static_cast<uint64_t>(view.record_bytes) + 15) / 16);
+	const uint32_t chunks = static_cast<uint32_t>((static_cast<uint64_t>(view.record_bytes) + 7) / 8);
 	const uint32_t col_blocks = (chunks + 255) / 256;
-	const uint64_t slab_stride = static_cast<uint64_t>(chunks) * 64u;
+	const uint64_t slab_stride = static_cast<uint64_t>(chunks) * kCols3Words * kCols3Planes; // dwords per slice
 	const uint32_t rows_per_launch = kCols3Super * kCols3Rows;
+	uint32_t *slabs = reinterpret_cast<uint32_t *>(scratch);
+	hipError_t e = hipMemsetAsync(out, 0, sizeof(uint32_t) * 3ull * out_stride, stream);
+	if (e != hipSuccess) {
+		return e;
+	}
 	for (uint32_t done = 0; done < v_count; done += rows_per_launch) {
 		const uint32_t n_rows = std::min(rows_per_launch, v_count - done);
 		const uint32_t slices = (n_rows + kCols3Rows - 1) / kCols3Rows;
 		hipLaunchKernelGGL(k_class_cols3, dim3(col_blocks, slices), dim3(256), 0, stream, view.rows, view.pitch, chunks,
-		                   v_first + done, vlist ? vlist + done : nullptr, n_rows, scratch, slab_stride);
-		hipError_t e = hipGetLastError();
+		                   v_first + done, vlist ? vlist + done : nullptr, n_rows, slabs, slab_stride);
+		e = hipGetLastError();
 		if (e != hipSuccess) {
 			return e;
 		}
-		hipLaunchKernelGGL(k_sum_class_bytes, dim3((view.sample_ct + 255) / 256, 3), dim3(256), 0, stream, scratch,
-		                   slab_stride, slices, view.sample_ct, out_stride, done ? 1u : 0u, out);
+		hipLaunchKernelGGL(k_sum_class_bits, dim3(col_blocks, (slices + kCols3SumGroup - 1) / kCols3SumGroup), dim3(256), 0,
+		                   stream, slabs, slab_stride, chunks, slices, view.sample_ct, out_stride, out);
 		e = hipGetLastError();
 		if (e != hipSuccess) {
 			return e;
