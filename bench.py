@@ -293,7 +293,7 @@ def main():
                 kernel_events.append((e0, e1))
             h_cls.copy_(d_cls, non_blocking=True)
 
-        kernel_name = "k_class_cols3 + k_sum_class_bytes"
+        kernel_name = "k_class_cols3 + k_sum_class_bits"
         metric = "read_pfile sample-orient counts genotypes/s"
     elif args.workload == "ld":
         # plink_ld windowed shape: every anchor of the first --ld-variants rows against its next
