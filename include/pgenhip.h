@@ -241,6 +241,15 @@ int pgh_dosage_sums_dev(const pgh_dataset *ds, const pgh_subset *subset, uint32_
 int pgh_dosage_unpack_dev(const pgh_dataset *ds, const pgh_subset *subset, uint32_t v_begin, uint32_t v_end,
                           void *d_out, size_t out_stride, void *stream, char *errbuf);
 
+/* read_pfile orient := 'sample' (src/pfile_reader.cpp:1560-1720: the reference pre-reads every effective
+ * variant with PgrGet / PgrGetD into a variants x samples matrix and emits one row per sample): the matrix
+ * sample-major, out[k][j] = call (0/1/2, missing -> missing_code) or dosage (-9.0 = missing) of output sample
+ * k at listed variant vidx[j]; rows of n_variants elements. */
+int pgh_unpack_samples(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_variants, const uint32_t *vidx,
+                       int8_t *out, int missing_code, char *errbuf);
+int pgh_dosage_unpack_samples(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_variants,
+                              const uint32_t *vidx, double *out, char *errbuf);
+
 /* read_pfile's sample-orient aggregate (src/pfile_reader.cpp:3308-3400, the streaming
  * accumulate_dense loop): counts[k] = {hom_ref, het, hom_alt, missing} of output sample k over
  * the variants [variant_begin, variant_begin + n_var) or, with vidx != NULL, the n_var listed

@@ -402,6 +402,61 @@ extern "C" int pgh_dosage_unpack(const pgh_dataset *ds, const pgh_subset *subset
 	return PGH_OK;
 }
 
+// read_pfile orient := 'sample': the variants x samples matrix, sample-major.  The output leaves the device in
+// runs of samples so the staging stays bounded whatever the number of variants.
+template <class T, class Launch>
+static int UnpackSamples(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_variants, const uint32_t *vidx,
+                         T *out, char *errbuf, Launch launch) {
+	if (!ds || (n_variants && (!vidx || !out))) {
+		SetErr(errbuf, "null argument");
+		return PGH_ERR_ARG;
+	}
+	int rc = CheckSubset(ds, subset, errbuf);
+	const uint32_t n_out = subset ? subset->n_out : ds->sample_ct;
+	if (rc != PGH_OK || n_variants == 0 || n_out == 0) {
+		return rc;
+	}
+	hipStream_t st = hipStreamPerThread;
+	DevBuf d_list, d_out;
+	std::vector<uint32_t> local;
+	rc = UploadVariantList(ds, 0, n_variants, vidx, d_list, st, local, errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	const uint64_t row_bytes = sizeof(T) * static_cast<uint64_t>(n_variants);
+	uint32_t chunk = static_cast<uint32_t>(std::min<uint64_t>(n_out, std::max<uint64_t>(64, (512ull << 20) / row_bytes)));
+	chunk = (chunk + 63) / 64 * 64;
+	PGH_HIP(d_out.Alloc(row_bytes * chunk), "hipMalloc(sample-major unpack)");
+	for (uint32_t k0 = 0; k0 < n_out; k0 += chunk) {
+		const uint32_t cnt = std::min(chunk, n_out - k0);
+		PGH_HIP(launch(d_list.As<uint32_t>(), k0, cnt, d_out.As<T>(), st), "sample-major unpack kernel");
+		PGH_HIP(hipMemcpyAsync(out + static_cast<uint64_t>(k0) * n_variants, d_out.p, row_bytes * cnt, hipMemcpyDeviceToHost, st),
+		        "sample-major unpack copy");
+		PGH_HIP(hipStreamSynchronize(st), "sample-major unpack sync");
+	}
+	return PGH_OK;
+}
+
+extern "C" int pgh_unpack_samples(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_variants,
+                                  const uint32_t *vidx, int8_t *out, int missing_code, char *errbuf) {
+	return UnpackSamples<int8_t>(ds, subset, n_variants, vidx, out, errbuf,
+	                             [&](const uint32_t *d_list, uint32_t k0, uint32_t cnt, int8_t *d_out, hipStream_t st) {
+		                             return pgh::LaunchUnpackTransposed(ds->View(), d_list, n_variants,
+		                                                                subset ? subset->d_sel : nullptr, k0, cnt, d_out,
+		                                                                n_variants, static_cast<int8_t>(missing_code), st);
+	                             });
+}
+
+extern "C" int pgh_dosage_unpack_samples(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_variants,
+                                         const uint32_t *vidx, double *out, char *errbuf) {
+	return UnpackSamples<double>(ds, subset, n_variants, vidx, out, errbuf,
+	                             [&](const uint32_t *d_list, uint32_t k0, uint32_t cnt, double *d_out, hipStream_t st) {
+		                             return pgh::LaunchDosageUnpackTransposed(ds->View(), ds->Dosage(), d_list, n_variants,
+		                                                                      subset ? subset->d_sel : nullptr, k0, cnt,
+		                                                                      d_out, n_variants, st);
+	                             });
+}
+
 // ---------------------------------------------------------------------------
 // plink_score
 // ---------------------------------------------------------------------------

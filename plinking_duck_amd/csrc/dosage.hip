@@ -489,6 +489,23 @@ __global__ __launch_bounds__(256) void k_dosage_unpack(const uint8_t *__restrict
 	out[static_cast<uint64_t>(i) * out_stride + k] = u == kNoDosage ? -9.0 : static_cast<double>(u) * 0x1p-14;
 }
 
+// sample-major form of the same doubles (read_pfile orient := 'sample', dosages := true): out[k][j]
+__global__ __launch_bounds__(256) void k_dosage_unpack_transposed(const uint8_t *__restrict__ rows, uint64_t pitch,
+                                                                  DosageView dos, const uint32_t *__restrict__ vlist,
+                                                                  uint32_t n_var, const uint32_t *__restrict__ sel,
+                                                                  uint32_t k_first, double *__restrict__ out,
+                                                                  uint64_t out_stride) {
+	const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+	if (j >= n_var) {
+		return;
+	}
+	const uint32_t k = k_first + blockIdx.y;
+	const uint32_t lv = vlist[j];
+	const uint32_t *row32 = reinterpret_cast<const uint32_t *>(rows + static_cast<uint64_t>(lv) * pitch);
+	const uint32_t u = DosageOrCall(RowOf(dos, lv), row32, sel ? sel[k] : k);
+	out[static_cast<uint64_t>(blockIdx.y) * out_stride + j] = u == kNoDosage ? -9.0 : static_cast<double>(u) * 0x1p-14;
+}
+
 __global__ __launch_bounds__(256) void k_score_tables_dosage(const uint64_t *__restrict__ sums,
                                                              const uint8_t *__restrict__ flip, uint32_t n_scored,
                                                              int mode, double *__restrict__ ts, double *__restrict__ td,
@@ -875,6 +892,21 @@ hipError_t LaunchDosageUnpack(const RowView &view, const DosageView &dos, uint32
 		const uint32_t n = min(65535u, n_var - done);
 		hipLaunchKernelGGL(k_dosage_unpack, dim3((n_out + 255) / 256, n), dim3(256), 0, stream, view.rows, view.pitch, dos,
 		                   v0 + done, vlist ? vlist + done : nullptr, sel, n_out, out + static_cast<uint64_t>(done) * out_stride,
+		                   out_stride);
+	}
+	return hipGetLastError();
+}
+
+hipError_t LaunchDosageUnpackTransposed(const RowView &view, const DosageView &dos, const uint32_t *vlist, uint32_t n_var,
+                                        const uint32_t *sel, uint32_t k_first, uint32_t k_count, double *out,
+                                        uint64_t out_stride, hipStream_t stream) {
+	if (n_var == 0 || k_count == 0) {
+		return hipSuccess;
+	}
+	for (uint32_t done = 0; done < k_count; done += 65535u) { // grid.y limit
+		const uint32_t n = min(65535u, k_count - done);
+		hipLaunchKernelGGL(k_dosage_unpack_transposed, dim3((n_var + 255) / 256, n), dim3(256), 0, stream, view.rows,
+		                   view.pitch, dos, vlist, n_var, sel, k_first + done, out + static_cast<uint64_t>(done) * out_stride,
 		                   out_stride);
 	}
 	return hipGetLastError();

@@ -74,6 +74,11 @@ hipError_t LaunchDosageUnpack(const RowView &view, const DosageView &dos, uint32
                               uint32_t n_var, const uint32_t *sel, uint32_t n_out, double *out, uint64_t out_stride,
                               hipStream_t stream);
 
+//! The sample-major form: out[k - k_first][j] = dosage of output sample k at variant vlist[j] (local indices).
+hipError_t LaunchDosageUnpackTransposed(const RowView &view, const DosageView &dos, const uint32_t *vlist, uint32_t n_var,
+                                        const uint32_t *sel, uint32_t k_first, uint32_t k_count, double *out,
+                                        uint64_t out_stride, hipStream_t stream);
+
 //! Per scored variant, from LaunchDosageSums' output: the contribution tables of the hardcall codes
 //! (ts / td as LaunchScoreTables writes them, with the mean taken over dosages), the affine map of an
 //! explicit dosage lin = {scale, shift}: contribution = (d * scale + shift), and the ALLELE_CT increment.

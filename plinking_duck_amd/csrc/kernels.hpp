@@ -72,6 +72,12 @@ hipError_t LaunchUnpack(const RowView &view, uint32_t v_first, uint32_t v_count,
 hipError_t LaunchUnpackSubset(const RowView &view, uint32_t v_first, uint32_t v_count, const uint32_t *sel,
                               uint32_t n_out, int8_t *out, uint64_t out_pitch, uint64_t *validity, int8_t fill,
                               hipStream_t stream);
+// Sample-major form: out[k - k_first][j] (rows of out_stride bytes) = call of output sample k at variant
+// vlist[j] (local indices), missing -> fill, for k in [k_first, k_first + k_count); k_first a multiple of 64.
+// sel == NULL: output samples are the raw samples.
+hipError_t LaunchUnpackTransposed(const RowView &view, const uint32_t *vlist, uint32_t n_var, const uint32_t *sel,
+                                  uint32_t k_first, uint32_t k_count, int8_t *out, uint64_t out_stride, int8_t fill,
+                                  hipStream_t stream);
 
 // ---- plink_score ------------------------------------------------------------
 // Per scored variant i, from its counts: the scored-dosage table ts[i][g], the

@@ -6,6 +6,8 @@
 // (a multiple of 16, so every row can be streamed as whole 16-byte lanes and
 // the pad decodes as hom-ref, which every kernel cancels against N).
 #include "device_utils.hpp"
+
+#include <algorithm>
 #include "kernels.hpp"
 
 #include <cstdlib>
@@ -183,6 +185,55 @@ __global__ __launch_bounds__(256) void k_unpack_subset(const uint8_t *__restrict
 	}
 }
 
+// Sample-major unpack (read_pfile orient := 'sample', src/pfile_reader.cpp:1560-1720: the reference pre-reads
+// every effective variant into a variants x samples matrix and emits one row per sample).  out[k][j] = call
+// of output sample k at listed variant j, missing -> fill.  A workgroup moves a 64-variant x 64-sample tile
+// through LDS: reads run along the samples of a row (one dword = 16 calls per lane), writes along the variants
+// of a sample (16 bytes per lane).
+template <bool SUBSET>
+__global__ __launch_bounds__(256) void k_unpack_transposed(const uint8_t *__restrict__ rows, uint64_t pitch,
+                                                           uint32_t sample_ct, const uint32_t *__restrict__ vlist,
+                                                           uint32_t n_var, const uint32_t *__restrict__ sel,
+                                                           uint32_t n_out, int8_t *__restrict__ out,
+                                                           uint64_t out_stride, int32_t fill) {
+	__shared__ uint8_t tile[64][64 + 4]; // [sample][variant]
+	const uint32_t k0 = blockIdx.x * 64u, j0 = blockIdx.y * 64u;
+	{
+		const uint32_t vr = threadIdx.x >> 2, dw = threadIdx.x & 3u;
+		const uint32_t j = j0 + vr;
+		if (j < n_var) {
+			const uint32_t *row32 = reinterpret_cast<const uint32_t *>(rows + static_cast<uint64_t>(vlist[j]) * pitch);
+			uint32_t word = 0;
+			if (!SUBSET && k0 + 16u * dw < sample_ct) {
+				word = row32[(k0 >> 4) + dw];
+			}
+#pragma unroll
+			for (uint32_t i = 0; i < 16; i++) {
+				uint32_t code;
+				if (SUBSET) {
+					const uint32_t k = k0 + 16u * dw + i;
+					const uint32_t s = k < n_out ? sel[k] : 0u;
+					code = (row32[s >> 4] >> (2u * (s & 15u))) & 3u;
+				} else {
+					code = (word >> (2u * i)) & 3u;
+				}
+				tile[16u * dw + i][vr] = static_cast<uint8_t>(code == 3u ? fill : static_cast<int32_t>(code));
+			}
+		}
+	}
+	__syncthreads();
+	const uint32_t samp = threadIdx.x >> 2, chunk = (threadIdx.x & 3u) * 16u;
+	const uint32_t k = k0 + samp;
+	if (k >= n_out || j0 + chunk >= n_var) {
+		return;
+	}
+	int8_t *dst = out + static_cast<uint64_t>(k) * out_stride + j0 + chunk;
+	const uint32_t left = n_var - (j0 + chunk);
+	for (uint32_t i = 0; i < 16u && i < left; i++) {
+		dst[i] = static_cast<int8_t>(tile[samp][chunk + i]);
+	}
+}
+
 } // namespace
 
 // ---------------------------------------------------------------------------
@@ -233,6 +284,30 @@ hipError_t LaunchUnpackSubset(const RowView &view, uint32_t v_first, uint32_t v_
 	dim3 grid((val_words16 + 255) / 256, v_count < 65535u ? v_count : 65535u);
 	hipLaunchKernelGGL(k_unpack_subset, grid, dim3(256), 0, stream, view.rows, view.pitch, v_first, v_count, sel,
 	                   n_out, out, out_pitch, validity, static_cast<int32_t>(fill));
+	return hipGetLastError();
+}
+
+hipError_t LaunchUnpackTransposed(const RowView &view, const uint32_t *vlist, uint32_t n_var, const uint32_t *sel,
+                                  uint32_t k_first, uint32_t k_count, int8_t *out, uint64_t out_stride, int8_t fill,
+                                  hipStream_t stream) {
+	if (n_var == 0 || k_count == 0) {
+		return hipSuccess;
+	}
+	// samples k_first .. k_first + k_count of the output order; k_first is a multiple of 64
+	for (uint32_t j_done = 0; j_done < n_var; j_done += 65535u * 64u) { // grid.y limit
+		const uint32_t n = std::min<uint64_t>(65535ull * 64ull, n_var - j_done);
+		dim3 grid((k_count + 63) / 64, (n + 63) / 64);
+		if (sel) {
+			hipLaunchKernelGGL(k_unpack_transposed<true>, grid, dim3(256), 0, stream, view.rows, view.pitch, view.sample_ct,
+			                   vlist + j_done, n, sel + k_first, k_count, out + j_done, out_stride, static_cast<int32_t>(fill));
+		} else {
+			RowView shifted = view;
+			shifted.rows = view.rows + (k_first / 4);
+			hipLaunchKernelGGL(k_unpack_transposed<false>, grid, dim3(256), 0, stream, shifted.rows, view.pitch,
+			                   view.sample_ct - k_first, vlist + j_done, n, nullptr, k_count, out + j_done, out_stride,
+			                   static_cast<int32_t>(fill));
+		}
+	}
 	return hipGetLastError();
 }
 

@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "pgh_counts_range_dev", "pgh_freq_from_counts_dev", "pgh_fused_tally_dev", "pgh_missing_per_sample", "pgh_missing_per_sample_dev", "pgh_unpack_range",
     "pgh_unpack_range_dev", "pgh_score", "pgh_score_dev", "pgh_score_plan_create", "pgh_score_run_dev",
     "pgh_score_plan_destroy", "pgh_pca", "pgh_pca_sharded", "pgh_ld_pairs", "pgh_ld_pairs_dev", "pgh_sample_counts", "pgh_sample_counts_dev",
-    "pgh_synth_add_dosage", "pgh_synth_write_dosage_files", "pgh_dosage_sums", "pgh_dosage_sums_dev", "pgh_dosage_unpack", "pgh_dosage_unpack_dev", "pgh_reader_create", "pgh_reader_destroy",
+    "pgh_synth_add_dosage", "pgh_synth_write_dosage_files", "pgh_dosage_sums", "pgh_dosage_sums_dev", "pgh_dosage_unpack", "pgh_dosage_unpack_dev", "pgh_unpack_samples", "pgh_dosage_unpack_samples", "pgh_reader_create", "pgh_reader_destroy",
     "pgh_get_2bit", "pgh_get_counts", "pgh_get_missingness", "pgh_get_int8", "pgh_get_dosage_f64", "pgh_get_phased",
     "pgh_reader_error", "pgh_hwe_lnp", "pgh_hwe_xchr_lnp", "pgh_hwe_lnp_batch", "pgh_hwe_lnp_batch_dev", "pgh_hwe_xchr_lnp_batch",
 ]
@@ -118,6 +118,8 @@ def _load():
         "pgh_dosage_sums": (C.c_int, [vp, vp, u32, u32, vp, vp, cp]),
         "pgh_dosage_sums_dev": (C.c_int, [vp, vp, u32, u32, vp, vp, cp]),
         "pgh_dosage_unpack": (C.c_int, [vp, vp, u32, u32, vp, vp, cp]),
+        "pgh_unpack_samples": (C.c_int, [vp, vp, u32, vp, vp, C.c_int, cp]),
+        "pgh_dosage_unpack_samples": (C.c_int, [vp, vp, u32, vp, vp, cp]),
         "pgh_dosage_unpack_dev": (C.c_int, [vp, vp, u32, u32, vp, C.c_size_t, vp, cp]),
         "pgh_ld_pairs_dev": (C.c_int, [vp, vp, u32, vp, vp, vp, vp, cp]),
         "pgh_pca_sharded": (C.c_int, [vp, vp, u32, vp, vp, vp, C.c_uint64, u32, vp, ALLREDUCE_FN, vp, vp, vp, cp]),
@@ -483,6 +485,22 @@ class Dataset:
         eb = _errbuf()
         _check(_lib.pgh_dosage_unpack(self._h, subset._h if subset else None, v0, n, _ptr(v) if v is not None else None,
                                       _ptr(out), eb), eb)
+        return out
+
+    def unpack_samples(self, vidx, subset: Subset | None = None, missing_code: int = -9) -> np.ndarray:
+        """int8[n_out][len(vidx)]: the calls sample-major (read_pfile orient := 'sample')."""
+        v = np.ascontiguousarray(vidx, dtype=np.uint32)
+        out = np.zeros((subset.size if subset else self.n_samples, len(v)), dtype=np.int8)
+        eb = _errbuf()
+        _check(_lib.pgh_unpack_samples(self._h, subset._h if subset else None, len(v), _ptr(v), _ptr(out), missing_code, eb), eb)
+        return out
+
+    def dosage_unpack_samples(self, vidx, subset: Subset | None = None) -> np.ndarray:
+        """float64[n_out][len(vidx)]: the dosages sample-major, -9 = missing."""
+        v = np.ascontiguousarray(vidx, dtype=np.uint32)
+        out = np.zeros((subset.size if subset else self.n_samples, len(v)), dtype=np.float64)
+        eb = _errbuf()
+        _check(_lib.pgh_dosage_unpack_samples(self._h, subset._h if subset else None, len(v), _ptr(v), _ptr(out), eb), eb)
         return out
 
     def dosage_sums_dev(self, v_begin, v_end, d_sums: int, stream: int = 0, subset: Subset | None = None):

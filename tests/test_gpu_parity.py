@@ -493,3 +493,25 @@ def test_hwe_xchr_batch_matches_host_and_oracle(gpu_lib, oracle):
                 assert abs(got[i] - exp) < 1e-6 or (np.isinf(exp) and got[i] < -700)
     # biobank-sized strata finish (the host routine takes ~0.1 s for this one table)
     assert np.isfinite(got[-1]) or got[-1] < -700
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,n", [(1, 1), (63, 65), (64, 64), (130, 1000), (1000, 4099), (17, 70001)])
+def test_sample_major_unpack_is_the_transposed_unpack(gpu_lib, m, n):
+    """pgh_unpack_samples (read_pfile orient := 'sample'): the variant-major unpack, transposed; ragged tiles,
+    listed variants in any order, sample subsets."""
+    ds = gpu_lib.Dataset.synth(0, m, n, SEED + 11, 0.07)
+    rows, _ = ds.unpack_range(missing_code=-9, want_validity=False)
+    rng = np.random.default_rng(m * 31 + n)
+    order = rng.permutation(m)[: max(1, m - 3)]
+    assert np.array_equal(ds.unpack_samples(np.arange(m)), rows.T)
+    assert np.array_equal(ds.unpack_samples(order, missing_code=3), np.where(rows[order].T == -9, 3, rows[order].T))
+    mask = rng.random(n) < 0.5
+    mask[n - 1] = True
+    ss = ds.subset(mask)
+    assert np.array_equal(ds.unpack_samples(order, subset=ss), rows[order][:, mask].T)
+    if m >= 63:
+        ds.synth_add_dosage(0.2, 5)
+        d = ds.dosage_unpack()
+        assert np.array_equal(ds.dosage_unpack_samples(order), d[order].T)
+        assert np.array_equal(ds.dosage_unpack_samples(order, subset=ss), d[order][:, mask].T)
