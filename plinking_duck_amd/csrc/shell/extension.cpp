@@ -343,6 +343,13 @@ string RunQuery(const string &request) {
 		}
 		pdkjson::EscapeTo(out, names[i]);
 	}
+	out += "],\"all_types\":[";
+	for (size_t i = 0; i < return_types.size(); i++) {
+		if (i) {
+			out += ',';
+		}
+		pdkjson::EscapeTo(out, return_types[i].ToString());
+	}
 	// phase times of this call (bind = companions + header probe, init = device residency, scan = threads)
 	out += "],\"bind_ms\":" + std::to_string(ms(t_bind0, t_bind1)) + ",\"init_ms\":" + std::to_string(ms(t_init0, t_init1)) +
 	       ",\"scan_ms\":" + std::to_string(ms(t_init1, t_scan1));

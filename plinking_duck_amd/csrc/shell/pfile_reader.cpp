@@ -12,18 +12,26 @@
 //                        {hom_ref, het, hom_alt, missing} tallies over the effective variants
 //                        -- the reference's streaming aggregate (src/pfile_reader.cpp:3308-3460:
 //                        every thread decodes variant batches and bumps per-sample counters,
-//                        merged under a mutex).  Here phase 1 is ONE pgh_sample_counts call (three
-//                        column-tally launches) by whichever thread scans first; phase 2 emits rows.
-// Not carried over (they materialise a variant x sample matrix on the host or fan variants out
-// to tidy rows -- no device work): orient := 'genotype', sample-oriented array/list/columns/
-// struct output, combine_samples other than the implicit one, parquet companions.
+//                        merged under a mutex).  Here phase 1 is ONE pgh_sample_counts call by
+//                        whichever thread scans first; phase 2 emits rows;
+//   orient := 'sample' with genotypes := 'array' | 'list' | 'columns' | 'struct' (calls or dosages)
+//                        one row per sample and its calls over the effective variants -- the
+//                        reference pre-reads a variants x samples matrix with PgrGet per variant
+//                        (src/pfile_reader.cpp:1560-1835); here pgh_unpack_samples hands the matrix
+//                        back sample-major (a tiled transpose on the device), source by source.
+// Not carried over (tidy per-(variant, sample) rows and host-only metadata plumbing): orient :=
+// 'genotype', phased output in sample orient, combine_samples other than the implicit one,
+// parquet companions.
+
 #include "pgen_reader.hpp"
 
 #include <cerrno>
 #include <cmath>
 #include <cstdlib>
 #include <limits>
+#include <cstring>
 #include <mutex>
+#include <unordered_set>
 
 namespace duckdb {
 
@@ -91,6 +99,7 @@ struct PfileSource {
 	PgenBindCommon c;                      // orient := 'sample'
 	bool has_variant_list = false;
 	vector<uint32_t> variant_indices;
+	vector<uint32_t> effective; // orient := 'sample', per-element modes: the variants whose calls are emitted
 };
 
 struct PfileBindData : public TableFunctionData {
@@ -104,6 +113,12 @@ struct PfileBindData : public TableFunctionData {
 	idx_t sex_col = static_cast<idx_t>(-1);
 	vector<idx_t> parent_cols;
 	vector<uint32_t> output_samples; // file index of every output sample, ascending
+	// orient := 'sample', per-element modes (ARRAY / LIST / COLUMNS / STRUCT of the effective variants)
+	bool element_mode = false;
+	bool dosages = false;
+	uint32_t effective_total = 0;
+	vector<uint8_t> all_pass; // per effective variant, list order: no call of it falls outside the genotype filter
+	idx_t first_geno_col = 0; // COLUMNS: the first per-variant column
 };
 
 struct PfileGlobalState : public GlobalTableFunctionState {
@@ -121,6 +136,8 @@ struct PfileGlobalState : public GlobalTableFunctionState {
 	vector<uint32_t> counts;     // [output sample][4]
 	vector<uint32_t> keep;       // output positions that pass the genotype row filter
 	bool use_keep = false;
+	vector<int8_t> calls;        // per-element modes: [output sample][effective variant], -9 = missing / filtered out
+	vector<double> dosage_rows;  // the same for dosages := true
 	uint32_t effective_variants = 0;
 	uint32_t candidate_variants = 0;
 	std::atomic<uint32_t> next_idx {0};
@@ -312,25 +329,27 @@ static unique_ptr<FunctionData> PfileBind(ClientContext &context, TableFunctionB
 		total_variants += src.c.raw_variant_ct;
 	}
 	auto &c = bind_data->sources[0].c;
-	bind_data->genotype_mode = ResolveGenotypeMode(genotypes_str, static_cast<uint32_t>(total_variants), "read_pfile");
-	if (!IsAggregateGenotypeMode(bind_data->genotype_mode)) {
-		throw InvalidInputException("read_pfile: orient := 'sample' with genotypes := '%s' is not available in this "
-		                            "build (the sample-oriented matrix is assembled on the host; use genotypes := "
-		                            "'counts' or 'stats')",
-		                            genotypes_str);
-	}
-	const char *label = bind_data->genotype_mode == GenotypeMode::COUNTS ? "counts" : "stats";
-	if (phased) {
-		throw InvalidInputException("read_pfile: genotypes := '%s' is incompatible with phased := true", label);
-	}
-	if (dosages) {
-		throw InvalidInputException("read_pfile: genotypes := '%s' is incompatible with dosages := true", label);
+	const bool aggregate = genotypes_str == "counts" || genotypes_str == "stats";
+	if (aggregate) {
+		bind_data->genotype_mode = ResolveGenotypeMode(genotypes_str, static_cast<uint32_t>(total_variants), "read_pfile");
+		const char *label = bind_data->genotype_mode == GenotypeMode::COUNTS ? "counts" : "stats";
+		if (phased) {
+			throw InvalidInputException("read_pfile: genotypes := '%s' is incompatible with phased := true", label);
+		}
+		if (dosages) {
+			throw InvalidInputException("read_pfile: genotypes := '%s' is incompatible with dosages := true", label);
+		}
+	} else if (phased) {
+		throw InvalidInputException("read_pfile: orient := 'sample' with phased := true is not available in this build "
+		                            "(phase tracks are decoded on the host per variant; use orient := 'variant')");
 	}
 	auto variants_it = input.named_parameters.find("variants");
 	if (variants_it != input.named_parameters.end()) { // single source only (guarded above)
 		auto &src = bind_data->sources[0];
 		src.variant_indices = ResolveVariantsParameter(variants_it->second, c.variants, c.raw_variant_ct, "read_pfile");
 		std::sort(src.variant_indices.begin(), src.variant_indices.end());
+		src.variant_indices.erase(std::unique(src.variant_indices.begin(), src.variant_indices.end()),
+		                          src.variant_indices.end());
 		src.has_variant_list = true;
 	}
 	auto af_it = input.named_parameters.find("af_range");
@@ -349,6 +368,10 @@ static unique_ptr<FunctionData> PfileBind(ClientContext &context, TableFunctionB
 		    "read_pfile: specify only one of include_genotypes or genotype_range (genotype_range is the numeric "
 		    "alias of include_genotypes)");
 	}
+	if ((ig_it != input.named_parameters.end() || gr_it != input.named_parameters.end()) && dosages) {
+		throw InvalidInputException("read_pfile: %s is incompatible with dosages := true",
+		                            ig_it != input.named_parameters.end() ? "include_genotypes" : "genotype_range");
+	}
 	if (ig_it != input.named_parameters.end()) {
 		ParseIncludeGenotypes(ig_it->second, bind_data->genotype_filter, "read_pfile");
 	} else if (gr_it != input.named_parameters.end()) {
@@ -361,7 +384,84 @@ static unique_ptr<FunctionData> PfileBind(ClientContext &context, TableFunctionB
 			bind_data->output_samples.push_back(s);
 		}
 	}
-	// schema: every psam column of source 0 (SEX is INTEGER, the rest VARCHAR), then the aggregate struct
+	if (!aggregate) {
+		// The effective variants fix the ARRAY dimension and the COLUMNS / STRUCT names, so they are settled
+		// here (src/pfile_reader.cpp:1300-1430): region and variants from the metadata, the count and genotype
+		// filters from one batched device tally per source.
+		bind_data->element_mode = true;
+		bind_data->dosages = dosages;
+		const bool filtered = bind_data->count_filter.HasFilter() || bind_data->genotype_filter.active;
+		for (auto &src : bind_data->sources) {
+			vector<uint32_t> candidates;
+			if (src.has_variant_list) {
+				for (auto v : src.variant_indices) {
+					if (!src.c.variant_range.has_filter || (v >= src.c.RangeStart() && v < src.c.RangeEnd())) {
+						candidates.push_back(v);
+					}
+				}
+			} else {
+				for (uint32_t v = src.c.RangeStart(); v < src.c.RangeEnd(); v++) {
+					candidates.push_back(v);
+				}
+			}
+			if (filtered && !candidates.empty()) {
+				auto dataset = DeviceDataset::Acquire(src.c.pgen_path, "read_pfile");
+				unique_ptr<DeviceSubset> subset;
+				if (c.has_sample_subset) {
+					subset = make_uniq<DeviceSubset>(*dataset, c.sample_subset->sample_include, "read_pfile");
+				}
+				char errbuf[PGH_ERRBUF_LEN] = {0};
+				uint32_t gc[4];
+				uint32_t run_begin = 0;
+				vector<uint32_t> tallies;
+				while (run_begin < candidates.size()) { // one device call per run of consecutive candidates
+					uint32_t run_end = run_begin + 1;
+					while (run_end < candidates.size() && candidates[run_end] == candidates[run_end - 1] + 1) {
+						run_end++;
+					}
+					tallies.resize(4 * static_cast<size_t>(run_end - run_begin));
+					if (pgh_counts_range(dataset->handle, subset ? subset->handle : nullptr, candidates[run_begin],
+					                     candidates[run_end - 1] + 1, reinterpret_cast<uint32_t(*)[4]>(tallies.data()),
+					                     errbuf) != PGH_OK) {
+						throw IOException("read_pfile: PgrGetCounts failed for variant %u during count filter: %s",
+						                  candidates[run_begin], string(errbuf));
+					}
+					for (uint32_t i = run_begin; i < run_end; i++) {
+						std::memcpy(gc, tallies.data() + 4 * static_cast<size_t>(i - run_begin), sizeof gc);
+						auto pf = CheckPreDecompFilters(bind_data->count_filter, bind_data->genotype_filter, gc,
+						                                c.effective_sample_ct);
+						if (!pf.skip) {
+							src.effective.push_back(candidates[i]);
+							bind_data->all_pass.push_back(pf.all_pass);
+						}
+					}
+					run_begin = run_end;
+				}
+			} else {
+				src.effective = std::move(candidates);
+				bind_data->all_pass.insert(bind_data->all_pass.end(), src.effective.size(), 1);
+			}
+			bind_data->effective_total += static_cast<uint32_t>(src.effective.size());
+		}
+		bind_data->genotype_mode = ResolveGenotypeMode(genotypes_str, bind_data->effective_total, "read_pfile");
+		const uint64_t matrix_size =
+		    static_cast<uint64_t>(bind_data->effective_total) * static_cast<uint64_t>(bind_data->output_samples.size());
+		int64_t max_elements = 16LL * 1024 * 1024 * 1024;
+		Value max_elements_val;
+		if (context.TryGetCurrentSetting("plinking_max_matrix_elements", max_elements_val)) {
+			max_elements = max_elements_val.GetValue<int64_t>();
+		}
+		if (matrix_size > static_cast<uint64_t>(max_elements)) {
+			throw InvalidInputException("read_pfile: orient := 'sample' would require %llu genotype values "
+			                            "(%u variants x %u samples, limit: %lld). "
+			                            "Use variants := [...] or samples := [...] to reduce, "
+			                            "or SET plinking_max_matrix_elements = <higher value>.",
+			                            static_cast<unsigned long long>(matrix_size), bind_data->effective_total,
+			                            static_cast<uint32_t>(bind_data->output_samples.size()),
+			                            static_cast<long long>(max_elements));
+		}
+	}
+	// schema: every psam column of source 0 (SEX is INTEGER, the rest VARCHAR), then the genotypes
 	for (idx_t i = 0; i < c.sample_info.column_names.size(); i++) {
 		const string &name = c.sample_info.column_names[i];
 		names.push_back(name);
@@ -376,9 +476,49 @@ static unique_ptr<FunctionData> PfileBind(ClientContext &context, TableFunctionB
 		}
 	}
 	bind_data->genotypes_col = names.size();
-	names.push_back("genotypes");
-	return_types.push_back(bind_data->genotype_mode == GenotypeMode::COUNTS ? MakeGenotypeCountsType()
-	                                                                         : MakeGenotypeStatsType());
+	if (aggregate) {
+		names.push_back("genotypes");
+		return_types.push_back(bind_data->genotype_mode == GenotypeMode::COUNTS ? MakeGenotypeCountsType()
+		                                                                         : MakeGenotypeStatsType());
+		return std::move(bind_data);
+	}
+	const LogicalType elem = dosages ? LogicalType(LogicalType::DOUBLE) : LogicalType(LogicalType::TINYINT);
+	if (bind_data->genotype_mode == GenotypeMode::COLUMNS || bind_data->genotype_mode == GenotypeMode::STRUCT) {
+		// one column / field per effective variant, named by its ID, else CHROM:POS (src/pfile_reader.cpp:1443-1512)
+		const char *label = bind_data->genotype_mode == GenotypeMode::COLUMNS ? "columns" : "struct";
+		std::unordered_set<string> seen;
+		child_list_t fields;
+		bind_data->first_geno_col = names.size();
+		for (auto &src : bind_data->sources) {
+			for (auto v : src.effective) {
+				string id = src.c.variants.GetId(v);
+				if (id.empty()) {
+					id = src.c.variants.GetChrom(v) + ":" + std::to_string(src.c.variants.GetPos(v));
+				}
+				if (!seen.insert(id).second) {
+					throw InvalidInputException(
+					    "read_pfile: genotypes := '%s' with orient := 'sample' requires unique variant identifiers, but "
+					    "'%s' appears more than once. Use variants := [...] to select unique variants.",
+					    label, id);
+				}
+				if (bind_data->genotype_mode == GenotypeMode::COLUMNS) {
+					names.push_back(id);
+					return_types.push_back(elem);
+				} else {
+					fields.push_back({id, elem});
+				}
+			}
+		}
+		if (bind_data->genotype_mode == GenotypeMode::STRUCT) {
+			names.push_back("genotypes");
+			return_types.push_back(LogicalType::STRUCT(std::move(fields)));
+		}
+	} else {
+		names.push_back("genotypes");
+		return_types.push_back(bind_data->genotype_mode == GenotypeMode::ARRAY
+		                           ? LogicalType::ARRAY(elem, bind_data->effective_total)
+		                           : LogicalType::LIST(elem));
+	}
 	return std::move(bind_data);
 }
 
@@ -399,15 +539,17 @@ static unique_ptr<GlobalTableFunctionState> PfileInitGlobal(ClientContext &conte
 	}
 	state->column_ids = input.column_ids;
 	for (auto col_id : input.column_ids) {
-		if (col_id == bind_data.genotypes_col) {
-			state->need_genotypes = true;
+		if (col_id != COLUMN_IDENTIFIER_ROW_ID && col_id >= bind_data.genotypes_col) {
+			state->need_genotypes = true; // the genotypes column, or one of the per-variant columns
 		}
 	}
 	for (auto &src : bind_data.sources) {
 		state->candidate_variants += src.has_variant_list ? static_cast<uint32_t>(src.variant_indices.size())
 		                                                  : src.c.RangeEnd() - src.c.RangeStart();
 	}
-	state->counts.assign(4 * bind_data.output_samples.size(), 0);
+	if (!bind_data.element_mode) {
+		state->counts.assign(4 * bind_data.output_samples.size(), 0);
+	}
 	// a row filter needs the tallies even when the struct itself is not projected
 	if (state->need_genotypes || bind_data.genotype_filter.active) {
 		for (auto &src : bind_data.sources) {
@@ -435,6 +577,81 @@ static unique_ptr<LocalTableFunctionState> PfileInitLocal(ExecutionContext &cont
 		}
 	}
 	return std::move(state);
+}
+
+//! Per-element modes, phase 1 (the reference's pre-read, src/pfile_reader.cpp:1560-1835): every source's
+//! effective variants, sample-major, side by side in list order; then the genotype filter -- a sample stays
+//! if any of its calls is allowed (or it has a missing call and missing is included), and calls outside the
+//! filter read as NULL at variants where not every call passes.
+static void RunSampleMatrixPhase1(const PfileBindData &bind_data, PfileGlobalState &gstate) {
+	char errbuf[PGH_ERRBUF_LEN] = {0};
+	const size_t n_out = bind_data.output_samples.size();
+	const size_t total = bind_data.effective_total;
+	if (bind_data.dosages) {
+		gstate.dosage_rows.assign(n_out * total, 0.0);
+	} else {
+		gstate.calls.assign(n_out * total, 0);
+	}
+	size_t at = 0;
+	vector<int8_t> part;
+	vector<double> dpart;
+	for (size_t si = 0; si < bind_data.sources.size(); si++) {
+		const auto &eff = bind_data.sources[si].effective;
+		if (eff.empty()) {
+			continue;
+		}
+		pgh_dataset *ds = gstate.datasets[si]->handle;
+		pgh_subset *ss = gstate.subsets[si] ? gstate.subsets[si]->handle : nullptr;
+		const uint32_t n_var = static_cast<uint32_t>(eff.size());
+		const bool whole = bind_data.sources.size() == 1; // one source: the call fills the matrix in place
+		int rc;
+		if (bind_data.dosages) {
+			double *dst = gstate.dosage_rows.data();
+			if (!whole) {
+				dpart.resize(n_out * eff.size());
+				dst = dpart.data();
+			}
+			rc = pgh_dosage_unpack_samples(ds, ss, n_var, eff.data(), dst, errbuf);
+			for (size_t k = 0; !whole && rc == PGH_OK && k < n_out; k++) {
+				std::memcpy(gstate.dosage_rows.data() + k * total + at, dpart.data() + k * eff.size(), 8 * eff.size());
+			}
+		} else {
+			int8_t *dst = gstate.calls.data();
+			if (!whole) {
+				part.resize(n_out * eff.size());
+				dst = part.data();
+			}
+			rc = pgh_unpack_samples(ds, ss, n_var, eff.data(), dst, -9, errbuf);
+			for (size_t k = 0; !whole && rc == PGH_OK && k < n_out; k++) {
+				std::memcpy(gstate.calls.data() + k * total + at, part.data() + k * eff.size(), eff.size());
+			}
+		}
+		if (rc != PGH_OK) {
+			throw IOException("read_pfile: %s failed during sample-orient pre-read: %s",
+			                  bind_data.dosages ? "PgrGetD" : "PgrGet", string(errbuf));
+		}
+		at += eff.size();
+	}
+	if (bind_data.genotype_filter.active && !bind_data.dosages) {
+		const auto &gf = bind_data.genotype_filter;
+		gstate.use_keep = true;
+		for (uint32_t k = 0; k < n_out; k++) {
+			int8_t *row = gstate.calls.data() + static_cast<size_t>(k) * total;
+			bool in_range = false, has_missing = false;
+			for (size_t j = 0; j < total; j++) {
+				if (row[j] == -9) {
+					has_missing = true;
+				} else if (gf.AllowsCall(static_cast<double>(row[j]))) {
+					in_range = true;
+				} else if (!bind_data.all_pass[j]) {
+					row[j] = -9;
+				}
+			}
+			if (in_range || (gf.include_missing && has_missing)) {
+				gstate.keep.push_back(k);
+			}
+		}
+	}
 }
 
 //! Phase 1: per source, the effective variants (region, variants, af/ac filters) and every sample's
@@ -534,7 +751,11 @@ static void PfileScan(ClientContext &context, TableFunctionInput &data_p, DataCh
 	if (!gstate.datasets.empty()) {
 		std::lock_guard<std::mutex> lock(gstate.phase1_mutex);
 		if (!gstate.phase1_done) {
-			RunSamplePhase1(bind_data, gstate);
+			if (bind_data.element_mode) {
+				RunSampleMatrixPhase1(bind_data, gstate);
+			} else {
+				RunSamplePhase1(bind_data, gstate);
+			}
 			gstate.phase1_done = true;
 		}
 	}
@@ -572,6 +793,61 @@ static void PfileScan(ClientContext &context, TableFunctionInput &data_p, DataCh
 					FlatVector::SetNull(vec, r, true);
 				} else {
 					FlatVector::GetData<string_t>(vec)[r] = StringVector::AddString(vec, val);
+				}
+			}
+			continue;
+		}
+		if (bind_data.element_mode) {
+			// one sample's calls (or dosages) over the effective variants: -9 reads as NULL
+			const size_t total = bind_data.effective_total;
+			auto put = [&](Vector &dst, idx_t slot, uint32_t sample_pos, size_t j) {
+				if (bind_data.dosages) {
+					const double d = gstate.dosage_rows[static_cast<size_t>(sample_pos) * total + j];
+					if (d == -9.0) {
+						FlatVector::Validity(dst).SetInvalid(slot);
+						FlatVector::GetData<double>(dst)[slot] = 0.0;
+					} else {
+						FlatVector::GetData<double>(dst)[slot] = d;
+					}
+				} else {
+					const int8_t g = gstate.calls[static_cast<size_t>(sample_pos) * total + j];
+					if (g == -9) {
+						FlatVector::Validity(dst).SetInvalid(slot);
+						FlatVector::GetData<int8_t>(dst)[slot] = 0;
+					} else {
+						FlatVector::GetData<int8_t>(dst)[slot] = g;
+					}
+				}
+			};
+			if (bind_data.genotype_mode == GenotypeMode::COLUMNS) {
+				const size_t j = file_col - bind_data.first_geno_col;
+				for (idx_t r = 0; r < n_rows; r++) {
+					put(vec, r, position(r), j);
+				}
+			} else if (bind_data.genotype_mode == GenotypeMode::STRUCT) {
+				auto &fields = StructVector::GetEntries(vec);
+				for (idx_t r = 0; r < n_rows; r++) {
+					for (size_t j = 0; j < total; j++) {
+						put(*fields[j], r, position(r), j);
+					}
+				}
+			} else {
+				const bool is_array = bind_data.genotype_mode == GenotypeMode::ARRAY;
+				Vector &child = is_array ? ArrayVector::GetEntry(vec) : ListVector::GetEntry(vec);
+				for (idx_t r = 0; r < n_rows; r++) {
+					idx_t base = r * total;
+					if (!is_array) {
+						base = ListVector::GetListSize(vec);
+						ListVector::Reserve(vec, base + total);
+						auto *entries = FlatVector::GetData<list_entry_t>(vec);
+						entries[r].offset = base;
+						entries[r].length = total;
+						ListVector::SetListSize(vec, base + total);
+					}
+					Vector &dst = is_array ? child : ListVector::GetEntry(vec);
+					for (size_t j = 0; j < total; j++) {
+						put(dst, base + j, position(r), j);
+					}
 				}
 			}
 			continue;

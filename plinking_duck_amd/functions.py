@@ -53,6 +53,7 @@ class Result:
         self.names = doc["names"]
         self.types = doc["types"]
         self.all_names = doc["all_names"]
+        self.all_types = doc.get("all_types", [])
         self.threads = doc["threads"]
         self.timing_ms = {k: doc.get(k + "_ms") for k in ("bind", "init", "scan")}
         self.rows = [tuple(r) for r in doc["rows"]]

@@ -229,6 +229,32 @@ def test_read_pfile_file_lists_bind():
         "read_pfile", [shards[0], data_path("does_not_exist")])
 
 
+def test_read_pfile_sample_orient_schemas():
+    """read_pfile_orient.test:55-90, :180-215, read_pfile_genotypes_columns.test:81-90, :142-159: the per-element
+    modes of orient := 'sample' bind from the metadata alone, and a metadata-only projection needs no device."""
+    P = data_path("pfile_example")
+    r = F.query("read_pfile", P, orient="sample", columns=["FID", "IID", "SEX"])
+    assert r.all_names == ["FID", "IID", "SEX", "genotypes"] and r.all_types[-1] == "TINYINT[4]"
+    assert sorted(r.rows) == [("FAM001", "SAMPLE1", 1), ("FAM001", "SAMPLE2", 2), ("FAM002", "SAMPLE3", None),
+                              ("FAM002", "SAMPLE4", 1)]
+    assert F.query("read_pfile", P, orient="sample", genotypes="list", columns=["IID"]).all_types[-1] == "TINYINT[]"
+    assert F.query("read_pfile", P, orient="sample", dosages=True, columns=["IID"]).all_types[-1] == "DOUBLE[4]"
+    assert F.query("read_pfile", P, orient="sample", variants=["rs1", "rs2"], columns=["IID"]).all_types[-1] == "TINYINT[2]"
+    assert F.query("read_pfile", P, orient="sample", region="1:10000-20000", columns=["IID"]).all_types[-1] == "TINYINT[2]"
+    assert F.query("read_pfile", P, orient="sample", region="1:10000-30000", variants=["rs1", "rs3"],
+                   samples=["SAMPLE1"], columns=["IID"]).rows == [("SAMPLE1",)]
+    c = F.query("read_pfile", P, orient="sample", genotypes="columns", columns=["FID", "IID"])
+    assert c.all_names == ["FID", "IID", "SEX", "rs1", "rs2", "rs3", "rs4"] and c.all_types[3:] == ["TINYINT"] * 4
+    assert sorted(c.rows) == [("FAM001", "SAMPLE1"), ("FAM001", "SAMPLE2"), ("FAM002", "SAMPLE3"), ("FAM002", "SAMPLE4")]
+    st = F.query("read_pfile", P, orient="sample", genotypes="struct", region="1:10000-20000", columns=["IID"])
+    assert st.all_types[-1] == "STRUCT(rs1 TINYINT, rs2 TINYINT)"
+    msg = err("read_pfile", P, orient="sample", settings={"plinking_max_matrix_elements": 15})
+    assert "would require 16 genotype values (4 variants x 4 samples, limit: 15)" in msg
+    assert len(F.query("read_pfile", P, orient="sample", settings={"plinking_max_matrix_elements": 16}, columns=["IID"])) == 4
+    assert "include_genotypes is incompatible with dosages" in err("read_pfile", P, orient="sample", dosages=True,
+                                                                   include_genotypes=["het"])
+
+
 def test_read_pfile_bind():
     PFX = data_path("pgen_example")
     r = F.query("read_pfile", PFX, columns=["ID", "POS"])
@@ -252,7 +278,7 @@ def test_read_pfile_bind():
     assert "incompatible with dosages" in err("read_pfile", PFX, orient="sample", genotypes="stats", dosages=True)
     assert "dosages and phased cannot both be true" in err("read_pfile", PFX, dosages=True, phased=True)
     assert "read_pfile: invalid genotypes value" in err("read_pfile", PFX, genotypes="matrix")
-    assert "not available in this build" in err("read_pfile", PFX, orient="sample")
+    assert "phased := true is not available in this build" in err("read_pfile", PFX, orient="sample", phased=True)
     assert "Invalid named parameter" in err("read_pgen", EX, region="1:1-2", exc=F.BinderException)
     # read_pfile_negative.test:113-131 and the open forms of its region grammar
     assert "invalid region" in err("read_pfile", PFX, region="invalid:abc-def")

@@ -663,6 +663,83 @@ def test_read_pfile_sample_orient_counts_add_up_over_shards():
     assert len(twice) == 4 and all({k: 2 * v for k, v in once[i].items()} == twice[i] for i in once)
 
 
+def test_read_pfile_sample_orient_matrices(oracle):
+    """read_pfile_orient.test:93-215, read_pfile_genotypes_columns.test:92-139, read_pfile_genotype_filter.test:64-93,
+    read_pfile_dosage.test: one row per sample, its calls over the effective variants."""
+    P = data_path("pfile_example")
+    want = {"SAMPLE1": [0, 1, 2, 0], "SAMPLE2": [1, 1, None, 0], "SAMPLE3": [2, 0, 1, 1], "SAMPLE4": [None, 2, 0, 2]}
+    r = F.query("read_pfile", P, orient="sample", columns=["IID", "genotypes"])
+    assert r.types[1] == "TINYINT[4]" and dict(r.rows) == want
+    r = F.query("read_pfile", P, orient="sample", genotypes="list", columns=["IID", "genotypes"])
+    assert r.types[1] == "TINYINT[]" and dict(r.rows) == want
+    r = F.query("read_pfile", P, orient="sample", samples=["SAMPLE1", "SAMPLE3"], columns=["IID", "genotypes"])
+    assert dict(r.rows) == {k: want[k] for k in ("SAMPLE1", "SAMPLE3")}
+    r = F.query("read_pfile", P, orient="sample", variants=["rs1", "rs2"], columns=["IID", "genotypes"])
+    assert r.types[1] == "TINYINT[2]" and dict(r.rows)["SAMPLE1"] == [0, 1]
+    r = F.query("read_pfile", P, orient="sample", region="1:10000-30000", variants=["rs1", "rs3"], samples=["SAMPLE1"],
+                columns=["IID", "genotypes"])
+    assert r.rows == [("SAMPLE1", [0, 2])]
+    r = F.query("read_pfile", P, orient="sample", genotypes="columns", columns=["IID", "rs1", "rs2", "rs3", "rs4"])
+    assert {row[0]: list(row[1:]) for row in r.rows} == want
+    r = F.query("read_pfile", P, orient="sample", genotypes="columns", region="1:10000-20000", columns=["IID", "rs2", "rs1"])
+    assert dict((a, (b, c)) for a, b, c in r.rows)["SAMPLE1"] == (1, 0)
+    r = F.query("read_pfile", P, orient="sample", genotypes="struct", columns=["IID", "genotypes"])
+    assert {iid: [g[f"rs{i}"] for i in range(1, 5)] for iid, g in r.rows} == want
+    # genotype filter: a sample stays if any call is allowed; calls outside read as NULL where not all pass
+    f = lambda **kw: sorted(F.query("read_pfile", P, orient="sample", variants=["rs1"], columns=["IID"], **kw).column("IID"))
+    assert f(include_genotypes=["hom_ref", "hom_alt"]) == ["SAMPLE1", "SAMPLE3"]
+    assert f(include_genotypes=["hom_alt", "missing"]) == ["SAMPLE3", "SAMPLE4"]
+    assert f(include_genotypes=[" Hom_Alt ", "MISSING"]) == ["SAMPLE3", "SAMPLE4"]
+    assert f(genotype_range={"min": 1, "max": 2}) == ["SAMPLE2", "SAMPLE3"]
+    r = F.query("read_pfile", P, orient="sample", include_genotypes=["het"], columns=["IID", "genotypes"])
+    assert dict(r.rows) == {"SAMPLE1": [None, 1, None, None], "SAMPLE2": [1, 1, None, None], "SAMPLE3": [None, None, 1, 1]}
+    assert len(F.query("read_pfile", data_path("all_missing"), orient="sample", include_genotypes=["het", "hom_alt"],
+                       columns=["IID"])) == 0
+    # af_range picks the effective variants at bind, so it shows in the type
+    r = F.query("read_pfile", P, orient="sample", af_range={"max": 0.4}, columns=["IID", "genotypes"])
+    assert r.types[1].startswith("TINYINT[") and len(r) == 4
+    # dosages
+    dz = data_path("dosage_example")
+    pg = oracle.Pgen(dz + ".pgen")
+    d = F.query("read_pfile", dz, orient="sample", dosages=True, columns=["IID", "genotypes"])
+    assert d.types[1] == f"DOUBLE[{pg.M}]"
+    cols = np.stack([pg.dosage(v) for v in range(pg.M)], axis=1)
+    for k, (iid, g) in enumerate(sorted(d.rows)):
+        assert [(-9.0 if x is None else x) for x in g] == cols[k].tolist()
+
+
+def test_read_pfile_sample_orient_over_shards_and_batches(tmp_path, gpu_lib, oracle):
+    """read_pfile_list.test:97-107 and a file wider than one transpose tile: the sources' effective variants side by
+    side in list order; every sample's row equals the whole file's column."""
+    shards = [data_path("shard%d" % i) for i in (1, 2, 3)]
+    whole = data_path("large_example")
+    for kw in ({}, {"region": "2:1-60000"}, {"samples": ["SAMP7", "SAMP2"]}, {"genotypes": "list"}):
+        mf = dict(F.query("read_pfile", shards, orient="sample", columns=["IID", "genotypes"], threads=3, **kw).rows)
+        ids = {}
+        for sh in shards:
+            ids[sh] = F.query("read_pfile", sh, columns=["ID"], **({"region": kw["region"]} if "region" in kw else {})).column("ID")
+        order = [i for sh in shards for i in ids[sh]]
+        wf = F.query("read_pfile", whole, genotypes="columns", columns=["ID"] + sorted(mf), **{k: v for k, v in kw.items() if k == "region"})
+        by_id = {row[0]: row[1:] for row in wf.rows}
+        for col, iid in enumerate(sorted(mf)):
+            assert mf[iid] == [by_id[i][col] for i in order], (kw, iid)
+    ex = data_path("pgen_example")
+    twice = dict(F.query("read_pfile", [ex, ex], orient="sample", columns=["IID", "genotypes"]).rows)
+    once = dict(F.query("read_pfile", ex, orient="sample", columns=["IID", "genotypes"]).rows)
+    assert all(twice[i] == once[i] + once[i] for i in once) and len(twice) == 4
+    # several tiles in both directions, against the oracle
+    prefix = str(tmp_path / "wide")
+    gpu_lib.synth_write_files(prefix, 300, 1003, 77, 0.04)
+    pg = oracle.Pgen(prefix + ".pgen")
+    r = F.query("read_pfile", prefix, orient="sample", genotypes="list", region="3:1-100000", threads=5,
+                columns=["IID", "genotypes"])
+    vsel = [v for v in range(300) if v // ((300 + 21) // 22) + 1 == 3]
+    cols = np.stack([pg.geno(v) for v in vsel], axis=1)
+    assert len(r) == 1003
+    for iid, g in r.rows:
+        assert [(-9 if x is None else x) for x in g] == cols[int(iid[1:])].tolist()
+
+
 # ---- every function over a file that spans several device batches, against the C ABI ---------------
 
 @pytest.fixture(scope="module")
