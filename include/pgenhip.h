@@ -272,8 +272,9 @@ int pgh_sample_counts_dev(const pgh_dataset *ds, uint32_t variant_begin, uint32_
  * windowed scan's order) read the anchor row once per four partners. */
 int pgh_ld_pairs(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_pairs, const uint32_t *vidx_a,
                  const uint32_t *vidx_b, uint32_t (*sums)[6], char *errbuf);
-/* Device-output form: sums land in d_sums (uint32[n_pairs][6]) on `stream`; vidx_a / vidx_b stay
- * host arrays (the task list is built from them and uploaded stream-ordered). */
+/* Device-output form: sums land in d_sums (uint32[n_pairs][6]), computed on `stream`; vidx_a / vidx_b stay
+ * host arrays.  The task list built from them goes up with a blocking copy and the call returns once the
+ * kernel has finished (it owns the task list), so unlike the other *_dev forms this one synchronises `stream`. */
 int pgh_ld_pairs_dev(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_pairs, const uint32_t *vidx_a,
                      const uint32_t *vidx_b, void *d_sums, void *stream, char *errbuf);
 

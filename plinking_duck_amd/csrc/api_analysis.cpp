@@ -1000,17 +1000,17 @@ extern "C" int pgh_ld_pairs_dev(const pgh_dataset *ds, const pgh_subset *subset,
 		tasks.push_back(pgh::LdTask {a - ds->v_begin, b - ds->v_begin, 1u, p});
 	}
 	hipStream_t st = static_cast<hipStream_t>(stream);
-	void *d_tasks = nullptr;
-	PGH_HIP(hipMallocAsync(&d_tasks, sizeof(pgh::LdTask) * tasks.size(), st), "ld scratch");
-	// pageable source: the copy is staged before the call returns, so `tasks` may die with this frame
-	hipError_t e = hipMemcpyAsync(d_tasks, tasks.data(), sizeof(pgh::LdTask) * tasks.size(), hipMemcpyHostToDevice, st);
-	if (e == hipSuccess) {
-		e = pgh::LaunchLdPairs(ds->View(), static_cast<const pgh::LdTask *>(d_tasks),
-		                       static_cast<uint32_t>(tasks.size()), subset ? subset->d_mask2 : nullptr,
-		                       static_cast<uint32_t(*)[6]>(d_sums), st);
-	}
-	(void)hipFreeAsync(d_tasks, st);
-	PGH_HIP(e, "ld pair kernel");
+	// The task list goes up through an ordinary allocation and a blocking copy.  (It used to ride the
+	// stream-ordered pool with an asynchronous copy from this pageable vector; on ROCm 7.2 that copy was
+	// seen to leave the pool block all zeros after a particular run of pool allocations and frees -- a task
+	// with n_b == 0 then sends the kernel 64 GB past the matrix.  The kernel also refuses such tasks now.)
+	DevBuf d_tasks;
+	PGH_HIP(d_tasks.Alloc(sizeof(pgh::LdTask) * tasks.size()), "hipMalloc(ld tasks)");
+	PGH_HIP(hipMemcpy(d_tasks.p, tasks.data(), sizeof(pgh::LdTask) * tasks.size(), hipMemcpyHostToDevice), "ld task upload");
+	PGH_HIP(pgh::LaunchLdPairs(ds->View(), d_tasks.As<pgh::LdTask>(), static_cast<uint32_t>(tasks.size()),
+	                           subset ? subset->d_mask2 : nullptr, static_cast<uint32_t(*)[6]>(d_sums), st),
+	        "ld pair kernel");
+	PGH_HIP(hipStreamSynchronize(st), "ld pair sync"); // d_tasks is freed with this frame
 	return PGH_OK;
 }
 

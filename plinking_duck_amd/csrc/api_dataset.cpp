@@ -325,6 +325,61 @@ static int AppendDosageTracksHost(pgh_dataset *ds, const pgh::RecordFile &file, 
 	return PGH_OK;
 }
 
+// Phase tracks -> two resident bit rows per phased variant (phase.hpp).  Records that go through the device
+// decode are expanded there (LaunchPhaseIngest); host-expanded ones (and files wider than the kernel's LDS
+// tables) through the host parser below.
+static int PreparePhase(pgh_dataset *ds, char *errbuf) {
+	const PgenIndex &ix = ds->index;
+	const uint32_t range = ds->v_end - ds->v_begin;
+	const uint32_t words = (ds->sample_ct + 63) / 64;
+	ds->ph_row_of.assign(range, -1);
+	uint32_t rows = 0;
+	for (uint32_t i = 0; i < range; i++) {
+		if (ix.vrtype[ds->v_begin + i] & 0x10) {
+			ds->ph_row_of[i] = static_cast<int32_t>(rows++);
+		}
+	}
+	if (rows == 0) {
+		ds->ph_row_of.clear();
+		return PGH_OK;
+	}
+	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_ph_present), 8ull * rows * words), "hipMalloc(phase)");
+	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_ph_info), 8ull * rows * words), "hipMalloc(phase)");
+	PGH_HIP(hipMemset(ds->d_ph_present, 0, 8ull * rows * words), "phase memset");
+	PGH_HIP(hipMemset(ds->d_ph_info, 0, 8ull * rows * words), "phase memset");
+	ds->ph_rows = rows;
+	return PGH_OK;
+}
+
+static int AppendPhaseTracksHost(pgh_dataset *ds, const pgh::RecordFile &file, const std::vector<uint32_t> &variants,
+                                 char *errbuf) {
+	const uint32_t N = ds->sample_ct;
+	const uint32_t words = (N + 63) / 64;
+	pgh::Normalizer norm(ds->index, file);
+	std::vector<uint8_t> row, pp, pi;
+	std::vector<uint64_t> bits(2ull * words);
+	std::string err;
+	for (uint32_t v : variants) {
+		if (!norm.DecodePhase(v, row, pp, pi, err)) {
+			SetErr(errbuf, err);
+			return PGH_ERR_FORMAT;
+		}
+		std::fill(bits.begin(), bits.end(), 0ull);
+		for (uint32_t s = 0; s < N; s++) {
+			if (pp[s]) {
+				bits[s >> 6] |= 1ull << (s & 63);
+				if (pi[s]) {
+					bits[words + (s >> 6)] |= 1ull << (s & 63);
+				}
+			}
+		}
+		const uint64_t at = static_cast<uint64_t>(ds->ph_row_of[v - ds->v_begin]) * words;
+		PGH_HIP(hipMemcpy(ds->d_ph_present + at, bits.data(), 8ull * words, hipMemcpyHostToDevice), "phase upload");
+		PGH_HIP(hipMemcpy(ds->d_ph_info + at, bits.data() + words, 8ull * words, hipMemcpyHostToDevice), "phase upload");
+	}
+	return PGH_OK;
+}
+
 extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t variant_begin, uint32_t variant_end,
                         pgh_dataset **out, char *errbuf) {
 	if (!pgen_path || !out) {
@@ -375,12 +430,18 @@ extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t va
 	if (rc == PGH_OK && ix.has_dosage) {
 		rc = PrepareDosage(ds.get(), dosage, errbuf);
 	}
+	if (rc == PGH_OK && ix.has_phase) {
+		rc = PreparePhase(ds.get(), errbuf);
+	}
+	std::vector<uint32_t> host_phase; // phased variants whose track the host parses
+	const bool phase_on_device = ds->sample_ct <= pgh::PhaseIngestMaxSamples();
 	if (rc != PGH_OK) {
 		pgh_close(ds.release());
 		return rc;
 	}
 	lap("dosage arrays");
 	auto has_track = [&](uint32_t r) { return ds->dos_rows != 0 && ds->dos_row_of[r - variant_begin] >= 0; };
+	auto has_phase = [&](uint32_t r) { return ds->ph_rows != 0 && ds->ph_row_of[r - variant_begin] >= 0; };
 
 	// Stream the body through two pinned staging buffers, three ways per run of records:
 	//   plain   a long run of literal 2-bit records is already the row image: pread into the
@@ -500,7 +561,7 @@ extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t va
 						break;
 					}
 					const uint64_t len = ix.offset[r + 1] - ix.offset[r];
-					if (raw + len + 64 + 37ull * (n + 2) > stage_bytes) {
+					if (raw + len + 64 + 41ull * (n + 2) > stage_bytes) {
 						break;
 					}
 					raw += len;
@@ -530,6 +591,9 @@ extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t va
 					if (has_track(r)) {
 						dosage.host_parsed.push_back(r);
 					}
+					if (has_phase(r)) {
+						host_phase.push_back(r);
+					}
 				}
 			} else {
 				stop = v + n;
@@ -540,14 +604,15 @@ extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t va
 				const uint64_t tables = (raw + 16 + 15) & ~15ull; // 16 zero bytes the kernel may read past the end
 				std::memset(h + raw, 0, tables - raw);
 				// tables behind the bytes: rec_begin u64[n+1] | aux_at u64[n] | track u64[n] | ld_row u32[n] |
-				// dos_row i32[n] | count u32[n] | vrtype u8[n]  (aux_at / track / count are device scratch)
+				// dos_row i32[n] | count u32[n] | ph_row i32[n] | vrtype u8[n]  (aux_at / track / count are device scratch)
 				uint64_t *rec_begin = reinterpret_cast<uint64_t *>(h + tables);
 				uint32_t *ld_row = reinterpret_cast<uint32_t *>(rec_begin + (n + 1) + 2ull * n);
 				int32_t *dos_row = reinterpret_cast<int32_t *>(ld_row + n);
-				uint8_t *vrtype = reinterpret_cast<uint8_t *>(dos_row + 2ull * n);
+				int32_t *ph_row = dos_row + 2ull * n;
+				uint8_t *vrtype = reinterpret_cast<uint8_t *>(ph_row + n);
 				bool any_ld = false;
 				int64_t first_track = -1;
-				uint32_t n_tracks = 0;
+				uint32_t n_tracks = 0, n_phased = 0;
 				for (uint32_t i = 0; i < n; i++) {
 					const uint32_t r = v + i;
 					rec_begin[i] = ix.offset[r] - ix.offset[v];
@@ -556,6 +621,15 @@ extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t va
 					if (dos_row[i] >= 0) {
 						first_track = first_track < 0 ? dos_row[i] : first_track;
 						n_tracks++;
+					}
+					ph_row[i] = -1;
+					if (has_phase(r)) {
+						if (phase_on_device) {
+							ph_row[i] = ds->ph_row_of[r - variant_begin];
+							n_phased++;
+						} else {
+							host_phase.push_back(r);
+						}
 					}
 					if (is_ld(r)) {
 						any_ld = true;
@@ -566,7 +640,7 @@ extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t va
 					}
 				}
 				rec_begin[n] = raw;
-				const uint64_t used_bytes = tables + 8ull * (n + 1) + 16ull * n + 12ull * n + n;
+				const uint64_t used_bytes = tables + 8ull * (n + 1) + 16ull * n + 16ull * n + n;
 				e = hipMemcpyAsync(d_stage[which], h, used_bytes, hipMemcpyHostToDevice, stream);
 				if (e == hipSuccess) {
 					pgh::DecodeBatch batch;
@@ -578,7 +652,8 @@ extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t va
 					batch.ld_row = reinterpret_cast<const uint32_t *>(d_track + n);
 					const int32_t *d_dos_row = reinterpret_cast<const int32_t *>(batch.ld_row + n);
 					uint32_t *d_count = reinterpret_cast<uint32_t *>(const_cast<int32_t *>(d_dos_row) + n);
-					batch.vrtype = reinterpret_cast<const uint8_t *>(d_count + n);
+					const int32_t *d_ph_row = reinterpret_cast<const int32_t *>(d_count + n);
+					batch.vrtype = reinterpret_cast<const uint8_t *>(d_ph_row + n);
 					batch.rows = ds->d_rows;
 					batch.pitch = ds->pitch;
 					batch.row0 = v - variant_begin;
@@ -587,8 +662,28 @@ extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t va
 					batch.sample_ct = ds->sample_ct;
 					batch.id_bytes = ix.sample_id_bytes;
 					batch.error = d_error;
-					batch.aux_at = n_tracks ? d_aux : nullptr;
+					batch.aux_at = (n_tracks || n_phased) ? d_aux : nullptr;
 					e = pgh::LaunchDecodeRecords(batch, any_ld, stream);
+					if (e == hipSuccess && n_phased) {
+						pgh::PhaseIngest ph;
+						ph.bytes = batch.bytes;
+						ph.bytes_len = raw;
+						ph.rec_begin = batch.rec_begin;
+						ph.vrtype = batch.vrtype;
+						ph.aux_at = d_aux;
+						ph.ph_row = d_ph_row;
+						ph.rows = ds->d_rows;
+						ph.pitch = ds->pitch;
+						ph.row0 = batch.row0;
+						ph.variant0 = v;
+						ph.n = n;
+						ph.sample_ct = ds->sample_ct;
+						ph.present = ds->d_ph_present;
+						ph.info = ds->d_ph_info;
+						ph.words = (ds->sample_ct + 63) / 64;
+						ph.error = d_error;
+						e = pgh::LaunchPhaseIngest(ph, stream);
+					}
 					if (e == hipSuccess && n_tracks) {
 						pgh::DosageIngest in;
 						in.bytes = batch.bytes;
@@ -648,6 +743,13 @@ extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t va
 		SetErr(errbuf, "malformed variant record " + std::to_string(bad_variant - 1));
 		pgh_close(ds.release());
 		return PGH_ERR_FORMAT;
+	}
+	if (!host_phase.empty()) {
+		rc = AppendPhaseTracksHost(ds.get(), file, host_phase, errbuf);
+		if (rc != PGH_OK) {
+			pgh_close(ds.release());
+			return rc;
+		}
 	}
 	if (ds->dos_rows) {
 		uint64_t filled = 0;
@@ -1086,7 +1188,8 @@ extern "C" void pgh_close(pgh_dataset *ds) {
 	}
 	for (void *p : {static_cast<void *>(ds->d_rows), static_cast<void *>(ds->d_dos_row_of),
 	                static_cast<void *>(ds->d_dos_present), static_cast<void *>(ds->d_dos_rank),
-	                static_cast<void *>(ds->d_dos_val_off), static_cast<void *>(ds->d_dos_values)}) {
+	                static_cast<void *>(ds->d_dos_val_off), static_cast<void *>(ds->d_dos_values),
+	                static_cast<void *>(ds->d_ph_present), static_cast<void *>(ds->d_ph_info)}) {
 		if (p) {
 			(void)hipFree(p);
 		}

@@ -7,6 +7,7 @@
 #include "hwe_core.hpp"
 #include "decode.hpp"
 #include "dosage.hpp"
+#include "phase.hpp"
 #include "kernels.hpp"
 #include "ld.hpp"
 #include "linalg.hpp"
@@ -54,6 +55,11 @@ struct pgh_dataset {
 	uint32_t *d_dos_rank = nullptr;
 	uint64_t *d_dos_val_off = nullptr;
 	uint16_t *d_dos_values = nullptr;
+	// phase tracks of the resident range (phase.hpp): two bit rows per phased variant; ph_rows == 0: none
+	uint32_t ph_rows = 0;
+	std::vector<int32_t> ph_row_of;
+	uint64_t *d_ph_present = nullptr;
+	uint64_t *d_ph_info = nullptr;
 
 	RowView View() const {
 		return RowView {d_rows, pitch, sample_ct, record_bytes};
@@ -92,8 +98,7 @@ struct pgh_reader {
 	uint8_t *h_row = nullptr;     // pinned, pitch bytes
 	double *d_dosage = nullptr;   // one dosage row, allocated by the first pgh_get_dosage_f64
 	double *h_dosage = nullptr;   // pinned
-	std::unique_ptr<pgh::RecordFile> file;
-	std::unique_ptr<pgh::Normalizer> norm;
+	uint64_t *h_phase = nullptr;  // pinned: phasepresent + phaseinfo words of one variant
 	std::string err;
 };
 

@@ -33,16 +33,6 @@ extern "C" int pgh_reader_create(const pgh_dataset *ds, const pgh_subset *subset
 		pgh_reader_destroy(rd.release());
 		return DeviceFail(errbuf, "reader setup", e);
 	}
-	if (ds->has_file && ds->index.has_phase) { // phase tracks are parsed on the host, per call
-		rd->file.reset(new pgh::RecordFile());
-		std::string err;
-		if (!rd->file->Open(ds->pgen_path, err)) {
-			SetErr(errbuf, err);
-			pgh_reader_destroy(rd.release());
-			return PGH_ERR_OPEN;
-		}
-		rd->norm.reset(new pgh::Normalizer(ds->index, *rd->file));
-	}
 	*out = rd.release();
 	return PGH_OK;
 }
@@ -68,6 +58,9 @@ extern "C" void pgh_reader_destroy(pgh_reader *rd) {
 	}
 	if (rd->h_dosage) {
 		(void)hipHostFree(rd->h_dosage);
+	}
+	if (rd->h_phase) {
+		(void)hipHostFree(rd->h_phase);
 	}
 	if (rd->stream) {
 		(void)hipStreamDestroy(rd->stream);
@@ -217,22 +210,40 @@ extern "C" int pgh_get_phased(pgh_reader *rd, uint32_t vidx, uint64_t *genovec, 
 	const uint32_t n_out = rd->subset ? rd->subset->n_out : ds->sample_ct;
 	std::memset(phasepresent, 0, sizeof(uint64_t) * ((n_out + 63) / 64));
 	std::memset(phaseinfo, 0, sizeof(uint64_t) * ((n_out + 63) / 64));
-	if (!(rd->norm && (ds->index.vrtype[vidx] & 0x10))) {
+	const int32_t pr = ds->ph_rows ? ds->ph_row_of[vidx - ds->v_begin] : -1;
+	if (pr < 0) {
 		return pgh_get_2bit(rd, vidx, genovec);
 	}
-	std::vector<uint8_t> row, pp, pi;
-	std::string err;
-	if (!rd->norm->DecodePhase(vidx, row, pp, pi, err)) {
-		return ReaderFail(rd, PGH_ERR_FORMAT, err);
+	// PgrGetP: the call row and the variant's two resident bit rows, compacted to the included samples
+	const uint32_t words = (ds->sample_ct + 63) / 64;
+	hipError_t e = hipSuccess;
+	if (!rd->h_phase) {
+		e = hipHostMalloc(reinterpret_cast<void **>(&rd->h_phase), 16ull * words, hipHostMallocDefault);
 	}
+	if (e == hipSuccess) {
+		e = hipMemcpyAsync(rd->h_phase, ds->d_ph_present + static_cast<uint64_t>(pr) * words, 8ull * words,
+		                   hipMemcpyDeviceToHost, rd->stream);
+	}
+	if (e == hipSuccess) {
+		e = hipMemcpyAsync(rd->h_phase + words, ds->d_ph_info + static_cast<uint64_t>(pr) * words, 8ull * words,
+		                   hipMemcpyDeviceToHost, rd->stream);
+	}
+	if (e != hipSuccess) {
+		return ReaderFail(rd, PGH_ERR_DEVICE, std::string("phase rows: ") + hipGetErrorString(e));
+	}
+	rc = FetchRow(rd, vidx); // synchronises the stream
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	const uint64_t *pp = rd->h_phase, *pi = rd->h_phase + words;
 	std::memset(genovec, 0, sizeof(uint64_t) * ((n_out + 31) / 32));
 	ForEachIncluded(rd, [&](uint32_t k, uint32_t s) {
-		genovec[k >> 5] |= static_cast<uint64_t>(RowCode(row.data(), s)) << (2 * (k & 31));
-		if (pp[s]) {
+		genovec[k >> 5] |= static_cast<uint64_t>(RowCode(rd->h_row, s)) << (2 * (k & 31));
+		if ((pp[s >> 6] >> (s & 63)) & 1ull) {
 			phasepresent[k >> 6] |= 1ull << (k & 63);
-		}
-		if (pi[s]) {
-			phaseinfo[k >> 6] |= 1ull << (k & 63);
+			if ((pi[s >> 6] >> (s & 63)) & 1ull) {
+				phaseinfo[k >> 6] |= 1ull << (k & 63);
+			}
 		}
 	});
 	return PGH_OK;

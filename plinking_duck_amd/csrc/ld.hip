@@ -60,10 +60,11 @@ __global__ __launch_bounds__(256) void k_ld_pairs(const uint8_t *__restrict__ ro
 	const uint32_t lane_in_unit = threadIdx.x % LANES;
 	const uint32_t unit = threadIdx.x / LANES;
 	const uint32_t t = blockIdx.x * kPerBlock + unit;
-	const bool live = t < n_tasks; // uniform per unit
+	bool live = t < n_tasks; // uniform per unit
 	LdTask task {0, 0, 0, 0};
 	if (live) {
 		task = tasks[t];
+		live = task.n_b != 0 && task.n_b <= kLdPartners; // a malformed task reads nothing (n_b - 1 indexes a partner row)
 	}
 	const uint32_t n_vec = ((sample_ct + 3) / 4 + 15) / 16; // 16-byte vectors that hold calls
 	const u32x4 *a_ptr = reinterpret_cast<const u32x4 *>(rows + static_cast<uint64_t>(task.a_row) * pitch);

@@ -273,3 +273,37 @@ def test_device_track_reader_survives_corrupt_bytes(files, gpu_lib, tmp_path):
     assert opened and failed  # both outcomes occur: damage to a value is silent, damage to the structure is not
     ds = gpu_lib.Dataset.open(path)  # the device is still healthy
     assert np.array_equal(ds.dosage_unpack(), want)
+
+
+def _bits(words, n):
+    return np.unpackbits(words.view(np.uint8), bitorder="little")[:n]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,n,seed", CASES)
+def test_phase_tracks_through_the_device_form(files, gpu_lib, oracle, m, n, seed, monkeypatch):
+    """pgh_get_phased (PgrGetP): the phase tracks of the written files -- both shapes, all hets phased or
+    flagged ones -- expanded on the device at open, against the oracle and against the host parser."""
+    path, geno, dos, dkinds, want = files[(m, n, True)]
+    pg = oracle.Pgen(path)
+    assert pg.has_phase
+    ds = gpu_lib.Dataset.open(path)
+    monkeypatch.setenv("PGH_HOST_NORMALIZE", "1")
+    hosted = gpu_lib.Dataset.open(path)
+    monkeypatch.delenv("PGH_HOST_NORMALIZE")
+    rng = np.random.default_rng(seed)
+    mask = rng.random(n) < 0.5
+    mask[0] = True
+    for dset in (ds, hosted):
+        for subset_mask in (None, mask):
+            ss = dset.subset(subset_mask) if subset_mask is not None else None
+            inc = None if subset_mask is None else subset_mask.astype(np.uint8)
+            n_out = n if subset_mask is None else int(subset_mask.sum())
+            rd = dset.reader(ss)
+            for v in range(m):
+                g, pp, pi = rd.get_phased(v)
+                eg, epp, epi = pg.phase(v, inc)
+                codes = (np.unpackbits(g.view(np.uint8), bitorder="little")[: 2 * n_out].reshape(-1, 2) * [1, 2]).sum(axis=1)
+                assert np.array_equal(np.where(codes == 3, -9, codes), eg), v
+                assert np.array_equal(_bits(pp, n_out), epp != 0), v
+                assert np.array_equal(_bits(pi, n_out) & _bits(pp, n_out), (epi != 0) & (epp != 0)), v
