@@ -332,7 +332,7 @@ int pgh_get_int8(pgh_reader *rd, uint32_t vidx, int8_t *out);
 int pgh_get_dosage_f64(pgh_reader *rd, uint32_t vidx, double *out);
 /* PgrGetP (src/pgen_reader.cpp:715): genovec as pgh_get_2bit plus the
  * phasepresent / phaseinfo bitarrays (ceil(n_out/64) words each, zero for
- * variants without a phase track).  The phase track is decoded on the host. */
+ * variants without a phase track).  The track was expanded into two resident bit rows at pgh_open. */
 int pgh_get_phased(pgh_reader *rd, uint32_t vidx, uint64_t *genovec, uint64_t *phasepresent, uint64_t *phaseinfo);
 const char *pgh_reader_error(const pgh_reader *rd);
 
