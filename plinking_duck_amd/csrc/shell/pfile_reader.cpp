@@ -19,9 +19,12 @@
 //                        reference pre-reads a variants x samples matrix with PgrGet per variant
 //                        (src/pfile_reader.cpp:1560-1835); here pgh_unpack_samples hands the matrix
 //                        back sample-major (a tiled transpose on the device), source by source.
-// Not carried over (tidy per-(variant, sample) rows and host-only metadata plumbing): orient :=
-// 'genotype', phased output in sample orient, combine_samples other than the implicit one,
-// parquet companions.
+//   orient := 'genotype'  one row per (effective variant, output sample): the variant columns, the psam
+//                        columns and the scalar call (or dosage); threads claim runs of <= 64 variants,
+//                        the device unpacks a run in one call, the genotype filter decides which rows
+//                        exist (src/pfile_reader.cpp:2342-2760).
+// Not carried over: phased output outside orient := 'variant', combine_samples other than the
+// implicit one, parquet companions.
 
 #include "pgen_reader.hpp"
 
@@ -119,6 +122,11 @@ struct PfileBindData : public TableFunctionData {
 	uint32_t effective_total = 0;
 	vector<uint8_t> all_pass; // per effective variant, list order: no call of it falls outside the genotype filter
 	idx_t first_geno_col = 0; // COLUMNS: the first per-variant column
+	// orient := 'genotype': one row per (effective variant, output sample); columns are the five variant
+	// columns, the psam columns, then `genotype`
+	bool genotype_orient = false;
+	vector<uint32_t> flat_source, flat_variant; // the effective variants of all sources, in list order
+	vector<uint32_t> batch_starts;              // scan batches: runs of <= 64 of them inside one source
 };
 
 struct PfileGlobalState : public GlobalTableFunctionState {
@@ -138,6 +146,7 @@ struct PfileGlobalState : public GlobalTableFunctionState {
 	bool use_keep = false;
 	vector<int8_t> calls;        // per-element modes: [output sample][effective variant], -9 = missing / filtered out
 	vector<double> dosage_rows;  // the same for dosages := true
+	std::atomic<uint32_t> next_variant {0}; // orient := 'genotype': the next unclaimed effective variant
 	uint32_t effective_variants = 0;
 	uint32_t candidate_variants = 0;
 	std::atomic<uint32_t> next_idx {0};
@@ -153,6 +162,10 @@ struct PfileGlobalState : public GlobalTableFunctionState {
 };
 
 struct PfileLocalState : public LocalTableFunctionState {
+	// orient := 'genotype': the claimed batch of variants and where the next row comes from
+	uint32_t batch_begin = 0, batch_cnt = 0, cur_variant = 0, cur_sample = 0;
+	vector<int8_t> batch_calls;    // [variant in batch][output sample], -9 = missing
+	vector<double> batch_dosages;
 	// orient := 'variant': this thread's read_pgen scan state per source, and the source it is draining
 	vector<unique_ptr<LocalTableFunctionState>> variant_states;
 	size_t current = 0;
@@ -304,11 +317,16 @@ static unique_ptr<FunctionData> PfileBind(ClientContext &context, TableFunctionB
 			                            "(aggregate modes require orient := 'variant' or 'sample')",
 			                            genotypes_str);
 		}
-		throw InvalidInputException("read_pfile: orient := 'genotype' is not available in this build "
-		                            "(use orient := 'variant', or orient := 'sample' with genotypes := 'counts'|'stats')");
+		if (genotypes_str == "columns" || genotypes_str == "struct") {
+			throw InvalidInputException("read_pfile: genotypes := '%s' is not compatible with orient := 'genotype' "
+			                            "(genotype mode already produces scalar output)",
+			                            genotypes_str);
+		}
+		bind_data->genotype_orient = true;
 	}
 
-	// --- orient := 'sample' ---
+	// --- orient := 'sample' and orient := 'genotype': both are built on the samples of source 0 and the
+	//     effective variants of every source ---
 	bind_data->sample_orient = true;
 	bool dosages = false, phased = false;
 	for (auto &kv : input.named_parameters) {
@@ -329,7 +347,7 @@ static unique_ptr<FunctionData> PfileBind(ClientContext &context, TableFunctionB
 		total_variants += src.c.raw_variant_ct;
 	}
 	auto &c = bind_data->sources[0].c;
-	const bool aggregate = genotypes_str == "counts" || genotypes_str == "stats";
+	const bool aggregate = !bind_data->genotype_orient && (genotypes_str == "counts" || genotypes_str == "stats");
 	if (aggregate) {
 		bind_data->genotype_mode = ResolveGenotypeMode(genotypes_str, static_cast<uint32_t>(total_variants), "read_pfile");
 		const char *label = bind_data->genotype_mode == GenotypeMode::COUNTS ? "counts" : "stats";
@@ -340,8 +358,9 @@ static unique_ptr<FunctionData> PfileBind(ClientContext &context, TableFunctionB
 			throw InvalidInputException("read_pfile: genotypes := '%s' is incompatible with dosages := true", label);
 		}
 	} else if (phased) {
-		throw InvalidInputException("read_pfile: orient := 'sample' with phased := true is not available in this build "
-		                            "(phase tracks are decoded on the host per variant; use orient := 'variant')");
+		throw InvalidInputException("read_pfile: orient := '%s' with phased := true is not available in this build "
+		                            "(use orient := 'variant')",
+		                            bind_data->genotype_orient ? "genotype" : "sample");
 	}
 	auto variants_it = input.named_parameters.find("variants");
 	if (variants_it != input.named_parameters.end()) { // single source only (guarded above)
@@ -443,6 +462,41 @@ static unique_ptr<FunctionData> PfileBind(ClientContext &context, TableFunctionB
 			}
 			bind_data->effective_total += static_cast<uint32_t>(src.effective.size());
 		}
+		if (bind_data->genotype_orient) {
+			// schema (src/pfile_reader.cpp:1272-1294): variant columns, psam columns, the scalar genotype
+			for (size_t si = 0; si < bind_data->sources.size(); si++) {
+				for (auto v : bind_data->sources[si].effective) {
+					if (bind_data->batch_starts.empty() || bind_data->flat_source.empty() ||
+					    bind_data->flat_source.back() != si ||
+					    bind_data->flat_source.size() - bind_data->batch_starts.back() >= 64) {
+						bind_data->batch_starts.push_back(static_cast<uint32_t>(bind_data->flat_source.size()));
+					}
+					bind_data->flat_source.push_back(static_cast<uint32_t>(si));
+					bind_data->flat_variant.push_back(v);
+				}
+			}
+			bind_data->batch_starts.push_back(static_cast<uint32_t>(bind_data->flat_source.size()));
+			names = {"CHROM", "POS", "ID", "REF", "ALT"};
+			return_types = {LogicalType::VARCHAR, LogicalType::INTEGER, LogicalType::VARCHAR, LogicalType::VARCHAR,
+			                LogicalType::VARCHAR};
+			for (idx_t i = 0; i < c.sample_info.column_names.size(); i++) {
+				const string &name = c.sample_info.column_names[i];
+				names.push_back(name);
+				if (name == "SEX") {
+					return_types.push_back(LogicalType::INTEGER);
+					bind_data->sex_col = i;
+				} else {
+					return_types.push_back(LogicalType::VARCHAR);
+					if (name == "PAT" || name == "MAT") {
+						bind_data->parent_cols.push_back(i);
+					}
+				}
+			}
+			bind_data->genotypes_col = names.size();
+			names.push_back("genotype");
+			return_types.push_back(dosages ? LogicalType(LogicalType::DOUBLE) : LogicalType(LogicalType::TINYINT));
+			return std::move(bind_data);
+		}
 		bind_data->genotype_mode = ResolveGenotypeMode(genotypes_str, bind_data->effective_total, "read_pfile");
 		const uint64_t matrix_size =
 		    static_cast<uint64_t>(bind_data->effective_total) * static_cast<uint64_t>(bind_data->output_samples.size());
@@ -542,6 +596,9 @@ static unique_ptr<GlobalTableFunctionState> PfileInitGlobal(ClientContext &conte
 		if (col_id != COLUMN_IDENTIFIER_ROW_ID && col_id >= bind_data.genotypes_col) {
 			state->need_genotypes = true; // the genotypes column, or one of the per-variant columns
 		}
+	}
+	if (bind_data.genotype_orient && bind_data.genotype_filter.active) {
+		state->need_genotypes = true; // the filter decides which rows exist, whatever is projected
 	}
 	for (auto &src : bind_data.sources) {
 		state->candidate_variants += src.has_variant_list ? static_cast<uint32_t>(src.variant_indices.size())
@@ -727,6 +784,148 @@ static void RunSamplePhase1(const PfileBindData &bind_data, PfileGlobalState &gs
 	}
 }
 
+//! FillSampleMetadataValue (src/pfile_reader.cpp:2846-2885): SEX is an integer with 0 / NA -> NULL,
+//! PAT / MAT "0" -> NULL, the usual missing tokens -> NULL.
+static void PutSampleField(const PfileBindData &bind_data, idx_t psam_col, uint32_t sample, Vector &vec, idx_t r) {
+	const auto &fields = bind_data.sources[0].c.sample_info.rows[sample];
+	const string val = psam_col < fields.size() ? fields[psam_col] : string();
+	if (psam_col == bind_data.sex_col) {
+		char *end = nullptr;
+		const long parsed = PsamMissing(val) ? 0 : std::strtol(val.c_str(), &end, 10);
+		if (parsed == 0 || end == val.c_str()) {
+			FlatVector::SetNull(vec, r, true);
+		} else {
+			FlatVector::GetData<int32_t>(vec)[r] = static_cast<int32_t>(parsed);
+		}
+		return;
+	}
+	const bool is_parent =
+	    std::find(bind_data.parent_cols.begin(), bind_data.parent_cols.end(), psam_col) != bind_data.parent_cols.end();
+	if (PsamMissing(val) || (is_parent && val == "0")) {
+		FlatVector::SetNull(vec, r, true);
+	} else {
+		FlatVector::GetData<string_t>(vec)[r] = StringVector::AddString(vec, val);
+	}
+}
+
+//! orient := 'genotype' (src/pfile_reader.cpp:2342-2760): one row per (effective variant, output sample).
+//! A thread claims a batch of variants, has their calls (or dosages) unpacked by the device in one call per
+//! run of consecutive variants, and fans them out; the genotype filter decides which rows exist.
+static void GenotypeOrientScan(const PfileBindData &bind_data, PfileGlobalState &gstate, PfileLocalState &lstate,
+                               DataChunk &output) {
+	const uint32_t n_out = static_cast<uint32_t>(bind_data.output_samples.size());
+	const auto &gf = bind_data.genotype_filter;
+	// the rows of this chunk: (flat variant, output sample)
+	vector<uint32_t> row_variant, row_sample;
+	row_variant.reserve(STANDARD_VECTOR_SIZE);
+	row_sample.reserve(STANDARD_VECTOR_SIZE);
+	vector<int8_t> row_call;
+	vector<double> row_dosage;
+	while (row_variant.size() < STANDARD_VECTOR_SIZE && n_out != 0) {
+		if (lstate.cur_variant >= lstate.batch_cnt) {
+			// next batch: bind cut the effective variants into runs of <= 64 that stay inside one source
+			const uint32_t b = gstate.next_variant.fetch_add(1);
+			if (b + 1 >= bind_data.batch_starts.size()) {
+				break;
+			}
+			const uint32_t begin = bind_data.batch_starts[b], cnt = bind_data.batch_starts[b + 1] - begin;
+			lstate.batch_begin = begin;
+			lstate.batch_cnt = cnt;
+			lstate.cur_variant = 0;
+			lstate.cur_sample = 0;
+			if (gstate.need_genotypes) {
+				const uint32_t si = bind_data.flat_source[begin];
+				pgh_dataset *ds = gstate.datasets[si]->handle;
+				pgh_subset *ss = gstate.subsets[si] ? gstate.subsets[si]->handle : nullptr;
+				char errbuf[PGH_ERRBUF_LEN] = {0};
+				int rc = PGH_OK;
+				if (bind_data.dosages) {
+					lstate.batch_dosages.resize(static_cast<size_t>(cnt) * n_out);
+					rc = pgh_dosage_unpack(ds, ss, 0, cnt, bind_data.flat_variant.data() + begin, lstate.batch_dosages.data(),
+					                       errbuf);
+				} else {
+					lstate.batch_calls.resize(static_cast<size_t>(cnt) * n_out);
+					uint32_t k = 0;
+					while (k < cnt && rc == PGH_OK) { // one device call per run of consecutive variants
+						uint32_t e = k + 1;
+						while (e < cnt && bind_data.flat_variant[begin + e] == bind_data.flat_variant[begin + e - 1] + 1) {
+							e++;
+						}
+						rc = pgh_unpack_range(ds, ss, bind_data.flat_variant[begin + k], bind_data.flat_variant[begin + e - 1] + 1,
+						                      lstate.batch_calls.data() + static_cast<size_t>(k) * n_out, nullptr, -9, errbuf);
+						k = e;
+					}
+				}
+				if (rc != PGH_OK) {
+					throw IOException("read_pfile: %s failed for variant %u: %s", bind_data.dosages ? "PgrGetD" : "PgrGet",
+					                  bind_data.flat_variant[begin], string(errbuf));
+				}
+			}
+		}
+		while (lstate.cur_variant < lstate.batch_cnt && row_variant.size() < STANDARD_VECTOR_SIZE) {
+			const uint32_t j = lstate.cur_variant, k = lstate.cur_sample;
+			bool keep = true;
+			int8_t call = 0;
+			double dose = 0.0;
+			if (gstate.need_genotypes) {
+				if (bind_data.dosages) {
+					dose = lstate.batch_dosages[static_cast<size_t>(j) * n_out + k];
+				} else {
+					call = lstate.batch_calls[static_cast<size_t>(j) * n_out + k];
+					if (gf.active) {
+						keep = call == -9 ? gf.include_missing : gf.AllowsCall(static_cast<double>(call));
+					}
+				}
+			}
+			if (keep) {
+				row_variant.push_back(lstate.batch_begin + j);
+				row_sample.push_back(k);
+				row_call.push_back(call);
+				row_dosage.push_back(dose);
+			}
+			if (++lstate.cur_sample == n_out) {
+				lstate.cur_sample = 0;
+				lstate.cur_variant++;
+			}
+		}
+	}
+	const idx_t n_rows = row_variant.size();
+	for (idx_t out_col = 0; out_col < gstate.column_ids.size(); out_col++) {
+		const auto file_col = gstate.column_ids[out_col];
+		if (file_col == COLUMN_IDENTIFIER_ROW_ID) {
+			continue;
+		}
+		auto &vec = output.data[out_col];
+		if (file_col < 5) {
+			for (idx_t r = 0; r < n_rows; r++) {
+				const auto &src = bind_data.sources[bind_data.flat_source[row_variant[r]]];
+				FillVariantMetadataColumn(src.c.variants, file_col, bind_data.flat_variant[row_variant[r]], vec, r);
+			}
+		} else if (file_col < bind_data.genotypes_col) {
+			for (idx_t r = 0; r < n_rows; r++) {
+				PutSampleField(bind_data, file_col - 5, bind_data.output_samples[row_sample[r]], vec, r);
+			}
+		} else if (bind_data.dosages) {
+			for (idx_t r = 0; r < n_rows; r++) {
+				if (row_dosage[r] == -9.0) {
+					FlatVector::SetNull(vec, r, true);
+				} else {
+					FlatVector::GetData<double>(vec)[r] = row_dosage[r];
+				}
+			}
+		} else {
+			for (idx_t r = 0; r < n_rows; r++) {
+				if (row_call[r] == -9) {
+					FlatVector::SetNull(vec, r, true);
+				} else {
+					FlatVector::GetData<int8_t>(vec)[r] = row_call[r];
+				}
+			}
+		}
+	}
+	CompatSetOutputCardinality(output, n_rows);
+}
+
 static void PfileScan(ClientContext &context, TableFunctionInput &data_p, DataChunk &output) {
 	auto &bind_data = data_p.bind_data->Cast<PfileBindData>();
 	auto &gstate = data_p.global_state->Cast<PfileGlobalState>();
@@ -746,6 +945,10 @@ static void PfileScan(ClientContext &context, TableFunctionInput &data_p, DataCh
 			output.Reset();
 		}
 		CompatSetOutputCardinality(output, 0);
+		return;
+	}
+	if (bind_data.genotype_orient) {
+		GenotypeOrientScan(bind_data, gstate, data_p.local_state->Cast<PfileLocalState>(), output);
 		return;
 	}
 	if (!gstate.datasets.empty()) {

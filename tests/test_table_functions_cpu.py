@@ -253,6 +253,17 @@ def test_read_pfile_sample_orient_schemas():
     assert len(F.query("read_pfile", P, orient="sample", settings={"plinking_max_matrix_elements": 16}, columns=["IID"])) == 4
     assert "include_genotypes is incompatible with dosages" in err("read_pfile", P, orient="sample", dosages=True,
                                                                    include_genotypes=["het"])
+    # orient := 'genotype' (read_pfile_genotype_orient.test): variant columns, psam columns, the scalar genotype
+    g = F.query("read_pfile", P, orient="genotype", columns=["ID", "IID", "SEX"])
+    assert g.all_names == ["CHROM", "POS", "ID", "REF", "ALT", "FID", "IID", "SEX", "genotype"]
+    assert g.all_types[-1] == "TINYINT" and len(g) == 16
+    assert sorted(r for r in g.rows if r[0] == "rs1") == [("rs1", "SAMPLE1", 1), ("rs1", "SAMPLE2", 2),
+                                                          ("rs1", "SAMPLE3", None), ("rs1", "SAMPLE4", 1)]
+    assert len(F.query("read_pfile", P, orient="genotype", samples=[2, 0], columns=["IID"])) == 8
+    assert F.query("read_pfile", P, orient="genotype", dosages=True, columns=["IID"]).all_types[-1] == "DOUBLE"
+    for mode in ("columns", "struct"):
+        assert "genotype mode already produces scalar output" in err("read_pfile", P, orient="genotype", genotypes=mode)
+    assert "phased := true is not available in this build" in err("read_pfile", P, orient="genotype", phased=True)
 
 
 def test_read_pfile_bind():

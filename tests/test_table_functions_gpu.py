@@ -708,6 +708,50 @@ def test_read_pfile_sample_orient_matrices(oracle):
         assert [(-9.0 if x is None else x) for x in g] == cols[k].tolist()
 
 
+def test_read_pfile_genotype_orient(oracle):
+    """read_pfile_genotype_orient.test, read_pfile_genotype_filter.test:150-200, read_pfile_list.test:28-60,
+    read_pfile_list_shards.test section 3 and 7: one row per (variant, sample)."""
+    P = data_path("pfile_example")
+    want = {"rs1": [0, 1, 2, None], "rs2": [1, 1, 0, 2], "rs3": [2, None, 1, 0], "rs4": [0, 0, 1, 2]}
+    for threads in (1, 4):
+        r = F.query("read_pfile", P, orient="genotype", columns=["ID", "IID", "genotype"], threads=threads)
+        assert len(r) == 16 and r.types[2] == "TINYINT"
+        got = {}
+        for vid, iid, g in r.rows:
+            got.setdefault(vid, {})[iid] = g
+        assert {v: [got[v][f"SAMPLE{i}"] for i in range(1, 5)] for v in got} == want
+    r = F.query("read_pfile", P, orient="genotype", columns=["CHROM", "POS", "ID", "REF", "ALT", "FID", "IID", "SEX"])
+    assert ("1", 10000, "rs1", "A", "G", "FAM001", "SAMPLE1", 1) in r.rows and len(r) == 16
+    r = F.query("read_pfile", P, orient="genotype", samples=["SAMPLE3", "SAMPLE1"], columns=["ID", "IID", "genotype"])
+    assert sorted(x[1:] for x in r.rows if x[0] == "rs1") == [("SAMPLE1", 0), ("SAMPLE3", 2)] and len(r) == 8
+    f = lambda **kw: sorted(F.query("read_pfile", P, orient="genotype", variants=["rs1"], **kw).rows)
+    assert f(include_genotypes=["het", "hom_alt"], columns=["IID", "genotype"]) == [("SAMPLE2", 1), ("SAMPLE3", 2)]
+    assert sorted(f(include_genotypes=["het", "missing"], columns=["IID", "genotype"]), key=lambda x: x[0]) == [
+        ("SAMPLE2", 1), ("SAMPLE4", None)]
+    assert f(include_genotypes=["het", "hom_alt"], columns=["IID"]) == [("SAMPLE2",), ("SAMPLE3",)]
+    ex = data_path("pgen_example")
+    assert len(F.query("read_pfile", [ex, ex], orient="genotype", columns=["ID"])) == 32
+    assert len(F.query("read_pfile", [ex, ex], orient="genotype", include_genotypes=["het"], columns=["ID"])) == 10
+    r = F.query("read_pfile", [ex, ex], orient="genotype", columns=["CHROM", "POS", "IID", "genotype"])
+    assert sorted(r.rows, key=lambda x: (x[1], x[2], x[3] is None, x[3]))[:4] == [
+        ("1", 10000, "SAMPLE1", 0), ("1", 10000, "SAMPLE1", 0), ("1", 10000, "SAMPLE2", 1), ("1", 10000, "SAMPLE2", 1)]
+    shards = [data_path("shard%d" % i) for i in (1, 2, 3)]
+    whole = data_path("large_example")
+    for threads in (1, 4):
+        mf = F.query("read_pfile", shards, orient="genotype", columns=["ID", "IID", "genotype"], threads=threads)
+        wf = F.query("read_pfile", whole, orient="genotype", columns=["ID", "IID", "genotype"], threads=threads)
+        key = lambda x: (x[0], x[1])
+        assert len(mf) == 24000 and sorted(mf.rows, key=key) == sorted(wf.rows, key=key)
+    het_mf = F.query("read_pfile", shards, orient="genotype", include_genotypes=["het"], columns=["ID", "IID"], threads=3)
+    het_wf = F.query("read_pfile", whole, orient="genotype", include_genotypes=["het"], columns=["ID", "IID"])
+    assert len(het_mf) == 6000 and sorted(het_mf.rows) == sorted(het_wf.rows)
+    # dosages: the scalar is a DOUBLE
+    dz = data_path("dosage_example")
+    pg = oracle.Pgen(dz + ".pgen")
+    d = F.query("read_pfile", dz, orient="genotype", dosages=True, columns=["ID", "IID", "genotype"])
+    assert d.types[2] == "DOUBLE" and len(d) == pg.M * pg.N
+
+
 def test_read_pfile_sample_orient_over_shards_and_batches(tmp_path, gpu_lib, oracle):
     """read_pfile_list.test:97-107 and a file wider than one transpose tile: the sources' effective variants side by
     side in list order; every sample's row equals the whole file's column."""
