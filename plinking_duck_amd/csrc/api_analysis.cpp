@@ -622,10 +622,12 @@ extern "C" int pgh_score_run_dev(const pgh_score_plan *plan, void *d_score_sum, 
 	double *ts = static_cast<double *>(plan->d_ts);
 	uint32_t *ac = static_cast<uint32_t *>(plan->d_ac);
 	const uint32_t n_hard = plan->n_hard, n_dos = plan->n_scored - plan->n_hard;
-	// One weight column (the SQL contract): dosage-bearing variants ride the hardcall kernel with their
-	// dosage-mean tables and k_score_dosage_fix adds what the explicit entries change.  More columns:
-	// hardcall-only variants through the MFMA kernel, dosage-bearing ones through k_score_dosage.
-	const bool two_step = plan->n_cols == 1;
+	// Dosage-bearing variants ride the hardcall kernels with their dosage-mean tables (every sample's term is
+	// ts[call], plus (affine(dosage) - ts[call]) where it has an explicit dosage), and k_score_dosage_fix adds
+	// what the explicit entries change, one weight column per launch.  PGH_SCORE_DOSAGE_LANES=1 keeps the
+	// one-lane-per-sample kernel (k_score_dosage) for the dosage-bearing variants instead.
+	const char *lanes_env = std::getenv("PGH_SCORE_DOSAGE_LANES");
+	const bool two_step = !(lanes_env && *lanes_env && *lanes_env != '0');
 	const uint32_t n_table = two_step ? plan->n_scored : n_hard;
 	const bool track = plan->mode != PGH_SCORE_CENTER && d_dosage_sum != nullptr;
 	if (n_table) {
@@ -654,11 +656,14 @@ extern "C" int pgh_score_run_dev(const pgh_score_plan *plan, void *d_score_sum, 
 	}
 	if (e == hipSuccess && n_dos) {
 		if (two_step) {
-			e = pgh::LaunchScoreDosageFix(ds->View(), ds->Dosage(), vlist + n_hard, n_dos, weights + n_hard, 1,
-			                              ts + 4ull * n_hard, static_cast<double *>(plan->d_lin), ac + n_hard,
-			                              static_cast<double *>(d_score_sum), 1,
-			                              track ? static_cast<double *>(d_dosage_sum) : nullptr,
-			                              static_cast<uint32_t *>(miss), st);
+			for (uint32_t c = 0; c < plan->n_cols && e == hipSuccess; c++) {
+				e = pgh::LaunchScoreDosageFix(ds->View(), ds->Dosage(), vlist + n_hard, n_dos,
+				                              weights + static_cast<uint64_t>(n_hard) * plan->n_cols + c, plan->n_cols,
+				                              ts + 4ull * n_hard, static_cast<double *>(plan->d_lin), ac + n_hard,
+				                              static_cast<double *>(d_score_sum) + c, plan->n_cols,
+				                              (track && c == 0) ? static_cast<double *>(d_dosage_sum) : nullptr,
+				                              c == 0 ? static_cast<uint32_t *>(miss) : nullptr, st);
+			}
 		} else {
 			e = pgh::LaunchScoreDosage(ds->View(), ds->Dosage(), vlist + n_hard, n_dos,
 			                           weights + static_cast<uint64_t>(n_hard) * plan->n_cols, plan->n_cols, plan->n_cols,

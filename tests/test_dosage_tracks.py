@@ -107,8 +107,11 @@ REL = 1e-12
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["default", "no_mean_imputation", "center"])
-@pytest.mark.parametrize("ncols", [1, 3, 6])
-def test_score_over_dosage_tracks(files, gpu_lib, oracle, mode, ncols):
+@pytest.mark.parametrize("ncols,lanes", [(1, False), (3, False), (6, False), (1, True), (5, True)])
+def test_score_over_dosage_tracks(files, gpu_lib, oracle, mode, ncols, lanes, monkeypatch):
+    """lanes: the one-lane-per-sample kernel (k_score_dosage) instead of hardcall sweep + k_score_dosage_fix."""
+    if lanes:
+        monkeypatch.setenv("PGH_SCORE_DOSAGE_LANES", "1")
     m, n = 120, 1000
     path, geno, dos, dkinds, want = files[(m, n, True)]
     ds = gpu_lib.Dataset.open(path)
