@@ -420,11 +420,12 @@ struct BitCounter {
 	}
 };
 
-__global__ __launch_bounds__(256) void k_class_cols3(const uint8_t *__restrict__ rows, uint64_t pitch, uint32_t chunks,
+constexpr uint32_t kCols3Threads = 1024; // an 8 KB stripe of every row per workgroup
+__global__ __launch_bounds__(kCols3Threads) void k_class_cols3(const uint8_t *__restrict__ rows, uint64_t pitch, uint32_t chunks,
                                                      uint32_t v_first, const uint32_t *__restrict__ vlist,
                                                      uint32_t v_count, uint32_t *__restrict__ slabs,
                                                      uint64_t slab_stride) {
-	const uint32_t col = blockIdx.x * 256u + threadIdx.x; // 8 bytes = 32 samples per lane
+	const uint32_t col = blockIdx.x * kCols3Threads + threadIdx.x; // 8 bytes = 32 samples per lane
 	if (col >= chunks) {
 		return;
 	}
@@ -998,7 +999,8 @@ hipError_t LaunchClassCounts3(const RowView &view, uint32_t v_first, const uint3
 		return hipMemsetAsync(out, 0, sizeof(uint32_t) * 3ull * out_stride, stream);
 	}
 	const uint32_t chunks = static_cast<uint32_t>((static_cast<uint64_t>(view.record_bytes) + 7) / 8);
-	const uint32_t col_blocks = (chunks + 255) / 256;
+	const uint32_t col_blocks = (chunks + kCols3Threads - 1) / kCols3Threads;
+	const uint32_t sum_blocks = (chunks + 255) / 256;
 	const uint64_t slab_stride = static_cast<uint64_t>(chunks) * kCols3Words * kCols3Planes; // dwords per slice
 	const uint32_t rows_per_launch = kCols3Super * kCols3Rows;
 	uint32_t *slabs = reinterpret_cast<uint32_t *>(scratch);
@@ -1009,13 +1011,13 @@ hipError_t LaunchClassCounts3(const RowView &view, uint32_t v_first, const uint3
 	for (uint32_t done = 0; done < v_count; done += rows_per_launch) {
 		const uint32_t n_rows = std::min(rows_per_launch, v_count - done);
 		const uint32_t slices = (n_rows + kCols3Rows - 1) / kCols3Rows;
-		hipLaunchKernelGGL(k_class_cols3, dim3(col_blocks, slices), dim3(256), 0, stream, view.rows, view.pitch, chunks,
+		hipLaunchKernelGGL(k_class_cols3, dim3(col_blocks, slices), dim3(kCols3Threads), 0, stream, view.rows, view.pitch, chunks,
 		                   v_first + done, vlist ? vlist + done : nullptr, n_rows, slabs, slab_stride);
 		e = hipGetLastError();
 		if (e != hipSuccess) {
 			return e;
 		}
-		hipLaunchKernelGGL(k_sum_class_bits, dim3(col_blocks, (slices + kCols3SumGroup - 1) / kCols3SumGroup), dim3(256), 0,
+		hipLaunchKernelGGL(k_sum_class_bits, dim3(sum_blocks, (slices + kCols3SumGroup - 1) / kCols3SumGroup), dim3(256), 0,
 		                   stream, slabs, slab_stride, chunks, slices, view.sample_ct, out_stride, out);
 		e = hipGetLastError();
 		if (e != hipSuccess) {
