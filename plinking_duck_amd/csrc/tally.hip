@@ -204,56 +204,61 @@ __global__ __launch_bounds__(256) void k_counts_wave(const uint8_t *__restrict__
 // per-sample missing tally (column sums of the missing indicator)
 // ---------------------------------------------------------------------------
 //
-// A lane owns one 16-byte column (64 samples) and walks down a slice of rows.
-// The indicator m = w & (w>>1) & 0x5555.. has one bit per 2-bit slot, so it is
-// added SWAR-style: 2-bit fields (<=3 rows) -> 4-bit fields (<=15) -> 8-bit
-// fields (<=255) -> 64 uint32 registers.  Each slice writes its totals to its
-// own slab row with plain stores; k_sum_slabs adds the slices.  No atomics: a
-// lane's 64 counters sit 256 B apart from its neighbour's, the worst shape for
-// the memory-side atomic units.
+// A lane owns one 16-byte column (64 samples) and walks down a slice of rows.  The indicator
+// m = w & (w>>1) & 0x5555.. has one bit per 2-bit slot; two of them pack into a full word of one bit per
+// sample, and the words of successive rows are summed as a positional population count: bit-sliced
+// counters (plane p holds bit p of every position's count) fed through a Harley-Seal carry-save tree.
+// Each slice writes its planes to its own slab with plain stores; k_sum_cols1 adds the slices in the same
+// bit-sliced form and turns bit positions into samples at the end.  (The first form widened SWAR fields
+// 2 -> 4 -> 8 -> 32 bits into 64 registers per lane; it streamed at the same 6.25 TB/s -- the column walk,
+// not the arithmetic, sets that -- with 3x the registers.)
 
-struct MissAcc {
-	uint32_t a4[8];
-	uint32_t a8[16];
-	uint32_t a32[64];
-};
-
-__device__ __forceinline__ void Fold2To4(MissAcc &acc, const uint32_t a2[4]) {
-#pragma unroll
-	for (int j = 0; j < 4; j++) {
-		acc.a4[2 * j] += a2[j] & 0x33333333u;
-		acc.a4[2 * j + 1] += (a2[j] >> 2) & 0x33333333u;
-	}
+__device__ __forceinline__ void Csa(uint32_t &h, uint32_t &l, uint32_t a, uint32_t b, uint32_t c) {
+	const uint32_t u = a ^ b;
+	h = (a & b) | (u & c);
+	l = u ^ c;
 }
 
-__device__ __forceinline__ void Fold4To8(MissAcc &acc) {
-#pragma unroll
-	for (int j = 0; j < 4; j++) {
-		acc.a8[4 * j + 0] += acc.a4[2 * j] & 0x0f0f0f0fu;
-		acc.a8[4 * j + 1] += (acc.a4[2 * j] >> 4) & 0x0f0f0f0fu;
-		acc.a8[4 * j + 2] += acc.a4[2 * j + 1] & 0x0f0f0f0fu;
-		acc.a8[4 * j + 3] += (acc.a4[2 * j + 1] >> 4) & 0x0f0f0f0fu;
-		acc.a4[2 * j] = 0;
-		acc.a4[2 * j + 1] = 0;
-	}
-}
+// bit-sliced counter of one 32-bit word of indicator bits, fed four rows at a time
+template <int PLANES>
+struct BitCounter {
+	uint32_t p[PLANES]; // p[0] ones, p[1] twos, p[2] fours, p[3] eights, p[4] sixteens, ...
+	uint32_t fours_a, eights_a; // carries waiting for their partner inside a 16-row trip
 
-__device__ __forceinline__ void Fold8To32(MissAcc &acc) {
-	// a8[4j+q] byte b counts sample 16j + 4b + {0,2,1,3}[q]
+	__device__ __forceinline__ void Clear() {
 #pragma unroll
-	for (int j = 0; j < 4; j++) {
+		for (int k = 0; k < PLANES; k++) {
+			p[k] = 0;
+		}
+		fours_a = eights_a = 0;
+	}
+	// rows 4g .. 4g+3 of a 16-row trip (g = 0..3, compile-time)
+	template <int G>
+	__device__ __forceinline__ void Add4(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) {
+		uint32_t twos_a, twos_b, fours;
+		Csa(twos_a, p[0], p[0], x0, x1);
+		Csa(twos_b, p[0], p[0], x2, x3);
+		Csa(fours, p[1], p[1], twos_a, twos_b);
+		if (G == 0 || G == 2) {
+			fours_a = fours;
+			return;
+		}
+		uint32_t eights;
+		Csa(eights, p[2], p[2], fours_a, fours);
+		if (G == 1) {
+			eights_a = eights;
+			return;
+		}
+		uint32_t carry;
+		Csa(carry, p[3], p[3], eights_a, eights);
 #pragma unroll
-		for (int q = 0; q < 4; q++) {
-			const uint32_t word = acc.a8[4 * j + q];
-			acc.a8[4 * j + q] = 0;
-			const int within = (q == 0) ? 0 : (q == 1 ? 2 : (q == 2 ? 1 : 3));
-#pragma unroll
-			for (int b = 0; b < 4; b++) {
-				acc.a32[16 * j + 4 * b + within] += (word >> (8 * b)) & 0xffu;
-			}
+		for (int k = 4; k < PLANES; k++) { // ripple the sixteens up
+			const uint32_t t = p[k] & carry;
+			p[k] ^= carry;
+			carry = t;
 		}
 	}
-}
+};
 
 // CLASS: which genotype code is tallied -- 3 missing (plink_missing, plink_score), 1 het,
 // 2 hom-alt (read_pfile's sample-orient counts)
@@ -268,86 +273,119 @@ __device__ __forceinline__ uint32_t ClassBits(uint32_t w) {
 	return (w >> 1) & ~w & 0x55555555u;
 }
 
+// One genotype code per sample over a slice of rows, as a positional population count (the scheme of
+// k_class_cols3 below with a single stream): a lane owns 16 bytes, its four indicator words (one bit per 2-bit
+// slot) pack into two full words, each feeds a 16-plane bit-sliced counter through the carry-save tree.
+// 1024 lanes per workgroup: a 16 KB stripe of every row.
+constexpr uint32_t kCols1Threads = 1024;
+constexpr int kCols1Planes = 16; // a slice holds at most 65280 rows
 template <int CLASS>
-__global__ __launch_bounds__(256) void k_missing_cols(const uint8_t *__restrict__ rows, uint64_t pitch,
-                                                      uint32_t chunks, uint32_t v_first,
-                                                      const uint32_t *__restrict__ vlist, uint32_t v_count,
-                                                      uint32_t slice_len, const uint32_t *__restrict__ row_flags,
-                                                      uint32_t *__restrict__ slabs, uint32_t slab_stride) {
-	// row_flags (optional): rows whose low byte is zero are not counted (skipped scored variants)
-	const uint32_t col = blockIdx.x * 256u + threadIdx.x;
+__global__ __launch_bounds__(kCols1Threads) void k_class_cols1(const uint8_t *__restrict__ rows, uint64_t pitch,
+                                                              uint32_t chunks, uint32_t v_first,
+                                                              const uint32_t *__restrict__ vlist, uint32_t v_count,
+                                                              uint32_t slice_len,
+                                                              const uint32_t *__restrict__ row_flags,
+                                                              uint32_t *__restrict__ slabs, uint64_t slab_stride) {
+	const uint32_t col = blockIdx.x * kCols1Threads + threadIdx.x;
 	if (col >= chunks) {
 		return;
 	}
 	const uint32_t i_begin = blockIdx.y * slice_len;
 	const uint32_t i_end = min(i_begin + slice_len, v_count);
-	MissAcc acc;
-#pragma unroll
-	for (int j = 0; j < 8; j++) {
-		acc.a4[j] = 0;
-	}
-#pragma unroll
-	for (int j = 0; j < 16; j++) {
-		acc.a8[j] = 0;
-	}
-#pragma unroll
-	for (int j = 0; j < 64; j++) {
-		acc.a32[j] = 0;
-	}
-	uint32_t n4 = 0, n8 = 0; // rows folded into the 4-bit / 8-bit fields so far
-	uint32_t i = i_begin;
-	auto row_ptr = [&](uint32_t idx) {
+	BitCounter<kCols1Planes> ctr[2];
+	ctr[0].Clear();
+	ctr[1].Clear();
+	// rows past the slice, and rows whose flag byte is zero (skipped scored variants), add nothing
+	auto load = [&](uint32_t idx) {
+		if (idx >= i_end || (row_flags && !(row_flags[idx] & 0xffu))) {
+			return make_uint4(0, 0, 0, 0);
+		}
 		const uint32_t v = vlist ? vlist[idx] : v_first + idx;
-		return reinterpret_cast<const uint4 *>(rows + static_cast<uint64_t>(v) * pitch) + col;
+		return LoadStream(reinterpret_cast<const uint4 *>(rows + static_cast<uint64_t>(v) * pitch) + col);
 	};
-	auto fold = [&](const uint32_t a2[4], uint32_t take) {
-		Fold2To4(acc, a2);
-		n4 += take;
-		if (n4 + 3 > 15) {
-			Fold4To8(acc);
-			n8 += n4;
-			n4 = 0;
-			if (n8 + 15 > 255) {
-				Fold8To32(acc);
-				n8 = 0;
+#define PGH_COLS1_GROUP(G, R0, R1, R2, R3)                                                                             \
+	ctr[0].Add4<G>(ClassBits<CLASS>(R0.x) | (ClassBits<CLASS>(R0.y) << 1), ClassBits<CLASS>(R1.x) | (ClassBits<CLASS>(R1.y) << 1), \
+	               ClassBits<CLASS>(R2.x) | (ClassBits<CLASS>(R2.y) << 1), ClassBits<CLASS>(R3.x) | (ClassBits<CLASS>(R3.y) << 1)); \
+	ctr[1].Add4<G>(ClassBits<CLASS>(R0.z) | (ClassBits<CLASS>(R0.w) << 1), ClassBits<CLASS>(R1.z) | (ClassBits<CLASS>(R1.w) << 1), \
+	               ClassBits<CLASS>(R2.z) | (ClassBits<CLASS>(R2.w) << 1), ClassBits<CLASS>(R3.z) | (ClassBits<CLASS>(R3.w) << 1));
+	for (uint32_t i = i_begin; i < i_end; i += 16u) {
+		uint4 a0 = load(i), a1 = load(i + 1), a2 = load(i + 2), a3 = load(i + 3);
+		uint4 b0 = load(i + 4), b1 = load(i + 5), b2 = load(i + 6), b3 = load(i + 7);
+		PGH_COLS1_GROUP(0, a0, a1, a2, a3)
+		a0 = load(i + 8), a1 = load(i + 9), a2 = load(i + 10), a3 = load(i + 11);
+		PGH_COLS1_GROUP(1, b0, b1, b2, b3)
+		b0 = load(i + 12), b1 = load(i + 13), b2 = load(i + 14), b3 = load(i + 15);
+		PGH_COLS1_GROUP(2, a0, a1, a2, a3)
+		PGH_COLS1_GROUP(3, b0, b1, b2, b3)
+	}
+#undef PGH_COLS1_GROUP
+	// planes of word k: slabs[slice][k][plane][col]
+	uint32_t *dst = slabs + static_cast<uint64_t>(blockIdx.y) * slab_stride + col;
+#pragma unroll
+	for (uint32_t k = 0; k < 2; k++) {
+#pragma unroll
+		for (int pl = 0; pl < kCols1Planes; pl++) {
+			dst[(static_cast<uint64_t>(k) * kCols1Planes + pl) * chunks] = ctr[k].p[pl];
+		}
+	}
+}
+
+// out[s] += the slices' counts of sample s.  A lane owns one column (64 samples) and a run of slices, adds their
+// 16-plane numbers in bit-sliced form and turns bit positions into samples at the end: packed word q holds
+// sample 32q + k at bit 2k and sample 32q + 16 + k at bit 2k + 1.
+constexpr int kCols1SumPlanes = 26;     // 1024 slices x 65280 rows < 2^26
+constexpr uint32_t kCols1SumGroup = 16; // slices per lane
+__global__ __launch_bounds__(256) void k_sum_cols1(const uint32_t *__restrict__ slabs, uint64_t slab_stride,
+                                                   uint32_t chunks, uint32_t n_slices, uint32_t n,
+                                                   uint32_t *__restrict__ out) {
+	const uint32_t col = blockIdx.x * 256u + threadIdx.x;
+	if (col >= chunks) {
+		return;
+	}
+	uint32_t acc[2][kCols1SumPlanes];
+#pragma unroll
+	for (int k = 0; k < 2; k++) {
+#pragma unroll
+		for (int pl = 0; pl < kCols1SumPlanes; pl++) {
+			acc[k][pl] = 0;
+		}
+	}
+	const uint32_t y_begin = blockIdx.y * kCols1SumGroup;
+	const uint32_t y_end = min(y_begin + kCols1SumGroup, n_slices);
+	for (uint32_t y = y_begin; y < y_end; y++) {
+		const uint32_t *sl = slabs + static_cast<uint64_t>(y) * slab_stride + col;
+		uint32_t x[2 * kCols1Planes];
+#pragma unroll
+		for (int q = 0; q < 2 * kCols1Planes; q++) {
+			x[q] = __builtin_nontemporal_load(sl + static_cast<uint64_t>(q) * chunks);
+		}
+#pragma unroll
+		for (int k = 0; k < 2; k++) {
+			uint32_t carry = 0;
+#pragma unroll
+			for (int pl = 0; pl < kCols1Planes; pl++) {
+				Csa(carry, acc[k][pl], acc[k][pl], x[k * kCols1Planes + pl], carry);
+			}
+#pragma unroll
+			for (int pl = kCols1Planes; pl < kCols1SumPlanes; pl++) {
+				const uint32_t t = acc[k][pl] & carry;
+				acc[k][pl] ^= carry;
+				carry = t;
 			}
 		}
-	};
-	// main loop: six independent 16-byte loads in flight per lane
-	while (!row_flags && i + 6 <= i_end) {
-		const uint4 w0 = LoadStream(row_ptr(i));
-		const uint4 w1 = LoadStream(row_ptr(i + 1));
-		const uint4 w2 = LoadStream(row_ptr(i + 2));
-		const uint4 w3 = LoadStream(row_ptr(i + 3));
-		const uint4 w4 = LoadStream(row_ptr(i + 4));
-		const uint4 w5 = LoadStream(row_ptr(i + 5));
-		uint32_t a[4], b[4];
-		a[0] = ClassBits<CLASS>(w0.x) + ClassBits<CLASS>(w1.x) + ClassBits<CLASS>(w2.x);
-		a[1] = ClassBits<CLASS>(w0.y) + ClassBits<CLASS>(w1.y) + ClassBits<CLASS>(w2.y);
-		a[2] = ClassBits<CLASS>(w0.z) + ClassBits<CLASS>(w1.z) + ClassBits<CLASS>(w2.z);
-		a[3] = ClassBits<CLASS>(w0.w) + ClassBits<CLASS>(w1.w) + ClassBits<CLASS>(w2.w);
-		b[0] = ClassBits<CLASS>(w3.x) + ClassBits<CLASS>(w4.x) + ClassBits<CLASS>(w5.x);
-		b[1] = ClassBits<CLASS>(w3.y) + ClassBits<CLASS>(w4.y) + ClassBits<CLASS>(w5.y);
-		b[2] = ClassBits<CLASS>(w3.z) + ClassBits<CLASS>(w4.z) + ClassBits<CLASS>(w5.z);
-		b[3] = ClassBits<CLASS>(w3.w) + ClassBits<CLASS>(w4.w) + ClassBits<CLASS>(w5.w);
-		fold(a, 3);
-		fold(b, 3);
-		i += 6;
 	}
-	while (i < i_end) {
-		if (!row_flags || (row_flags[i] & 0xffu)) { // wave-uniform
-			const uint4 w0 = LoadStream(row_ptr(i));
-			uint32_t a[4] = {ClassBits<CLASS>(w0.x), ClassBits<CLASS>(w0.y), ClassBits<CLASS>(w0.z), ClassBits<CLASS>(w0.w)};
-			fold(a, 1);
-		}
-		i += 1;
-	}
-	Fold4To8(acc);
-	Fold8To32(acc);
-	uint4 *dst = reinterpret_cast<uint4 *>(slabs + static_cast<uint64_t>(blockIdx.y) * slab_stride + col * 64u);
 #pragma unroll
-	for (int k = 0; k < 16; k++) {
-		dst[k] = make_uint4(acc.a32[4 * k], acc.a32[4 * k + 1], acc.a32[4 * k + 2], acc.a32[4 * k + 3]);
+	for (uint32_t t = 0; t < 64; t++) {
+		const uint32_t s = 64u * col + t;
+		const uint32_t q = t >> 5, bit = 2u * (t & 15u) + ((t >> 4) & 1u);
+		uint32_t cnt = 0;
+#pragma unroll
+		for (int pl = 0; pl < kCols1SumPlanes; pl++) {
+			cnt += ((acc[q][pl] >> bit) & 1u) << pl;
+		}
+		if (s < n && cnt) {
+			atomicAdd(out + s, cnt);
+		}
 	}
 }
 
@@ -374,52 +412,6 @@ constexpr uint32_t kCols3Super = 256;  // slices per launch (bounds the plane sc
 constexpr int kCols3Planes = 10;
 constexpr uint32_t kCols3Words = 3;    // per lane: two raw dwords (lo / hi bits interleaved) + their packed `both` word
 
-__device__ __forceinline__ void Csa(uint32_t &h, uint32_t &l, uint32_t a, uint32_t b, uint32_t c) {
-	const uint32_t u = a ^ b;
-	h = (a & b) | (u & c);
-	l = u ^ c;
-}
-
-// bit-sliced counter of one 32-bit word of indicator bits, fed four rows at a time
-struct BitCounter {
-	uint32_t p[kCols3Planes]; // p[0] ones, p[1] twos, p[2] fours, p[3] eights, p[4] sixteens, ...
-	uint32_t fours_a, eights_a; // carries waiting for their partner inside a 16-row trip
-
-	__device__ __forceinline__ void Clear() {
-#pragma unroll
-		for (int k = 0; k < kCols3Planes; k++) {
-			p[k] = 0;
-		}
-		fours_a = eights_a = 0;
-	}
-	// rows 4g .. 4g+3 of a 16-row trip (g = 0..3, compile-time)
-	template <int G>
-	__device__ __forceinline__ void Add4(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) {
-		uint32_t twos_a, twos_b, fours;
-		Csa(twos_a, p[0], p[0], x0, x1);
-		Csa(twos_b, p[0], p[0], x2, x3);
-		Csa(fours, p[1], p[1], twos_a, twos_b);
-		if (G == 0 || G == 2) {
-			fours_a = fours;
-			return;
-		}
-		uint32_t eights;
-		Csa(eights, p[2], p[2], fours_a, fours);
-		if (G == 1) {
-			eights_a = eights;
-			return;
-		}
-		uint32_t carry;
-		Csa(carry, p[3], p[3], eights_a, eights);
-#pragma unroll
-		for (int k = 4; k < kCols3Planes; k++) { // ripple the sixteens up
-			const uint32_t t = p[k] & carry;
-			p[k] ^= carry;
-			carry = t;
-		}
-	}
-};
-
 constexpr uint32_t kCols3Threads = 1024; // an 8 KB stripe of every row per workgroup
 __global__ __launch_bounds__(kCols3Threads) void k_class_cols3(const uint8_t *__restrict__ rows, uint64_t pitch, uint32_t chunks,
                                                      uint32_t v_first, const uint32_t *__restrict__ vlist,
@@ -431,7 +423,7 @@ __global__ __launch_bounds__(kCols3Threads) void k_class_cols3(const uint8_t *__
 	}
 	const uint32_t i_begin = blockIdx.y * kCols3Rows;
 	const uint32_t i_end = min(i_begin + kCols3Rows, v_count);
-	BitCounter ctr[kCols3Words];
+	BitCounter<kCols3Planes> ctr[kCols3Words];
 #pragma unroll
 	for (uint32_t k = 0; k < kCols3Words; k++) {
 		ctr[k].Clear();
@@ -945,11 +937,35 @@ void MissingPerSamplePlan(uint32_t record_bytes, uint32_t v_count, uint32_t *sli
 	*slices_out = v_count ? (v_count + slice_len - 1) / slice_len : 0;
 }
 
+// slices of k_class_cols1: >= ~2048 workgroups where the rows allow it, multiples of 16 rows, <= 65280 rows
+static void ClassCols1Plan(uint32_t record_bytes, uint32_t v_count, uint32_t *slice_len_out, uint32_t *slices_out) {
+	const uint32_t chunks = (record_bytes + 15) / 16;
+	const uint32_t col_blocks = (chunks + kCols1Threads - 1) / kCols1Threads;
+	uint32_t want_slices = (2048 + col_blocks - 1) / col_blocks;
+	if (want_slices > 1024) {
+		want_slices = 1024;
+	}
+	uint32_t slice_len = (v_count + want_slices - 1) / want_slices;
+	slice_len = ((slice_len + 15) / 16) * 16;
+	if (slice_len < 96) {
+		slice_len = 96;
+	}
+	if (slice_len > 65280u) {
+		slice_len = 65280u;
+	}
+	*slice_len_out = slice_len;
+	*slices_out = v_count ? (v_count + slice_len - 1) / slice_len : 0;
+}
+
 size_t MissingPerSampleScratchBytes(uint32_t record_bytes, uint32_t v_count) {
+	// the fused kernel's uint32 partial rows, or k_class_cols1's plane words, whichever is larger
 	uint32_t slice_len, slices;
 	MissingPerSamplePlan(record_bytes, v_count, &slice_len, &slices);
-	const uint64_t stride = static_cast<uint64_t>((record_bytes + 15) / 16) * 64;
-	return static_cast<size_t>(slices) * stride * sizeof(uint32_t);
+	const uint64_t chunks = (record_bytes + 15) / 16;
+	const uint64_t fused = static_cast<uint64_t>(slices) * chunks * 64 * sizeof(uint32_t);
+	ClassCols1Plan(record_bytes, v_count, &slice_len, &slices);
+	const uint64_t planes = static_cast<uint64_t>(slices) * chunks * 2 * kCols1Planes * sizeof(uint32_t);
+	return static_cast<size_t>(std::max(fused, planes));
 }
 
 hipError_t LaunchMissingPerSample(const RowView &view, uint32_t v_first, const uint32_t *vlist, uint32_t v_count,
@@ -960,17 +976,18 @@ hipError_t LaunchMissingPerSample(const RowView &view, uint32_t v_first, const u
 hipError_t LaunchClassPerSample(const RowView &view, int genotype_class, uint32_t v_first, const uint32_t *vlist,
                                 uint32_t v_count, const uint32_t *row_flags, uint32_t *scratch, uint32_t *out,
                                 hipStream_t stream) {
-	if (v_count == 0) {
-		return hipMemsetAsync(out, 0, sizeof(uint32_t) * view.sample_ct, stream);
+	hipError_t e = hipMemsetAsync(out, 0, sizeof(uint32_t) * view.sample_ct, stream);
+	if (v_count == 0 || e != hipSuccess) {
+		return e;
 	}
 	const uint32_t chunks = static_cast<uint32_t>((static_cast<uint64_t>(view.record_bytes) + 15) / 16);
-	const uint32_t col_blocks = (chunks + 255) / 256;
+	const uint32_t col_blocks = (chunks + kCols1Threads - 1) / kCols1Threads;
 	uint32_t slice_len, slices;
-	MissingPerSamplePlan(view.record_bytes, v_count, &slice_len, &slices);
-	const uint32_t stride = chunks * 64u;
+	ClassCols1Plan(view.record_bytes, v_count, &slice_len, &slices);
+	const uint64_t stride = static_cast<uint64_t>(chunks) * 2 * kCols1Planes; // dwords per slice
 #define PGH_COLS(CLASS)                                                                                                \
-	hipLaunchKernelGGL(k_missing_cols<CLASS>, dim3(col_blocks, slices), dim3(256), 0, stream, view.rows, view.pitch,   \
-	                   chunks, v_first, vlist, v_count, slice_len, row_flags, scratch, stride)
+	hipLaunchKernelGGL(k_class_cols1<CLASS>, dim3(col_blocks, slices), dim3(kCols1Threads), 0, stream, view.rows,      \
+	                   view.pitch, chunks, v_first, vlist, v_count, slice_len, row_flags, scratch, stride)
 	if (genotype_class == 1) {
 		PGH_COLS(1);
 	} else if (genotype_class == 2) {
@@ -979,12 +996,12 @@ hipError_t LaunchClassPerSample(const RowView &view, int genotype_class, uint32_
 		PGH_COLS(3);
 	}
 #undef PGH_COLS
-	hipError_t e = hipGetLastError();
+	e = hipGetLastError();
 	if (e != hipSuccess) {
 		return e;
 	}
-	hipLaunchKernelGGL(k_sum_slabs, dim3((view.sample_ct + 255) / 256), dim3(256), 0, stream, scratch, stride, slices,
-	                   view.sample_ct, out);
+	hipLaunchKernelGGL(k_sum_cols1, dim3((chunks + 255) / 256, (slices + kCols1SumGroup - 1) / kCols1SumGroup), dim3(256), 0,
+	                   stream, scratch, stride, chunks, slices, view.sample_ct, out);
 	return hipGetLastError();
 }
 
