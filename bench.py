@@ -159,42 +159,59 @@ def main():
     dtype = "u32"
 
     if args.workload in ("freq", "fused"):
-        d_counts = torch.empty((m, 4), dtype=torch.int32, device=dev)
-        d_freq = torch.empty(m, dtype=torch.float64, device=dev)
-        d_obs = torch.empty(m, dtype=torch.int32, device=dev)
+        # Two sets of result buffers: while the tally of step i+1 streams the matrix, the results of step i
+        # travel to pinned host memory on a side stream (the copy engine).
+        side = torch.cuda.Stream(device=dev)
+        d_counts = [torch.empty((m, 4), dtype=torch.int32, device=dev) for _ in range(2)]
+        d_freq = [torch.empty(m, dtype=torch.float64, device=dev) for _ in range(2)]
+        d_obs = [torch.empty(m, dtype=torch.int32, device=dev) for _ in range(2)]
         h_counts = torch.empty((m, 4), dtype=torch.int32, pin_memory=True)
         h_freq = torch.empty(m, dtype=torch.float64, pin_memory=True)
         h_obs = torch.empty(m, dtype=torch.int32, pin_memory=True)
         if args.workload == "fused":
-            d_lnp = torch.empty(m, dtype=torch.float64, device=dev)
+            d_lnp = [torch.empty(m, dtype=torch.float64, device=dev) for _ in range(2)]
             h_lnp = torch.empty(m, dtype=torch.float64, pin_memory=True)
-            d_miss = torch.empty((n + 63) // 64 * 64, dtype=torch.int32, device=dev)
+            d_miss = [torch.empty((n + 63) // 64 * 64, dtype=torch.int32, device=dev) for _ in range(2)]
             h_miss = torch.empty(n, dtype=torch.int32, pin_memory=True)
         algo_bytes = m * record_bytes  # ceil(N/4) bytes read per variant
+        tallied = [torch.cuda.Event() for _ in range(2)]   # the tally of a buffer set is complete
+        drained = [None, None]                             # its derived columns have left for the host
+        step_no = [0]
 
         def step(timed):
+            b = step_no[0] & 1
+            step_no[0] += 1
+            if drained[b] is not None:
+                stream.wait_event(drained[b])  # the set is free again
             if timed:
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
             if args.workload == "fused":
                 # row sums (class tallies) and column sums (per-sample missing) in ONE pass
-                ds.fused_tally_dev(v_begin, v_end, d_counts.data_ptr(), d_miss.data_ptr(), st)
+                ds.fused_tally_dev(v_begin, v_end, d_counts[b].data_ptr(), d_miss[b].data_ptr(), st)
             else:
-                ds.counts_range_dev(v_begin, v_end, d_counts.data_ptr(), st)
+                ds.counts_range_dev(v_begin, v_end, d_counts[b].data_ptr(), st)
             if timed:
                 e1.record(stream)
                 kernel_events.append((e0, e1))
-            L.freq_from_counts_dev(d_counts.data_ptr(), m, d_freq.data_ptr(), d_obs.data_ptr(), st)
-            h_counts.copy_(d_counts, non_blocking=True)
-            h_freq.copy_(d_freq, non_blocking=True)
-            h_obs.copy_(d_obs, non_blocking=True)
+            L.freq_from_counts_dev(d_counts[b].data_ptr(), m, d_freq[b].data_ptr(), d_obs[b].data_ptr(), st)
             if args.workload == "fused":
-                # plink_hardy: exact test per variant from the same counts;
-                # plink_missing variant mode: counts[:,3]; sample mode: column sums
-                L.hwe_lnp_batch_dev(d_counts.data_ptr(), m, d_lnp.data_ptr(), False, st)
-                h_lnp.copy_(d_lnp, non_blocking=True)
-                h_miss.copy_(d_miss[:n], non_blocking=True)
+                # plink_hardy: exact test per variant from the same counts (a compute kernel: it stays on the
+                # main stream so that it does not share the CUs with the next tally, whose duration is what
+                # `roofline` reports); plink_missing variant mode: counts[:,3]; sample mode: column sums
+                L.hwe_lnp_batch_dev(d_counts[b].data_ptr(), m, d_lnp[b].data_ptr(), False, st)
+            tallied[b].record(stream)
+            side.wait_event(tallied[b])
+            with torch.cuda.stream(side):
+                h_counts.copy_(d_counts[b], non_blocking=True)
+                h_freq.copy_(d_freq[b], non_blocking=True)
+                h_obs.copy_(d_obs[b], non_blocking=True)
+                if args.workload == "fused":
+                    h_lnp.copy_(d_lnp[b], non_blocking=True)
+                    h_miss.copy_(d_miss[b][:n], non_blocking=True)
+                drained[b] = torch.cuda.Event()
+                drained[b].record(side)
 
         kernel_name = "k_counts_block" if args.workload == "freq" else "k_fused_tally"
         metric = "plink_freq genotypes/s" if args.workload == "freq" else "plink_freq+hardy+missing genotypes/s"
