@@ -143,6 +143,30 @@ def test_synth_files_roundtrip_through_oracle(lib, oracle, tmp_path):
     assert np.array_equal(rows[3], lib.synth_record_host(13, N, seed, 0.02))
 
 
+def test_synth_dosage_files_roundtrip_through_oracle(lib, oracle, tmp_path):
+    """pgh_synth_write_dosage_files: records = the same 2-bit bytes + a 0x60 dosage track, variable lengths,
+    tables written after the body; two 65,536-variant blocks.  Read back with the oracle."""
+    prefix = str(tmp_path / "dz")
+    M, N, seed = 66000, 37, 11
+    lib.synth_write_dosage_files(prefix, M, N, seed, 0.05, 0.3)
+    pg = oracle.Pgen(prefix + ".pgen")
+    assert (pg.M, pg.N, pg.has_dosage) == (M, N, True)
+    info = lib.probe(prefix + ".pgen")
+    assert info.has_dosage == 1 and info.raw_variant_ct == M
+    explicit = 0
+    for v in (0, 1, 777, 65535, 65536, 65999):
+        assert pg.vrtype(v) == 0x60
+        assert np.array_equal(lib.synth_record_host(v, N, seed, 0.05), pack_rows(pg.raw(v)))  # hardcalls untouched
+        d = pg.dosage(v)
+        g = pg.geno(v).astype(np.float64)
+        differs = d != g
+        explicit += int(differs.sum())
+        assert ((d == -9.0) | ((d >= 0.0) & (d <= 2.0))).all()
+        assert np.array_equal(lib.normalize_range_host(prefix + ".pgen", v, v + 1)[0], pack_rows(pg.raw(v)))
+    assert 0.1 < explicit / (6 * N) < 0.5  # ~30 % of the samples carry a value
+    assert len(oracle.load_pvar(prefix + ".pvar")["id"]) == M and len(oracle.load_psam(prefix + ".psam")["iid"]) == N
+
+
 def test_multi_block_header_roundtrip(lib, oracle, tmp_path):
     """> 65536 variants: per-block tables, parsed identically by both decoders."""
     prefix = str(tmp_path / "blocks")
