@@ -310,3 +310,26 @@ def test_phase_tracks_through_the_device_form(files, gpu_lib, oracle, m, n, seed
                 assert np.array_equal(np.where(codes == 3, -9, codes), eg), v
                 assert np.array_equal(_bits(pp, n_out), epp != 0), v
                 assert np.array_equal(_bits(pi, n_out) & _bits(pp, n_out), (epi != 0) & (epp != 0)), v
+
+
+@pytest.mark.gpu
+def test_dosage_ingest_across_staging_batches(tmp_path, gpu_lib, oracle):
+    """A file whose records fill several 64 MB staging buffers: value offsets carry over from batch to batch."""
+    prefix = str(tmp_path / "wide")
+    m, n = 3000, 100_003
+    gpu_lib.synth_write_dosage_files(prefix, m, n, 3, 0.02, 0.1)
+    assert m * (n // 4 + n // 8 + n // 5) > 2 * (64 << 20)  # three staging buffers' worth
+    pg = oracle.Pgen(prefix + ".pgen")
+    ds = gpu_lib.Dataset.open(prefix + ".pgen")
+    assert ds.info.dosage_variant_ct == m
+    picks = [0, 1, 1170, 1171, 2340, 2341, 2999]
+    got = ds.dosage_unpack(vidx=picks)
+    sums = ds.dosage_sums()
+    total = 0
+    for i, v in enumerate(picks):
+        assert np.array_equal(got[i], pg.dosage(v)), v
+    for v in range(0, m, 97):
+        counts, dosages, _ = pg.dcounts(v)
+        assert int(sums[v][0]) == int(dosages[1]) and int(sums[v][2]) * 32768 - int(sums[v][0]) == int(dosages[0]), v
+    part = gpu_lib.Dataset.open(prefix + ".pgen", variant_begin=1171, variant_end=2341)
+    assert np.array_equal(part.dosage_sums(), sums[1171:2341])
