@@ -220,6 +220,26 @@ static PfileSource ResolveSource(const string &prefix, const string &pgen_overri
 	return src;
 }
 
+//! combine_samples := 'identical' (src/pfile_reader.cpp:1099-1131): every shard must carry the IIDs of the
+//! first one, in the same order; 'implicit' trusts the positions.
+static void CheckIdenticalSamples(const SampleInfo &ref, const string &ref_path, const SampleInfo &other,
+                                  const string &other_path) {
+	if (other.iids.size() != ref.iids.size()) {
+		throw InvalidInputException("read_pfile: combine_samples := 'identical' but '%s' has %llu samples vs %llu in '%s'",
+		                            other_path, static_cast<unsigned long long>(other.iids.size()),
+		                            static_cast<unsigned long long>(ref.iids.size()), ref_path);
+	}
+	for (idx_t k = 0; k < ref.iids.size(); k++) {
+		if (other.iids[k] != ref.iids[k]) {
+			throw InvalidInputException(
+			    "read_pfile: combine_samples := 'identical' but sample %llu differs: '%s' in '%s' vs '%s' in "
+			    "'%s'. All shards must share the same IIDs in the same order (or use combine_samples := "
+			    "'implicit' to trust positional alignment).",
+			    static_cast<unsigned long long>(k), other.iids[k], other_path, ref.iids[k], ref_path);
+		}
+	}
+}
+
 static unique_ptr<FunctionData> PfileBind(ClientContext &context, TableFunctionBindInput &input,
                                           vector<LogicalType> &return_types, vector<string> &names) {
 	auto bind_data = make_uniq<PfileBindData>();
@@ -266,6 +286,8 @@ static unique_ptr<FunctionData> PfileBind(ClientContext &context, TableFunctionB
 		}
 		throw InvalidInputException("read_pfile: unknown combine_samples '%s'", combine);
 	}
+	// 'identical' verifies the shards' IIDs; a psam override makes them identical by construction
+	const bool check_iids = multi_file && combine == "identical" && !input.named_parameters.count("psam");
 	if (multi_file) {
 		if (!pgen_override.empty() || input.named_parameters.count("pvar")) {
 			throw InvalidInputException(
@@ -308,6 +330,11 @@ static unique_ptr<FunctionData> PfileBind(ClientContext &context, TableFunctionB
 				want = have;
 			}
 			same_samples(have, want, src);
+			if (i && check_iids) {
+				CheckIdenticalSamples(bind_data->sources[0].variant_bind->Cast<PgenBindData>().c.sample_info,
+				                      bind_data->sources[0].pgen_path,
+				                      src.variant_bind->Cast<PgenBindData>().c.sample_info, src.pgen_path);
+			}
 		}
 		return std::move(bind_data);
 	}
@@ -344,6 +371,10 @@ static unique_ptr<FunctionData> PfileBind(ClientContext &context, TableFunctionB
 		auto &src = bind_data->sources[i];
 		src.c.Bind(context, src.inner, "read_pfile", i == 0);
 		same_samples(src.c.raw_sample_ct, bind_data->sources[0].c.raw_sample_ct, src);
+		if (i && check_iids) {
+			CheckIdenticalSamples(bind_data->sources[0].c.sample_info, bind_data->sources[0].pgen_path, src.c.sample_info,
+			                      src.pgen_path);
+		}
 		total_variants += src.c.raw_variant_ct;
 	}
 	auto &c = bind_data->sources[0].c;

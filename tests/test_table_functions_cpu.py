@@ -266,6 +266,35 @@ def test_read_pfile_sample_orient_schemas():
     assert "phased := true is not available in this build" in err("read_pfile", P, orient="genotype", phased=True)
 
 
+def test_read_pfile_sample_multifile_bind():
+    """read_pfile_sample_multifile.test: dimensions, combine_samples modes, psam override, negatives (bind only)."""
+    shards = [data_path("shard%d" % i) for i in (1, 2, 3)]
+    q = lambda files, **kw: F.query("read_pfile", files, orient="sample", columns=["IID"], **kw)
+    assert q(shards).all_types[-1] == "TINYINT[3000]" and len(q(shards)) == 8
+    assert q(shards[:2], combine_samples="identical").all_types[-1] == "TINYINT[2000]"
+    assert len(q(shards[:2], combine_samples="implicit")) == 8
+    r = q(shards, samples=["SAMP1", "SAMP2"])
+    assert len(r) == 2 and r.all_types[-1] == "TINYINT[3000]"
+    c = q(shards, genotypes="columns")
+    assert {"var1", "var2", "var3", "var3000"} <= set(c.all_names) and len(c.all_names) == 2 + 3000
+    r = q(shards[:2], psam=shards[0] + ".psam")
+    assert len(r) == 8 and r.all_types[-1] == "TINYINT[2000]"
+    assert len(q(shards[:2], psam=shards[0] + ".psam", combine_samples="identical")) == 8
+    for mode in ("union", "intersect", "concatenate"):
+        assert "not yet implemented" in err("read_pfile", shards[:2], orient="sample", combine_samples=mode)
+    assert "unknown combine_samples" in err("read_pfile", shards[:1], orient="sample", combine_samples="nonsense")
+    assert "sample count mismatch" in err("read_pfile", shards[:2], psam=data_path("pgen_example.psam"))
+    for kw in ({"pgen": shards[0] + ".pgen"}, {"pvar": shards[0] + ".pvar"}):
+        assert "pgen/pvar overrides cannot be combined with a multi-file list" in err("read_pfile", shards[:2], **kw)
+    # 'identical' compares the shards' IIDs; 'implicit' trusts the positions (large_example: SAMP*, streaming: SAMPLE*)
+    two = [data_path("large_example"), data_path("streaming_example")]
+    for orient in ("variant", "sample"):
+        msg = err("read_pfile", two, orient=orient, combine_samples="identical")
+        assert "combine_samples := 'identical' but sample 0 differs: 'SAMPLE1'" in msg and "vs 'SAMP1'" in msg
+    assert len(F.query("read_pfile", two, combine_samples="implicit", columns=["ID"])) == 53000
+    assert len(F.query("read_pfile", two, combine_samples="identical", psam=two[0] + ".psam", columns=["ID"])) == 53000
+
+
 def test_read_pfile_bind():
     PFX = data_path("pgen_example")
     r = F.query("read_pfile", PFX, columns=["ID", "POS"])

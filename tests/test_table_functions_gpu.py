@@ -708,6 +708,25 @@ def test_read_pfile_sample_orient_matrices(oracle):
         assert [(-9.0 if x is None else x) for x in g] == cols[k].tolist()
 
 
+def test_read_pfile_sample_multifile_values():
+    """read_pfile_sample_multifile.test: a sample's row over the shards is its rows over each shard, side by side;
+    filters apply per shard and shrink the dimension."""
+    shards = [data_path("shard%d" % i) for i in (1, 2, 3)]
+    mf = dict(F.query("read_pfile", shards, orient="sample", genotypes="list", columns=["IID", "genotypes"]).rows)
+    parts = [dict(F.query("read_pfile", sh, orient="sample", genotypes="list", columns=["IID", "genotypes"]).rows)
+             for sh in shards]
+    for iid in ("SAMP1", "SAMP5"):
+        assert mf[iid][:1000] == parts[0][iid] and mf[iid][1000:2000] == parts[1][iid] and mf[iid][2000:] == parts[2][iid]
+    kw = dict(samples=["SAMP1", "SAMP2", "SAMP3"], ac_range={"min": 2, "max": 4})
+    r = F.query("read_pfile", shards, orient="sample", columns=["IID", "genotypes"], **kw)
+    n_var = len(F.query("read_pfile", shards, columns=["ID"], **kw))
+    assert r.types[1] == f"TINYINT[{n_var}]" and {len(g) for _, g in r.rows} == {n_var} and len(r) == 3
+    ov = dict(F.query("read_pfile", shards[:2], orient="sample", genotypes="list", psam=shards[0] + ".psam",
+                      columns=["IID", "genotypes"]).rows)
+    au = dict(F.query("read_pfile", shards[:2], orient="sample", genotypes="list", columns=["IID", "genotypes"]).rows)
+    assert ov == au and len(ov["SAMP1"]) == 2000
+
+
 def test_read_pfile_genotype_orient(oracle):
     """read_pfile_genotype_orient.test, read_pfile_genotype_filter.test:150-200, read_pfile_list.test:28-60,
     read_pfile_list_shards.test section 3 and 7: one row per (variant, sample)."""
