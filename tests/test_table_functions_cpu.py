@@ -283,6 +283,10 @@ def test_read_pfile_sample_multifile_bind():
     for mode in ("union", "intersect", "concatenate"):
         assert "not yet implemented" in err("read_pfile", shards[:2], orient="sample", combine_samples=mode)
     assert "unknown combine_samples" in err("read_pfile", shards[:1], orient="sample", combine_samples="nonsense")
+    # read_pfile_orient_negative.test: read_pgen has the variant orientation only
+    for orient in ("sample", "genotype"):
+        assert f"orient := '{orient}' is not supported" in err("read_pgen", data_path("pgen_example.pgen"), orient=orient)
+    assert "invalid orient value 'invalid'" in err("read_pfile", data_path("pfile_example"), orient="invalid")
     assert "sample count mismatch" in err("read_pfile", shards[:2], psam=data_path("pgen_example.psam"))
     for kw in ({"pgen": shards[0] + ".pgen"}, {"pvar": shards[0] + ".pvar"}):
         assert "pgen/pvar overrides cannot be combined with a multi-file list" in err("read_pfile", shards[:2], **kw)
