@@ -273,8 +273,8 @@ int pgh_sample_counts_dev(const pgh_dataset *ds, uint32_t variant_begin, uint32_
 int pgh_ld_pairs(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_pairs, const uint32_t *vidx_a,
                  const uint32_t *vidx_b, uint32_t (*sums)[6], char *errbuf);
 /* Device-output form: sums land in d_sums (uint32[n_pairs][6]), computed on `stream`; vidx_a / vidx_b stay
- * host arrays.  The task list built from them goes up with a blocking copy and the call returns once the
- * kernel has finished (it owns the task list), so unlike the other *_dev forms this one synchronises `stream`. */
+ * host arrays.  The task list built from them goes up through the calling thread's own pinned staging buffer,
+ * stream-ordered; a thread's next call waits for this one's kernel before it reuses that buffer. */
 int pgh_ld_pairs_dev(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_pairs, const uint32_t *vidx_a,
                      const uint32_t *vidx_b, void *d_sums, void *stream, char *errbuf);
 

@@ -971,6 +971,30 @@ extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, 
 // plink_ld
 // ---------------------------------------------------------------------------
 
+namespace {
+// pgh_ld_pairs_dev's task list: one device buffer + one pinned host buffer per calling thread
+struct LdTaskBuffers {
+	void *d = nullptr, *h = nullptr;
+	size_t cap = 0;
+	int device = -1;           // the buffers belong to this device
+	hipEvent_t done = nullptr; // recorded behind the kernel that reads d
+	bool used = false;
+	~LdTaskBuffers() {
+		// thread exit: the runtime may already be gone at process exit, errors are of no interest here
+		if (d) {
+			(void)hipFree(d);
+		}
+		if (h) {
+			(void)hipHostFree(h);
+		}
+		if (done) {
+			(void)hipEventDestroy(done);
+		}
+	}
+};
+thread_local LdTaskBuffers t_ld_tasks;
+} // namespace
+
 extern "C" int pgh_ld_pairs_dev(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_pairs,
                                 const uint32_t *vidx_a, const uint32_t *vidx_b, void *d_sums, void *stream,
                                 char *errbuf) {
@@ -1005,17 +1029,42 @@ extern "C" int pgh_ld_pairs_dev(const pgh_dataset *ds, const pgh_subset *subset,
 		tasks.push_back(pgh::LdTask {a - ds->v_begin, b - ds->v_begin, 1u, p});
 	}
 	hipStream_t st = static_cast<hipStream_t>(stream);
-	// The task list goes up through an ordinary allocation and a blocking copy.  (It used to ride the
-	// stream-ordered pool with an asynchronous copy from this pageable vector; on ROCm 7.2 that copy was
-	// seen to leave the pool block all zeros after a particular run of pool allocations and frees -- a task
-	// with n_b == 0 then sends the kernel 64 GB past the matrix.  The kernel also refuses such tasks now.)
-	DevBuf d_tasks;
-	PGH_HIP(d_tasks.Alloc(sizeof(pgh::LdTask) * tasks.size()), "hipMalloc(ld tasks)");
-	PGH_HIP(hipMemcpy(d_tasks.p, tasks.data(), sizeof(pgh::LdTask) * tasks.size(), hipMemcpyHostToDevice), "ld task upload");
-	PGH_HIP(pgh::LaunchLdPairs(ds->View(), d_tasks.As<pgh::LdTask>(), static_cast<uint32_t>(tasks.size()),
+	// The task list goes up through this thread's own pair of buffers (device + pinned host), reused from
+	// call to call.  (It used to ride the stream-ordered pool with an asynchronous copy from the pageable
+	// vector; on ROCm 7.2 that copy was seen to leave the pool block all zeros after a particular run of pool
+	// allocations and frees -- a task with n_b == 0 then sent the kernel 64 GB past the matrix.  The kernel
+	// also refuses such tasks now.)
+	LdTaskBuffers &buf = t_ld_tasks;
+	const size_t need = sizeof(pgh::LdTask) * tasks.size();
+	if (buf.cap < need || buf.device != ds->device) {
+		if (buf.d) {
+			PGH_HIP(hipEventSynchronize(buf.done), "ld task buffers");
+			(void)hipFree(buf.d);
+			(void)hipHostFree(buf.h);
+			(void)hipEventDestroy(buf.done);
+			buf.d = buf.h = nullptr;
+			buf.done = nullptr;
+			buf.cap = 0;
+			buf.used = false;
+		}
+		buf.device = ds->device;
+		const size_t cap = std::max<size_t>(2 * need, 64u << 10);
+		PGH_HIP(hipMalloc(&buf.d, cap), "hipMalloc(ld tasks)");
+		PGH_HIP(hipHostMalloc(&buf.h, cap, hipHostMallocDefault), "hipHostMalloc(ld tasks)");
+		if (!buf.done) {
+			PGH_HIP(hipEventCreateWithFlags(&buf.done, hipEventDisableTiming), "ld task event");
+		}
+		buf.cap = cap;
+	} else if (buf.used) {
+		PGH_HIP(hipEventSynchronize(buf.done), "ld task buffers"); // the previous call's kernel has read them
+	}
+	std::memcpy(buf.h, tasks.data(), need);
+	PGH_HIP(hipMemcpyAsync(buf.d, buf.h, need, hipMemcpyHostToDevice, st), "ld task upload");
+	PGH_HIP(pgh::LaunchLdPairs(ds->View(), static_cast<const pgh::LdTask *>(buf.d), static_cast<uint32_t>(tasks.size()),
 	                           subset ? subset->d_mask2 : nullptr, static_cast<uint32_t(*)[6]>(d_sums), st),
 	        "ld pair kernel");
-	PGH_HIP(hipStreamSynchronize(st), "ld pair sync"); // d_tasks is freed with this frame
+	PGH_HIP(hipEventRecord(buf.done, st), "ld task event");
+	buf.used = true;
 	return PGH_OK;
 }
 
