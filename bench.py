@@ -51,7 +51,7 @@ def parse_args():
     ap.add_argument("--samples", type=int, default=500_000)
     ap.add_argument("--ld-variants", type=int, default=20000, help="anchors of the ld workload")
     ap.add_argument("--ld-window", type=int, default=64, help="partners per anchor of the ld workload")
-    ap.add_argument("--workload", choices=["freq", "fused", "unpack", "score", "pca", "ld", "samplecounts", "dosagefreq", "dosagescore"], default="freq")
+    ap.add_argument("--workload", choices=["freq", "fused", "unpack", "score", "pca", "ld", "samplecounts", "missingsample", "dosagefreq", "dosagescore"], default="freq")
     ap.add_argument("--n-pcs", type=int, default=10)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 disables)")
@@ -291,6 +291,26 @@ def main():
 
             kernel_name = "k_score_gemv_pairs + k_score_dosage_fix"
             metric = "plink_score(dosage) genotypes/s"
+    elif args.workload == "missingsample":
+        # plink_missing mode := 'sample': per-sample missing tallies over every variant (column sums)
+        padded = (n + 63) // 64 * 64
+        d_miss = torch.empty(padded, dtype=torch.int32, device=dev)
+        h_miss = torch.empty(padded, dtype=torch.int32, pin_memory=True)
+        algo_bytes = m * record_bytes
+
+        def step(timed):
+            if timed:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+            ds.missing_per_sample_dev(v_begin, v_end, d_miss.data_ptr(), st)
+            if timed:
+                e1.record(stream)
+                kernel_events.append((e0, e1))
+            h_miss.copy_(d_miss, non_blocking=True)
+
+        kernel_name = "k_class_cols1 + k_sum_cols1"
+        metric = "plink_missing(sample) genotypes/s"
     elif args.workload == "samplecounts":
         # read_pfile orient := 'sample', genotypes := 'counts': per-sample {het, hom_alt, missing}
         # tallies over every variant (hom_ref by subtraction) -- one pass, three counter sets per lane

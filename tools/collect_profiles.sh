@@ -30,6 +30,7 @@ run_bench score1 --workload score --score-cols 1 --steps 3 --warmup 1 --cpu-seco
 run_bench pca --workload pca --variants 100000 --steps 2 --warmup 1 --cpu-seconds 0
 run_bench ld --workload ld --variants 20000 --steps 3 --warmup 1 --cpu-seconds 0
 run_bench samplecounts --workload samplecounts --steps 3 --warmup 1 --cpu-seconds 0
+run_bench missingsample --workload missingsample --steps 5 --warmup 1 --cpu-seconds 0
 run_bench dosagefreq --workload dosagefreq --steps 5 --warmup 2 --cpu-seconds 0
 run_bench dosagescore --workload dosagescore --steps 3 --warmup 1 --cpu-seconds 0
 stats freq --steps 10 --warmup 2
@@ -39,6 +40,7 @@ stats score --workload score --variants 200000 --steps 3 --warmup 1
 stats pca --workload pca --variants 100000 --steps 1 --warmup 0
 stats ld --workload ld --variants 20000 --steps 2 --warmup 1
 stats samplecounts --workload samplecounts --steps 2 --warmup 1
+stats missingsample --workload missingsample --steps 3 --warmup 1
 stats dosagefreq --workload dosagefreq --steps 3 --warmup 1
 stats dosagescore --workload dosagescore --steps 2 --warmup 1
 for c in FETCH_SIZE WRITE_SIZE; do
