@@ -919,7 +919,9 @@ extern "C" int pgh_synth_add_dosage(pgh_dataset *ds, double rate, uint64_t seed,
 	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_dos_values), 2 * total + 32), "hipMalloc(dosage)");
 	PGH_HIP(hipMemsetAsync(ds->d_dos_values, 0, 2 * total + 32, st), "dosage memset");
 	PGH_HIP(hipMemcpyAsync(ds->d_dos_val_off, off.data(), 8ull * (rows + 1), hipMemcpyHostToDevice, st), "dosage upload");
-	PGH_HIP(pgh::LaunchSynthDosageValues(ds->d_dos_values, total, seed, st), "synthetic dosage values");
+	PGH_HIP(pgh::LaunchSynthDosageValues(ds->d_dos_present, ds->d_dos_rank, ds->d_dos_val_off, ds->d_dos_values, rows, words,
+	                                     ds->sample_ct, ds->v_begin, seed, st),
+	        "synthetic dosage values");
 	PGH_HIP(hipStreamSynchronize(st), "synthetic dosage sync");
 	ds->dos_rows = rows;
 	ds->dos_values = total;

@@ -364,11 +364,23 @@ __global__ __launch_bounds__(256) void k_dosage_row_totals(const uint64_t *__res
 	}
 }
 
-__global__ __launch_bounds__(256) void k_synth_dosage_values(uint16_t *__restrict__ values, uint64_t count,
-                                                             uint64_t seed) {
-	const uint64_t key = Mix64(seed ^ 0x2545f4914f6cdd1dULL);
-	for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < count; i += gridDim.x * 256ull) {
-		values[i] = static_cast<uint16_t>(((Mix64(key ^ i) & 0xffffffffull) * 32769ull) >> 32);
+// values keyed by (variant, sample), the same draw the presence bit came from: a shard holds the same
+// tracks as the whole, and pgh_synth_write_dosage_files writes them too
+__global__ __launch_bounds__(256) void k_synth_dosage_values(const uint64_t *__restrict__ present,
+                                                             const uint32_t *__restrict__ rank,
+                                                             const uint64_t *__restrict__ val_off,
+                                                             uint16_t *__restrict__ values, uint32_t words,
+                                                             uint32_t sample_ct, uint32_t variant0, uint64_t seed) {
+	const uint64_t key = Mix64(Mix64(seed) ^ (static_cast<uint64_t>(variant0 + blockIdx.x) << 32) ^ 0x5851f42d4c957f2dULL);
+	const uint64_t at = static_cast<uint64_t>(blockIdx.x) * words;
+	uint16_t *out = values + val_off[blockIdx.x];
+	for (uint32_t s = threadIdx.x; s < sample_ct; s += 256u) {
+		const uint64_t bits = present[at + (s >> 6)];
+		if ((bits >> (s & 63u)) & 1ull) {
+			const uint64_t h = Mix64(key ^ s);
+			out[rank[at + (s >> 6)] + static_cast<uint32_t>(__popcll(bits & ((1ull << (s & 63u)) - 1ull)))] =
+			    static_cast<uint16_t>(((h >> 32) * 32769ull) >> 32);
+		}
 	}
 }
 
@@ -859,11 +871,14 @@ hipError_t LaunchDosageRowTotals(const uint64_t *present, const uint32_t *rank, 
 	return hipGetLastError();
 }
 
-hipError_t LaunchSynthDosageValues(uint16_t *values, uint64_t count, uint64_t seed, hipStream_t stream) {
-	if (count == 0) {
+hipError_t LaunchSynthDosageValues(const uint64_t *present, const uint32_t *rank, const uint64_t *val_off,
+                                   uint16_t *values, uint32_t rows, uint32_t words, uint32_t sample_ct,
+                                   uint32_t variant0, uint64_t seed, hipStream_t stream) {
+	if (rows == 0) {
 		return hipSuccess;
 	}
-	hipLaunchKernelGGL(k_synth_dosage_values, dim3(4096), dim3(256), 0, stream, values, count, seed);
+	hipLaunchKernelGGL(k_synth_dosage_values, dim3(rows), dim3(256), 0, stream, present, rank, val_off, values, words,
+	                   sample_ct, variant0, seed);
 	return hipGetLastError();
 }
 

@@ -55,12 +55,15 @@ hipError_t LaunchDosageIngest(const DosageIngest &batch, uint32_t first_row, uin
 hipError_t LaunchDosageRank(const uint64_t *present, uint32_t rows, uint32_t words, uint32_t *rank,
                             hipStream_t stream);
 
-//! Seeded synthetic tracks: presence bits Bernoulli(rate) per (variant, sample); row totals; uniform values.
+//! Seeded synthetic tracks: presence bits Bernoulli(rate) and values uniform on 0..32768, both keyed by
+//! (seed, variant, sample) -- the draws pgh_synth_write_dosage_files makes; row totals.
 hipError_t LaunchSynthDosageBits(uint64_t *present, uint32_t rows, uint32_t words, uint32_t sample_ct, uint32_t variant0,
                                  uint64_t seed, double rate, hipStream_t stream);
 hipError_t LaunchDosageRowTotals(const uint64_t *present, const uint32_t *rank, uint32_t rows, uint32_t words,
                                  uint64_t *totals, hipStream_t stream);
-hipError_t LaunchSynthDosageValues(uint16_t *values, uint64_t count, uint64_t seed, hipStream_t stream);
+hipError_t LaunchSynthDosageValues(const uint64_t *present, const uint32_t *rank, const uint64_t *val_off,
+                                   uint16_t *values, uint32_t rows, uint32_t words, uint32_t sample_ct,
+                                   uint32_t variant0, uint64_t seed, hipStream_t stream);
 
 //! PgrGetDCounts (src/plink_freq.cpp:475): per variant {sum of dosages, sum of squares, samples with a
 //! dosage or a call} on the 16384-per-copy scale, over the included samples; hardcalls count as 0 / 16384 / 32768.

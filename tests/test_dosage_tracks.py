@@ -333,3 +333,47 @@ def test_dosage_ingest_across_staging_batches(tmp_path, gpu_lib, oracle):
         assert int(sums[v][0]) == int(dosages[1]) and int(sums[v][2]) * 32768 - int(sums[v][0]) == int(dosages[0]), v
     part = gpu_lib.Dataset.open(prefix + ".pgen", variant_begin=1171, variant_end=2341)
     assert np.array_equal(part.dosage_sums(), sums[1171:2341])
+    # the file-free generator makes the same draws: tracks written to disk and read back = tracks made in HBM
+    twin = gpu_lib.Dataset.synth(0, m, n, 3, 0.02)
+    twin.synth_add_dosage(0.1, 3)
+    assert np.array_equal(twin.dosage_sums(), sums) and np.array_equal(twin.dosage_unpack(vidx=picks), got)
+    assert int(twin.info.dosage_value_ct) == int(ds.info.dosage_value_ct)
+
+
+@pytest.mark.gpu
+def test_wide_dosage_matrix_properties(gpu_lib, monkeypatch):
+    """500,000 samples wide (the BASELINE width), 4,000 variants, synthetic tracks: size-independent properties --
+    shards add up, the unpacked doubles reproduce the integer moments, the two score formulations agree."""
+    n, m, seed = 500_000, 4_000, 20260807
+    whole = gpu_lib.Dataset.synth(0, m, n, seed, 0.02)
+    whole.synth_add_dosage(0.1, seed + 7)
+    sums = whole.dosage_sums()
+    assert int(whole.info.dosage_variant_ct) == m and 0.09 < int(whole.info.dosage_value_ct) / (m * n) < 0.11
+    lo = gpu_lib.Dataset.synth(0, 1500, n, seed, 0.02)
+    hi = gpu_lib.Dataset.synth(1500, m, n, seed, 0.02)
+    lo.synth_add_dosage(0.1, seed + 7)
+    hi.synth_add_dosage(0.1, seed + 7)
+    assert np.array_equal(np.concatenate([lo.dosage_sums(), hi.dosage_sums()]), sums)
+    picks = [0, 1499, 1500, 3999]
+    d = whole.dosage_unpack(vidx=picks)
+    for i, v in enumerate(picks):
+        row = d[i]
+        u = np.rint(row[row != -9.0] * 16384.0).astype(np.uint64)
+        assert (int(u.sum()), int((u * u).sum()), len(u)) == tuple(int(x) for x in sums[v])
+    counts = whole.counts_range()
+    assert np.all(sums[:, 2] >= (counts[:, :3].sum(axis=1)).astype(np.uint64))  # a dosage can stand in for a missing call
+    rng = np.random.default_rng(1)
+    vidx = np.sort(rng.choice(m, size=1000, replace=False))
+    w = rng.standard_normal((len(vidx), 1))
+    for mode in (gpu_lib.SCORE_MEAN_IMPUTE, gpu_lib.SCORE_NO_MEAN_IMPUTATION, gpu_lib.SCORE_CENTER):
+        s2, d2, ac2 = whole.score(vidx, w, mode=mode)
+        monkeypatch.setenv("PGH_SCORE_DOSAGE_LANES", "1")
+        s1, d1, ac1 = whole.score(vidx, w, mode=mode)
+        monkeypatch.delenv("PGH_SCORE_DOSAGE_LANES")
+        assert np.array_equal(ac1, ac2)
+        assert np.allclose(s1, s2, rtol=1e-9, atol=1e-9) and np.allclose(d1, d2, rtol=1e-9, atol=1e-9)
+    # shards' scores add up to the whole's
+    a = lo.score(vidx[vidx < 1500], w[vidx < 1500])
+    b = hi.score(vidx[vidx >= 1500], w[vidx >= 1500])
+    s, dsum, ac = whole.score(vidx, w)
+    assert np.array_equal(a[2] + b[2], ac) and np.allclose(a[0] + b[0], s, rtol=1e-9, atol=1e-9)
