@@ -708,6 +708,30 @@ def test_read_pfile_sample_orient_matrices(oracle):
         assert [(-9.0 if x is None else x) for x in g] == cols[k].tolist()
 
 
+def test_read_pfile_variant_orient_equals_read_pgen_in_every_mode():
+    """read_pfile_genotypes*.test, read_pfile_filter.test, read_pfile_dosage.test, read_pfile_phased.test,
+    read_pfile_pgi.test: variant orient is the read_pgen scan, so every mode and filter gives read_pgen's rows."""
+    for name, extra in (("pgen_example", {}), ("dosage_example", {"dosages": True}), ("phased_example", {"phased": True})):
+        pfx, pgen = data_path(name), data_path(name + ".pgen")
+        for kw in ({}, {"genotypes": "list"}, {"genotypes": "struct"}, {"genotypes": "counts"}, {"genotypes": "stats"},
+                   {"samples": [3, 1]}, {"af_range": {"max": 0.4}}, {"ac_range": {"min": 3}},
+                   {"include_genotypes": ["het"]}, {"genotype_range": {"min": 1, "max": 2}}, {"variants": ["rs3", "rs1"]}):
+            kw = dict(kw)
+            if extra and ("include_genotypes" in kw or "genotype_range" in kw or kw.get("genotypes") in ("counts", "stats")):
+                continue  # incompatible with dosages / phased by the reference's own rules
+            kw.update(extra)
+            a = F.query("read_pfile", pfx, columns=["ID", "genotypes"], **kw)
+            b = F.query("read_pgen", pgen, columns=["ID", "genotypes"], **kw)
+            assert a.types == b.types and sorted(a.rows, key=lambda r: r[0]) == sorted(b.rows, key=lambda r: r[0]), (name, kw)
+        cols = ["ID", "SAMPLE1", "SAMPLE4"]
+        a = F.query("read_pfile", pfx, genotypes="columns", columns=cols, **({"dosages": True} if "dosages" in extra else {}))
+        b = F.query("read_pgen", pgen, genotypes="columns", columns=cols, **({"dosages": True} if "dosages" in extra else {}))
+        assert sorted(a.rows) == sorted(b.rows)
+    split = data_path("pgen_split")
+    a = F.query("read_pfile", split, columns=["ID", "genotypes"])
+    assert len(a) > 0 and sorted(a.rows) == sorted(F.query("read_pgen", split + ".pgen", columns=["ID", "genotypes"]).rows)
+
+
 def test_read_pfile_sample_multifile_values():
     """read_pfile_sample_multifile.test: a sample's row over the shards is its rows over each shard, side by side;
     filters apply per shard and shrink the dimension."""
