@@ -325,6 +325,20 @@ static int AppendDosageTracksHost(pgh_dataset *ds, const pgh::RecordFile &file, 
 	return PGH_OK;
 }
 
+//! Explicit dosages per row, to the host (the score plan picks a kernel per variant by density).
+static int FetchDosageRowCounts(pgh_dataset *ds, char *errbuf) {
+	const uint32_t rows = ds->dos_rows, words = (ds->sample_ct + 63) / 64;
+	DevBuf d_tot;
+	PGH_HIP(d_tot.Alloc(8ull * rows), "hipMalloc(dosage totals)");
+	PGH_HIP(pgh::LaunchDosageRowTotals(ds->d_dos_present, ds->d_dos_rank, rows, words, d_tot.As<uint64_t>(), hipStreamPerThread),
+	        "dosage totals kernel");
+	std::vector<uint64_t> tot(rows);
+	PGH_HIP(hipMemcpyAsync(tot.data(), d_tot.p, 8ull * rows, hipMemcpyDeviceToHost, hipStreamPerThread), "dosage totals copy");
+	PGH_HIP(hipStreamSynchronize(hipStreamPerThread), "dosage totals sync");
+	ds->dos_row_count.assign(tot.begin(), tot.end());
+	return PGH_OK;
+}
+
 // Phase tracks -> two resident bit rows per phased variant (phase.hpp).  Records that go through the device
 // decode are expanded there (LaunchPhaseIngest); host-expanded ones (and files wider than the kernel's LDS
 // tables) through the host parser below.
@@ -766,6 +780,11 @@ extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t va
 			}
 		}
 		ds->dos_values = filled;
+		rc = FetchDosageRowCounts(ds.get(), errbuf);
+		if (rc != PGH_OK) {
+			pgh_close(ds.release());
+			return rc;
+		}
 		lap("dosage tracks");
 	}
 	*out = ds.release();
@@ -925,7 +944,7 @@ extern "C" int pgh_synth_add_dosage(pgh_dataset *ds, double rate, uint64_t seed,
 	PGH_HIP(hipStreamSynchronize(st), "synthetic dosage sync");
 	ds->dos_rows = rows;
 	ds->dos_values = total;
-	return PGH_OK;
+	return FetchDosageRowCounts(ds, errbuf);
 }
 
 extern "C" int pgh_synth_record_host(uint32_t v, uint32_t sample_ct, uint64_t seed, double missing_rate,

@@ -50,6 +50,7 @@ struct pgh_dataset {
 	uint32_t dos_rows = 0;
 	uint64_t dos_values = 0; // explicit dosages held
 	std::vector<int32_t> dos_row_of;
+	std::vector<uint32_t> dos_row_count; // explicit dosages per dosage row (the score plan sorts rows by density)
 	int32_t *d_dos_row_of = nullptr;
 	uint64_t *d_dos_present = nullptr;
 	uint32_t *d_dos_rank = nullptr;

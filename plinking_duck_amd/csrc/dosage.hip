@@ -14,6 +14,8 @@
 #include "device_utils.hpp"
 #include "synth.hpp"
 
+#include <algorithm>
+
 namespace pgh {
 
 namespace {
@@ -694,6 +696,100 @@ __global__ __launch_bounds__(256) void k_score_dosage(const uint8_t *__restrict_
 	}
 }
 
+// Variants whose every sample carries an explicit dosage (densely imputed data): the value run is indexed by
+// the sample itself, no presence bits, ranks or calls are read, and a lane's term is the affine map of its
+// value.  Same shape as k_score_dosage: one lane per sample, eight variants' loads in flight.
+template <int NCOLS>
+__global__ __launch_bounds__(256) void k_score_dosage_full(uint32_t sample_ct, DosageView dos,
+                                                           const uint32_t *__restrict__ vlist, uint32_t n_scored,
+                                                           uint32_t slice_len, const double *__restrict__ weights,
+                                                           uint32_t w_stride, uint32_t n_cols, uint32_t out_stride,
+                                                           const double *__restrict__ lin,
+                                                           const uint32_t *__restrict__ ac, int mode,
+                                                           double *__restrict__ score,
+                                                           double *__restrict__ dosage_sum) {
+	constexpr uint32_t kStage = 64;
+	constexpr uint32_t kGroup = 4;
+	constexpr uint32_t kPer = 4; // samples per lane: one 8-byte load of the value run (2-byte aligned)
+	__shared__ double s_lin[kStage][4];
+	__shared__ double s_w[kStage][NCOLS];
+	__shared__ uint64_t s_vals[kStage];
+	const uint32_t s0 = (blockIdx.x * 256u + threadIdx.x) * kPer;
+	// a lane past the end re-reads the last full group of four (its sums are dropped)
+	const uint32_t s_load = s0 + kPer <= sample_ct ? s0 : (sample_ct >= kPer ? sample_ct - kPer : 0u);
+	const uint32_t i_begin = blockIdx.y * slice_len;
+	const uint32_t i_end = min(i_begin + slice_len, n_scored);
+	double acc[kPer][NCOLS];
+	double dsum[kPer];
+#pragma unroll
+	for (uint32_t q = 0; q < kPer; q++) {
+		dsum[q] = 0.0;
+#pragma unroll
+		for (int c = 0; c < NCOLS; c++) {
+			acc[q][c] = 0.0;
+		}
+	}
+	for (uint32_t base = i_begin; base < i_end; base += kStage) {
+		const uint32_t cnt = min(kStage, i_end - base);
+		__syncthreads();
+		for (uint32_t k = threadIdx.x; k < kStage * 4u; k += 256u) {
+			// a skipped variant (ac == 0) has an all-zero map; entries past the slice likewise
+			s_lin[k >> 2][k & 3] = (k >> 2) < cnt ? lin[4ull * base + k] : 0.0;
+		}
+		for (uint32_t k = threadIdx.x; k < kStage * NCOLS; k += 256u) {
+			const uint32_t c = k % NCOLS, v = k / NCOLS;
+			s_w[v][c] = (v < cnt && c < n_cols) ? weights[static_cast<uint64_t>(base + v) * w_stride + c] : 0.0;
+		}
+		for (uint32_t k = threadIdx.x; k < kStage; k += 256u) {
+			const uint32_t lv = vlist[k < cnt ? base + k : i_begin];
+			s_vals[k] = dos.val_off[dos.row_of[lv]];
+		}
+		__syncthreads();
+		for (uint32_t k0 = 0; k0 < cnt; k0 += kGroup) {
+			uint2 u[kGroup];
+#pragma unroll
+			for (uint32_t j = 0; j < kGroup; j++) {
+				__builtin_memcpy(&u[j], dos.values + s_vals[k0 + j] + s_load, 8);
+			}
+#pragma unroll
+			for (uint32_t j = 0; j < kGroup; j++) {
+				const uint32_t k = k0 + j;
+				const uint32_t v4[kPer] = {u[j].x & 0xffffu, u[j].x >> 16, u[j].y & 0xffffu, u[j].y >> 16};
+#pragma unroll
+				for (uint32_t q = 0; q < kPer; q++) {
+					const double d = static_cast<double>(v4[q]) * 0x1p-14;
+					const double x = ((s_lin[k][0] * d + s_lin[k][1]) - s_lin[k][2]) * s_lin[k][3];
+					dsum[q] += x;
+#pragma unroll
+					for (int c = 0; c < NCOLS; c++) {
+						acc[q][c] = fma(s_w[k][c], x, acc[q][c]);
+					}
+				}
+			}
+		}
+	}
+	(void)ac;
+	if (s0 + kPer <= sample_ct || s0 < sample_ct) {
+#pragma unroll
+		for (uint32_t q = 0; q < kPer; q++) {
+			// lanes that re-read the last group own only the samples at or past s0
+			const uint32_t s = s_load + q;
+			if (s < s0 || s >= sample_ct) {
+				continue;
+			}
+#pragma unroll
+			for (int c = 0; c < NCOLS; c++) {
+				if (static_cast<uint32_t>(c) < n_cols) {
+					unsafeAtomicAdd(score + static_cast<uint64_t>(s) * out_stride + c, acc[q][c]);
+				}
+			}
+			if (dosage_sum && mode != 2) {
+				unsafeAtomicAdd(dosage_sum + s, dsum[q]);
+			}
+		}
+	}
+}
+
 // plink_score's single weight column, the fast way round.  A sample's contribution at a variant is
 //     ts[call]                                   without an explicit dosage,
 //     ts[call] + (affine(dosage) - ts[call])     with one,
@@ -1000,6 +1096,39 @@ hipError_t LaunchScoreDosageFix(const RowView &view, const DosageView &dos, cons
 		hipLaunchKernelGGL(k_score_dosage_fix<false>, dim3(tiles, slices), dim3(1024), 0, stream, view.rows, view.pitch,
 		                   view.sample_ct, dos, vlist, n_scored, slice_len, weights, w_stride, ts, lin, ac, score, out_stride,
 		                   dosage_sum, miss);
+	}
+	return hipGetLastError();
+}
+
+hipError_t LaunchScoreDosageFull(const RowView &view, const DosageView &dos, const uint32_t *vlist, uint32_t n_scored,
+                                 const double *weights, uint32_t w_stride, uint32_t n_cols, const double *lin,
+                                 const uint32_t *ac, int mode, double *score, uint32_t out_stride, double *dosage_sum,
+                                 hipStream_t stream) {
+	if (n_scored == 0 || n_cols == 0) {
+		return hipSuccess;
+	}
+	const uint32_t sample_blocks = (view.sample_ct + 1023) / 1024; // four samples per lane
+	const uint32_t want_slices = (2048 + sample_blocks - 1) / sample_blocks;
+	uint32_t slice_len = (n_scored + want_slices - 1) / want_slices;
+	slice_len = ((slice_len + 63) / 64) * 64;
+	uint32_t slices = (n_scored + slice_len - 1) / slice_len;
+	if (slices > 65535u) {
+		slices = 65535u;
+		slice_len = ((n_scored + slices - 1) / slices + 63) / 64 * 64;
+		slices = (n_scored + slice_len - 1) / slice_len;
+	}
+	for (uint32_t c0 = 0; c0 < n_cols; c0 += 4) {
+		const uint32_t cols = std::min(4u, n_cols - c0);
+		double *dsum = c0 == 0 ? dosage_sum : nullptr;
+		if (cols == 1) {
+			hipLaunchKernelGGL((k_score_dosage_full<1>), dim3(sample_blocks, slices), dim3(256), 0, stream, view.sample_ct, dos,
+			                   vlist, n_scored, slice_len, weights + c0, w_stride, cols, out_stride, lin, ac, mode, score + c0,
+			                   dsum);
+		} else {
+			hipLaunchKernelGGL((k_score_dosage_full<4>), dim3(sample_blocks, slices), dim3(256), 0, stream, view.sample_ct, dos,
+			                   vlist, n_scored, slice_len, weights + c0, w_stride, cols, out_stride, lin, ac, mode, score + c0,
+			                   dsum);
+		}
 	}
 	return hipGetLastError();
 }

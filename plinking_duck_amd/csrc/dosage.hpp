@@ -103,4 +103,11 @@ hipError_t LaunchScoreDosageFix(const RowView &view, const DosageView &dos, cons
                                 const uint32_t *ac, double *score, uint32_t out_stride, double *dosage_sum,
                                 uint32_t *miss, hipStream_t stream);
 
+//! Variants at which EVERY sample has an explicit dosage: contribution = affine map of the sample's value, read
+//! straight from the value run (no presence bits, ranks or calls).  Nobody is missing at such a variant.
+hipError_t LaunchScoreDosageFull(const RowView &view, const DosageView &dos, const uint32_t *vlist, uint32_t n_scored,
+                                 const double *weights, uint32_t w_stride, uint32_t n_cols, const double *lin,
+                                 const uint32_t *ac, int mode, double *score, uint32_t out_stride, double *dosage_sum,
+                                 hipStream_t stream);
+
 } // namespace pgh
