@@ -33,6 +33,7 @@ run_bench samplecounts --workload samplecounts --steps 3 --warmup 1 --cpu-second
 run_bench missingsample --workload missingsample --steps 5 --warmup 1 --cpu-seconds 0
 run_bench dosagefreq --workload dosagefreq --steps 5 --warmup 2 --cpu-seconds 0
 run_bench dosagescore --workload dosagescore --steps 3 --warmup 1 --cpu-seconds 0
+run_bench dosagefull --workload dosagescore --dosage-rate 1.0 --variants 50000 --steps 3 --warmup 1 --cpu-seconds 0
 stats freq --steps 10 --warmup 2
 stats fused --workload fused --steps 5 --warmup 1
 stats unpack --workload unpack --steps 3 --warmup 1
@@ -43,6 +44,7 @@ stats samplecounts --workload samplecounts --steps 2 --warmup 1
 stats missingsample --workload missingsample --steps 3 --warmup 1
 stats dosagefreq --workload dosagefreq --steps 3 --warmup 1
 stats dosagescore --workload dosagescore --steps 2 --warmup 1
+stats dosagefull --workload dosagescore --dosage-rate 1.0 --variants 50000 --steps 2 --warmup 1
 for c in FETCH_SIZE WRITE_SIZE; do
 	pmc freq $c --steps 3 --warmup 1
 	pmc fused $c --workload fused --steps 3 --warmup 1

@@ -37,14 +37,14 @@ def main():
     ap.add_argument("--round", type=int, required=True)
     args = ap.parse_args()
     tag = f"r{args.round:02d}"
-    for name in ("freq", "fused", "unpack", "score", "score1", "pca", "ld", "samplecounts", "missingsample", "dosagefreq", "dosagescore"):
+    for name in ("freq", "fused", "unpack", "score", "score1", "pca", "ld", "samplecounts", "missingsample", "dosagefreq", "dosagescore", "dosagefull"):
         src = os.path.join(SRC, f"bench_{name}.json")
         if os.path.exists(src):
             line = [ln for ln in open(src).read().splitlines() if ln.startswith("{")][-1]
             json.loads(line)
             with open(os.path.join(DST, f"{tag}_bench_{name}_n1.json"), "w") as f:
                 f.write(line + "\n")
-    for name in ("freq", "fused", "unpack", "score", "pca", "ld", "samplecounts", "missingsample", "dosagefreq", "dosagescore"):
+    for name in ("freq", "fused", "unpack", "score", "pca", "ld", "samplecounts", "missingsample", "dosagefreq", "dosagescore", "dosagefull"):
         src = os.path.join(SRC, f"{name}_kernel_stats.csv")
         if os.path.exists(src):
             shutil.copy(src, os.path.join(DST, f"{tag}_{name}_kernel_stats.csv"))
