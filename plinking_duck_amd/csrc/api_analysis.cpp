@@ -465,7 +465,8 @@ struct pgh_score_plan {
 	const pgh_dataset *ds = nullptr;
 	uint32_t n_scored = 0, n_cols = 0;
 	uint32_t n_hard = 0; // the first n_hard entries have hardcalls only; the rest carry dosage tracks:
-	uint32_t n_full = 0; // ... the LAST n_full of them with an explicit dosage for every sample
+	uint32_t n_gaps = 0; // ... then n_gaps whose tracks cover most samples (scored by the sample-owning kernel)
+	uint32_t n_full = 0; // ... and the LAST n_full with an explicit dosage for every sample
 	int mode = 0;
 	void *d_vlist = nullptr, *d_weights = nullptr, *d_flip = nullptr, *d_counts = nullptr, *d_ts = nullptr,
 	     *d_td = nullptr, *d_ac = nullptr, *d_lin = nullptr;
@@ -515,29 +516,29 @@ extern "C" int pgh_score_plan_create(const pgh_dataset *ds, const pgh_subset *su
 	// Variants that carry dosage tracks are scored by their own kernel (dosage.hip); they go to the back
 	// of the list so each kernel sees one contiguous run.  Per-sample sums do not depend on the order.
 	std::vector<uint32_t> order(n_scored);
-	uint32_t n_hard = n_scored, n_full = 0;
+	uint32_t n_hard = n_scored, n_gaps = 0, n_full = 0;
 	if (ds->dos_rows) {
-		// [hardcalls only][dosage tracks with gaps][dosage tracks covering every sample]
+		// [hardcalls only][sparse tracks][tracks covering most samples][tracks covering every sample].  The
+		// explicit-entry kernel costs ~2.2 ps per entry, the sample-owning one ~0.65 us per variant at 500 k
+		// samples: they meet where ~60 % of the samples are explicit.
 		n_hard = 0;
-		auto full = [&](uint32_t i) {
+		auto kind = [&](uint32_t i) { // 0 hardcalls, 1 sparse, 2 mostly explicit, 3 fully explicit
 			const int32_t r = ds->dos_row_of[local[i]];
-			return r >= 0 && ds->dos_row_count[static_cast<uint32_t>(r)] == ds->sample_ct;
+			if (r < 0) {
+				return 0;
+			}
+			const uint64_t have = ds->dos_row_count[static_cast<uint32_t>(r)];
+			return have == ds->sample_ct ? 3 : (have * 5 >= static_cast<uint64_t>(ds->sample_ct) * 3 ? 2 : 1);
 		};
-		for (uint32_t i = 0; i < n_scored; i++) {
-			if (ds->dos_row_of[local[i]] < 0) {
-				order[n_hard++] = i;
-			}
-		}
-		uint32_t at = n_hard;
-		for (uint32_t i = 0; i < n_scored; i++) {
-			if (ds->dos_row_of[local[i]] >= 0 && !full(i)) {
-				order[at++] = i;
-			}
-		}
-		for (uint32_t i = 0; i < n_scored; i++) {
-			if (full(i)) {
-				order[at++] = i;
-				n_full++;
+		uint32_t at = 0;
+		for (int want = 0; want < 4; want++) {
+			for (uint32_t i = 0; i < n_scored; i++) {
+				if (kind(i) == want) {
+					order[at++] = i;
+					n_hard += want == 0;
+					n_gaps += want == 2;
+					n_full += want == 3;
+				}
 			}
 		}
 	} else {
@@ -561,6 +562,7 @@ extern "C" int pgh_score_plan_create(const pgh_dataset *ds, const pgh_subset *su
 	plan->n_scored = n_scored;
 	plan->n_hard = n_hard;
 	plan->n_full = n_full;
+	plan->n_gaps = n_gaps;
 	plan->n_cols = n_cols;
 	plan->mode = mode;
 	if (n_scored) {
@@ -634,15 +636,20 @@ extern "C" int pgh_score_run_dev(const pgh_score_plan *plan, void *d_score_sum, 
 	double *weights = static_cast<double *>(plan->d_weights);
 	double *ts = static_cast<double *>(plan->d_ts);
 	uint32_t *ac = static_cast<uint32_t *>(plan->d_ac);
-	// dosage-bearing variants: n_dos with gaps in their tracks, then n_full without
-	const uint32_t n_hard = plan->n_hard, n_full = plan->n_full, n_dos = plan->n_scored - plan->n_hard - plan->n_full;
+	// dosage-bearing variants: n_dos sparse tracks, n_gaps tracks covering most samples, n_full covering all
+	const uint32_t n_hard = plan->n_hard, n_full = plan->n_full;
+	uint32_t n_gaps = plan->n_gaps, n_dos = plan->n_scored - plan->n_hard - plan->n_full - plan->n_gaps;
 	// Dosage-bearing variants ride the hardcall kernels with their dosage-mean tables (every sample's term is
 	// ts[call], plus (affine(dosage) - ts[call]) where it has an explicit dosage), and k_score_dosage_fix adds
 	// what the explicit entries change, one weight column per launch.  PGH_SCORE_DOSAGE_LANES=1 keeps the
 	// one-lane-per-sample kernel (k_score_dosage) for the dosage-bearing variants instead.
 	const char *lanes_env = std::getenv("PGH_SCORE_DOSAGE_LANES");
 	const bool two_step = !(lanes_env && *lanes_env && *lanes_env != '0');
-	const uint32_t n_table = two_step ? n_hard + n_dos : n_hard;
+	if (!two_step) {
+		n_gaps += n_dos; // the cross-check: every track with gaps through the sample-owning kernel
+		n_dos = 0;
+	}
+	const uint32_t n_table = n_hard + n_dos;
 	const bool track = plan->mode != PGH_SCORE_CENTER && d_dosage_sum != nullptr;
 	if (n_table) {
 		PGH_HIP(pgh::LaunchScoreAccumulate(ds->View(), vlist, n_table, weights, plan->n_cols, ts,
@@ -669,29 +676,29 @@ extern "C" int pgh_score_run_dev(const pgh_score_plan *plan, void *d_score_sum, 
 		}
 	}
 	if (e == hipSuccess && n_dos) {
-		if (two_step) {
-			for (uint32_t c = 0; c < plan->n_cols && e == hipSuccess; c++) {
-				e = pgh::LaunchScoreDosageFix(ds->View(), ds->Dosage(), vlist + n_hard, n_dos,
-				                              weights + static_cast<uint64_t>(n_hard) * plan->n_cols + c, plan->n_cols,
-				                              ts + 4ull * n_hard, static_cast<double *>(plan->d_lin), ac + n_hard,
-				                              static_cast<double *>(d_score_sum) + c, plan->n_cols,
-				                              (track && c == 0) ? static_cast<double *>(d_dosage_sum) : nullptr,
-				                              c == 0 ? static_cast<uint32_t *>(miss) : nullptr, st);
-			}
-		} else {
-			e = pgh::LaunchScoreDosage(ds->View(), ds->Dosage(), vlist + n_hard, n_dos,
-			                           weights + static_cast<uint64_t>(n_hard) * plan->n_cols, plan->n_cols, plan->n_cols,
-			                           ts + 4ull * n_hard, static_cast<double *>(plan->d_lin), ac + n_hard, plan->mode,
-			                           static_cast<double *>(d_score_sum), plan->n_cols,
-			                           static_cast<double *>(d_dosage_sum), static_cast<uint32_t *>(miss), st);
+		for (uint32_t c = 0; c < plan->n_cols && e == hipSuccess; c++) {
+			e = pgh::LaunchScoreDosageFix(ds->View(), ds->Dosage(), vlist + n_hard, n_dos,
+			                              weights + static_cast<uint64_t>(n_hard) * plan->n_cols + c, plan->n_cols,
+			                              ts + 4ull * n_hard, static_cast<double *>(plan->d_lin), ac + n_hard,
+			                              static_cast<double *>(d_score_sum) + c, plan->n_cols,
+			                              (track && c == 0) ? static_cast<double *>(d_dosage_sum) : nullptr,
+			                              c == 0 ? static_cast<uint32_t *>(miss) : nullptr, st);
 		}
+	}
+	if (e == hipSuccess && n_gaps) {
+		const uint32_t at = n_hard + n_dos;
+		e = pgh::LaunchScoreDosage(ds->View(), ds->Dosage(), vlist + at, n_gaps,
+		                           weights + static_cast<uint64_t>(at) * plan->n_cols, plan->n_cols, plan->n_cols,
+		                           ts + 4ull * at, static_cast<double *>(plan->d_lin) + 4ull * n_dos, ac + at, plan->mode,
+		                           static_cast<double *>(d_score_sum), plan->n_cols,
+		                           track ? static_cast<double *>(d_dosage_sum) : nullptr, static_cast<uint32_t *>(miss), st);
 	}
 	if (e == hipSuccess && n_full) {
 		// every sample has a value at these variants: its affine map is the whole term, and nobody is missing
-		const uint32_t at = n_hard + n_dos;
+		const uint32_t at = n_hard + n_dos + n_gaps;
 		e = pgh::LaunchScoreDosageFull(ds->View(), ds->Dosage(), vlist + at, n_full,
 		                               weights + static_cast<uint64_t>(at) * plan->n_cols, plan->n_cols, plan->n_cols,
-		                               static_cast<double *>(plan->d_lin) + 4ull * n_dos, ac + at, plan->mode,
+		                               static_cast<double *>(plan->d_lin) + 4ull * (n_dos + n_gaps), ac + at, plan->mode,
 		                               static_cast<double *>(d_score_sum), plan->n_cols,
 		                               track ? static_cast<double *>(d_dosage_sum) : nullptr, st);
 	}

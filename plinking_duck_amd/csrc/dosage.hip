@@ -578,11 +578,11 @@ __global__ __launch_bounds__(256) void k_score_tables_dosage(const uint64_t *__r
 	ac[i] = inc;
 }
 
-// One lane per sample, a slice of the scored variants per workgroup row (the shape of
-// score.hip:k_score_accumulate); per variant the lane takes its explicit dosage through the
-// affine map, or its call through the code table.  Variants go eight at a time: first every
-// load that does not depend on another (presence word, rank, the 2-bit word), then the eight
-// value loads, then the arithmetic -- the loop is latency-bound otherwise.
+// Sample-owning form for tracks with gaps, at a constant cost per variant whatever its density: a lane owns four
+// consecutive samples (one nibble of a presence word, one byte of the 2-bit row) over a slice of the scored
+// variants.  Its present samples' values are consecutive in the value run -- one 8-byte load at
+// rank + popcount(bits below the nibble) covers them -- and each sample takes its explicit dosage through the
+// affine map or its call through the code table.  Four variants' loads are in flight together.
 template <int NCOLS>
 __global__ __launch_bounds__(256) void k_score_dosage(const uint8_t *__restrict__ rows, uint64_t pitch,
                                                       uint32_t sample_ct, DosageView dos,
@@ -594,7 +594,8 @@ __global__ __launch_bounds__(256) void k_score_dosage(const uint8_t *__restrict_
                                                       double *__restrict__ score, double *__restrict__ dosage_sum,
                                                       uint32_t *__restrict__ miss) {
 	constexpr uint32_t kStage = 64;
-	constexpr uint32_t kGroup = 8;
+	constexpr uint32_t kGroup = 4;
+	constexpr uint32_t kPer = 4;
 	__shared__ double s_ts[kStage][4];
 	__shared__ double s_lin[kStage][4];
 	__shared__ double s_w[kStage][NCOLS];
@@ -603,20 +604,26 @@ __global__ __launch_bounds__(256) void k_score_dosage(const uint8_t *__restrict_
 	__shared__ uint64_t s_vals[kStage]; // where its values start
 	__shared__ uint32_t s_on[kStage];   // ~0: scored and carrying a track; 0 otherwise (presence reads as empty)
 	__shared__ uint32_t s_counts[kStage];
-	const uint32_t s = min(blockIdx.x * 256u + threadIdx.x, sample_ct - 1u);
-	const bool live = blockIdx.x * 256u + threadIdx.x < sample_ct;
-	const uint32_t w = s >> 6, b = s & 63u;
-	const uint64_t below = (1ull << b) - 1ull;
-	const uint32_t shift = 2u * (s & 15u);
+	const uint32_t s0 = (blockIdx.x * 256u + threadIdx.x) * kPer;
+	const bool live = s0 < sample_ct;
+	const uint32_t sl = live ? s0 : 0u; // lanes past the end read sample 0's words and write nothing
+	const uint32_t w = sl >> 6, b0 = sl & 63u;
+	const uint64_t below = (1ull << b0) - 1ull;
+	const uint32_t shift = 2u * (sl & 15u);
 	const uint32_t i_begin = blockIdx.y * slice_len;
 	const uint32_t i_end = min(i_begin + slice_len, n_scored);
-	double acc[NCOLS];
+	double acc[kPer][NCOLS];
+	double dsum[kPer];
+	uint32_t missed[kPer];
 #pragma unroll
-	for (int c = 0; c < NCOLS; c++) {
-		acc[c] = 0.0;
+	for (uint32_t q = 0; q < kPer; q++) {
+		dsum[q] = 0.0;
+		missed[q] = 0;
+#pragma unroll
+		for (int c = 0; c < NCOLS; c++) {
+			acc[q][c] = 0.0;
+		}
 	}
-	double dsum = 0.0;
-	uint32_t missed = 0;
 	for (uint32_t base = i_begin; base < i_end; base += kStage) {
 		const uint32_t cnt = min(kStage, i_end - base);
 		__syncthreads();
@@ -630,7 +637,7 @@ __global__ __launch_bounds__(256) void k_score_dosage(const uint8_t *__restrict_
 			s_w[v][c] = (v < cnt && c < n_cols) ? weights[static_cast<uint64_t>(base + v) * w_stride + c] : 0.0;
 		}
 		for (uint32_t k = threadIdx.x; k < kStage; k += 256u) {
-			// entries past the slice read variant 0 with empty tables: they add nothing
+			// entries past the slice read the slice's first variant with empty tables: they add nothing
 			const uint32_t lv = k < cnt ? vlist[base + k] : vlist[i_begin];
 			const int32_t r = k < cnt ? dos.row_of[lv] : -1;
 			const uint32_t on = k < cnt ? ac[base + k] : 0u;
@@ -641,57 +648,72 @@ __global__ __launch_bounds__(256) void k_score_dosage(const uint8_t *__restrict_
 			s_counts[k] = on != 0u;
 		}
 		__syncthreads();
-		for (uint32_t k0 = 0; k0 < kStage && k0 < cnt; k0 += kGroup) {
-			uint64_t bits[kGroup];
-			uint32_t rk[kGroup], word[kGroup], u[kGroup];
+		for (uint32_t k0 = 0; k0 < cnt; k0 += kGroup) {
+			uint64_t bits[kGroup], vals[kGroup];
+			uint32_t word[kGroup];
 #pragma unroll
 			for (uint32_t j = 0; j < kGroup; j++) {
 				const uint32_t k = k0 + j;
 				bits[j] = dos.present[s_bits[k] + w];
-				rk[j] = dos.rank[s_bits[k] + w];
-				word[j] = reinterpret_cast<const uint32_t *>(rows + s_row[k])[s >> 4];
+				word[j] = reinterpret_cast<const uint32_t *>(rows + s_row[k])[sl >> 4];
 			}
 #pragma unroll
 			for (uint32_t j = 0; j < kGroup; j++) {
 				const uint32_t k = k0 + j;
 				bits[j] &= static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(s_on[k]))); // all ones or zero
-				u[j] = 0;
-				if ((bits[j] >> b) & 1ull) {
-					u[j] = dos.values[s_vals[k] + rk[j] + static_cast<uint32_t>(__popcll(bits[j] & below))];
+				vals[j] = 0;
+				if ((bits[j] >> b0) & 0xfull) {
+					const uint32_t idx = dos.rank[s_bits[k] + w] + static_cast<uint32_t>(__popcll(bits[j] & below));
+					__builtin_memcpy(&vals[j], dos.values + s_vals[k] + idx, 8); // up to four values; the run is padded
 				}
 			}
 #pragma unroll
 			for (uint32_t j = 0; j < kGroup; j++) {
 				const uint32_t k = k0 + j;
-				const uint32_t g = (word[j] >> shift) & 3u;
-				double x;
-				if ((bits[j] >> b) & 1ull) {
-					const double d = static_cast<double>(u[j]) * 0x1p-14;
-					x = ((s_lin[k][0] * d + s_lin[k][1]) - s_lin[k][2]) * s_lin[k][3];
-				} else {
-					x = s_ts[k][g];
-					missed += (g == 3u) & s_counts[k];
-				}
-				dsum += x;
+				const uint32_t nib = static_cast<uint32_t>(bits[j] >> b0) & 0xfu;
+				const uint32_t codes = word[j] >> shift;
+				uint64_t run = vals[j];
 #pragma unroll
-				for (int c = 0; c < NCOLS; c++) {
-					acc[c] = fma(s_w[k][c], x, acc[c]);
+				for (uint32_t q = 0; q < kPer; q++) {
+					double x;
+					if ((nib >> q) & 1u) {
+						const double d = static_cast<double>(static_cast<uint32_t>(run) & 0xffffu) * 0x1p-14;
+						run >>= 16;
+						x = ((s_lin[k][0] * d + s_lin[k][1]) - s_lin[k][2]) * s_lin[k][3];
+					} else {
+						const uint32_t g = (codes >> (2u * q)) & 3u;
+						x = s_ts[k][g];
+						missed[q] += (g == 3u) & s_counts[k];
+					}
+					dsum[q] += x;
+#pragma unroll
+					for (int c = 0; c < NCOLS; c++) {
+						acc[q][c] = fma(s_w[k][c], x, acc[q][c]);
+					}
 				}
 			}
 		}
 	}
-	if (live) {
+	if (!live) {
+		return;
+	}
+#pragma unroll
+	for (uint32_t q = 0; q < kPer; q++) {
+		const uint32_t s = s0 + q;
+		if (s >= sample_ct) {
+			break;
+		}
 #pragma unroll
 		for (int c = 0; c < NCOLS; c++) {
 			if (static_cast<uint32_t>(c) < n_cols) {
-				unsafeAtomicAdd(score + static_cast<uint64_t>(s) * out_stride + c, acc[c]);
+				unsafeAtomicAdd(score + static_cast<uint64_t>(s) * out_stride + c, acc[q][c]);
 			}
 		}
 		if (dosage_sum && mode != 2) {
-			unsafeAtomicAdd(dosage_sum + s, dsum);
+			unsafeAtomicAdd(dosage_sum + s, dsum[q]);
 		}
-		if (miss && missed) {
-			atomicAdd(miss + s, missed);
+		if (miss && missed[q]) {
+			atomicAdd(miss + s, missed[q]);
 		}
 	}
 }
@@ -1040,14 +1062,15 @@ hipError_t LaunchScoreDosage(const RowView &view, const DosageView &dos, const u
 	if (n_scored == 0 || n_cols == 0) {
 		return hipSuccess;
 	}
-	const uint32_t sample_blocks = (view.sample_ct + 255) / 256;
+	const uint32_t sample_blocks = (view.sample_ct + 1023) / 1024; // four samples per lane
 	const uint32_t want_slices = (2048 + sample_blocks - 1) / sample_blocks;
 	uint32_t slice_len = (n_scored + want_slices - 1) / want_slices;
 	slice_len = ((slice_len + 63) / 64) * 64;
 	uint32_t slices = (n_scored + slice_len - 1) / slice_len;
 	if (slices > 65535u) {
 		slices = 65535u;
-		slice_len = (n_scored + slices - 1) / slices;
+		slice_len = ((n_scored + slices - 1) / slices + 63) / 64 * 64;
+		slices = (n_scored + slice_len - 1) / slice_len;
 	}
 	// weight columns four at a time; the dosage sum and the missing tally ride with the first pass
 	for (uint32_t c0 = 0; c0 < n_cols; c0 += 4) {
