@@ -519,8 +519,8 @@ extern "C" int pgh_score_plan_create(const pgh_dataset *ds, const pgh_subset *su
 	uint32_t n_hard = n_scored, n_gaps = 0, n_full = 0;
 	if (ds->dos_rows) {
 		// [hardcalls only][sparse tracks][tracks covering most samples][tracks covering every sample].  The
-		// explicit-entry kernel costs ~2.2 ps per entry, the sample-owning one ~0.65 us per variant at 500 k
-		// samples: they meet where ~60 % of the samples are explicit.
+		// explicit-entry kernel costs ~2.2 ps per entry, the sample-owning one ~0.5 us per variant at 500 k
+		// samples: they meet where ~40 % of the samples are explicit.
 		n_hard = 0;
 		auto kind = [&](uint32_t i) { // 0 hardcalls, 1 sparse, 2 mostly explicit, 3 fully explicit
 			const int32_t r = ds->dos_row_of[local[i]];
@@ -528,7 +528,7 @@ extern "C" int pgh_score_plan_create(const pgh_dataset *ds, const pgh_subset *su
 				return 0;
 			}
 			const uint64_t have = ds->dos_row_count[static_cast<uint32_t>(r)];
-			return have == ds->sample_ct ? 3 : (have * 5 >= static_cast<uint64_t>(ds->sample_ct) * 3 ? 2 : 1);
+			return have == ds->sample_ct ? 3 : (have * 5 >= static_cast<uint64_t>(ds->sample_ct) * 2 ? 2 : 1);
 		};
 		uint32_t at = 0;
 		for (int want = 0; want < 4; want++) {

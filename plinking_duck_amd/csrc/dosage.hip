@@ -582,7 +582,8 @@ __global__ __launch_bounds__(256) void k_score_tables_dosage(const uint64_t *__r
 // consecutive samples (one nibble of a presence word, one byte of the 2-bit row) over a slice of the scored
 // variants.  Its present samples' values are consecutive in the value run -- one 8-byte load at
 // rank + popcount(bits below the nibble) covers them -- and each sample takes its explicit dosage through the
-// affine map or its call through the code table.  Four variants' loads are in flight together.
+// affine map or its call through the code table.  Two variants' loads are in flight together (more costs
+// occupancy: 82 VGPRs at two, 102 at four).
 template <int NCOLS>
 __global__ __launch_bounds__(256) void k_score_dosage(const uint8_t *__restrict__ rows, uint64_t pitch,
                                                       uint32_t sample_ct, DosageView dos,
@@ -594,7 +595,7 @@ __global__ __launch_bounds__(256) void k_score_dosage(const uint8_t *__restrict_
                                                       double *__restrict__ score, double *__restrict__ dosage_sum,
                                                       uint32_t *__restrict__ miss) {
 	constexpr uint32_t kStage = 64;
-	constexpr uint32_t kGroup = 4;
+	constexpr uint32_t kGroup = 2;
 	constexpr uint32_t kPer = 4;
 	__shared__ double s_ts[kStage][4];
 	__shared__ double s_lin[kStage][4];
@@ -650,11 +651,12 @@ __global__ __launch_bounds__(256) void k_score_dosage(const uint8_t *__restrict_
 		__syncthreads();
 		for (uint32_t k0 = 0; k0 < cnt; k0 += kGroup) {
 			uint64_t bits[kGroup], vals[kGroup];
-			uint32_t word[kGroup];
+			uint32_t word[kGroup], rk[kGroup];
 #pragma unroll
 			for (uint32_t j = 0; j < kGroup; j++) {
 				const uint32_t k = k0 + j;
 				bits[j] = dos.present[s_bits[k] + w];
+				rk[j] = dos.rank[s_bits[k] + w]; // with the bits, not behind them: one dependent load fewer
 				word[j] = reinterpret_cast<const uint32_t *>(rows + s_row[k])[sl >> 4];
 			}
 #pragma unroll
@@ -663,7 +665,7 @@ __global__ __launch_bounds__(256) void k_score_dosage(const uint8_t *__restrict_
 				bits[j] &= static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(s_on[k]))); // all ones or zero
 				vals[j] = 0;
 				if ((bits[j] >> b0) & 0xfull) {
-					const uint32_t idx = dos.rank[s_bits[k] + w] + static_cast<uint32_t>(__popcll(bits[j] & below));
+					const uint32_t idx = rk[j] + static_cast<uint32_t>(__popcll(bits[j] & below));
 					__builtin_memcpy(&vals[j], dos.values + s_vals[k] + idx, 8); // up to four values; the run is padded
 				}
 			}
