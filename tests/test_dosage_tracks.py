@@ -377,3 +377,34 @@ def test_wide_dosage_matrix_properties(gpu_lib, monkeypatch):
     b = hi.score(vidx[vidx >= 1500], w[vidx >= 1500])
     s, dsum, ac = whole.score(vidx, w)
     assert np.array_equal(a[2] + b[2], ac) and np.allclose(a[0] + b[0], s, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_phase_and_dosage_tracks_beyond_64kb_of_lds(tmp_path, gpu_lib, oracle):
+    """600,000 samples: the phase kernel's two per-word prefix tables need 75 KB of LDS (an opt-in above 64 KB),
+    sample ids in difflists and dosage lists are three bytes wide."""
+    n, m = 600_000, 6
+    rng = np.random.default_rng(5)
+    geno = rng.choice(4, size=(m, n), p=[0.55, 0.3, 0.1, 0.05]).astype(np.uint8)
+    geno[3] = 0
+    geno[3, rng.choice(n, 500, replace=False)] = 1  # a sparse row: type 4 with a multi-group difflist
+    kinds = [0, 1, 0, 4, 0, 6]
+    dos = np.full((m, n), 0xFFFF, dtype=np.uint16)
+    dkinds = [0x60, 0x20, 0x40, 0, 0x60, 0x20]
+    for v, k in enumerate(dkinds):
+        if k:
+            hit = rng.random(n) < (0.01 if k == 0x20 else 0.3)
+            dos[v, hit] = rng.integers(0, 32769, int(hit.sum()), dtype=np.uint16)
+    path = str(tmp_path / "big.pgen")
+    W.write_pgen(path, geno, kinds, dosage=dos, dosage_kinds=dkinds, phase_rng=np.random.default_rng(6))
+    pg = oracle.Pgen(path)
+    ds = gpu_lib.Dataset.open(path)
+    want = np.where(dos != 0xFFFF, dos.astype(np.float64) / 16384.0, np.where(geno == 3, -9.0, geno.astype(np.float64)))
+    assert np.array_equal(ds.dosage_unpack(), want)
+    rd = ds.reader()
+    for v in range(m):
+        g, pp, pi = rd.get_phased(v)
+        eg, epp, epi = pg.phase(v)
+        assert np.array_equal(_bits(pp, n), epp != 0), v
+        assert np.array_equal(_bits(pi, n) & _bits(pp, n), (epi != 0) & (epp != 0)), v
+    assert np.array_equal(ds.counts_range(), np.stack([pg.counts(v) for v in range(m)]))
