@@ -408,3 +408,12 @@ def test_phase_and_dosage_tracks_beyond_64kb_of_lds(tmp_path, gpu_lib, oracle):
         assert np.array_equal(_bits(pp, n), epp != 0), v
         assert np.array_equal(_bits(pi, n) & _bits(pp, n), (epi != 0) & (epp != 0)), v
     assert np.array_equal(ds.counts_range(), np.stack([pg.counts(v) for v in range(m)]))
+    # the column-owning kernels and the score at this width
+    g = np.stack([pg.geno(v) for v in range(m)])
+    sc = ds.sample_counts()
+    assert np.array_equal(sc[:, 1], (g == 1).sum(axis=0)) and np.array_equal(sc[:, 2], (g == 2).sum(axis=0))
+    assert np.array_equal(sc[:, 3], (g == -9).sum(axis=0)) and np.array_equal(ds.missing_per_sample(), (g == -9).sum(axis=0))
+    w = rng.standard_normal((m, 1))
+    s_, d_, ac_ = ds.score(np.arange(m), w)
+    es, ed, eac = oracle.score(pg, np.arange(m), w)
+    assert np.array_equal(ac_, eac) and np.allclose(s_, es, rtol=1e-11, atol=1e-11) and np.allclose(d_, ed, rtol=1e-11, atol=1e-11)
