@@ -289,7 +289,9 @@ def main():
                 if dist is not None:
                     dist.reduce(d_score, dst=0)
 
-            kernel_name = ("k_score_dosage_full" if args.dosage_rate >= 1.0 else "k_score_gemv_pairs + k_score_dosage_fix")
+            # the plan picks the kernel by track density (api_analysis.cpp): all samples explicit, >= 40 %, below
+            kernel_name = ("k_score_dosage_full" if args.dosage_rate >= 1.0 else
+                           "k_score_dosage" if args.dosage_rate >= 0.42 else "k_score_gemv_pairs + k_score_dosage_fix")
             metric = "plink_score(dosage) genotypes/s"
     elif args.workload == "missingsample":
         # plink_missing mode := 'sample': per-sample missing tallies over every variant (column sums)

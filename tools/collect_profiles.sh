@@ -34,6 +34,7 @@ run_bench missingsample --workload missingsample --steps 5 --warmup 1 --cpu-seco
 run_bench dosagefreq --workload dosagefreq --steps 5 --warmup 2 --cpu-seconds 0
 run_bench dosagescore --workload dosagescore --steps 3 --warmup 1 --cpu-seconds 0
 run_bench dosagefull --workload dosagescore --dosage-rate 1.0 --variants 50000 --steps 3 --warmup 1 --cpu-seconds 0
+run_bench dosagegaps --workload dosagescore --dosage-rate 0.8 --variants 50000 --steps 3 --warmup 1 --cpu-seconds 0
 stats freq --steps 10 --warmup 2
 stats fused --workload fused --steps 5 --warmup 1
 stats unpack --workload unpack --steps 3 --warmup 1

@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--round", type=int, required=True)
     args = ap.parse_args()
     tag = f"r{args.round:02d}"
-    for name in ("freq", "fused", "unpack", "score", "score1", "pca", "ld", "samplecounts", "missingsample", "dosagefreq", "dosagescore", "dosagefull"):
+    for name in ("freq", "fused", "unpack", "score", "score1", "pca", "ld", "samplecounts", "missingsample", "dosagefreq", "dosagescore", "dosagefull", "dosagegaps"):
         src = os.path.join(SRC, f"bench_{name}.json")
         if os.path.exists(src):
             line = [ln for ln in open(src).read().splitlines() if ln.startswith("{")][-1]
