@@ -675,18 +675,16 @@ __global__ __launch_bounds__(256) void k_score_dosage(const uint8_t *__restrict_
 				const uint32_t nib = static_cast<uint32_t>(bits[j] >> b0) & 0xfu;
 				const uint32_t codes = word[j] >> shift;
 				uint64_t run = vals[j];
+				const double l0 = s_lin[k][0], l1 = s_lin[k][1], l2 = s_lin[k][2], l3 = s_lin[k][3];
 #pragma unroll
 				for (uint32_t q = 0; q < kPer; q++) {
-					double x;
-					if ((nib >> q) & 1u) {
-						const double d = static_cast<double>(static_cast<uint32_t>(run) & 0xffffu) * 0x1p-14;
-						run >>= 16;
-						x = ((s_lin[k][0] * d + s_lin[k][1]) - s_lin[k][2]) * s_lin[k][3];
-					} else {
-						const uint32_t g = (codes >> (2u * q)) & 3u;
-						x = s_ts[k][g];
-						missed[q] += (g == 3u) & s_counts[k];
-					}
+					// both candidates, then a select: no divergent branch per sample
+					const bool has = (nib >> q) & 1u;
+					const double d = static_cast<double>(static_cast<uint32_t>(run) & 0xffffu) * 0x1p-14;
+					run >>= has ? 16u : 0u;
+					const uint32_t g = (codes >> (2u * q)) & 3u;
+					const double x = has ? ((l0 * d + l1) - l2) * l3 : s_ts[k][g];
+					missed[q] += (!has && g == 3u) ? s_counts[k] : 0u;
 					dsum[q] += x;
 #pragma unroll
 					for (int c = 0; c < NCOLS; c++) {
