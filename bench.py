@@ -12,7 +12,19 @@ before the timed region (seeded counter-based generator).
 
 N > 1: one process per GPU (torch.distributed, backend nccl == RCCL), variants
 sharded across ranks, no data-path collective for plink_freq (SURVEY.md 8e);
-only the timing barrier / max-over-ranks uses the process group.
+only the timing barrier / max-over-ranks uses the process group.  Under
+`python -m torch.distributed.run` the ranks are the launcher's; started bare
+(`python bench.py --gpus N`, no WORLD_SIZE) this process touches no GPU and
+starts the N rank processes itself, relays rank 0's JSON line and exits non-zero
+if the node has fewer than N GPUs or any rank fails.  The default is STRONG
+scaling: --variants is the whole matrix (the north star's fixed 1 M x 500 k
+file) split into N contiguous ranges; --scaling weak gives every rank its own
+--variants rows.
+
+After the timed region the last step's host-side results are checked (rows tally
+to N, sampled rows equal a host recomputation from the seeded generator, the
+fused pass's per-sample missing counts add up to the per-variant ones) and the
+line carries "verified": true; a failed check exits non-zero without a line.
 
 Prints ONE JSON line on rank 0 (see the driver contract), including
   "roofline":     algorithmic HBM bytes of the tally kernel / its mean launch
@@ -47,13 +59,15 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--variants", type=int, default=1_000_000, help="variants per rank (weak) or in total (strong)")
+    ap.add_argument("--variants", type=int, default=1_000_000, help="variants in total (strong scaling, the default) or per rank (weak)")
     ap.add_argument("--samples", type=int, default=500_000)
     ap.add_argument("--ld-variants", type=int, default=20000, help="anchors of the ld workload")
     ap.add_argument("--ld-window", type=int, default=64, help="partners per anchor of the ld workload")
     ap.add_argument("--workload", choices=["freq", "fused", "unpack", "score", "pca", "ld", "samplecounts", "missingsample", "dosagefreq", "dosagescore"], default="freq")
     ap.add_argument("--n-pcs", type=int, default=10)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="strong (default): --variants is the whole matrix, split across the GPUs; "
+                         "weak: every GPU holds --variants rows of its own")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 disables)")
     ap.add_argument("--cpu-sample-variants", type=int, default=8192)
     ap.add_argument("--dosage-rate", type=float, default=0.1,
@@ -115,8 +129,144 @@ def load_traffic(workload, variants, samples):
     return None
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks as fresh child processes.
+    This process has not imported torch or touched HIP (a process that has initialised the GPU must
+    not be re-executed), and it does not: the device count comes from a probe child."""
+    import signal
+    import socket
+    import subprocess
+
+    probe = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                           capture_output=True, text=True)
+    try:
+        have = int(probe.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        raise SystemExit(f"bench.py: could not count the GPUs of this node: {probe.stderr.strip()[-300:]}")
+    if have < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but this node has {have} GPU(s); "
+                         f"no line is reported for a rank count that was not run")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    children = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                         start_new_session=True))
+    rc = 0
+    pending = list(children)
+    while pending and rc == 0:
+        for c in list(pending):
+            try:
+                code = c.wait(timeout=0.2)
+            except subprocess.TimeoutExpired:
+                continue
+            pending.remove(c)
+            if code != 0:
+                rc = code
+    for c in pending:  # a rank failed: the others would wait in a collective forever
+        try:
+            os.killpg(c.pid, signal.SIGTERM)
+        except ProcessLookupError:
+            pass
+    for c in pending:
+        try:
+            c.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            os.killpg(c.pid, signal.SIGKILL)
+    if rc != 0:
+        raise SystemExit(f"bench.py: a rank exited with status {rc}; no line reported")
+
+
+def host_tallies(np, rec, n):
+    """{hom_ref, het, hom_alt, missing} of one packed 2-bit record, recomputed on the host with numpy."""
+    codes = (rec[:, None] >> np.array([0, 2, 4, 6], dtype=np.uint8)) & 3
+    return np.bincount(codes.reshape(-1)[:n], minlength=4).astype(np.int64), codes.reshape(-1)[:n]
+
+
+def verify(args, L, np, torch, ds, env):
+    """Size-independent checks on the LAST timed step's results (the timed region has ended and was
+    synchronised).  True / False, or None for a workload without a check."""
+    n, m = env["n"], env["m"]
+    v_begin = env["v_begin"]
+    if m == 0:
+        return True
+    picks = sorted({0, m // 2, m - 1})
+    wl = args.workload
+    if wl in ("freq", "fused"):
+        hc = env["h_counts"].numpy().astype(np.int64)
+        if not np.array_equal(hc.sum(axis=1), np.full(m, n)):
+            print("verify: rows do not tally to N", file=sys.stderr)
+            return False
+        obs = hc[:, :3].sum(axis=1)
+        af = (hc[:, 1] + 2 * hc[:, 2]) / np.where(obs > 0, 2.0 * obs, np.nan)
+        hf = env["h_freq"].numpy()
+        if not (np.array_equal(env["h_obs"].numpy(), 2 * obs) and np.array_equal(hf[obs > 0], af[obs > 0])):
+            print("verify: ALT_FREQ / OBS_CT differ from the host arithmetic on the tallies", file=sys.stderr)
+            return False
+        for r in picks:
+            want, _ = host_tallies(np, L.synth_record_host(v_begin + r, n, SEED, MISSING_RATE), n)
+            if not np.array_equal(want, hc[r]):
+                print(f"verify: variant {v_begin + r}: {hc[r]} != host {want}", file=sys.stderr)
+                return False
+        if wl == "fused":
+            if int(env["h_miss"].numpy().astype(np.int64).sum()) != int(hc[:, 3].sum()):
+                print("verify: per-sample missing counts do not add up to the per-variant ones", file=sys.stderr)
+                return False
+        return True
+    if wl == "unpack":
+        chunk = env["chunk"]
+        last0 = (m - 1) // chunk * chunk  # the rows of the last launch
+        out = env["d_out"]
+        val = env["d_val"]
+        for r in sorted({last0, m - 1}):
+            _, codes = host_tallies(np, L.synth_record_host(v_begin + r, n, SEED, MISSING_RATE), n)
+            got = out[r - last0, :n].cpu().numpy()
+            want = np.where(codes == 3, 0, codes).astype(np.int8)
+            bits = np.unpackbits(val[r - last0].cpu().numpy().view(np.uint8), bitorder="little")[:n]
+            if not (np.array_equal(got, want) and np.array_equal(bits, (codes != 3).astype(np.uint8))):
+                print(f"verify: unpacked variant {v_begin + r} differs from the host decode", file=sys.stderr)
+                return False
+        return True
+    if wl in ("missingsample", "samplecounts"):
+        hc = ds.counts_range().astype(np.int64)
+        if wl == "missingsample":
+            ok = int(env["d_miss"][:n].cpu().numpy().astype(np.int64).sum()) == int(hc[:, 3].sum())
+        else:
+            cls = env["d_cls"][:, :n].cpu().numpy().astype(np.int64).sum(axis=1)
+            ok = np.array_equal(cls, hc[:, 1:4].sum(axis=0))
+        if not ok:
+            print("verify: per-sample tallies do not add up to the per-variant ones", file=sys.stderr)
+        return bool(ok)
+    if wl == "score":
+        # checksum of checksums: the column sums over samples of SCORE_SUM follow from the per-variant tallies
+        # (mean imputation: a missing call contributes the variant's mean dosage, src/plink_score.cpp:598-631)
+        hc = ds.counts_range().astype(np.float64)
+        nonmiss = hc[:, :3].sum(axis=1)
+        alt = hc[:, 1] + 2 * hc[:, 2]
+        mean = np.where(nonmiss > 0, alt / np.maximum(nonmiss, 1), 0.0)
+        per_variant = np.where(nonmiss > 0, alt + hc[:, 3] * mean, 0.0)
+        want = per_variant @ env["w"]
+        got = env["d_score"].cpu().numpy().sum(axis=0)
+        if env["dist"] is not None:
+            return None  # rank 0 holds the reduced sums of every shard; the single-GPU line carries the check
+        scale = np.abs(per_variant[:, None] * env["w"]).sum(axis=0)
+        ok = bool(np.all(np.abs(got - want) <= 1e-9 * scale))
+        if not ok:
+            print(f"verify: score column sums {got} != {want} from the tallies", file=sys.stderr)
+        return ok
+    return None
+
+
 def main():
     args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
     import numpy as np
     import torch
 
@@ -126,10 +276,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but {world} rank(s) were launched (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank} but this node has {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
     L.set_device(local_rank)
     dist = None
@@ -451,6 +603,15 @@ def main():
     if dist is not None:
         elapsed = sharding.max_over_ranks(dist, elapsed, dev)
 
+    verified = verify(args, L, np, torch, ds, locals())
+    if dist is not None:
+        ok = torch.tensor([0 if verified is False else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            verified = False
+    if verified is False:
+        raise SystemExit("bench.py: the last step's results failed verification; no line reported")
+
     kernel_ms = [a.elapsed_time(b) for a, b in kernel_events]
     kern_avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
     total_units = sharding.total_variants(world, args.variants, args.scaling) * n
@@ -488,6 +649,7 @@ def main():
             "vs_baseline": None,
             "dtype": dtype,
             "data": "synthetic",
+            "verified": verified,
             "config": {
                 "workload": f"{args.workload}: {args.variants} variants x {n} samples "
                             f"({'per GPU' if args.scaling == 'weak' else 'total'}), 2-bit hardcalls resident in HBM, "

@@ -272,11 +272,15 @@ int pgh_sample_counts_dev(const pgh_dataset *ds, uint32_t variant_begin, uint32_
  * windowed scan's order) read the anchor row once per four partners. */
 int pgh_ld_pairs(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_pairs, const uint32_t *vidx_a,
                  const uint32_t *vidx_b, uint32_t (*sums)[6], char *errbuf);
-/* Device-output form: sums land in d_sums (uint32[n_pairs][6]), computed on `stream`; vidx_a / vidx_b stay
- * host arrays.  The task list built from them goes up through the calling thread's own pinned staging buffer,
- * stream-ordered; a thread's next call waits for this one's kernel before it reuses that buffer. */
+/* Device-output form: sums land in d_sums (uint32[n_pairs][6], zeroed by the call), computed on `stream`;
+ * vidx_a / vidx_b stay host arrays.  The task list built from them goes up through the calling thread's own
+ * pinned staging buffer, stream-ordered; a thread's next call waits for this one's kernel before it reuses
+ * that buffer.  The kernel refuses a task the host cannot have built (no partners, rows outside the resident
+ * matrix) and reports it: pgh_ld_pairs_status -- and the thread's next pgh_ld_pairs(_dev) call, and
+ * pgh_ld_pairs itself -- wait for the launch and return PGH_ERR_DEVICE if that happened. */
 int pgh_ld_pairs_dev(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_pairs, const uint32_t *vidx_a,
                      const uint32_t *vidx_b, void *d_sums, void *stream, char *errbuf);
+int pgh_ld_pairs_status(char *errbuf);
 
 /* plink_pca's randomized subspace iteration (src/plink_pca.cpp:630-1080): n_pcs + 1
  * passes of Y = X G1 (Step A) and G1 = X^T Y / M (Step B) over the n_var effective

@@ -173,6 +173,7 @@ extern "C" int pgh_sample_counts(const pgh_dataset *ds, const pgh_subset *subset
 	const uint32_t padded = (N + 63) / 64 * 64;
 	hipStream_t st = hipStreamPerThread;
 	DevBuf d_cls, d_list, d_scratch;
+	HostSourceFence fence(st); // `local` feeds an asynchronous upload
 	PGH_HIP(d_cls.Alloc(sizeof(uint32_t) * 3ull * padded), "hipMalloc(sample counts)");
 	PGH_HIP(d_scratch.Alloc(pgh::ClassCounts3ScratchBytes(ds->record_bytes)), "hipMalloc(sample counts)");
 	if (vidx && n_var) {
@@ -283,6 +284,7 @@ extern "C" int pgh_unpack_range(const pgh_dataset *ds, const pgh_subset *subset,
 // ---------------------------------------------------------------------------
 
 //! Local variant indices of [v_begin, v_begin + n) or of vidx[0..n) on the device; NULL when the run is contiguous.
+//! `local` is the upload's (pageable) source: the caller keeps it alive behind a HostSourceFence on `st`.
 static int UploadVariantList(const pgh_dataset *ds, uint32_t v_begin, uint32_t n, const uint32_t *vidx, DevBuf &d_list,
                              hipStream_t st, std::vector<uint32_t> &local, char *errbuf) {
 	if (!vidx) {
@@ -334,6 +336,7 @@ extern "C" int pgh_dosage_sums(const pgh_dataset *ds, const pgh_subset *subset, 
 	hipStream_t st = hipStreamPerThread;
 	DevBuf d_list, d_sums;
 	std::vector<uint32_t> local;
+	HostSourceFence fence(st); // `local` feeds an asynchronous upload
 	rc = UploadVariantList(ds, variant_begin, n_variants, vidx, d_list, st, local, errbuf);
 	if (rc != PGH_OK) {
 		return rc;
@@ -382,6 +385,7 @@ extern "C" int pgh_dosage_unpack(const pgh_dataset *ds, const pgh_subset *subset
 	hipStream_t st = hipStreamPerThread;
 	DevBuf d_list, d_out;
 	std::vector<uint32_t> local;
+	HostSourceFence fence(st); // `local` feeds an asynchronous upload
 	rc = UploadVariantList(ds, variant_begin, n_variants, vidx, d_list, st, local, errbuf);
 	if (rc != PGH_OK) {
 		return rc;
@@ -419,6 +423,7 @@ static int UnpackSamples(const pgh_dataset *ds, const pgh_subset *subset, uint32
 	hipStream_t st = hipStreamPerThread;
 	DevBuf d_list, d_out;
 	std::vector<uint32_t> local;
+	HostSourceFence fence(st); // `local` feeds an asynchronous upload
 	rc = UploadVariantList(ds, 0, n_variants, vidx, d_list, st, local, errbuf);
 	if (rc != PGH_OK) {
 		return rc;
@@ -569,6 +574,7 @@ extern "C" int pgh_score_plan_create(const pgh_dataset *ds, const pgh_subset *su
 		const uint32_t N = ds->sample_ct;
 		const uint32_t n_dos = n_scored - n_hard;
 		hipStream_t st = hipStreamPerThread;
+		HostSourceFence fence(st); // p_local / p_weights / p_flip feed asynchronous uploads
 		PGH_HIP(hipMalloc(&plan->d_vlist, sizeof(uint32_t) * n_scored), "hipMalloc(score)");
 		PGH_HIP(hipMalloc(&plan->d_weights, sizeof(double) * n_scored * n_cols), "hipMalloc(score)");
 		PGH_HIP(hipMalloc(&plan->d_counts, 24ull * n_scored), "hipMalloc(score)"); // counts[4] u32, or dosage sums[3] u64
@@ -899,6 +905,7 @@ extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, 
 		PGH_HIP(d_tmp.Alloc(sizeof(double) * m_alloc * k2), "hipMalloc(pca)");
 		double *q = d_qq.As<double>();
 		std::vector<double> g(static_cast<size_t>(k2) * k2), lam, vec, t(static_cast<size_t>(k2) * k2);
+		HostSourceFence fence(st); // `t` feeds an asynchronous upload
 		for (uint32_t p = 0; p <= n_pcs; p++) {
 			double *bp = q + static_cast<size_t>(p) * k2;
 			const uint32_t prev = p * k2;
@@ -975,6 +982,7 @@ extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, 
 		}
 		pgh::SymmetricEigen(g, qq, lam, vec);
 		std::vector<double> vk(static_cast<size_t>(qq) * n_pcs);
+		HostSourceFence fence(st); // `vk` feeds an asynchronous upload
 		for (uint32_t pc = 0; pc < n_pcs; pc++) {
 			const double l = lam[pc] > 0.0 ? lam[pc] : 0.0;
 			eigenvalues[pc] = l / m_total;
@@ -1002,28 +1010,67 @@ extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, 
 // ---------------------------------------------------------------------------
 
 namespace {
-// pgh_ld_pairs_dev's task list: one device buffer + one pinned host buffer per calling thread
+// pgh_ld_pairs_dev's task list: one device buffer + one pinned host buffer per calling thread, plus the
+// kernel's "malformed task" word and its pinned mirror
 struct LdTaskBuffers {
 	void *d = nullptr, *h = nullptr;
+	uint32_t *d_bad = nullptr, *h_bad = nullptr;
 	size_t cap = 0;
 	int device = -1;           // the buffers belong to this device
-	hipEvent_t done = nullptr; // recorded behind the kernel that reads d
+	hipEvent_t done = nullptr; // recorded behind the kernel that reads d and the copy that fills h_bad
 	bool used = false;
-	~LdTaskBuffers() {
-		// thread exit: the runtime may already be gone at process exit, errors are of no interest here
+	void Release() {
 		if (d) {
 			(void)hipFree(d);
 		}
 		if (h) {
 			(void)hipHostFree(h);
 		}
+		if (d_bad) {
+			(void)hipFree(d_bad);
+		}
+		if (h_bad) {
+			(void)hipHostFree(h_bad);
+		}
 		if (done) {
 			(void)hipEventDestroy(done);
 		}
+		d = h = nullptr;
+		d_bad = h_bad = nullptr;
+		done = nullptr;
+		cap = 0;
+		used = false;
+	}
+	~LdTaskBuffers() {
+		Release(); // thread exit: the runtime may already be gone at process exit, errors are of no interest here
 	}
 };
 thread_local LdTaskBuffers t_ld_tasks;
+
+//! Waits for this thread's last LD launch and fails if its kernel met a task the host cannot have built.
+int LdCheckLast(char *errbuf) {
+	LdTaskBuffers &buf = t_ld_tasks;
+	if (!buf.used) {
+		return PGH_OK;
+	}
+	PGH_HIP(hipEventSynchronize(buf.done), "ld pair kernel");
+	buf.used = false;
+	if (*buf.h_bad != UINT32_MAX) {
+		char msg[200];
+		std::snprintf(msg, sizeof msg,
+		              "plink_ld: task %u of the launch was not well-formed on the device (the task list did not "
+		              "arrive intact); its sums were not computed",
+		              *buf.h_bad - 1);
+		SetErr(errbuf, msg);
+		return PGH_ERR_DEVICE;
+	}
+	return PGH_OK;
+}
 } // namespace
+
+extern "C" int pgh_ld_pairs_status(char *errbuf) {
+	return LdCheckLast(errbuf);
+}
 
 extern "C" int pgh_ld_pairs_dev(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_pairs,
                                 const uint32_t *vidx_a, const uint32_t *vidx_b, void *d_sums, void *stream,
@@ -1059,40 +1106,47 @@ extern "C" int pgh_ld_pairs_dev(const pgh_dataset *ds, const pgh_subset *subset,
 		tasks.push_back(pgh::LdTask {a - ds->v_begin, b - ds->v_begin, 1u, p});
 	}
 	hipStream_t st = static_cast<hipStream_t>(stream);
-	// The task list goes up through this thread's own pair of buffers (device + pinned host), reused from
-	// call to call.  (It used to ride the stream-ordered pool with an asynchronous copy from the pageable
-	// vector; on ROCm 7.2 that copy was seen to leave the pool block all zeros after a particular run of pool
-	// allocations and frees -- a task with n_b == 0 then sent the kernel 64 GB past the matrix.  The kernel
-	// also refuses such tasks now.)
+	// The task list goes up through this thread's own pair of buffers (device + PINNED host), reused from call
+	// to call.  Round 1's first form -- hipMallocAsync, hipMemcpyAsync straight from the frame-local pageable
+	// `tasks` vector, launch, hipFreeAsync, return -- delivered all-zero tasks: hipMemcpyAsync from pageable
+	// memory may read its source after it returns when the stream has work queued ahead of it
+	// (tools/pageable_async_probe.hip shows it on this runtime), and by then the vector had been destroyed and
+	// its storage reused.  A source-lifetime bug in this caller, not a defect of the stream-ordered pool.  The
+	// rule since: an asynchronous upload's source is either pinned memory that outlives the copy (here) or the
+	// call synchronises the stream before the source goes out of scope (HostSourceFence, api_internal.hpp).
+	// The previous launch of this thread is checked first: it must have finished with the buffers anyway.
+	rc = LdCheckLast(errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
 	LdTaskBuffers &buf = t_ld_tasks;
 	const size_t need = sizeof(pgh::LdTask) * tasks.size();
 	if (buf.cap < need || buf.device != ds->device) {
-		if (buf.d) {
-			PGH_HIP(hipEventSynchronize(buf.done), "ld task buffers");
-			(void)hipFree(buf.d);
-			(void)hipHostFree(buf.h);
-			(void)hipEventDestroy(buf.done);
-			buf.d = buf.h = nullptr;
-			buf.done = nullptr;
-			buf.cap = 0;
-			buf.used = false;
-		}
+		buf.Release();
 		buf.device = ds->device;
 		const size_t cap = std::max<size_t>(2 * need, 64u << 10);
 		PGH_HIP(hipMalloc(&buf.d, cap), "hipMalloc(ld tasks)");
 		PGH_HIP(hipHostMalloc(&buf.h, cap, hipHostMallocDefault), "hipHostMalloc(ld tasks)");
-		if (!buf.done) {
-			PGH_HIP(hipEventCreateWithFlags(&buf.done, hipEventDisableTiming), "ld task event");
-		}
+		PGH_HIP(hipMalloc(reinterpret_cast<void **>(&buf.d_bad), sizeof(uint32_t)), "hipMalloc(ld tasks)");
+		PGH_HIP(hipHostMalloc(reinterpret_cast<void **>(&buf.h_bad), sizeof(uint32_t), hipHostMallocDefault),
+		        "hipHostMalloc(ld tasks)");
+		PGH_HIP(hipEventCreateWithFlags(&buf.done, hipEventDisableTiming), "ld task event");
 		buf.cap = cap;
-	} else if (buf.used) {
-		PGH_HIP(hipEventSynchronize(buf.done), "ld task buffers"); // the previous call's kernel has read them
 	}
 	std::memcpy(buf.h, tasks.data(), need);
+	if (const char *t = std::getenv("PGH_TEST_ZERO_LD_TASKS"); t && *t == '1') {
+		std::memset(buf.h, 0, need); // test hook: what round 1's lost upload looked like on the device
+	}
+	*buf.h_bad = UINT32_MAX;
+	// a pair whose task were refused must not hand back whatever the caller's buffer held
+	PGH_HIP(hipMemsetAsync(d_sums, 0, 24ull * n_pairs, st), "ld memset");
+	PGH_HIP(hipMemsetAsync(buf.d_bad, 0xff, sizeof(uint32_t), st), "ld memset");
 	PGH_HIP(hipMemcpyAsync(buf.d, buf.h, need, hipMemcpyHostToDevice, st), "ld task upload");
-	PGH_HIP(pgh::LaunchLdPairs(ds->View(), static_cast<const pgh::LdTask *>(buf.d), static_cast<uint32_t>(tasks.size()),
-	                           subset ? subset->d_mask2 : nullptr, static_cast<uint32_t(*)[6]>(d_sums), st),
+	PGH_HIP(pgh::LaunchLdPairs(ds->View(), ds->v_end - ds->v_begin, static_cast<const pgh::LdTask *>(buf.d),
+	                           static_cast<uint32_t>(tasks.size()), subset ? subset->d_mask2 : nullptr,
+	                           static_cast<uint32_t(*)[6]>(d_sums), buf.d_bad, st),
 	        "ld pair kernel");
+	PGH_HIP(hipMemcpyAsync(buf.h_bad, buf.d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost, st), "ld status copy");
 	PGH_HIP(hipEventRecord(buf.done, st), "ld task event");
 	buf.used = true;
 	return PGH_OK;
@@ -1115,5 +1169,5 @@ extern "C" int pgh_ld_pairs(const pgh_dataset *ds, const pgh_subset *subset, uin
 	}
 	PGH_HIP(hipMemcpyAsync(sums, d_out.p, 24ull * n_pairs, hipMemcpyDeviceToHost, hipStreamPerThread), "ld copy");
 	PGH_HIP(hipStreamSynchronize(hipStreamPerThread), "ld sync");
-	return PGH_OK;
+	return LdCheckLast(errbuf);
 }

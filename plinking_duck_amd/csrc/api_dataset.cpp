@@ -910,6 +910,8 @@ extern "C" int pgh_synth_add_dosage(pgh_dataset *ds, double rate, uint64_t seed,
 		return PGH_OK;
 	}
 	hipStream_t st = hipStreamPerThread;
+	std::vector<uint64_t> off(rows + 1);
+	HostSourceFence fence(st); // `off` feeds an asynchronous upload (dos_row_of lives in the handle)
 	ds->dos_row_of.resize(rows);
 	for (uint32_t i = 0; i < rows; i++) {
 		ds->dos_row_of[i] = static_cast<int32_t>(i);
@@ -925,7 +927,6 @@ extern "C" int pgh_synth_add_dosage(pgh_dataset *ds, double rate, uint64_t seed,
 	PGH_HIP(pgh::LaunchDosageRank(ds->d_dos_present, rows, words, ds->d_dos_rank, st), "dosage rank kernel");
 	PGH_HIP(pgh::LaunchDosageRowTotals(ds->d_dos_present, ds->d_dos_rank, rows, words, ds->d_dos_val_off, st),
 	        "dosage totals kernel");
-	std::vector<uint64_t> off(rows + 1);
 	PGH_HIP(hipMemcpyAsync(off.data(), ds->d_dos_val_off, 8ull * rows, hipMemcpyDeviceToHost, st), "dosage totals copy");
 	PGH_HIP(hipStreamSynchronize(st), "dosage totals sync");
 	uint64_t total = 0;

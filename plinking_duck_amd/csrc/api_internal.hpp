@@ -148,6 +148,21 @@ struct DevBuf {
 	}
 };
 
+// hipMemcpyAsync from PAGEABLE host memory may read its source after it returns (the copy is queued behind
+// whatever the stream already holds; tools/pageable_async_probe.hip), so a frame-local container that feeds
+// one must outlive the copy on EVERY exit path, the PGH_HIP early returns included.  Declare one of these
+// right after the container(s): it is destroyed before them and drains the stream first.
+struct HostSourceFence {
+	hipStream_t st;
+	explicit HostSourceFence(hipStream_t s) : st(s) {
+	}
+	HostSourceFence(const HostSourceFence &) = delete;
+	HostSourceFence &operator=(const HostSourceFence &) = delete;
+	~HostSourceFence() {
+		(void)hipStreamSynchronize(st);
+	}
+};
+
 [[maybe_unused]] int CheckRange(const pgh_dataset *ds, uint32_t v_begin, uint32_t v_end, char *errbuf) {
 	if (!ds) {
 		SetErr(errbuf, "null dataset");

@@ -318,6 +318,7 @@ extern "C" int pgh_hwe_lnp_batch(const uint32_t (*counts)[4], uint32_t n, uint32
 		return PGH_ERR_ARG;
 	}
 	DevBuf d_counts, d_lnp;
+	HostSourceFence fence(hipStreamPerThread); // the caller's `counts` / `ln_p` are in flight until the stream drains
 	PGH_HIP(d_counts.Alloc(16ull * n), "hipMalloc(hwe)");
 	PGH_HIP(d_lnp.Alloc(8ull * n), "hipMalloc(hwe)");
 	PGH_HIP(hipMemcpyAsync(d_counts.p, counts, 16ull * n, hipMemcpyHostToDevice, hipStreamPerThread), "hwe upload");
@@ -338,6 +339,7 @@ extern "C" int pgh_hwe_xchr_lnp_batch(const int32_t (*strata)[5], uint32_t n, ui
 		return PGH_ERR_ARG;
 	}
 	DevBuf d_strata, d_lnp;
+	HostSourceFence fence(hipStreamPerThread); // the caller's `strata` / `ln_p` are in flight until the stream drains
 	PGH_HIP(d_strata.Alloc(20ull * n), "hipMalloc(hwe)");
 	PGH_HIP(d_lnp.Alloc(8ull * n), "hipMalloc(hwe)");
 	PGH_HIP(hipMemcpyAsync(d_strata.p, strata, 20ull * n, hipMemcpyHostToDevice, hipStreamPerThread), "hwe upload");

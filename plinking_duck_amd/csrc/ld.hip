@@ -53,8 +53,9 @@ __device__ inline uint32_t WaveSum32(uint32_t v) {
 // LANES = 256: one workgroup per task; LANES = 64: one wave per task, four tasks per workgroup
 template <uint32_t LANES, bool MASKED>
 __global__ __launch_bounds__(256) void k_ld_pairs(const uint8_t *__restrict__ rows, uint64_t pitch, uint32_t sample_ct,
-                                                  const LdTask *__restrict__ tasks, uint32_t n_tasks,
-                                                  const uint8_t *__restrict__ mask2, uint32_t (*out)[6]) {
+                                                  uint32_t n_rows, const LdTask *__restrict__ tasks, uint32_t n_tasks,
+                                                  const uint8_t *__restrict__ mask2, uint32_t (*out)[6],
+                                                  uint32_t *__restrict__ bad_task) {
 	constexpr uint32_t kPerBlock = 256 / LANES;
 	__shared__ uint32_t s_part[4][kLdPartners][9];
 	const uint32_t lane_in_unit = threadIdx.x % LANES;
@@ -64,7 +65,14 @@ __global__ __launch_bounds__(256) void k_ld_pairs(const uint8_t *__restrict__ ro
 	LdTask task {0, 0, 0, 0};
 	if (live) {
 		task = tasks[t];
-		live = task.n_b != 0 && task.n_b <= kLdPartners; // a malformed task reads nothing (n_b - 1 indexes a partner row)
+		// A task the host could not have built (no partners, too many, rows outside the resident matrix) means
+		// the task list did not reach the device intact.  It reads nothing, and it is reported: the smallest
+		// offending task index + 1 lands in *bad_task and the host fails the call (PGH_ERR_DEVICE).
+		live = task.n_b != 0 && task.n_b <= kLdPartners && task.a_row < n_rows && task.b_row < n_rows &&
+		       task.n_b <= n_rows - task.b_row;
+		if (!live && lane_in_unit == 0) {
+			atomicMin(bad_task, t + 1);
+		}
 	}
 	const uint32_t n_vec = ((sample_ct + 3) / 4 + 15) / 16; // 16-byte vectors that hold calls
 	const u32x4 *a_ptr = reinterpret_cast<const u32x4 *>(rows + static_cast<uint64_t>(task.a_row) * pitch);
@@ -145,15 +153,15 @@ __global__ __launch_bounds__(256) void k_ld_pairs(const uint8_t *__restrict__ ro
 
 } // namespace
 
-hipError_t LaunchLdPairs(const RowView &view, const LdTask *tasks, uint32_t n_tasks, const uint8_t *mask2,
-                         uint32_t (*out)[6], hipStream_t stream) {
+hipError_t LaunchLdPairs(const RowView &view, uint32_t n_rows, const LdTask *tasks, uint32_t n_tasks,
+                         const uint8_t *mask2, uint32_t (*out)[6], uint32_t *bad_task, hipStream_t stream) {
 	if (n_tasks == 0) {
 		return hipSuccess;
 	}
 	const bool wide = view.record_bytes >= 4096;
 #define PGH_LD(LANES, MASKED, BLOCKS)                                                                                  \
 	hipLaunchKernelGGL((k_ld_pairs<LANES, MASKED>), dim3(BLOCKS), dim3(256), 0, stream, view.rows, view.pitch,         \
-	                   view.sample_ct, tasks, n_tasks, mask2, out)
+	                   view.sample_ct, n_rows, tasks, n_tasks, mask2, out, bad_task)
 	if (wide) {
 		if (mask2) {
 			PGH_LD(256, true, n_tasks);

@@ -17,7 +17,10 @@ struct LdTask {
 // out[p] = {n, sum_a, sum_b, sum_ab, sum_a2, sum_b2} over the samples at which BOTH variants are
 // non-missing (and which mask2 keeps, if given) -- the five sums and the count of the reference's
 // ComputeLdStats (src/plink_ld.cpp:52-84), as exact integers.
-hipError_t LaunchLdPairs(const RowView &view, const LdTask *tasks, uint32_t n_tasks, const uint8_t *mask2,
-                         uint32_t (*out)[6], hipStream_t stream);
+// n_rows = resident rows behind view.rows.  *bad_task (device, preset to UINT32_MAX by the caller) receives
+// 1 + the index of the first task that is not well-formed (n_b outside 1..4, a row >= n_rows); such a task
+// reads and writes nothing.
+hipError_t LaunchLdPairs(const RowView &view, uint32_t n_rows, const LdTask *tasks, uint32_t n_tasks,
+                         const uint8_t *mask2, uint32_t (*out)[6], uint32_t *bad_task, hipStream_t stream);
 
 } // namespace pgh

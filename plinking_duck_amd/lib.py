@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     "pgh_close", "pgh_subset_create", "pgh_subset_size", "pgh_subset_destroy", "pgh_counts_range",
     "pgh_counts_range_dev", "pgh_freq_from_counts_dev", "pgh_fused_tally_dev", "pgh_missing_per_sample", "pgh_missing_per_sample_dev", "pgh_unpack_range",
     "pgh_unpack_range_dev", "pgh_score", "pgh_score_dev", "pgh_score_plan_create", "pgh_score_run_dev",
-    "pgh_score_plan_destroy", "pgh_pca", "pgh_pca_sharded", "pgh_ld_pairs", "pgh_ld_pairs_dev", "pgh_sample_counts", "pgh_sample_counts_dev",
+    "pgh_score_plan_destroy", "pgh_pca", "pgh_pca_sharded", "pgh_ld_pairs", "pgh_ld_pairs_dev", "pgh_ld_pairs_status", "pgh_sample_counts", "pgh_sample_counts_dev",
     "pgh_synth_add_dosage", "pgh_synth_write_dosage_files", "pgh_dosage_sums", "pgh_dosage_sums_dev", "pgh_dosage_unpack", "pgh_dosage_unpack_dev", "pgh_unpack_samples", "pgh_dosage_unpack_samples", "pgh_reader_create", "pgh_reader_destroy",
     "pgh_get_2bit", "pgh_get_counts", "pgh_get_missingness", "pgh_get_int8", "pgh_get_dosage_f64", "pgh_get_phased",
     "pgh_reader_error", "pgh_hwe_lnp", "pgh_hwe_xchr_lnp", "pgh_hwe_lnp_batch", "pgh_hwe_lnp_batch_dev", "pgh_hwe_xchr_lnp_batch",
@@ -122,6 +122,7 @@ def _load():
         "pgh_dosage_unpack_samples": (C.c_int, [vp, vp, u32, vp, vp, cp]),
         "pgh_dosage_unpack_dev": (C.c_int, [vp, vp, u32, u32, vp, C.c_size_t, vp, cp]),
         "pgh_ld_pairs_dev": (C.c_int, [vp, vp, u32, vp, vp, vp, vp, cp]),
+        "pgh_ld_pairs_status": (C.c_int, [cp]),
         "pgh_pca_sharded": (C.c_int, [vp, vp, u32, vp, vp, vp, C.c_uint64, u32, vp, ALLREDUCE_FN, vp, vp, vp, cp]),
         "pgh_reader_create": (C.c_int, [vp, vp, C.POINTER(vp), cp]),
         "pgh_reader_destroy": (None, [vp]),

@@ -1,0 +1,56 @@
+"""bench.py's launch contract: a rank count that was not run never produces a line."""
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def run_bench(args, env_extra=None, timeout=600):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, BENCH] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_more_gpus_than_the_node_has_is_an_error_not_a_one_gpu_line():
+    """`python bench.py --gpus 64` outside a launcher starts the ranks itself -- after checking that the
+    node has that many GPUs.  Round 1 printed an n_gpus = 1 line here."""
+    r = run_bench(["--gpus", "64", "--steps", "1", "--warmup", "0"])
+    assert r.returncode != 0
+    assert "--gpus 64" in r.stderr and "GPU(s)" in r.stderr
+    assert r.stdout.strip() == ""
+
+
+def test_rank_count_from_the_launcher_must_match():
+    r = run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0
+    assert "--gpus 2 but 1 rank(s)" in r.stderr
+    assert r.stdout.strip() == ""
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_a_one_gpu_box_fail_loudly():
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has two GPUs")
+    r = run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+    assert r.returncode != 0 and r.stdout.strip() == ""
+
+
+@pytest.mark.gpu
+def test_default_line_is_strong_scaling_and_verified():
+    """A small matrix through the default workload: the line names the whole-matrix (strong) split and carries
+    the self-check of the last step's results."""
+    r = run_bench(["--variants", "20000", "--samples", "50000", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["scaling"] == "strong" and line["verified"] is True
+    assert line["roofline"]["bound"] == "hbm" and line["roofline"]["frac"] > 0

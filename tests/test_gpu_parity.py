@@ -413,6 +413,23 @@ def test_ld_pair_sums_match_oracle(gpu_lib, oracle, n):
         assert np.array_equal(got.astype(np.uint64), want)
 
 
+@pytest.mark.parametrize("n", [1000, 70001])
+def test_ld_refuses_a_task_list_that_did_not_arrive(gpu_lib, monkeypatch, n):
+    """Round 1 saw the task list reach the device as zeros (its pageable source had died before the
+    asynchronous copy ran).  The kernel must neither read out of bounds nor hand back sums for such a
+    task: the call fails with PGH_ERR_DEVICE, and the next, intact call works."""
+    m = 12
+    host = np.stack([gpu_lib.synth_record_host(v, n, SEED + 6, 0.05) for v in range(m)])
+    ds = gpu_lib.Dataset.from_host_rows(host, n)
+    a, b = [0, 0, 0, 5], [1, 2, 3, 9]
+    good = ds.ld_pairs(a, b)
+    monkeypatch.setenv("PGH_TEST_ZERO_LD_TASKS", "1")
+    with pytest.raises(gpu_lib.PghError, match="did not arrive intact"):
+        ds.ld_pairs(a, b)
+    monkeypatch.setenv("PGH_TEST_ZERO_LD_TASKS", "0")
+    assert np.array_equal(ds.ld_pairs(a, b), good)
+
+
 @pytest.mark.parametrize("n", [5, 1000, 70001])
 def test_sample_counts_match_oracle(gpu_lib, oracle, n):
     m = 300
