@@ -1108,12 +1108,14 @@ extern "C" int pgh_ld_pairs_dev(const pgh_dataset *ds, const pgh_subset *subset,
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	// The task list goes up through this thread's own pair of buffers (device + PINNED host), reused from call
 	// to call.  Round 1's first form -- hipMallocAsync, hipMemcpyAsync straight from the frame-local pageable
-	// `tasks` vector, launch, hipFreeAsync, return -- delivered all-zero tasks: hipMemcpyAsync from pageable
-	// memory may read its source after it returns when the stream has work queued ahead of it
-	// (tools/pageable_async_probe.hip shows it on this runtime), and by then the vector had been destroyed and
-	// its storage reused.  A source-lifetime bug in this caller, not a defect of the stream-ordered pool.  The
-	// rule since: an asynchronous upload's source is either pinned memory that outlives the copy (here) or the
-	// call synchronises the stream before the source goes out of scope (HostSourceFence, api_internal.hpp).
+	// `tasks` vector, launch, hipFreeAsync, return -- once delivered all-zero tasks.  What the box shows
+	// (tools/pageable_async_probe.hip, profiles/r02_pageable_probe.txt): the runtime takes a pageable source's
+	// bytes before hipMemcpyAsync returns, so the dying vector was not the cause; but a pool block that an
+	// earlier owner zeroed with a still-queued hipMemsetAsync, freed stream-ordered and got handed out again was
+	// seen to keep the EARLIER zeros after the LATER pageable copy (once in three probe runs) -- exactly this
+	// call's shape after plink_score's `miss` block.  Rule since: pool blocks are written only by kernels and
+	// memsets of their stream; uploads go through pinned memory into plain allocations (here), or from pageable
+	// memory into plain allocations behind a HostSourceFence (api_internal.hpp).
 	// The previous launch of this thread is checked first: it must have finished with the buffers anyway.
 	rc = LdCheckLast(errbuf);
 	if (rc != PGH_OK) {

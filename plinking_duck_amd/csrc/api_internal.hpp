@@ -148,10 +148,10 @@ struct DevBuf {
 	}
 };
 
-// hipMemcpyAsync from PAGEABLE host memory may read its source after it returns (the copy is queued behind
-// whatever the stream already holds; tools/pageable_async_probe.hip), so a frame-local container that feeds
-// one must outlive the copy on EVERY exit path, the PGH_HIP early returns included.  Declare one of these
-// right after the container(s): it is destroyed before them and drains the stream first.
+// HIP does not promise that hipMemcpyAsync has finished with a PAGEABLE source when it returns (this runtime
+// happens to stage it first, tools/pageable_async_probe.hip), so a frame-local container that feeds one must
+// outlive the copy on EVERY exit path, the PGH_HIP early returns included.  Declare one of these right after
+// the container(s): it is destroyed before them and drains the stream first.
 struct HostSourceFence {
 	hipStream_t st;
 	explicit HostSourceFence(hipStream_t s) : st(s) {
