@@ -466,8 +466,18 @@ extern "C" int pgh_dosage_unpack_samples(const pgh_dataset *ds, const pgh_subset
 // plink_score
 // ---------------------------------------------------------------------------
 
+// one prepared pass of the int8 contraction (score_i8.hpp): up to kI8MaxCols weight columns
+struct ScoreI8Pass {
+	uint32_t c0 = 0, n_cols = 0;
+	pgh::ScoreI8Buffers buf;
+	void *d_bmat = nullptr, *d_rowidx = nullptr, *d_cols = nullptr, *d_small = nullptr;
+};
+
 struct pgh_score_plan {
 	const pgh_dataset *ds = nullptr;
+	std::vector<ScoreI8Pass> i8; // the table-scored variants (hardcalls + sparse dosage tracks), cut into digits
+	uint32_t n_table = 0;        // ... their number: the first n_table entries of d_vlist
+	bool two_step = true;        // sparse dosage tracks ride the hardcall kernel + k_score_dosage_fix
 	uint32_t n_scored = 0, n_cols = 0;
 	uint32_t n_hard = 0; // the first n_hard entries have hardcalls only; the rest carry dosage tracks:
 	uint32_t n_gaps = 0; // ... then n_gaps whose tracks cover most samples (scored by the sample-owning kernel)
@@ -485,6 +495,13 @@ extern "C" void pgh_score_plan_destroy(pgh_score_plan *plan) {
 	                plan->d_lin}) {
 		if (p) {
 			(void)hipFree(p);
+		}
+	}
+	for (ScoreI8Pass &pass : plan->i8) {
+		for (void *p : {pass.d_bmat, pass.d_rowidx, pass.d_cols, pass.d_small}) {
+			if (p) {
+				(void)hipFree(p);
+			}
 		}
 	}
 	delete plan;
@@ -615,6 +632,38 @@ extern "C" int pgh_score_plan_create(const pgh_dataset *ds, const pgh_subset *su
 			                                     static_cast<uint32_t *>(plan->d_ac) + n_hard, st),
 			        "score table kernel");
 		}
+		// The contraction itself runs on the int8 matrix cores: cut the coefficients of the table-scored
+		// variants into digits once (score_i8.hpp).  PGH_SCORE_DOSAGE_LANES=1 keeps the sample-owning
+		// k_score_dosage for every track with gaps (a cross-check): those variants then leave the tables.
+		const char *lanes_env = std::getenv("PGH_SCORE_DOSAGE_LANES");
+		plan->two_step = !(lanes_env && *lanes_env && *lanes_env != '0');
+		const uint32_t n_sparse = n_scored - n_hard - n_gaps - n_full;
+		plan->n_table = n_hard + (plan->two_step ? n_sparse : 0u);
+		if (plan->n_table) {
+			for (uint32_t c0 = 0; c0 < n_cols; c0 += pgh::kI8MaxCols) {
+				plan->i8.emplace_back();
+				ScoreI8Pass &pass = plan->i8.back();
+				pass.c0 = c0;
+				pass.n_cols = std::min(pgh::kI8MaxCols, n_cols - c0);
+				const pgh::ScoreI8Sizes z = pgh::ScoreI8Bytes(plan->n_table, pass.n_cols);
+				PGH_HIP(hipMalloc(&pass.d_bmat, z.bmat), "hipMalloc(score digits)");
+				PGH_HIP(hipMalloc(&pass.d_rowidx, z.rowidx), "hipMalloc(score digits)");
+				PGH_HIP(hipMalloc(&pass.d_cols, z.cols), "hipMalloc(score digits)");
+				PGH_HIP(hipMalloc(&pass.d_small, z.small), "hipMalloc(score digits)");
+				pass.buf.bmat = static_cast<int8_t *>(pass.d_bmat);
+				pass.buf.rowidx = static_cast<uint32_t *>(pass.d_rowidx);
+				pass.buf.mult = static_cast<double *>(pass.d_cols);
+				pass.buf.target = reinterpret_cast<uint32_t *>(pass.buf.mult + 16ull * z.n_tiles16);
+				pass.buf.colmax = static_cast<unsigned long long *>(pass.d_small);
+				pass.buf.k0 = reinterpret_cast<double *>(pass.buf.colmax + (pass.n_cols + 2));
+				pass.buf.scale_exp = pass.buf.k0 + (pass.n_cols + 2);
+				PGH_HIP(pgh::LaunchScoreI8Prepare(vlist, plan->n_table, static_cast<double *>(plan->d_weights) + c0, n_cols,
+				                                  pass.n_cols, static_cast<double *>(plan->d_ts),
+				                                  static_cast<double *>(plan->d_td), static_cast<uint32_t *>(plan->d_ac),
+				                                  mode != PGH_SCORE_MEAN_IMPUTE, pass.buf, st),
+				        "score digit kernels");
+			}
+		}
 		PGH_HIP(hipStreamSynchronize(st), "score plan sync"); // host staging vectors die with this frame
 	}
 	*out = plan.release();
@@ -645,41 +694,35 @@ extern "C" int pgh_score_run_dev(const pgh_score_plan *plan, void *d_score_sum, 
 	// dosage-bearing variants: n_dos sparse tracks, n_gaps tracks covering most samples, n_full covering all
 	const uint32_t n_hard = plan->n_hard, n_full = plan->n_full;
 	uint32_t n_gaps = plan->n_gaps, n_dos = plan->n_scored - plan->n_hard - plan->n_full - plan->n_gaps;
-	// Dosage-bearing variants ride the hardcall kernels with their dosage-mean tables (every sample's term is
-	// ts[call], plus (affine(dosage) - ts[call]) where it has an explicit dosage), and k_score_dosage_fix adds
-	// what the explicit entries change, one weight column per launch.  PGH_SCORE_DOSAGE_LANES=1 keeps the
-	// one-lane-per-sample kernel (k_score_dosage) for the dosage-bearing variants instead.
-	const char *lanes_env = std::getenv("PGH_SCORE_DOSAGE_LANES");
-	const bool two_step = !(lanes_env && *lanes_env && *lanes_env != '0');
-	if (!two_step) {
+	// Dosage-bearing variants with sparse tracks ride the hardcall contraction with their dosage-mean tables
+	// (every sample's term is ts[call], plus (affine(dosage) - ts[call]) where it has an explicit dosage), and
+	// k_score_dosage_fix adds what the explicit entries change, one weight column per launch.
+	if (!plan->two_step) {
 		n_gaps += n_dos; // the cross-check: every track with gaps through the sample-owning kernel
 		n_dos = 0;
 	}
 	const uint32_t n_table = n_hard + n_dos;
 	const bool track = plan->mode != PGH_SCORE_CENTER && d_dosage_sum != nullptr;
-	if (n_table) {
-		PGH_HIP(pgh::LaunchScoreAccumulate(ds->View(), vlist, n_table, weights, plan->n_cols, ts,
-		                                   static_cast<double *>(plan->d_td), ac, track,
-		                                   static_cast<double *>(d_score_sum), static_cast<double *>(d_dosage_sum),
-		                                   static_cast<uint32_t *>(d_allele_ct), st),
-		        "score accumulate kernel");
-	}
 	// ALLELE_CT is integer bookkeeping: 2 per scored, non-skipped variant, minus 2 per such
 	// variant at which the sample is missing unless missing calls are mean-imputed
-	// (src/plink_score.cpp:632-651).  Under a dosage track "missing" means no dosage and no call.
+	// (src/plink_score.cpp:632-651).  Under a dosage track "missing" means no dosage and no call.  The
+	// missing calls at the table-scored variants are one more digit column of the contraction.
 	const bool count_missing = plan->mode != PGH_SCORE_MEAN_IMPUTE;
-	void *scratch = nullptr, *miss = nullptr;
+	void *miss = nullptr;
 	hipError_t e = hipSuccess;
 	if (count_missing) {
-		const size_t scratch_bytes = pgh::MissingPerSampleScratchBytes(ds->record_bytes, std::max(n_table, 1u));
 		const size_t miss_bytes = sizeof(uint32_t) * ((N + 63) / 64 * 64);
-		PGH_HIP(hipMallocAsync(&scratch, scratch_bytes ? scratch_bytes : 16, st), "score scratch");
 		PGH_HIP(hipMallocAsync(&miss, miss_bytes, st), "score scratch");
 		e = hipMemsetAsync(miss, 0, miss_bytes, st);
-		if (e == hipSuccess && n_table) {
-			e = pgh::LaunchMissingPerSample(ds->View(), 0, vlist, n_table, ac, static_cast<uint32_t *>(scratch),
-			                                static_cast<uint32_t *>(miss), st);
+	}
+	for (const ScoreI8Pass &pass : plan->i8) {
+		if (e != hipSuccess) {
+			break;
 		}
+		const bool first = pass.c0 == 0;
+		e = pgh::LaunchScoreI8(ds->View(), n_table, pass.n_cols, pass.buf, static_cast<double *>(d_score_sum) + pass.c0,
+		                       plan->n_cols, (first && track) ? static_cast<double *>(d_dosage_sum) : nullptr,
+		                       first ? static_cast<uint32_t *>(miss) : nullptr, st);
 	}
 	if (e == hipSuccess && n_dos) {
 		for (uint32_t c = 0; c < plan->n_cols && e == hipSuccess; c++) {
@@ -711,9 +754,6 @@ extern "C" int pgh_score_run_dev(const pgh_score_plan *plan, void *d_score_sum, 
 	if (e == hipSuccess) {
 		e = pgh::LaunchAlleleCt(ac, plan->n_scored, static_cast<uint32_t *>(miss), N,
 		                        static_cast<uint32_t *>(d_allele_ct), st);
-	}
-	if (scratch) {
-		(void)hipFreeAsync(scratch, st);
 	}
 	if (miss) {
 		(void)hipFreeAsync(miss, st);

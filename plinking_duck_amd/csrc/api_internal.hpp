@@ -9,6 +9,7 @@
 #include "dosage.hpp"
 #include "phase.hpp"
 #include "kernels.hpp"
+#include "score_i8.hpp"
 #include "ld.hpp"
 #include "linalg.hpp"
 #include "pgen_file.hpp"

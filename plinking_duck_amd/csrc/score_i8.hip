@@ -1,0 +1,671 @@
+// score_i8.hip -- plink_score's genotype x weight contraction on the int8 matrix cores (gfx950),
+// exact in fixed point.
+//
+//   score[s][c] = sum_v  W[v][c] * T_v[g(v,s)]          (src/plink_score.cpp:575-654)
+//
+// T_v is affine in the call for g = 0, 1, 2 in every mode of the reference (dosage g or 2 - g, centred or
+// not) and takes its own value for a missing call (the variant's mean, or nothing).  With the raw 2-bit
+// code c(v,s) in {0,1,2,3} and miss = [c == 3]:
+//
+//   W T_v[g] = W t0  +  c * (W d)  +  miss * W (t3 - t0 - 3 d),          d = t1 - t0
+//              -----     ---------     --------------------------
+//              K0[c]      alpha          beta
+//
+// so the whole sum is two integer-matrix x real-vector products: the code plane and the missing plane.
+// The real coefficients are cut into signed base-256 digits of a fixed-point number (one power-of-two
+// scale per output column -- the Ozaki splitting), the planes are int8 matrices, and
+// v_mfma_i32_16x16x64_i8 accumulates every digit column EXACTLY in int32.  Sixteen digit columns ride in
+// one instruction: one weight column (7 digits, 54 bits below the column's largest coefficient), the
+// unweighted NAMED_ALLELE_DOSAGE_SUM (5 digits) and the count of missing calls (ALLELE_CT) fit in a single
+// 16-column tile, so the reference's one-column SQL contract costs two matrix instructions per
+// 64 variants x 16 samples and reads every byte of the matrix once; sixteen weight columns (BASELINE
+// config 4) take eight tiles.  Rounding happens once, where a coefficient is cut to 54 bits; the sums
+// themselves are exact, i.e. closer to the real-number result than a double accumulation in any order.
+//
+// Kernel shape (k_score_i8<NT, TS>): a workgroup of four waves owns 64*TS samples and walks a slice of
+// the scored variants 64 at a time.  All lanes fetch the tile's packed bytes with 16-byte loads (whole
+// 16*TS-byte row segments), park them in LDS, and each lane reads back the 16 variants of its matrix k-group
+// for one 4-byte word of samples.  Four 4x4 transposes on 2-bit fields (16 bitfield ops) turn four such words
+// into bytes that hold one sample's four calls; a multiply and a shift-or spread such a byte into four int8
+// codes (three ops per four calls), a byte permute derives the missing plane (one op), and the two matrix
+// instructions consume them against the tile's digit bytes -- ~1.25 vector ops per call, under the HBM time.
+#include "device_utils.hpp"
+#include "score_i8.hpp"
+
+namespace pgh {
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+constexpr uint32_t kTileVariants = 64; // K of v_mfma_i32_16x16x64_i8
+
+// ---------------------------------------------------------------------------
+// preparation: scales, digits, constants (once per plan)
+// ---------------------------------------------------------------------------
+
+struct Coef {
+	double alpha, beta, k0;
+};
+
+// coefficients of target column t at variant i: t < n_cols a weight column, t == n_cols the dosage sum
+__device__ __forceinline__ Coef CoefOf(uint32_t i, uint32_t t, uint32_t n_cols, const double *__restrict__ weights,
+                                       uint32_t w_stride, const double *__restrict__ ts,
+                                       const double *__restrict__ td) {
+	const double *tab = (t < n_cols) ? ts : td;
+	const double w = (t < n_cols) ? weights[static_cast<uint64_t>(i) * w_stride + t] : 1.0;
+	const double t0 = tab[4ull * i], t1 = tab[4ull * i + 1], t3 = tab[4ull * i + 3];
+	const double d = t1 - t0;
+	Coef c;
+	c.alpha = w * d;
+	c.beta = w * (t3 - t0 - 3.0 * d);
+	c.k0 = w * t0;
+	return c;
+}
+
+__device__ __forceinline__ double BlockMax(double v, double *s_red) {
+	for (int off = 32; off > 0; off >>= 1) {
+		v = fmax(v, __shfl_xor(v, off, 64));
+	}
+	if ((threadIdx.x & 63u) == 0) {
+		s_red[threadIdx.x >> 6] = v;
+	}
+	__syncthreads();
+	v = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+	__syncthreads();
+	return v;
+}
+
+__device__ __forceinline__ double BlockSum(double v, double *s_red) {
+	for (int off = 32; off > 0; off >>= 1) {
+		v += __shfl_xor(v, off, 64);
+	}
+	if ((threadIdx.x & 63u) == 0) {
+		s_red[threadIdx.x >> 6] = v;
+	}
+	__syncthreads();
+	v = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+	__syncthreads();
+	return v;
+}
+
+// colmax[t] = max over variants of max(|alpha|, |beta|) (as the bit pattern of a non-negative double:
+// monotone under integer max); k0[t] = sum over variants of W t0.  grid.y = target column.
+__global__ __launch_bounds__(256) void k_i8_ranges(uint32_t n_var, uint32_t n_cols, const double *__restrict__ weights,
+                                                   uint32_t w_stride, const double *__restrict__ ts,
+                                                   const double *__restrict__ td,
+                                                   unsigned long long *__restrict__ colmax,
+                                                   double *__restrict__ k0) {
+	__shared__ double s_red[4];
+	const uint32_t t = blockIdx.y;
+	double mx = 0.0, sum = 0.0;
+	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_var; i += gridDim.x * 256u) {
+		const Coef c = CoefOf(i, t, n_cols, weights, w_stride, ts, td);
+		mx = fmax(mx, fmax(fabs(c.alpha), fabs(c.beta)));
+		sum += c.k0;
+	}
+	mx = BlockMax(mx, s_red);
+	sum = BlockSum(sum, s_red);
+	if (threadIdx.x == 0) {
+		atomicMax(colmax + t, static_cast<unsigned long long>(__double_as_longlong(mx)));
+		unsafeAtomicAdd(k0 + t, sum);
+	}
+}
+
+// Digit columns: weight column c owns columns [7c, 7c+7), the dosage sum the next 5, the missing count 1.
+__host__ __device__ constexpr uint32_t DigitColumns(uint32_t n_cols) {
+	return kI8WeightDigits * n_cols + kI8DosageDigits + 1u;
+}
+
+// mult[J] = value of one unit of digit column J; target[J] = output column (n_cols: dosage sum,
+// n_cols + 1: missing count, 0xffffffff: unused)
+__global__ void k_i8_columns(uint32_t n_cols, uint32_t n_tiles16, const unsigned long long *__restrict__ colmax,
+                             double *__restrict__ scale_exp, double *__restrict__ mult,
+                             uint32_t *__restrict__ target) {
+	const uint32_t J = blockIdx.x * blockDim.x + threadIdx.x;
+	if (J >= n_tiles16 * 16u) {
+		return;
+	}
+	const uint32_t used = DigitColumns(n_cols);
+	if (J >= used) {
+		mult[J] = 0.0;
+		target[J] = 0xffffffffu;
+		return;
+	}
+	uint32_t t, d, digits;
+	if (J < kI8WeightDigits * n_cols) {
+		t = J / kI8WeightDigits;
+		d = J % kI8WeightDigits;
+		digits = kI8WeightDigits;
+	} else if (J < kI8WeightDigits * n_cols + kI8DosageDigits) {
+		t = n_cols;
+		d = J - kI8WeightDigits * n_cols;
+		digits = kI8DosageDigits;
+	} else {
+		mult[J] = 1.0;
+		target[J] = n_cols + 1u;
+		return;
+	}
+	// the column's coefficients are cut at 2^e / 2^(8 digits - 2), 2^e >= the largest of them: the top digit
+	// then stays within +-65
+	const double mx = __longlong_as_double(static_cast<long long>(colmax[t]));
+	int e = 0;
+	if (mx > 0.0) {
+		(void)frexp(mx, &e); // mx = f * 2^e, f in [0.5, 1)
+	}
+	if (d == 0) {
+		scale_exp[t] = static_cast<double>(e);
+	}
+	mult[J] = ldexp(1.0, e - static_cast<int>(8u * digits - 2u) + static_cast<int>(8u * d));
+	target[J] = t;
+}
+
+// signed base-256 digits of x (|x| <= 2^(8n-2)), least significant first
+__device__ __forceinline__ void Digits(long long x, uint32_t n, int8_t *out) {
+	for (uint32_t d = 0; d < n; d++) {
+		const long long q = ((x + 128) & 255) - 128;
+		out[d] = static_cast<int8_t>(q);
+		x = (x - q) >> 8;
+	}
+}
+
+// bmat layout: [tile][plane][tile16][k-group g][digit column x][16 variants of the group] int8, so that a
+// matrix-instruction lane (x, g) reads its 16 operand bytes as one 16-byte vector.
+__device__ __forceinline__ uint64_t BmatOffset(uint32_t i, uint32_t plane, uint32_t J, uint32_t n_tiles16) {
+	const uint32_t tile = i / kTileVariants, k = i % kTileVariants;
+	return ((((static_cast<uint64_t>(tile) * 2u + plane) * n_tiles16 + J / 16u) * 4u + k / 16u) * 16u + J % 16u) * 16u +
+	       k % 16u;
+}
+
+// one thread per (variant, target column); rows past n_var (tile padding) keep the zeros of the memset
+__global__ __launch_bounds__(256) void k_i8_digits(uint32_t n_var, uint32_t n_cols, uint32_t n_tiles16,
+                                                   const double *__restrict__ weights, uint32_t w_stride,
+                                                   const double *__restrict__ ts, const double *__restrict__ td,
+                                                   const uint32_t *__restrict__ ac, int count_missing,
+                                                   const double *__restrict__ scale_exp, int8_t *__restrict__ bmat) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	const uint32_t t = blockIdx.y; // 0..n_cols: weight columns, dosage; n_cols + 1: the missing count
+	if (i >= n_var) {
+		return;
+	}
+	if (t == n_cols + 1u) {
+		// ALLELE_CT bookkeeping (src/plink_score.cpp:632-651): variants whose missing calls take 2 alleles
+		// away are those that count 2 for a present call and nothing for a missing one
+		const uint32_t a = ac[i];
+		const bool counts = count_missing && (a & 0xffu) != 0u && ((a >> 8) & 0xffu) == 0u;
+		bmat[BmatOffset(i, 1, DigitColumns(n_cols) - 1u, n_tiles16)] = counts ? 1 : 0;
+		return;
+	}
+	const Coef c = CoefOf(i, t, n_cols, weights, w_stride, ts, td);
+	const uint32_t digits = t < n_cols ? kI8WeightDigits : kI8DosageDigits;
+	const uint32_t J0 = t < n_cols ? kI8WeightDigits * t : kI8WeightDigits * n_cols;
+	const int e = static_cast<int>(scale_exp[t]);
+	const int shift = static_cast<int>(8u * digits - 2u) - e;
+	int8_t qa[8], qb[8];
+	Digits(llrint(ldexp(c.alpha, shift)), digits, qa);
+	Digits(llrint(ldexp(c.beta, shift)), digits, qb);
+	for (uint32_t d = 0; d < digits; d++) {
+		bmat[BmatOffset(i, 0, J0 + d, n_tiles16)] = qa[d];
+		bmat[BmatOffset(i, 1, J0 + d, n_tiles16)] = qb[d];
+	}
+}
+
+// ---------------------------------------------------------------------------
+// the contraction
+// ---------------------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t Bfi(uint32_t mask, uint32_t a, uint32_t b) {
+	return (mask & a) | (~mask & b); // v_bfi_b32
+}
+
+// Four words (variants v0..v3, 16 samples each) -> four words whose BYTES hold one sample's four calls
+// (v0 | v1 << 2 | v2 << 4 | v3 << 6): out[k] byte b is sample 4 b + {0, 2, 1, 3}[k].
+__device__ __forceinline__ void Transpose4(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t *out) {
+	const uint32_t e01 = Bfi(0x33333333u, w0, w1 << 2);
+	const uint32_t o01 = Bfi(0xccccccccu, w1, w0 >> 2);
+	const uint32_t e23 = Bfi(0x33333333u, w2, w3 << 2);
+	const uint32_t o23 = Bfi(0xccccccccu, w3, w2 >> 2);
+	out[0] = Bfi(0x0f0f0f0fu, e01, e23 << 4);
+	out[1] = Bfi(0xf0f0f0f0u, e23, e01 >> 4);
+	out[2] = Bfi(0x0f0f0f0fu, o01, o23 << 4);
+	out[3] = Bfi(0xf0f0f0f0u, o23, o01 >> 4);
+}
+
+// byte B of x (four 2-bit calls) -> four int8 codes, one per byte: x * 0x1001 puts copies at bits 0 and 12,
+// (a << 6) | a adds copies at 6 and 18, and call c of copy c sits at bit 8 c.
+#define PGH_SPREAD(B)                                                                                                  \
+	__device__ __forceinline__ uint32_t Spread##B(uint32_t x, uint32_t k1001) {                                       \
+		uint32_t a;                                                                                                    \
+		asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_" #B " src1_sel:DWORD"    \
+		    : "=v"(a)                                                                                                  \
+		    : "v"(x), "v"(k1001));                                                                                     \
+		return ((a << 6) | a) & 0x03030303u;                                                                           \
+	}
+PGH_SPREAD(0)
+PGH_SPREAD(1)
+PGH_SPREAD(2)
+PGH_SPREAD(3)
+#undef PGH_SPREAD
+
+template <int B>
+__device__ __forceinline__ uint32_t Spread(uint32_t x, uint32_t k1001) {
+	if (B == 0) {
+		return Spread0(x, k1001);
+	}
+	if (B == 1) {
+		return Spread1(x, k1001);
+	}
+	if (B == 2) {
+		return Spread2(x, k1001);
+	}
+	return Spread3(x, k1001);
+}
+
+// NT 16-column digit tiles; TS samples per lane (16, 8 or 4): accumulators = TS * NT * 4 registers
+template <int NT, int TS>
+struct I8Shape {
+	static constexpr uint32_t kRowBytes = 16u * TS;            // bytes of one row that a workgroup owns (4 waves)
+	static constexpr uint32_t kChunksPerRow = TS;              // 16-byte chunks
+	static constexpr uint32_t kChunksPerThread = TS / 4;       // 64 rows * TS chunks / 256 threads
+	static constexpr uint32_t kWordsPerRow = 4u * TS;
+	static constexpr uint32_t kSwizzleChunks = kWordsPerRow >= 32 ? 4u : kWordsPerRow / 8u; // XOR for odd k-groups
+	static constexpr uint32_t kGenoBytes = kTileVariants * kRowBytes;
+	static constexpr uint32_t kBBytes = 2u * NT * 1024u;
+	static constexpr uint32_t kBChunks = kBBytes / 16u; // 128 NT
+	static constexpr uint32_t kSamplesPerGroup = 64u * TS;
+};
+
+// LDS-DMA (global_load_lds_*): 64 lanes x 16 (4) bytes from per-lane global addresses to consecutive LDS bytes
+// starting at the wave-uniform LDS address in M0.  Issued from inline asm so that the compiler's wait-count
+// bookkeeping does not see them: with the builtin form hipcc drains vmcnt to zero in front of every LDS read that
+// might alias a pending DMA, which is every one here.  Completion is counted by hand (PGH_WAIT_VM below).
+__device__ __forceinline__ void Glds16Stream(const void *gsrc, uint32_t lds_dst) {
+	uint32_t keep;
+	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+	             : "=&s"(keep)
+	             : "v"(gsrc), "s"(lds_dst)
+	             : "memory");
+}
+__device__ __forceinline__ void Glds16(const void *gsrc, uint32_t lds_dst) {
+	uint32_t keep;
+	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+	             : "=&s"(keep)
+	             : "v"(gsrc), "s"(lds_dst)
+	             : "memory");
+}
+__device__ __forceinline__ void Glds4(const void *gsrc, uint32_t lds_dst) {
+	uint32_t keep;
+	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+	             : "=&s"(keep)
+	             : "v"(gsrc), "s"(lds_dst)
+	             : "memory");
+}
+__device__ __forceinline__ uint32_t LdsAddress(const void *p) {
+	return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) void *)p));
+}
+
+// LDS slots per workgroup: the tile being multiplied + the ones on their way from HBM.  Four where two workgroups
+// of that size still fit a CU's 160 KB, else three (the many-column shapes are matrix-bound: a trip is long).
+template <int NT, int TS>
+constexpr uint32_t RingSlots() {
+	return 4u * (64u * 16u * TS + 2048u * NT) + 4096u <= 80u * 1024u ? 4u : 3u;
+}
+
+template <int NT, int TS>
+__global__ __launch_bounds__(256) void k_score_i8(const uint8_t *__restrict__ rows, uint64_t pitch, uint32_t sample_ct,
+                                                  const uint32_t *__restrict__ rowidx, uint32_t n_tiles,
+                                                  uint32_t tiles_per_slice, const int8_t *__restrict__ bmat,
+                                                  const double *__restrict__ mult,
+                                                  const uint32_t *__restrict__ target, uint32_t n_cols,
+                                                  double *__restrict__ score, uint32_t out_stride,
+                                                  double *__restrict__ dosage_sum,
+                                                  uint32_t *__restrict__ missing_ct) {
+	using S = I8Shape<NT, TS>;
+	constexpr uint32_t kRing = RingSlots<NT, TS>();
+	constexpr uint32_t kSlotBytes = S::kGenoBytes + S::kBBytes;
+	__shared__ __attribute__((aligned(16))) uint8_t s_ring[kRing][kSlotBytes];
+	const uint32_t tid = threadIdx.x;
+	const uint32_t lane = tid & 63u, wave = tid >> 6;
+	const uint32_t x = lane & 15u, g = lane >> 4;
+	const uint32_t tile_begin = blockIdx.y * tiles_per_slice;
+	const uint32_t tile_end = min(tile_begin + tiles_per_slice, n_tiles);
+	if (tile_begin >= tile_end) {
+		return;
+	}
+	const uint64_t group_byte = static_cast<uint64_t>(blockIdx.x) * S::kRowBytes; // first byte of this workgroup's stripe
+
+	// ---- staging: HBM -> LDS without a register stop (global_load_lds_dwordx4) ----
+	// One such instruction writes 64 x 16 B to consecutive LDS bytes (lane l at base + 16 l), so the slot's image
+	// is filled piece by piece in linear order: piece p = 4 n + wave (n < TS / 4) holds chunks 64 p .. 64 p + 63
+	// of the tile, chunk c = row c / TS, position c % TS.  Position q of a row of an odd k-group holds the row's
+	// chunk q ^ swizzle (the lanes that read k-groups 0/1 resp. 2/3 together then hit different banks); the
+	// swizzle is applied to the SOURCE address here and to the read address below.
+	// The resident row of each of the tile's 64 variants (variant lists need not be contiguous) travels the
+	// same way, 4 bytes per lane, into a small ring of its own, six tiles ahead: by the time a tile's pieces are
+	// issued its row numbers are plain LDS reads.  Nothing in the loop is an ordinary vector load, so the only
+	// vmcnt wait is the counted one that retires the oldest tile in flight.
+	constexpr uint32_t kGenoPieces = S::kChunksPerThread;      // per wave and tile
+	constexpr uint32_t kBPieces = (S::kBChunks + 255u) / 256u; // per wave and tile (the last may be half a wave)
+	constexpr uint32_t kPieces = kGenoPieces + kBPieces + 1u;  // + the row numbers
+	constexpr uint32_t kRowAhead = 2u * kRing - 2u;            // tiles between a row-number DMA and its use
+	static_assert(kPieces * (kRing - 2) < 64, "vmcnt field");
+	__shared__ uint32_t s_rows[16][kTileVariants]; // by tile number mod 16: a slot is rewritten 16 tiles (>= 6 barriers) after its last read
+	const uint32_t wave_u = __builtin_amdgcn_readfirstlane(wave);
+	const uint32_t st_pos = lane % S::kChunksPerRow;
+	uint32_t st_row[kGenoPieces];
+	uint64_t st_col[kGenoPieces]; // byte offset inside a row of the chunk this lane fetches for piece n
+#pragma unroll
+	for (uint32_t n = 0; n < kGenoPieces; n++) {
+		const uint32_t row = ((4u * n + wave) * 64u + lane) / S::kChunksPerRow;
+		const uint32_t logical = st_pos ^ (((row >> 4) & 1u) * S::kSwizzleChunks);
+		const uint64_t want = group_byte + 16ull * logical;
+		st_row[n] = row;
+		st_col[n] = want < pitch ? want : 0ull; // past the row: some valid bytes; such samples are never stored
+	}
+	const uint32_t last_tile = tile_end - 1u;
+	const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(LdsAddress(&s_ring[0][0]));
+	const uint32_t rows_lds = __builtin_amdgcn_readfirstlane(LdsAddress(&s_rows[0][0]));
+	auto issue_rows = [&](uint32_t tile) {
+		const uint32_t t = min(tile, last_tile);
+		Glds4(rowidx + static_cast<uint64_t>(t) * kTileVariants + lane, rows_lds + ((tile - tile_begin) & 15u) * 256u);
+	};
+	auto issue = [&](uint32_t tile, uint32_t slot) {
+		// (past the slice: a harmless repeat of its last tile keeps the counts uniform)
+		issue_rows(tile + kRowAhead);
+		const uint32_t base = ring_lds + slot * kSlotBytes;
+		const uint32_t *rp = &s_rows[(tile - tile_begin) & 15u][0];
+#pragma unroll
+		for (uint32_t n = 0; n < kGenoPieces; n++) {
+			const uint32_t r = rp[st_row[n]];
+			const uint8_t *src = rows + static_cast<uint64_t>(r) * pitch + st_col[n];
+			Glds16Stream(src, base + (4u * n + wave_u) * 1024u);
+		}
+		const int8_t *bsrc = bmat + static_cast<uint64_t>(min(tile, last_tile)) * S::kBBytes;
+#pragma unroll
+		for (uint32_t n = 0; n < kBPieces; n++) {
+			// every wave issues every piece (the vmcnt arithmetic wants equal counts): pieces past the digit bytes
+			// repeat the last one
+			const uint32_t p = min(4u * n + wave_u, S::kBChunks / 64u - 1u);
+			Glds16(bsrc + 1024ull * p + 16u * lane, base + S::kGenoBytes + p * 1024u);
+		}
+	};
+
+	// ---- compute roles ----
+	// this lane's word of every row of its k-group: wave `wave` owns words [wave * TS, (wave + 1) * TS) of the
+	// workgroup's stripe, lane x the word x / (16 / TS) of those; with TS < 16 it uses bytes b0 .. of the
+	// transposed words
+	constexpr uint32_t kLanesPerWord = 16u / TS;
+	const uint32_t word = wave * TS + x / kLanesPerWord;
+	const uint32_t word_phys = word ^ ((g & 1u) * S::kSwizzleChunks * 4u);
+	const uint32_t byte_shift = 8u * ((x % kLanesPerWord) * (TS / 4u));
+	const uint32_t geno_off = (16u * g) * S::kRowBytes + 4u * word_phys;
+	const uint32_t k1001 = 0x1001u;
+
+	v4i acc[TS][NT];
+#pragma unroll
+	for (int t = 0; t < TS; t++) {
+#pragma unroll
+		for (int nt = 0; nt < NT; nt++) {
+			acc[t][nt] = v4i {0, 0, 0, 0};
+		}
+	}
+
+	auto compute = [&](uint32_t slot) {
+		// the 16 variants of this lane's k-group, 16 samples each -> bytes of four calls
+		uint32_t X[4][4];
+		const uint8_t *gp = &s_ring[slot][geno_off];
+#pragma unroll
+		for (int q = 0; q < 4; q++) {
+			const uint32_t w0 = *reinterpret_cast<const uint32_t *>(gp + (4 * q + 0) * S::kRowBytes);
+			const uint32_t w1 = *reinterpret_cast<const uint32_t *>(gp + (4 * q + 1) * S::kRowBytes);
+			const uint32_t w2 = *reinterpret_cast<const uint32_t *>(gp + (4 * q + 2) * S::kRowBytes);
+			const uint32_t w3 = *reinterpret_cast<const uint32_t *>(gp + (4 * q + 3) * S::kRowBytes);
+			Transpose4(w0, w1, w2, w3, X[q]);
+			if (TS < 16) {
+#pragma unroll
+				for (int k = 0; k < 4; k++) {
+					X[q][k] >>= byte_shift;
+				}
+			}
+		}
+		const v4i *bp = reinterpret_cast<const v4i *>(&s_ring[slot][S::kGenoBytes]);
+#pragma unroll
+		for (int nt0 = 0; nt0 < NT; nt0 += 2) {
+			// digit operands of up to two tiles stay in registers across the samples
+			constexpr int kHold = NT >= 2 ? 2 : 1;
+			v4i bg[kHold], bm[kHold];
+#pragma unroll
+			for (int h = 0; h < kHold; h++) {
+				if (nt0 + h < NT) {
+					bg[h] = bp[((0 * NT + nt0 + h) * 4 + g) * 16 + x];
+					bm[h] = bp[((1 * NT + nt0 + h) * 4 + g) * 16 + x];
+				}
+			}
+#pragma unroll
+			for (int bb = 0; bb < TS / 4; bb++) {
+#pragma unroll
+				for (int k = 0; k < 4; k++) {
+					v4i u, m;
+#define PGH_SP(Q)                                                                                                      \
+	u[Q] = static_cast<int>(bb == 0   ? Spread<0>(X[Q][k], k1001)                                                      \
+	                        : bb == 1 ? Spread<1>(X[Q][k], k1001)                                                      \
+	                        : bb == 2 ? Spread<2>(X[Q][k], k1001)                                                      \
+	                                  : Spread<3>(X[Q][k], k1001));                                                    \
+	m[Q] = static_cast<int>(__builtin_amdgcn_perm(0u, 0x01000000u, static_cast<uint32_t>(u[Q])));
+					PGH_SP(0)
+					PGH_SP(1)
+					PGH_SP(2)
+					PGH_SP(3)
+#undef PGH_SP
+					const int t = bb * 4 + k;
+#pragma unroll
+					for (int h = 0; h < kHold; h++) {
+						if (nt0 + h < NT) {
+							acc[t][nt0 + h] = __builtin_amdgcn_mfma_i32_16x16x64_i8(u, bg[h], acc[t][nt0 + h], 0, 0, 0);
+							acc[t][nt0 + h] = __builtin_amdgcn_mfma_i32_16x16x64_i8(m, bm[h], acc[t][nt0 + h], 0, 0, 0);
+						}
+					}
+				}
+			}
+		}
+	};
+
+	// Ring protocol (kRing = 4).  Trip t multiplies slot t % 4 while the DMAs of tiles t+1 .. t+3 are in flight or landed;
+	// it first issues tile t+3 into the slot trip t-1 finished with (every wave passed that trip's barrier).
+	// At the end each wave waits until all but its 2 x kPieces youngest DMAs have landed -- its share of tile
+	// t+1, and the row numbers it asked for three trips ago -- and the barrier makes that true of every wave's
+	// share before anyone reads them.
+#define PGH_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+#pragma unroll
+	for (uint32_t d = 0; d < kRowAhead; d++) {
+		issue_rows(tile_begin + d);
+	}
+	PGH_WAIT_VM(0);
+	__builtin_amdgcn_s_barrier();
+#pragma unroll
+	for (uint32_t d = 0; d + 1 < kRing; d++) {
+		issue(tile_begin + d, d);
+	}
+	PGH_WAIT_VM(kPieces * (kRing - 2));
+	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+	__builtin_amdgcn_s_barrier();
+	uint32_t slot = 0;
+	for (uint32_t tile = tile_begin; tile < tile_end; tile++) {
+		issue(tile + (kRing - 1), (slot + kRing - 1) % kRing);
+		compute(slot);
+		PGH_WAIT_VM(kPieces * (kRing - 2));
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		__builtin_amdgcn_s_barrier();
+		slot = (slot + 1) % kRing;
+	}
+	PGH_WAIT_VM(0); // the tail's repeats must land before the LDS is handed back
+#undef PGH_WAIT_VM
+
+	// ---- epilogue: lane (j = lane & 15, g) holds digit column 16 nt + j of the sample slots 4 g + r ----
+	const uint32_t wave_sample0 = blockIdx.x * S::kSamplesPerGroup + wave * 16u * TS;
+#pragma unroll
+	for (int nt = 0; nt < NT; nt++) {
+		const uint32_t J = 16u * nt + x;
+		const uint32_t tg = target[J];
+		if (tg == 0xffffffffu) {
+			continue;
+		}
+		const double mu = mult[J];
+#pragma unroll
+		for (int t = 0; t < TS; t++) {
+			const uint32_t bb = t >> 2, k = t & 3;
+			const uint32_t off = 4u * bb + (k == 0 ? 0u : k == 1 ? 2u : k == 2 ? 1u : 3u);
+#pragma unroll
+			for (int r = 0; r < 4; r++) {
+				const uint32_t s = wave_sample0 + TS * (4u * g + r) + off;
+				const int v = acc[t][nt][r];
+				if (s < sample_ct && v != 0) {
+					if (tg < n_cols) {
+						unsafeAtomicAdd(score + static_cast<uint64_t>(s) * out_stride + tg, mu * static_cast<double>(v));
+					} else if (tg == n_cols) {
+						if (dosage_sum) {
+							unsafeAtomicAdd(dosage_sum + s, mu * static_cast<double>(v));
+						}
+					} else if (missing_ct) {
+						atomicAdd(missing_ct + s, static_cast<uint32_t>(v));
+					}
+				}
+			}
+		}
+	}
+}
+
+// score[s][c] += k0[c]; dosage_sum[s] += k0[n_cols]
+__global__ __launch_bounds__(256) void k_i8_constants(uint32_t sample_ct, uint32_t n_cols, const double *__restrict__ k0,
+                                                      double *__restrict__ score, uint32_t out_stride,
+                                                      double *__restrict__ dosage_sum) {
+	const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+	if (s >= sample_ct) {
+		return;
+	}
+	for (uint32_t c = 0; c < n_cols; c++) {
+		const double k = k0[c];
+		if (k != 0.0) {
+			score[static_cast<uint64_t>(s) * out_stride + c] += k;
+		}
+	}
+	if (dosage_sum && k0[n_cols] != 0.0) {
+		dosage_sum[s] += k0[n_cols];
+	}
+}
+
+__global__ __launch_bounds__(256) void k_i8_rowidx(const uint32_t *__restrict__ vlist, uint32_t n_var, uint32_t n_pad,
+                                                   uint32_t *__restrict__ rowidx) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i < n_pad) {
+		rowidx[i] = i < n_var ? vlist[i] : vlist[n_var - 1]; // padding rows carry all-zero digits
+	}
+}
+
+} // namespace
+
+uint32_t ScoreI8Tiles16(uint32_t n_cols) {
+	return (DigitColumns(n_cols) + 15u) / 16u;
+}
+
+ScoreI8Sizes ScoreI8Bytes(uint32_t n_var, uint32_t n_cols) {
+	ScoreI8Sizes z;
+	z.n_tiles = ((n_var + kTileVariants - 1) / kTileVariants + 1u) & ~1u; // an even number: the kernel walks tile pairs
+	z.n_tiles16 = ScoreI8Tiles16(n_cols);
+	z.bmat = static_cast<size_t>(z.n_tiles) * 2u * z.n_tiles16 * 1024u;
+	z.rowidx = sizeof(uint32_t) * static_cast<size_t>(z.n_tiles) * kTileVariants;
+	z.cols = static_cast<size_t>(z.n_tiles16) * 16u * (sizeof(double) + sizeof(uint32_t));
+	z.small = sizeof(double) * 3u * (n_cols + 2u);
+	return z;
+}
+
+hipError_t LaunchScoreI8Prepare(const uint32_t *vlist, uint32_t n_var, const double *weights, uint32_t w_stride,
+                                uint32_t n_cols, const double *ts, const double *td, const uint32_t *ac,
+                                bool count_missing, const ScoreI8Buffers &b, hipStream_t stream) {
+	if (n_var == 0) {
+		return hipSuccess;
+	}
+	const ScoreI8Sizes z = ScoreI8Bytes(n_var, n_cols);
+	hipError_t e = hipMemsetAsync(b.bmat, 0, z.bmat, stream);
+	if (e == hipSuccess) {
+		e = hipMemsetAsync(b.colmax, 0, z.small, stream); // colmax, k0, scale_exp
+	}
+	if (e != hipSuccess) {
+		return e;
+	}
+	const uint32_t blocks = (n_var + 255) / 256;
+	hipLaunchKernelGGL(k_i8_rowidx, dim3((z.n_tiles * kTileVariants + 255) / 256), dim3(256), 0, stream, vlist, n_var,
+	                   z.n_tiles * kTileVariants, b.rowidx);
+	hipLaunchKernelGGL(k_i8_ranges, dim3(blocks < 1024 ? blocks : 1024, n_cols + 1), dim3(256), 0, stream, n_var, n_cols,
+	                   weights, w_stride, ts, td, b.colmax, b.k0);
+	hipLaunchKernelGGL(k_i8_columns, dim3((z.n_tiles16 * 16 + 63) / 64), dim3(64), 0, stream, n_cols, z.n_tiles16,
+	                   b.colmax, b.scale_exp, b.mult, b.target);
+	hipLaunchKernelGGL(k_i8_digits, dim3(blocks, n_cols + 2), dim3(256), 0, stream, n_var, n_cols, z.n_tiles16, weights,
+	                   w_stride, ts, td, ac, count_missing ? 1 : 0, b.scale_exp, b.bmat);
+	return hipGetLastError();
+}
+
+template <int NT, int TS>
+static hipError_t LaunchI8(const RowView &view, uint32_t n_var, uint32_t n_cols, const ScoreI8Buffers &b, double *score,
+                           uint32_t out_stride, double *dosage_sum, uint32_t *missing_ct, hipStream_t stream) {
+	using S = I8Shape<NT, TS>;
+	const uint32_t n_tiles = ScoreI8Bytes(n_var, n_cols).n_tiles;
+	const uint32_t groups = (view.sample_ct + S::kSamplesPerGroup - 1) / S::kSamplesPerGroup;
+	// enough workgroups to fill the chip several times over; a slice keeps the int32 sums far from overflow
+	// (|sum| <= 512 per variant) and its digit bytes inside one XCD's L2
+	uint32_t want = (8192u + groups - 1) / groups;
+	uint32_t tps = (n_tiles + want - 1) / want;
+	const uint32_t tps_min = 16, tps_max = 16384; // 1,024 .. 1,048,576 variants
+	tps = tps < tps_min ? tps_min : (tps > tps_max ? tps_max : tps);
+	tps = (tps + 1u) & ~1u;
+	uint32_t slices = (n_tiles + tps - 1) / tps;
+	if (slices > 65535u) {
+		return hipErrorInvalidValue;
+	}
+	hipLaunchKernelGGL((k_score_i8<NT, TS>), dim3(groups, slices), dim3(256), 0, stream, view.rows, view.pitch,
+	                   view.sample_ct, b.rowidx, n_tiles, tps, b.bmat, b.mult, b.target, n_cols, score, out_stride,
+	                   dosage_sum, missing_ct);
+	return hipGetLastError();
+}
+
+hipError_t LaunchScoreI8(const RowView &view, uint32_t n_var, uint32_t n_cols, const ScoreI8Buffers &b, double *score,
+                         uint32_t out_stride, double *dosage_sum, uint32_t *missing_ct, hipStream_t stream) {
+	if (n_var == 0) {
+		return hipSuccess;
+	}
+	const uint32_t nt = ScoreI8Tiles16(n_cols);
+	hipError_t e;
+	if (nt == 1) {
+		e = LaunchI8<1, 16>(view, n_var, n_cols, b, score, out_stride, dosage_sum, missing_ct, stream);
+	} else if (nt == 2) {
+		e = LaunchI8<2, 16>(view, n_var, n_cols, b, score, out_stride, dosage_sum, missing_ct, stream);
+	} else if (nt <= 4) {
+		e = nt == 3 ? LaunchI8<3, 8>(view, n_var, n_cols, b, score, out_stride, dosage_sum, missing_ct, stream)
+		            : LaunchI8<4, 8>(view, n_var, n_cols, b, score, out_stride, dosage_sum, missing_ct, stream);
+	} else if (nt <= 8) {
+		switch (nt) {
+		case 5:
+			e = LaunchI8<5, 4>(view, n_var, n_cols, b, score, out_stride, dosage_sum, missing_ct, stream);
+			break;
+		case 6:
+			e = LaunchI8<6, 4>(view, n_var, n_cols, b, score, out_stride, dosage_sum, missing_ct, stream);
+			break;
+		case 7:
+			e = LaunchI8<7, 4>(view, n_var, n_cols, b, score, out_stride, dosage_sum, missing_ct, stream);
+			break;
+		default:
+			e = LaunchI8<8, 4>(view, n_var, n_cols, b, score, out_stride, dosage_sum, missing_ct, stream);
+			break;
+		}
+	} else {
+		return hipErrorInvalidValue; // the caller splits wider weight sets into passes of <= kI8MaxCols columns
+	}
+	if (e != hipSuccess) {
+		return e;
+	}
+	hipLaunchKernelGGL(k_i8_constants, dim3((view.sample_ct + 255) / 256), dim3(256), 0, stream, view.sample_ct, n_cols,
+	                   b.k0, score, out_stride, dosage_sum);
+	return hipGetLastError();
+}
+
+} // namespace pgh
