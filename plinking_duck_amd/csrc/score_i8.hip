@@ -397,9 +397,7 @@ __global__ __launch_bounds__(256) void k_score_i8(const uint8_t *__restrict__ ro
 	constexpr uint32_t kLanesPerWord = 16u / TS;
 	const uint32_t word = wave * TS + x / kLanesPerWord;
 	const uint32_t word_phys = word ^ ((g & 1u) * S::kSwizzleChunks * 4u);
-	const uint32_t byte_shift = 8u * ((x % kLanesPerWord) * (TS / 4u));
 	const uint32_t geno_off = (16u * g) * S::kRowBytes + 4u * word_phys;
-	const uint32_t k1001 = 0x1001u;
 
 	v4i acc[TS][NT];
 #pragma unroll
@@ -410,9 +408,23 @@ __global__ __launch_bounds__(256) void k_score_i8(const uint8_t *__restrict__ ro
 		}
 	}
 
+	// Operand bytes.  The matrix instruction wants, per lane, sixteen variants of ONE sample as sixteen bytes;
+	// a packed word holds sixteen samples of ONE variant.  Byte c of such a word is samples 4c .. 4c+3, so two
+	// byte permutes gather byte c of four variants' words into one register G (byte j = variant 4q + j); the call
+	// of sample 4c + e then sits at bits 2e, 2e+1 of EVERY byte and a single AND leaves the instruction's operand
+	// -- scaled by 4^e, which is the same for the whole matrix row (one sample) and is divided out of that
+	// sample's sums at the end.  e = 3 would reach 192: it is taken from G >> 1 instead (scale 32).  The
+	// missing plane is one three-input AND of G, G >> 1 and a bit mask, at the same scale.  ~12 vector ops per
+	// sixteen calls and both planes.
+	constexpr uint32_t kBytesPerLane = TS / 4u; // bytes of each word this lane turns into operands
+	uint32_t sel_first = 0;                     // TS < 16: which bytes -- lane-dependent permute selectors
+	if (TS == 8) {
+		sel_first = (x & 1u) ? 0x07030602u : 0x05010400u;
+	} else if (TS == 4) {
+		sel_first = ((4u + (x & 3u)) << 8) | (x & 3u);
+	}
 	auto compute = [&](uint32_t slot) {
-		// the 16 variants of this lane's k-group, 16 samples each -> bytes of four calls
-		uint32_t X[4][4];
+		uint32_t G[4][kBytesPerLane];
 		const uint8_t *gp = &s_ring[slot][geno_off];
 #pragma unroll
 		for (int q = 0; q < 4; q++) {
@@ -420,11 +432,18 @@ __global__ __launch_bounds__(256) void k_score_i8(const uint8_t *__restrict__ ro
 			const uint32_t w1 = *reinterpret_cast<const uint32_t *>(gp + (4 * q + 1) * S::kRowBytes);
 			const uint32_t w2 = *reinterpret_cast<const uint32_t *>(gp + (4 * q + 2) * S::kRowBytes);
 			const uint32_t w3 = *reinterpret_cast<const uint32_t *>(gp + (4 * q + 3) * S::kRowBytes);
-			Transpose4(w0, w1, w2, w3, X[q]);
-			if (TS < 16) {
-#pragma unroll
-				for (int k = 0; k < 4; k++) {
-					X[q][k] >>= byte_shift;
+			if (TS == 16) {
+				const uint32_t pa = __builtin_amdgcn_perm(w1, w0, 0x05010400u), pb = __builtin_amdgcn_perm(w1, w0, 0x07030602u);
+				const uint32_t qa = __builtin_amdgcn_perm(w3, w2, 0x05010400u), qb = __builtin_amdgcn_perm(w3, w2, 0x07030602u);
+				G[q][0] = __builtin_amdgcn_perm(qa, pa, 0x05040100u);
+				G[q][1 % kBytesPerLane] = __builtin_amdgcn_perm(qa, pa, 0x07060302u);
+				G[q][2 % kBytesPerLane] = __builtin_amdgcn_perm(qb, pb, 0x05040100u);
+				G[q][3 % kBytesPerLane] = __builtin_amdgcn_perm(qb, pb, 0x07060302u);
+			} else {
+				const uint32_t pa = __builtin_amdgcn_perm(w1, w0, sel_first), qa = __builtin_amdgcn_perm(w3, w2, sel_first);
+				G[q][0] = __builtin_amdgcn_perm(qa, pa, 0x05040100u);
+				if (TS == 8) {
+					G[q][1 % kBytesPerLane] = __builtin_amdgcn_perm(qa, pa, 0x07060302u);
 				}
 			}
 		}
@@ -442,22 +461,28 @@ __global__ __launch_bounds__(256) void k_score_i8(const uint8_t *__restrict__ ro
 				}
 			}
 #pragma unroll
-			for (int bb = 0; bb < TS / 4; bb++) {
+			for (int cc = 0; cc < static_cast<int>(kBytesPerLane); cc++) {
+				uint32_t h1[4], h2[4];
 #pragma unroll
-				for (int k = 0; k < 4; k++) {
+				for (int q = 0; q < 4; q++) {
+					h1[q] = G[q][cc] >> 1;
+					h2[q] = G[q][cc] >> 2;
+				}
+#pragma unroll
+				for (int e = 0; e < 4; e++) {
 					v4i u, m;
-#define PGH_SP(Q)                                                                                                      \
-	u[Q] = static_cast<int>(bb == 0   ? Spread<0>(X[Q][k], k1001)                                                      \
-	                        : bb == 1 ? Spread<1>(X[Q][k], k1001)                                                      \
-	                        : bb == 2 ? Spread<2>(X[Q][k], k1001)                                                      \
-	                                  : Spread<3>(X[Q][k], k1001));                                                    \
-	m[Q] = static_cast<int>(__builtin_amdgcn_perm(0u, 0x01000000u, static_cast<uint32_t>(u[Q])));
-					PGH_SP(0)
-					PGH_SP(1)
-					PGH_SP(2)
-					PGH_SP(3)
-#undef PGH_SP
-					const int t = bb * 4 + k;
+#pragma unroll
+					for (int q = 0; q < 4; q++) {
+						const uint32_t gq = G[q][cc];
+						if (e < 3) {
+							u[q] = static_cast<int>(gq & (0x03030303u << (2 * e)));
+							m[q] = static_cast<int>(gq & h1[q] & (0x01010101u << (2 * e)));
+						} else {
+							u[q] = static_cast<int>(h1[q] & 0x60606060u);
+							m[q] = static_cast<int>(h1[q] & h2[q] & 0x20202020u);
+						}
+					}
+					const int t = cc * 4 + e;
 #pragma unroll
 					for (int h = 0; h < kHold; h++) {
 						if (nt0 + h < NT) {
@@ -513,21 +538,22 @@ __global__ __launch_bounds__(256) void k_score_i8(const uint8_t *__restrict__ ro
 		const double mu = mult[J];
 #pragma unroll
 		for (int t = 0; t < TS; t++) {
-			const uint32_t bb = t >> 2, k = t & 3;
-			const uint32_t off = 4u * bb + (k == 0 ? 0u : k == 1 ? 2u : k == 2 ? 1u : 3u);
+			// sample t of the lane's span was multiplied at scale {1, 4, 16, 32}[t & 3]: exact powers of two
+			const int scale = (t & 3) == 3 ? 32 : (1 << (2 * (t & 3)));
+			const double mu_t = mu / static_cast<double>(scale);
 #pragma unroll
 			for (int r = 0; r < 4; r++) {
-				const uint32_t s = wave_sample0 + TS * (4u * g + r) + off;
+				const uint32_t s = wave_sample0 + TS * (4u * g + r) + t;
 				const int v = acc[t][nt][r];
 				if (s < sample_ct && v != 0) {
 					if (tg < n_cols) {
-						unsafeAtomicAdd(score + static_cast<uint64_t>(s) * out_stride + tg, mu * static_cast<double>(v));
+						unsafeAtomicAdd(score + static_cast<uint64_t>(s) * out_stride + tg, mu_t * static_cast<double>(v));
 					} else if (tg == n_cols) {
 						if (dosage_sum) {
-							unsafeAtomicAdd(dosage_sum + s, mu * static_cast<double>(v));
+							unsafeAtomicAdd(dosage_sum + s, mu_t * static_cast<double>(v));
 						}
 					} else if (missing_ct) {
-						atomicAdd(missing_ct + s, static_cast<uint32_t>(v));
+						atomicAdd(missing_ct + s, static_cast<uint32_t>(v / scale));
 					}
 				}
 			}
@@ -612,10 +638,10 @@ static hipError_t LaunchI8(const RowView &view, uint32_t n_var, uint32_t n_cols,
 	const uint32_t n_tiles = ScoreI8Bytes(n_var, n_cols).n_tiles;
 	const uint32_t groups = (view.sample_ct + S::kSamplesPerGroup - 1) / S::kSamplesPerGroup;
 	// enough workgroups to fill the chip several times over; a slice keeps the int32 sums far from overflow
-	// (|sum| <= 512 per variant) and its digit bytes inside one XCD's L2
+	// (operand bytes reach 96, digits 128) and its digit bytes inside one XCD's L2
 	uint32_t want = (8192u + groups - 1) / groups;
 	uint32_t tps = (n_tiles + want - 1) / want;
-	const uint32_t tps_min = 16, tps_max = 16384; // 1,024 .. 1,048,576 variants
+	const uint32_t tps_min = 16, tps_max = 1024; // 1,024 .. 65,536 variants: |int32 sum| <= 16,384 per variant
 	tps = tps < tps_min ? tps_min : (tps > tps_max ? tps_max : tps);
 	tps = (tps + 1u) & ~1u;
 	uint32_t slices = (n_tiles + tps - 1) / tps;
