@@ -52,6 +52,7 @@ SEED = 20260807
 MISSING_RATE = 0.02
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector/matrix peak
+I8_PEAK_TOPS = 5000.0       # dense int8 MFMA: 2x the bf16 rate (MI355X_MICROARCH.md, Matrix cores)
 
 
 def parse_args():
@@ -443,7 +444,7 @@ def main():
 
             # the plan picks the kernel by track density (api_analysis.cpp): all samples explicit, >= 40 %, below
             kernel_name = ("k_score_dosage_full" if args.dosage_rate >= 1.0 else
-                           "k_score_dosage" if args.dosage_rate >= 0.42 else "k_score_gemv_pairs + k_score_dosage_fix")
+                           "k_score_dosage" if args.dosage_rate >= 0.42 else "k_score_i8 + k_score_dosage_fix")
             metric = "plink_score(dosage) genotypes/s"
     elif args.workload == "missingsample":
         # plink_missing mode := 'sample': per-sample missing tallies over every variant (column sums)
@@ -568,6 +569,13 @@ def main():
         d_ac = torch.empty(n, dtype=torch.int32, device=dev)
         algo_bytes = m * (record_bytes + 8 * ncol)
         algo_flops = 2.0 * m * n * ncol
+        # the contraction runs on v_mfma_i32_16x16x64_i8 over exact fixed-point digits of the weights
+        # (score_i8.hip): 7 digit columns per weight column + 6 (dosage sum, missing count), 16 per tile,
+        # two planes (calls, missing calls) per tile, <= 17 weight columns per pass
+        i8_ops = 0.0
+        for c0 in range(0, ncol, 17):
+            tiles16 = (7 * min(17, ncol - c0) + 6 + 15) // 16
+            i8_ops += 2.0 * (((m + 127) // 128) * 128) * (((n + 15) // 16) * 16) * 16 * 2 * tiles16
         plan = ds.score_plan(vidx, w, None, L.SCORE_MEAN_IMPUTE)  # weights + per-variant tables resident
 
         def step(timed):
@@ -583,9 +591,9 @@ def main():
                 # per-sample partials of the variant shards: RCCL reduce over xGMI
                 sharding.reduce_partials(dist, [d_score, d_ac] if args.score_no_dosage_sum else [d_score, d_dos, d_ac])
 
-        kernel_name = "k_score_gemv_pairs" if ncol == 1 else ("k_accumulate_mfma" if ncol >= 3 else "k_score_accumulate")
+        kernel_name = "k_score_i8"
         metric = f"plink_score genotypes/s ({ncol} weight columns{', no dosage sum' if args.score_no_dosage_sum else ''})"
-        dtype = "f64"
+        dtype = "i8 x i8 -> i32 (exact base-256 digits of the f64 coefficients), f64 out"
 
     def barrier():
         if dist is not None:
@@ -619,7 +627,16 @@ def main():
         total_units = units_per_step * (world if args.scaling == "weak" else 1)  # sample pairs, every rank the same shape
     value = total_units * args.steps / elapsed
 
-    if algo_flops is not None and (args.workload == "pca" or args.score_cols >= 3):
+    if args.workload == "score" and args.score_cols >= 2:
+        # priced against the dense int8 matrix peak (the instruction the kernel issues); the f64 FLOP rate the
+        # same contraction would need on the FP64 pipes is given beside it
+        achieved = i8_ops / (kern_avg_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "achieved": achieved, "peak": I8_PEAK_TOPS, "unit": "TFLOP/s",
+                    "frac": achieved / I8_PEAK_TOPS, "traffic": None, "kernel": kernel_name,
+                    "kernel_ms_avg": kern_avg_ms, "launches_timed": len(kernel_ms), "ops": "int8 multiply-adds x 2",
+                    "f64_equivalent_tflops": algo_flops / (kern_avg_ms * 1e-3) / 1e12,
+                    "hbm_frac": algo_bytes / (kern_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    elif algo_flops is not None and args.workload == "pca":
         achieved = algo_flops / (kern_avg_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None, "kernel": kernel_name,

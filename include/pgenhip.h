@@ -130,6 +130,30 @@ const void *pgh_device_rows(const pgh_dataset *ds);
 /* CleanupPgr + CleanupPgfi (src/plink_freq.cpp:109-115). */
 void pgh_close(pgh_dataset *ds);
 
+/* ---- shard groups: one process, several devices -------------------------------
+ * The reference parallelises inside ONE process and merges per-thread partial sums under a mutex
+ * (src/plink_score.cpp:657-664, src/plink_missing.cpp:614-619, src/plink_pca.cpp:940-954).  A shard group is
+ * the same shape with devices in the place of threads: contiguous, ascending variant ranges of one file, one
+ * resident dataset per device, behind ONE pgh_dataset handle.  Every host-buffer entry point of this header
+ * accepts a group handle: per-variant outputs (pgh_counts_range, pgh_unpack_range, pgh_dosage_*, the pgh_get_*
+ * reader calls) are filled shard by shard with no exchange; per-sample outputs (pgh_missing_per_sample,
+ * pgh_sample_counts, pgh_score, pgh_pca) are reduced per shard on its device and the partials are summed on the
+ * first shard's device after device-to-device copies (xGMI between the GPUs of a node); pgh_ld_pairs computes the
+ * pairs that straddle a shard boundary on a scratch dataset built from the rows they name.  Subsets and readers
+ * created on a group handle are groups themselves.  The *_dev / plan entry points and pgh_device_rows take one
+ * device's dataset: hand them pgh_shard(group, k).
+ *
+ * pgh_open_sharded: pgh_open of n_devices near-equal ranges of [variant_begin, variant_end), concurrently, shard k
+ * on devices[k] (a device may be named more than once).  pgh_group_create: a group over datasets the caller made
+ * (pgh_open / pgh_synth_create / pgh_from_host_rows, each with pgh_set_device in effect); it takes ownership:
+ * pgh_close(group) closes them. */
+int pgh_open_sharded(const char *pgen_path, const char *pgi_path, uint32_t variant_begin, uint32_t variant_end,
+                     const int *devices, uint32_t n_devices, pgh_dataset **out, char *errbuf);
+int pgh_group_create(pgh_dataset *const *shards, uint32_t n_shards, pgh_dataset **out, char *errbuf);
+/* 0 for a plain dataset. */
+uint32_t pgh_shard_count(const pgh_dataset *ds);
+const pgh_dataset *pgh_shard(const pgh_dataset *ds, uint32_t k);
+
 /* ---- sample subsets ------------------------------------------------------ */
 
 /* Replaces BuildSampleSubset / PgrSetSampleSubsetIndex (src/plink_common.cpp:1222-1250,

@@ -15,6 +15,8 @@ extern "C" int pgh_counts_range_dev(const pgh_dataset *ds, const pgh_subset *sub
 	if (rc != PGH_OK) {
 		return rc;
 	}
+	PGH_ONE_DEVICE(ds);
+	PGH_ENTER(ds);
 	PGH_HIP(pgh::LaunchCounts(ds->View(), v_begin - ds->v_begin, nullptr, v_end - v_begin,
 	                          subset ? subset->d_mask2 : nullptr, subset ? subset->n_out : ds->sample_ct,
 	                          static_cast<uint32_t *>(d_out), static_cast<hipStream_t>(stream)),
@@ -32,6 +34,10 @@ extern "C" int pgh_counts_range(const pgh_dataset *ds, const pgh_subset *subset,
 	if (n == 0) {
 		return PGH_OK;
 	}
+	if (ds->IsGroup()) {
+		return pgh_group::CountsRange(ds, subset, v_begin, v_end, out, errbuf);
+	}
+	PGH_ENTER(ds);
 	DevBuf buf;
 	PGH_HIP(buf.Alloc(n * 16), "hipMalloc(counts)");
 	rc = pgh_counts_range_dev(ds, subset, v_begin, v_end, buf.p, hipStreamPerThread, errbuf);
@@ -61,6 +67,8 @@ extern "C" int pgh_missing_per_sample_dev(const pgh_dataset *ds, uint32_t v_begi
 	if (rc != PGH_OK) {
 		return rc;
 	}
+	PGH_ONE_DEVICE(ds);
+	PGH_ENTER(ds);
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	// per-slice partial rows: a few MB, stream-ordered so the call stays enqueue-only
 	const size_t scratch_bytes = pgh::MissingPerSampleScratchBytes(ds->record_bytes, v_end - v_begin);
@@ -83,6 +91,8 @@ extern "C" int pgh_fused_tally_dev(const pgh_dataset *ds, uint32_t v_begin, uint
 		SetErr(errbuf, "null argument");
 		return PGH_ERR_ARG;
 	}
+	PGH_ONE_DEVICE(ds);
+	PGH_ENTER(ds);
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	const size_t scratch_bytes = pgh::MissingPerSampleScratchBytes(ds->record_bytes, v_end - v_begin);
 	void *scratch = nullptr;
@@ -104,6 +114,10 @@ extern "C" int pgh_missing_per_sample(const pgh_dataset *ds, const pgh_subset *s
 	if (rc != PGH_OK) {
 		return rc;
 	}
+	if (ds->IsGroup()) {
+		return pgh_group::MissingPerSample(ds, subset, v_begin, v_end, out, errbuf);
+	}
+	PGH_ENTER(ds);
 	const uint32_t N = ds->sample_ct;
 	const uint32_t padded = (N + 63) / 64 * 64;
 	DevBuf buf;
@@ -130,6 +144,8 @@ extern "C" int pgh_sample_counts_dev(const pgh_dataset *ds, uint32_t v_begin, ui
 		SetErr(errbuf, "null argument");
 		return PGH_ERR_ARG;
 	}
+	PGH_ONE_DEVICE(ds);
+	PGH_ENTER(ds);
 	const uint32_t padded = (ds->sample_ct + 63) / 64 * 64;
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	const size_t scratch_bytes = pgh::ClassCounts3ScratchBytes(ds->record_bytes);
@@ -148,6 +164,10 @@ extern "C" int pgh_sample_counts(const pgh_dataset *ds, const pgh_subset *subset
 		SetErr(errbuf, "null argument");
 		return PGH_ERR_ARG;
 	}
+	if (ds->IsGroup()) {
+		return pgh_group::SampleCounts(ds, subset, variant_begin, n_var, vidx, counts, errbuf);
+	}
+	PGH_ENTER(ds);
 	int rc = CheckSubset(ds, subset, errbuf);
 	if (rc != PGH_OK) {
 		return rc;
@@ -211,6 +231,8 @@ extern "C" int pgh_unpack_range_dev(const pgh_dataset *ds, const pgh_subset *sub
 	if (rc != PGH_OK) {
 		return rc;
 	}
+	PGH_ONE_DEVICE(ds);
+	PGH_ENTER(ds);
 	const uint32_t n_out = subset ? subset->n_out : ds->sample_ct;
 	if (d_out && (out_pitch % 16 != 0 || out_pitch < (static_cast<size_t>(n_out) + 15) / 16 * 16)) {
 		SetErr(errbuf, "out_pitch must be a multiple of 16 covering the row");
@@ -245,6 +267,10 @@ extern "C" int pgh_unpack_range(const pgh_dataset *ds, const pgh_subset *subset,
 	if (rows == 0 || n_out == 0) {
 		return PGH_OK;
 	}
+	if (ds->IsGroup()) {
+		return pgh_group::UnpackRange(ds, subset, v_begin, v_end, out, validity, missing_code, errbuf);
+	}
+	PGH_ENTER(ds);
 	const size_t out_pitch = (static_cast<size_t>(n_out) + 15) / 16 * 16;
 	const size_t val_words = (n_out + 63) / 64;
 	// chunk the range so the device staging stays bounded (output is 4x the input)
@@ -316,6 +342,8 @@ extern "C" int pgh_dosage_sums_dev(const pgh_dataset *ds, const pgh_subset *subs
 		SetErr(errbuf, "null argument");
 		return PGH_ERR_ARG;
 	}
+	PGH_ONE_DEVICE(ds);
+	PGH_ENTER(ds);
 	PGH_HIP(pgh::LaunchDosageSums(ds->View(), ds->Dosage(), v_begin - ds->v_begin, nullptr, v_end - v_begin,
 	                              subset ? subset->d_include : nullptr, static_cast<uint64_t *>(d_sums),
 	                              static_cast<hipStream_t>(stream)),
@@ -329,6 +357,10 @@ extern "C" int pgh_dosage_sums(const pgh_dataset *ds, const pgh_subset *subset, 
 		SetErr(errbuf, "null argument");
 		return PGH_ERR_ARG;
 	}
+	if (ds->IsGroup()) {
+		return n_variants ? pgh_group::DosageSums(ds, subset, variant_begin, n_variants, vidx, sums, errbuf) : PGH_OK;
+	}
+	PGH_ENTER(ds);
 	int rc = CheckSubset(ds, subset, errbuf);
 	if (rc != PGH_OK || n_variants == 0) {
 		return rc;
@@ -364,6 +396,8 @@ extern "C" int pgh_dosage_unpack_dev(const pgh_dataset *ds, const pgh_subset *su
 		SetErr(errbuf, "out_stride must cover the row");
 		return PGH_ERR_ARG;
 	}
+	PGH_ONE_DEVICE(ds);
+	PGH_ENTER(ds);
 	PGH_HIP(pgh::LaunchDosageUnpack(ds->View(), ds->Dosage(), v_begin - ds->v_begin, nullptr, v_end - v_begin,
 	                                subset ? subset->d_sel : nullptr, n_out, static_cast<double *>(d_out), out_stride,
 	                                static_cast<hipStream_t>(stream)),
@@ -377,6 +411,10 @@ extern "C" int pgh_dosage_unpack(const pgh_dataset *ds, const pgh_subset *subset
 		SetErr(errbuf, "null argument");
 		return PGH_ERR_ARG;
 	}
+	if (ds->IsGroup()) {
+		return n_variants ? pgh_group::DosageUnpack(ds, subset, variant_begin, n_variants, vidx, out, errbuf) : PGH_OK;
+	}
+	PGH_ENTER(ds);
 	int rc = CheckSubset(ds, subset, errbuf);
 	const uint32_t n_out = subset ? subset->n_out : ds->sample_ct;
 	if (rc != PGH_OK || n_variants == 0 || n_out == 0) {
@@ -415,6 +453,7 @@ static int UnpackSamples(const pgh_dataset *ds, const pgh_subset *subset, uint32
 		SetErr(errbuf, "null argument");
 		return PGH_ERR_ARG;
 	}
+	PGH_ENTER(ds);
 	int rc = CheckSubset(ds, subset, errbuf);
 	const uint32_t n_out = subset ? subset->n_out : ds->sample_ct;
 	if (rc != PGH_OK || n_variants == 0 || n_out == 0) {
@@ -444,6 +483,9 @@ static int UnpackSamples(const pgh_dataset *ds, const pgh_subset *subset, uint32
 
 extern "C" int pgh_unpack_samples(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_variants,
                                   const uint32_t *vidx, int8_t *out, int missing_code, char *errbuf) {
+	if (ds && ds->IsGroup()) {
+		return n_variants ? pgh_group::UnpackSamples(ds, subset, n_variants, vidx, out, missing_code, errbuf) : PGH_OK;
+	}
 	return UnpackSamples<int8_t>(ds, subset, n_variants, vidx, out, errbuf,
 	                             [&](const uint32_t *d_list, uint32_t k0, uint32_t cnt, int8_t *d_out, hipStream_t st) {
 		                             return pgh::LaunchUnpackTransposed(ds->View(), d_list, n_variants,
@@ -454,6 +496,9 @@ extern "C" int pgh_unpack_samples(const pgh_dataset *ds, const pgh_subset *subse
 
 extern "C" int pgh_dosage_unpack_samples(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_variants,
                                          const uint32_t *vidx, double *out, char *errbuf) {
+	if (ds && ds->IsGroup()) {
+		return n_variants ? pgh_group::DosageUnpackSamples(ds, subset, n_variants, vidx, out, errbuf) : PGH_OK;
+	}
 	return UnpackSamples<double>(ds, subset, n_variants, vidx, out, errbuf,
 	                             [&](const uint32_t *d_list, uint32_t k0, uint32_t cnt, double *d_out, hipStream_t st) {
 		                             return pgh::LaunchDosageUnpackTransposed(ds->View(), ds->Dosage(), d_list, n_variants,
@@ -515,6 +560,8 @@ extern "C" int pgh_score_plan_create(const pgh_dataset *ds, const pgh_subset *su
 		return PGH_ERR_ARG;
 	}
 	*out = nullptr;
+	PGH_ONE_DEVICE(ds);
+	PGH_ENTER(ds);
 	if (mode < 0 || mode > 2) {
 		SetErr(errbuf, "unknown score mode");
 		return PGH_ERR_ARG;
@@ -677,6 +724,7 @@ extern "C" int pgh_score_run_dev(const pgh_score_plan *plan, void *d_score_sum, 
 		return PGH_ERR_ARG;
 	}
 	const pgh_dataset *ds = plan->ds;
+	PGH_ENTER(ds);
 	const uint32_t N = ds->sample_ct;
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	PGH_HIP(hipMemsetAsync(d_score_sum, 0, sizeof(double) * N * plan->n_cols, st), "score memset");
@@ -765,6 +813,8 @@ extern "C" int pgh_score_run_dev(const pgh_score_plan *plan, void *d_score_sum, 
 extern "C" int pgh_score_dev(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_scored, const uint32_t *vidx,
                              const double *weights, const uint8_t *flip, uint32_t n_cols, int mode, void *d_score_sum,
                              void *d_dosage_sum, void *d_allele_ct, void *stream, char *errbuf) {
+	PGH_ONE_DEVICE(ds);
+	PGH_ENTER(ds);
 	pgh_score_plan *plan = nullptr;
 	int rc = pgh_score_plan_create(ds, subset, n_scored, vidx, weights, flip, n_cols, mode, &plan, errbuf);
 	if (rc != PGH_OK) {
@@ -788,6 +838,11 @@ extern "C" int pgh_score(const pgh_dataset *ds, const pgh_subset *subset, uint32
 		SetErr(errbuf, "null dataset");
 		return PGH_ERR_ARG;
 	}
+	if (ds->IsGroup()) {
+		return pgh_group::Score(ds, subset, n_scored, vidx, weights, flip, n_cols, mode, score_sum, dosage_sum, allele_ct,
+		                        errbuf);
+	}
+	PGH_ENTER(ds);
 	const uint32_t N = ds->sample_ct;
 	DevBuf d_score, d_dos, d_ac;
 	PGH_HIP(d_score.Alloc(sizeof(double) * N * std::max<uint32_t>(1, n_cols)), "hipMalloc(score out)");
@@ -822,6 +877,10 @@ extern "C" int pgh_score(const pgh_dataset *ds, const pgh_subset *subset, uint32
 extern "C" int pgh_pca(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_var, const uint32_t *vidx,
                        const double *center, const double *inv_stdev, uint32_t n_pcs, const double *g1_init,
                        double *eigenvalues, double *eigenvectors, char *errbuf) {
+	if (ds && ds->IsGroup()) {
+		return pgh_group::Pca(ds, subset, n_var, vidx, center, inv_stdev, n_pcs, g1_init, eigenvalues, eigenvectors,
+		                      errbuf);
+	}
 	return pgh_pca_sharded(ds, subset, n_var, vidx, center, inv_stdev, n_var, n_pcs, g1_init, nullptr, nullptr,
 	                       eigenvalues, eigenvectors, errbuf);
 }
@@ -839,6 +898,8 @@ extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, 
 		SetErr(errbuf, "n_var_total must cover this shard's variants (and equal them without an all-reduce)");
 		return PGH_ERR_ARG;
 	}
+	PGH_ONE_DEVICE(ds);
+	PGH_ENTER(ds);
 	int rc = CheckSubset(ds, subset, errbuf);
 	if (rc != PGH_OK) {
 		return rc;
@@ -1119,6 +1180,8 @@ extern "C" int pgh_ld_pairs_dev(const pgh_dataset *ds, const pgh_subset *subset,
 		SetErr(errbuf, "null argument");
 		return PGH_ERR_ARG;
 	}
+	PGH_ONE_DEVICE(ds);
+	PGH_ENTER(ds);
 	int rc = CheckSubset(ds, subset, errbuf);
 	if (rc != PGH_OK) {
 		return rc;
@@ -1203,6 +1266,10 @@ extern "C" int pgh_ld_pairs(const pgh_dataset *ds, const pgh_subset *subset, uin
 	if (n_pairs == 0) {
 		return PGH_OK;
 	}
+	if (ds && ds->IsGroup()) {
+		return pgh_group::LdPairs(ds, subset, n_pairs, vidx_a, vidx_b, sums, errbuf);
+	}
+	PGH_ENTER(ds);
 	DevBuf d_out;
 	PGH_HIP(d_out.Alloc(24ull * n_pairs), "hipMalloc(ld)");
 	int rc = pgh_ld_pairs_dev(ds, subset, n_pairs, vidx_a, vidx_b, d_out.p, hipStreamPerThread, errbuf);

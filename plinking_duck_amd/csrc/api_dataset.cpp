@@ -904,6 +904,8 @@ extern "C" int pgh_synth_add_dosage(pgh_dataset *ds, double rate, uint64_t seed,
 		SetErr(errbuf, "bad argument (null dataset, tracks already present, or rate outside [0, 1])");
 		return PGH_ERR_ARG;
 	}
+	PGH_ONE_DEVICE(ds);
+	PGH_ENTER(ds);
 	const uint32_t rows = ds->v_end - ds->v_begin;
 	const uint32_t words = (ds->sample_ct + 63) / 64;
 	if (rows == 0) {
@@ -1171,6 +1173,10 @@ extern "C" int pgh_copy_rows_to_host(const pgh_dataset *ds, uint32_t v_begin, ui
 		SetErr(errbuf, "bad destination");
 		return PGH_ERR_ARG;
 	}
+	if (ds->IsGroup()) {
+		return pgh_group::CopyRowsToHost(ds, v_begin, v_end, rows, row_stride, errbuf);
+	}
+	PGH_ENTER(ds);
 	PGH_HIP(hipMemcpy2D(rows, row_stride, ds->d_rows + static_cast<uint64_t>(v_begin - ds->v_begin) * ds->pitch,
 	                    ds->pitch, ds->record_bytes, v_end - v_begin, hipMemcpyDeviceToHost),
 	        "row download");
@@ -1180,6 +1186,9 @@ extern "C" int pgh_copy_rows_to_host(const pgh_dataset *ds, uint32_t v_begin, ui
 extern "C" int pgh_get_info(const pgh_dataset *ds, pgh_info *out) {
 	if (!ds || !out) {
 		return PGH_ERR_ARG;
+	}
+	if (ds->IsGroup()) {
+		return pgh_group::GetInfo(ds, out);
 	}
 	if (ds->has_file) {
 		FillInfo(ds->index, out);
@@ -1201,13 +1210,18 @@ extern "C" int pgh_get_info(const pgh_dataset *ds, pgh_info *out) {
 }
 
 extern "C" const void *pgh_device_rows(const pgh_dataset *ds) {
-	return ds ? ds->d_rows : nullptr;
+	return ds ? ds->d_rows : nullptr; // NULL for a shard group: ask its shards
 }
 
 extern "C" void pgh_close(pgh_dataset *ds) {
 	if (!ds) {
 		return;
 	}
+	if (ds->IsGroup()) {
+		pgh_group::Close(ds);
+		return;
+	}
+	PGH_ENTER(ds);
 	for (void *p : {static_cast<void *>(ds->d_rows), static_cast<void *>(ds->d_dos_row_of),
 	                static_cast<void *>(ds->d_dos_present), static_cast<void *>(ds->d_dos_rank),
 	                static_cast<void *>(ds->d_dos_val_off), static_cast<void *>(ds->d_dos_values),
@@ -1230,6 +1244,10 @@ extern "C" int pgh_subset_create(const pgh_dataset *ds, const uint64_t *sample_i
 		return PGH_ERR_ARG;
 	}
 	*out = nullptr;
+	if (ds->IsGroup()) {
+		return pgh_group::SubsetCreate(ds, sample_include, out, errbuf);
+	}
+	PGH_ENTER(ds);
 	std::unique_ptr<pgh_subset> ss(new pgh_subset());
 	ss->ds = ds;
 	const uint32_t N = ds->sample_ct;
@@ -1274,6 +1292,10 @@ extern "C" void pgh_subset_destroy(pgh_subset *ss) {
 	if (!ss) {
 		return;
 	}
+	for (pgh_subset *part : ss->parts) {
+		pgh_subset_destroy(part);
+	}
+	PGH_ENTER(ss->ds);
 	if (ss->d_mask2) {
 		(void)hipFree(ss->d_mask2);
 	}

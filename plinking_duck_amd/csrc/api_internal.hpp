@@ -62,6 +62,13 @@ struct pgh_dataset {
 	std::vector<int32_t> ph_row_of;
 	uint64_t *d_ph_present = nullptr;
 	uint64_t *d_ph_info = nullptr;
+	// A shard GROUP (pgh_open_sharded / pgh_group_create): contiguous, ascending variant ranges of one file, one
+	// resident dataset per entry, each on its own device (api_sharded.cpp).  The group handle itself holds no
+	// rows (device == -1); [v_begin, v_end) is the union of its shards' ranges.
+	std::vector<pgh_dataset *> shards;
+	bool IsGroup() const {
+		return !shards.empty();
+	}
 
 	RowView View() const {
 		return RowView {d_rows, pitch, sample_ct, record_bytes};
@@ -86,6 +93,7 @@ struct pgh_subset {
 	uint8_t *d_mask2 = nullptr;    // one pitched row of 01 slots
 	uint64_t *d_include = nullptr; // the include words, for the kernels that walk samples bit by bit
 	uint32_t *d_sel = nullptr;
+	std::vector<pgh_subset *> parts; // subset of a shard group: one staged copy per shard (device)
 };
 
 struct pgh_reader {
@@ -102,7 +110,71 @@ struct pgh_reader {
 	double *h_dosage = nullptr;   // pinned
 	uint64_t *h_phase = nullptr;  // pinned: phasepresent + phaseinfo words of one variant
 	std::string err;
+	std::vector<pgh_reader *> parts; // reader of a shard group: one per shard, created on first use
 };
+
+// Every entry point runs on the device that holds the dataset it was handed, whatever device the calling thread
+// had current (one process may hold shards on several devices); the previous device is restored on return.
+struct DeviceScope {
+	int prev = -1;
+	bool changed = false;
+	explicit DeviceScope(int device) {
+		if (device >= 0 && hipGetDevice(&prev) == hipSuccess && prev != device) {
+			changed = hipSetDevice(device) == hipSuccess;
+		}
+	}
+	DeviceScope(const DeviceScope &) = delete;
+	DeviceScope &operator=(const DeviceScope &) = delete;
+	~DeviceScope() {
+		if (changed) {
+			(void)hipSetDevice(prev);
+		}
+	}
+};
+#define PGH_ENTER(ds_) DeviceScope pgh_scope_((ds_) ? (ds_)->device : -1)
+// entry points that hand out or take raw device pointers work on one device's dataset only
+#define PGH_ONE_DEVICE(ds_)                                                                                            \
+	do {                                                                                                               \
+		if ((ds_) && (ds_)->IsGroup()) {                                                                               \
+			SetErr(errbuf, "this entry point takes one device's dataset: pass pgh_shard(group, k)");                   \
+			return PGH_ERR_ARG;                                                                                        \
+		}                                                                                                              \
+	} while (0)
+
+// shard-group forms of the host-buffer entry points (api_sharded.cpp)
+namespace pgh_group {
+int CountsRange(const pgh_dataset *g, const pgh_subset *ss, uint32_t v_begin, uint32_t v_end, uint32_t (*out)[4],
+                char *errbuf);
+int MissingPerSample(const pgh_dataset *g, const pgh_subset *ss, uint32_t v_begin, uint32_t v_end, uint32_t *out,
+                     char *errbuf);
+int SampleCounts(const pgh_dataset *g, const pgh_subset *ss, uint32_t variant_begin, uint32_t n_var,
+                 const uint32_t *vidx, uint32_t (*counts)[4], char *errbuf);
+int UnpackRange(const pgh_dataset *g, const pgh_subset *ss, uint32_t v_begin, uint32_t v_end, int8_t *out,
+                uint64_t *validity, int missing_code, char *errbuf);
+int DosageSums(const pgh_dataset *g, const pgh_subset *ss, uint32_t variant_begin, uint32_t n_variants,
+               const uint32_t *vidx, uint64_t (*sums)[3], char *errbuf);
+int DosageUnpack(const pgh_dataset *g, const pgh_subset *ss, uint32_t variant_begin, uint32_t n_variants,
+                 const uint32_t *vidx, double *out, char *errbuf);
+int UnpackSamples(const pgh_dataset *g, const pgh_subset *ss, uint32_t n_variants, const uint32_t *vidx, int8_t *out,
+                  int missing_code, char *errbuf);
+int DosageUnpackSamples(const pgh_dataset *g, const pgh_subset *ss, uint32_t n_variants, const uint32_t *vidx,
+                        double *out, char *errbuf);
+int Score(const pgh_dataset *g, const pgh_subset *ss, uint32_t n_scored, const uint32_t *vidx, const double *weights,
+          const uint8_t *flip, uint32_t n_cols, int mode, double *score_sum, double *dosage_sum, uint32_t *allele_ct,
+          char *errbuf);
+int Pca(const pgh_dataset *g, const pgh_subset *ss, uint32_t n_var, const uint32_t *vidx, const double *center,
+        const double *inv_stdev, uint32_t n_pcs, const double *g1_init, double *eigenvalues, double *eigenvectors,
+        char *errbuf);
+int LdPairs(const pgh_dataset *g, const pgh_subset *ss, uint32_t n_pairs, const uint32_t *vidx_a, const uint32_t *vidx_b,
+            uint32_t (*sums)[6], char *errbuf);
+int CopyRowsToHost(const pgh_dataset *g, uint32_t v_begin, uint32_t v_end, uint8_t *rows, size_t row_stride,
+                   char *errbuf);
+int SubsetCreate(const pgh_dataset *g, const uint64_t *sample_include, pgh_subset **out, char *errbuf);
+int GetInfo(const pgh_dataset *g, pgh_info *out);
+void Close(pgh_dataset *g);
+//! The reader of the shard that holds vidx (created on first use), or nullptr with rd->err set.
+pgh_reader *ReaderFor(pgh_reader *rd, uint32_t vidx);
+} // namespace pgh_group
 
 namespace {
 

@@ -19,6 +19,13 @@ extern "C" int pgh_reader_create(const pgh_dataset *ds, const pgh_subset *subset
 	std::unique_ptr<pgh_reader> rd(new pgh_reader());
 	rd->ds = ds;
 	rd->subset = subset;
+	if (ds->IsGroup()) {
+		// per-shard readers come into being on the first call that lands in their shard
+		rd->parts.assign(ds->shards.size(), nullptr);
+		*out = rd.release();
+		return PGH_OK;
+	}
+	PGH_ENTER(ds);
 	hipError_t e = hipStreamCreateWithFlags(&rd->stream, hipStreamNonBlocking);
 	if (e == hipSuccess) {
 		e = hipMalloc(reinterpret_cast<void **>(&rd->d_counts), 16 * pgh_reader::kWindow);
@@ -41,6 +48,10 @@ extern "C" void pgh_reader_destroy(pgh_reader *rd) {
 	if (!rd) {
 		return;
 	}
+	for (pgh_reader *part : rd->parts) {
+		pgh_reader_destroy(part);
+	}
+	PGH_ENTER(rd->ds);
 	if (rd->stream) {
 		(void)hipStreamSynchronize(rd->stream);
 	}
@@ -123,6 +134,18 @@ void ForEachIncluded(const pgh_reader *rd, Fn &&fn) {
 } // namespace
 
 extern "C" int pgh_get_counts(pgh_reader *rd, uint32_t vidx, uint32_t out[4]) {
+	if (rd && rd->ds->IsGroup()) {
+		pgh_reader *part = pgh_group::ReaderFor(rd, vidx);
+		if (!part) {
+			return PGH_ERR_ARG;
+		}
+		const int rc_part = pgh_get_counts(part, vidx, out);
+		if (rc_part != PGH_OK) {
+			rd->err = part->err;
+		}
+		return rc_part;
+	}
+	PGH_ENTER(rd ? rd->ds : nullptr);
 	int rc = ReaderCheck(rd, vidx);
 	if (rc != PGH_OK) {
 		return rc;
@@ -152,6 +175,18 @@ extern "C" int pgh_get_counts(pgh_reader *rd, uint32_t vidx, uint32_t out[4]) {
 }
 
 extern "C" int pgh_get_2bit(pgh_reader *rd, uint32_t vidx, uint64_t *genovec) {
+	if (rd && rd->ds->IsGroup()) {
+		pgh_reader *part = pgh_group::ReaderFor(rd, vidx);
+		if (!part) {
+			return PGH_ERR_ARG;
+		}
+		const int rc_part = pgh_get_2bit(part, vidx, genovec);
+		if (rc_part != PGH_OK) {
+			rd->err = part->err;
+		}
+		return rc_part;
+	}
+	PGH_ENTER(rd ? rd->ds : nullptr);
 	int rc = ReaderCheck(rd, vidx);
 	if (rc == PGH_OK) {
 		rc = FetchRow(rd, vidx);
@@ -168,6 +203,18 @@ extern "C" int pgh_get_2bit(pgh_reader *rd, uint32_t vidx, uint64_t *genovec) {
 }
 
 extern "C" int pgh_get_missingness(pgh_reader *rd, uint32_t vidx, uint64_t *bits) {
+	if (rd && rd->ds->IsGroup()) {
+		pgh_reader *part = pgh_group::ReaderFor(rd, vidx);
+		if (!part) {
+			return PGH_ERR_ARG;
+		}
+		const int rc_part = pgh_get_missingness(part, vidx, bits);
+		if (rc_part != PGH_OK) {
+			rd->err = part->err;
+		}
+		return rc_part;
+	}
+	PGH_ENTER(rd ? rd->ds : nullptr);
 	int rc = ReaderCheck(rd, vidx);
 	if (rc == PGH_OK) {
 		rc = FetchRow(rd, vidx);
@@ -186,6 +233,18 @@ extern "C" int pgh_get_missingness(pgh_reader *rd, uint32_t vidx, uint64_t *bits
 }
 
 extern "C" int pgh_get_int8(pgh_reader *rd, uint32_t vidx, int8_t *out) {
+	if (rd && rd->ds->IsGroup()) {
+		pgh_reader *part = pgh_group::ReaderFor(rd, vidx);
+		if (!part) {
+			return PGH_ERR_ARG;
+		}
+		const int rc_part = pgh_get_int8(part, vidx, out);
+		if (rc_part != PGH_OK) {
+			rd->err = part->err;
+		}
+		return rc_part;
+	}
+	PGH_ENTER(rd ? rd->ds : nullptr);
 	int rc = ReaderCheck(rd, vidx);
 	if (rc == PGH_OK) {
 		rc = FetchRow(rd, vidx);
@@ -202,6 +261,18 @@ extern "C" int pgh_get_int8(pgh_reader *rd, uint32_t vidx, int8_t *out) {
 
 extern "C" int pgh_get_phased(pgh_reader *rd, uint32_t vidx, uint64_t *genovec, uint64_t *phasepresent,
                               uint64_t *phaseinfo) {
+	if (rd && rd->ds->IsGroup()) {
+		pgh_reader *part = pgh_group::ReaderFor(rd, vidx);
+		if (!part) {
+			return PGH_ERR_ARG;
+		}
+		const int rc_part = pgh_get_phased(part, vidx, genovec, phasepresent, phaseinfo);
+		if (rc_part != PGH_OK) {
+			rd->err = part->err;
+		}
+		return rc_part;
+	}
+	PGH_ENTER(rd ? rd->ds : nullptr);
 	int rc = ReaderCheck(rd, vidx);
 	if (rc != PGH_OK) {
 		return rc;
@@ -250,6 +321,18 @@ extern "C" int pgh_get_phased(pgh_reader *rd, uint32_t vidx, uint64_t *genovec, 
 }
 
 extern "C" int pgh_get_dosage_f64(pgh_reader *rd, uint32_t vidx, double *out) {
+	if (rd && rd->ds->IsGroup()) {
+		pgh_reader *part = pgh_group::ReaderFor(rd, vidx);
+		if (!part) {
+			return PGH_ERR_ARG;
+		}
+		const int rc_part = pgh_get_dosage_f64(part, vidx, out);
+		if (rc_part != PGH_OK) {
+			rd->err = part->err;
+		}
+		return rc_part;
+	}
+	PGH_ENTER(rd ? rd->ds : nullptr);
 	int rc = ReaderCheck(rd, vidx);
 	if (rc != PGH_OK) {
 		return rc;

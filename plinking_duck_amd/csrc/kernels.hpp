@@ -130,6 +130,11 @@ hipError_t LaunchTallTimesSmall(const double *A, uint32_t lda, uint32_t na, cons
 hipError_t LaunchCopyCols(const double *src, uint32_t ld_src, double *dst, uint32_t ld_dst, uint32_t n, uint64_t m,
                           hipStream_t stream);
 
+// ---- shard-group combine (reduce.hip) -----------------------------------------
+// dst[i] += src[i]; both 16-byte aligned device buffers of the current device
+hipError_t LaunchAddF64(double *dst, const double *src, uint64_t n, hipStream_t stream);
+hipError_t LaunchAddU32(uint32_t *dst, const uint32_t *src, uint64_t n, hipStream_t stream);
+
 // ---- HWE --------------------------------------------------------------------
 hipError_t LaunchHweBatch(const uint32_t *counts, uint32_t n, uint32_t midp, double *ln_p, hipStream_t stream);
 // chrX: strata[i] = {female_hets, female_hom1, female_hom2, male1, male2}; one workgroup per variant

@@ -214,53 +214,6 @@ __global__ __launch_bounds__(256) void k_i8_digits(uint32_t n_var, uint32_t n_co
 // the contraction
 // ---------------------------------------------------------------------------
 
-__device__ __forceinline__ uint32_t Bfi(uint32_t mask, uint32_t a, uint32_t b) {
-	return (mask & a) | (~mask & b); // v_bfi_b32
-}
-
-// Four words (variants v0..v3, 16 samples each) -> four words whose BYTES hold one sample's four calls
-// (v0 | v1 << 2 | v2 << 4 | v3 << 6): out[k] byte b is sample 4 b + {0, 2, 1, 3}[k].
-__device__ __forceinline__ void Transpose4(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t *out) {
-	const uint32_t e01 = Bfi(0x33333333u, w0, w1 << 2);
-	const uint32_t o01 = Bfi(0xccccccccu, w1, w0 >> 2);
-	const uint32_t e23 = Bfi(0x33333333u, w2, w3 << 2);
-	const uint32_t o23 = Bfi(0xccccccccu, w3, w2 >> 2);
-	out[0] = Bfi(0x0f0f0f0fu, e01, e23 << 4);
-	out[1] = Bfi(0xf0f0f0f0u, e23, e01 >> 4);
-	out[2] = Bfi(0x0f0f0f0fu, o01, o23 << 4);
-	out[3] = Bfi(0xf0f0f0f0u, o23, o01 >> 4);
-}
-
-// byte B of x (four 2-bit calls) -> four int8 codes, one per byte: x * 0x1001 puts copies at bits 0 and 12,
-// (a << 6) | a adds copies at 6 and 18, and call c of copy c sits at bit 8 c.
-#define PGH_SPREAD(B)                                                                                                  \
-	__device__ __forceinline__ uint32_t Spread##B(uint32_t x, uint32_t k1001) {                                       \
-		uint32_t a;                                                                                                    \
-		asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_" #B " src1_sel:DWORD"    \
-		    : "=v"(a)                                                                                                  \
-		    : "v"(x), "v"(k1001));                                                                                     \
-		return ((a << 6) | a) & 0x03030303u;                                                                           \
-	}
-PGH_SPREAD(0)
-PGH_SPREAD(1)
-PGH_SPREAD(2)
-PGH_SPREAD(3)
-#undef PGH_SPREAD
-
-template <int B>
-__device__ __forceinline__ uint32_t Spread(uint32_t x, uint32_t k1001) {
-	if (B == 0) {
-		return Spread0(x, k1001);
-	}
-	if (B == 1) {
-		return Spread1(x, k1001);
-	}
-	if (B == 2) {
-		return Spread2(x, k1001);
-	}
-	return Spread3(x, k1001);
-}
-
 // NT 16-column digit tiles; TS samples per lane (16, 8 or 4): accumulators = TS * NT * 4 registers
 template <int NT, int TS>
 struct I8Shape {

@@ -8,6 +8,7 @@
 // Register* functions are handed to its ExtensionLoader instead.
 #include "duck_api.hpp"
 #include "json.hpp"
+#include "plink_common.hpp"
 
 #include <algorithm>
 #include <mutex>
@@ -182,6 +183,14 @@ string RunQuery(const string &request) {
 			if (kv.first == "plinking_max_threads" && !v.IsNull() && v.GetValue<int64_t>() < 0) {
 				return ErrorJson(InvalidInputException::Kind(),
 				                 "plinking_max_threads must be non-negative (0 = default, >0 = cap)");
+			}
+			if (kv.first == "plinking_devices") {
+				// the option's SET callback: which GPUs hold the variant shards of files opened from now on
+				try {
+					SetPlinkingDevices(v.IsNull() ? string() : v.GetValue<string>());
+				} catch (const InvalidInputException &ex) {
+					return ErrorJson(InvalidInputException::Kind(), ex.what());
+				}
 			}
 			context.settings[kv.first] = v;
 		}

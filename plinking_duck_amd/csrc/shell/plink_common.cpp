@@ -1029,12 +1029,49 @@ DeviceDataset::~DeviceDataset() {
 }
 
 namespace {
+std::mutex g_devices_mutex;
+vector<int> g_devices;
+bool g_devices_from_env = false;
+
+vector<int> ParseDeviceList(const string &spec) {
+	vector<int> devices;
+	const int have = pgh_device_count();
+	if (spec == "all" || spec == "ALL") {
+		for (int d = 0; d < have; d++) {
+			devices.push_back(d);
+		}
+		return devices;
+	}
+	size_t at = 0;
+	while (at < spec.size()) {
+		size_t comma = spec.find(',', at);
+		if (comma == string::npos) {
+			comma = spec.size();
+		}
+		string tok = spec.substr(at, comma - at);
+		tok.erase(0, tok.find_first_not_of(" \t"));
+		tok.erase(tok.find_last_not_of(" \t") + 1);
+		if (tok.empty() || tok.find_first_not_of("0123456789") != string::npos) {
+			throw InvalidInputException("plinking_devices must be '', 'all' or a comma-separated list of device "
+			                            "ordinals, got '%s'", spec);
+		}
+		const int d = std::atoi(tok.c_str());
+		if (d >= have) {
+			throw InvalidInputException("plinking_devices: device %d does not exist (%d visible)", d, have);
+		}
+		devices.push_back(d);
+		at = comma + 1;
+	}
+	return devices;
+}
+
 struct CacheKey {
 	string path;
 	int64_t mtime_ns;
 	int64_t size;
+	vector<int> devices;
 	bool operator==(const CacheKey &o) const {
-		return path == o.path && mtime_ns == o.mtime_ns && size == o.size;
+		return path == o.path && mtime_ns == o.mtime_ns && size == o.size && devices == o.devices;
 	}
 };
 struct CacheEntry {
@@ -1052,13 +1089,32 @@ uint64_t CacheBudgetBytes() {
 }
 } // namespace
 
+void SetPlinkingDevices(const string &spec) {
+	vector<int> parsed = ParseDeviceList(spec);
+	std::lock_guard<std::mutex> lock(g_devices_mutex);
+	g_devices = std::move(parsed);
+	g_devices_from_env = true; // an explicit setting, '' included, overrides the environment
+}
+
+vector<int> GetPlinkingDevices() {
+	std::lock_guard<std::mutex> lock(g_devices_mutex);
+	if (!g_devices_from_env) {
+		g_devices_from_env = true;
+		if (const char *env = std::getenv("PLINKING_DEVICES")) {
+			g_devices = ParseDeviceList(env);
+		}
+	}
+	return g_devices;
+}
+
 shared_ptr<DeviceDataset> DeviceDataset::Acquire(const string &pgen_path, const string &func_name) {
 	struct stat st;
 	if (::stat(pgen_path.c_str(), &st) != 0) {
 		throw IOException("%s: failed to open '%s': %s", func_name, pgen_path, string(std::strerror(errno)));
 	}
+	const vector<int> devices = GetPlinkingDevices();
 	CacheKey key {pgen_path, static_cast<int64_t>(st.st_mtim.tv_sec) * 1000000000LL + st.st_mtim.tv_nsec,
-	              static_cast<int64_t>(st.st_size)};
+	              static_cast<int64_t>(st.st_size), devices};
 	std::lock_guard<std::mutex> lock(g_cache_mutex);
 	for (size_t i = 0; i < g_cache.size(); i++) {
 		if (g_cache[i].key == key) {
@@ -1071,7 +1127,11 @@ shared_ptr<DeviceDataset> DeviceDataset::Acquire(const string &pgen_path, const 
 	auto ds = make_shared<DeviceDataset>();
 	ds->path = pgen_path;
 	char errbuf[PGH_ERRBUF_LEN] = {0};
-	int rc = pgh_open(pgen_path.c_str(), nullptr, 0, UINT32_MAX, &ds->handle, errbuf);
+	// one resident matrix on the current device, or one contiguous variant shard per listed device behind one
+	// handle: every pgh_* call the table functions make accepts either
+	int rc = devices.empty() ? pgh_open(pgen_path.c_str(), nullptr, 0, UINT32_MAX, &ds->handle, errbuf)
+	                         : pgh_open_sharded(pgen_path.c_str(), nullptr, 0, UINT32_MAX, devices.data(),
+	                                            static_cast<uint32_t>(devices.size()), &ds->handle, errbuf);
 	if (rc != PGH_OK) {
 		throw IOException("%s: failed to open '%s': %s", func_name, pgen_path, string(errbuf));
 	}

@@ -203,6 +203,16 @@ public:
 	static shared_ptr<DeviceDataset> Acquire(const string &pgen_path, const string &func_name);
 };
 
+//! The extension option `plinking_devices` (next to plinking_max_threads, the reference's only option:
+//! src/plinking_duck_extension.cpp:49-86): which GPUs of the node hold a file's variants.  '' (default) = the
+//! current device; '0,1,2,3' = one contiguous variant shard on each listed device (a device may repeat);
+//! 'all' = every visible device.  Datasets opened afterwards are shard groups (pgh_open_sharded): the table
+//! functions need no other change, the per-sample merges of plink_score / plink_missing / plink_pca become
+//! device-to-device sums.  Throws InvalidInputException on a malformed list or an ordinal the node lacks.
+void SetPlinkingDevices(const string &spec);
+//! The current list (empty = single current device); PLINKING_DEVICES in the environment is the initial value.
+vector<int> GetPlinkingDevices();
+
 //! RAII pgh_subset
 class DeviceSubset {
 public:

@@ -21,7 +21,7 @@ SCORE_MEAN_IMPUTE, SCORE_NO_MEAN_IMPUTATION, SCORE_CENTER = 0, 1, 2
 # every symbol include/pgenhip.h declares (tests/test_abi.py checks the .so exports each)
 EXPORTED_SYMBOLS = [
     "pgh_version", "pgh_device_count", "pgh_set_device", "pgh_open", "pgh_probe", "pgh_normalize_range_host",
-    "pgh_from_host_rows",
+    "pgh_from_host_rows", "pgh_open_sharded", "pgh_group_create", "pgh_shard_count", "pgh_shard",
     "pgh_synth_create", "pgh_synth_record_host", "pgh_synth_write_files", "pgh_copy_rows_to_host", "pgh_get_info", "pgh_device_rows",
     "pgh_close", "pgh_subset_create", "pgh_subset_size", "pgh_subset_destroy", "pgh_counts_range",
     "pgh_counts_range_dev", "pgh_freq_from_counts_dev", "pgh_fused_tally_dev", "pgh_missing_per_sample", "pgh_missing_per_sample_dev", "pgh_unpack_range",
@@ -85,6 +85,10 @@ def _load():
         "pgh_normalize_range_host": (C.c_int, [cp, cp, u32, u32, vp, C.c_size_t, cp]),
         "pgh_from_host_rows": (C.c_int, [vp, C.c_size_t, u32, u32, C.POINTER(vp), cp]),
         "pgh_synth_create": (C.c_int, [u32, u32, u32, u64, C.c_double, C.POINTER(vp), cp]),
+        "pgh_open_sharded": (C.c_int, [cp, cp, u32, u32, vp, u32, C.POINTER(vp), cp]),
+        "pgh_group_create": (C.c_int, [vp, u32, C.POINTER(vp), cp]),
+        "pgh_shard_count": (u32, [vp]),
+        "pgh_shard": (vp, [vp, u32]),
         "pgh_synth_record_host": (C.c_int, [u32, u32, u64, C.c_double, vp]),
         "pgh_synth_write_files": (C.c_int, [cp, u32, u32, u64, C.c_double, cp]),
         "pgh_copy_rows_to_host": (C.c_int, [vp, u32, u32, vp, C.c_size_t, cp]),
@@ -293,6 +297,31 @@ class Dataset:
         _check(_lib.pgh_open(path.encode(), pgi_path.encode() if pgi_path else None, variant_begin,
                              0xFFFFFFFF if variant_end is None else variant_end, C.byref(h), eb), eb)
         return cls(h)
+
+    @classmethod
+    def open_sharded(cls, path: str, devices, pgi_path: str | None = None, variant_begin: int = 0,
+                     variant_end: int | None = None):
+        """One handle over len(devices) contiguous variant ranges of the file, shard k resident on devices[k]."""
+        h, eb = C.c_void_p(), _errbuf()
+        dev = np.ascontiguousarray(devices, dtype=np.int32)
+        _check(_lib.pgh_open_sharded(path.encode(), pgi_path.encode() if pgi_path else None, variant_begin,
+                                     0xFFFFFFFF if variant_end is None else variant_end, _ptr(dev), len(dev),
+                                     C.byref(h), eb), eb)
+        return cls(h)
+
+    @classmethod
+    def group(cls, shards):
+        """A shard group over datasets that hold contiguous, ascending variant ranges; takes them over."""
+        h, eb = C.c_void_p(), _errbuf()
+        arr = (C.c_void_p * len(shards))(*[s._h for s in shards])
+        _check(_lib.pgh_group_create(arr, len(shards), C.byref(h), eb), eb)
+        for s in shards:
+            s._h = None  # owned by the group now
+        return cls(h)
+
+    @property
+    def shard_count(self) -> int:
+        return int(_lib.pgh_shard_count(self._h))
 
     @classmethod
     def from_host_rows(cls, rows: np.ndarray, n_samples: int):

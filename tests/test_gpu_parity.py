@@ -266,8 +266,9 @@ def test_score_matches_oracle(gpu_lib, oracle, mode, ncols):
 
 @pytest.mark.parametrize("ncols", [2, 3, 5, 15, 17, 20, 21, 24, 25, 28, 29, 33, 52])
 def test_score_any_number_of_columns(gpu_lib, oracle, ncols):
-    """1 column: pair-table lookups; 2: FMAs; >= 3: FP64 MFMA tiles -- 32 columns per pass, the tail as
-    one 16-column tile plus up to three 4-column quarter tiles (v_mfma_f64_4x4x4_4b_f64)."""
+    """Every count of weight columns: 7 digit columns each + 6 for the dosage sum and the missing count fill
+    1..8 sixteen-column tiles of the int8 contraction (k_score_i8<NT, TS>); more than 17 columns take a second
+    pass."""
     m, n = 150, 1500
     host = np.stack([gpu_lib.synth_record_host(v, n, SEED + 3, 0.05) for v in range(m)])
     ds = gpu_lib.Dataset.from_host_rows(host, n)
@@ -281,6 +282,81 @@ def test_score_any_number_of_columns(gpu_lib, oracle, ncols):
     scale = np.abs(w).sum(axis=0) * 2.0
     assert np.all(np.abs(s - es) <= REL * np.maximum(np.abs(es), 1e-9 * scale))
     assert np.allclose(d, ed, rtol=REL, atol=1e-9)
+
+
+@pytest.mark.parametrize("ncols,mode", [(1, "default"), (1, "no_mean_imputation"), (1, "center"), (2, "default"),
+                                        (3, "center"), (7, "default"), (16, "default"), (19, "no_mean_imputation")])
+def test_score_over_many_tiles_and_slices(gpu_lib, oracle, ncols, mode):
+    """The contraction walks 64-variant tiles through a four-slot LDS ring, several slices per sample group:
+    4,500 scored variants picked out of 6,000 (a non-contiguous list: 71 tiles, the last one padded) over
+    2,500 samples (ragged last word, three sample groups of the one-column shape) against the oracle."""
+    m, n = 6000, 2500
+    host = np.stack([gpu_lib.synth_record_host(v, n, SEED + 21, 0.04) for v in range(m)])
+    host[17] = 0xFF
+    host[4000] = 0x00
+    ds = gpu_lib.Dataset.from_host_rows(host, n)
+    pg = oracle.Pgen(mem=mem_pgen(host, n))
+    rng = np.random.default_rng(100 + ncols)
+    vidx = np.union1d(np.sort(rng.choice(m, size=4498, replace=False)), [17, 4000])
+    w = rng.standard_normal((len(vidx), ncols)) * np.exp(rng.normal(0, 2, size=(len(vidx), 1)))
+    flip = (rng.random(len(vidx)) < 0.4).astype(np.uint8)
+    code = {"default": gpu_lib.SCORE_MEAN_IMPUTE, "no_mean_imputation": gpu_lib.SCORE_NO_MEAN_IMPUTATION,
+            "center": gpu_lib.SCORE_CENTER}[mode]
+    mask = rng.random(n) < 0.7
+    for ss, inc in ((None, None), (ds.subset(mask), mask.astype(np.uint8))):
+        s, d, ac = ds.score(vidx, w, flip=flip, mode=code, subset=ss)
+        es, ed, eac = oracle.score(pg, vidx, w, flip=flip, mode=mode, include=inc)
+        assert np.array_equal(ac, eac)
+        # sums of ~4,500 terms: compare against the magnitude of what was summed (a double accumulation in
+        # another order differs by as much)
+        scale = np.abs(w).sum(axis=0) * 2.0
+        assert np.all(np.abs(s - es) <= 1e-12 * scale + REL * np.abs(es) * 1e-3)
+        assert np.allclose(d, ed, rtol=1e-9, atol=1e-9)
+
+
+def test_score_weights_spanning_twelve_orders_of_magnitude(gpu_lib, oracle):
+    """Fixed-point digits are cut below each column's LARGEST coefficient (54 bits): small weights next to
+    large ones keep 54 - log2(ratio) bits.  With a 1e12 spread the small terms still carry ~14 bits, and the
+    sum stays within 1e-6 of the oracle relative to its own size wherever it is not dominated by cancellation."""
+    m, n = 512, 1200
+    host = np.stack([gpu_lib.synth_record_host(v, n, SEED + 22, 0.03) for v in range(m)])
+    ds = gpu_lib.Dataset.from_host_rows(host, n)
+    pg = oracle.Pgen(mem=mem_pgen(host, n))
+    rng = np.random.default_rng(5)
+    vidx = np.arange(m)
+    w = (10.0 ** rng.uniform(-6, 6, size=(m, 2))) * rng.choice([-1.0, 1.0], size=(m, 2))
+    s, d, ac = ds.score(vidx, w)
+    es, ed, eac = oracle.score(pg, vidx, w)
+    assert np.array_equal(ac, eac)
+    bound = 2.0 ** -50 * np.abs(w).max(axis=0) * 3 * m + 1e-12 * np.abs(es)
+    assert np.all(np.abs(s - es) <= bound)
+    assert np.allclose(d, ed, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("mode", ["default", "no_mean_imputation", "center"])
+def test_score_at_baseline_width(gpu_lib, oracle, mode):
+    """BASELINE config 4's shape on the sample axis: 500,000 samples x 16 weight columns (and the one-column SQL
+    contract) over 70 variants -- 1,954 workgroup columns, sample indices up to 5e5 in the epilogue, the ragged
+    last group -- against the oracle, with flips and a sample subset."""
+    m, n = 70, 500_000
+    host = np.stack([gpu_lib.synth_record_host(v, n, SEED + 23, 0.02) for v in range(m)])
+    ds = gpu_lib.Dataset.from_host_rows(host, n)
+    pg = oracle.Pgen(mem=mem_pgen(host, n))
+    rng = np.random.default_rng(9)
+    vidx = np.arange(m)
+    flip = (rng.random(m) < 0.3).astype(np.uint8)
+    code = {"default": gpu_lib.SCORE_MEAN_IMPUTE, "no_mean_imputation": gpu_lib.SCORE_NO_MEAN_IMPUTATION,
+            "center": gpu_lib.SCORE_CENTER}[mode]
+    mask = rng.random(n) < 0.6
+    for ncols in (16, 1):
+        w = rng.standard_normal((m, ncols))
+        for ss, inc in ((None, None), (ds.subset(mask), mask.astype(np.uint8))):
+            s, d, ac = ds.score(vidx, w, flip=flip, mode=code, subset=ss)
+            es, ed, eac = oracle.score(pg, vidx, w, flip=flip, mode=mode, include=inc)
+            assert np.array_equal(ac, eac)
+            scale = np.abs(w).sum(axis=0) * 2.0
+            assert np.all(np.abs(s - es) <= 1e-12 * scale + 1e-9 * np.abs(es))
+            assert np.allclose(d, ed, rtol=1e-9, atol=1e-9)
 
 
 @pytest.mark.parametrize("n_pcs,m,n", [(2, 700, 2100), (9, 700, 2100), (10, 700, 2100), (11, 700, 2100),
