@@ -1250,6 +1250,7 @@ extern "C" int pgh_subset_create(const pgh_dataset *ds, const uint64_t *sample_i
 	PGH_ENTER(ds);
 	std::unique_ptr<pgh_subset> ss(new pgh_subset());
 	ss->ds = ds;
+	ss->device = ds->device;
 	const uint32_t N = ds->sample_ct;
 	ss->include.assign(sample_include, sample_include + (N + 63) / 64);
 	std::vector<uint8_t> mask2(ds->pitch, 0);
@@ -1295,7 +1296,7 @@ extern "C" void pgh_subset_destroy(pgh_subset *ss) {
 	for (pgh_subset *part : ss->parts) {
 		pgh_subset_destroy(part);
 	}
-	PGH_ENTER(ss->ds);
+	DeviceScope scope(ss->device);
 	if (ss->d_mask2) {
 		(void)hipFree(ss->d_mask2);
 	}

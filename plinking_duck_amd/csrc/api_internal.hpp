@@ -87,6 +87,7 @@ struct pgh_dataset {
 
 struct pgh_subset {
 	const pgh_dataset *ds = nullptr;
+	int device = -1; // where the staged copies live (kept here: the dataset may be closed before the subset)
 	uint32_t n_out = 0;
 	std::vector<uint64_t> include; // ceil(N/64) words
 	std::vector<uint32_t> sel;     // raw index of each included sample, ascending
@@ -98,6 +99,7 @@ struct pgh_subset {
 
 struct pgh_reader {
 	const pgh_dataset *ds = nullptr;
+	int device = -1; // of the stream and staging buffers (-1: a shard group's reader owns none)
 	const pgh_subset *subset = nullptr;
 	hipStream_t stream = nullptr;
 	// counts window: one launch serves the next kWindow per-variant calls
@@ -121,6 +123,9 @@ struct DeviceScope {
 	explicit DeviceScope(int device) {
 		if (device >= 0 && hipGetDevice(&prev) == hipSuccess && prev != device) {
 			changed = hipSetDevice(device) == hipSuccess;
+			if (!changed) {
+				(void)hipGetLastError(); // do not leave the failure for an unrelated launch check to find
+			}
 		}
 	}
 	DeviceScope(const DeviceScope &) = delete;

@@ -26,6 +26,7 @@ extern "C" int pgh_reader_create(const pgh_dataset *ds, const pgh_subset *subset
 		return PGH_OK;
 	}
 	PGH_ENTER(ds);
+	rd->device = ds->device;
 	hipError_t e = hipStreamCreateWithFlags(&rd->stream, hipStreamNonBlocking);
 	if (e == hipSuccess) {
 		e = hipMalloc(reinterpret_cast<void **>(&rd->d_counts), 16 * pgh_reader::kWindow);
@@ -51,7 +52,7 @@ extern "C" void pgh_reader_destroy(pgh_reader *rd) {
 	for (pgh_reader *part : rd->parts) {
 		pgh_reader_destroy(part);
 	}
-	PGH_ENTER(rd->ds);
+	DeviceScope scope(rd->device);
 	if (rd->stream) {
 		(void)hipStreamSynchronize(rd->stream);
 	}
