@@ -349,13 +349,14 @@ def main():
                 e1.record(stream)
                 kernel_events.append((e0, e1))
             L.freq_from_counts_dev(d_counts[b].data_ptr(), m, d_freq[b].data_ptr(), d_obs[b].data_ptr(), st)
-            if args.workload == "fused":
-                # plink_hardy: exact test per variant from the same counts (a compute kernel: it stays on the
-                # main stream so that it does not share the CUs with the next tally, whose duration is what
-                # `roofline` reports); plink_missing variant mode: counts[:,3]; sample mode: column sums
-                L.hwe_lnp_batch_dev(d_counts[b].data_ptr(), m, d_lnp[b].data_ptr(), False, st)
             tallied[b].record(stream)
             side.wait_event(tallied[b])
+            if args.workload == "fused":
+                # plink_hardy: exact test per variant from the same counts.  A latency-bound compute kernel
+                # (one lane per variant): it runs on the side stream UNDER the next step's tally, which leaves
+                # most of every CU's issue slots free; plink_missing variant mode: counts[:,3]; sample mode:
+                # the column sums of the same pass
+                L.hwe_lnp_batch_dev(d_counts[b].data_ptr(), m, d_lnp[b].data_ptr(), False, side.cuda_stream)
             with torch.cuda.stream(side):
                 h_counts.copy_(d_counts[b], non_blocking=True)
                 h_freq.copy_(d_freq[b], non_blocking=True)

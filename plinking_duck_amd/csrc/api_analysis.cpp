@@ -922,7 +922,19 @@ extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, 
 		}
 		local[i] = vidx[i] - ds->v_begin;
 	}
-	hipStream_t st = hipStreamPerThread;
+	// A stream of the call's own (not the per-thread default): the all-reduce callback is handed a real stream
+	// handle that a host framework can wrap and order against its own streams with events.
+	struct OwnStream {
+		hipStream_t s = nullptr;
+		~OwnStream() {
+			if (s) {
+				(void)hipStreamSynchronize(s);
+				(void)hipStreamDestroy(s);
+			}
+		}
+	} own;
+	PGH_HIP(hipStreamCreateWithFlags(&own.s, hipStreamNonBlocking), "hipStreamCreate(pca)");
+	hipStream_t st = own.s;
 	// Sum a device buffer over the variant shards (X is split by rows, so every X^T(...)
 	// product and every Gram matrix of a tall factor is a sum of per-shard terms).
 	auto all_sum = [&](double *buf, uint64_t count) -> int {

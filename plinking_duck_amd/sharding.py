@@ -53,16 +53,24 @@ class _DeviceDoubles:
 def device_allreduce(dist, group=None):
     """The `allreduce(d_ptr, count, stream)` callable Dataset.pca_sharded wants, over a
     torch.distributed process group (nccl == RCCL over xGMI on a multi-GPU node; gloo stages
-    through the host).  The library enqueued its kernels on its own stream, torch reduces on
-    torch's: fence both sides with a device synchronize — a handful of calls per PCA."""
+    through the host).  The library enqueued its kernels on ITS stream; torch reduces on torch's
+    current stream.  The two are ordered with events, both ways -- no device-wide drain: the
+    collective waits for the library's producer kernels, the library's consumer kernels wait for
+    the collective, and the host thread goes straight on enqueueing."""
     import torch
 
     def allreduce(d_ptr: int, count: int, stream: int):
         if count == 0:
             return
-        torch.cuda.synchronize()
+        lib_stream = torch.cuda.ExternalStream(stream)
+        cur = torch.cuda.current_stream()
+        produced = torch.cuda.Event()
+        produced.record(lib_stream)
+        cur.wait_event(produced)
         t = torch.as_tensor(_DeviceDoubles(d_ptr, count), device="cuda")
         dist.all_reduce(t, group=group)
-        torch.cuda.synchronize()
+        reduced = torch.cuda.Event()
+        reduced.record(cur)
+        lib_stream.wait_event(reduced)
 
     return allreduce
