@@ -692,7 +692,7 @@ extern "C" int pgh_score_plan_create(const pgh_dataset *ds, const pgh_subset *su
 				ScoreI8Pass &pass = plan->i8.back();
 				pass.c0 = c0;
 				pass.n_cols = std::min(pgh::kI8MaxCols, n_cols - c0);
-				const pgh::ScoreI8Sizes z = pgh::ScoreI8Bytes(plan->n_table, pass.n_cols);
+				const pgh::ScoreI8Sizes z = pgh::ScoreI8Bytes(plan->n_table, pass.n_cols, true);
 				PGH_HIP(hipMalloc(&pass.d_bmat, z.bmat), "hipMalloc(score digits)");
 				PGH_HIP(hipMalloc(&pass.d_rowidx, z.rowidx), "hipMalloc(score digits)");
 				PGH_HIP(hipMalloc(&pass.d_cols, z.cols), "hipMalloc(score digits)");
@@ -707,7 +707,7 @@ extern "C" int pgh_score_plan_create(const pgh_dataset *ds, const pgh_subset *su
 				PGH_HIP(pgh::LaunchScoreI8Prepare(vlist, plan->n_table, static_cast<double *>(plan->d_weights) + c0, n_cols,
 				                                  pass.n_cols, static_cast<double *>(plan->d_ts),
 				                                  static_cast<double *>(plan->d_td), static_cast<uint32_t *>(plan->d_ac),
-				                                  mode != PGH_SCORE_MEAN_IMPUTE, pass.buf, st),
+				                                  mode != PGH_SCORE_MEAN_IMPUTE, true, pgh::kI8Tables, pass.buf, st),
 				        "score digit kernels");
 			}
 		}
@@ -768,7 +768,8 @@ extern "C" int pgh_score_run_dev(const pgh_score_plan *plan, void *d_score_sum, 
 			break;
 		}
 		const bool first = pass.c0 == 0;
-		e = pgh::LaunchScoreI8(ds->View(), n_table, pass.n_cols, pass.buf, static_cast<double *>(d_score_sum) + pass.c0,
+		e = pgh::LaunchScoreI8(ds->View(), n_table, pass.n_cols, true, pgh::kI8Tables, pass.buf,
+		                       static_cast<double *>(d_score_sum) + pass.c0,
 		                       plan->n_cols, (first && track) ? static_cast<double *>(d_dosage_sum) : nullptr,
 		                       first ? static_cast<uint32_t *>(miss) : nullptr, st);
 	}
@@ -981,6 +982,79 @@ extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, 
 		PGH_HIP(pgh::LaunchNormTables(d_center.As<double>(), d_inv.As<double>(), M, d_ts.As<double>(), st), "pca tables");
 	}
 	const RowView view = ds->View();
+	// Both contractions run on the int8 matrix cores (score_i8.hip): the dense factor of each pass is cut into
+	// exact fixed-point digits, <= 18 columns per pass.  X^T (...) walks the resident rows; X G1 walks the
+	// transposed packed matrix, built here once (pca_i8.hip).
+	DevBuf d_xt, d_iota, d_a, d_mm, d_colsum, i8_bmat, i8_rowidx, i8_cols, i8_small;
+	pgh::ScoreI8Buffers i8;
+	RowView view_t {nullptr, 0, M, (M + 3) / 4};
+	{
+		const uint32_t longest = std::max(M, N);
+		const pgh::ScoreI8Sizes z = pgh::ScoreI8Bytes(longest, pgh::kI8MaxColsBare, false);
+		PGH_HIP(i8_bmat.Alloc(z.bmat), "hipMalloc(pca digits)");
+		PGH_HIP(i8_rowidx.Alloc(z.rowidx), "hipMalloc(pca digits)");
+		PGH_HIP(i8_cols.Alloc(z.cols), "hipMalloc(pca digits)");
+		PGH_HIP(i8_small.Alloc(z.small), "hipMalloc(pca digits)");
+		i8.bmat = i8_bmat.As<int8_t>();
+		i8.rowidx = i8_rowidx.As<uint32_t>();
+		i8.mult = i8_cols.As<double>();
+		i8.target = reinterpret_cast<uint32_t *>(i8.mult + 16ull * z.n_tiles16);
+		i8.colmax = i8_small.As<unsigned long long>();
+		i8.k0 = reinterpret_cast<double *>(i8.colmax + (pgh::kI8MaxColsBare + 2));
+		i8.scale_exp = i8.k0 + (pgh::kI8MaxColsBare + 2);
+		PGH_HIP(d_iota.Alloc(sizeof(uint32_t) * N), "hipMalloc(pca)");
+		PGH_HIP(pgh::LaunchIota(d_iota.As<uint32_t>(), N, st), "pca iota");
+		PGH_HIP(d_a.Alloc(sizeof(double) * m_alloc * k2), "hipMalloc(pca)");
+		PGH_HIP(d_mm.Alloc(sizeof(double) * m_alloc * k2), "hipMalloc(pca)");
+		PGH_HIP(d_colsum.Alloc(sizeof(double) * k2), "hipMalloc(pca)");
+		if (M) {
+			view_t.pitch = pgh::TransposedPitch(M);
+			PGH_HIP(d_xt.Alloc(view_t.pitch * N), "hipMalloc(transposed genotypes)");
+			PGH_HIP(pgh::LaunchTranspose2bit(view, d_vlist.As<uint32_t>(), M, d_xt.As<uint8_t>(), st), "pca transpose");
+			view_t.rows = d_xt.As<uint8_t>();
+		}
+	}
+	// out[s][c] += sum_v t_v[g(v,s)] W[v][c] over this shard's variants (Step B, phase 3); out zeroed by the caller
+	auto contract_variants = [&](const double *w, uint32_t w_stride, uint32_t n_cols, double *out,
+	                             uint32_t out_stride) -> hipError_t {
+		hipError_t e = hipSuccess;
+		for (uint32_t c0 = 0; c0 < n_cols && e == hipSuccess; c0 += pgh::kI8MaxColsBare) {
+			const uint32_t nc = std::min(pgh::kI8MaxColsBare, n_cols - c0);
+			e = pgh::LaunchScoreI8Prepare(d_vlist.As<uint32_t>(), M, w + c0, w_stride, nc, d_ts.As<double>(), nullptr, nullptr,
+			                              false, false, pgh::kI8Tables, i8, st);
+			if (e == hipSuccess) {
+				e = pgh::LaunchScoreI8(view, M, nc, false, pgh::kI8Tables, i8, out + c0, out_stride, nullptr, nullptr, st);
+			}
+		}
+		return e;
+	};
+	// y[v][c] = sum_s x(v,s) G[s][c] for this shard's variants (Step A): the two integer planes over the transposed
+	// matrix, then the per-variant normalisation
+	auto contract_samples = [&](const double *g, double *y_out) -> hipError_t {
+		hipError_t e = hipMemsetAsync(d_a.p, 0, sizeof(double) * m_alloc * k2, st);
+		if (e == hipSuccess) {
+			e = hipMemsetAsync(d_mm.p, 0, sizeof(double) * m_alloc * k2, st);
+		}
+		for (int plane = pgh::kI8CodePlane; plane <= pgh::kI8MissingPlane && e == hipSuccess; plane++) {
+			double *dst = plane == pgh::kI8CodePlane ? d_a.As<double>() : d_mm.As<double>();
+			for (uint32_t c0 = 0; c0 < k2 && e == hipSuccess; c0 += pgh::kI8MaxColsBare) {
+				const uint32_t nc = std::min(pgh::kI8MaxColsBare, k2 - c0);
+				e = pgh::LaunchScoreI8Prepare(d_iota.As<uint32_t>(), N, g + c0, k2, nc, nullptr, nullptr, nullptr, false, false,
+				                              plane, i8, st);
+				if (e == hipSuccess) {
+					e = pgh::LaunchScoreI8(view_t, N, nc, false, plane, i8, dst + c0, k2, nullptr, nullptr, st);
+				}
+			}
+		}
+		if (e == hipSuccess) {
+			e = pgh::LaunchColumnSums(g, N, k2, k2, d_colsum.As<double>(), st);
+		}
+		if (e == hipSuccess) {
+			e = pgh::LaunchPcaCombine(d_a.As<double>(), d_mm.As<double>(), d_colsum.As<double>(), d_center.As<double>(),
+			                          d_inv.As<double>(), M, k2, y_out, qq, st);
+		}
+		return e;
+	};
 	double *g1 = d_g1.As<double>();
 	double *g2 = d_g2.As<double>();
 	const uint8_t *mask2 = subset ? subset->d_mask2 : nullptr;
@@ -988,16 +1062,13 @@ extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, 
 		double *y = d_qq.As<double>() + static_cast<size_t>(pass) * k2;
 		// Step A: QQ[:, pass*2k : (pass+1)*2k] = X * G1   (rows of this shard only)
 		if (M) {
-			PGH_HIP(pgh::LaunchVariantReduce(view, d_vlist.As<uint32_t>(), M, d_ts.As<double>(), g1, k2, k2, y, qq, st),
-			        "pca step A");
+			PGH_HIP(contract_samples(g1, y), "pca step A");
 		}
 		if (pass < n_pcs) {
 			// Step B + merge: G1 = X^T Y / M, summed over shards
 			PGH_HIP(hipMemsetAsync(g2, 0, sizeof(double) * N * k2, st), "pca memset");
 			if (M) {
-				PGH_HIP(pgh::LaunchTableAccumulate(view, d_vlist.As<uint32_t>(), M, y, qq, k2, d_ts.As<double>(),
-				                                   nullptr, nullptr, false, g2, k2, nullptr, nullptr, st),
-				        "pca step B");
+				PGH_HIP(contract_variants(y, qq, k2, g2, k2), "pca step B");
 			}
 			PGH_SUM(g2, static_cast<uint64_t>(N) * k2);
 			PGH_HIP(pgh::LaunchMaskRows(g2, N, k2, k2, mask2, st), "pca mask");
@@ -1067,10 +1138,7 @@ extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, 
 	PGH_HIP(d_bb.Alloc(sizeof(double) * static_cast<size_t>(N) * qq), "hipMalloc(pca)");
 	PGH_HIP(hipMemsetAsync(d_bb.p, 0, sizeof(double) * static_cast<size_t>(N) * qq, st), "pca memset");
 	if (M) {
-		PGH_HIP(pgh::LaunchTableAccumulate(view, d_vlist.As<uint32_t>(), M, d_qq.As<double>(), qq, qq,
-		                                   d_ts.As<double>(), nullptr, nullptr, false, d_bb.As<double>(), qq, nullptr,
-		                                   nullptr, st),
-		        "pca phase 3");
+		PGH_HIP(contract_variants(d_qq.As<double>(), qq, qq, d_bb.As<double>(), qq), "pca phase 3");
 	}
 	PGH_SUM(d_bb.As<double>(), static_cast<uint64_t>(N) * qq);
 	PGH_HIP(pgh::LaunchMaskRows(d_bb.As<double>(), N, qq, qq, mask2, st), "pca mask");

@@ -130,6 +130,21 @@ hipError_t LaunchTallTimesSmall(const double *A, uint32_t lda, uint32_t na, cons
 hipError_t LaunchCopyCols(const double *src, uint32_t ld_src, double *dst, uint32_t ld_dst, uint32_t n, uint64_t m,
                           hipStream_t stream);
 
+// ---- plink_pca on the int8 contraction (pca_i8.hip) -----------------------------
+// The packed matrix of the listed variants, sample-major: out row s = calls of sample s at vlist[0..n_var), 2 bits
+// each, rows TransposedPitch(n_var) bytes apart (zero padded); out holds view.sample_ct rows.
+uint64_t TransposedPitch(uint32_t n_var);
+hipError_t LaunchTranspose2bit(const RowView &view, const uint32_t *vlist, uint32_t n_var, uint8_t *out,
+                               hipStream_t stream);
+hipError_t LaunchIota(uint32_t *p, uint32_t n, hipStream_t stream);
+// out[c] = sum_r m[r * stride + c]
+hipError_t LaunchColumnSums(const double *m, uint64_t n_rows, uint32_t stride, uint32_t n_cols, double *out,
+                            hipStream_t stream);
+// y[v * y_stride + c] = s_v (a[v][c] - 3 mm[v][c]) - c_v s_v (colsum[c] - mm[v][c]);  a, mm: n_var x n_cols, dense
+hipError_t LaunchPcaCombine(const double *a, const double *mm, const double *colsum, const double *center,
+                            const double *inv_stdev, uint64_t n_var, uint32_t n_cols, double *y, uint32_t y_stride,
+                            hipStream_t stream);
+
 // ---- shard-group combine (reduce.hip) -----------------------------------------
 // dst[i] += src[i]; both 16-byte aligned device buffers of the current device
 hipError_t LaunchAddF64(double *dst, const double *src, uint64_t n, hipStream_t stream);

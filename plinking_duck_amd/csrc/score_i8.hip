@@ -51,9 +51,17 @@ struct Coef {
 // coefficients of target column t at variant i: t < n_cols a weight column, t == n_cols the dosage sum
 __device__ __forceinline__ Coef CoefOf(uint32_t i, uint32_t t, uint32_t n_cols, const double *__restrict__ weights,
                                        uint32_t w_stride, const double *__restrict__ ts,
-                                       const double *__restrict__ td) {
-	const double *tab = (t < n_cols) ? ts : td;
+                                       const double *__restrict__ td, int table_mode) {
 	const double w = (t < n_cols) ? weights[static_cast<uint64_t>(i) * w_stride + t] : 1.0;
+	if (table_mode != kI8Tables) {
+		// bare planes (plink_pca's X G1 over the transposed matrix): the code itself, or the missing indicator
+		Coef c;
+		c.alpha = table_mode == kI8CodePlane ? w : 0.0;
+		c.beta = table_mode == kI8MissingPlane ? w : 0.0;
+		c.k0 = 0.0;
+		return c;
+	}
+	const double *tab = (t < n_cols) ? ts : td;
 	const double t0 = tab[4ull * i], t1 = tab[4ull * i + 1], t3 = tab[4ull * i + 3];
 	const double d = t1 - t0;
 	Coef c;
@@ -93,14 +101,14 @@ __device__ __forceinline__ double BlockSum(double v, double *s_red) {
 // monotone under integer max); k0[t] = sum over variants of W t0.  grid.y = target column.
 __global__ __launch_bounds__(256) void k_i8_ranges(uint32_t n_var, uint32_t n_cols, const double *__restrict__ weights,
                                                    uint32_t w_stride, const double *__restrict__ ts,
-                                                   const double *__restrict__ td,
+                                                   const double *__restrict__ td, int table_mode,
                                                    unsigned long long *__restrict__ colmax,
                                                    double *__restrict__ k0) {
 	__shared__ double s_red[4];
 	const uint32_t t = blockIdx.y;
 	double mx = 0.0, sum = 0.0;
 	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_var; i += gridDim.x * 256u) {
-		const Coef c = CoefOf(i, t, n_cols, weights, w_stride, ts, td);
+		const Coef c = CoefOf(i, t, n_cols, weights, w_stride, ts, td, table_mode);
 		mx = fmax(mx, fmax(fabs(c.alpha), fabs(c.beta)));
 		sum += c.k0;
 	}
@@ -112,21 +120,22 @@ __global__ __launch_bounds__(256) void k_i8_ranges(uint32_t n_var, uint32_t n_co
 	}
 }
 
-// Digit columns: weight column c owns columns [7c, 7c+7), the dosage sum the next 5, the missing count 1.
-__host__ __device__ constexpr uint32_t DigitColumns(uint32_t n_cols) {
-	return kI8WeightDigits * n_cols + kI8DosageDigits + 1u;
+// Digit columns: weight column c owns columns [7c, 7c+7); with `extras` (plink_score) the dosage sum takes the
+// next 5 and the missing count 1.
+__host__ __device__ constexpr uint32_t DigitColumns(uint32_t n_cols, bool extras) {
+	return kI8WeightDigits * n_cols + (extras ? kI8DosageDigits + 1u : 0u);
 }
 
 // mult[J] = value of one unit of digit column J; target[J] = output column (n_cols: dosage sum,
 // n_cols + 1: missing count, 0xffffffff: unused)
-__global__ void k_i8_columns(uint32_t n_cols, uint32_t n_tiles16, const unsigned long long *__restrict__ colmax,
+__global__ void k_i8_columns(uint32_t n_cols, int extras, uint32_t n_tiles16, const unsigned long long *__restrict__ colmax,
                              double *__restrict__ scale_exp, double *__restrict__ mult,
                              uint32_t *__restrict__ target) {
 	const uint32_t J = blockIdx.x * blockDim.x + threadIdx.x;
 	if (J >= n_tiles16 * 16u) {
 		return;
 	}
-	const uint32_t used = DigitColumns(n_cols);
+	const uint32_t used = DigitColumns(n_cols, extras != 0);
 	if (J >= used) {
 		mult[J] = 0.0;
 		target[J] = 0xffffffffu;
@@ -181,7 +190,7 @@ __device__ __forceinline__ uint64_t BmatOffset(uint32_t i, uint32_t plane, uint3
 __global__ __launch_bounds__(256) void k_i8_digits(uint32_t n_var, uint32_t n_cols, uint32_t n_tiles16,
                                                    const double *__restrict__ weights, uint32_t w_stride,
                                                    const double *__restrict__ ts, const double *__restrict__ td,
-                                                   const uint32_t *__restrict__ ac, int count_missing,
+                                                   const uint32_t *__restrict__ ac, int count_missing, int table_mode,
                                                    const double *__restrict__ scale_exp, int8_t *__restrict__ bmat) {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	const uint32_t t = blockIdx.y; // 0..n_cols: weight columns, dosage; n_cols + 1: the missing count
@@ -193,10 +202,10 @@ __global__ __launch_bounds__(256) void k_i8_digits(uint32_t n_var, uint32_t n_co
 		// away are those that count 2 for a present call and nothing for a missing one
 		const uint32_t a = ac[i];
 		const bool counts = count_missing && (a & 0xffu) != 0u && ((a >> 8) & 0xffu) == 0u;
-		bmat[BmatOffset(i, 1, DigitColumns(n_cols) - 1u, n_tiles16)] = counts ? 1 : 0;
+		bmat[BmatOffset(i, 1, DigitColumns(n_cols, true) - 1u, n_tiles16)] = counts ? 1 : 0;
 		return;
 	}
-	const Coef c = CoefOf(i, t, n_cols, weights, w_stride, ts, td);
+	const Coef c = CoefOf(i, t, n_cols, weights, w_stride, ts, td, table_mode);
 	const uint32_t digits = t < n_cols ? kI8WeightDigits : kI8DosageDigits;
 	const uint32_t J0 = t < n_cols ? kI8WeightDigits * t : kI8WeightDigits * n_cols;
 	const int e = static_cast<int>(scale_exp[t]);
@@ -264,7 +273,9 @@ constexpr uint32_t RingSlots() {
 	return 4u * (64u * 16u * TS + 2048u * NT) + 4096u <= 80u * 1024u ? 4u : 3u;
 }
 
-template <int NT, int TS>
+// PLANES: 3 = code plane and missing plane (plink_score, plink_pca's X^T Y); 1 / 2 = one of them alone (the two
+// products of plink_pca's X G1, whose per-variant normalisation is applied afterwards).
+template <int NT, int TS, int PLANES>
 __global__ __launch_bounds__(256) void k_score_i8(const uint8_t *__restrict__ rows, uint64_t pitch, uint32_t sample_ct,
                                                   const uint32_t *__restrict__ rowidx, uint32_t n_tiles,
                                                   uint32_t tiles_per_slice, const int8_t *__restrict__ bmat,
@@ -409,8 +420,12 @@ __global__ __launch_bounds__(256) void k_score_i8(const uint8_t *__restrict__ ro
 #pragma unroll
 			for (int h = 0; h < kHold; h++) {
 				if (nt0 + h < NT) {
-					bg[h] = bp[((0 * NT + nt0 + h) * 4 + g) * 16 + x];
-					bm[h] = bp[((1 * NT + nt0 + h) * 4 + g) * 16 + x];
+					if (PLANES & 1) {
+						bg[h] = bp[((0 * NT + nt0 + h) * 4 + g) * 16 + x];
+					}
+					if (PLANES & 2) {
+						bm[h] = bp[((1 * NT + nt0 + h) * 4 + g) * 16 + x];
+					}
 				}
 			}
 #pragma unroll
@@ -439,8 +454,12 @@ __global__ __launch_bounds__(256) void k_score_i8(const uint8_t *__restrict__ ro
 #pragma unroll
 					for (int h = 0; h < kHold; h++) {
 						if (nt0 + h < NT) {
-							acc[t][nt0 + h] = __builtin_amdgcn_mfma_i32_16x16x64_i8(u, bg[h], acc[t][nt0 + h], 0, 0, 0);
-							acc[t][nt0 + h] = __builtin_amdgcn_mfma_i32_16x16x64_i8(m, bm[h], acc[t][nt0 + h], 0, 0, 0);
+							if (PLANES & 1) {
+								acc[t][nt0 + h] = __builtin_amdgcn_mfma_i32_16x16x64_i8(u, bg[h], acc[t][nt0 + h], 0, 0, 0);
+							}
+							if (PLANES & 2) {
+								acc[t][nt0 + h] = __builtin_amdgcn_mfma_i32_16x16x64_i8(m, bm[h], acc[t][nt0 + h], 0, 0, 0);
+							}
 						}
 					}
 				}
@@ -543,14 +562,14 @@ __global__ __launch_bounds__(256) void k_i8_rowidx(const uint32_t *__restrict__ 
 
 } // namespace
 
-uint32_t ScoreI8Tiles16(uint32_t n_cols) {
-	return (DigitColumns(n_cols) + 15u) / 16u;
+uint32_t ScoreI8Tiles16(uint32_t n_cols, bool extras) {
+	return (DigitColumns(n_cols, extras) + 15u) / 16u;
 }
 
-ScoreI8Sizes ScoreI8Bytes(uint32_t n_var, uint32_t n_cols) {
+ScoreI8Sizes ScoreI8Bytes(uint32_t n_var, uint32_t n_cols, bool extras) {
 	ScoreI8Sizes z;
 	z.n_tiles = ((n_var + kTileVariants - 1) / kTileVariants + 1u) & ~1u; // an even number: the kernel walks tile pairs
-	z.n_tiles16 = ScoreI8Tiles16(n_cols);
+	z.n_tiles16 = ScoreI8Tiles16(n_cols, extras);
 	z.bmat = static_cast<size_t>(z.n_tiles) * 2u * z.n_tiles16 * 1024u;
 	z.rowidx = sizeof(uint32_t) * static_cast<size_t>(z.n_tiles) * kTileVariants;
 	z.cols = static_cast<size_t>(z.n_tiles16) * 16u * (sizeof(double) + sizeof(uint32_t));
@@ -560,14 +579,22 @@ ScoreI8Sizes ScoreI8Bytes(uint32_t n_var, uint32_t n_cols) {
 
 hipError_t LaunchScoreI8Prepare(const uint32_t *vlist, uint32_t n_var, const double *weights, uint32_t w_stride,
                                 uint32_t n_cols, const double *ts, const double *td, const uint32_t *ac,
-                                bool count_missing, const ScoreI8Buffers &b, hipStream_t stream) {
+                                bool count_missing, bool extras, int table_mode, const ScoreI8Buffers &b,
+                                hipStream_t stream) {
 	if (n_var == 0) {
 		return hipSuccess;
 	}
-	const ScoreI8Sizes z = ScoreI8Bytes(n_var, n_cols);
+	const ScoreI8Sizes z = ScoreI8Bytes(n_var, n_cols, extras);
 	hipError_t e = hipMemsetAsync(b.bmat, 0, z.bmat, stream);
+	// (the three small arrays need not be adjacent: a caller may size one block for its widest pass)
 	if (e == hipSuccess) {
-		e = hipMemsetAsync(b.colmax, 0, z.small, stream); // colmax, k0, scale_exp
+		e = hipMemsetAsync(b.colmax, 0, sizeof(unsigned long long) * (n_cols + 2u), stream);
+	}
+	if (e == hipSuccess) {
+		e = hipMemsetAsync(b.k0, 0, sizeof(double) * (n_cols + 2u), stream);
+	}
+	if (e == hipSuccess) {
+		e = hipMemsetAsync(b.scale_exp, 0, sizeof(double) * (n_cols + 2u), stream);
 	}
 	if (e != hipSuccess) {
 		return e;
@@ -575,24 +602,25 @@ hipError_t LaunchScoreI8Prepare(const uint32_t *vlist, uint32_t n_var, const dou
 	const uint32_t blocks = (n_var + 255) / 256;
 	hipLaunchKernelGGL(k_i8_rowidx, dim3((z.n_tiles * kTileVariants + 255) / 256), dim3(256), 0, stream, vlist, n_var,
 	                   z.n_tiles * kTileVariants, b.rowidx);
-	hipLaunchKernelGGL(k_i8_ranges, dim3(blocks < 1024 ? blocks : 1024, n_cols + 1), dim3(256), 0, stream, n_var, n_cols,
-	                   weights, w_stride, ts, td, b.colmax, b.k0);
-	hipLaunchKernelGGL(k_i8_columns, dim3((z.n_tiles16 * 16 + 63) / 64), dim3(64), 0, stream, n_cols, z.n_tiles16,
-	                   b.colmax, b.scale_exp, b.mult, b.target);
-	hipLaunchKernelGGL(k_i8_digits, dim3(blocks, n_cols + 2), dim3(256), 0, stream, n_var, n_cols, z.n_tiles16, weights,
-	                   w_stride, ts, td, ac, count_missing ? 1 : 0, b.scale_exp, b.bmat);
+	const uint32_t n_targets = n_cols + (extras ? 1u : 0u); // real-valued columns: the weights (+ the dosage sum)
+	hipLaunchKernelGGL(k_i8_ranges, dim3(blocks < 1024 ? blocks : 1024, n_targets), dim3(256), 0, stream, n_var, n_cols,
+	                   weights, w_stride, ts, td, table_mode, b.colmax, b.k0);
+	hipLaunchKernelGGL(k_i8_columns, dim3((z.n_tiles16 * 16 + 63) / 64), dim3(64), 0, stream, n_cols, extras ? 1 : 0,
+	                   z.n_tiles16, b.colmax, b.scale_exp, b.mult, b.target);
+	hipLaunchKernelGGL(k_i8_digits, dim3(blocks, n_targets + (extras ? 1u : 0u)), dim3(256), 0, stream, n_var, n_cols,
+	                   z.n_tiles16, weights, w_stride, ts, td, ac, count_missing ? 1 : 0, table_mode, b.scale_exp, b.bmat);
 	return hipGetLastError();
 }
 
-template <int NT, int TS>
-static hipError_t LaunchI8(const RowView &view, uint32_t n_var, uint32_t n_cols, const ScoreI8Buffers &b, double *score,
+template <int NT, int TS, int PLANES>
+static hipError_t LaunchI8(const RowView &view, uint32_t n_tiles, uint32_t n_cols, const ScoreI8Buffers &b, double *score,
                            uint32_t out_stride, double *dosage_sum, uint32_t *missing_ct, hipStream_t stream) {
 	using S = I8Shape<NT, TS>;
-	const uint32_t n_tiles = ScoreI8Bytes(n_var, n_cols).n_tiles;
 	const uint32_t groups = (view.sample_ct + S::kSamplesPerGroup - 1) / S::kSamplesPerGroup;
-	// enough workgroups to fill the chip several times over; a slice keeps the int32 sums far from overflow
-	// (operand bytes reach 96, digits 128) and its digit bytes inside one XCD's L2
-	uint32_t want = (8192u + groups - 1) / groups;
+	// enough workgroups to fill the chip several times over (every slice ends in one atomic add per sample and
+	// digit column, so no more than that); a slice keeps the int32 sums far from overflow (operand bytes reach
+	// 96, digits 128) and its digit bytes inside one XCD's L2
+	uint32_t want = (4096u + groups - 1) / groups;
 	uint32_t tps = (n_tiles + want - 1) / want;
 	const uint32_t tps_min = 16, tps_max = 1024; // 1,024 .. 65,536 variants: |int32 sum| <= 16,384 per variant
 	tps = tps < tps_min ? tps_min : (tps > tps_max ? tps_max : tps);
@@ -601,49 +629,56 @@ static hipError_t LaunchI8(const RowView &view, uint32_t n_var, uint32_t n_cols,
 	if (slices > 65535u) {
 		return hipErrorInvalidValue;
 	}
-	hipLaunchKernelGGL((k_score_i8<NT, TS>), dim3(groups, slices), dim3(256), 0, stream, view.rows, view.pitch,
+	hipLaunchKernelGGL((k_score_i8<NT, TS, PLANES>), dim3(groups, slices), dim3(256), 0, stream, view.rows, view.pitch,
 	                   view.sample_ct, b.rowidx, n_tiles, tps, b.bmat, b.mult, b.target, n_cols, score, out_stride,
 	                   dosage_sum, missing_ct);
 	return hipGetLastError();
 }
 
-hipError_t LaunchScoreI8(const RowView &view, uint32_t n_var, uint32_t n_cols, const ScoreI8Buffers &b, double *score,
-                         uint32_t out_stride, double *dosage_sum, uint32_t *missing_ct, hipStream_t stream) {
+template <int PLANES>
+static hipError_t LaunchI8Shape(uint32_t nt, const RowView &view, uint32_t n_tiles, uint32_t n_cols,
+                                const ScoreI8Buffers &b, double *score, uint32_t out_stride, double *dosage_sum,
+                                uint32_t *missing_ct, hipStream_t stream) {
+#define PGH_I8(NT, TS)                                                                                                 \
+	case NT:                                                                                                           \
+		return LaunchI8<NT, TS, PLANES>(view, n_tiles, n_cols, b, score, out_stride, dosage_sum, missing_ct, stream)
+	switch (nt) {
+		PGH_I8(1, 16);
+		PGH_I8(2, 16);
+		PGH_I8(3, 8);
+		PGH_I8(4, 8);
+		PGH_I8(5, 4);
+		PGH_I8(6, 4);
+		PGH_I8(7, 4);
+		PGH_I8(8, 4);
+	default:
+		return hipErrorInvalidValue; // the caller splits wider weight sets into passes of <= kI8MaxCols columns
+	}
+#undef PGH_I8
+}
+
+hipError_t LaunchScoreI8(const RowView &view, uint32_t n_var, uint32_t n_cols, bool extras, int planes,
+                         const ScoreI8Buffers &b, double *score, uint32_t out_stride, double *dosage_sum,
+                         uint32_t *missing_ct, hipStream_t stream) {
 	if (n_var == 0) {
 		return hipSuccess;
 	}
-	const uint32_t nt = ScoreI8Tiles16(n_cols);
+	const ScoreI8Sizes z = ScoreI8Bytes(n_var, n_cols, extras);
 	hipError_t e;
-	if (nt == 1) {
-		e = LaunchI8<1, 16>(view, n_var, n_cols, b, score, out_stride, dosage_sum, missing_ct, stream);
-	} else if (nt == 2) {
-		e = LaunchI8<2, 16>(view, n_var, n_cols, b, score, out_stride, dosage_sum, missing_ct, stream);
-	} else if (nt <= 4) {
-		e = nt == 3 ? LaunchI8<3, 8>(view, n_var, n_cols, b, score, out_stride, dosage_sum, missing_ct, stream)
-		            : LaunchI8<4, 8>(view, n_var, n_cols, b, score, out_stride, dosage_sum, missing_ct, stream);
-	} else if (nt <= 8) {
-		switch (nt) {
-		case 5:
-			e = LaunchI8<5, 4>(view, n_var, n_cols, b, score, out_stride, dosage_sum, missing_ct, stream);
-			break;
-		case 6:
-			e = LaunchI8<6, 4>(view, n_var, n_cols, b, score, out_stride, dosage_sum, missing_ct, stream);
-			break;
-		case 7:
-			e = LaunchI8<7, 4>(view, n_var, n_cols, b, score, out_stride, dosage_sum, missing_ct, stream);
-			break;
-		default:
-			e = LaunchI8<8, 4>(view, n_var, n_cols, b, score, out_stride, dosage_sum, missing_ct, stream);
-			break;
-		}
+	if (planes == kI8CodePlane) {
+		e = LaunchI8Shape<1>(z.n_tiles16, view, z.n_tiles, n_cols, b, score, out_stride, dosage_sum, missing_ct, stream);
+	} else if (planes == kI8MissingPlane) {
+		e = LaunchI8Shape<2>(z.n_tiles16, view, z.n_tiles, n_cols, b, score, out_stride, dosage_sum, missing_ct, stream);
 	} else {
-		return hipErrorInvalidValue; // the caller splits wider weight sets into passes of <= kI8MaxCols columns
+		e = LaunchI8Shape<3>(z.n_tiles16, view, z.n_tiles, n_cols, b, score, out_stride, dosage_sum, missing_ct, stream);
 	}
 	if (e != hipSuccess) {
 		return e;
 	}
-	hipLaunchKernelGGL(k_i8_constants, dim3((view.sample_ct + 255) / 256), dim3(256), 0, stream, view.sample_ct, n_cols,
-	                   b.k0, score, out_stride, dosage_sum);
+	if (planes == kI8Tables) {
+		hipLaunchKernelGGL(k_i8_constants, dim3((view.sample_ct + 255) / 256), dim3(256), 0, stream, view.sample_ct,
+		                   n_cols, b.k0, score, out_stride, dosage_sum);
+	}
 	return hipGetLastError();
 }
 

@@ -10,14 +10,20 @@ namespace pgh {
 constexpr uint32_t kI8WeightDigits = 7; // base-256 digits per weight column: 54 bits below the column's largest coefficient
 constexpr uint32_t kI8DosageDigits = 5; // NAMED_ALLELE_DOSAGE_SUM: terms are >= 0 and <= 3, 38 bits suffice
 constexpr uint32_t kI8MaxCols = 17;     // weight columns per pass: 7 * 17 + 5 + 1 = 125 <= 128 digit columns (8 tiles)
+constexpr uint32_t kI8MaxColsBare = 18; // ... without the dosage-sum / missing-count columns: 7 * 18 = 126
+
+// What the two integer planes are multiplied with.  kI8Tables: per-variant contribution tables (ts / td), both
+// planes; kI8CodePlane / kI8MissingPlane: the bare 2-bit code resp. the missing indicator times the weight, one
+// plane only -- the two products plink_pca's X G1 is made of (its normalisation is per OUTPUT row).
+enum { kI8Tables = 0, kI8CodePlane = 1, kI8MissingPlane = 2 };
 
 struct ScoreI8Sizes {
 	uint32_t n_tiles = 0;   // 64-variant tiles
 	uint32_t n_tiles16 = 0; // 16-column digit tiles
 	size_t bmat = 0, rowidx = 0, cols = 0, small = 0;
 };
-ScoreI8Sizes ScoreI8Bytes(uint32_t n_var, uint32_t n_cols);
-uint32_t ScoreI8Tiles16(uint32_t n_cols);
+ScoreI8Sizes ScoreI8Bytes(uint32_t n_var, uint32_t n_cols, bool extras);
+uint32_t ScoreI8Tiles16(uint32_t n_cols, bool extras);
 
 // Device buffers of one prepared pass (sizes from ScoreI8Bytes):
 //   bmat    digit bytes of both planes, tile by tile           (bmat bytes)
@@ -38,14 +44,18 @@ struct ScoreI8Buffers {
 // missing-call count into digits.  ts / td: the per-variant tables of LaunchScoreTables (four doubles each);
 // ac: its allele-count increments; count_missing: ALLELE_CT loses 2 per missing call (every mode but mean
 // imputation).  Runs once per plan.
+// extras: also the dosage-sum and missing-count columns (n_cols <= kI8MaxCols; without them kI8MaxColsBare,
+// td / ac unused).  table_mode: kI8Tables, or one bare plane (ts / td unused).
 hipError_t LaunchScoreI8Prepare(const uint32_t *vlist, uint32_t n_var, const double *weights, uint32_t w_stride,
                                 uint32_t n_cols, const double *ts, const double *td, const uint32_t *ac,
-                                bool count_missing, const ScoreI8Buffers &b, hipStream_t stream);
+                                bool count_missing, bool extras, int table_mode, const ScoreI8Buffers &b,
+                                hipStream_t stream);
 
 // score[s * out_stride + c] += sum_v W[v][c] T_v[g(v,s)] for the prepared columns; dosage_sum[s] += the same with
 // td and unit weights (NULL: not wanted); missing_ct[s] += missing calls of s at the variants that count
 // (NULL: not wanted).  Outputs are raw-sample order and are added to.
-hipError_t LaunchScoreI8(const RowView &view, uint32_t n_var, uint32_t n_cols, const ScoreI8Buffers &b, double *score,
-                         uint32_t out_stride, double *dosage_sum, uint32_t *missing_ct, hipStream_t stream);
+hipError_t LaunchScoreI8(const RowView &view, uint32_t n_var, uint32_t n_cols, bool extras, int planes,
+                         const ScoreI8Buffers &b, double *score, uint32_t out_stride, double *dosage_sum,
+                         uint32_t *missing_ct, hipStream_t stream);
 
 } // namespace pgh
