@@ -182,6 +182,17 @@ def self_launch(args):
         raise SystemExit(f"bench.py: a rank exited with status {rc}; no line reported")
 
 
+def i8_contract_ops(n_contract, n_out, n_cols, planes, extras):
+    """int8 multiply-adds x 2 of one contraction on v_mfma_i32_16x16x64_i8 (score_i8.hip): 7 digit columns per
+    real column (+6 with plink_score's dosage-sum / missing-count columns), 16 per tile, <= 22 real columns per
+    pass, one instruction per plane, tile and 16 outputs x 64 contracted rows."""
+    ops = 0.0
+    for c0 in range(0, n_cols, 22):
+        tiles16 = (7 * min(22, n_cols - c0) + (6 if extras else 0) + 15) // 16
+        ops += 2.0 * (((n_contract + 127) // 128) * 128) * (((n_out + 15) // 16) * 16) * 16 * planes * tiles16
+    return ops
+
+
 def host_tallies(np, rec, n):
     """{hom_ref, het, hom_alt, missing} of one packed 2-bit record, recomputed on the host with numpy."""
     codes = (rec[:, None] >> np.array([0, 2, 4, 6], dtype=np.uint8)) & 3
@@ -541,6 +552,10 @@ def main():
         algo_bytes = (k + 2) * m_eff * record_bytes
         # k power passes (A+B) + the last Step A + phase 3
         algo_flops = k * (2 * 2.0 * m_eff * n * 2 * k) + 2.0 * m_eff * n * 2 * k + 2.0 * m_eff * n * qq
+        # on the int8 matrix cores: Step A = two single-plane contractions over the samples (transposed matrix),
+        # Step B and phase 3 = two-plane contractions over the variants
+        i8_ops = ((k + 1) * 2 * i8_contract_ops(n, m_eff, 2 * k, 1, False) + k * i8_contract_ops(m_eff, n, 2 * k, 2, False)
+                  + i8_contract_ops(m_eff, n, qq, 2, False))
         pca_ev = []
 
         def step(timed):
@@ -557,9 +572,9 @@ def main():
                 e1.record(stream)
                 kernel_events.append((e0, e1))
 
-        kernel_name = "pgh_pca (k_variant_reduce_mfma + k_accumulate_mfma + orthonormalisation)"
+        kernel_name = "pgh_pca (k_score_i8 over rows and over the transposed matrix + orthonormalisation)"
         metric = f"plink_pca genotypes/s (n_pcs={k}, {k + 2} passes)"
-        dtype = "f64"
+        dtype = "i8 x i8 -> i32 (exact base-256 digits of the f64 factors), f64 elsewhere"
     else:  # score
         ncol = args.score_cols
         rng = np.random.default_rng(SEED + 1)
@@ -572,11 +587,8 @@ def main():
         algo_flops = 2.0 * m * n * ncol
         # the contraction runs on v_mfma_i32_16x16x64_i8 over exact fixed-point digits of the weights
         # (score_i8.hip): 7 digit columns per weight column + 6 (dosage sum, missing count), 16 per tile,
-        # two planes (calls, missing calls) per tile, <= 17 weight columns per pass
-        i8_ops = 0.0
-        for c0 in range(0, ncol, 17):
-            tiles16 = (7 * min(17, ncol - c0) + 6 + 15) // 16
-            i8_ops += 2.0 * (((m + 127) // 128) * 128) * (((n + 15) // 16) * 16) * 16 * 2 * tiles16
+        # two planes (calls, missing calls) per tile, <= 22 weight columns per pass
+        i8_ops = i8_contract_ops(m, n, ncol, 2, True)
         plan = ds.score_plan(vidx, w, None, L.SCORE_MEAN_IMPUTE)  # weights + per-variant tables resident
 
         def step(timed):
@@ -628,7 +640,7 @@ def main():
         total_units = units_per_step * (world if args.scaling == "weak" else 1)  # sample pairs, every rank the same shape
     value = total_units * args.steps / elapsed
 
-    if args.workload == "score" and args.score_cols >= 2:
+    if (args.workload == "score" and args.score_cols >= 2) or args.workload == "pca":
         # priced against the dense int8 matrix peak (the instruction the kernel issues); the f64 FLOP rate the
         # same contraction would need on the FP64 pipes is given beside it
         achieved = i8_ops / (kern_avg_ms * 1e-3) / 1e12
@@ -637,11 +649,6 @@ def main():
                     "kernel_ms_avg": kern_avg_ms, "launches_timed": len(kernel_ms), "ops": "int8 multiply-adds x 2",
                     "f64_equivalent_tflops": algo_flops / (kern_avg_ms * 1e-3) / 1e12,
                     "hbm_frac": algo_bytes / (kern_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
-    elif algo_flops is not None and args.workload == "pca":
-        achieved = algo_flops / (kern_avg_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None, "kernel": kernel_name,
-                    "kernel_ms_avg": kern_avg_ms, "launches_timed": len(kernel_ms)}
     else:
         achieved = algo_bytes / (kern_avg_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -309,7 +309,10 @@ __global__ __launch_bounds__(256) void k_score_i8(const uint8_t *__restrict__ ro
 	// issued its row numbers are plain LDS reads.  Nothing in the loop is an ordinary vector load, so the only
 	// vmcnt wait is the counted one that retires the oldest tile in flight.
 	constexpr uint32_t kGenoPieces = S::kChunksPerThread;      // per wave and tile
-	constexpr uint32_t kBPieces = (S::kBChunks + 255u) / 256u; // per wave and tile (the last may be half a wave)
+	// digit bytes: 1 KiB pieces, NT per plane; only the planes this instantiation multiplies are fetched
+	constexpr uint32_t kBFirstPiece = (PLANES & 1) ? 0u : NT;
+	constexpr uint32_t kBPieceCount = PLANES == 3 ? 2u * NT : NT;
+	constexpr uint32_t kBPieces = (kBPieceCount + 3u) / 4u; // per wave and tile
 	constexpr uint32_t kPieces = kGenoPieces + kBPieces + 1u;  // + the row numbers
 	constexpr uint32_t kRowAhead = 2u * kRing - 2u;            // tiles between a row-number DMA and its use
 	static_assert(kPieces * (kRing - 2) < 64, "vmcnt field");
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(256) void k_score_i8(const uint8_t *__restrict__ ro
 		for (uint32_t n = 0; n < kBPieces; n++) {
 			// every wave issues every piece (the vmcnt arithmetic wants equal counts): pieces past the digit bytes
 			// repeat the last one
-			const uint32_t p = min(4u * n + wave_u, S::kBChunks / 64u - 1u);
+			const uint32_t p = kBFirstPiece + min(4u * n + wave_u, kBPieceCount - 1u);
 			Glds16(bsrc + 1024ull * p + 16u * lane, base + S::kGenoBytes + p * 1024u);
 		}
 	};
@@ -499,15 +502,23 @@ __global__ __launch_bounds__(256) void k_score_i8(const uint8_t *__restrict__ ro
 #undef PGH_WAIT_VM
 
 	// ---- epilogue: lane (j = lane & 15, g) holds digit column 16 nt + j of the sample slots 4 g + r ----
+	// The digits of one output column sit in up to seven NEIGHBOURING lanes of a 16-lane row: they are scaled,
+	// summed across those lanes (three shuffle steps inside the row, gated on "same output column") and the lane
+	// that holds the column's lowest digit of this tile issues ONE atomic add per sample.
 	const uint32_t wave_sample0 = blockIdx.x * S::kSamplesPerGroup + wave * 16u * TS;
 #pragma unroll
 	for (int nt = 0; nt < NT; nt++) {
 		const uint32_t J = 16u * nt + x;
 		const uint32_t tg = target[J];
-		if (tg == 0xffffffffu) {
-			continue;
+		const double mu = tg == 0xffffffffu ? 0.0 : mult[J];
+		// which of the next 1, 2, 4 lanes of this row carry a digit of the same output column
+		bool same[3];
+#pragma unroll
+		for (int st = 0; st < 3; st++) {
+			const uint32_t off = 1u << st;
+			same[st] = tg != 0xffffffffu && x + off < 16u && target[J + off] == tg;
 		}
-		const double mu = mult[J];
+		const bool head = tg != 0xffffffffu && (x == 0u || target[J - 1] != tg);
 #pragma unroll
 		for (int t = 0; t < TS; t++) {
 			// sample t of the lane's span was multiplied at scale {1, 4, 16, 32}[t & 3]: exact powers of two
@@ -517,15 +528,23 @@ __global__ __launch_bounds__(256) void k_score_i8(const uint8_t *__restrict__ ro
 			for (int r = 0; r < 4; r++) {
 				const uint32_t s = wave_sample0 + TS * (4u * g + r) + t;
 				const int v = acc[t][nt][r];
-				if (s < sample_ct && v != 0) {
-					if (tg < n_cols) {
-						unsafeAtomicAdd(score + static_cast<uint64_t>(s) * out_stride + tg, mu_t * static_cast<double>(v));
-					} else if (tg == n_cols) {
-						if (dosage_sum) {
-							unsafeAtomicAdd(dosage_sum + s, mu_t * static_cast<double>(v));
-						}
-					} else if (missing_ct) {
+				if (tg == n_cols + 1u) { // the missing count: an integer column of its own
+					if (missing_ct && s < sample_ct && v != 0) {
 						atomicAdd(missing_ct + s, static_cast<uint32_t>(v / scale));
+					}
+					continue;
+				}
+				double val = mu_t * static_cast<double>(v);
+#pragma unroll
+				for (int st = 0; st < 3; st++) {
+					const double up = __shfl_down(val, 1u << st, 16);
+					val += same[st] ? up : 0.0;
+				}
+				if (head && s < sample_ct && val != 0.0) {
+					if (tg < n_cols) {
+						unsafeAtomicAdd(score + static_cast<uint64_t>(s) * out_stride + tg, val);
+					} else if (dosage_sum) {
+						unsafeAtomicAdd(dosage_sum + s, val);
 					}
 				}
 			}
@@ -622,7 +641,18 @@ static hipError_t LaunchI8(const RowView &view, uint32_t n_tiles, uint32_t n_col
 	// 96, digits 128) and its digit bytes inside one XCD's L2
 	uint32_t want = (4096u + groups - 1) / groups;
 	uint32_t tps = (n_tiles + want - 1) / want;
-	const uint32_t tps_min = 16, tps_max = 1024; // 1,024 .. 65,536 variants: |int32 sum| <= 16,384 per variant
+	// 1,024 .. 128,000 variants per slice: |int32 sum| <= 16,384 per variant (operand bytes reach 96 + 32, digits
+	// 128) stays below 2^31.  Long slices win: every slice costs a ring fill and one atomic add per sample and
+	// column (64-tile slices ran plink_pca 2.7x slower than 1,024-tile ones).
+	const uint32_t tps_min = 16;
+	uint32_t tps_max = 2000;
+	static const int tps_env = [] {
+		const char *e = getenv("PGH_I8_TPS_MAX"); // tuning knob: tiles per slice
+		return e ? atoi(e) : 0;
+	}();
+	if (tps_env > 0 && tps_env < 2000) {
+		tps_max = static_cast<uint32_t>(tps_env);
+	}
 	tps = tps < tps_min ? tps_min : (tps > tps_max ? tps_max : tps);
 	tps = (tps + 1u) & ~1u;
 	uint32_t slices = (n_tiles + tps - 1) / tps;
@@ -651,6 +681,8 @@ static hipError_t LaunchI8Shape(uint32_t nt, const RowView &view, uint32_t n_til
 		PGH_I8(6, 4);
 		PGH_I8(7, 4);
 		PGH_I8(8, 4);
+		PGH_I8(9, 4);
+		PGH_I8(10, 4);
 	default:
 		return hipErrorInvalidValue; // the caller splits wider weight sets into passes of <= kI8MaxCols columns
 	}

@@ -9,8 +9,8 @@ namespace pgh {
 
 constexpr uint32_t kI8WeightDigits = 7; // base-256 digits per weight column: 54 bits below the column's largest coefficient
 constexpr uint32_t kI8DosageDigits = 5; // NAMED_ALLELE_DOSAGE_SUM: terms are >= 0 and <= 3, 38 bits suffice
-constexpr uint32_t kI8MaxCols = 17;     // weight columns per pass: 7 * 17 + 5 + 1 = 125 <= 128 digit columns (8 tiles)
-constexpr uint32_t kI8MaxColsBare = 18; // ... without the dosage-sum / missing-count columns: 7 * 18 = 126
+constexpr uint32_t kI8MaxCols = 22;     // weight columns per pass: 7 * 22 + 5 + 1 = 160 digit columns (10 tiles)
+constexpr uint32_t kI8MaxColsBare = 22; // ... without the dosage-sum / missing-count columns: 7 * 22 = 154
 
 // What the two integer planes are multiplied with.  kI8Tables: per-variant contribution tables (ts / td), both
 // planes; kI8CodePlane / kI8MissingPlane: the bare 2-bit code resp. the missing indicator times the weight, one
