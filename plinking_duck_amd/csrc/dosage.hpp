@@ -95,7 +95,7 @@ hipError_t LaunchScoreDosage(const RowView &view, const DosageView &dos, const u
                              const double *lin, const uint32_t *ac, int mode, double *score, uint32_t out_stride,
                              double *dosage_sum, uint32_t *miss, hipStream_t stream);
 
-//! The single-column form in two steps: the caller first runs the hardcall accumulate (LaunchScoreAccumulate)
+//! The single-column form in two steps: the caller first runs the hardcall contraction (LaunchScoreI8)
 //! over the same variants with the same tables; this adds (affine(dosage) - ts[call]) for the explicit entries
 //! and takes the samples that have a dosage but a missing call back out of `miss` (NULL: not tracked).
 hipError_t LaunchScoreDosageFix(const RowView &view, const DosageView &dos, const uint32_t *vlist, uint32_t n_scored,

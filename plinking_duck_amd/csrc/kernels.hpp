@@ -1,4 +1,5 @@
-// kernels.hpp -- launch wrappers of the gfx950 kernels (definitions in tally.hip, unpack.hip, score.hip, pca.hip).
+// kernels.hpp -- launch wrappers of the gfx950 kernels (definitions in tally.hip, unpack.hip, score.hip, pca.hip,
+// pca_i8.hip, reduce.hip; the int8 contraction has its own header, score_i8.hpp).
 // All pointers are device pointers unless named h_*.  Every wrapper only
 // enqueues work on `stream` and returns the hipError_t of the launch.
 #pragma once
@@ -85,35 +86,14 @@ hipError_t LaunchUnpackTransposed(const RowView &view, const uint32_t *vlist, ui
 // byte 1: g==3).  Skipped variants get all-zero tables.
 hipError_t LaunchScoreTables(const uint32_t *counts, const uint8_t *flip, uint32_t n_scored, int mode, double *ts,
                              double *td, uint32_t *ac, hipStream_t stream);
-// score[s][c] += sum_i w[i][c]*ts[i][g]; dosage_sum[s] += td[i][g]; allele_ct[s] += ac.
-// Outputs are raw-sample order, zeroed by the caller.
-// track_dosage: dosage_sum[s] += td[i][g] (false in plink_score's center mode, where td is all zero)
-hipError_t LaunchScoreAccumulate(const RowView &view, const uint32_t *vlist, uint32_t n_scored, const double *weights,
-                                 uint32_t n_cols, const double *ts, const double *td, const uint32_t *ac,
-                                 bool track_dosage, double *score, double *dosage_sum, uint32_t *allele_ct,
-                                 hipStream_t stream);
-
 // allele_ct[s] = sum_i (ac[i] & 0xff) - 2 * miss[s]   (miss == NULL: every sample gets the full sum)
 hipError_t LaunchAlleleCt(const uint32_t *ac, uint32_t n_scored, const uint32_t *miss, uint32_t sample_ct,
                           uint32_t *allele_ct, hipStream_t stream);
-
-// General form: out[s*out_stride + c] += sum_i weights[i*w_stride + c] * ts[i][g(i,s)]
-// for any n_cols: >= 3 columns run on FP64 MFMA tiles (k_accumulate_mfma), 1-2 columns on
-// plain FMAs; td/dosage_sum may be NULL.  ac/allele_ct are accepted for symmetry but the
-// allele-count bookkeeping is the caller's (LaunchAlleleCt).
-hipError_t LaunchTableAccumulate(const RowView &view, const uint32_t *vlist, uint32_t n_var, const double *weights,
-                                 uint32_t w_stride, uint32_t n_cols, const double *ts, const double *td,
-                                 const uint32_t *ac, bool track_dosage, double *out, uint32_t out_stride,
-                                 double *dosage_sum, uint32_t *allele_ct, hipStream_t stream);
 
 // ---- plink_pca ----------------------------------------------------------------
 // ts[i] = {(0-c)is, (1-c)is, (2-c)is, 0} (NormalizeGenotypes)
 hipError_t LaunchNormTables(const double *center, const double *inv_stdev, uint32_t n, double *ts,
                             hipStream_t stream);
-// out[i*out_stride + c] = sum_s ts[i][g(i,s)] * G[s*g_stride + c]
-hipError_t LaunchVariantReduce(const RowView &view, const uint32_t *vlist, uint32_t n_var, const double *ts,
-                               const double *G, uint32_t g_stride, uint32_t n_cols, double *out, uint32_t out_stride,
-                               hipStream_t stream);
 // zero the rows of samples whose slot in mask2 is clear
 hipError_t LaunchMaskRows(double *m, uint32_t n_rows, uint32_t stride, uint32_t n_cols, const uint8_t *mask2,
                           hipStream_t stream);
