@@ -59,15 +59,18 @@ extern "C" int pgh_probe(const char *pgen_path, const char *pgi_path, pgh_info *
 	return PGH_OK;
 }
 
-// pgh_open's staging buffers (2 pinned + 2 device, 64 MB each) cost ~40 ms to allocate, more
-// than a small file takes to ingest: one set per device is parked here between opens.
+// pgh_open's staging buffers (kStages pinned + kStages device, 64 MB each) cost ~40 ms apiece to allocate, more
+// than a small file takes to ingest: one set per device is parked here between opens.  Four stages: while
+// one is being filled from the page cache, up to three are queued on the copy engine, so neither the readers
+// (~90 GB/s with 8 threads on this box) nor the host link (~56 GB/s, tools/ingest_probe.hip) waits for the other.
+constexpr int kStages = 4;
 struct StageSet {
-	uint8_t *pinned[2] = {nullptr, nullptr};
-	uint8_t *device[2] = {nullptr, nullptr};
+	uint8_t *pinned[kStages] = {};
+	uint8_t *device[kStages] = {};
 	uint64_t bytes = 0;
 	int device_id = -1;
 	void Free() {
-		for (int i = 0; i < 2; i++) {
+		for (int i = 0; i < kStages; i++) {
 			if (pinned[i]) {
 				(void)hipHostFree(pinned[i]);
 			}
@@ -92,7 +95,7 @@ static hipError_t AcquireStage(uint64_t bytes, int device_id, bool want_device, 
 	}
 	out.device_id = device_id;
 	hipError_t e = hipSuccess;
-	for (int i = 0; i < 2 && e == hipSuccess; i++) {
+	for (int i = 0; i < kStages && e == hipSuccess; i++) {
 		if (!out.pinned[i]) {
 			e = hipHostMalloc(reinterpret_cast<void **>(&out.pinned[i]), bytes, hipHostMallocDefault);
 		}
@@ -124,7 +127,12 @@ static void ReleaseStage(StageSet &set) {
 static bool ReadParallel(const pgh::RecordFile &file, uint64_t offset, size_t bytes, uint8_t *dst, std::string &err) {
 	constexpr size_t kMinSlice = 4u << 20;
 	const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-	const unsigned parts = static_cast<unsigned>(std::min<size_t>(std::min(8u, hw), std::max<size_t>(1, bytes / kMinSlice)));
+	static const unsigned want = [] {
+		const char *e = std::getenv("PGH_OPEN_THREADS"); // tuning knob: reader threads per stage
+		const int v = e ? std::atoi(e) : 0;
+		return v > 0 ? static_cast<unsigned>(v) : 8u;
+	}();
+	const unsigned parts = static_cast<unsigned>(std::min<size_t>(std::min(want, hw), std::max<size_t>(1, bytes / kMinSlice)));
 	if (parts <= 1) {
 		return file.ReadAt(offset, bytes, dst, err);
 	}
@@ -489,11 +497,11 @@ extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t va
 	const uint32_t rows_per_stage = static_cast<uint32_t>(std::max<uint64_t>(1, stage_bytes / ds->pitch));
 	StageSet staging;
 	int *d_error = nullptr;
-	hipEvent_t done[2] = {nullptr, nullptr};
+	hipEvent_t done[kStages] = {};
 	hipStream_t stream = nullptr;
 	auto cleanup = [&]() {
 		ReleaseStage(staging);
-		for (int i = 0; i < 2; i++) {
+		for (int i = 0; i < kStages; i++) {
 			if (done[i]) {
 				(void)hipEventDestroy(done[i]);
 			}
@@ -510,7 +518,7 @@ extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t va
 	if (e == hipSuccess) {
 		e = AcquireStage(stage_bytes, ds->device, device_decode, staging);
 	}
-	for (int i = 0; i < 2 && e == hipSuccess; i++) {
+	for (int i = 0; i < kStages && e == hipSuccess; i++) {
 		e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
 	}
 	uint8_t *const *stage = staging.pinned;
@@ -535,7 +543,7 @@ extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t va
 		return code;
 	};
 	int which = 0;
-	bool used[2] = {false, false};
+	bool used[kStages] = {};
 	int64_t last_base = -1; // most recent non-LD variant inside the opened range
 	uint32_t v = variant_begin;
 	while (v < variant_end) {
@@ -735,7 +743,7 @@ extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t va
 			break;
 		}
 		used[which] = true;
-		which ^= 1;
+		which = (which + 1) % kStages;
 		v = stop;
 	}
 	lap("runs enqueued");

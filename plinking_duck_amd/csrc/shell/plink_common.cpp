@@ -129,7 +129,18 @@ string FindCompanionFile(const string &pgen_path, const vector<string> &extensio
 // variant metadata
 // ---------------------------------------------------------------------------
 
-VariantMetadataIndex LoadVariantMetadata(ClientContext &, const string &path, const string &func_name) {
+namespace {
+struct PvarCacheEntry {
+	string path;
+	int64_t mtime_ns = 0, size = 0;
+	VariantMetadataIndex index;
+};
+std::mutex g_pvar_cache_mutex;
+vector<PvarCacheEntry> g_pvar_cache; // most recently used last; a handful of files
+constexpr size_t kPvarCacheEntries = 8;
+} // namespace
+
+static VariantMetadataIndex ParseVariantMetadata(const string &path, const string &func_name) {
 	string content;
 	if (!ReadWholeFile(path, content)) {
 		throw IOException("%s: cannot open .pvar/.bim file '%s'", func_name, path);
@@ -137,7 +148,9 @@ VariantMetadataIndex LoadVariantMetadata(ClientContext &, const string &path, co
 	if (content.empty()) {
 		throw InvalidInputException("%s: .pvar/.bim file '%s' is empty", func_name, path);
 	}
-	VariantMetadataIndex idx;
+	VariantMetadataIndex out;
+	auto columns = make_shared<VariantColumns>();
+	VariantColumns &idx = *columns;
 	auto lines = Lines(content);
 	size_t li = 0;
 	while (li < lines.size() && (lines[li].empty() || lines[li].compare(0, 2, "##") == 0)) {
@@ -166,7 +179,7 @@ VariantMetadataIndex LoadVariantMetadata(ClientContext &, const string &path, co
 		li++;
 	} else {
 		// .bim: CHROM ID CM POS ALT REF
-		idx.is_bim = true;
+		out.is_bim = true;
 		chrom_f = 0;
 		id_f = 1;
 		pos_f = 3;
@@ -183,7 +196,7 @@ VariantMetadataIndex LoadVariantMetadata(ClientContext &, const string &path, co
 		if (lines[li].empty()) {
 			continue;
 		}
-		auto f = SplitFields(lines[li], idx.is_bim);
+		auto f = SplitFields(lines[li], out.is_bim);
 		if (f.size() <= max_f) {
 			throw InvalidInputException("%s: .pvar/.bim file '%s' has a line missing required fields (line %llu)",
 			                            func_name, path, static_cast<unsigned long long>(li + 1));
@@ -201,12 +214,12 @@ VariantMetadataIndex LoadVariantMetadata(ClientContext &, const string &path, co
 		idx.refs.push_back(f[ref_f]);
 		idx.alts.push_back(f[alt_f] == "." ? "" : f[alt_f]);
 	}
-	idx.variant_ct = idx.chroms.size();
+	out.variant_ct = idx.chroms.size();
 	// contiguous chromosome runs (region lookups binary-search POS inside a run)
 	idx_t run_start = 0;
-	for (idx_t i = 1; i <= idx.variant_ct; i++) {
-		if (i == idx.variant_ct || idx.chroms[i] != idx.chroms[run_start]) {
-			if (idx.variant_ct == 0) {
+	for (idx_t i = 1; i <= out.variant_ct; i++) {
+		if (i == out.variant_ct || idx.chroms[i] != idx.chroms[run_start]) {
+			if (out.variant_ct == 0) {
 				break;
 			}
 			auto ins = idx.chrom_offsets.emplace(idx.chroms[run_start], std::make_pair(run_start, i));
@@ -218,7 +231,35 @@ VariantMetadataIndex LoadVariantMetadata(ClientContext &, const string &path, co
 			run_start = i;
 		}
 	}
-	return idx;
+	out.cols = std::move(columns);
+	return out;
+}
+
+VariantMetadataIndex LoadVariantMetadata(ClientContext &, const string &path, const string &func_name) {
+	struct stat st;
+	const bool have_stat = ::stat(path.c_str(), &st) == 0;
+	const int64_t mtime_ns = have_stat ? static_cast<int64_t>(st.st_mtim.tv_sec) * 1000000000LL + st.st_mtim.tv_nsec : 0;
+	const int64_t size = have_stat ? static_cast<int64_t>(st.st_size) : -1;
+	if (have_stat) {
+		std::lock_guard<std::mutex> lock(g_pvar_cache_mutex);
+		for (size_t i = 0; i < g_pvar_cache.size(); i++) {
+			if (g_pvar_cache[i].path == path && g_pvar_cache[i].mtime_ns == mtime_ns && g_pvar_cache[i].size == size) {
+				PvarCacheEntry hit = g_pvar_cache[i];
+				g_pvar_cache.erase(g_pvar_cache.begin() + static_cast<std::ptrdiff_t>(i));
+				g_pvar_cache.push_back(hit);
+				return hit.index; // shares the columns
+			}
+		}
+	}
+	VariantMetadataIndex parsed = ParseVariantMetadata(path, func_name); // outside the lock: binds of other files go on
+	if (have_stat) {
+		std::lock_guard<std::mutex> lock(g_pvar_cache_mutex);
+		g_pvar_cache.push_back(PvarCacheEntry {path, mtime_ns, size, parsed});
+		if (g_pvar_cache.size() > kPvarCacheEntries) {
+			g_pvar_cache.erase(g_pvar_cache.begin());
+		}
+	}
+	return parsed;
 }
 
 // ---------------------------------------------------------------------------
@@ -400,10 +441,10 @@ public:
 	uint32_t FromText(const string &text) {
 		if (text.find(':') == string::npos) {
 			if (by_id_.empty()) {
-				by_id_.reserve(variants_.ids.size());
-				for (idx_t v = 0; v < variants_.ids.size(); v++) {
-					if (!variants_.ids[v].empty()) {
-						by_id_[variants_.ids[v]] = static_cast<uint32_t>(v); // duplicates: last one wins
+				by_id_.reserve(variants_.ids().size());
+				for (idx_t v = 0; v < variants_.ids().size(); v++) {
+					if (!variants_.ids()[v].empty()) {
+						by_id_[variants_.ids()[v]] = static_cast<uint32_t>(v); // duplicates: last one wins
 					}
 				}
 			}
@@ -504,13 +545,13 @@ public:
 private:
 	// POS is ascending inside a CHROM run: lower_bound, then walk the ties for the alleles.
 	uint32_t FromLocus(const string &chrom, int32_t pos, const string *ref, const string *alt, const string &desc) const {
-		auto run = variants_.chrom_offsets.find(chrom);
-		if (run != variants_.chrom_offsets.end()) {
-			auto first = variants_.positions.begin() + static_cast<std::ptrdiff_t>(run->second.first);
-			auto last = variants_.positions.begin() + static_cast<std::ptrdiff_t>(run->second.second);
+		auto run = variants_.chrom_offsets().find(chrom);
+		if (run != variants_.chrom_offsets().end()) {
+			auto first = variants_.positions().begin() + static_cast<std::ptrdiff_t>(run->second.first);
+			auto last = variants_.positions().begin() + static_cast<std::ptrdiff_t>(run->second.second);
 			for (auto it = std::lower_bound(first, last, pos); it != last && *it == pos; ++it) {
-				idx_t v = static_cast<idx_t>(it - variants_.positions.begin());
-				if (!ref || (variants_.refs[v] == *ref && variants_.alts[v] == *alt)) {
+				idx_t v = static_cast<idx_t>(it - variants_.positions().begin());
+				if (!ref || (variants_.refs()[v] == *ref && variants_.alts()[v] == *alt)) {
 					return static_cast<uint32_t>(v);
 				}
 			}
@@ -641,16 +682,16 @@ VariantRange ParseRegion(const string &region_str, const VariantMetadataIndex &v
 	}
 	VariantRange range;
 	range.has_filter = true;
-	auto it = variants.chrom_offsets.find(chrom); // exact string match, no chr-prefix normalisation
-	if (it == variants.chrom_offsets.end()) {
+	auto it = variants.chrom_offsets().find(chrom); // exact string match, no chr-prefix normalisation
+	if (it == variants.chrom_offsets().end()) {
 		return range; // empty
 	}
-	auto first = variants.positions.begin() + static_cast<std::ptrdiff_t>(it->second.first);
-	auto last = variants.positions.begin() + static_cast<std::ptrdiff_t>(it->second.second);
+	auto first = variants.positions().begin() + static_cast<std::ptrdiff_t>(it->second.first);
+	auto last = variants.positions().begin() + static_cast<std::ptrdiff_t>(it->second.second);
 	auto lo = std::lower_bound(first, last, static_cast<int32_t>(start_pos));
 	auto hi = std::upper_bound(first, last, static_cast<int32_t>(end_pos));
-	range.start_idx = static_cast<uint32_t>(lo - variants.positions.begin());
-	range.end_idx = static_cast<uint32_t>(hi - variants.positions.begin());
+	range.start_idx = static_cast<uint32_t>(lo - variants.positions().begin());
+	range.end_idx = static_cast<uint32_t>(hi - variants.positions().begin());
 	if (range.end_idx < range.start_idx) {
 		range.end_idx = range.start_idx;
 	}

@@ -16,31 +16,57 @@ namespace duckdb {
 
 // ---- variant / sample metadata ---------------------------------------------------
 
-struct VariantMetadataIndex {
+//! The parsed columns of one .pvar / .bim file.  Immutable once built and shared: every bind of the same file
+//! (same path, mtime and size) gets the same object out of a process-wide cache instead of re-parsing the text --
+//! the reference's bind is dominated by LoadVariantMetadata (src/plink_common.cpp:171-375), and a DuckDB session
+//! binds the same file again and again.
+struct VariantColumns {
 	vector<string> chroms, ids, refs, alts;
 	vector<int32_t> positions;
+	std::unordered_map<string, std::pair<idx_t, idx_t>> chrom_offsets; // contiguous CHROM runs
+};
+
+struct VariantMetadataIndex {
+	shared_ptr<const VariantColumns> cols = make_shared<VariantColumns>();
 	idx_t variant_ct = 0;
 	bool is_bim = false;
-	std::unordered_map<string, std::pair<idx_t, idx_t>> chrom_offsets; // contiguous CHROM runs
 
+	const vector<string> &chroms() const {
+		return cols->chroms;
+	}
+	const vector<string> &ids() const {
+		return cols->ids;
+	}
+	const vector<string> &refs() const {
+		return cols->refs;
+	}
+	const vector<string> &alts() const {
+		return cols->alts;
+	}
+	const vector<int32_t> &positions() const {
+		return cols->positions;
+	}
+	const std::unordered_map<string, std::pair<idx_t, idx_t>> &chrom_offsets() const {
+		return cols->chrom_offsets;
+	}
 	const string &GetChrom(idx_t v) const {
-		return chroms[v];
+		return cols->chroms[v];
 	}
 	int32_t GetPos(idx_t v) const {
-		return positions[v];
+		return cols->positions[v];
 	}
 	const string &GetId(idx_t v) const {
-		return ids[v];
+		return cols->ids[v];
 	}
 	const string &GetRef(idx_t v) const {
-		return refs[v];
+		return cols->refs[v];
 	}
 	const string &GetAlt(idx_t v) const {
-		return alts[v];
+		return cols->alts[v];
 	}
 };
 
-//! src/plink_common.cpp:171-375 (text path only)
+//! src/plink_common.cpp:171-375 (text path only); parsed once per (path, mtime, size) and process
 VariantMetadataIndex LoadVariantMetadata(ClientContext &context, const string &path, const string &func_name);
 
 struct SampleInfo {

@@ -146,8 +146,8 @@ static unique_ptr<FunctionData> PlinkLdBind(ClientContext &context, TableFunctio
 	if (bind_data->mode == LdMode::PAIRWISE) {
 		// ID -> index, the later of two equal IDs winning (src/plink_common.cpp:1598-1612)
 		auto find_id = [&](const string &id) {
-			for (idx_t v = c.variants.ids.size(); v-- > 0;) {
-				if (c.variants.ids[v] == id) {
+			for (idx_t v = c.variants.ids().size(); v-- > 0;) {
+				if (c.variants.ids()[v] == id) {
 					return static_cast<uint32_t>(v);
 				}
 			}

@@ -114,8 +114,8 @@ static vector<ScoredVariant> ResolveWeights(const Value &weights, const VariantM
 	// IDs of the region; of two variants with one ID the later one is the one that gets scored
 	std::unordered_map<string, uint32_t> by_id;
 	for (uint32_t v = range_start; v < range_end; v++) {
-		if (!variants.ids[v].empty()) {
-			by_id[variants.ids[v]] = v;
+		if (!variants.ids()[v].empty()) {
+			by_id[variants.ids()[v]] = v;
 		}
 	}
 	for (const auto &item : items) {

@@ -976,3 +976,28 @@ def test_read_pgen_genotypes_test_mirror():
     for kw in (dict(pvar=data_path("pgen_example.pvar"), psam=data_path("pgen_example.psam")),
                dict(pvar=data_path("pgen_example.bim"))):
         assert dict(F.query("read_pgen", EX, genotypes="list", columns=["ID", "genotypes"], **kw).rows)["rs1"] == [0, 1, 2, None]
+
+
+def test_pvar_text_is_parsed_once_per_file_version(tmp_path, gpu_lib):
+    """Bind re-uses the parsed .pvar columns of a file it has seen (same path, mtime, size) instead of re-reading
+    the text (the reference's bind is dominated by LoadVariantMetadata, src/plink_common.cpp:171-375); a rewritten
+    file is parsed again."""
+    import shutil
+    import time
+
+    m, n = 120_000, 64
+    prefix = str(tmp_path / "meta")
+    gpu_lib.synth_write_files(prefix, m, n, 3, 0.01)
+    first = F.query("plink_freq", prefix + ".pgen", columns=["ID", "ALT_FREQ"], threads=2)
+    again = F.query("plink_freq", prefix + ".pgen", columns=["ID", "ALT_FREQ"], threads=2)
+    assert sorted(first.rows) == sorted(again.rows) and len(first) == m
+    assert again.timing_ms["bind"] < 0.5 * first.timing_ms["bind"], (first.timing_ms, again.timing_ms)
+    # a new version of the companion file: ids change, the cache must not serve the old ones
+    with open(prefix + ".pvar") as f:
+        text = f.read()
+    time.sleep(0.01)
+    with open(prefix + ".pvar", "w") as f:
+        f.write(text.replace("\tsv", "\tqv"))
+    renamed = F.query("plink_freq", prefix + ".pgen", columns=["ID"], threads=2)
+    assert all(r[0].startswith("sv") for r in first.rows) and all(r[0].startswith("qv") for r in renamed.rows)
+    shutil.rmtree(tmp_path, ignore_errors=True)

@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import plinking_duck_amd.lib as L  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--variants", type=int, default=4000)
+ap.add_argument("--variants", type=int, default=64000, help="64,000 x 500,000 = 8 GB: large enough that the fixed costs of an open (allocations, header parse) do not set the rate")
 ap.add_argument("--samples", type=int, default=500000)
 ap.add_argument("--dosage-rate", type=float, default=0.0, help="> 0: every record carries a 0x60 dosage track")
 args = ap.parse_args()
