@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "profiles")
 DST = os.path.join(ROOT, "profiles")
 
-DOMINANT = {"freq": "k_counts_block", "fused": "k_fused_tally", "unpack": "k_unpack_wide", "dosagefreq": "k_dosage_sums"}
+DOMINANT = {"freq": "k_counts_block", "fused": "k_fused_tally", "unpack": "k_unpack_wide", "score1": "k_score_i8"}
 
 
 def short(name):
@@ -34,17 +34,18 @@ def pmc_means(path):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--round", type=int, required=True)
+    ap.add_argument("--round", type=int, default=2)
+    ap.add_argument("src", nargs="?", default=None)
     args = ap.parse_args()
     tag = f"r{args.round:02d}"
-    for name in ("freq", "fused", "unpack", "score", "score1", "pca", "ld", "samplecounts", "missingsample", "dosagefreq", "dosagescore", "dosagefull", "dosagegaps"):
+    for name in ("freq", "fused", "unpack", "score", "score1", "score2", "pca", "ld", "samplecounts", "missingsample", "dosagefreq", "dosagescore", "dosagefull", "dosagegaps"):
         src = os.path.join(SRC, f"bench_{name}.json")
         if os.path.exists(src):
             line = [ln for ln in open(src).read().splitlines() if ln.startswith("{")][-1]
             json.loads(line)
             with open(os.path.join(DST, f"{tag}_bench_{name}_n1.json"), "w") as f:
                 f.write(line + "\n")
-    for name in ("freq", "fused", "unpack", "score", "pca", "ld", "samplecounts", "missingsample", "dosagefreq", "dosagescore", "dosagefull"):
+    for name in ("freq", "fused", "unpack", "score", "score1", "pca", "ld", "samplecounts", "missingsample", "dosagefreq", "dosagescore", "dosagefull"):
         src = os.path.join(SRC, f"{name}_kernel_stats.csv")
         if os.path.exists(src):
             shutil.copy(src, os.path.join(DST, f"{tag}_{name}_kernel_stats.csv"))
@@ -58,7 +59,7 @@ def main():
     for name, kernel in DOMINANT.items():
         raw = {}
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-            src = os.path.join(SRC, f"{name}_{ctr}.csv")
+            src = os.path.join(SRC, f"{name}_pmc_{ctr}.csv")
             if not os.path.exists(src):
                 continue
             means = pmc_means(src)
@@ -80,6 +81,17 @@ def main():
                 "hbm_bytes_per_launch": (2 * raw["FETCH_SIZE"][1] + raw["WRITE_SIZE"][1]) * 1024,
                 "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
             }
+    # matrix-core counters of the int8 contraction
+    for name in ("score", "score1", "pca"):
+        src = os.path.join(SRC, f"{name}_pmc_mfma.csv")
+        if not os.path.exists(src):
+            continue
+        means = pmc_means(src)
+        with open(os.path.join(DST, f"{tag}_{name}_pmc_mfma.csv"), "w") as f:
+            f.write("kernel,counter,dispatches,sum_value,mean_value\n")
+            for (k, c), (n, total) in means.items():
+                if k.startswith("k_score_i8"):
+                    f.write(f"\"{k}\",{c},{n},{total:.6g},{total / n:.6g}\n")
     with open(os.path.join(DST, "traffic.json"), "w") as f:
         json.dump(traffic, f, indent=1)
         f.write("\n")
