@@ -652,7 +652,8 @@ def main():
     else:
         achieved = algo_bytes / (kern_avg_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic(args.workload, m, n),
+                    "frac": achieved / HBM_PEAK_GBPS,
+                    "traffic": load_traffic("score1" if args.workload == "score" else args.workload, m, n),
                     "kernel": kernel_name, "kernel_ms_avg": kern_avg_ms, "launches_timed": len(kernel_ms),
                     "algorithmic_bytes_per_launch": algo_bytes}
 
