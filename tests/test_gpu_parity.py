@@ -359,6 +359,45 @@ def test_score_at_baseline_width(gpu_lib, oracle, mode):
             assert np.allclose(d, ed, rtol=1e-9, atol=1e-9)
 
 
+def test_pca_at_baseline_width(gpu_lib):
+    """BASELINE config 5's sample axis: pgh_pca at N = 500,000 (k = 4, 2,500 variants).  No second implementation
+    fits the budget at this width, so the checks are size-independent identities: the eigenvectors are
+    orthonormal, the eigenvalues equal those of the same matrix held as a three-shard group (another
+    summation order, another set of fixed-point scales), and the Rayleigh quotients |X u_k|^2 / M recomputed on the
+    host in float64 bracket the reported eigenvalues as the algebra says they must."""
+    m, n, k = 2500, 500_000, 4
+    whole = gpu_lib.Dataset.synth(0, m, n, SEED + 31, 0.02)
+    c = whole.counts_range().astype(np.float64)
+    obs = c[:, :3].sum(axis=1)
+    af = (c[:, 1] + 2 * c[:, 2]) / (2 * np.maximum(obs, 1))
+    keep = np.flatnonzero((obs > 0) & (af > 0) & (af < 1)).astype(np.uint32)
+    center, inv = 2 * af[keep], 1.0 / np.sqrt(2 * af[keep] * (1 - af[keep]))
+    g1 = np.random.default_rng(8).standard_normal((n, 2 * k))
+    ev, vec = whole.pca(keep, center, inv, k, g1)
+    assert np.all(np.diff(ev) <= 0) and np.all(ev > 0)
+    assert np.allclose(vec.T @ vec, np.eye(k), atol=1e-9)
+    shards = [gpu_lib.Dataset.synth(a, b, n, SEED + 31, 0.02) for a, b in ((0, 900), (900, 1700), (1700, m))]
+    ev2, vec2 = gpu_lib.Dataset.group(shards).pca(keep, center, inv, k, g1)
+    assert np.allclose(ev, ev2, rtol=1e-9)
+    # Rayleigh quotients on the host, X row by row from the unpacked calls (missing -> 0 after normalisation).
+    # u_k = X^T z_k / S_k with |z_k| = 1 (a unit vector of the Krylov basis), so |X u_k|^2 >= (z^T X X^T z)^2 / S_k^2
+    # = S_k^2: the quotient can exceed the reported eigenvalue (where the subspace has not converged) but never
+    # fall below it -- and it cannot exceed the whole spectrum's sum, trace(X^T X) / M, known from the tallies.
+    t2 = (np.stack([(0 - center) * inv, (1 - center) * inv, (2 - center) * inv], axis=1)) ** 2
+    trace_over_m = float(np.sum(c[keep, :3] * t2)) / len(keep)
+    assert ev.sum() <= trace_over_m * (1 + 1e-12) and ev[0] >= trace_over_m / len(keep)
+    for pc in range(2):
+        acc = 0.0
+        for lo in range(0, len(keep), 250):
+            rows = keep[lo:lo + 250]
+            g, _ = whole.unpack_range(int(rows[0]), int(rows[-1]) + 1, missing_code=-9, want_validity=False)
+            g = g[rows - rows[0]].astype(np.float64)
+            x = np.where(g == -9, 0.0, (g - center[lo:lo + 250, None]) * inv[lo:lo + 250, None])
+            acc += float(np.sum((x @ vec[:, pc]) ** 2))
+        rayleigh = acc / len(keep)
+        assert ev[pc] * (1 - 1e-9) <= rayleigh <= trace_over_m
+
+
 @pytest.mark.parametrize("n_pcs,m,n", [(2, 700, 2100), (9, 700, 2100), (10, 700, 2100), (11, 700, 2100),
                                        (13, 700, 2100), (2, 300, 20000), (10, 900, 20000)])
 def test_pca_matches_oracle_on_wide_rows(gpu_lib, oracle, n_pcs, m, n):
