@@ -414,58 +414,76 @@ __global__ __launch_bounds__(256) void k_score_i8(const uint8_t *__restrict__ ro
 				}
 			}
 		}
-		const v4i *bp = reinterpret_cast<const v4i *>(&s_ring[slot][S::kGenoBytes]);
+		// operand bytes of the whole tile, once: TS samples x (code plane, missing plane) x 4 registers
+		v4i U[TS], Mi[TS];
 #pragma unroll
-		for (int nt0 = 0; nt0 < NT; nt0 += 2) {
-			// digit operands of up to two tiles stay in registers across the samples
-			constexpr int kHold = NT >= 2 ? 2 : 1;
-			v4i bg[kHold], bm[kHold];
+		for (int cc = 0; cc < static_cast<int>(kBytesPerLane); cc++) {
+			uint32_t h1[4], h2[4];
+#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				h1[q] = G[q][cc] >> 1;
+				h2[q] = G[q][cc] >> 2;
+			}
+#pragma unroll
+			for (int e = 0; e < 4; e++) {
+#pragma unroll
+				for (int q = 0; q < 4; q++) {
+					const uint32_t gq = G[q][cc];
+					if (e < 3) {
+						U[cc * 4 + e][q] = static_cast<int>(gq & (0x03030303u << (2 * e)));
+						Mi[cc * 4 + e][q] = static_cast<int>(gq & h1[q] & (0x01010101u << (2 * e)));
+					} else {
+						U[cc * 4 + e][q] = static_cast<int>(h1[q] & 0x60606060u);
+						Mi[cc * 4 + e][q] = static_cast<int>(h1[q] & h2[q] & 0x20202020u);
+					}
+				}
+			}
+		}
+		// digit operands: two tiles at a time stay in registers across the samples, and the next two are read
+		// from LDS while these multiply.  (What keeps the matrix pipe at ~70 % with many tiles is not this read:
+		// a tile costs a fixed ~450 cycles of operand building, DMA issue and barrier per wave whatever the
+		// number of matrix instructions behind it, and on gfx950 that vector work of one wave did not run
+		// under the int8 matrix instructions of the other wave of the SIMD -- DESIGN.md section 6.)
+		const v4i *bp = reinterpret_cast<const v4i *>(&s_ring[slot][S::kGenoBytes]);
+		constexpr int kHold = NT >= 2 ? 2 : 1;
+		v4i bg[kHold], bm[kHold], ng[kHold], nm[kHold];
+		auto load_b = [&](v4i *dg, v4i *dm, int nt_first) {
 #pragma unroll
 			for (int h = 0; h < kHold; h++) {
-				if (nt0 + h < NT) {
+				if (nt_first + h < NT) {
 					if (PLANES & 1) {
-						bg[h] = bp[((0 * NT + nt0 + h) * 4 + g) * 16 + x];
+						dg[h] = bp[((0 * NT + nt_first + h) * 4 + g) * 16 + x];
 					}
 					if (PLANES & 2) {
-						bm[h] = bp[((1 * NT + nt0 + h) * 4 + g) * 16 + x];
+						dm[h] = bp[((1 * NT + nt_first + h) * 4 + g) * 16 + x];
+					}
+				}
+			}
+		};
+		load_b(bg, bm, 0);
+#pragma unroll
+		for (int nt0 = 0; nt0 < NT; nt0 += kHold) {
+			if (nt0 + kHold < NT) {
+				load_b(ng, nm, nt0 + kHold);
+			}
+#pragma unroll
+			for (int t = 0; t < TS; t++) {
+#pragma unroll
+				for (int h = 0; h < kHold; h++) {
+					if (nt0 + h < NT) {
+						if (PLANES & 1) {
+							acc[t][nt0 + h] = __builtin_amdgcn_mfma_i32_16x16x64_i8(U[t], bg[h], acc[t][nt0 + h], 0, 0, 0);
+						}
+						if (PLANES & 2) {
+							acc[t][nt0 + h] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Mi[t], bm[h], acc[t][nt0 + h], 0, 0, 0);
+						}
 					}
 				}
 			}
 #pragma unroll
-			for (int cc = 0; cc < static_cast<int>(kBytesPerLane); cc++) {
-				uint32_t h1[4], h2[4];
-#pragma unroll
-				for (int q = 0; q < 4; q++) {
-					h1[q] = G[q][cc] >> 1;
-					h2[q] = G[q][cc] >> 2;
-				}
-#pragma unroll
-				for (int e = 0; e < 4; e++) {
-					v4i u, m;
-#pragma unroll
-					for (int q = 0; q < 4; q++) {
-						const uint32_t gq = G[q][cc];
-						if (e < 3) {
-							u[q] = static_cast<int>(gq & (0x03030303u << (2 * e)));
-							m[q] = static_cast<int>(gq & h1[q] & (0x01010101u << (2 * e)));
-						} else {
-							u[q] = static_cast<int>(h1[q] & 0x60606060u);
-							m[q] = static_cast<int>(h1[q] & h2[q] & 0x20202020u);
-						}
-					}
-					const int t = cc * 4 + e;
-#pragma unroll
-					for (int h = 0; h < kHold; h++) {
-						if (nt0 + h < NT) {
-							if (PLANES & 1) {
-								acc[t][nt0 + h] = __builtin_amdgcn_mfma_i32_16x16x64_i8(u, bg[h], acc[t][nt0 + h], 0, 0, 0);
-							}
-							if (PLANES & 2) {
-								acc[t][nt0 + h] = __builtin_amdgcn_mfma_i32_16x16x64_i8(m, bm[h], acc[t][nt0 + h], 0, 0, 0);
-							}
-						}
-					}
-				}
+			for (int h = 0; h < kHold; h++) {
+				bg[h] = ng[h];
+				bm[h] = nm[h];
 			}
 		}
 	};
