@@ -270,6 +270,32 @@ def verify(args, L, np, torch, ds, env):
         if not ok:
             print(f"verify: score column sums {got} != {want} from the tallies", file=sys.stderr)
         return ok
+    if wl in ("dosagefreq", "dosagescore"):
+        if env["dist"] is not None:
+            return None  # as above: the single-GPU line carries the check
+        # the per-variant {sum, sum of squares, count} on the 16384 scale (k_dosage_sums) against the moments of three
+        # rows unpacked to doubles by a different kernel (k_dosage_unpack)
+        sums = env["h_sums"].numpy().astype(np.uint64) if wl == "dosagefreq" else ds.dosage_sums().astype(np.uint64)
+        rows = ds.dosage_unpack(vidx=[v_begin + r for r in picks])
+        for i, r in enumerate(picks):
+            u = np.rint(rows[i][rows[i] != -9.0] * 16384.0).astype(np.uint64)
+            if (int(u.sum()), int((u * u).sum()), len(u)) != tuple(int(x) for x in sums[r]):
+                print(f"verify: dosage moments of variant {v_begin + r} differ from its unpacked row", file=sys.stderr)
+                return False
+        if wl == "dosagefreq":
+            return True
+        # checksum of checksums: under mean imputation a sample with neither dosage nor call contributes the
+        # variant's mean, so SCORE_SUM summed over samples is sum_v w_v * (dosage sum of v) * N / (samples observed)
+        total, seen = sums[:, 0].astype(np.float64) / 16384.0, sums[:, 2].astype(np.float64)
+        per_variant = np.where(seen > 0, total * n / np.maximum(seen, 1.0), 0.0)
+        want = float(per_variant @ env["weights"][:, 0])
+        got = float(env["d_score"].cpu().numpy().sum())
+        scale = float(np.abs(per_variant * env["weights"][:, 0]).sum())
+        ok = abs(got - want) <= 1e-9 * scale and bool((env["d_ac"].cpu().numpy() == 2 * m).all())
+        if not ok:
+            print(f"verify: dosage score sum {got} != {want} from the per-variant dosage sums (or ALLELE_CT != 2M)",
+                  file=sys.stderr)
+        return bool(ok)
     return None
 
 
@@ -413,7 +439,14 @@ def main():
         # 2-bit record + presence bits + the explicit values; the score's explicit-entry sweep also needs the
         # per-word ranks (its second read of the record, hardcall sweep then dosage sweep, is not counted)
         algo_bytes = m * record_bytes + m * words * 8 + 2 * int(ds.info.dosage_value_ct)
-        if args.workload == "dosagescore":
+        via_records = (args.workload == "dosagescore" and args.dosage_rate < 0.4
+                       and os.environ.get("PGH_SCORE_DOSAGE_RECORDS", "1") != "0")
+        if via_records:
+            # sparse tracks: the hardcall contraction reads the 2-bit records, k_score_dosage_records the 4-byte entry
+            # records (value, tile element, hardcall) and two ranks per 4096-sample tile -- no bits, no second
+            # read of the rows
+            algo_bytes = m * record_bytes + 4 * int(ds.info.dosage_value_ct) + m * ((words + 63) // 64) * 8
+        elif args.workload == "dosagescore":
             algo_bytes += m * words * 4
         dtype = "u16"
         if args.workload == "dosagefreq":
@@ -456,7 +489,8 @@ def main():
 
             # the plan picks the kernel by track density (api_analysis.cpp): all samples explicit, >= 40 %, below
             kernel_name = ("k_score_dosage_full" if args.dosage_rate >= 1.0 else
-                           "k_score_dosage" if args.dosage_rate >= 0.42 else "k_score_i8 + k_score_dosage_fix")
+                           "k_score_dosage" if args.dosage_rate >= 0.42 else
+                           "k_score_i8 + k_score_dosage_records" if via_records else "k_score_i8 + k_score_dosage_fix")
             metric = "plink_score(dosage) genotypes/s"
     elif args.workload == "missingsample":
         # plink_missing mode := 'sample': per-sample missing tallies over every variant (column sums)

@@ -231,7 +231,10 @@ int pgh_score_dev(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_sc
 /* The same in two steps, for callers that score the same weight set repeatedly or
  * want an enqueue-only launch: the plan uploads vidx / weights / flip once and
  * runs the tally + table kernels; pgh_score_run_dev only enqueues the memsets
- * and the accumulate kernel on `stream`. */
+ * and the accumulate kernels on `stream`.
+ * The first plan over a dataset with sparse dosage tracks also builds that
+ * dataset's entry records (4 bytes per explicit dosage, resident until
+ * pgh_close; skipped without error when they do not fit). */
 typedef struct pgh_score_plan pgh_score_plan;
 int pgh_score_plan_create(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_scored, const uint32_t *vidx,
                           const double *weights, const uint8_t *flip, uint32_t n_cols, int mode,

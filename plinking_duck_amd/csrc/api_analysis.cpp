@@ -522,7 +522,8 @@ struct pgh_score_plan {
 	const pgh_dataset *ds = nullptr;
 	std::vector<ScoreI8Pass> i8; // the table-scored variants (hardcalls + sparse dosage tracks), cut into digits
 	uint32_t n_table = 0;        // ... their number: the first n_table entries of d_vlist
-	bool two_step = true;        // sparse dosage tracks ride the hardcall kernel + k_score_dosage_fix
+	bool two_step = true;        // sparse dosage tracks ride the hardcall kernel + an explicit-entry kernel:
+	bool records = false;        // ... k_score_dosage_records over the dataset's entry records, else k_score_dosage_fix
 	uint32_t n_scored = 0, n_cols = 0;
 	uint32_t n_hard = 0; // the first n_hard entries have hardcalls only; the rest carry dosage tracks:
 	uint32_t n_gaps = 0; // ... then n_gaps whose tracks cover most samples (scored by the sample-owning kernel)
@@ -531,6 +532,67 @@ struct pgh_score_plan {
 	void *d_vlist = nullptr, *d_weights = nullptr, *d_flip = nullptr, *d_counts = nullptr, *d_ts = nullptr,
 	     *d_td = nullptr, *d_ac = nullptr, *d_lin = nullptr;
 };
+
+// The entry records of every sparse dosage track of the dataset (dosage.hpp), built once -- by the first plan that
+// scores such a track -- and resident until the dataset is closed: 4 bytes per explicit dosage, in the order and
+// form k_score_dosage_records streams them.  "Sparse" is the plan's own cut (fewer than 40 % of the samples
+// explicit).  Not fitting in HBM is not an error: the plans then keep to the bit-walking k_score_dosage_fix.
+static int EnsureDosageRecords(const pgh_dataset *ds, hipStream_t st, char *errbuf) {
+	std::lock_guard<std::mutex> lock(ds->dos_rec_mutex);
+	if (ds->dos_rec_state != 0) {
+		return PGH_OK;
+	}
+	const uint32_t rows = ds->dos_rows;
+	std::vector<uint64_t> off(rows + 1, 0);
+	for (uint32_t r = 0; r < rows; r++) {
+		const uint64_t have = ds->dos_row_count[r];
+		const bool sparse = have != ds->sample_ct && have * 5 < static_cast<uint64_t>(ds->sample_ct) * 2;
+		off[r + 1] = off[r] + (sparse ? have : 0);
+	}
+	ds->dos_rec_state = -1;
+	if (off[rows] == 0) {
+		return PGH_OK;
+	}
+	std::vector<uint32_t> row_variant(rows, 0);
+	for (size_t v = 0; v < ds->dos_row_of.size(); v++) {
+		if (ds->dos_row_of[v] >= 0) {
+			row_variant[static_cast<uint32_t>(ds->dos_row_of[v])] = static_cast<uint32_t>(v);
+		}
+	}
+	uint32_t *d_rec = nullptr, *d_row_variant = nullptr;
+	uint64_t *d_off = nullptr;
+	if (hipMalloc(reinterpret_cast<void **>(&d_rec), 4ull * off[rows] + 64) != hipSuccess) {
+		(void)hipGetLastError(); // no room: not an error
+		return PGH_OK;
+	}
+	hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_off), 8ull * (rows + 1));
+	if (e == hipSuccess) {
+		e = hipMalloc(reinterpret_cast<void **>(&d_row_variant), 4ull * rows);
+	}
+	if (e == hipSuccess) {
+		e = hipMemcpyAsync(d_off, off.data(), 8ull * (rows + 1), hipMemcpyHostToDevice, st);
+	}
+	if (e == hipSuccess) {
+		e = hipMemcpyAsync(d_row_variant, row_variant.data(), 4ull * rows, hipMemcpyHostToDevice, st);
+	}
+	if (e == hipSuccess) {
+		e = pgh::LaunchDosageRecords(ds->View(), ds->Dosage(), rows, d_row_variant, d_off, d_rec, st);
+	}
+	if (e == hipSuccess) {
+		e = hipStreamSynchronize(st); // off / row_variant die with this frame
+	}
+	(void)hipFree(d_row_variant);
+	if (e != hipSuccess) {
+		(void)hipFree(d_rec);
+		(void)hipFree(d_off);
+		return DeviceFail(errbuf, "dosage entry records", e);
+	}
+	ds->d_dos_rec = d_rec;
+	ds->d_dos_rec_off = d_off;
+	ds->dos_rec_ct = off[rows];
+	ds->dos_rec_state = 1;
+	return PGH_OK;
+}
 
 extern "C" void pgh_score_plan_destroy(pgh_score_plan *plan) {
 	if (!plan) {
@@ -686,6 +748,18 @@ extern "C" int pgh_score_plan_create(const pgh_dataset *ds, const pgh_subset *su
 		plan->two_step = !(lanes_env && *lanes_env && *lanes_env != '0');
 		const uint32_t n_sparse = n_scored - n_hard - n_gaps - n_full;
 		plan->n_table = n_hard + (plan->two_step ? n_sparse : 0u);
+		if (plan->two_step && n_sparse) {
+			// PGH_SCORE_DOSAGE_RECORDS=0 keeps the bit-walking explicit-entry kernel (a cross-check, and what a
+			// dataset whose records do not fit in HBM gets)
+			const char *rec_env = std::getenv("PGH_SCORE_DOSAGE_RECORDS");
+			if (!(rec_env && *rec_env == '0')) {
+				rc = EnsureDosageRecords(ds, st, errbuf);
+				if (rc != PGH_OK) {
+					return rc;
+				}
+				plan->records = ds->dos_rec_state == 1;
+			}
+		}
 		if (plan->n_table) {
 			for (uint32_t c0 = 0; c0 < n_cols; c0 += pgh::kI8MaxCols) {
 				plan->i8.emplace_back();
@@ -763,6 +837,19 @@ extern "C" int pgh_score_run_dev(const pgh_score_plan *plan, void *d_score_sum, 
 		PGH_HIP(hipMallocAsync(&miss, miss_bytes, st), "score scratch");
 		e = hipMemsetAsync(miss, 0, miss_bytes, st);
 	}
+	// (The explicit-entry kernel is bound by LDS atomics and the contraction by HBM and the matrix cores, but side
+	// by side on two streams they gained 1.5 %: each fills the CUs' LDS by itself, so the second only gets the CUs
+	// the first drains.  They run one after the other.)
+	if (e == hipSuccess && n_dos) {
+		for (uint32_t c = 0; c < plan->n_cols && e == hipSuccess; c++) {
+			e = (plan->records ? pgh::LaunchScoreDosageRecords : pgh::LaunchScoreDosageFix)(
+			    ds->View(), ds->Dosage(), vlist + n_hard, n_dos,
+			    weights + static_cast<uint64_t>(n_hard) * plan->n_cols + c, plan->n_cols, ts + 4ull * n_hard,
+			    static_cast<double *>(plan->d_lin), ac + n_hard, static_cast<double *>(d_score_sum) + c, plan->n_cols,
+			    (track && c == 0) ? static_cast<double *>(d_dosage_sum) : nullptr,
+			    c == 0 ? static_cast<uint32_t *>(miss) : nullptr, st);
+		}
+	}
 	for (const ScoreI8Pass &pass : plan->i8) {
 		if (e != hipSuccess) {
 			break;
@@ -772,16 +859,6 @@ extern "C" int pgh_score_run_dev(const pgh_score_plan *plan, void *d_score_sum, 
 		                       static_cast<double *>(d_score_sum) + pass.c0,
 		                       plan->n_cols, (first && track) ? static_cast<double *>(d_dosage_sum) : nullptr,
 		                       first ? static_cast<uint32_t *>(miss) : nullptr, st);
-	}
-	if (e == hipSuccess && n_dos) {
-		for (uint32_t c = 0; c < plan->n_cols && e == hipSuccess; c++) {
-			e = pgh::LaunchScoreDosageFix(ds->View(), ds->Dosage(), vlist + n_hard, n_dos,
-			                              weights + static_cast<uint64_t>(n_hard) * plan->n_cols + c, plan->n_cols,
-			                              ts + 4ull * n_hard, static_cast<double *>(plan->d_lin), ac + n_hard,
-			                              static_cast<double *>(d_score_sum) + c, plan->n_cols,
-			                              (track && c == 0) ? static_cast<double *>(d_dosage_sum) : nullptr,
-			                              c == 0 ? static_cast<uint32_t *>(miss) : nullptr, st);
-		}
 	}
 	if (e == hipSuccess && n_gaps) {
 		const uint32_t at = n_hard + n_dos;

@@ -1233,6 +1233,7 @@ extern "C" void pgh_close(pgh_dataset *ds) {
 	for (void *p : {static_cast<void *>(ds->d_rows), static_cast<void *>(ds->d_dos_row_of),
 	                static_cast<void *>(ds->d_dos_present), static_cast<void *>(ds->d_dos_rank),
 	                static_cast<void *>(ds->d_dos_val_off), static_cast<void *>(ds->d_dos_values),
+	                static_cast<void *>(ds->d_dos_rec), static_cast<void *>(ds->d_dos_rec_off),
 	                static_cast<void *>(ds->d_ph_present), static_cast<void *>(ds->d_ph_info)}) {
 		if (p) {
 			(void)hipFree(p);

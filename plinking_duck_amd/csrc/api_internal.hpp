@@ -57,6 +57,14 @@ struct pgh_dataset {
 	uint32_t *d_dos_rank = nullptr;
 	uint64_t *d_dos_val_off = nullptr;
 	uint16_t *d_dos_values = nullptr;
+	// Entry records of the sparse tracks (dosage.hpp), built by the first plink_score plan that meets such a track
+	// and resident from then on: 4 bytes per explicit dosage.  rec_state: 0 not tried, 1 resident, -1 did not fit
+	// (the plans then keep to the bit-walking kernel).
+	mutable std::mutex dos_rec_mutex;
+	mutable int dos_rec_state = 0;
+	mutable uint32_t *d_dos_rec = nullptr;
+	mutable uint64_t *d_dos_rec_off = nullptr;
+	mutable uint64_t dos_rec_ct = 0;
 	// phase tracks of the resident range (phase.hpp): two bit rows per phased variant; ph_rows == 0: none
 	uint32_t ph_rows = 0;
 	std::vector<int32_t> ph_row_of;
@@ -80,6 +88,8 @@ struct pgh_dataset {
 		d.rank = d_dos_rank;
 		d.val_off = d_dos_val_off;
 		d.values = d_dos_values;
+		d.rec = d_dos_rec;
+		d.rec_off = d_dos_rec_off;
 		d.words = (sample_ct + 63) / 64;
 		return d;
 	}

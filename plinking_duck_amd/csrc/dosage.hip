@@ -832,15 +832,20 @@ __global__ __launch_bounds__(1024, 8) void k_score_dosage_fix(const uint8_t *__r
                                                            double *__restrict__ score, uint32_t out_stride,
                                                            double *__restrict__ dosage_sum,
                                                            uint32_t *__restrict__ miss) {
-	constexpr uint32_t kPad = 65;    // row stride of the tile in LDS: spreads equal bit positions over the banks
+	// The tile's sums in LDS, [bit of the word][word]: a wave's atomic instruction has lane l at 8-byte element
+	// 64 b_l + l, i.e. in bank pair l mod 32 whatever its bit b_l is -- the two-pass minimum of a 64 x 8-byte
+	// access.  (Round 1 had [word][bit] with a row stride of 65, which sends the lanes to RANDOM banks: 22 LDS cycles
+	// per FP64 atomic instruction instead of 7.4, tools/lds_atomic_probe.hip, profiles/r02_lds_atomic.txt.)
 	constexpr uint32_t kWaves = 16;  // sixteen waves share one tile: the loop is a chain of memory latencies
 	constexpr uint32_t kChunk = 128; // variants whose constants are staged in LDS at a time
-	__shared__ double s_acc[64 * kPad];
-	__shared__ double s_dsum[TRACK ? 64 * kPad : 1];
+	__shared__ double s_acc[64 * 64];
+	__shared__ double s_dsum[TRACK ? 64 * 64 : 1];
 	__shared__ uint64_t s_row[kChunk], s_bits[kChunk], s_vals[kChunk]; // row bytes / presence row / first value
-	__shared__ double s_wt[kChunk], s_t[kChunk][4], s_l[kChunk][4];
+	// an explicit dosage u (in 2^-14) replaces the call's term: delta = ((l0 d + l1) - l2) l3 - ts[call], d = u 2^-14,
+	// staged as delta = a u + b[call] with a = l0 l3 2^-14 and b[call] = (l1 - l2) l3 - ts[call]
+	__shared__ double s_wt[kChunk], s_a[kChunk], s_b[kChunk][4];
 	__shared__ uint32_t s_on[kChunk];
-	for (uint32_t t = threadIdx.x; t < 64 * kPad; t += 64u * kWaves) {
+	for (uint32_t t = threadIdx.x; t < 64 * 64; t += 64u * kWaves) {
 		s_acc[t] = 0.0;
 		if (TRACK) {
 			s_dsum[t] = 0.0;
@@ -864,10 +869,13 @@ __global__ __launch_bounds__(1024, 8) void k_score_dosage_fix(const uint8_t *__r
 			s_bits[threadIdx.x] = static_cast<uint64_t>(r < 0 ? 0 : r) * dos.words;
 			s_vals[threadIdx.x] = r < 0 ? 0ull : dos.val_off[r];
 			s_wt[threadIdx.x] = weights[static_cast<uint64_t>(i) * w_stride];
-		}
-		for (uint32_t k = threadIdx.x; k < cnt * 4u; k += 64u * kWaves) {
-			s_t[k >> 2][k & 3] = ts[4ull * base + k];
-			s_l[k >> 2][k & 3] = lin[4ull * base + k];
+			const double l0 = lin[4ull * i + 0], l1 = lin[4ull * i + 1], l2 = lin[4ull * i + 2], l3 = lin[4ull * i + 3];
+			s_a[threadIdx.x] = l0 * l3 * 0x1p-14;
+			const double shift = (l1 - l2) * l3;
+#pragma unroll
+			for (int c = 0; c < 4; c++) {
+				s_b[threadIdx.x][c] = shift - ts[4ull * i + c];
+			}
 		}
 		__syncthreads();
 	for (uint32_t k = wave; k < cnt; k += kWaves) {
@@ -885,20 +893,17 @@ __global__ __launch_bounds__(1024, 8) void k_score_dosage_fix(const uint8_t *__r
 			continue; // no explicit dosage in this tile
 		}
 		const uint16_t *vals = dos.values + s_vals[k] + rk;
-		const double wt = s_wt[k];
-		const double l0 = s_l[k][0], l1 = s_l[k][1], l2 = s_l[k][2], l3 = s_l[k][3];
+		const double wt = s_wt[k], a = s_a[k];
+		const uint64_t q_lo = q.x | (static_cast<uint64_t>(q.y) << 32), q_hi = q.z | (static_cast<uint64_t>(q.w) << 32);
 #define PGH_DOSAGE_ENTRY(U)                                                                                            \
 	{                                                                                                                  \
 		const uint32_t b = static_cast<uint32_t>(__ffsll(static_cast<long long>(e))) - 1u;                             \
 		e &= e - 1ull;                                                                                                 \
-		const uint32_t word = b < 32u ? (b < 16u ? q.x : q.y) : (b < 48u ? q.z : q.w);                                 \
-		const uint32_t code = (word >> (2u * (b & 15u))) & 3u;                                                         \
-		const double table = s_t[k][code];                                                                             \
-		const double d = static_cast<double>(U) * 0x1p-14;                                                             \
-		const double delta = ((l0 * d + l1) - l2) * l3 - table;                                                        \
-		atomicAdd(&s_acc[lane * kPad + b], wt * delta);                                                                \
+		const uint32_t code = static_cast<uint32_t>((b < 32u ? q_lo : q_hi) >> (2u * (b & 31u))) & 3u;                 \
+		const double delta = fma(a, static_cast<double>(U), s_b[k][code]);                                             \
+		atomicAdd(&s_acc[b * 64u + lane], wt * delta);                                                                 \
 		if (TRACK) {                                                                                                   \
-			atomicAdd(&s_dsum[lane * kPad + b], delta);                                                                \
+			atomicAdd(&s_dsum[b * 64u + lane], delta);                                                                 \
 		}                                                                                                              \
 		if (miss && code == 3u) {                                                                                      \
 			atomicSub(miss + 64u * w + b, 1u); /* it has a dosage: not missing after all */                            \
@@ -933,7 +938,200 @@ __global__ __launch_bounds__(1024, 8) void k_score_dosage_fix(const uint8_t *__r
 	__syncthreads();
 	for (uint32_t t = threadIdx.x; t < 4096u; t += 64u * kWaves) {
 		const uint32_t s = blockIdx.x * 4096u + t;
-		const uint32_t at = (t >> 6) * kPad + (t & 63u);
+		const uint32_t at = (t & 63u) * 64u + (t >> 6); // (a 64-way bank conflict, eight times per slice: noise)
+		if (s < sample_ct) {
+			if (s_acc[at] != 0.0) {
+				unsafeAtomicAdd(score + static_cast<uint64_t>(s) * out_stride, s_acc[at]);
+			}
+			if (TRACK && s_dsum[at] != 0.0) {
+				unsafeAtomicAdd(dosage_sum + s, s_dsum[at]);
+			}
+		}
+	}
+}
+
+
+// ---- entry records: the explicit dosages of sparse tracks, laid out for plink_score -----------------------------
+// One 32-bit record per explicit dosage:
+//     [31:16] the value (0 .. 32768)   [14:3] 64 * bit + word: the sample's element in the 4096-sample tile's LDS
+//     image, pre-multiplied by 8          [1:0] the sample's hardcall
+// A (row, tile) run holds the same entries as values[] does -- it starts at rank[row][64 tile] -- but ROUND-MAJOR:
+// first the first entry of every word of the tile (words ascending), then every word's second entry, and so on.
+// Any 64 consecutive records therefore belong to (nearly) 64 different words, and with the tile stored
+// [bit][word] in LDS a wave's 64 atomic adds fall into 64 different 8-byte bank slots -- while every lane has an
+// entry to work on (the bit walk of k_score_dosage_fix leaves half the lanes idle behind the fullest word).
+// One wave per (row, tile); a round is one ballot.
+__global__ __launch_bounds__(256) void k_dosage_records(const uint8_t *__restrict__ rows, uint64_t pitch, DosageView dos,
+                                                        const uint32_t *__restrict__ row_variant,
+                                                        const uint64_t *__restrict__ rec_off,
+                                                        uint32_t *__restrict__ rec) {
+	const uint32_t r = blockIdx.y;
+	const uint64_t first = rec_off[r];
+	if (rec_off[r + 1] == first) {
+		return; // a track too dense for records (or an empty one)
+	}
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6);
+	if (tile * 64u >= dos.words) {
+		return;
+	}
+	const uint32_t w = tile * 64u + lane;
+	const bool in_row = w < dos.words;
+	const uint64_t at = static_cast<uint64_t>(r) * dos.words + w;
+	uint64_t e = in_row ? dos.present[at] : 0ull;
+	const uint32_t rk = in_row ? dos.rank[at] : 0u;
+	uint4 q = make_uint4(0, 0, 0, 0);
+	if (in_row) {
+		q = *reinterpret_cast<const uint4 *>(rows + static_cast<uint64_t>(row_variant[r]) * pitch + 16ull * w);
+	}
+	const uint64_t q_lo = q.x | (static_cast<uint64_t>(q.y) << 32), q_hi = q.z | (static_cast<uint64_t>(q.w) << 32);
+	const uint16_t *vals = dos.values + dos.val_off[r] + rk;
+	uint32_t *out = rec + first + __shfl(rk, 0); // lane 0 holds the tile's first word
+	uint32_t base = 0;
+	for (uint32_t i = 0;; i++) {
+		const uint64_t mask = __ballot(e != 0ull);
+		if (mask == 0ull) {
+			break;
+		}
+		const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32),
+		                                                      __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+		if (e != 0ull) {
+			const uint32_t b = static_cast<uint32_t>(__ffsll(static_cast<long long>(e))) - 1u;
+			e &= e - 1ull;
+			const uint32_t code = static_cast<uint32_t>((b < 32u ? q_lo : q_hi) >> (2u * (b & 31u))) & 3u;
+			out[pos] = (static_cast<uint32_t>(vals[i]) << 16) | ((b * 64u + lane) << 3) | code;
+		}
+		base += static_cast<uint32_t>(__popcll(mask));
+	}
+}
+
+// plink_score's explicit-entry step over the records (same contract as k_score_dosage_fix, which stays as the
+// path for datasets whose records did not fit).  Sixteen waves share a 4096-sample tile in LDS; a wave takes every
+// sixteenth variant of the slice and streams that variant's run of the tile: 256 B per wave-instruction, the next
+// 512 entries in registers while the current ones are added.  Per 64 entries: one load, ~10 vector instructions,
+// one LDS read (the term of the hardcall the dosage replaces) and one or two FP64 LDS atomics without conflicts.
+constexpr uint32_t kRecNone = 0xffffffffu; // not a record: values stop at 32768
+constexpr uint32_t kRecGroup = 8;          // wave-loads of 64 records in flight per wave
+
+template <bool TRACK>
+__global__ __launch_bounds__(1024) void k_score_dosage_records(uint32_t sample_ct, DosageView dos,
+                                                                const uint32_t *__restrict__ vlist, uint32_t n_scored,
+                                                                uint32_t slice_len, const double *__restrict__ weights,
+                                                                uint32_t w_stride, const double *__restrict__ ts,
+                                                                const double *__restrict__ lin,
+                                                                const uint32_t *__restrict__ ac,
+                                                                double *__restrict__ score, uint32_t out_stride,
+                                                                double *__restrict__ dosage_sum,
+                                                                uint32_t *__restrict__ miss) {
+	constexpr uint32_t kWaves = 16;
+	constexpr uint32_t kChunk = 128; // variants whose constants are staged in LDS at a time
+	__shared__ double s_acc[64 * 64]; // [bit][word]
+	__shared__ double s_dsum[TRACK ? 64 * 64 : 1];
+	__shared__ uint64_t s_first[kChunk]; // the tile's first record of each variant
+	__shared__ uint32_t s_count[kChunk]; // and how many there are (0: nothing to add)
+	__shared__ double s_wt[kChunk], s_a[kChunk], s_b[kChunk][4]; // delta = a u + b[call] (k_score_dosage_fix)
+	for (uint32_t t = threadIdx.x; t < 64 * 64; t += 64u * kWaves) {
+		s_acc[t] = 0.0;
+		if (TRACK) {
+			s_dsum[t] = 0.0;
+		}
+	}
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint32_t w0 = blockIdx.x * 64u; // first word of the tile
+	const uint32_t i_begin = blockIdx.y * slice_len;
+	const uint32_t i_end = min(i_begin + slice_len, n_scored);
+	for (uint32_t base = i_begin; base < i_end; base += kChunk) {
+		const uint32_t cnt = min(kChunk, i_end - base);
+		__syncthreads();
+		if (threadIdx.x < cnt) {
+			const uint32_t i = base + threadIdx.x;
+			const int32_t r = dos.row_of[vlist[i]];
+			uint32_t n = 0;
+			uint64_t first = 0;
+			if (ac[i] != 0u && r >= 0) { // (skipped by the reference otherwise: nobody observed, or no variance)
+				const uint64_t row_first = dos.rec_off[r], row_n = dos.rec_off[r + 1] - row_first;
+				const uint64_t rk = static_cast<uint64_t>(r) * dos.words + w0;
+				const uint32_t start = dos.rank[rk];
+				const uint32_t end = w0 + 64u < dos.words ? dos.rank[rk + 64u] : static_cast<uint32_t>(row_n);
+				first = row_first + start;
+				n = row_n ? end - start : 0u;
+			}
+			s_first[threadIdx.x] = first;
+			s_count[threadIdx.x] = n;
+			s_wt[threadIdx.x] = weights[static_cast<uint64_t>(i) * w_stride];
+			const double l0 = lin[4ull * i + 0], l1 = lin[4ull * i + 1], l2 = lin[4ull * i + 2], l3 = lin[4ull * i + 3];
+			s_a[threadIdx.x] = l0 * l3 * 0x1p-14;
+			const double shift = (l1 - l2) * l3;
+#pragma unroll
+			for (int c = 0; c < 4; c++) {
+				s_b[threadIdx.x][c] = shift - ts[4ull * i + c];
+			}
+		}
+		__syncthreads();
+		// this wave's work items: (variant k, group g of 512 records), walked with the next item's records in flight
+		auto fetch = [&](uint32_t k, uint32_t g, uint32_t(&dst)[kRecGroup]) {
+			const uint32_t n = s_count[k] - g * (64u * kRecGroup);
+			const uint32_t *p = dos.rec + s_first[k] + g * (64u * kRecGroup);
+#pragma unroll
+			for (uint32_t j = 0; j < kRecGroup; j++) {
+				const uint32_t idx = 64u * j + lane;
+				dst[j] = idx < n ? __builtin_nontemporal_load(p + idx) : kRecNone;
+			}
+		};
+		auto next_variant = [&](uint32_t k) {
+			while (k < cnt && s_count[k] == 0u) {
+				k += kWaves;
+			}
+			return k;
+		};
+		uint32_t k = next_variant(wave), g = 0;
+		uint32_t cur[kRecGroup], nxt[kRecGroup];
+		if (k < cnt) {
+			fetch(k, 0, cur);
+		}
+		while (k < cnt) {
+			uint32_t k2 = k, g2 = g + 1u;
+			if (g2 * (64u * kRecGroup) >= s_count[k]) {
+				k2 = next_variant(k + kWaves);
+				g2 = 0;
+			}
+			if (k2 < cnt) {
+				fetch(k2, g2, nxt);
+			}
+			const double wt = s_wt[k], a = s_a[k];
+			// (the four terms of the variant held in registers and picked by two selects instead of this per-entry
+			// LDS read: no faster, 14.8 vs 14.5 ms -- the atomics are what fills the LDS pipe)
+			const uint8_t *bk = reinterpret_cast<const uint8_t *>(&s_b[k][0]);
+#pragma unroll
+			for (uint32_t j = 0; j < kRecGroup; j++) {
+				const uint32_t rv = cur[j];
+				if (rv != kRecNone) {
+					const uint32_t code = rv & 3u;
+					const double delta = fma(a, static_cast<double>(rv >> 16), *reinterpret_cast<const double *>(bk + 8u * code));
+					const uint32_t at = rv & 0x7ff8u;
+					atomicAdd(reinterpret_cast<double *>(reinterpret_cast<uint8_t *>(s_acc) + at), wt * delta);
+					if (TRACK) {
+						atomicAdd(reinterpret_cast<double *>(reinterpret_cast<uint8_t *>(s_dsum) + at), delta);
+					}
+					if (miss && code == 3u) { // it has a dosage: not missing after all
+						const uint32_t el = at >> 3;
+						atomicSub(miss + 64u * (w0 + (el & 63u)) + (el >> 6), 1u);
+					}
+				}
+			}
+#pragma unroll
+			for (uint32_t j = 0; j < kRecGroup; j++) {
+				cur[j] = nxt[j];
+			}
+			k = k2;
+			g = g2;
+		}
+	}
+	__syncthreads();
+	for (uint32_t t = threadIdx.x; t < 4096u; t += 64u * kWaves) {
+		const uint32_t s = blockIdx.x * 4096u + t;
+		const uint32_t at = (t & 63u) * 64u + (t >> 6); // (a 64-way bank conflict, eight times per slice: noise)
 		if (s < sample_ct) {
 			if (s_acc[at] != 0.0) {
 				unsafeAtomicAdd(score + static_cast<uint64_t>(s) * out_stride, s_acc[at]);
@@ -1119,6 +1317,54 @@ hipError_t LaunchScoreDosageFix(const RowView &view, const DosageView &dos, cons
 		hipLaunchKernelGGL(k_score_dosage_fix<false>, dim3(tiles, slices), dim3(1024), 0, stream, view.rows, view.pitch,
 		                   view.sample_ct, dos, vlist, n_scored, slice_len, weights, w_stride, ts, lin, ac, score, out_stride,
 		                   dosage_sum, miss);
+	}
+	return hipGetLastError();
+}
+
+hipError_t LaunchDosageRecords(const RowView &view, const DosageView &dos, uint32_t rows, const uint32_t *row_variant,
+                               const uint64_t *rec_off, uint32_t *rec, hipStream_t stream) {
+	if (rows == 0 || dos.words == 0) {
+		return hipSuccess;
+	}
+	const uint32_t tiles = (dos.words + 63) / 64;
+	for (uint32_t done = 0; done < rows; done += 65535u) { // grid.y limit
+		const uint32_t n = min(65535u, rows - done);
+		DosageView part = dos;
+		part.present += static_cast<uint64_t>(done) * dos.words;
+		part.rank += static_cast<uint64_t>(done) * dos.words;
+		part.val_off += done;
+		hipLaunchKernelGGL(k_dosage_records, dim3((tiles + 3) / 4, n), dim3(256), 0, stream, view.rows, view.pitch, part,
+		                   row_variant + done, rec_off + done, rec);
+	}
+	return hipGetLastError();
+}
+
+hipError_t LaunchScoreDosageRecords(const RowView &view, const DosageView &dos, const uint32_t *vlist, uint32_t n_scored,
+                                    const double *weights, uint32_t w_stride, const double *ts, const double *lin,
+                                    const uint32_t *ac, double *score, uint32_t out_stride, double *dosage_sum,
+                                    uint32_t *miss, hipStream_t stream) {
+	if (n_scored == 0) {
+		return hipSuccess;
+	}
+	if (!dos.rec || !dos.rec_off) {
+		return hipErrorInvalidValue;
+	}
+	const uint32_t tiles = (dos.words + 63) / 64;
+	const uint32_t want_slices = (2048 + tiles - 1) / tiles;
+	uint32_t slice_len = (n_scored + want_slices - 1) / want_slices;
+	slice_len = ((slice_len + 127) / 128) * 128;
+	uint32_t slices = (n_scored + slice_len - 1) / slice_len;
+	if (slices > 65535u) {
+		slices = 65535u;
+		slice_len = ((n_scored + slices - 1) / slices + 127) / 128 * 128;
+		slices = (n_scored + slice_len - 1) / slice_len;
+	}
+	if (dosage_sum) {
+		hipLaunchKernelGGL(k_score_dosage_records<true>, dim3(tiles, slices), dim3(1024), 0, stream, view.sample_ct, dos,
+		                   vlist, n_scored, slice_len, weights, w_stride, ts, lin, ac, score, out_stride, dosage_sum, miss);
+	} else {
+		hipLaunchKernelGGL(k_score_dosage_records<false>, dim3(tiles, slices), dim3(1024), 0, stream, view.sample_ct, dos,
+		                   vlist, n_scored, slice_len, weights, w_stride, ts, lin, ac, score, out_stride, dosage_sum, miss);
 	}
 	return hipGetLastError();
 }

@@ -21,6 +21,10 @@ struct DosageView {
 	const uint64_t *val_off = nullptr; // rows + 1: where each row's values start, and where the last one ends
 	const uint16_t *values = nullptr;  // 16-byte aligned, padded by 16 bytes: rows are streamed in aligned 16-byte loads
 	uint32_t words = 0; // ceil(sample_ct / 64)
+	// Entry records of the sparse tracks (LaunchDosageRecords; NULL until the first plink_score plan that needs
+	// them): rec_off[rows + 1], a row's records at rec[rec_off[r] .. rec_off[r + 1]) -- none for the dense tracks.
+	const uint32_t *rec = nullptr;
+	const uint64_t *rec_off = nullptr;
 };
 
 //! One staged run of records (decode.hpp:DecodeBatch) whose dosage tracks go into the resident form.
@@ -102,6 +106,18 @@ hipError_t LaunchScoreDosageFix(const RowView &view, const DosageView &dos, cons
                                 const double *weights, uint32_t w_stride, const double *ts, const double *lin,
                                 const uint32_t *ac, double *score, uint32_t out_stride, double *dosage_sum,
                                 uint32_t *miss, hipStream_t stream);
+
+//! The entry records of the rows with rec_off[r + 1] > rec_off[r] (dosage.hip: value, tile element and hardcall of
+//! every explicit dosage in 32 bits, round-major inside each 4096-sample tile).  row_variant[r]: the resident row
+//! of dosage row r.  dos.present / rank / val_off / values are read; dos.rec / rec_off are not.
+hipError_t LaunchDosageRecords(const RowView &view, const DosageView &dos, uint32_t rows, const uint32_t *row_variant,
+                               const uint64_t *rec_off, uint32_t *rec, hipStream_t stream);
+
+//! LaunchScoreDosageFix's contract over the entry records (dos.rec): every listed variant's row must have them.
+hipError_t LaunchScoreDosageRecords(const RowView &view, const DosageView &dos, const uint32_t *vlist, uint32_t n_scored,
+                                    const double *weights, uint32_t w_stride, const double *ts, const double *lin,
+                                    const uint32_t *ac, double *score, uint32_t out_stride, double *dosage_sum,
+                                    uint32_t *miss, hipStream_t stream);
 
 //! Variants at which EVERY sample has an explicit dosage: contribution = affine map of the sample's value, read
 //! straight from the value run (no presence bits, ranks or calls).  Nobody is missing at such a variant.

@@ -107,11 +107,16 @@ REL = 1e-12
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["default", "no_mean_imputation", "center"])
-@pytest.mark.parametrize("ncols,lanes", [(1, False), (3, False), (6, False), (1, True), (5, True)])
-def test_score_over_dosage_tracks(files, gpu_lib, oracle, mode, ncols, lanes, monkeypatch):
-    """lanes: the one-lane-per-sample kernel (k_score_dosage) instead of hardcall sweep + k_score_dosage_fix."""
-    if lanes:
+@pytest.mark.parametrize("ncols,path", [(1, "records"), (3, "records"), (6, "records"), (1, "bitwalk"), (3, "bitwalk"),
+                                        (1, "lanes"), (5, "lanes")])
+def test_score_over_dosage_tracks(files, gpu_lib, oracle, mode, ncols, path, monkeypatch):
+    """The three ways a sparse track is scored: the hardcall contraction + k_score_dosage_records over the dataset's
+    entry records (the default), + the bit-walking k_score_dosage_fix (what a dataset whose records do not fit gets),
+    and the one-lane-per-sample k_score_dosage."""
+    if path == "lanes":
         monkeypatch.setenv("PGH_SCORE_DOSAGE_LANES", "1")
+    elif path == "bitwalk":
+        monkeypatch.setenv("PGH_SCORE_DOSAGE_RECORDS", "0")
     m, n = 120, 1000
     path, geno, dos, dkinds, want = files[(m, n, True)]
     ds = gpu_lib.Dataset.open(path)
@@ -372,6 +377,12 @@ def test_wide_dosage_matrix_properties(gpu_lib, monkeypatch):
         monkeypatch.delenv("PGH_SCORE_DOSAGE_LANES")
         assert np.array_equal(ac1, ac2)
         assert np.allclose(s1, s2, rtol=1e-9, atol=1e-9) and np.allclose(d1, d2, rtol=1e-9, atol=1e-9)
+        # ... and the entry records (round-major runs per 4096-sample tile, 123 tiles here) against the bit walk
+        monkeypatch.setenv("PGH_SCORE_DOSAGE_RECORDS", "0")
+        s3, d3, ac3 = whole.score(vidx, w, mode=mode)
+        monkeypatch.delenv("PGH_SCORE_DOSAGE_RECORDS")
+        assert np.array_equal(ac3, ac2)
+        assert np.allclose(s3, s2, rtol=1e-12, atol=1e-12) and np.allclose(d3, d2, rtol=1e-12, atol=1e-12)
     # shards' scores add up to the whole's
     a = lo.score(vidx[vidx < 1500], w[vidx < 1500])
     b = hi.score(vidx[vidx >= 1500], w[vidx >= 1500])

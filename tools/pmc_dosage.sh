@@ -11,7 +11,7 @@ import csv, glob, collections
 for f in sorted(glob.glob('gpurun_out/dos_pmc/*/*/*counter_collection.csv')):
     acc=collections.defaultdict(float)
     for r in csv.DictReader(open(f)):
-        if 'k_score_dosage_fix' in r['Kernel_Name']:
+        if 'k_score_dosage_' in r['Kernel_Name']:
             acc[r['Counter_Name']]+=float(r['Counter_Value'])
     print({k: f"{v:.4g}" for k, v in acc.items()})
 PY
