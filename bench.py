@@ -334,6 +334,8 @@ def main():
     n = args.samples
     if args.workload.startswith("dosage") and args.variants == 1_000_000:
         args.variants = 250_000  # rows + presence bits + ranks + values of 1M variants do not fit one GPU
+    if args.workload == "pca" and args.variants == 1_000_000:
+        args.variants = 100_000  # BASELINE.json's plink_pca configuration: 100k variants x 500k samples
     v_begin, v_end = sharding.shard_range(rank, world, args.variants, args.scaling)
     m = v_end - v_begin
     ds = L.Dataset.synth(v_begin, v_end, n, SEED, MISSING_RATE)

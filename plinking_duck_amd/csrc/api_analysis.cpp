@@ -982,6 +982,24 @@ extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, 
 	if (rc != PGH_OK) {
 		return rc;
 	}
+	// PGH_PCA_TIMING=1: wall-clock of the call's phases on stderr (each mark drains the stream first)
+	static const bool timing = [] {
+		const char *e = std::getenv("PGH_PCA_TIMING");
+		return e && *e && *e != '0';
+	}();
+	auto t_last = std::chrono::steady_clock::now();
+	hipStream_t t_stream = nullptr;
+	auto mark = [&](const char *what) {
+		if (!timing) {
+			return;
+		}
+		if (t_stream) {
+			(void)hipStreamSynchronize(t_stream);
+		}
+		const auto now = std::chrono::steady_clock::now();
+		std::fprintf(stderr, "pca %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+		t_last = now;
+	};
 	const uint32_t N = ds->sample_ct;
 	const uint32_t n_out = subset ? subset->n_out : N;
 	const uint32_t M = n_var; // this shard's rows of X; every 1/M and the eigenvalue divisor use the total
@@ -1013,6 +1031,8 @@ extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, 
 	} own;
 	PGH_HIP(hipStreamCreateWithFlags(&own.s, hipStreamNonBlocking), "hipStreamCreate(pca)");
 	hipStream_t st = own.s;
+	t_stream = st;
+	mark("checks + stream");
 	// Sum a device buffer over the variant shards (X is split by rows, so every X^T(...)
 	// product and every Gram matrix of a tall factor is a sum of per-shard terms).
 	auto all_sum = [&](double *buf, uint64_t count) -> int {
@@ -1046,7 +1066,10 @@ extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, 
 		PGH_HIP(hipMemcpy(d_center.p, center, sizeof(double) * M, hipMemcpyHostToDevice), "pca upload");
 		PGH_HIP(hipMemcpy(d_inv.p, inv_stdev, sizeof(double) * M, hipMemcpyHostToDevice), "pca upload");
 	}
-	{
+	if (!subset) {
+		// every sample is in: the caller's start matrix already is in raw-sample rows
+		PGH_HIP(hipMemcpy(d_g1.p, g1_init, sizeof(double) * static_cast<size_t>(N) * k2, hipMemcpyHostToDevice), "pca upload");
+	} else {
 		// start matrix in raw-sample rows (excluded samples stay zero)
 		std::vector<double> g1_raw(static_cast<size_t>(N) * k2, 0.0);
 		for (uint32_t k = 0; k < n_out; k++) {
@@ -1059,6 +1082,7 @@ extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, 
 		PGH_HIP(pgh::LaunchNormTables(d_center.As<double>(), d_inv.As<double>(), M, d_ts.As<double>(), st), "pca tables");
 	}
 	const RowView view = ds->View();
+	mark("allocations + uploads");
 	// Both contractions run on the int8 matrix cores (score_i8.hip): the dense factor of each pass is cut into
 	// exact fixed-point digits, <= 18 columns per pass.  X^T (...) walks the resident rows; X G1 walks the
 	// transposed packed matrix, built here once (pca_i8.hip).
@@ -1091,6 +1115,7 @@ extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, 
 			view_t.rows = d_xt.As<uint8_t>();
 		}
 	}
+	mark("i8 buffers + transpose");
 	// out[s][c] += sum_v t_v[g(v,s)] W[v][c] over this shard's variants (Step B, phase 3); out zeroed by the caller
 	auto contract_variants = [&](const double *w, uint32_t w_stride, uint32_t n_cols, double *out,
 	                             uint32_t out_stride) -> hipError_t {
@@ -1153,6 +1178,7 @@ extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, 
 			std::swap(g1, g2);
 		}
 	}
+	mark("power iterations");
 	// Orthonormal basis of the Krylov block's column space, on the device.  The
 	// reference takes the left singular vectors of QQ (src/plink_pca.cpp:683-697); the
 	// only thing phase 3 uses of them is that they are an orthonormal basis of that
@@ -1211,6 +1237,7 @@ extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, 
 			}
 		}
 	}
+	mark("orthonormal basis");
 	// Phase 3: BB = X^T U   (src/plink_pca.cpp:664-676)
 	PGH_HIP(d_bb.Alloc(sizeof(double) * static_cast<size_t>(N) * qq), "hipMalloc(pca)");
 	PGH_HIP(hipMemsetAsync(d_bb.p, 0, sizeof(double) * static_cast<size_t>(N) * qq, st), "pca memset");
@@ -1219,6 +1246,7 @@ extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, 
 	}
 	PGH_SUM(d_bb.As<double>(), static_cast<uint64_t>(N) * qq);
 	PGH_HIP(pgh::LaunchMaskRows(d_bb.As<double>(), N, qq, qq, mask2, st), "pca mask");
+	mark("phase 3");
 	// Final SVD of BB (src/plink_pca.cpp:700-720) through its qq x qq Gram matrix:
 	// BB^T BB = V S^2 V^T gives the eigenvalues S^2 / M directly and U_k = BB V_k S_k^-1.
 	{
@@ -1238,7 +1266,9 @@ extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, 
 				g[static_cast<size_t>(i) * qq + j] = g[static_cast<size_t>(j) * qq + i] = avg;
 			}
 		}
+		mark("gram of BB");
 		pgh::SymmetricEigen(g, qq, lam, vec);
+		mark("eigen (host)");
 		std::vector<double> vk(static_cast<size_t>(qq) * n_pcs);
 		HostSourceFence fence(st); // `vk` feeds an asynchronous upload
 		for (uint32_t pc = 0; pc < n_pcs; pc++) {
@@ -1253,11 +1283,19 @@ extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, 
 		PGH_HIP(pgh::LaunchTallTimesSmall(d_bb.As<double>(), qq, qq, d_vk.As<double>(), n_pcs, n_pcs, 1.0, 0.0, nullptr, 0,
 		                                  d_uk.As<double>(), n_pcs, N, st),
 		        "pca eigenvectors");
-		std::vector<double> uk_raw(static_cast<size_t>(N) * n_pcs);
-		PGH_HIP(hipMemcpyAsync(uk_raw.data(), d_uk.p, sizeof(double) * uk_raw.size(), hipMemcpyDeviceToHost, st),
-		        "pca download");
-		PGH_HIP(hipStreamSynchronize(st), "pca sync");
-		Compact<double>(subset, uk_raw.data(), n_pcs, eigenvectors, N);
+		if (!subset) {
+			PGH_HIP(hipMemcpyAsync(eigenvectors, d_uk.p, sizeof(double) * static_cast<size_t>(N) * n_pcs,
+			                       hipMemcpyDeviceToHost, st),
+			        "pca download");
+			PGH_HIP(hipStreamSynchronize(st), "pca sync");
+		} else {
+			std::vector<double> uk_raw(static_cast<size_t>(N) * n_pcs);
+			PGH_HIP(hipMemcpyAsync(uk_raw.data(), d_uk.p, sizeof(double) * uk_raw.size(), hipMemcpyDeviceToHost, st),
+			        "pca download");
+			PGH_HIP(hipStreamSynchronize(st), "pca sync");
+			Compact<double>(subset, uk_raw.data(), n_pcs, eigenvectors, N);
+		}
+		mark("eigenvectors + download");
 	}
 	return PGH_OK;
 #undef PGH_SUM

@@ -275,6 +275,10 @@ constexpr uint32_t RingSlots() {
 
 // PLANES: 3 = code plane and missing plane (plink_score, plink_pca's X^T Y); 1 / 2 = one of them alone (the two
 // products of plink_pca's X G1, whose per-variant normalisation is applied afterwards).
+//
+// Knock-out builds (tools/i8_experiment.sh, profiles/r02_i8_knockout.txt): -DPGH_I8_NO_BUILD takes the operand
+// building out of the loop, -DPGH_I8_NO_DMA / _NO_DMA_G / _NO_DMA_B the LDS-DMA (all of it / the genotype piece /
+// the digit pieces) after the first tiles.  Results are then wrong; only the launch time is read.
 template <int NT, int TS, int PLANES>
 __global__ __launch_bounds__(256) void k_score_i8(const uint8_t *__restrict__ rows, uint64_t pitch, uint32_t sample_ct,
                                                   const uint32_t *__restrict__ rowidx, uint32_t n_tiles,
@@ -296,7 +300,15 @@ __global__ __launch_bounds__(256) void k_score_i8(const uint8_t *__restrict__ ro
 	if (tile_begin >= tile_end) {
 		return;
 	}
-	const uint64_t group_byte = static_cast<uint64_t>(blockIdx.x) * S::kRowBytes; // first byte of this workgroup's stripe
+	// Which sample group this workgroup takes.  With TS = 4 a stripe is 64 bytes of every row, half a 128-byte cache
+	// line: consecutive workgroup ids go to consecutive XCDs (eight L2s), so the two halves of a line would be fetched
+	// from HBM twice (PMC: 271 GB per launch over 125 GB of rows).  Inside every run of 16 ids, ids i and i + 8 --
+	// the same XCD, dispatched together -- therefore take the stripes 2 (i % 8) and 2 (i % 8) + 1.
+	uint32_t group = blockIdx.x;
+	if (TS == 4 && (group | 15u) < gridDim.x) {
+		group = (group & ~15u) + ((group & 7u) << 1) + ((group >> 3) & 1u);
+	}
+	const uint64_t group_byte = static_cast<uint64_t>(group) * S::kRowBytes; // first byte of this workgroup's stripe
 
 	// ---- staging: HBM -> LDS without a register stop (global_load_lds_dwordx4) ----
 	// One such instruction writes 64 x 16 B to consecutive LDS bytes (lane l at base + 16 l), so the slot's image
@@ -313,7 +325,13 @@ __global__ __launch_bounds__(256) void k_score_i8(const uint8_t *__restrict__ ro
 	constexpr uint32_t kBFirstPiece = (PLANES & 1) ? 0u : NT;
 	constexpr uint32_t kBPieceCount = PLANES == 3 ? 2u * NT : NT;
 	constexpr uint32_t kBPieces = (kBPieceCount + 3u) / 4u; // per wave and tile
+#if defined(PGH_I8_NO_DMA_B)
+	constexpr uint32_t kPieces = kGenoPieces + 1u;
+#elif defined(PGH_I8_NO_DMA_G)
+	constexpr uint32_t kPieces = kBPieces + 1u;
+#else
 	constexpr uint32_t kPieces = kGenoPieces + kBPieces + 1u;  // + the row numbers
+#endif
 	constexpr uint32_t kRowAhead = 2u * kRing - 2u;            // tiles between a row-number DMA and its use
 	static_assert(kPieces * (kRing - 2) < 64, "vmcnt field");
 	__shared__ uint32_t s_rows[16][kTileVariants]; // by tile number mod 16: a slot is rewritten 16 tiles (>= 6 barriers) after its last read
@@ -336,18 +354,27 @@ __global__ __launch_bounds__(256) void k_score_i8(const uint8_t *__restrict__ ro
 		const uint32_t t = min(tile, last_tile);
 		Glds4(rowidx + static_cast<uint64_t>(t) * kTileVariants + lane, rows_lds + ((tile - tile_begin) & 15u) * 256u);
 	};
-	auto issue = [&](uint32_t tile, uint32_t slot) {
-		// (past the slice: a harmless repeat of its last tile keeps the counts uniform)
-		issue_rows(tile + kRowAhead);
-		const uint32_t base = ring_lds + slot * kSlotBytes;
+	// the resident rows this lane fetches for `tile` (plain LDS reads: the numbers landed trips ago).  The loop asks
+	// for them one trip before the DMA that needs them, so the read's latency is not in front of that DMA.
+	auto read_rows = [&](uint32_t tile, uint32_t(&r)[kGenoPieces]) {
 		const uint32_t *rp = &s_rows[(tile - tile_begin) & 15u][0];
 #pragma unroll
 		for (uint32_t n = 0; n < kGenoPieces; n++) {
-			const uint32_t r = rp[st_row[n]];
-			const uint8_t *src = rows + static_cast<uint64_t>(r) * pitch + st_col[n];
-			Glds16Stream(src, base + (4u * n + wave_u) * 1024u);
+			r[n] = rp[st_row[n]];
 		}
+	};
+	auto issue = [&](uint32_t tile, uint32_t slot, const uint32_t(&r)[kGenoPieces]) {
+#ifdef PGH_I8_NO_DMA
+		if (tile > tile_begin + 8u) {
+			return;
+		}
+#endif
+		// (past the slice: a harmless repeat of its last tile keeps the counts uniform)
+		issue_rows(tile + kRowAhead);
+		const uint32_t base = ring_lds + slot * kSlotBytes;
+
 		const int8_t *bsrc = bmat + static_cast<uint64_t>(min(tile, last_tile)) * S::kBBytes;
+#ifndef PGH_I8_NO_DMA_B
 #pragma unroll
 		for (uint32_t n = 0; n < kBPieces; n++) {
 			// every wave issues every piece (the vmcnt arithmetic wants equal counts): pieces past the digit bytes
@@ -355,6 +382,17 @@ __global__ __launch_bounds__(256) void k_score_i8(const uint8_t *__restrict__ ro
 			const uint32_t p = kBFirstPiece + min(4u * n + wave_u, kBPieceCount - 1u);
 			Glds16(bsrc + 1024ull * p + 16u * lane, base + S::kGenoBytes + p * 1024u);
 		}
+#else
+		(void)bsrc;
+#endif
+#ifndef PGH_I8_NO_DMA_G
+		// (the genotype piece goes last: 16 rows x 64 B per instruction with TS = 4, the slow one of the batch)
+#pragma unroll
+		for (uint32_t n = 0; n < kGenoPieces; n++) {
+			const uint8_t *src = rows + static_cast<uint64_t>(r[n]) * pitch + st_col[n];
+			Glds16Stream(src, base + (4u * n + wave_u) * 1024u);
+		}
+#endif
 	};
 
 	// ---- compute roles ----
@@ -390,15 +428,25 @@ __global__ __launch_bounds__(256) void k_score_i8(const uint8_t *__restrict__ ro
 	} else if (TS == 4) {
 		sel_first = ((4u + (x & 3u)) << 8) | (x & 3u);
 	}
-	auto compute = [&](uint32_t slot) {
-		uint32_t G[4][kBytesPerLane];
+	// this lane's sixteen words of the tile in `slot`: read at the top of a trip, in front of the DMA issue, so that
+	// the LDS round trip runs under the issue's scalar work instead of after it
+	auto load_words = [&](uint32_t slot, uint32_t(&wd)[16]) {
 		const uint8_t *gp = &s_ring[slot][geno_off];
 #pragma unroll
+		for (int k = 0; k < 16; k++) {
+#ifdef PGH_I8_NO_BUILD
+			wd[k] = lane * (k + 3u);
+			(void)gp;
+#else
+			wd[k] = *reinterpret_cast<const uint32_t *>(gp + k * S::kRowBytes);
+#endif
+		}
+	};
+	auto compute = [&](uint32_t slot, const uint32_t(&wd)[16]) {
+		uint32_t G[4][kBytesPerLane];
+#pragma unroll
 		for (int q = 0; q < 4; q++) {
-			const uint32_t w0 = *reinterpret_cast<const uint32_t *>(gp + (4 * q + 0) * S::kRowBytes);
-			const uint32_t w1 = *reinterpret_cast<const uint32_t *>(gp + (4 * q + 1) * S::kRowBytes);
-			const uint32_t w2 = *reinterpret_cast<const uint32_t *>(gp + (4 * q + 2) * S::kRowBytes);
-			const uint32_t w3 = *reinterpret_cast<const uint32_t *>(gp + (4 * q + 3) * S::kRowBytes);
+			const uint32_t w0 = wd[4 * q + 0], w1 = wd[4 * q + 1], w2 = wd[4 * q + 2], w3 = wd[4 * q + 3];
 			if (TS == 16) {
 				const uint32_t pa = __builtin_amdgcn_perm(w1, w0, 0x05010400u), pb = __builtin_amdgcn_perm(w1, w0, 0x07030602u);
 				const uint32_t qa = __builtin_amdgcn_perm(w3, w2, 0x05010400u), qb = __builtin_amdgcn_perm(w3, w2, 0x07030602u);
@@ -440,10 +488,9 @@ __global__ __launch_bounds__(256) void k_score_i8(const uint8_t *__restrict__ ro
 			}
 		}
 		// digit operands: two tiles at a time stay in registers across the samples, and the next two are read
-		// from LDS while these multiply.  (What keeps the matrix pipe at ~70 % with many tiles is not this read:
-		// a tile costs a fixed ~450 cycles of operand building, DMA issue and barrier per wave whatever the
-		// number of matrix instructions behind it, and on gfx950 that vector work of one wave did not run
-		// under the int8 matrix instructions of the other wave of the SIMD -- DESIGN.md section 6.)
+		// from LDS while these multiply.  (What keeps the matrix pipe at ~70 % with many tiles is not this read and
+		// not the operand building either -- without the LDS-DMA the launch runs at the matrix-instruction floor;
+		// the knock-out table is in DESIGN.md section 6.)
 		const v4i *bp = reinterpret_cast<const v4i *>(&s_ring[slot][S::kGenoBytes]);
 		constexpr int kHold = NT >= 2 ? 2 : 1;
 		v4i bg[kHold], bm[kHold], ng[kHold], nm[kHold];
@@ -500,21 +547,31 @@ __global__ __launch_bounds__(256) void k_score_i8(const uint8_t *__restrict__ ro
 	}
 	PGH_WAIT_VM(0);
 	__builtin_amdgcn_s_barrier();
+	uint32_t r_cur[kGenoPieces], r_nxt[kGenoPieces];
 #pragma unroll
 	for (uint32_t d = 0; d + 1 < kRing; d++) {
-		issue(tile_begin + d, d);
+		read_rows(tile_begin + d, r_cur);
+		issue(tile_begin + d, d, r_cur);
 	}
+	read_rows(tile_begin + (kRing - 1), r_cur);
 	PGH_WAIT_VM(kPieces * (kRing - 2));
 	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 	__builtin_amdgcn_s_barrier();
 	uint32_t slot = 0;
 	for (uint32_t tile = tile_begin; tile < tile_end; tile++) {
-		issue(tile + (kRing - 1), (slot + kRing - 1) % kRing);
-		compute(slot);
+		uint32_t wd[16];
+		load_words(slot, wd);
+		read_rows(tile + kRing, r_nxt); // for the next trip's DMA (its slot of s_rows was filled 2 kRing - 3 trips ago)
+		issue(tile + (kRing - 1), (slot + kRing - 1) % kRing, r_cur);
+		compute(slot, wd);
 		PGH_WAIT_VM(kPieces * (kRing - 2));
 		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 		__builtin_amdgcn_s_barrier();
 		slot = (slot + 1) % kRing;
+#pragma unroll
+		for (uint32_t n = 0; n < kGenoPieces; n++) {
+			r_cur[n] = r_nxt[n];
+		}
 	}
 	PGH_WAIT_VM(0); // the tail's repeats must land before the LDS is handed back
 #undef PGH_WAIT_VM
@@ -523,7 +580,7 @@ __global__ __launch_bounds__(256) void k_score_i8(const uint8_t *__restrict__ ro
 	// The digits of one output column sit in up to seven NEIGHBOURING lanes of a 16-lane row: they are scaled,
 	// summed across those lanes (three shuffle steps inside the row, gated on "same output column") and the lane
 	// that holds the column's lowest digit of this tile issues ONE atomic add per sample.
-	const uint32_t wave_sample0 = blockIdx.x * S::kSamplesPerGroup + wave * 16u * TS;
+	const uint32_t wave_sample0 = group * S::kSamplesPerGroup + wave * 16u * TS;
 #pragma unroll
 	for (int nt = 0; nt < NT; nt++) {
 		const uint32_t J = 16u * nt + x;

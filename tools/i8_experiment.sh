@@ -1,0 +1,23 @@
+#!/bin/bash
+# Where k_score_i8's time goes: rebuild score_i8.hip with one part removed at a time and time the 16-column launch.
+#   bash tools/i8_experiment.sh     (run on the GPU box through gpurun; leaves the regular build in place at the end)
+cd "$GRAFT_REPO_ROOT/plinking_duck_amd/csrc"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -mllvm -amdgpu-mfma-vgpr-form"
+OBJS="build/tally.o build/unpack.o build/score.o build/reduce.o build/pca.o build/pca_i8.o build/decode.o build/ld.o build/dosage.o build/phase.o build/api_dataset.o build/api_analysis.o build/api_reader.o build/api_sharded.o build/pgen_file.o build/linalg.o"
+cp ../libpgenhip.so /tmp/libpgenhip.keep
+for v in ${VARIANTS:-NONE NO_BUILD NO_DMA NO_DMA_B NO_DMA_G HOT_B}; do
+  /opt/rocm/bin/hipcc $FLAGS -DPGH_I8_$v -c score_i8.hip -o /tmp/score_i8_x.o 2>/dev/null || { echo "compile failed: $v"; continue; }
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libpgenhip.so $OBJS /tmp/score_i8_x.o
+  cd "$GRAFT_REPO_ROOT"
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/i8x -- python3 bench.py --workload score --score-cols ${COLS:-16} --steps 3 --warmup 1 --cpu-seconds 0 > /dev/null 2> /tmp/i8x_err.txt
+  f=$(ls -t /tmp/i8x/*/*_kernel_stats.csv 2>/dev/null | head -1)
+  printf "%-28s " "$v"; python3 - "$f" <<'PY'
+import csv, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    if 'k_score_i8' in r['Name']:
+        print(f"k_score_i8 avg {float(r['AverageNs'])/1e6:8.2f} ms over {r['Calls']} calls")
+PY
+  rm -rf /tmp/i8x
+  cd "$GRAFT_REPO_ROOT/plinking_duck_amd/csrc"
+done
+cp /tmp/libpgenhip.keep ../libpgenhip.so

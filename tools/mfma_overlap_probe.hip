@@ -108,7 +108,7 @@ __device__ inline unsigned SimdId() {
 enum { kMfmaOnly, kValuOnly, kPair, kMix };
 
 template <bool BIG, int MODE, int R>
-__global__ void probe(int iters, unsigned seed, int *__restrict__ sink, unsigned *__restrict__ roles) {
+__global__ __launch_bounds__(512) void probe(int iters, unsigned seed, int *__restrict__ sink, unsigned *__restrict__ roles) {
 	extern __shared__ unsigned s_dyn[];   // sized by the host to keep one workgroup per CU
 	__shared__ unsigned s_cnt[4];
 	if (threadIdx.x < 4) {
