@@ -26,6 +26,21 @@ namespace pgh {
 // tables whose probability equals the observed one up to rounding count as ties
 constexpr double kHweTieEps = 9.313225746154785e-10; // 2^-30
 
+// num / den inside the walks below.  On the host the IEEE quotient; on the device v_rcp_f64 refined by two Newton
+// steps and one multiply (~7 instructions instead of the ~25 of a correctly rounded FP64 division, which was most
+// of k_hwe_batch): the quotient can differ from the IEEE one in its last bit, the walk's sums by ~1e-13 relative
+// after its few thousand steps -- four orders below the tie band (2^-30) and the tests' 1e-12.
+PGH_HD inline double HweRatio(double num, double den) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	double x = __builtin_amdgcn_rcp(den);
+	x = fma(fma(-den, x, 1.0), x, x);
+	x = fma(fma(-den, x, 1.0), x, x);
+	return num * x;
+#else
+	return num / den;
+#endif
+}
+
 // P(k+2 hets) / P(k hets) for rare-allele count `rare`, common-allele count `common`
 PGH_HD inline double HweStepUp(int64_t rare, int64_t common, int64_t k) {
 	return 4.0 * static_cast<double>((rare - k) >> 1) * static_cast<double>((common - k) >> 1) /
@@ -70,7 +85,7 @@ PGH_HD inline double HweLnP(int32_t obs_hets, int32_t obs_hom1, int32_t obs_hom2
 	if (obs_hets > mode) {
 		double k = kd0, hr = hr0, hc = hc0;
 		for (int64_t it = (obs_hets - mode) >> 1; it > 0 && p_obs > 0.0; it--) {
-			p_obs *= 4.0 * hr * hc / ((k + 2.0) * (k + 1.0));
+			p_obs *= HweRatio(4.0 * hr * hc, (k + 2.0) * (k + 1.0));
 			k += 2.0;
 			hr -= 1.0;
 			hc -= 1.0;
@@ -78,7 +93,7 @@ PGH_HD inline double HweLnP(int32_t obs_hets, int32_t obs_hom1, int32_t obs_hom2
 	} else {
 		double k = kd0, hr = hr0, hc = hc0;
 		for (int64_t it = (mode - obs_hets) >> 1; it > 0 && p_obs > 0.0; it--) {
-			p_obs *= k * (k - 1.0) / (4.0 * (hr + 1.0) * (hc + 1.0));
+			p_obs *= HweRatio(k * (k - 1.0), 4.0 * (hr + 1.0) * (hc + 1.0));
 			k -= 2.0;
 			hr += 1.0;
 			hc += 1.0;
@@ -100,7 +115,7 @@ PGH_HD inline double HweLnP(int32_t obs_hets, int32_t obs_hom1, int32_t obs_hom2
 	{
 		double p = 1.0, k = kd0, hr = hr0, hc = hc0;
 		for (int64_t it = (rare - mode) >> 1; it > 0; it--) {
-			p *= 4.0 * hr * hc / ((k + 2.0) * (k + 1.0));
+			p *= HweRatio(4.0 * hr * hc, (k + 2.0) * (k + 1.0));
 			k += 2.0;
 			hr -= 1.0;
 			hc -= 1.0;
@@ -119,7 +134,7 @@ PGH_HD inline double HweLnP(int32_t obs_hets, int32_t obs_hom1, int32_t obs_hom2
 	{
 		double p = 1.0, k = kd0, hr = hr0, hc = hc0;
 		for (int64_t it = mode >> 1; it > 0; it--) {
-			p *= k * (k - 1.0) / (4.0 * (hr + 1.0) * (hc + 1.0));
+			p *= HweRatio(k * (k - 1.0), 4.0 * (hr + 1.0) * (hc + 1.0));
 			k -= 2.0;
 			hr += 1.0;
 			hc += 1.0;

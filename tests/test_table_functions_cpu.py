@@ -342,3 +342,47 @@ def test_null_list_params_test_mirror():
     assert "variants must not be NULL" in err("read_pfile", PFX, variants=None)
     assert len(F.query("read_pfile", PFX, include_genotypes=None, columns=["ID"])) == 4
     assert "weights must not be NULL" in err("plink_score", EX, weights=None)
+
+
+def test_pvar_and_bim_text_forms(tmp_path):
+    """The single-pass .pvar/.bim parser (csrc/shell/plink_common.cpp, replacing src/plink_common.cpp:171-375):
+    CRLF line ends, a last line without a newline, extra and reordered columns, '.' for ID and ALT, blank runs in a
+    .bim, empty lines, a POS with leading zeros longer than the small buffer -- metadata only, no device."""
+    pv = tmp_path / "a.pvar"
+    pv.write_bytes(b"##fileformat=x\r\n##more\r\n#CHROM\tID\tPOS\tALT\tREF\tQUAL\tINFO\r\n"
+                   b"1\trs1\t10000\tG\tA\t.\tx=1\r\n"
+                   b"\r\n"
+                   b"1\t.\t" + b"0" * 40 + b"20000\t.\tC\t9\ty\r\n"
+                   b"1\trs3\t30000\tA,T\tG\t.\t.\r\n"
+                   b"2\trs4\t15000\tC\tT\t.\t.")
+    r = F.query("plink_freq", EX, pvar=str(pv), columns=["CHROM", "POS", "ID", "REF", "ALT"])
+    assert r.sorted("CHROM", "POS") == [("1", 10000, "rs1", "A", "G"), ("1", 20000, None, "C", None),
+                                        ("1", 30000, "rs3", "G", "A,T"), ("2", 15000, "rs4", "T", "C")]
+    bim = tmp_path / "a.bim"
+    bim.write_text("1  rs1\t0   10000 G A\n1\trs2 0 20000\tT  C\n1 rs3 0 30000 A G\n2 . 0 15000 . T\n")
+    r = F.query("plink_freq", EX, pvar=str(bim), columns=["CHROM", "POS", "ID", "REF", "ALT"])
+    assert r.sorted("CHROM", "POS") == [("1", 10000, "rs1", "A", "G"), ("1", 20000, "rs2", "C", "T"),
+                                        ("1", 30000, "rs3", "G", "A"), ("2", 15000, None, "T", None)]
+    assert sorted(F.query("plink_freq", EX, pvar=str(bim), columns=["ID"], region="1:15000-30000").column("ID")) == [
+        "rs2", "rs3"]
+
+
+def test_pvar_parse_errors(tmp_path):
+    """The reference's messages for malformed variant metadata, with the line numbers of the FILE (comment, header
+    and empty lines counted)."""
+    def pvar(text):
+        p = tmp_path / "bad.pvar"
+        p.write_text(text)
+        return str(p)
+
+    head = "##c\n#CHROM\tPOS\tID\tREF\tALT\n"
+    assert "is empty" in err("plink_freq", EX, pvar=pvar(""))
+    assert "contains no header or data" in err("plink_freq", EX, pvar=pvar("##only\n\n##comments\n"))
+    assert "missing required columns" in err("plink_freq", EX, pvar=pvar("#CHROM\tPOS\tID\tREF\n1\t1\ta\tA\n"))
+    msg = err("plink_freq", EX, pvar=pvar(head + "1\t10\ta\tA\tG\n\n1\t12x\tb\tA\tG\n"))
+    assert "invalid POS value '12x' at line 5" in msg
+    assert "invalid POS value '' at line 3" in err("plink_freq", EX, pvar=pvar(head + "1\t\ta\tA\tG\n"))
+    assert "invalid POS value" in err("plink_freq", EX, pvar=pvar(head + "1\t99999999999999999999\ta\tA\tG\n"))
+    assert "missing required fields (line 4)" in err("plink_freq", EX, pvar=pvar(head + "1\t10\ta\tA\tG\n1\t20\tb\tA\n"))
+    assert "missing required fields (line 1)" in err("plink_freq", EX, pvar=pvar("1 rs1 0 10000 G\n"))
+    assert "non-contiguous" in err("plink_freq", EX, pvar=pvar(head + "1\t1\ta\tA\tG\n2\t1\tb\tA\tG\n1\t2\tc\tA\tG\n2\t2\td\tA\tG\n"))
