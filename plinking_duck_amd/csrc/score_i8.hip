@@ -22,7 +22,7 @@
 // config 4) take eight tiles.  Rounding happens once, where a coefficient is cut to 54 bits; the sums
 // themselves are exact, i.e. closer to the real-number result than a double accumulation in any order.
 //
-// Kernel shape (k_score_i8<NT, TS>): a workgroup of four waves owns 64*TS samples and walks a slice of
+// Kernel shape (k_score_i8<NT, TS>): a workgroup of four waves (eight with TS = 4) owns 16*TS samples per wave and walks a slice of
 // the scored variants 64 at a time.  All lanes fetch the tile's packed bytes with 16-byte loads (whole
 // 16*TS-byte row segments), park them in LDS, and each lane reads back the 16 variants of its matrix k-group
 // for one 4-byte word of samples.  Four 4x4 transposes on 2-bit fields (16 bitfield ops) turn four such words
@@ -223,18 +223,24 @@ __global__ __launch_bounds__(256) void k_i8_digits(uint32_t n_var, uint32_t n_co
 // the contraction
 // ---------------------------------------------------------------------------
 
-// NT 16-column digit tiles; TS samples per lane (16, 8 or 4): accumulators = TS * NT * 4 registers
+// NT 16-column digit tiles; TS samples per lane (16, 8 or 4): accumulators = TS * NT * 4 registers.  A workgroup is
+// kWaves waves, each owning 16 TS samples, i.e. a stripe of 4 TS kWaves bytes of every row.  Eight waves (one
+// workgroup per CU instead of two of four) where TS = 4: the stripe is then 128 bytes -- a whole cache line per row
+// and DMA lane group instead of half of one -- and a tile's digit bytes are fetched once per 512 samples instead of
+// once per 256 (the same 8 columns with 64-byte stripes instead of 128-byte ones: 49.1 vs 41.7 ms).
 template <int NT, int TS>
 struct I8Shape {
-	static constexpr uint32_t kRowBytes = 16u * TS;            // bytes of one row that a workgroup owns (4 waves)
-	static constexpr uint32_t kChunksPerRow = TS;              // 16-byte chunks
-	static constexpr uint32_t kChunksPerThread = TS / 4;       // 64 rows * TS chunks / 256 threads
-	static constexpr uint32_t kWordsPerRow = 4u * TS;
+	static constexpr uint32_t kWaves = TS == 4 ? 8u : 4u;
+	static constexpr uint32_t kThreads = 64u * kWaves;
+	static constexpr uint32_t kRowBytes = 4u * TS * kWaves;    // bytes of one row that a workgroup owns
+	static constexpr uint32_t kChunksPerRow = kRowBytes / 16u; // 16-byte chunks
+	static constexpr uint32_t kChunksPerThread = TS / 4;       // 64 rows * kChunksPerRow chunks / kThreads
+	static constexpr uint32_t kWordsPerRow = kRowBytes / 4u;
 	static constexpr uint32_t kSwizzleChunks = kWordsPerRow >= 32 ? 4u : kWordsPerRow / 8u; // XOR for odd k-groups
 	static constexpr uint32_t kGenoBytes = kTileVariants * kRowBytes;
 	static constexpr uint32_t kBBytes = 2u * NT * 1024u;
 	static constexpr uint32_t kBChunks = kBBytes / 16u; // 128 NT
-	static constexpr uint32_t kSamplesPerGroup = 64u * TS;
+	static constexpr uint32_t kSamplesPerGroup = 16u * TS * kWaves;
 };
 
 // LDS-DMA (global_load_lds_*): 64 lanes x 16 (4) bytes from per-lane global addresses to consecutive LDS bytes
@@ -266,11 +272,13 @@ __device__ __forceinline__ uint32_t LdsAddress(const void *p) {
 	return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) void *)p));
 }
 
-// LDS slots per workgroup: the tile being multiplied + the ones on their way from HBM.  Four where two workgroups
-// of that size still fit a CU's 160 KB, else three (the many-column shapes are matrix-bound: a trip is long).
+// LDS slots per workgroup: the tile being multiplied + the ones on their way from HBM.  Four where the workgroups
+// of a CU (two of four waves, or one of eight) still fit its 160 KB, else three (the many-column shapes are
+// matrix-bound: a trip is long).
 template <int NT, int TS>
 constexpr uint32_t RingSlots() {
-	return 4u * (64u * 16u * TS + 2048u * NT) + 4096u <= 80u * 1024u ? 4u : 3u;
+	using S = I8Shape<NT, TS>;
+	return 4u * (S::kGenoBytes + S::kBBytes) + 4096u <= (S::kWaves == 8 ? 160u : 80u) * 1024u ? 4u : 3u;
 }
 
 // PLANES: 3 = code plane and missing plane (plink_score, plink_pca's X^T Y); 1 / 2 = one of them alone (the two
@@ -280,7 +288,7 @@ constexpr uint32_t RingSlots() {
 // building out of the loop, -DPGH_I8_NO_DMA / _NO_DMA_G / _NO_DMA_B the LDS-DMA (all of it / the genotype piece /
 // the digit pieces) after the first tiles.  Results are then wrong; only the launch time is read.
 template <int NT, int TS, int PLANES>
-__global__ __launch_bounds__(256) void k_score_i8(const uint8_t *__restrict__ rows, uint64_t pitch, uint32_t sample_ct,
+__global__ __launch_bounds__((I8Shape<NT, TS>::kThreads)) void k_score_i8(const uint8_t *__restrict__ rows, uint64_t pitch, uint32_t sample_ct,
                                                   const uint32_t *__restrict__ rowidx, uint32_t n_tiles,
                                                   uint32_t tiles_per_slice, const int8_t *__restrict__ bmat,
                                                   const double *__restrict__ mult,
@@ -305,14 +313,14 @@ __global__ __launch_bounds__(256) void k_score_i8(const uint8_t *__restrict__ ro
 	// from HBM twice (PMC: 271 GB per launch over 125 GB of rows).  Inside every run of 16 ids, ids i and i + 8 --
 	// the same XCD, dispatched together -- therefore take the stripes 2 (i % 8) and 2 (i % 8) + 1.
 	uint32_t group = blockIdx.x;
-	if (TS == 4 && (group | 15u) < gridDim.x) {
+	if (S::kRowBytes == 64u && (group | 15u) < gridDim.x) {
 		group = (group & ~15u) + ((group & 7u) << 1) + ((group >> 3) & 1u);
 	}
 	const uint64_t group_byte = static_cast<uint64_t>(group) * S::kRowBytes; // first byte of this workgroup's stripe
 
 	// ---- staging: HBM -> LDS without a register stop (global_load_lds_dwordx4) ----
 	// One such instruction writes 64 x 16 B to consecutive LDS bytes (lane l at base + 16 l), so the slot's image
-	// is filled piece by piece in linear order: piece p = 4 n + wave (n < TS / 4) holds chunks 64 p .. 64 p + 63
+	// is filled piece by piece in linear order: piece p = kWaves n + wave (n < TS / 4) holds chunks 64 p .. 64 p + 63
 	// of the tile, chunk c = row c / TS, position c % TS.  Position q of a row of an odd k-group holds the row's
 	// chunk q ^ swizzle (the lanes that read k-groups 0/1 resp. 2/3 together then hit different banks); the
 	// swizzle is applied to the SOURCE address here and to the read address below.
@@ -324,7 +332,7 @@ __global__ __launch_bounds__(256) void k_score_i8(const uint8_t *__restrict__ ro
 	// digit bytes: 1 KiB pieces, NT per plane; only the planes this instantiation multiplies are fetched
 	constexpr uint32_t kBFirstPiece = (PLANES & 1) ? 0u : NT;
 	constexpr uint32_t kBPieceCount = PLANES == 3 ? 2u * NT : NT;
-	constexpr uint32_t kBPieces = (kBPieceCount + 3u) / 4u; // per wave and tile
+	constexpr uint32_t kBPieces = (kBPieceCount + S::kWaves - 1u) / S::kWaves; // per wave and tile
 #if defined(PGH_I8_NO_DMA_B)
 	constexpr uint32_t kPieces = kGenoPieces + 1u;
 #elif defined(PGH_I8_NO_DMA_G)
@@ -341,7 +349,7 @@ __global__ __launch_bounds__(256) void k_score_i8(const uint8_t *__restrict__ ro
 	uint64_t st_col[kGenoPieces]; // byte offset inside a row of the chunk this lane fetches for piece n
 #pragma unroll
 	for (uint32_t n = 0; n < kGenoPieces; n++) {
-		const uint32_t row = ((4u * n + wave) * 64u + lane) / S::kChunksPerRow;
+		const uint32_t row = ((S::kWaves * n + wave) * 64u + lane) / S::kChunksPerRow;
 		const uint32_t logical = st_pos ^ (((row >> 4) & 1u) * S::kSwizzleChunks);
 		const uint64_t want = group_byte + 16ull * logical;
 		st_row[n] = row;
@@ -379,7 +387,7 @@ __global__ __launch_bounds__(256) void k_score_i8(const uint8_t *__restrict__ ro
 		for (uint32_t n = 0; n < kBPieces; n++) {
 			// every wave issues every piece (the vmcnt arithmetic wants equal counts): pieces past the digit bytes
 			// repeat the last one
-			const uint32_t p = kBFirstPiece + min(4u * n + wave_u, kBPieceCount - 1u);
+			const uint32_t p = kBFirstPiece + min(S::kWaves * n + wave_u, kBPieceCount - 1u);
 			Glds16(bsrc + 1024ull * p + 16u * lane, base + S::kGenoBytes + p * 1024u);
 		}
 #else
@@ -390,7 +398,7 @@ __global__ __launch_bounds__(256) void k_score_i8(const uint8_t *__restrict__ ro
 #pragma unroll
 		for (uint32_t n = 0; n < kGenoPieces; n++) {
 			const uint8_t *src = rows + static_cast<uint64_t>(r[n]) * pitch + st_col[n];
-			Glds16Stream(src, base + (4u * n + wave_u) * 1024u);
+			Glds16Stream(src, base + (S::kWaves * n + wave_u) * 1024u);
 		}
 #endif
 	};
@@ -714,7 +722,7 @@ static hipError_t LaunchI8(const RowView &view, uint32_t n_tiles, uint32_t n_col
 	// enough workgroups to fill the chip several times over (every slice ends in one atomic add per sample and
 	// digit column, so no more than that); a slice keeps the int32 sums far from overflow (operand bytes reach
 	// 96, digits 128) and its digit bytes inside one XCD's L2
-	uint32_t want = (4096u + groups - 1) / groups;
+	uint32_t want = (4096u * 4u / S::kWaves + groups - 1) / groups; // (the same number of waves either way)
 	uint32_t tps = (n_tiles + want - 1) / want;
 	// 1,024 .. 128,000 variants per slice: |int32 sum| <= 16,384 per variant (operand bytes reach 96 + 32, digits
 	// 128) stays below 2^31.  Long slices win: every slice costs a ring fill and one atomic add per sample and
@@ -734,7 +742,7 @@ static hipError_t LaunchI8(const RowView &view, uint32_t n_tiles, uint32_t n_col
 	if (slices > 65535u) {
 		return hipErrorInvalidValue;
 	}
-	hipLaunchKernelGGL((k_score_i8<NT, TS, PLANES>), dim3(groups, slices), dim3(256), 0, stream, view.rows, view.pitch,
+	hipLaunchKernelGGL((k_score_i8<NT, TS, PLANES>), dim3(groups, slices), dim3(S::kThreads), 0, stream, view.rows, view.pitch,
 	                   view.sample_ct, b.rowidx, n_tiles, tps, b.bmat, b.mult, b.target, n_cols, score, out_stride,
 	                   dosage_sum, missing_ct);
 	return hipGetLastError();
