@@ -28,6 +28,8 @@ run_bench unpack --workload unpack --steps 5 --warmup 1 --cpu-seconds 0
 run_bench score --workload score --steps 3 --warmup 1 --cpu-seconds 0
 run_bench score1 --workload score --score-cols 1 --steps 3 --warmup 1 --cpu-seconds 0
 run_bench score2 --workload score --score-cols 2 --steps 3 --warmup 1 --cpu-seconds 0
+run_bench score4 --workload score --score-cols 4 --steps 3 --warmup 1 --cpu-seconds 0
+run_bench score8 --workload score --score-cols 8 --steps 3 --warmup 1 --cpu-seconds 0
 run_bench pca --workload pca --variants 100000 --steps 2 --warmup 1 --cpu-seconds 0
 run_bench ld --workload ld --variants 20000 --steps 3 --warmup 1 --cpu-seconds 0
 run_bench samplecounts --workload samplecounts --steps 3 --warmup 1 --cpu-seconds 0
@@ -43,11 +45,17 @@ stats score --workload score --steps 3 --warmup 1
 stats score1 --workload score --score-cols 1 --steps 3 --warmup 1
 stats pca --workload pca --variants 100000 --steps 1 --warmup 0
 stats dosagescore --workload dosagescore --steps 2 --warmup 1
+stats dosagefreq --workload dosagefreq --steps 3 --warmup 1
+stats ld --workload ld --variants 20000 --steps 3 --warmup 1
+stats samplecounts --workload samplecounts --steps 3 --warmup 1
+stats missingsample --workload missingsample --steps 3 --warmup 1
 for c in FETCH_SIZE WRITE_SIZE; do
 	pmc freq $c $c --steps 3 --warmup 1
 	pmc fused $c $c --workload fused --steps 3 --warmup 1
 	pmc unpack $c $c --workload unpack --steps 2 --warmup 1
 	pmc score1 $c $c --workload score --score-cols 1 --steps 2 --warmup 1
+	pmc score $c $c --workload score --steps 2 --warmup 1
+	pmc dosagescore $c $c --workload dosagescore --steps 2 --warmup 1
 done
 # matrix-core utilisation of the int8 contraction (north star: MFMA-utilisation counters against chip peak)
 MF="SQ_INSTS_VALU_MFMA_I8 SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE"

@@ -14,7 +14,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "profiles")
 DST = os.path.join(ROOT, "profiles")
 
-DOMINANT = {"freq": "k_counts_block", "fused": "k_fused_tally", "unpack": "k_unpack_wide", "score1": "k_score_i8"}
+# the kernels whose HBM traffic a workload's roofline line is about (a tuple: their per-launch means are added)
+DOMINANT = {"freq": ("k_counts_block",), "fused": ("k_fused_tally",), "unpack": ("k_unpack_wide",),
+            "score1": ("k_score_i8",), "score": ("k_score_i8",),
+            "dosagescore": ("k_score_i8", "k_score_dosage_records")}
 
 
 def short(name):
@@ -38,7 +41,7 @@ def main():
     ap.add_argument("src", nargs="?", default=None)
     args = ap.parse_args()
     tag = f"r{args.round:02d}"
-    for name in ("freq", "fused", "unpack", "score", "score1", "score2", "pca", "ld", "samplecounts", "missingsample", "dosagefreq", "dosagescore", "dosagefull", "dosagegaps"):
+    for name in ("freq", "fused", "unpack", "score", "score1", "score2", "score4", "score8", "pca", "ld", "samplecounts", "missingsample", "dosagefreq", "dosagescore", "dosagefull", "dosagegaps"):
         src = os.path.join(SRC, f"bench_{name}.json")
         if os.path.exists(src):
             line = [ln for ln in open(src).read().splitlines() if ln.startswith("{")][-1]
@@ -56,7 +59,7 @@ def main():
                    "over the dominant kernel's dispatches. Per-counter means: profiles/rNN_*_pmc_*.csv "
                    "(tools/summarise_profiles.py).",
     }
-    for name, kernel in DOMINANT.items():
+    for name, kernels in DOMINANT.items():
         raw = {}
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             src = os.path.join(SRC, f"{name}_pmc_{ctr}.csv")
@@ -67,19 +70,22 @@ def main():
                 f.write("kernel,counter,dispatches,mean_value,unit\n")
                 for (k, c), (n, total) in means.items():
                     f.write(f"\"{k}\",{c},{n},{total / n:.3f},KiB\n")
-                    if k.startswith(kernel):
-                        raw[ctr] = (n, total / n)
+                    if any(k.startswith(kernel) for kernel in kernels):
+                        seen = raw.get(ctr, (n, 0.0))
+                        raw[ctr] = (seen[0], seen[1] + total / n)
         if len(raw) == 2:
             bench = json.loads(open(os.path.join(DST, f"{tag}_bench_{name}_n1.json")).read())
             traffic[name] = {
-                "kernel": kernel,
+                "kernel": " + ".join(kernels),
                 "variants": bench["config"]["variants_per_rank"],
                 "samples": bench["config"]["samples"],
                 "fetch_size_kib_raw": raw["FETCH_SIZE"][1],
                 "write_size_kib_raw": raw["WRITE_SIZE"][1],
                 "dispatches": raw["FETCH_SIZE"][0],
                 "hbm_bytes_per_launch": (2 * raw["FETCH_SIZE"][1] + raw["WRITE_SIZE"][1]) * 1024,
-                "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
+                "algorithmic_bytes_per_launch": bench["roofline"].get(
+                    "algorithmic_bytes_per_launch",
+                    bench["config"]["variants_per_rank"] * bench["config"]["record_bytes"]),  # (a matrix-bound line: the rows)
             }
     # matrix-core counters of the int8 contraction
     for name in ("score", "score1", "pca"):
