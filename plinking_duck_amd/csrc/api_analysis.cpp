@@ -40,12 +40,12 @@ extern "C" int pgh_counts_range(const pgh_dataset *ds, const pgh_subset *subset,
 	PGH_ENTER(ds);
 	DevBuf buf;
 	PGH_HIP(buf.Alloc(n * 16), "hipMalloc(counts)");
-	rc = pgh_counts_range_dev(ds, subset, v_begin, v_end, buf.p, hipStreamPerThread, errbuf);
+	rc = pgh_counts_range_dev(ds, subset, v_begin, v_end, buf.p, PghThreadStream(), errbuf);
 	if (rc != PGH_OK) {
 		return rc;
 	}
-	PGH_HIP(hipMemcpyAsync(out, buf.p, n * 16, hipMemcpyDeviceToHost, hipStreamPerThread), "counts copy");
-	PGH_HIP(hipStreamSynchronize(hipStreamPerThread), "counts sync");
+	PGH_HIP(hipMemcpyAsync(out, buf.p, n * 16, hipMemcpyDeviceToHost, PghThreadStream()), "counts copy");
+	PGH_HIP(hipStreamSynchronize(PghThreadStream()), "counts sync");
 	return PGH_OK;
 }
 
@@ -73,10 +73,9 @@ extern "C" int pgh_missing_per_sample_dev(const pgh_dataset *ds, uint32_t v_begi
 	// per-slice partial rows: a few MB, stream-ordered so the call stays enqueue-only
 	const size_t scratch_bytes = pgh::MissingPerSampleScratchBytes(ds->record_bytes, v_end - v_begin);
 	void *scratch = nullptr;
-	PGH_HIP(hipMallocAsync(&scratch, scratch_bytes ? scratch_bytes : 16, st), "missing scratch");
+	PGH_HIP(PghThreadScratch(scratch_bytes, st, &scratch), "missing scratch");
 	hipError_t e = pgh::LaunchMissingPerSample(ds->View(), v_begin - ds->v_begin, nullptr, v_end - v_begin, nullptr,
 	                                           static_cast<uint32_t *>(scratch), static_cast<uint32_t *>(d_out), st);
-	(void)hipFreeAsync(scratch, st);
 	PGH_HIP(e, "missing-per-sample kernel");
 	return PGH_OK;
 }
@@ -96,11 +95,10 @@ extern "C" int pgh_fused_tally_dev(const pgh_dataset *ds, uint32_t v_begin, uint
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	const size_t scratch_bytes = pgh::MissingPerSampleScratchBytes(ds->record_bytes, v_end - v_begin);
 	void *scratch = nullptr;
-	PGH_HIP(hipMallocAsync(&scratch, scratch_bytes ? scratch_bytes : 16, st), "fused scratch");
+	PGH_HIP(PghThreadScratch(scratch_bytes, st, &scratch), "fused scratch");
 	hipError_t e = pgh::LaunchFusedTally(ds->View(), v_begin - ds->v_begin, v_end - v_begin,
 	                                     static_cast<uint32_t *>(scratch), static_cast<uint32_t *>(d_counts),
 	                                     static_cast<uint32_t *>(d_missing), st);
-	(void)hipFreeAsync(scratch, st);
 	PGH_HIP(e, "fused tally kernel");
 	return PGH_OK;
 }
@@ -122,14 +120,14 @@ extern "C" int pgh_missing_per_sample(const pgh_dataset *ds, const pgh_subset *s
 	const uint32_t padded = (N + 63) / 64 * 64;
 	DevBuf buf;
 	PGH_HIP(buf.Alloc(sizeof(uint32_t) * padded), "hipMalloc(missing)");
-	rc = pgh_missing_per_sample_dev(ds, v_begin, v_end, buf.p, hipStreamPerThread, errbuf);
+	hipStream_t st = PghThreadStream();
+	rc = pgh_missing_per_sample_dev(ds, v_begin, v_end, buf.p, st, errbuf);
 	if (rc != PGH_OK) {
 		return rc;
 	}
 	std::vector<uint32_t> raw(N);
-	PGH_HIP(hipMemcpyAsync(raw.data(), buf.p, sizeof(uint32_t) * N, hipMemcpyDeviceToHost, hipStreamPerThread),
-	        "missing copy");
-	PGH_HIP(hipStreamSynchronize(hipStreamPerThread), "missing sync");
+	PGH_HIP(hipMemcpyAsync(raw.data(), buf.p, sizeof(uint32_t) * N, hipMemcpyDeviceToHost, st), "missing copy");
+	PGH_HIP(hipStreamSynchronize(st), "missing sync");
 	Compact<uint32_t>(subset, raw.data(), 1, out, N);
 	return PGH_OK;
 }
@@ -150,10 +148,9 @@ extern "C" int pgh_sample_counts_dev(const pgh_dataset *ds, uint32_t v_begin, ui
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	const size_t scratch_bytes = pgh::ClassCounts3ScratchBytes(ds->record_bytes);
 	void *scratch = nullptr;
-	PGH_HIP(hipMallocAsync(&scratch, scratch_bytes, st), "sample counts scratch");
+	PGH_HIP(PghThreadScratch(scratch_bytes, st, &scratch), "sample counts scratch");
 	hipError_t e = pgh::LaunchClassCounts3(ds->View(), v_begin - ds->v_begin, nullptr, v_end - v_begin,
 	                                       static_cast<uint8_t *>(scratch), static_cast<uint32_t *>(d_classes), padded, st);
-	(void)hipFreeAsync(scratch, st);
 	PGH_HIP(e, "sample counts kernel");
 	return PGH_OK;
 }
@@ -191,7 +188,7 @@ extern "C" int pgh_sample_counts(const pgh_dataset *ds, const pgh_subset *subset
 	const uint32_t N = ds->sample_ct;
 	const uint32_t n_out = subset ? subset->n_out : N;
 	const uint32_t padded = (N + 63) / 64 * 64;
-	hipStream_t st = hipStreamPerThread;
+	hipStream_t st = PghThreadStream();
 	DevBuf d_cls, d_list, d_scratch;
 	HostSourceFence fence(st); // `local` feeds an asynchronous upload
 	PGH_HIP(d_cls.Alloc(sizeof(uint32_t) * 3ull * padded), "hipMalloc(sample counts)");
@@ -286,21 +283,21 @@ extern "C" int pgh_unpack_range(const pgh_dataset *ds, const pgh_subset *subset,
 	for (size_t r0 = 0; r0 < rows; r0 += chunk_rows) {
 		const size_t r1 = std::min(rows, r0 + chunk_rows);
 		rc = pgh_unpack_range_dev(ds, subset, v_begin + static_cast<uint32_t>(r0), v_begin + static_cast<uint32_t>(r1),
-		                          d_out.p, out_pitch, d_val.p, missing_code, hipStreamPerThread, errbuf);
+		                          d_out.p, out_pitch, d_val.p, missing_code, PghThreadStream(), errbuf);
 		if (rc != PGH_OK) {
 			return rc;
 		}
 		if (out) {
 			PGH_HIP(hipMemcpy2DAsync(out + r0 * n_out, n_out, d_out.p, out_pitch, n_out, r1 - r0,
-			                         hipMemcpyDeviceToHost, hipStreamPerThread),
+			                         hipMemcpyDeviceToHost, PghThreadStream()),
 			        "unpack copy");
 		}
 		if (validity) {
 			PGH_HIP(hipMemcpyAsync(validity + r0 * val_words, d_val.p, (r1 - r0) * val_words * 8,
-			                       hipMemcpyDeviceToHost, hipStreamPerThread),
+			                       hipMemcpyDeviceToHost, PghThreadStream()),
 			        "validity copy");
 		}
-		PGH_HIP(hipStreamSynchronize(hipStreamPerThread), "unpack sync");
+		PGH_HIP(hipStreamSynchronize(PghThreadStream()), "unpack sync");
 	}
 	return PGH_OK;
 }
@@ -365,7 +362,7 @@ extern "C" int pgh_dosage_sums(const pgh_dataset *ds, const pgh_subset *subset, 
 	if (rc != PGH_OK || n_variants == 0) {
 		return rc;
 	}
-	hipStream_t st = hipStreamPerThread;
+	hipStream_t st = PghThreadStream();
 	DevBuf d_list, d_sums;
 	std::vector<uint32_t> local;
 	HostSourceFence fence(st); // `local` feeds an asynchronous upload
@@ -420,7 +417,7 @@ extern "C" int pgh_dosage_unpack(const pgh_dataset *ds, const pgh_subset *subset
 	if (rc != PGH_OK || n_variants == 0 || n_out == 0) {
 		return rc;
 	}
-	hipStream_t st = hipStreamPerThread;
+	hipStream_t st = PghThreadStream();
 	DevBuf d_list, d_out;
 	std::vector<uint32_t> local;
 	HostSourceFence fence(st); // `local` feeds an asynchronous upload
@@ -459,7 +456,7 @@ static int UnpackSamples(const pgh_dataset *ds, const pgh_subset *subset, uint32
 	if (rc != PGH_OK || n_variants == 0 || n_out == 0) {
 		return rc;
 	}
-	hipStream_t st = hipStreamPerThread;
+	hipStream_t st = PghThreadStream();
 	DevBuf d_list, d_out;
 	std::vector<uint32_t> local;
 	HostSourceFence fence(st); // `local` feeds an asynchronous upload
@@ -699,7 +696,7 @@ extern "C" int pgh_score_plan_create(const pgh_dataset *ds, const pgh_subset *su
 	if (n_scored) {
 		const uint32_t N = ds->sample_ct;
 		const uint32_t n_dos = n_scored - n_hard;
-		hipStream_t st = hipStreamPerThread;
+		hipStream_t st = PghThreadStream();
 		HostSourceFence fence(st); // p_local / p_weights / p_flip feed asynchronous uploads
 		PGH_HIP(hipMalloc(&plan->d_vlist, sizeof(uint32_t) * n_scored), "hipMalloc(score)");
 		PGH_HIP(hipMalloc(&plan->d_weights, sizeof(double) * n_scored * n_cols), "hipMalloc(score)");
@@ -834,7 +831,7 @@ extern "C" int pgh_score_run_dev(const pgh_score_plan *plan, void *d_score_sum, 
 	hipError_t e = hipSuccess;
 	if (count_missing) {
 		const size_t miss_bytes = sizeof(uint32_t) * ((N + 63) / 64 * 64);
-		PGH_HIP(hipMallocAsync(&miss, miss_bytes, st), "score scratch");
+		PGH_HIP(PghThreadScratch(miss_bytes, st, &miss), "score scratch");
 		e = hipMemsetAsync(miss, 0, miss_bytes, st);
 	}
 	// (The explicit-entry kernel is bound by LDS atomics and the contraction by HBM and the matrix cores, but side
@@ -881,9 +878,6 @@ extern "C" int pgh_score_run_dev(const pgh_score_plan *plan, void *d_score_sum, 
 		e = pgh::LaunchAlleleCt(ac, plan->n_scored, static_cast<uint32_t *>(miss), N,
 		                        static_cast<uint32_t *>(d_allele_ct), st);
 	}
-	if (miss) {
-		(void)hipFreeAsync(miss, st);
-	}
 	PGH_HIP(e, "score kernels");
 	return PGH_OK;
 }
@@ -929,7 +923,7 @@ extern "C" int pgh_score(const pgh_dataset *ds, const pgh_subset *subset, uint32
 	}
 	PGH_HIP(d_ac.Alloc(sizeof(uint32_t) * N), "hipMalloc(score out)");
 	int rc = pgh_score_dev(ds, subset, n_scored, vidx, weights, flip, n_cols, mode, d_score.p, d_dos.p, d_ac.p,
-	                       hipStreamPerThread, errbuf);
+	                       PghThreadStream(), errbuf);
 	if (rc != PGH_OK) {
 		return rc;
 	}
@@ -1411,9 +1405,10 @@ extern "C" int pgh_ld_pairs_dev(const pgh_dataset *ds, const pgh_subset *subset,
 	// bytes before hipMemcpyAsync returns, so the dying vector was not the cause; but a pool block that an
 	// earlier owner zeroed with a still-queued hipMemsetAsync, freed stream-ordered and got handed out again was
 	// seen to keep the EARLIER zeros after the LATER pageable copy (once in three probe runs) -- exactly this
-	// call's shape after plink_score's `miss` block.  Rule since: pool blocks are written only by kernels and
-	// memsets of their stream; uploads go through pinned memory into plain allocations (here), or from pageable
-	// memory into plain allocations behind a HostSourceFence (api_internal.hpp).
+	// call's shape after plink_score's `miss` block.  Round 2 then lost KERNEL-written data in a block of the same
+	// pool (pgh_missing_per_sample's scratch, profiles/r02_async_pool_ab.txt): nothing here allocates
+	// stream-ordered any more (api_internal.hpp:PghThreadScratch); uploads go through pinned memory into plain
+	// allocations (here), or from pageable memory into plain allocations behind a HostSourceFence.
 	// The previous launch of this thread is checked first: it must have finished with the buffers anyway.
 	rc = LdCheckLast(errbuf);
 	if (rc != PGH_OK) {
@@ -1467,11 +1462,11 @@ extern "C" int pgh_ld_pairs(const pgh_dataset *ds, const pgh_subset *subset, uin
 	PGH_ENTER(ds);
 	DevBuf d_out;
 	PGH_HIP(d_out.Alloc(24ull * n_pairs), "hipMalloc(ld)");
-	int rc = pgh_ld_pairs_dev(ds, subset, n_pairs, vidx_a, vidx_b, d_out.p, hipStreamPerThread, errbuf);
+	int rc = pgh_ld_pairs_dev(ds, subset, n_pairs, vidx_a, vidx_b, d_out.p, PghThreadStream(), errbuf);
 	if (rc != PGH_OK) {
 		return rc;
 	}
-	PGH_HIP(hipMemcpyAsync(sums, d_out.p, 24ull * n_pairs, hipMemcpyDeviceToHost, hipStreamPerThread), "ld copy");
-	PGH_HIP(hipStreamSynchronize(hipStreamPerThread), "ld sync");
+	PGH_HIP(hipMemcpyAsync(sums, d_out.p, 24ull * n_pairs, hipMemcpyDeviceToHost, PghThreadStream()), "ld copy");
+	PGH_HIP(hipStreamSynchronize(PghThreadStream()), "ld sync");
 	return LdCheckLast(errbuf);
 }

@@ -3,6 +3,106 @@
 #include "api_internal.hpp"
 
 // ---------------------------------------------------------------------------
+// per-thread streams (api_internal.hpp:PghThreadStream)
+// ---------------------------------------------------------------------------
+
+namespace {
+struct ThreadScratchBlock {
+	int device;
+	hipStream_t stream;
+	void *p;
+	size_t bytes;
+};
+struct ThreadStreams {
+	std::vector<std::pair<int, hipStream_t>> by_device;
+	std::vector<ThreadScratchBlock> scratch;
+	~ThreadStreams() {
+		for (auto &b : scratch) {
+			DeviceScope scope(b.device);
+			(void)hipFree(b.p); // (waits for the device: nothing of this thread's is still running on it afterwards)
+		}
+		for (auto &e : by_device) {
+			DeviceScope scope(e.first);
+			(void)hipStreamSynchronize(e.second);
+			(void)hipStreamDestroy(e.second);
+		}
+	}
+};
+thread_local ThreadStreams t_streams;
+} // namespace
+
+hipError_t PghThreadScratch(size_t bytes, hipStream_t st, void **out) {
+	int device = 0;
+	hipError_t e = hipGetDevice(&device);
+	if (e != hipSuccess) {
+		return e;
+	}
+	if (bytes == 0) {
+		bytes = 16;
+	}
+	ThreadScratchBlock *slot = nullptr;
+	for (auto &b : t_streams.scratch) {
+		if (b.device == device && b.stream == st) {
+			slot = &b;
+			break;
+		}
+	}
+	if (slot && slot->bytes >= bytes) {
+		*out = slot->p;
+		return hipSuccess;
+	}
+	if (slot) {
+		e = hipStreamSynchronize(st); // the block may still be read by what this thread enqueued before
+		if (e != hipSuccess) {
+			return e;
+		}
+		(void)hipFree(slot->p);
+		slot->p = nullptr;
+		slot->bytes = 0;
+	}
+	void *p = nullptr;
+	e = hipMalloc(&p, bytes);
+	if (e != hipSuccess) {
+		return e;
+	}
+	if (slot) {
+		slot->p = p;
+		slot->bytes = bytes;
+	} else {
+		if (t_streams.scratch.size() >= 8) { // a thread that keeps changing streams: drop the oldest block
+			ThreadScratchBlock &old = t_streams.scratch.front();
+			DeviceScope scope(old.device);
+			(void)hipStreamSynchronize(old.stream);
+			(void)hipFree(old.p);
+			t_streams.scratch.erase(t_streams.scratch.begin());
+		}
+		t_streams.scratch.push_back(ThreadScratchBlock {device, st, p, bytes});
+	}
+	*out = p;
+	return hipSuccess;
+}
+
+hipStream_t PghThreadStream() {
+	int device = 0;
+	if (hipGetDevice(&device) != hipSuccess) {
+		(void)hipGetLastError();
+		return nullptr; // no device: the caller's next HIP call reports it
+	}
+	for (auto &e : t_streams.by_device) {
+		if (e.first == device) {
+			return e.second;
+		}
+	}
+	hipStream_t s = nullptr;
+	if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+		(void)hipGetLastError();
+		return nullptr; // the null stream still orders everything behind it
+	}
+	t_streams.by_device.emplace_back(device, s);
+	return s;
+}
+
+// ---------------------------------------------------------------------------
 // library / device
 // ---------------------------------------------------------------------------
 
@@ -325,10 +425,10 @@ static int AppendDosageTracksHost(pgh_dataset *ds, const pgh::RecordFile &file, 
 			}
 			filled += h_values[k].size();
 			PGH_HIP(pgh::LaunchDosageRank(ds->d_dos_present + static_cast<uint64_t>(row) * words, 1, words,
-			                              ds->d_dos_rank + static_cast<uint64_t>(row) * words, hipStreamPerThread),
+			                              ds->d_dos_rank + static_cast<uint64_t>(row) * words, PghThreadStream()),
 			        "dosage rank kernel");
 		}
-		PGH_HIP(hipStreamSynchronize(hipStreamPerThread), "dosage rank sync");
+		PGH_HIP(hipStreamSynchronize(PghThreadStream()), "dosage rank sync");
 	}
 	return PGH_OK;
 }
@@ -338,11 +438,11 @@ static int FetchDosageRowCounts(pgh_dataset *ds, char *errbuf) {
 	const uint32_t rows = ds->dos_rows, words = (ds->sample_ct + 63) / 64;
 	DevBuf d_tot;
 	PGH_HIP(d_tot.Alloc(8ull * rows), "hipMalloc(dosage totals)");
-	PGH_HIP(pgh::LaunchDosageRowTotals(ds->d_dos_present, ds->d_dos_rank, rows, words, d_tot.As<uint64_t>(), hipStreamPerThread),
+	PGH_HIP(pgh::LaunchDosageRowTotals(ds->d_dos_present, ds->d_dos_rank, rows, words, d_tot.As<uint64_t>(), PghThreadStream()),
 	        "dosage totals kernel");
 	std::vector<uint64_t> tot(rows);
-	PGH_HIP(hipMemcpyAsync(tot.data(), d_tot.p, 8ull * rows, hipMemcpyDeviceToHost, hipStreamPerThread), "dosage totals copy");
-	PGH_HIP(hipStreamSynchronize(hipStreamPerThread), "dosage totals sync");
+	PGH_HIP(hipMemcpyAsync(tot.data(), d_tot.p, 8ull * rows, hipMemcpyDeviceToHost, PghThreadStream()), "dosage totals copy");
+	PGH_HIP(hipStreamSynchronize(PghThreadStream()), "dosage totals sync");
 	ds->dos_row_count.assign(tot.begin(), tot.end());
 	return PGH_OK;
 }
@@ -919,7 +1019,7 @@ extern "C" int pgh_synth_add_dosage(pgh_dataset *ds, double rate, uint64_t seed,
 	if (rows == 0) {
 		return PGH_OK;
 	}
-	hipStream_t st = hipStreamPerThread;
+	hipStream_t st = PghThreadStream();
 	std::vector<uint64_t> off(rows + 1);
 	HostSourceFence fence(st); // `off` feeds an asynchronous upload (dos_row_of lives in the handle)
 	ds->dos_row_of.resize(rows);

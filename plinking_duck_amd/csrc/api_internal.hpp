@@ -191,6 +191,27 @@ void Close(pgh_dataset *g);
 pgh_reader *ReaderFor(pgh_reader *rd, uint32_t vidx);
 } // namespace pgh_group
 
+// The calling thread's own stream on the current device: what every host-output entry point enqueues on.
+// NOT hipStreamPerThread.  On this runtime (ROCm 7.2) the special handle did not stay ONE stream for a thread:
+// in the first call after other threads had come and gone (a DuckDB scan pool, pgh_open's readers), a memset,
+// two kernels and a copy all enqueued "on hipStreamPerThread" ran unordered -- pgh_missing_per_sample returned
+// sums 9 % short, once, and was right again on the next call (tests/test_table_functions_gpu.py caught it; with
+// a stream created by the library the same sequence never failed).  Streams are created on first use per
+// (thread, device) and destroyed when the thread ends.
+hipStream_t PghThreadStream();
+
+// Device scratch for an enqueue-only entry point: at least `bytes`, valid for the work the caller enqueues on `st`
+// right now.  One block per (calling thread, device, stream), kept and re-used (work on one stream is ordered, so the
+// next call's kernels cannot start before this call's are done with it), grown with hipMalloc when a call needs more
+// (after draining `st`), freed when the thread ends.
+// NOT hipMallocAsync / hipFreeAsync: with scratch from the stream-ordered pool pgh_missing_per_sample returned sums
+// 9 % short about once in thirty calls -- whole slices of the first kernel's output were gone when the second kernel
+// read them -- and 60 of 60 calls were right with hipMalloc'ed scratch and nothing else changed
+// (profiles/r02_async_pool_ab.txt).  Round 1's plink_ld task list that "arrived all zeros" sat in a block of the same
+// pool.
+hipError_t PghThreadScratch(size_t bytes, hipStream_t st, void **out);
+
+
 namespace {
 
 [[maybe_unused]] void SetErr(char *errbuf, const std::string &msg) {

@@ -402,14 +402,14 @@ extern "C" int pgh_hwe_lnp_batch(const uint32_t (*counts)[4], uint32_t n, uint32
 		return PGH_ERR_ARG;
 	}
 	DevBuf d_counts, d_lnp;
-	HostSourceFence fence(hipStreamPerThread); // the caller's `counts` / `ln_p` are in flight until the stream drains
+	HostSourceFence fence(PghThreadStream()); // the caller's `counts` / `ln_p` are in flight until the stream drains
 	PGH_HIP(d_counts.Alloc(16ull * n), "hipMalloc(hwe)");
 	PGH_HIP(d_lnp.Alloc(8ull * n), "hipMalloc(hwe)");
-	PGH_HIP(hipMemcpyAsync(d_counts.p, counts, 16ull * n, hipMemcpyHostToDevice, hipStreamPerThread), "hwe upload");
-	PGH_HIP(pgh::LaunchHweBatch(d_counts.As<uint32_t>(), n, midp, d_lnp.As<double>(), hipStreamPerThread),
+	PGH_HIP(hipMemcpyAsync(d_counts.p, counts, 16ull * n, hipMemcpyHostToDevice, PghThreadStream()), "hwe upload");
+	PGH_HIP(pgh::LaunchHweBatch(d_counts.As<uint32_t>(), n, midp, d_lnp.As<double>(), PghThreadStream()),
 	        "hwe kernel");
-	PGH_HIP(hipMemcpyAsync(ln_p, d_lnp.p, 8ull * n, hipMemcpyDeviceToHost, hipStreamPerThread), "hwe copy");
-	PGH_HIP(hipStreamSynchronize(hipStreamPerThread), "hwe sync");
+	PGH_HIP(hipMemcpyAsync(ln_p, d_lnp.p, 8ull * n, hipMemcpyDeviceToHost, PghThreadStream()), "hwe copy");
+	PGH_HIP(hipStreamSynchronize(PghThreadStream()), "hwe sync");
 	return PGH_OK;
 }
 
@@ -423,13 +423,13 @@ extern "C" int pgh_hwe_xchr_lnp_batch(const int32_t (*strata)[5], uint32_t n, ui
 		return PGH_ERR_ARG;
 	}
 	DevBuf d_strata, d_lnp;
-	HostSourceFence fence(hipStreamPerThread); // the caller's `strata` / `ln_p` are in flight until the stream drains
+	HostSourceFence fence(PghThreadStream()); // the caller's `strata` / `ln_p` are in flight until the stream drains
 	PGH_HIP(d_strata.Alloc(20ull * n), "hipMalloc(hwe)");
 	PGH_HIP(d_lnp.Alloc(8ull * n), "hipMalloc(hwe)");
-	PGH_HIP(hipMemcpyAsync(d_strata.p, strata, 20ull * n, hipMemcpyHostToDevice, hipStreamPerThread), "hwe upload");
-	PGH_HIP(pgh::LaunchHweXchrBatch(d_strata.As<int32_t>(), n, midp, d_lnp.As<double>(), hipStreamPerThread),
+	PGH_HIP(hipMemcpyAsync(d_strata.p, strata, 20ull * n, hipMemcpyHostToDevice, PghThreadStream()), "hwe upload");
+	PGH_HIP(pgh::LaunchHweXchrBatch(d_strata.As<int32_t>(), n, midp, d_lnp.As<double>(), PghThreadStream()),
 	        "chrX hwe kernel");
-	PGH_HIP(hipMemcpyAsync(ln_p, d_lnp.p, 8ull * n, hipMemcpyDeviceToHost, hipStreamPerThread), "hwe copy");
-	PGH_HIP(hipStreamSynchronize(hipStreamPerThread), "hwe sync");
+	PGH_HIP(hipMemcpyAsync(ln_p, d_lnp.p, 8ull * n, hipMemcpyDeviceToHost, PghThreadStream()), "hwe copy");
+	PGH_HIP(hipStreamSynchronize(PghThreadStream()), "hwe sync");
 	return PGH_OK;
 }

@@ -120,19 +120,19 @@ int SumToRoot(const Shards &shards, const std::vector<T *> &bufs, uint64_t count
 			continue;
 		}
 		PGH_HIP(stage[k].Alloc(bytes), "hipMalloc(shard partial)");
-		PGH_HIP(hipMemcpyPeerAsync(stage[k].p, root, bufs[k], shards[k]->device, bytes, hipStreamPerThread),
+		PGH_HIP(hipMemcpyPeerAsync(stage[k].p, root, bufs[k], shards[k]->device, bytes, PghThreadStream()),
 		        "device-to-device copy of a shard partial");
 		if (sizeof(T) == 8) {
 			PGH_HIP(pgh::LaunchAddF64(reinterpret_cast<double *>(bufs[0]), stage[k].template As<double>(), count,
-			                          hipStreamPerThread),
+			                          PghThreadStream()),
 			        "partial sum kernel");
 		} else {
 			PGH_HIP(pgh::LaunchAddU32(reinterpret_cast<uint32_t *>(bufs[0]), stage[k].template As<uint32_t>(), count,
-			                          hipStreamPerThread),
+			                          PghThreadStream()),
 			        "partial sum kernel");
 		}
 	}
-	PGH_HIP(hipStreamSynchronize(hipStreamPerThread), "partial sum sync");
+	PGH_HIP(hipStreamSynchronize(PghThreadStream()), "partial sum sync");
 	return PGH_OK;
 }
 
@@ -620,11 +620,11 @@ int Score(const pgh_dataset *g, const pgh_subset *ss, uint32_t n_scored, const u
 			}
 		}
 		int rck = pgh_score_dev(g->shards[k], PartOf(ss, k), n_k, cut.idx[k].data(), w_k.data(), flip ? f_k.data() : nullptr,
-		                        n_cols, mode, d_score[k].p, d_dos[k].p, d_ac[k].p, hipStreamPerThread, eb);
+		                        n_cols, mode, d_score[k].p, d_dos[k].p, d_ac[k].p, PghThreadStream(), eb);
 		if (rck != PGH_OK) {
 			return rck;
 		}
-		PGH_HIP(hipStreamSynchronize(hipStreamPerThread), "score sync");
+		PGH_HIP(hipStreamSynchronize(PghThreadStream()), "score sync");
 		p_score[k] = d_score[k].As<double>();
 		p_dos[k] = d_dos[k].As<double>();
 		p_ac[k] = d_ac[k].As<uint32_t>();
@@ -699,16 +699,16 @@ int AllReduceCallback(void *ctx, void *d_buf, uint64_t count, void *stream) {
 			ar->stage_bytes = e == hipSuccess ? bytes : 0;
 		}
 		for (size_t j = 1; j < shards.size() && e == hipSuccess; j++) {
-			e = hipMemcpyPeerAsync(ar->stage.p, root, ar->bufs[j], shards[j]->device, bytes, hipStreamPerThread);
+			e = hipMemcpyPeerAsync(ar->stage.p, root, ar->bufs[j], shards[j]->device, bytes, PghThreadStream());
 			if (e == hipSuccess) {
-				e = pgh::LaunchAddF64(static_cast<double *>(d_buf), ar->stage.As<double>(), count, hipStreamPerThread);
+				e = pgh::LaunchAddF64(static_cast<double *>(d_buf), ar->stage.As<double>(), count, PghThreadStream());
 			}
 		}
 		for (size_t j = 1; j < shards.size() && e == hipSuccess; j++) {
-			e = hipMemcpyPeerAsync(ar->bufs[j], shards[j]->device, d_buf, root, bytes, hipStreamPerThread);
+			e = hipMemcpyPeerAsync(ar->bufs[j], shards[j]->device, d_buf, root, bytes, PghThreadStream());
 		}
 		if (e == hipSuccess) {
-			e = hipStreamSynchronize(hipStreamPerThread);
+			e = hipStreamSynchronize(PghThreadStream());
 		}
 		if (e != hipSuccess) {
 			ar->failed = 1;

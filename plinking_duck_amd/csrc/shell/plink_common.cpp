@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cerrno>
+#include <condition_variable>
 #include <cstring>
 #include <cmath>
 #include <cstdlib>
@@ -1229,11 +1230,12 @@ struct CacheKey {
 };
 struct CacheEntry {
 	CacheKey key;
-	shared_ptr<DeviceDataset> ds;
+	shared_ptr<DeviceDataset> ds; // null while the first caller is still opening the file
 	uint64_t bytes;
 };
 std::mutex g_cache_mutex;
-vector<CacheEntry> g_cache; // most recently used last
+std::condition_variable g_cache_opened; // an entry finished opening (or gave up)
+vector<CacheEntry> g_cache;             // most recently used last
 
 uint64_t CacheBudgetBytes() {
 	const char *env = std::getenv("PLINKING_HBM_CACHE_GB");
@@ -1268,15 +1270,30 @@ shared_ptr<DeviceDataset> DeviceDataset::Acquire(const string &pgen_path, const 
 	const vector<int> devices = GetPlinkingDevices();
 	CacheKey key {pgen_path, static_cast<int64_t>(st.st_mtim.tv_sec) * 1000000000LL + st.st_mtim.tv_nsec,
 	              static_cast<int64_t>(st.st_size), devices};
-	std::lock_guard<std::mutex> lock(g_cache_mutex);
-	for (size_t i = 0; i < g_cache.size(); i++) {
-		if (g_cache[i].key == key) {
-			auto e = g_cache[i];
-			g_cache.erase(g_cache.begin() + static_cast<std::ptrdiff_t>(i));
+	// The cache lock is NOT held while a file travels to HBM (seconds for a large one): the first caller leaves an
+	// entry without a dataset behind, binds of the same file wait for it, binds of other files go on.
+	std::unique_lock<std::mutex> lock(g_cache_mutex);
+	for (;;) {
+		size_t at = g_cache.size();
+		for (size_t i = 0; i < g_cache.size(); i++) {
+			if (g_cache[i].key == key) {
+				at = i;
+				break;
+			}
+		}
+		if (at == g_cache.size()) {
+			break; // nobody has it: this caller opens it
+		}
+		if (g_cache[at].ds) {
+			auto e = g_cache[at];
+			g_cache.erase(g_cache.begin() + static_cast<std::ptrdiff_t>(at));
 			g_cache.push_back(e);
 			return e.ds;
 		}
+		g_cache_opened.wait(lock); // being opened by another thread (which removes the entry if it fails)
 	}
+	g_cache.push_back({key, nullptr, 0});
+	lock.unlock();
 	auto ds = make_shared<DeviceDataset>();
 	ds->path = pgen_path;
 	char errbuf[PGH_ERRBUF_LEN] = {0};
@@ -1285,20 +1302,50 @@ shared_ptr<DeviceDataset> DeviceDataset::Acquire(const string &pgen_path, const 
 	int rc = devices.empty() ? pgh_open(pgen_path.c_str(), nullptr, 0, UINT32_MAX, &ds->handle, errbuf)
 	                         : pgh_open_sharded(pgen_path.c_str(), nullptr, 0, UINT32_MAX, devices.data(),
 	                                            static_cast<uint32_t>(devices.size()), &ds->handle, errbuf);
+	lock.lock();
+	size_t mine = g_cache.size();
+	for (size_t i = 0; i < g_cache.size(); i++) {
+		if (g_cache[i].key == key && !g_cache[i].ds) {
+			mine = i;
+			break;
+		}
+	}
 	if (rc != PGH_OK) {
+		if (mine < g_cache.size()) {
+			g_cache.erase(g_cache.begin() + static_cast<std::ptrdiff_t>(mine));
+		}
+		g_cache_opened.notify_all();
 		throw IOException("%s: failed to open '%s': %s", func_name, pgen_path, string(errbuf));
 	}
 	pgh_get_info(ds->handle, &ds->info);
-	uint64_t bytes = ds->info.pitch_bytes * (ds->info.variant_end - ds->info.variant_begin);
-	g_cache.push_back({key, ds, bytes});
-	// evict least recently used datasets beyond the HBM budget (in-flight queries keep theirs alive)
+	// what the dataset holds in HBM: the 2-bit rows, and per dosage-bearing variant a presence bit and a 4-byte rank
+	// per 64 samples, 2 bytes per explicit value and up to 4 more once plink_score has built the entry records of
+	// the sparse tracks (phase tracks, two bit rows per phased variant, are not reported by pgh_get_info: not counted)
+	const uint64_t words = (static_cast<uint64_t>(ds->info.raw_sample_ct) + 63) / 64;
+	const uint64_t bytes = ds->info.pitch_bytes * (ds->info.variant_end - ds->info.variant_begin) +
+	                       12ull * words * ds->info.dosage_variant_ct + 6ull * ds->info.dosage_value_ct;
+	if (mine < g_cache.size()) {
+		g_cache[mine].ds = ds;
+		g_cache[mine].bytes = bytes;
+		// most recently used last
+		CacheEntry e = g_cache[mine];
+		g_cache.erase(g_cache.begin() + static_cast<std::ptrdiff_t>(mine));
+		g_cache.push_back(e);
+	}
+	g_cache_opened.notify_all();
+	// evict least recently used datasets beyond the HBM budget (in-flight queries keep theirs alive; entries
+	// still opening hold no bytes yet and stay)
 	uint64_t total = 0;
 	for (auto &e : g_cache) {
 		total += e.bytes;
 	}
-	while (g_cache.size() > 1 && total > CacheBudgetBytes()) {
-		total -= g_cache.front().bytes;
-		g_cache.erase(g_cache.begin());
+	for (size_t i = 0; i + 1 < g_cache.size() && total > CacheBudgetBytes();) {
+		if (!g_cache[i].ds) {
+			i++;
+			continue;
+		}
+		total -= g_cache[i].bytes;
+		g_cache.erase(g_cache.begin() + static_cast<std::ptrdiff_t>(i));
 	}
 	return ds;
 }

@@ -860,7 +860,8 @@ def test_shells_agree_with_the_library_across_device_batches(midsize, gpu_lib, t
     assert len(r) == m and all(counts[pos_key(c, p), 3] == mc and oc == n - mc for c, p, mc, oc in r.rows)
     r = F.query("plink_missing", path, mode="sample", threads=threads, columns=["IID", "MISSING_CT", "OBS_CT"])
     miss = ds.missing_per_sample()
-    assert len(r) == n and all(miss[int(iid[1:])] == mc and oc == m - mc for iid, mc, oc in r.rows)
+    bad = [(iid, mc, oc, int(miss[int(iid[1:])])) for iid, mc, oc in r.rows if miss[int(iid[1:])] != mc or oc != m - mc]
+    assert len(r) == n and not bad, (len(bad), bad[:8], int(miss.sum()), int(counts[:, 3].sum()))
     r = F.query("plink_hardy", path, threads=threads, region="7:1-100000000",
                 columns=["POS", "HOM_REF_CT", "HET_CT", "HOM_ALT_CT", "P_HWE"])
     per = (m + 21) // 22
@@ -1001,3 +1002,63 @@ def test_pvar_text_is_parsed_once_per_file_version(tmp_path, gpu_lib):
     renamed = F.query("plink_freq", prefix + ".pgen", columns=["ID"], threads=2)
     assert all(r[0].startswith("sv") for r in first.rows) and all(r[0].startswith("qv") for r in renamed.rows)
     shutil.rmtree(tmp_path, ignore_errors=True)
+
+
+def test_concurrent_first_binds_share_one_open(tmp_path, gpu_lib):
+    """Several sessions binding the same unseen file at once: one of them moves it to HBM, the others wait for that
+    entry of the dataset cache (the cache lock is not held across pgh_open, so a bind of ANOTHER file meanwhile is not
+    blocked behind it); a file that cannot be opened leaves no entry behind for the next bind to wait on."""
+    import shutil
+    import threading
+
+    a, b = str(tmp_path / "a"), str(tmp_path / "b")
+    gpu_lib.synth_write_files(a, 40_000, 2_000, 5, 0.02)
+    gpu_lib.synth_write_files(b, 3_000, 500, 6, 0.02)
+    out, errors = {}, []
+
+    def run(key, path):
+        try:
+            out[key] = sorted(F.query("plink_freq", path + ".pgen", columns=["ID", "ALT_FREQ", "OBS_CT"], threads=2).rows)
+        except Exception as e:  # noqa: BLE001 -- reported below
+            errors.append((key, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(f"a{i}", a)) for i in range(4)]
+    threads += [threading.Thread(target=run, args=(f"b{i}", b)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors and not any(t.is_alive() for t in threads), errors
+    assert len(out["a0"]) == 40_000 and all(out[f"a{i}"] == out["a0"] for i in range(4))
+    assert len(out["b0"]) == 3_000 and out["b1"] == out["b0"]
+    # a failing open (truncated body) twice in a row: the second bind must not hang on a stale in-flight entry
+    bad = str(tmp_path / "bad")
+    for ext in (".pvar", ".psam"):
+        shutil.copy(b + ext, bad + ext)
+    with open(b + ".pgen", "rb") as f:
+        body = f.read()
+    with open(bad + ".pgen", "wb") as f:
+        f.write(body[: len(body) // 2])
+    for _ in range(2):
+        with pytest.raises(Exception):
+            F.query("plink_freq", bad + ".pgen", columns=["ID", "ALT_FREQ"], threads=2)
+    shutil.rmtree(tmp_path, ignore_errors=True)
+
+
+@pytest.mark.parametrize("threads", [1, 6, 1])
+def test_host_calls_next_to_scan_threads_repeat_exactly(midsize, gpu_lib, threads):
+    """The regression test of the stream-ordered-pool defect (profiles/r02_async_pool_ab.txt): with
+    its scratch from hipMallocAsync, pgh_missing_per_sample returned sums 9 % short about once in thirty calls made
+    right after table-function queries (scan threads coming and going).  Scratch now lives in per-thread blocks from
+    hipMalloc; every repetition must be identical, and equal to the per-variant tallies' total."""
+    prefix, ds = midsize
+    path = prefix + ".pgen"
+    want = int(ds.counts_range()[:, 3].astype(np.int64).sum())
+    for _ in range(2):
+        F.query("plink_freq", path, counts=True, threads=threads, columns=["CHROM", "POS", "MISSING_CT", "ALT_FREQ"])
+        F.query("plink_missing", path, threads=threads, columns=["CHROM", "POS", "MISSING_CT", "OBS_CT"])
+        sums = [int(ds.missing_per_sample().astype(np.int64).sum()) for _ in range(6)]
+        assert sums == [want] * 6, sums
+        F.query("plink_missing", path, mode="sample", threads=threads, columns=["IID", "MISSING_CT"])
+        cls = [ds.sample_counts().astype(np.int64).sum(axis=0) for _ in range(3)]
+        assert all(np.array_equal(c, cls[0]) for c in cls) and int(cls[0][3]) == want
