@@ -97,6 +97,41 @@ def test_score_over_shards_equals_one_dataset(gpu_lib, ncols, mode):
     assert not s0.any() and not a0.any()
 
 
+@pytest.mark.parametrize("rate", [0.1, 0.7, 1.0])
+def test_dosage_score_over_shards_equals_one_dataset(gpu_lib, rate, monkeypatch):
+    """plink_score over dosage tracks through a group: each shard builds its own entry records (sparse tracks), or
+    takes the sample-owning / fully explicit kernels (denser ones); the partial sums meet on the root device.  Sample
+    count chosen to span two 4096-sample record tiles."""
+    m, n, seed = 900, 5003, SEED
+    cuts = [250, 251, 700]
+    whole = gpu_lib.Dataset.synth(0, m, n, seed, 0.03)
+    whole.synth_add_dosage(rate, seed + 7)
+    edges = [0] + cuts + [m]
+    shards = []
+    for a, b in zip(edges[:-1], edges[1:]):
+        sh = gpu_lib.Dataset.synth(a, b, n, seed, 0.03)
+        sh.synth_add_dosage(rate, seed + 7)
+        shards.append(sh)
+    group = gpu_lib.Dataset.group(shards)
+    assert np.array_equal(group.dosage_sums(), whole.dosage_sums())
+    rng = np.random.default_rng(11)
+    vidx = np.sort(rng.choice(m, size=600, replace=False))
+    flip = (rng.random(len(vidx)) < 0.3).astype(np.uint8)
+    for ncols, mode in ((1, "MEAN_IMPUTE"), (3, "NO_MEAN_IMPUTATION"), (1, "CENTER")):
+        w = rng.standard_normal((len(vidx), ncols))
+        code = getattr(gpu_lib, "SCORE_" + mode)
+        s1, d1, a1 = whole.score(vidx, w, flip=flip, mode=code)
+        s2, d2, a2 = group.score(vidx, w, flip=flip, mode=code)
+        scale = np.abs(w).sum(axis=0) * 2.0
+        assert np.array_equal(a1, a2) and np.all(np.abs(s1 - s2) <= 1e-12 * scale)
+        assert np.allclose(d1, d2, rtol=1e-12, atol=1e-9)
+        if rate < 0.4:  # the bit-walking kernel against the records, shard by shard
+            monkeypatch.setenv("PGH_SCORE_DOSAGE_RECORDS", "0")
+            s3, d3, a3 = group.score(vidx, w, flip=flip, mode=code)
+            monkeypatch.delenv("PGH_SCORE_DOSAGE_RECORDS")
+            assert np.array_equal(a3, a2) and np.all(np.abs(s3 - s2) <= 1e-12 * scale)
+
+
 def test_pca_over_shards_equals_one_dataset(gpu_lib):
     m, n, k = 900, 2100, 4
     whole, group = make_pair(gpu_lib, m, n, [300, 650], missing=0.03, seed=SEED + 11)
