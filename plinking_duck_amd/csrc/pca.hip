@@ -95,40 +95,53 @@ __global__ __launch_bounds__(256) void k_tall_gram(const double *__restrict__ A,
 }
 
 // out[r][j] = beta * B[r][j] + alpha * sum_i A[r][i] * C[i][j]   (j < nb; C: na x nb, small)
-// 4 rows per workgroup staged in LDS; a lane produces 4 adjacent columns of one row.
+// A lane owns one ROW and up to W of its output columns in registers; the workgroup's 256 rows of A pass through
+// LDS sixteen columns at a time (coalesced 128-byte row segments in, conflict-free column reads out), and C's
+// entries are wave-uniform operands.  (The first form gave a lane four adjacent columns of a row: with the 20 or
+// 10 columns plink_pca asks for, five or three lanes of a wave worked -- 1 ms per call, 43 calls per plink_pca.)
+constexpr uint32_t kTtsRows = 256, kTtsChunk = 16;
+template <int W>
 __global__ __launch_bounds__(256) void k_tall_times_small(const double *__restrict__ A, uint32_t lda, uint32_t na,
                                                           const double *__restrict__ C, uint32_t ldc, uint32_t nb,
-                                                          double alpha, double beta, const double *__restrict__ B,
-                                                          uint32_t ldb, double *__restrict__ out, uint32_t ldo,
-                                                          uint64_t m) {
-	extern __shared__ double s_rows[]; // [4][na]
-	const uint32_t rr = threadIdx.x >> 6, jg = threadIdx.x & 63u;
-	const uint64_t r0 = static_cast<uint64_t>(blockIdx.x) * 4u;
-	for (uint32_t e = threadIdx.x; e < 4u * na; e += 256u) {
-		const uint64_t row = r0 + e / na;
-		s_rows[e] = row < m ? A[row * lda + e % na] : 0.0;
-	}
-	__syncthreads();
-	const uint64_t row = r0 + rr;
-	if (row >= m) {
-		return;
-	}
-	for (uint32_t j0 = jg * 4u; j0 < nb; j0 += 256u) {
-		double acc[4] = {0.0, 0.0, 0.0, 0.0};
-		const uint32_t w = min(4u, nb - j0);
-		for (uint32_t i = 0; i < na; i++) {
-			const double a = s_rows[rr * na + i];
-			const double *c = C + static_cast<uint64_t>(i) * ldc + j0;
+                                                          double alpha, double beta, const double *B, uint32_t ldb,
+                                                          double *out, uint32_t ldo, uint64_t m) {
+	__shared__ double s_a[kTtsRows][kTtsChunk + 1];
+	const uint64_t r0 = static_cast<uint64_t>(blockIdx.x) * kTtsRows;
+	const uint64_t row = r0 + threadIdx.x;
+	for (uint32_t j0 = 0; j0 < nb; j0 += W) {
+		double acc[W];
 #pragma unroll
-			for (uint32_t q = 0; q < 4; q++) {
-				if (q < w) {
-					acc[q] = fma(a, c[q], acc[q]);
+		for (int q = 0; q < W; q++) {
+			acc[q] = 0.0;
+		}
+		for (uint32_t i0 = 0; i0 < na; i0 += kTtsChunk) {
+			__syncthreads();
+#pragma unroll
+			for (uint32_t k = 0; k < kTtsChunk; k++) {
+				const uint32_t e = threadIdx.x + 256u * k;
+				const uint32_t rr = e / kTtsChunk, cc = e % kTtsChunk;
+				s_a[rr][cc] = (r0 + rr < m && i0 + cc < na) ? A[(r0 + rr) * lda + i0 + cc] : 0.0;
+			}
+			__syncthreads();
+#pragma unroll 1
+			for (uint32_t i = 0; i < kTtsChunk; i++) { // (unrolled, C's entries overflow the scalar registers)
+				const double a = s_a[threadIdx.x][i];
+				const double *c = C + static_cast<uint64_t>(min(i0 + i, na - 1u)) * ldc; // (past na: a is 0)
+#pragma unroll
+				for (int q = 0; q < W; q++) {
+					const double cq = j0 + q < nb ? c[j0 + q] : 0.0;
+					acc[q] = fma(a, cq, acc[q]);
 				}
 			}
 		}
-		for (uint32_t q = 0; q < w; q++) {
-			const double prev = beta != 0.0 ? beta * B[row * ldb + j0 + q] : 0.0;
-			out[row * ldo + j0 + q] = prev + alpha * acc[q];
+		if (row < m) {
+#pragma unroll
+			for (int q = 0; q < W; q++) {
+				if (j0 + q < nb) {
+					const double prev = beta != 0.0 ? beta * B[row * ldb + j0 + q] : 0.0;
+					out[row * ldo + j0 + q] = prev + alpha * acc[q];
+				}
+			}
 		}
 	}
 }
@@ -203,9 +216,24 @@ hipError_t LaunchTallTimesSmall(const double *A, uint32_t lda, uint32_t na, cons
 	if (m == 0 || nb == 0) {
 		return hipSuccess;
 	}
-	const uint64_t blocks = (m + 3) / 4;
-	hipLaunchKernelGGL(k_tall_times_small, dim3(static_cast<uint32_t>(blocks)), dim3(256), 4 * na * sizeof(double), stream,
-	                   A, lda, na, C, ldc, nb, alpha, beta, B, ldb, out, ldo, m);
+	const uint32_t blocks = static_cast<uint32_t>((m + kTtsRows - 1) / kTtsRows);
+#define PGH_TTS(W)                                                                                                     \
+	hipLaunchKernelGGL(k_tall_times_small<W>, dim3(blocks), dim3(256), 0, stream, A, lda, na, C, ldc, nb, alpha, beta, B,  \
+	                   ldb, out, ldo, m)
+	if (nb <= 8) {
+		PGH_TTS(8);
+	} else if (nb <= 12) {
+		PGH_TTS(12);
+	} else if (nb <= 16) {
+		PGH_TTS(16);
+	} else if (nb <= 20) {
+		PGH_TTS(20);
+	} else if (nb <= 24) {
+		PGH_TTS(24);
+	} else {
+		PGH_TTS(32); // wider outputs: 32 columns at a time, A re-read per group
+	}
+#undef PGH_TTS
 	return hipGetLastError();
 }
 
