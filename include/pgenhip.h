@@ -17,9 +17,13 @@
  *     (src/plink_common.cpp:1222-1250).
  *
  * Pointers named d_* are device (HBM) pointers owned by the caller; `stream`
- * is a hipStream_t passed as void* (NULL = the library's own stream).  The
- * *_dev entry points only enqueue work; the host-buffer forms synchronise and
- * copy the result back.
+ * is a hipStream_t passed as void* (NULL = HIP's default stream).  The
+ * *_dev entry points only enqueue work; the host-buffer forms run on a stream
+ * the library keeps for the calling thread, synchronise and copy the result
+ * back.  Entry points that need device scratch keep one block per calling
+ * thread, device and stream (grown on demand, released when the thread ends);
+ * nothing is allocated from HIP's stream-ordered pool (hipMallocAsync), which
+ * was seen to lose kernel-written data on this runtime.
  */
 #ifndef PGENHIP_H_
 #define PGENHIP_H_

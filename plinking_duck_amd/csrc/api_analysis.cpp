@@ -70,7 +70,7 @@ extern "C" int pgh_missing_per_sample_dev(const pgh_dataset *ds, uint32_t v_begi
 	PGH_ONE_DEVICE(ds);
 	PGH_ENTER(ds);
 	hipStream_t st = static_cast<hipStream_t>(stream);
-	// per-slice partial rows: a few MB, stream-ordered so the call stays enqueue-only
+	// per-slice partial rows: a few MB from this thread's scratch block for `st`, so the call stays enqueue-only
 	const size_t scratch_bytes = pgh::MissingPerSampleScratchBytes(ds->record_bytes, v_end - v_begin);
 	void *scratch = nullptr;
 	PGH_HIP(PghThreadScratch(scratch_bytes, st, &scratch), "missing scratch");

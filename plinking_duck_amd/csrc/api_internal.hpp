@@ -192,12 +192,10 @@ pgh_reader *ReaderFor(pgh_reader *rd, uint32_t vidx);
 } // namespace pgh_group
 
 // The calling thread's own stream on the current device: what every host-output entry point enqueues on.
-// NOT hipStreamPerThread.  On this runtime (ROCm 7.2) the special handle did not stay ONE stream for a thread:
-// in the first call after other threads had come and gone (a DuckDB scan pool, pgh_open's readers), a memset,
-// two kernels and a copy all enqueued "on hipStreamPerThread" ran unordered -- pgh_missing_per_sample returned
-// sums 9 % short, once, and was right again on the next call (tests/test_table_functions_gpu.py caught it; with
-// a stream created by the library the same sequence never failed).  Streams are created on first use per
-// (thread, device) and destroyed when the thread ends.
+// A real stream handle created by the library (on first use per thread and device, destroyed when the thread ends)
+// rather than the special hipStreamPerThread value: PghThreadScratch below keys its blocks by stream, and the
+// handle can be handed to callbacks that need a concrete stream.  (hipStreamPerThread was the first suspect of the
+// lost-scratch defect described below; a library-owned stream failed the same way -- the allocator was the cause.)
 hipStream_t PghThreadStream();
 
 // Device scratch for an enqueue-only entry point: at least `bytes`, valid for the work the caller enqueues on `st`
