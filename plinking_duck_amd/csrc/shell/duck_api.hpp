@@ -108,15 +108,15 @@ struct LogicalType {
 		return ToString() == o.ToString();
 	}
 
-	static const LogicalTypeId SQLNULL = LogicalTypeId::SQLNULL;
-	static const LogicalTypeId BOOLEAN = LogicalTypeId::BOOLEAN;
-	static const LogicalTypeId TINYINT = LogicalTypeId::TINYINT;
-	static const LogicalTypeId INTEGER = LogicalTypeId::INTEGER;
-	static const LogicalTypeId UINTEGER = LogicalTypeId::UINTEGER;
-	static const LogicalTypeId BIGINT = LogicalTypeId::BIGINT;
-	static const LogicalTypeId DOUBLE = LogicalTypeId::DOUBLE;
-	static const LogicalTypeId VARCHAR = LogicalTypeId::VARCHAR;
-	static const LogicalTypeId ANY = LogicalTypeId::ANY;
+	static constexpr LogicalTypeId SQLNULL = LogicalTypeId::SQLNULL;
+	static constexpr LogicalTypeId BOOLEAN = LogicalTypeId::BOOLEAN;
+	static constexpr LogicalTypeId TINYINT = LogicalTypeId::TINYINT;
+	static constexpr LogicalTypeId INTEGER = LogicalTypeId::INTEGER;
+	static constexpr LogicalTypeId UINTEGER = LogicalTypeId::UINTEGER;
+	static constexpr LogicalTypeId BIGINT = LogicalTypeId::BIGINT;
+	static constexpr LogicalTypeId DOUBLE = LogicalTypeId::DOUBLE;
+	static constexpr LogicalTypeId VARCHAR = LogicalTypeId::VARCHAR;
+	static constexpr LogicalTypeId ANY = LogicalTypeId::ANY;
 
 	static LogicalType LIST(const LogicalType &elem) {
 		LogicalType t(LogicalTypeId::LIST);
