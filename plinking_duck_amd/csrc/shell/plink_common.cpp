@@ -10,7 +10,9 @@
 #include <fstream>
 #include <limits>
 #include <sstream>
+#include <climits>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <unordered_set>
 
 namespace duckdb {
@@ -348,6 +350,265 @@ static VariantMetadataIndex ParseVariantMetadata(const string &path, const strin
 	return out;
 }
 
+// ---- the on-disk side-cache of the parsed columns ---------------------------------------------------------------
+// A second process binding the same big .pvar need not split a million text lines again: the first parse leaves
+// the columns behind in binary form -- positions as int32, the string columns as offsets + one blob each, CHROM as
+// its runs -- under $PLINKING_PVAR_CACHE_DIR (else $XDG_CACHE_HOME/plinking_duck_amd, else
+// ~/.cache/plinking_duck_amd), in a file named after the absolute path's hash and valid for exactly one
+// (path, size, mtime).  PLINKING_PVAR_CACHE=0 turns it off; files under 256 KB are not worth a cache entry; every
+// failure on the way (no directory, short read, stale or foreign contents) falls back to parsing the text.
+namespace {
+
+constexpr char kPvarCacheMagic[8] = {'P', 'G', 'H', 'P', 'V', 'A', 'R', '1'};
+constexpr int64_t kPvarCacheMinBytes = 256 << 10;
+
+string PvarCacheDir() {
+	const char *off = std::getenv("PLINKING_PVAR_CACHE");
+	if (off && off[0] == '0') {
+		return "";
+	}
+	if (const char *dir = std::getenv("PLINKING_PVAR_CACHE_DIR")) {
+		return dir;
+	}
+	if (const char *xdg = std::getenv("XDG_CACHE_HOME")) {
+		if (*xdg) {
+			return string(xdg) + "/plinking_duck_amd";
+		}
+	}
+	if (const char *home = std::getenv("HOME")) {
+		if (*home) {
+			return string(home) + "/.cache/plinking_duck_amd";
+		}
+	}
+	return "";
+}
+
+string AbsolutePath(const string &path) {
+	char buf[PATH_MAX];
+	return ::realpath(path.c_str(), buf) ? string(buf) : path;
+}
+
+string PvarCacheFile(const string &dir, const string &abs_path) {
+	uint64_t h = 1469598103934665603ull; // FNV-1a
+	for (unsigned char c : abs_path) {
+		h = (h ^ c) * 1099511628211ull;
+	}
+	char name[40];
+	std::snprintf(name, sizeof name, "/%016llx.pvarc", static_cast<unsigned long long>(h));
+	return dir + name;
+}
+
+struct ByteWriter {
+	string out;
+	template <class T>
+	void Put(const T &v) {
+		out.append(reinterpret_cast<const char *>(&v), sizeof v);
+	}
+	void PutStrings(const vector<string> &col) {
+		uint64_t total = 0;
+		for (auto &x : col) {
+			total += x.size();
+		}
+		Put(total);
+		// offsets and bytes written in place (one append per element made the write twice as slow as the parse)
+		const size_t offs_at = out.size(), blob_at = offs_at + 4 * (col.size() + 1);
+		out.resize(blob_at + total);
+		char *base = &out[0];
+		uint32_t at = 0;
+		for (size_t i = 0; i < col.size(); i++) {
+			std::memcpy(base + offs_at + 4 * i, &at, 4);
+			std::memcpy(base + blob_at + at, col[i].data(), col[i].size());
+			at += static_cast<uint32_t>(col[i].size());
+		}
+		std::memcpy(base + offs_at + 4 * col.size(), &at, 4);
+	}
+};
+
+struct ByteReader {
+	const char *p, *end;
+	bool ok = true;
+	template <class T>
+	T Get() {
+		T v {};
+		if (static_cast<size_t>(end - p) < sizeof v) {
+			ok = false;
+			return v;
+		}
+		std::memcpy(&v, p, sizeof v);
+		p += sizeof v;
+		return v;
+	}
+	const char *Take(uint64_t n) {
+		if (static_cast<uint64_t>(end - p) < n) {
+			ok = false;
+			return nullptr;
+		}
+		const char *q = p;
+		p += n;
+		return q;
+	}
+	bool GetStrings(uint64_t n, vector<string> &col) {
+		const uint64_t total = Get<uint64_t>();
+		const char *offs = Take(4 * (n + 1));
+		const char *blob = Take(total);
+		if (!ok) {
+			return false;
+		}
+		col.clear();
+		col.reserve(n);
+		uint32_t a, b;
+		std::memcpy(&a, offs, 4);
+		for (uint64_t i = 0; i < n; i++) {
+			std::memcpy(&b, offs + 4 * (i + 1), 4);
+			if (b < a || b > total) {
+				return false;
+			}
+			col.emplace_back(blob + a, b - a);
+			a = b;
+		}
+		return true;
+	}
+};
+
+void WritePvarCache(const string &file, const string &abs_path, int64_t size, int64_t mtime_ns,
+                    const VariantMetadataIndex &idx) {
+	const VariantColumns &c = *idx.cols;
+	const uint64_t n = idx.variant_ct;
+	uint64_t blob = 0;
+	for (auto *col : {&c.ids, &c.refs, &c.alts}) {
+		for (auto &x : *col) {
+			blob += x.size();
+		}
+	}
+	if (n > 0xfffffff0ull || blob > 0xfffffff0ull) {
+		return; // the 32-bit offsets of the format do not hold it
+	}
+	ByteWriter w;
+	w.out.reserve(64 + abs_path.size() + 4 * n + 3 * 4 * (n + 1) + blob);
+	w.out.append(kPvarCacheMagic, sizeof kPvarCacheMagic);
+	w.Put(static_cast<int64_t>(size));
+	w.Put(static_cast<int64_t>(mtime_ns));
+	w.Put(static_cast<uint64_t>(abs_path.size()));
+	w.out.append(abs_path);
+	w.Put(static_cast<uint8_t>(idx.is_bim ? 1 : 0));
+	w.Put(n);
+	// CHROM as its runs, in variant order
+	vector<std::pair<idx_t, const string *>> runs;
+	for (auto &kv : c.chrom_offsets) {
+		runs.emplace_back(kv.second.first, &kv.first);
+	}
+	std::sort(runs.begin(), runs.end());
+	w.Put(static_cast<uint32_t>(runs.size()));
+	for (auto &r : runs) {
+		w.Put(static_cast<uint32_t>(c.chrom_offsets.at(*r.second).first));
+		w.Put(static_cast<uint32_t>(c.chrom_offsets.at(*r.second).second));
+		w.Put(static_cast<uint32_t>(r.second->size()));
+		w.out.append(*r.second);
+	}
+	w.out.append(reinterpret_cast<const char *>(c.positions.data()), 4 * n);
+	w.PutStrings(c.ids);
+	w.PutStrings(c.refs);
+	w.PutStrings(c.alts);
+	const string tmp = file + "." + std::to_string(static_cast<long long>(::getpid())) + ".tmp";
+	{
+		std::ofstream f(tmp, std::ios::binary | std::ios::trunc);
+		if (!f) {
+			return;
+		}
+		f.write(w.out.data(), static_cast<std::streamsize>(w.out.size()));
+		if (!f) {
+			f.close();
+			::unlink(tmp.c_str());
+			return;
+		}
+	}
+	if (::rename(tmp.c_str(), file.c_str()) != 0) {
+		::unlink(tmp.c_str());
+	}
+}
+
+bool ReadPvarCache(const string &file, const string &abs_path, int64_t size, int64_t mtime_ns,
+                   VariantMetadataIndex &out) {
+	string bytes;
+	if (!ReadWholeFile(file, bytes) || bytes.size() < sizeof kPvarCacheMagic ||
+	    std::memcmp(bytes.data(), kPvarCacheMagic, sizeof kPvarCacheMagic) != 0) {
+		return false;
+	}
+	ByteReader r {bytes.data() + sizeof kPvarCacheMagic, bytes.data() + bytes.size()};
+	if (r.Get<int64_t>() != size || r.Get<int64_t>() != mtime_ns) {
+		return false;
+	}
+	const uint64_t path_len = r.Get<uint64_t>();
+	const char *path_bytes = r.Take(path_len);
+	if (!r.ok || path_len != abs_path.size() || std::memcmp(path_bytes, abs_path.data(), path_len) != 0) {
+		return false;
+	}
+	auto columns = make_shared<VariantColumns>();
+	VariantColumns &c = *columns;
+	const bool is_bim = r.Get<uint8_t>() != 0;
+	const uint64_t n = r.Get<uint64_t>();
+	const uint32_t n_runs = r.Get<uint32_t>();
+	if (!r.ok || n > 0xfffffff0ull || n_runs > n) {
+		return false;
+	}
+	c.chroms.resize(n);
+	uint64_t covered = 0;
+	for (uint32_t k = 0; k < n_runs; k++) {
+		const uint32_t a = r.Get<uint32_t>(), b = r.Get<uint32_t>(), len = r.Get<uint32_t>();
+		const char *name = r.Take(len);
+		if (!r.ok || a != covered || b <= a || b > n) {
+			return false;
+		}
+		const string chrom(name, len);
+		if (!c.chrom_offsets.emplace(chrom, std::make_pair(static_cast<idx_t>(a), static_cast<idx_t>(b))).second) {
+			return false;
+		}
+		for (uint32_t v = a; v < b; v++) {
+			c.chroms[v] = chrom;
+		}
+		covered = b;
+	}
+	if (covered != n) {
+		return false;
+	}
+	const char *pos = r.Take(4 * n);
+	if (!r.ok) {
+		return false;
+	}
+	c.positions.resize(n);
+	std::memcpy(c.positions.data(), pos, 4 * n);
+	if (!r.GetStrings(n, c.ids) || !r.GetStrings(n, c.refs) || !r.GetStrings(n, c.alts) || r.p != r.end) {
+		return false;
+	}
+	out.cols = std::move(columns);
+	out.variant_ct = n;
+	out.is_bim = is_bim;
+	return true;
+}
+
+} // namespace
+
+static VariantMetadataIndex ParseOrLoadVariantMetadata(const string &path, const string &func_name, bool have_stat,
+                                                       int64_t size, int64_t mtime_ns) {
+	string dir;
+	if (have_stat && size >= kPvarCacheMinBytes) {
+		dir = PvarCacheDir();
+	}
+	if (dir.empty()) {
+		return ParseVariantMetadata(path, func_name);
+	}
+	const string abs_path = AbsolutePath(path);
+	const string file = PvarCacheFile(dir, abs_path);
+	VariantMetadataIndex cached;
+	if (ReadPvarCache(file, abs_path, size, mtime_ns, cached)) {
+		return cached;
+	}
+	VariantMetadataIndex parsed = ParseVariantMetadata(path, func_name);
+	::mkdir(dir.c_str(), 0700); // (one level: the parent is the user's cache directory or the one they named)
+	WritePvarCache(file, abs_path, size, mtime_ns, parsed);
+	return parsed;
+}
+
 VariantMetadataIndex LoadVariantMetadata(ClientContext &, const string &path, const string &func_name) {
 	struct stat st;
 	const bool have_stat = ::stat(path.c_str(), &st) == 0;
@@ -364,7 +625,8 @@ VariantMetadataIndex LoadVariantMetadata(ClientContext &, const string &path, co
 			}
 		}
 	}
-	VariantMetadataIndex parsed = ParseVariantMetadata(path, func_name); // outside the lock: binds of other files go on
+	// outside the lock: binds of other files go on
+	VariantMetadataIndex parsed = ParseOrLoadVariantMetadata(path, func_name, have_stat, size, mtime_ns);
 	if (have_stat) {
 		std::lock_guard<std::mutex> lock(g_pvar_cache_mutex);
 		g_pvar_cache.push_back(PvarCacheEntry {path, mtime_ns, size, parsed});

@@ -9,6 +9,10 @@ if ROOT not in sys.path:
 
 DATA = os.path.join(ROOT, "tests", "golden", "data")
 
+# the shells' on-disk .pvar side-cache stays out of the user's cache directory during tests; the test of the cache
+# itself points it at a temporary directory
+os.environ.setdefault("PLINKING_PVAR_CACHE", "0")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")

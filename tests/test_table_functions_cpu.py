@@ -3,6 +3,8 @@ reference's *_negative.test files assert happens at bind time, the registration
 contract, projection pushdown of metadata-only queries, and MaxThreads().
 Message substrings are the ones the reference's tests require."""
 
+import os
+
 import pytest
 
 from conftest import data_path
@@ -386,3 +388,66 @@ def test_pvar_parse_errors(tmp_path):
     assert "missing required fields (line 4)" in err("plink_freq", EX, pvar=pvar(head + "1\t10\ta\tA\tG\n1\t20\tb\tA\n"))
     assert "missing required fields (line 1)" in err("plink_freq", EX, pvar=pvar("1 rs1 0 10000 G\n"))
     assert "non-contiguous" in err("plink_freq", EX, pvar=pvar(head + "1\t1\ta\tA\tG\n2\t1\tb\tA\tG\n1\t2\tc\tA\tG\n2\t2\td\tA\tG\n"))
+
+
+def test_pvar_side_cache_serves_a_fresh_process(tmp_path):
+    """The binary side-cache of the parsed .pvar columns (csrc/shell/plink_common.cpp; the cost it removes from a
+    new process's first bind is the reference's LoadVariantMetadata, src/plink_common.cpp:171-375): written by the
+    first bind, read by the next PROCESS, ignored when the text changed, survived when it is garbage."""
+    import glob
+    import struct
+    import subprocess
+    import sys
+
+    m, n = 30_000, 8
+    prefix = tmp_path / "big"
+    # a fixed-width (mode 0x02) .pgen: 12-byte header, one 2-byte record per variant
+    with open(str(prefix) + ".pgen", "wb") as f:
+        f.write(bytes([0x6c, 0x1b, 0x02]) + struct.pack("<II", m, n) + b"\x40" + b"\x00\x00" * m)
+    with open(str(prefix) + ".psam", "w") as f:
+        f.write("#IID\n" + "".join(f"S{i}\n" for i in range(n)))
+
+    def write_pvar(tag):
+        with open(str(prefix) + ".pvar", "w") as f:
+            f.write("##x\n#CHROM\tPOS\tID\tREF\tALT\n")
+            f.write("".join(f"{1 + i * 22 // m}\t{100 + i}\t{tag}{i}\t{'ACGT'[i % 4]}\t{'.' if i % 97 == 0 else 'T'}\n"
+                            for i in range(m)))
+
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    code = ("import sys, json; sys.path.insert(0, %r); import plinking_duck_amd.functions as F; "
+            "r = F.query('plink_freq', %r, columns=['CHROM', 'POS', 'ID', 'REF', 'ALT'], region='3:1-100000000'); "
+            "print(json.dumps({'n': len(r), 'first': r.sorted('POS')[0], 'last': r.sorted('POS')[-1], "
+            "'nulls': sum(1 for x in r.rows if x[4] is None), 'bind': r.timing_ms['bind']}))"
+            % (str(__import__("conftest").ROOT), str(prefix) + ".pgen"))
+
+    def run(extra_env=None):
+        env = dict(os.environ, PLINKING_PVAR_CACHE="1", PLINKING_PVAR_CACHE_DIR=str(cache))
+        env.update(extra_env or {})
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return __import__("json").loads(out.stdout.strip().splitlines()[-1])
+
+    write_pvar("rs")
+    assert os.path.getsize(str(prefix) + ".pvar") > 256 << 10
+    first = run()
+    files = glob.glob(str(cache / "*.pvarc"))
+    assert len(files) == 1 and first["n"] > 1000 and first["first"][2].startswith("rs")
+    second = run()                                   # a new process: served from the side-cache
+    assert {k: second[k] for k in ("n", "first", "last", "nulls")} == {k: first[k] for k in ("n", "first", "last", "nulls")}
+    off = run({"PLINKING_PVAR_CACHE": "0"})          # and the text parse says the same
+    assert {k: off[k] for k in ("n", "first", "last", "nulls")} == {k: first[k] for k in ("n", "first", "last", "nulls")}
+    stamp = os.path.getmtime(files[0])
+    # garbage in the cache file: parsed again, file rewritten
+    with open(files[0], "r+b") as f:
+        f.seek(40)
+        f.write(b"\xff" * 64)
+    assert run()["first"] == first["first"]
+    # a new version of the text: never the old columns
+    import time
+    time.sleep(0.02)
+    write_pvar("qv")
+    renamed = run()
+    assert renamed["first"][2].startswith("qv") and renamed["n"] == first["n"]
+    assert glob.glob(str(cache / "*.pvarc")) == files and os.path.getmtime(files[0]) >= stamp
+    assert not glob.glob(str(cache / "*.tmp"))

@@ -8,6 +8,8 @@ Python harness inside scan, which DuckDB would not pay).
 """
 import argparse
 import os
+
+os.environ.setdefault("PLINKING_PVAR_CACHE", "0")  # "first bind" below is the text parse, not the on-disk side-cache
 import sys
 import tempfile
 import time
