@@ -647,3 +647,36 @@ def test_sample_major_unpack_is_the_transposed_unpack(gpu_lib, m, n):
         d = ds.dosage_unpack()
         assert np.array_equal(ds.dosage_unpack_samples(order), d[order].T)
         assert np.array_equal(ds.dosage_unpack_samples(order, subset=ss), d[order][:, mask].T)
+
+
+@pytest.mark.gpu
+def test_thread_scratch_grows_and_is_reused(gpu_lib):
+    """Entry points that need device scratch keep one block per calling thread and stream (PghThreadScratch; no
+    stream-ordered allocations -- DESIGN.md section 6): alternate a small and a larger dataset on one thread, through
+    three entry points with different scratch needs, and on a second thread; every answer must equal the per-variant
+    tallies' totals."""
+    import threading
+
+    small = gpu_lib.Dataset.synth(0, 700, 1000, 5, 0.05)
+    large = gpu_lib.Dataset.synth(0, 6000, 70_001, 6, 0.02)
+    want = {id(d): d.counts_range().astype(np.int64).sum(axis=0) for d in (small, large)}
+    errors = []
+
+    def work():
+        try:
+            for d in (small, large, small, large, large, small):
+                w = want[id(d)]
+                assert int(d.missing_per_sample().astype(np.int64).sum()) == int(w[3])
+                cls = d.sample_counts().astype(np.int64).sum(axis=0)
+                assert np.array_equal(cls, w)
+                s, dsum, ac = d.score(np.arange(0, d.v_end, 7), np.ones((len(range(0, d.v_end, 7)), 1)),
+                                      mode=gpu_lib.SCORE_NO_MEAN_IMPUTATION)
+                assert ac.min() >= 0 and np.isfinite(s).all()
+        except Exception as e:  # noqa: BLE001 -- reported by the main thread
+            errors.append(repr(e))
+
+    work()
+    t = threading.Thread(target=work)
+    t.start()
+    t.join(timeout=120)
+    assert not errors and not t.is_alive(), errors
