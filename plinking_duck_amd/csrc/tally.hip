@@ -615,18 +615,19 @@ __global__ __launch_bounds__(256) void k_fused_tally(const uint8_t *__restrict__
 	// one row: class popcounts packed as lo | hi << 10 | both << 20, missing bits into a2
 	auto one_row = [&](const uint4 &w, uint32_t a2[4]) -> uint32_t {
 		const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
-		uint32_t lo_ct = 0, hi_ct = 0, both_ct = 0;
+		// popc(low bits) + popc(high bits) = popc(word): the high-bit count comes from one subtraction per row
+		// instead of a shift-and-mask per word (this kernel is vector-issue bound next to its HBM stream)
+		uint32_t lo_ct = 0, all_ct = 0, both_ct = 0;
 #pragma unroll
 		for (int j = 0; j < 4; j++) {
 			const uint32_t lo = ws[j] & kLow;
-			const uint32_t hi = (ws[j] >> 1) & kLow;
-			const uint32_t both = lo & hi;
+			const uint32_t both = lo & (ws[j] >> 1);
 			lo_ct += __popc(lo);
-			hi_ct += __popc(hi);
+			all_ct += __popc(ws[j]);
 			both_ct += __popc(both);
 			a2[j] += both;
 		}
-		return lo_ct | (hi_ct << 10) | (both_ct << 20);
+		return lo_ct | ((all_ct - lo_ct) << 10) | (both_ct << 20);
 	};
 	const uint4 zero4 = make_uint4(0, 0, 0, 0);
 	auto load_row = [&](uint32_t idx) {
