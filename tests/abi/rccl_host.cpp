@@ -1,6 +1,7 @@
 // The C++ host INTEGRATION.md section 4 describes: one process per GPU, variants sharded, and the
 // all-reduce that pgh_pca_sharded asks for done by RCCL on the library's own stream.  Compiled (not
-// run) by tests/test_abi.py: it pins the callback signature and the order of the arguments.
+// run) by tests/test_abi.py: it pins the callback signature and the order of the arguments; built together with
+// rccl_host_main.cpp and RUN with a one-rank communicator by tests/test_gpu_parity.py on the GPU box.
 #include "pgenhip.h"
 
 #include <hip/hip_runtime.h>

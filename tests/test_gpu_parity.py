@@ -680,3 +680,24 @@ def test_thread_scratch_grows_and_is_reused(gpu_lib):
     t.start()
     t.join(timeout=120)
     assert not errors and not t.is_alive(), errors
+
+
+@pytest.mark.gpu
+def test_rccl_host_runs_on_one_rank(tmp_path):
+    """tests/abi/rccl_host.cpp + rccl_host_main.cpp, built with hipcc against libpgenhip and librccl and RUN: a C++
+    host whose all-reduce callback is ncclAllReduce on the stream pgh_pca_sharded hands it (one rank on the box's one
+    GPU -- the RCCL launch, the stream handle and the library's ordering around the callback are what is exercised;
+    the multi-rank arithmetic is covered by the gloo tests and the in-process shard groups)."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "plinking_duck_amd")
+    exe = tmp_path / "rccl_host"
+    build = subprocess.run(["/opt/rocm/bin/hipcc", "-std=c++17", "-O1", "-I", os.path.join(root, "include"),
+                            os.path.join(root, "tests", "abi", "rccl_host.cpp"),
+                            os.path.join(root, "tests", "abi", "rccl_host_main.cpp"), "-o", str(exe), "-L", libdir,
+                            "-lpgenhip", "-lrccl", "-Wl,-rpath," + libdir], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([str(exe), str(tmp_path / "pcs")], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, (run.stdout[-1500:], run.stderr[-1500:])
+    assert "worst relative difference" in run.stdout
