@@ -9,13 +9,15 @@ for v in ${VARIANTS:-NONE NO_BUILD NO_DMA NO_DMA_B NO_DMA_G HOT_B}; do
   /opt/rocm/bin/hipcc $FLAGS -DPGH_I8_$v -c score_i8.hip -o /tmp/score_i8_x.o 2>/dev/null || { echo "compile failed: $v"; continue; }
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libpgenhip.so $OBJS /tmp/score_i8_x.o
   cd "$GRAFT_REPO_ROOT"
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/i8x -- python3 bench.py --workload score --score-cols ${COLS:-16} --steps 3 --warmup 1 --cpu-seconds 0 > /dev/null 2> /tmp/i8x_err.txt
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/i8x -- python3 bench.py ${BENCH_ARGS:---workload score --score-cols ${COLS:-16}} --steps ${STEPS:-3} --warmup 1 --cpu-seconds 0 > /dev/null 2> /tmp/i8x_err.txt
   f=$(ls -t /tmp/i8x/*/*_kernel_stats.csv 2>/dev/null | head -1)
   printf "%-28s " "$v"; python3 - "$f" <<'PY'
 import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):
     if 'k_score_i8' in r['Name']:
-        print(f"k_score_i8 avg {float(r['AverageNs'])/1e6:8.2f} ms over {r['Calls']} calls")
+        shape = r['Name'].split('k_score_i8')[1].split('(')[0]
+        print(f"k_score_i8{shape} avg {float(r['AverageNs'])/1e6:8.2f} ms over {r['Calls']} calls", end='; ')
+print()
 PY
   rm -rf /tmp/i8x
   cd "$GRAFT_REPO_ROOT/plinking_duck_amd/csrc"
