@@ -4,8 +4,8 @@
 // the library taken away: per call { hipMalloc out; hipMallocAsync scratch; memset out; k_write fills scratch slice
 // by slice; k_sum adds the slices into out; hipFreeAsync scratch; copy out; sync; hipFree out }, on the calling
 // thread's stream, with short-lived helper threads doing their own hipMalloc / kernel / copy / hipFree rounds in
-// between (a scan pool coming and going).  Run with "malloc" as the first argument for the control: the same loop with
-// the scratch from hipMalloc.
+// between (a scan pool coming and going).  First argument: "pool" (default), "malloc" for the control -- the same loop
+// with the scratch from hipMalloc --, "keep" for the pool with its release threshold at the maximum.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -69,6 +69,14 @@ static void Helper(int rounds) {
 
 int main(int argc, char **argv) {
 	const bool use_pool = !(argc > 1 && std::strcmp(argv[1], "malloc") == 0);
+	if (argc > 1 && std::strcmp(argv[1], "keep") == 0) {
+		// "keep": the pool never gives memory back at a synchronisation point (release threshold = max) -- does the
+		// loss need a block that was released and mapped again?
+		hipMemPool_t pool;
+		CHECK(hipDeviceGetDefaultMemPool(&pool, 0));
+		uint64_t keep = ~0ull;
+		CHECK(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
+	}
 	const int calls = argc > 2 ? std::atoi(argv[2]) : 600;
 	const size_t scratch_bytes = static_cast<size_t>(kSlices) * kPlanes * kCols * 4u;
 	const unsigned want = kSlices * kPlanes;
