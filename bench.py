@@ -270,6 +270,39 @@ def verify(args, L, np, torch, ds, env):
         if not ok:
             print(f"verify: score column sums {got} != {want} from the tallies", file=sys.stderr)
         return ok
+    if wl == "ld":
+        # three pairs recomputed on the host from the synthetic records: {n, sum a, sum b, sum ab, sum a^2, sum b^2}
+        # over the samples called at both variants (src/plink_ld.cpp's sample loop)
+        hs = env["h_sums"].numpy().astype(np.int64)
+        p_a, p_b = env["p_a"], env["p_b"]
+        for i in sorted({0, len(p_a) // 2, len(p_a) - 1}):
+            _, a = host_tallies(np, L.synth_record_host(int(p_a[i]), n, SEED, MISSING_RATE), n)
+            _, b = host_tallies(np, L.synth_record_host(int(p_b[i]), n, SEED, MISSING_RATE), n)
+            both = (a != 3) & (b != 3)
+            a, b = a[both].astype(np.int64), b[both].astype(np.int64)
+            want = [int(both.sum()), int(a.sum()), int(b.sum()), int((a * b).sum()), int((a * a).sum()), int((b * b).sum())]
+            if want != hs[i].tolist():
+                print(f"verify: pair ({p_a[i]}, {p_b[i]}): {hs[i].tolist()} != host {want}", file=sys.stderr)
+                return False
+        return True
+    if wl == "pca":
+        if env["dist"] is not None or not env["pca_vec"]:
+            return None
+        # identities that hold at any size: orthonormal eigenvectors, positive descending eigenvalues that repeat from
+        # step to step, and their sum bounded by the total variance of the normalised matrix (from the tallies)
+        vec, evs = env["pca_vec"][0], np.array(env["pca_ev"])
+        k = vec.shape[1]
+        ok = bool(np.allclose(vec.T @ vec, np.eye(k), atol=1e-8))
+        ok = ok and bool(np.all(evs[-1] > 0) and np.all(np.diff(evs[-1]) <= 0))
+        ok = ok and bool(np.allclose(evs, evs[-1], rtol=1e-9))
+        counts = env["counts"][env["keep"]]
+        c, inv = env["p_center"], env["p_inv"]
+        total = sum((counts[:, g] * ((g - c) * inv) ** 2).sum() for g in range(3))
+        ok = ok and bool(evs[-1].sum() <= total / env["m_total"] * (1 + 1e-9))
+        if not ok:
+            print(f"verify: plink_pca identities fail: eigenvalues {evs[-1]}, total variance / M {total / env['m_total']}",
+                  file=sys.stderr)
+        return ok
     if wl in ("dosagefreq", "dosagescore"):
         if env["dist"] is not None:
             return None  # as above: the single-GPU line carries the check
@@ -593,6 +626,7 @@ def main():
         i8_ops = ((k + 1) * 2 * i8_contract_ops(n, m_eff, 2 * k, 1, False) + k * i8_contract_ops(m_eff, n, 2 * k, 2, False)
                   + i8_contract_ops(m_eff, n, qq, 2, False))
         pca_ev = []
+        pca_vec = []
 
         def step(timed):
             if timed:
@@ -600,10 +634,11 @@ def main():
                 e1 = torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
             if pca_allreduce is None:
-                ev, _ = ds.pca(p_vidx, p_center, p_inv, k, g1)
+                ev, vec = ds.pca(p_vidx, p_center, p_inv, k, g1)
             else:
-                ev, _ = ds.pca_sharded(p_vidx, p_center, p_inv, m_total, k, g1, pca_allreduce)
+                ev, vec = ds.pca_sharded(p_vidx, p_center, p_inv, m_total, k, g1, pca_allreduce)
             pca_ev.append(ev)
+            pca_vec[:] = [vec]
             if timed:
                 e1.record(stream)
                 kernel_events.append((e0, e1))
