@@ -198,6 +198,48 @@ int pgh_missing_per_sample_dev(const pgh_dataset *ds, uint32_t v_begin, uint32_t
 int pgh_fused_tally_dev(const pgh_dataset *ds, uint32_t v_begin, uint32_t v_end, void *d_counts, void *d_missing,
                         void *stream, char *errbuf);
 
+/* ---- tally pass: one asynchronous walk of the matrix that serves several table functions ----------
+ * The reference's plink_freq, plink_hardy and plink_missing each scan the file for themselves
+ * (src/plink_freq.cpp:434-488, src/plink_hardy.cpp:472-516, src/plink_missing.cpp:463-486 and :585-619), one
+ * blocking PgrGetCounts / PgrGetMissingness per variant.  A tally pass enqueues the whole range at once -- batch by
+ * batch on streams it owns, results landing in pinned host memory the pass keeps -- and returns; scan threads then
+ * wait only for the rows they are about to emit, while the device works on the batches behind them.  A pass is
+ * immutable once its products have landed and may be read by any number of threads, so a caller that keeps it
+ * (the shells cache it per dataset, subset and range) serves later functions without touching the matrix again:
+ * the three scans of BASELINE config 3 cost one read of each byte.
+ *
+ * Products (PGH_TALLY_*): COUNTS is always made: {hom_ref, het, hom_alt, missing} per variant over the (subset of)
+ * samples.  SAMPLE_MISSING: per included sample, the number of variants of the pass at which it is missing
+ * (src/plink_missing.cpp:599-609); without a subset it comes out of the same kernel pass as the counts
+ * (k_fused_tally), with one it is a second sweep.  HWE / HWE_MIDP: plink2::HweLnP of every variant's counts
+ * (src/plink_hardy.cpp:52-79), on a side stream behind each batch's tally.
+ * pgh_tally_start enqueues the products named in `products`; pgh_tally_request adds products later (a no-op for the
+ * ones already there; HWE then runs from the resident counts, SAMPLE_MISSING re-reads the rows).  Both only enqueue.
+ * pgh_tally_wait blocks until the named products of variants [v_begin, v_end) have landed (SAMPLE_MISSING: the whole
+ * pass).  The accessors return pass-owned pinned arrays indexed by (variant - the pass's v_begin); rows are valid
+ * once waited for.  Accepts a shard group: every shard walks its own range on its own device. */
+typedef struct pgh_tally pgh_tally;
+enum { PGH_TALLY_COUNTS = 1, PGH_TALLY_SAMPLE_MISSING = 2, PGH_TALLY_HWE = 4, PGH_TALLY_HWE_MIDP = 8 };
+int pgh_tally_start(const pgh_dataset *ds, const pgh_subset *subset, uint32_t v_begin, uint32_t v_end,
+                    uint32_t products, pgh_tally **out, char *errbuf);
+int pgh_tally_request(pgh_tally *t, uint32_t products, char *errbuf);
+int pgh_tally_wait(pgh_tally *t, uint32_t products, uint32_t v_begin, uint32_t v_end, char *errbuf);
+const uint32_t (*pgh_tally_counts(const pgh_tally *t))[4];
+/* ln p of the exact test per variant (product HWE or HWE_MIDP), NULL when that product was never requested. */
+const double *pgh_tally_hwe_lnp(const pgh_tally *t, uint32_t midp);
+/* Waits for the product; out[k] for the n_out included samples in ascending file order. */
+int pgh_tally_sample_missing(pgh_tally *t, uint32_t *out, char *errbuf);
+/* Waits for everything the pass has enqueued, then releases it. */
+void pgh_tally_destroy(pgh_tally *t);
+/* Passes started by this process so far (a diagnostic: the tests assert that plink_hardy after plink_freq starts none). */
+uint64_t pgh_tally_passes_started(void);
+
+/* Page-locked host memory for callers that hand output buffers to the host-buffer entry points again and again
+ * (read_pgen's chunk buffers: a device-to-host copy into pinned memory runs at the link's rate and without a
+ * staging hop).  Portable across the node's devices.  pgh_host_free(NULL) is a no-op. */
+int pgh_host_alloc(size_t bytes, void **out, char *errbuf);
+void pgh_host_free(void *p);
+
 /* PgrGet + GenoarrToBytesMinus9 over a variant range (src/pgen_reader.cpp:727-733)
  * plus the validity fill of the ARRAY/LIST child (src/pgen_reader.cpp:1009-1047).
  * out: int8 [v_end-v_begin][n_out] with n_out = subset size or N; a missing call is

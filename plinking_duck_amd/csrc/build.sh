@@ -6,7 +6,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -mllvm -amdgpu-mfma-vgpr-form"
 mkdir -p build
 pids=()
-for f in tally.hip unpack.hip score.hip score_i8.hip reduce.hip pca.hip pca_i8.hip decode.hip ld.hip dosage.hip phase.hip api_dataset.cpp api_analysis.cpp api_reader.cpp api_sharded.cpp pgen_file.cpp linalg.cpp; do
+for f in tally.hip unpack.hip score.hip score_i8.hip reduce.hip pca.hip pca_i8.hip decode.hip ld.hip dosage.hip phase.hip api_dataset.cpp api_analysis.cpp api_reader.cpp api_sharded.cpp api_tally.cpp pgen_file.cpp linalg.cpp; do
 	o=build/${f%.*}.o
 	if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ -n "$(find . -maxdepth 1 -name '*.hpp' -newer "$o")" ] || [ ../../include/pgenhip.h -nt "$o" ]; then
 		# translation units are independent: compile them side by side
@@ -21,7 +21,7 @@ done
 for p in "${pids[@]}"; do
 	wait "$p"
 done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libpgenhip.so build/tally.o build/unpack.o build/score.o build/score_i8.o build/reduce.o build/pca.o build/pca_i8.o build/decode.o build/ld.o build/dosage.o build/phase.o build/api_dataset.o build/api_analysis.o build/api_reader.o build/api_sharded.o build/pgen_file.o build/linalg.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libpgenhip.so build/tally.o build/unpack.o build/score.o build/score_i8.o build/reduce.o build/pca.o build/pca_i8.o build/decode.o build/ld.o build/dosage.o build/phase.o build/api_dataset.o build/api_analysis.o build/api_reader.o build/api_sharded.o build/api_tally.o build/pgen_file.o build/linalg.o
 echo "built $(cd .. && pwd)/libpgenhip.so"
 
 # host-side table-function shells (plain C++; link against the C ABI only)

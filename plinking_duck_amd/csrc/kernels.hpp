@@ -60,9 +60,11 @@ hipError_t LaunchClassCounts3(const RowView &view, uint32_t v_first, const uint3
 
 // Both reductions in one pass over [v_first, v_first + v_count): counts[i] = class tallies
 // of row i (all samples), missing_per_sample[s] as above.  Same scratch size as
-// LaunchMissingPerSample.
+// LaunchMissingPerSample.  accumulate: missing_per_sample[s] += this range's tally instead of being
+// overwritten (a pass that walks the matrix batch by batch, api_tally.cpp).
 hipError_t LaunchFusedTally(const RowView &view, uint32_t v_first, uint32_t v_count, uint32_t *scratch,
-                            uint32_t *counts, uint32_t *missing_per_sample, hipStream_t stream);
+                            uint32_t *counts, uint32_t *missing_per_sample, hipStream_t stream,
+                            bool accumulate = false);
 
 // ---- 2-bit -> int8 unpack --------------------------------------------------
 // out row i: int8[N] (+pad to out_pitch, multiple of 16) with missing -> fill;

@@ -149,6 +149,70 @@ void CellToJson(string &out, Vector &v, idx_t row) {
 	}
 }
 
+//! Reads every valid cell of the first `rows` rows once (order-independent sum): the consumer's side of a chunk.
+uint64_t DrainColumn(Vector &v, idx_t rows) {
+	uint64_t sum = 0;
+	auto bits = [](double d) {
+		uint64_t u;
+		std::memcpy(&u, &d, sizeof u);
+		return u;
+	};
+	switch (v.type.id()) {
+	case LogicalTypeId::BOOLEAN:
+	case LogicalTypeId::TINYINT:
+		for (idx_t r = 0; r < rows; r++) {
+			sum += v.validity.RowIsValid(r) ? static_cast<uint8_t>(FlatVector::GetData<int8_t>(v)[r]) : 0x9eu;
+		}
+		break;
+	case LogicalTypeId::INTEGER:
+	case LogicalTypeId::UINTEGER:
+		for (idx_t r = 0; r < rows; r++) {
+			sum += v.validity.RowIsValid(r) ? FlatVector::GetData<uint32_t>(v)[r] : 0x9e37u;
+		}
+		break;
+	case LogicalTypeId::BIGINT:
+		for (idx_t r = 0; r < rows; r++) {
+			sum += v.validity.RowIsValid(r) ? static_cast<uint64_t>(FlatVector::GetData<int64_t>(v)[r]) : 0x9e37u;
+		}
+		break;
+	case LogicalTypeId::DOUBLE:
+		for (idx_t r = 0; r < rows; r++) {
+			sum += v.validity.RowIsValid(r) ? bits(FlatVector::GetData<double>(v)[r]) : 0x9e37u;
+		}
+		break;
+	case LogicalTypeId::VARCHAR:
+		for (idx_t r = 0; r < rows; r++) {
+			if (v.validity.RowIsValid(r)) {
+				const string &str = v.heap[FlatVector::GetData<string_t>(v)[r].index];
+				sum += str.size() + (str.empty() ? 0u : static_cast<uint8_t>(str.back()));
+			}
+		}
+		break;
+	case LogicalTypeId::LIST:
+		for (idx_t r = 0; r < rows; r++) {
+			if (v.validity.RowIsValid(r)) {
+				sum += FlatVector::GetData<list_entry_t>(v)[r].length;
+			}
+		}
+		if (rows) {
+			const auto last = FlatVector::GetData<list_entry_t>(v)[rows - 1];
+			sum += DrainColumn(*v.children[0], last.offset + last.length);
+		}
+		break;
+	case LogicalTypeId::ARRAY:
+		sum += DrainColumn(*v.children[0], rows * v.type.array_size);
+		break;
+	case LogicalTypeId::STRUCT:
+		for (auto &child : v.children) {
+			sum += DrainColumn(*child, rows);
+		}
+		break;
+	default:
+		break;
+	}
+	return sum;
+}
+
 string ErrorJson(const char *kind, const string &msg) {
 	string out = "{\"error\":{\"kind\":";
 	pdkjson::EscapeTo(out, kind);
@@ -260,9 +324,17 @@ string RunQuery(const string &request) {
 	const auto t_init1 = std::chrono::steady_clock::now();
 	idx_t n_threads = std::max<idx_t>(1, std::min<idx_t>(gstate->MaxThreads(), context.db_threads));
 
+	// "drain": true -- consume the chunks as DuckDB's pipeline would (every projected cell is read once) without
+	// serialising rows for the caller: what tools/shell_bench.py times at full size, where a JSON copy of a million
+	// rows would dwarf the scan.  The reply then carries row_count and a checksum instead of rows.
+	bool drain = false;
+	if (const Json *d = req.Get("drain")) {
+		drain = d->kind == Json::BOOL && d->b;
+	}
 	std::mutex result_mutex;
 	vector<string> row_chunks;
 	idx_t total_rows = 0;
+	uint64_t drain_checksum = 0;
 	string first_error, first_error_kind;
 	auto worker = [&]() {
 		try {
@@ -279,6 +351,16 @@ string RunQuery(const string &request) {
 				tf.function(context, in, chunk);
 				if (chunk.size() == 0) {
 					break; // DuckDB marks the thread FINISHED on an empty chunk
+				}
+				if (drain) {
+					uint64_t sum = 0;
+					for (size_t c = 0; c < emit.size(); c++) {
+						sum += DrainColumn(chunk.data[emit[c]], chunk.size());
+					}
+					std::lock_guard<std::mutex> lock(result_mutex);
+					total_rows += chunk.size();
+					drain_checksum += sum;
+					continue;
 				}
 				string rows;
 				for (idx_t r = 0; r < chunk.size(); r++) {
@@ -362,7 +444,11 @@ string RunQuery(const string &request) {
 	// phase times of this call (bind = companions + header probe, init = device residency, scan = threads)
 	out += "],\"bind_ms\":" + std::to_string(ms(t_bind0, t_bind1)) + ",\"init_ms\":" + std::to_string(ms(t_init0, t_init1)) +
 	       ",\"scan_ms\":" + std::to_string(ms(t_init1, t_scan1));
-	out += ",\"threads\":" + std::to_string(n_threads) + ",\"row_count\":" + std::to_string(total_rows) + ",\"rows\":[";
+	out += ",\"threads\":" + std::to_string(n_threads) + ",\"row_count\":" + std::to_string(total_rows);
+	if (drain) {
+		out += ",\"checksum\":" + std::to_string(drain_checksum);
+	}
+	out += ",\"rows\":[";
 	bool first = true;
 	for (auto &rc : row_chunks) {
 		if (!first) {

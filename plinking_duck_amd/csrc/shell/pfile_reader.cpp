@@ -182,7 +182,11 @@ static PfileSource ResolveSource(const string &prefix, const string &pgen_overri
 		if (prefix.empty()) {
 			throw InvalidInputException("read_pfile: no .pgen file path provided");
 		}
-		if (FileExists(prefix + ".pgen")) {
+		SynthSpec synth;
+		if (ParseSynthPath(prefix, synth)) {
+			src.pgen_path = prefix; // a resident synthetic fileset: the spec stands in for all three files
+			eff_prefix.clear();
+		} else if (FileExists(prefix + ".pgen")) {
 			src.pgen_path = prefix + ".pgen";
 		} else if (FileExists(prefix)) {
 			src.pgen_path = prefix; // a full .pgen path given as the prefix

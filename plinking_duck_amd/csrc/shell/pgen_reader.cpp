@@ -200,6 +200,9 @@ unique_ptr<GlobalTableFunctionState> PgenInitGlobal(ClientContext &context, Tabl
 			state->scan.subset =
 			    make_uniq<DeviceSubset>(*state->scan.dataset, bind_data.c.sample_subset->sample_include, bind_data.func);
 		}
+		// the filters' and the counts / stats modes' tallies: the range's pass (shared with plink_freq & co.)
+		state->scan.StartTallies(bind_data.c.sample_subset.get(), nullptr, bind_data.c.raw_sample_ct, nullptr, 0u, false,
+		                         GetPlinkingTallyCache(context), bind_data.func);
 	}
 	return std::move(state);
 }
@@ -268,8 +271,6 @@ void PgenScan(ClientContext &, TableFunctionInput &data_p, DataChunk &output) {
 	const bool per_variant_decode = gstate.need_genotypes && !dosage_rows && phased_out;
 	const bool plain_hardcalls =
 	    gstate.need_genotypes && !IsAggregateGenotypeMode(mode) && !bind_data.include_dosages && !phased_out;
-	auto no_strata = [](uint32_t, uint32_t) { return false; };
-
 	// 1. choose the variants of this chunk (filters run off the batched tallies).  A chunk
 	//    never straddles two claimed batches: their tallies and unpack span are per batch.
 	vector<RowPlan> plan;
@@ -280,7 +281,7 @@ void PgenScan(ClientContext &, TableFunctionInput &data_p, DataChunk &output) {
 		    (lstate.scan.BatchDrained() || (!listed && vidx + 1 - plan.front().vidx >= kUnpackSpan))) {
 			break; // the next Scan call continues
 		}
-		if (!lstate.scan.Next(gstate.scan, bind_data.func, no_strata, vidx)) {
+		if (!lstate.scan.Next(gstate.scan, bind_data.func, vidx)) {
 			break;
 		}
 		bool all_pass = true;

@@ -40,8 +40,8 @@ struct PgenGlobalState : public GlobalTableFunctionState {
 struct PgenLocalState : public LocalTableFunctionState {
 	VariantScanLocal scan;
 	pgh_reader *reader = nullptr;
-	vector<int8_t> bytes;       // unpacked span [rows][n_out]
-	vector<uint64_t> validity;  // [rows][ceil(n_out/64)]
+	PinnedBuffer<int8_t> bytes;      // unpacked span [rows][n_out]; page-locked: the device copies straight into it
+	PinnedBuffer<uint64_t> validity; // [rows][ceil(n_out/64)]
 	vector<double> dosage_doubles;
 	vector<uint64_t> genovec, phasepresent, phaseinfo;
 	~PgenLocalState() override {

@@ -133,7 +133,51 @@ bool FileExists(const string &path) {
 	return ::stat(path.c_str(), &st) == 0 && S_ISREG(st.st_mode);
 }
 
+bool ParseSynthPath(const string &path, SynthSpec &out) {
+	if (path.compare(0, 6, "synth:") != 0) {
+		return false;
+	}
+	// synth:<variants>x<samples>[:<seed>[:<missing rate>]]
+	SynthSpec spec;
+	const char *p = path.c_str() + 6;
+	char *end = nullptr;
+	const unsigned long long m = std::strtoull(p, &end, 10);
+	if (end == p || *end != 'x') {
+		throw InvalidInputException("'%s': expected synth:<variants>x<samples>[:<seed>[:<missing rate>]]", path);
+	}
+	p = end + 1;
+	const unsigned long long n = std::strtoull(p, &end, 10);
+	if (end == p || m == 0 || n == 0 || m > 0x7fffffffull || n > 0x7fffffffull) {
+		throw InvalidInputException("'%s': expected synth:<variants>x<samples>[:<seed>[:<missing rate>]]", path);
+	}
+	spec.variants = static_cast<uint32_t>(m);
+	spec.samples = static_cast<uint32_t>(n);
+	if (*end == ':') {
+		p = end + 1;
+		spec.seed = std::strtoull(p, &end, 10);
+		if (end == p) {
+			throw InvalidInputException("'%s': bad seed", path);
+		}
+		if (*end == ':') {
+			p = end + 1;
+			spec.missing_rate = std::strtod(p, &end);
+			if (end == p || !(spec.missing_rate >= 0.0 && spec.missing_rate <= 1.0)) {
+				throw InvalidInputException("'%s': bad missing rate", path);
+			}
+		}
+	}
+	if (*end != '\0') {
+		throw InvalidInputException("'%s': expected synth:<variants>x<samples>[:<seed>[:<missing rate>]]", path);
+	}
+	out = spec;
+	return true;
+}
+
 string FindCompanionFile(const string &pgen_path, const vector<string> &extensions) {
+	SynthSpec synth;
+	if (ParseSynthPath(pgen_path, synth)) {
+		return pgen_path; // the generator stands in for all three files
+	}
 	for (auto &ext : extensions) {
 		auto candidate = ReplaceExtension(pgen_path, ext);
 		if (FileExists(candidate)) {
@@ -609,7 +653,49 @@ static VariantMetadataIndex ParseOrLoadVariantMetadata(const string &path, const
 	return parsed;
 }
 
+//! The columns pgh_synth_write_files writes for `variants` variants (api_dataset.cpp:WriteSynthCompanions).
+static VariantMetadataIndex SynthVariantMetadata(uint32_t variants) {
+	auto columns = make_shared<VariantColumns>();
+	VariantColumns &c = *columns;
+	c.chroms.reserve(variants);
+	c.ids.reserve(variants);
+	c.positions.reserve(variants);
+	const uint32_t per_chrom = (variants + 21) / 22;
+	for (uint32_t v = 0; v < variants; v++) {
+		c.chroms.push_back(std::to_string(v / per_chrom + 1));
+		c.positions.push_back(static_cast<int32_t>((v % per_chrom + 1) * 100));
+		c.ids.push_back("sv" + std::to_string(v));
+	}
+	c.refs.assign(variants, "A");
+	c.alts.assign(variants, "G");
+	for (uint32_t a = 0; a < variants; a += per_chrom) {
+		c.chrom_offsets.emplace(c.chroms[a], std::make_pair(static_cast<idx_t>(a),
+		                                                    static_cast<idx_t>(std::min(variants, a + per_chrom))));
+	}
+	VariantMetadataIndex out;
+	out.cols = std::move(columns);
+	out.variant_ct = variants;
+	return out;
+}
+
 VariantMetadataIndex LoadVariantMetadata(ClientContext &, const string &path, const string &func_name) {
+	SynthSpec synth;
+	if (ParseSynthPath(path, synth)) {
+		std::unique_lock<std::mutex> lock(g_pvar_cache_mutex);
+		for (auto &e : g_pvar_cache) {
+			if (e.path == path) {
+				return e.index;
+			}
+		}
+		lock.unlock();
+		VariantMetadataIndex made = SynthVariantMetadata(synth.variants);
+		lock.lock();
+		g_pvar_cache.push_back(PvarCacheEntry {path, 0, 0, made});
+		if (g_pvar_cache.size() > kPvarCacheEntries) {
+			g_pvar_cache.erase(g_pvar_cache.begin());
+		}
+		return made;
+	}
 	struct stat st;
 	const bool have_stat = ::stat(path.c_str(), &st) == 0;
 	const int64_t mtime_ns = have_stat ? static_cast<int64_t>(st.st_mtim.tv_sec) * 1000000000LL + st.st_mtim.tv_nsec : 0;
@@ -657,6 +743,24 @@ static bool IsMissingValue(const string &s) {
 }
 
 SampleInfo LoadSampleMetadata(ClientContext &, const string &path) {
+	SynthSpec synth;
+	if (ParseSynthPath(path, synth)) {
+		// '#FID IID SEX' rows of WriteSynthCompanions: F<s/4>, S<s>, 1 + (s & 1)
+		SampleInfo info;
+		info.column_names = {"FID", "IID", "SEX"};
+		info.iids.reserve(synth.samples);
+		info.fids.reserve(synth.samples);
+		info.sexes.reserve(synth.samples);
+		info.rows.reserve(synth.samples);
+		for (uint32_t s = 0; s < synth.samples; s++) {
+			info.fids.push_back("F" + std::to_string(s / 4));
+			info.iids.push_back("S" + std::to_string(s));
+			info.sexes.push_back(static_cast<uint8_t>(1 + (s & 1)));
+			info.rows.push_back({info.fids.back(), info.iids.back(), (s & 1) ? "2" : "1"});
+		}
+		info.sample_ct = synth.samples;
+		return info;
+	}
 	string content;
 	if (!ReadWholeFile(path, content)) {
 		throw IOException("cannot open .psam/.fam file '%s'", path);
@@ -1325,27 +1429,88 @@ ParBounds ResolveParBounds(const string &build, const string &func_name) {
 	                            func_name, build);
 }
 
-ChromPloidy ClassifyChromPloidy(const string &chrom, int32_t pos, const ParBounds &par) {
-	string c = Lower(chrom);
-	if (c.compare(0, 3, "chr") == 0) {
-		c = c.substr(3);
+namespace {
+//! What a chromosome NAME says about ploidy (case and a "chr" prefix do not matter; PLINK's numeric codes
+//! 23-26 count): X still depends on the position (the PARs are diploid), everything not listed is diploid.
+ChromPloidy ChromNameClass(const string &chrom) {
+	static const struct {
+		const char *name;
+		ChromPloidy cls;
+	} kNames[] = {{"x", ChromPloidy::CHR_X},   {"23", ChromPloidy::CHR_X},  {"y", ChromPloidy::CHR_Y},
+	              {"24", ChromPloidy::CHR_Y},  {"mt", ChromPloidy::CHR_MT}, {"m", ChromPloidy::CHR_MT},
+	              {"26", ChromPloidy::CHR_MT}}; // par1 / par2 / xy / 25 and the autosomes: diploid
+	size_t from = 0;
+	if (chrom.size() >= 3 && (chrom[0] | 0x20) == 'c' && (chrom[1] | 0x20) == 'h' && (chrom[2] | 0x20) == 'r') {
+		from = 3;
 	}
-	if (c == "par1" || c == "par2" || c == "xy" || c == "25") {
-		return ChromPloidy::AUTOSOMAL;
-	}
-	if (c == "y" || c == "24") {
-		return ChromPloidy::CHR_Y;
-	}
-	if (c == "mt" || c == "m" || c == "26") {
-		return ChromPloidy::CHR_MT;
-	}
-	if (c == "x" || c == "23") {
-		if (par.active && ((pos > 0 && pos <= par.par1_end) || (pos >= par.par2_start && pos <= par.par2_end))) {
-			return ChromPloidy::AUTOSOMAL;
+	const size_t len = chrom.size() - from;
+	for (auto &e : kNames) {
+		if (std::strlen(e.name) != len) {
+			continue;
 		}
-		return ChromPloidy::CHR_X;
+		bool same = true;
+		for (size_t i = 0; i < len && same; i++) {
+			const char c = chrom[from + i];
+			same = ((c >= 'A' && c <= 'Z') ? static_cast<char>(c | 0x20) : c) == e.name[i];
+		}
+		if (same) {
+			return e.cls;
+		}
 	}
 	return ChromPloidy::AUTOSOMAL;
+}
+
+inline bool InPar(int32_t pos, const ParBounds &par) {
+	return par.active && ((pos > 0 && pos <= par.par1_end) || (pos >= par.par2_start && pos <= par.par2_end));
+}
+} // namespace
+
+ChromPloidy ClassifyChromPloidy(const string &chrom, int32_t pos, const ParBounds &par) {
+	const ChromPloidy cls = ChromNameClass(chrom);
+	return cls == ChromPloidy::CHR_X && InPar(pos, par) ? ChromPloidy::AUTOSOMAL : cls;
+}
+
+PloidyMap::PloidyMap(const VariantMetadataIndex &variants, const ParBounds &par) : cols_(variants.cols), par_(par) {
+	for (auto &kv : variants.chrom_offsets()) {
+		const ChromPloidy cls = ChromNameClass(kv.first);
+		if (cls != ChromPloidy::AUTOSOMAL) {
+			runs_.push_back(Run {static_cast<uint32_t>(kv.second.first), static_cast<uint32_t>(kv.second.second), cls});
+		}
+	}
+	std::sort(runs_.begin(), runs_.end(), [](const Run &a, const Run &b) { return a.begin < b.begin; });
+}
+
+ChromPloidy PloidyMap::At(uint32_t vidx) const {
+	for (auto &r : runs_) { // a handful at most (X, Y, MT)
+		if (vidx >= r.begin && vidx < r.end) {
+			return r.name_class == ChromPloidy::CHR_X && InPar(cols_->positions[vidx], par_) ? ChromPloidy::AUTOSOMAL
+			                                                                                  : r.name_class;
+		}
+	}
+	return ChromPloidy::AUTOSOMAL;
+}
+
+bool PloidyMap::NonAutosomalSpan(uint32_t begin, uint32_t end, uint32_t &first, uint32_t &last) const {
+	bool any = false;
+	for (auto &r : runs_) {
+		uint32_t a = std::max(begin, r.begin), b = std::min(end, r.end);
+		if (r.name_class == ChromPloidy::CHR_X && par_.active) {
+			// positions ascend inside a run: trim the PAR rows off both ends
+			while (a < b && InPar(cols_->positions[a], par_)) {
+				a++;
+			}
+			while (b > a && InPar(cols_->positions[b - 1], par_)) {
+				b--;
+			}
+		}
+		if (a >= b) {
+			continue;
+		}
+		first = any ? std::min(first, a) : a;
+		last = any ? std::max(last, b) : b;
+		any = true;
+	}
+	return any;
 }
 
 vector<uint8_t> BuildAlignedSex(const SampleInfo &sample_info, const vector<uint32_t> *subset_sorted) {
@@ -1430,6 +1595,18 @@ void ThrowOnPghError(int rc, const char *errbuf, const string &func_name, const 
 
 pgh_info ProbePgen(const string &pgen_path, const string &func_name) {
 	pgh_info info;
+	SynthSpec synth;
+	if (ParseSynthPath(pgen_path, synth)) {
+		std::memset(&info, 0, sizeof info);
+		info.raw_variant_ct = synth.variants;
+		info.raw_sample_ct = synth.samples;
+		info.variant_end = synth.variants;
+		info.record_bytes = (synth.samples + 3) / 4;
+		info.max_record_bytes = info.record_bytes;
+		info.vrtype_hist[0] = synth.variants;
+		info.device = -1;
+		return info;
+	}
 	char errbuf[PGH_ERRBUF_LEN] = {0};
 	int rc = pgh_probe(pgen_path.c_str(), nullptr, &info, errbuf);
 	if (rc != PGH_OK) {
@@ -1439,9 +1616,99 @@ pgh_info ProbePgen(const string &pgen_path, const string &func_name) {
 }
 
 DeviceDataset::~DeviceDataset() {
+	tallies_.clear(); // passes read the matrix: they go first (queries that still hold one keep the dataset too)
 	if (handle) {
 		pgh_close(handle);
 	}
+}
+
+// ---- tally passes ------------------------------------------------------------------------------
+
+bool GetPlinkingTallyCache(ClientContext &context) {
+	const char *env = std::getenv("PLINKING_TALLY_CACHE");
+	if (env && env[0] == '0') {
+		return false;
+	}
+	Value val;
+	if (context.TryGetCurrentSetting("plinking_tally_cache", val) && !val.IsNull()) {
+		return val.GetValue<bool>();
+	}
+	return true;
+}
+
+DeviceTally::DeviceTally(DeviceDataset &ds, const vector<uint64_t> *sample_include, uint32_t begin_p, uint32_t end_p,
+                         uint32_t products, const string &func_name)
+    : begin(begin_p), end(end_p) {
+	if (sample_include) {
+		mask = *sample_include;
+		subset_ = make_uniq<DeviceSubset>(ds, mask, func_name);
+	}
+	char errbuf[PGH_ERRBUF_LEN] = {0};
+	int rc = pgh_tally_start(ds.handle, subset_ ? subset_->handle : nullptr, begin, end, products, &handle, errbuf);
+	if (rc != PGH_OK) {
+		throw IOException("%s: PgrGetCounts failed for variants [%u, %u): %s", func_name, begin, end, string(errbuf));
+	}
+	counts_ = pgh_tally_counts(handle);
+}
+
+DeviceTally::~DeviceTally() {
+	if (handle) {
+		pgh_tally_destroy(handle); // drains the pass before the subset below goes
+	}
+}
+
+void DeviceTally::Request(uint32_t products, const string &func_name) {
+	char errbuf[PGH_ERRBUF_LEN] = {0};
+	if (pgh_tally_request(handle, products, errbuf) != PGH_OK) {
+		throw IOException("%s: tally pass over variants [%u, %u) failed: %s", func_name, begin, end, string(errbuf));
+	}
+}
+
+void DeviceTally::Wait(uint32_t products, uint32_t v_begin, uint32_t v_end, const string &func_name) {
+	char errbuf[PGH_ERRBUF_LEN] = {0};
+	if (pgh_tally_wait(handle, products, v_begin, v_end, errbuf) != PGH_OK) {
+		throw IOException("%s: PgrGetCounts failed for variants [%u, %u): %s", func_name, v_begin, v_end,
+		                  string(errbuf));
+	}
+}
+
+void DeviceTally::SampleMissing(uint32_t *out, const string &func_name) {
+	char errbuf[PGH_ERRBUF_LEN] = {0};
+	if (pgh_tally_sample_missing(handle, out, errbuf) != PGH_OK) {
+		throw IOException("%s: PgrGetMissingness failed: %s", func_name, string(errbuf));
+	}
+}
+
+shared_ptr<DeviceTally> DeviceDataset::AcquireTally(const vector<uint64_t> *sample_include, uint32_t begin,
+                                                    uint32_t end, uint32_t products, bool exact_range, bool use_cache,
+                                                    const string &func_name) {
+	static const vector<uint64_t> kAll;
+	const vector<uint64_t> &want_mask = sample_include ? *sample_include : kAll;
+	if (use_cache) {
+		std::lock_guard<std::mutex> lock(tally_mutex_);
+		for (size_t i = 0; i < tallies_.size(); i++) {
+			auto &t = tallies_[i];
+			const bool covers = exact_range ? (t->begin == begin && t->end == end) : (t->begin <= begin && t->end >= end);
+			if (covers && t->mask == want_mask) {
+				auto hit = t;
+				tallies_.erase(tallies_.begin() + static_cast<std::ptrdiff_t>(i));
+				tallies_.push_back(hit);
+				hit->Request(products, func_name);
+				return hit;
+			}
+		}
+	}
+	// (outside the lock: starting a pass only enqueues, but it allocates)
+	auto made = make_shared<DeviceTally>(*this, sample_include, begin, end, products, func_name);
+	if (use_cache) {
+		std::lock_guard<std::mutex> lock(tally_mutex_);
+		tallies_.push_back(made);
+		constexpr size_t kTallyEntries = 6; // 40 B per variant of pinned host memory each, at most
+		if (tallies_.size() > kTallyEntries) {
+			tallies_.erase(tallies_.begin());
+		}
+	}
+	return made;
 }
 
 namespace {
@@ -1516,17 +1783,51 @@ void SetPlinkingDevices(const string &spec) {
 vector<int> GetPlinkingDevices() {
 	std::lock_guard<std::mutex> lock(g_devices_mutex);
 	if (!g_devices_from_env) {
-		g_devices_from_env = true;
 		if (const char *env = std::getenv("PLINKING_DEVICES")) {
-			g_devices = ParseDeviceList(env);
+			g_devices = ParseDeviceList(env); // throws on a malformed list -- every time, not only the first
 		}
+		g_devices_from_env = true;
 	}
 	return g_devices;
 }
 
+//! pgh_synth_create of the spec: one dataset, or near-equal contiguous ranges on the listed devices as a group.
+static int OpenSynth(const SynthSpec &spec, const vector<int> &devices, pgh_dataset **out, char *errbuf) {
+	if (devices.empty()) {
+		return pgh_synth_create(0, spec.variants, spec.samples, spec.seed, spec.missing_rate, out, errbuf);
+	}
+	vector<pgh_dataset *> shards;
+	int rc = PGH_OK;
+	const uint64_t k_total = devices.size();
+	for (uint64_t k = 0; k < k_total && rc == PGH_OK; k++) {
+		const uint32_t b = static_cast<uint32_t>(spec.variants * k / k_total);
+		const uint32_t e = static_cast<uint32_t>(spec.variants * (k + 1) / k_total);
+		pgh_dataset *sh = nullptr;
+		rc = pgh_set_device(devices[k], errbuf);
+		if (rc == PGH_OK) {
+			rc = pgh_synth_create(b, e, spec.samples, spec.seed, spec.missing_rate, &sh, errbuf);
+		}
+		if (rc == PGH_OK) {
+			shards.push_back(sh);
+		}
+	}
+	if (rc == PGH_OK) {
+		rc = pgh_group_create(shards.data(), static_cast<uint32_t>(shards.size()), out, errbuf);
+	}
+	if (rc != PGH_OK) {
+		for (auto *sh : shards) {
+			pgh_close(sh);
+		}
+	}
+	return rc;
+}
+
 shared_ptr<DeviceDataset> DeviceDataset::Acquire(const string &pgen_path, const string &func_name) {
 	struct stat st;
-	if (::stat(pgen_path.c_str(), &st) != 0) {
+	std::memset(&st, 0, sizeof st);
+	SynthSpec synth;
+	const bool is_synth = ParseSynthPath(pgen_path, synth);
+	if (!is_synth && ::stat(pgen_path.c_str(), &st) != 0) {
 		throw IOException("%s: failed to open '%s': %s", func_name, pgen_path, string(std::strerror(errno)));
 	}
 	const vector<int> devices = GetPlinkingDevices();
@@ -1556,15 +1857,40 @@ shared_ptr<DeviceDataset> DeviceDataset::Acquire(const string &pgen_path, const 
 	}
 	g_cache.push_back({key, nullptr, 0});
 	lock.unlock();
+	// Whatever happens between here and the relock -- an allocation that throws included -- the placeholder must
+	// not stay behind without a dataset: binds of this file wait on it.
+	struct PlaceholderGuard {
+		const CacheKey &key;
+		bool armed = true;
+		~PlaceholderGuard() {
+			if (!armed) {
+				return;
+			}
+			std::lock_guard<std::mutex> relock(g_cache_mutex);
+			for (size_t i = 0; i < g_cache.size(); i++) {
+				if (g_cache[i].key == key && !g_cache[i].ds) {
+					g_cache.erase(g_cache.begin() + static_cast<std::ptrdiff_t>(i));
+					break;
+				}
+			}
+			g_cache_opened.notify_all();
+		}
+	} guard {key};
 	auto ds = make_shared<DeviceDataset>();
 	ds->path = pgen_path;
 	char errbuf[PGH_ERRBUF_LEN] = {0};
 	// one resident matrix on the current device, or one contiguous variant shard per listed device behind one
 	// handle: every pgh_* call the table functions make accepts either
-	int rc = devices.empty() ? pgh_open(pgen_path.c_str(), nullptr, 0, UINT32_MAX, &ds->handle, errbuf)
-	                         : pgh_open_sharded(pgen_path.c_str(), nullptr, 0, UINT32_MAX, devices.data(),
-	                                            static_cast<uint32_t>(devices.size()), &ds->handle, errbuf);
+	int rc;
+	if (is_synth) {
+		rc = OpenSynth(synth, devices, &ds->handle, errbuf);
+	} else {
+		rc = devices.empty() ? pgh_open(pgen_path.c_str(), nullptr, 0, UINT32_MAX, &ds->handle, errbuf)
+		                     : pgh_open_sharded(pgen_path.c_str(), nullptr, 0, UINT32_MAX, devices.data(),
+		                                        static_cast<uint32_t>(devices.size()), &ds->handle, errbuf);
+	}
 	lock.lock();
+	guard.armed = false;
 	size_t mine = g_cache.size();
 	for (size_t i = 0; i < g_cache.size(); i++) {
 		if (g_cache[i].key == key && !g_cache[i].ds) {

@@ -89,6 +89,19 @@ SampleInfo LoadSampleMetadata(ClientContext &context, const string &path);
 string FindCompanionFile(const string &pgen_path, const vector<string> &extensions);
 bool FileExists(const string &path);
 
+//! A resident synthetic fileset instead of files on disk: 'synth:<variants>x<samples>[:<seed>[:<missing rate>]]'
+//! in the place of the .pgen path.  The matrix is pgh_synth_create's (written straight into HBM), the .pvar / .psam
+//! columns are the ones pgh_synth_write_files would have written -- so every table function runs over BASELINE's
+//! 1,000,000 x 500,000 shape through bind / init / scan without a 125 GB file (tools/shell_bench.py), and a small
+//! spec can be compared with the same fileset on disk.  Not a reference feature; companions of a synth: path are
+//! the path itself.
+struct SynthSpec {
+	uint32_t variants = 0, samples = 0;
+	uint64_t seed = 20260807;
+	double missing_rate = 0.02;
+};
+bool ParseSynthPath(const string &path, SynthSpec &out);
+
 // ---- samples / regions ------------------------------------------------------------
 
 //! src/plink_common.cpp:1161-1216
@@ -193,8 +206,33 @@ struct ParBounds {
 };
 //! src/plink_common.cpp:1928-1958
 ParBounds ResolveParBounds(const string &build, const string &func_name);
-//! src/plink_common.cpp:1960-1979
+//! src/plink_common.cpp:1960-1979 (one variant)
 ChromPloidy ClassifyChromPloidy(const string &chrom, int32_t pos, const ParBounds &par);
+
+//! The ploidy class of every variant of a file, decided once per CHROM run instead of once per row (a .pvar's
+//! chromosomes are contiguous runs, LoadVariantMetadata refuses anything else): only rows of an X run consult the
+//! PAR bounds.  Shared read-only by the scan threads.
+class PloidyMap {
+public:
+	PloidyMap() = default;
+	PloidyMap(const VariantMetadataIndex &variants, const ParBounds &par);
+	ChromPloidy At(uint32_t vidx) const;
+	//! [first, last) = the smallest range that holds every non-autosomal variant of [begin, end); false if none
+	bool NonAutosomalSpan(uint32_t begin, uint32_t end, uint32_t &first, uint32_t &last) const;
+	bool AnyNonAutosomal(uint32_t begin, uint32_t end) const {
+		uint32_t a, b;
+		return NonAutosomalSpan(begin, end, a, b);
+	}
+
+private:
+	struct Run {
+		uint32_t begin, end;
+		ChromPloidy name_class; // CHR_X: subject to the PAR test per position
+	};
+	vector<Run> runs_; // the non-autosomal runs only, ascending
+	shared_ptr<const VariantColumns> cols_;
+	ParBounds par_;
+};
 //! src/plink_common.cpp:1981-1994
 vector<uint8_t> BuildAlignedSex(const SampleInfo &sample_info, const vector<uint32_t> *subset_sorted);
 
@@ -220,6 +258,8 @@ void ThrowOnPghError(int rc, const char *errbuf, const string &func_name, const 
 
 //! A genotype matrix resident in HBM, shared by every scan thread of a query and
 //! kept across queries on the same file (process-wide cache).
+class DeviceTally;
+class DeviceSubset;
 class DeviceDataset {
 public:
 	~DeviceDataset();
@@ -227,6 +267,48 @@ public:
 	pgh_info info;
 	string path;
 	static shared_ptr<DeviceDataset> Acquire(const string &pgen_path, const string &func_name);
+
+	//! The tally pass over [begin, end) for this sample mask (nullptr = every sample), started if nobody has one:
+	//! plink_freq, plink_hardy, plink_missing and read_pgen's filters on the same file, subset and range share ONE
+	//! walk of the matrix (pgh_tally_*), whichever of them comes first, in this query or an earlier one.  A pass
+	//! that covers more than the asked range serves per-variant products too (`exact_range` = false); the
+	//! per-sample product needs the range itself.  `products`: PGH_TALLY_* wanted now (more can be requested from
+	//! the pass later).  Kept per dataset, least recently used dropped beyond a few entries; the option
+	//! plinking_tally_cache = false (or PLINKING_TALLY_CACHE=0) gives every call a pass of its own.
+	shared_ptr<DeviceTally> AcquireTally(const vector<uint64_t> *sample_include, uint32_t begin, uint32_t end,
+	                                     uint32_t products, bool exact_range, bool use_cache, const string &func_name);
+
+private:
+	std::mutex tally_mutex_;
+	vector<shared_ptr<DeviceTally>> tallies_; // most recently used last
+};
+
+//! RAII pgh_tally plus the subset it was started with (the enqueued work reads the subset's device mask).
+class DeviceTally {
+public:
+	DeviceTally(DeviceDataset &ds, const vector<uint64_t> *sample_include, uint32_t begin, uint32_t end,
+	            uint32_t products, const string &func_name);
+	~DeviceTally();
+	DeviceTally(const DeviceTally &) = delete;
+	//! enqueue-only; idempotent
+	void Request(uint32_t products, const string &func_name);
+	//! blocks until the products of [v_begin, v_end) are in host memory
+	void Wait(uint32_t products, uint32_t v_begin, uint32_t v_end, const string &func_name);
+	const uint32_t *Counts(uint32_t vidx) const {
+		return counts_[vidx - begin];
+	}
+	double LnP(uint32_t vidx, bool midp) const {
+		return pgh_tally_hwe_lnp(handle, midp ? 1u : 0u)[vidx - begin];
+	}
+	void SampleMissing(uint32_t *out, const string &func_name);
+
+	pgh_tally *handle = nullptr;
+	uint32_t begin = 0, end = 0;
+	vector<uint64_t> mask; // empty = all samples
+
+private:
+	unique_ptr<DeviceSubset> subset_;
+	const uint32_t (*counts_)[4] = nullptr;
 };
 
 //! The extension option `plinking_devices` (next to plinking_max_threads, the reference's only option:
@@ -239,6 +321,10 @@ void SetPlinkingDevices(const string &spec);
 //! The current list (empty = single current device); PLINKING_DEVICES in the environment is the initial value.
 vector<int> GetPlinkingDevices();
 
+//! The extension option `plinking_tally_cache` (default true; PLINKING_TALLY_CACHE=0 in the environment turns it
+//! off process-wide): whether tally passes are shared across table-function calls on the same file.
+bool GetPlinkingTallyCache(ClientContext &context);
+
 //! RAII pgh_subset
 class DeviceSubset {
 public:
@@ -246,6 +332,47 @@ public:
 	~DeviceSubset();
 	DeviceSubset(const DeviceSubset &) = delete;
 	pgh_subset *handle = nullptr;
+};
+
+//! A grow-only buffer of page-locked host memory (pgh_host_alloc): what a scan thread hands to the host-buffer
+//! entry points chunk after chunk, so the device-to-host copies run at the link's rate with no staging hop
+//! (the reference's counterpart is the per-thread AlignedBuffer, src/plink_common.hpp:65-118).
+template <class T>
+class PinnedBuffer {
+public:
+	PinnedBuffer() = default;
+	PinnedBuffer(const PinnedBuffer &) = delete;
+	PinnedBuffer &operator=(const PinnedBuffer &) = delete;
+	~PinnedBuffer() {
+		pgh_host_free(p_);
+	}
+	//! at least n elements; contents are not kept
+	void resize(size_t n) {
+		if (n <= cap_) {
+			return;
+		}
+		pgh_host_free(p_);
+		p_ = nullptr;
+		cap_ = 0;
+		void *q = nullptr;
+		char errbuf[PGH_ERRBUF_LEN] = {0};
+		if (pgh_host_alloc(n * sizeof(T), &q, errbuf) != PGH_OK) {
+			throw IOException("cannot allocate %llu bytes of pinned host memory: %s",
+			                  static_cast<unsigned long long>(n * sizeof(T)), string(errbuf));
+		}
+		p_ = static_cast<T *>(q);
+		cap_ = n;
+	}
+	T *data() {
+		return p_;
+	}
+	const T *data() const {
+		return p_;
+	}
+
+private:
+	T *p_ = nullptr;
+	size_t cap_ = 0;
 };
 
 //! Header probe (replaces the bind-time PgfiInitPhase1/2 of every function).

@@ -24,6 +24,7 @@ struct PlinkFreqBindData : public TableFunctionData {
 	bool include_counts = false;
 	bool include_dosage = false;
 	ParBounds par_bounds;
+	PloidyMap ploidy; // per CHROM run, built once at bind
 	bool have_sex = false;
 	idx_t imp_r2_col_idx = 0;
 };
@@ -61,6 +62,7 @@ static unique_ptr<FunctionData> PlinkFreqBind(ClientContext &context, TableFunct
 	bind_data->par_bounds = ResolveParBounds(build_str, "plink_freq");
 	bind_data->c.Bind(context, input, "plink_freq", false);
 	bind_data->have_sex = bind_data->c.has_sample_info && !bind_data->c.sample_info.sexes.empty();
+	bind_data->ploidy = PloidyMap(bind_data->c.variants, bind_data->par_bounds);
 
 	names = {"CHROM", "POS", "ID", "REF", "ALT", "ALT_FREQ", "OBS_CT"};
 	return_types = {LogicalType::VARCHAR, LogicalType::INTEGER, LogicalType::VARCHAR, LogicalType::VARCHAR,
@@ -104,10 +106,14 @@ static unique_ptr<GlobalTableFunctionState> PlinkFreqInitGlobal(ClientContext &c
 			state->scan.subset =
 			    make_uniq<DeviceSubset>(*state->scan.dataset, bind_data.c.sample_subset->sample_include, "plink_freq");
 		}
-		if (bind_data.have_sex) {
-			BuildSexStrata(state->scan, bind_data.c.sample_info, bind_data.c.sample_subset.get(),
-			               bind_data.c.raw_sample_ct, "plink_freq");
-		}
+		// the range's tallies start now and land while the scan threads emit (variant_scan.hpp); with no sample
+		// subset the same pass tallies missing calls per sample too, so plink_hardy / plink_missing on this file
+		// need no pass of their own (the reference scans three times: src/plink_freq.cpp:482,
+		// src/plink_hardy.cpp:510, src/plink_missing.cpp:479,593-609)
+		state->scan.StartTallies(bind_data.c.sample_subset.get(), bind_data.have_sex ? &bind_data.c.sample_info : nullptr,
+		                         bind_data.c.raw_sample_ct, &bind_data.ploidy,
+		                         bind_data.c.has_sample_subset ? 0u : static_cast<uint32_t>(PGH_TALLY_SAMPLE_MISSING), false,
+		                         GetPlinkingTallyCache(context), "plink_freq");
 		state->dosage_on_device = bind_data.include_dosage && bind_data.c.file_has_dosage;
 	}
 	return std::move(state);
@@ -127,16 +133,6 @@ static void PlinkFreqScan(ClientContext &, TableFunctionInput &data_p, DataChunk
 	auto &column_ids = gstate.column_ids;
 	auto &variants = bind_data.c.variants;
 
-	auto needs_strata = [&](uint32_t begin, uint32_t end) {
-		for (uint32_t v = begin; v < end; v++) {
-			if (ClassifyChromPloidy(variants.GetChrom(v), variants.GetPos(v), bind_data.par_bounds) !=
-			    ChromPloidy::AUTOSOMAL) {
-				return true;
-			}
-		}
-		return false;
-	};
-
 	// Two steps per chunk, the columnar way round: first the derived values of every row the
 	// chunk will hold (the tallies are already there, batch by batch), then one tight loop per
 	// projected column.
@@ -153,14 +149,14 @@ static void PlinkFreqScan(ClientContext &, TableFunctionInput &data_p, DataChunk
 	rows.reserve(STANDARD_VECTOR_SIZE);
 	vector<uint32_t> dosage_rows, dosage_vidx; // rows whose frequency comes from the dosage tracks
 	uint32_t vidx;
-	while (rows.size() < STANDARD_VECTOR_SIZE && lstate.scan.Next(gstate.scan, "plink_freq", needs_strata, vidx)) {
+	while (rows.size() < STANDARD_VECTOR_SIZE && lstate.scan.Next(gstate.scan, "plink_freq", vidx)) {
 		FreqRow row;
 		row.vidx = vidx;
 		if (!gstate.need_frequencies) {
 			rows.push_back(row);
 			continue;
 		}
-		const ChromPloidy ploidy = ClassifyChromPloidy(variants.GetChrom(vidx), variants.GetPos(vidx), bind_data.par_bounds);
+		const ChromPloidy ploidy = bind_data.ploidy.At(vidx);
 		const uint32_t *gc = lstate.scan.Counts(vidx);
 		for (int k = 0; k < 4; k++) {
 			row.counts[k] = static_cast<int32_t>(gc[k]);
@@ -169,10 +165,8 @@ static void PlinkFreqScan(ClientContext &, TableFunctionInput &data_p, DataChunk
 		if (ploidy != ChromPloidy::AUTOSOMAL) {
 			// chrX / chrY / chrMT: ploidy-aware allele counts from the sex strata
 			// (ComputeSexAwareCounts, src/plink_freq.cpp:463-472); IMP_R2 is not defined here
-			static const uint32_t zero[4] = {0, 0, 0, 0};
-			const bool strata = lstate.scan.have_strata;
-			SexAwareCounts sac = SexAwareFromStrata(ploidy, gc, strata ? lstate.scan.MaleCounts(vidx) : zero,
-			                                        strata ? lstate.scan.FemaleCounts(vidx) : zero, bind_data.have_sex);
+			SexAwareCounts sac = SexAwareFromStrata(ploidy, gc, lstate.scan.MaleCounts(vidx),
+			                                        lstate.scan.FemaleCounts(vidx), bind_data.have_sex);
 			row.r2_is_null = true;
 			row.counts_are_null = sac.sex_unavailable;
 			row.freq_is_null = sac.sex_unavailable || sac.obs_allele_ct == 0;

@@ -1,12 +1,14 @@
 // plink_hardy.cpp -- plink_hardy(path, pvar, psam, samples, region, midp, build)
 //
-// Surface of the reference's src/plink_hardy.cpp; counts come from the batched
-// device tally, and the exact tests of a whole device batch from two more launches
-// (pgh_hwe_lnp_batch / pgh_hwe_xchr_lnp_batch, the replacements for one
-// plink2::HweLnP / HweXchrLnP call per variant).
+// Surface of the reference's src/plink_hardy.cpp; counts and the autosomal exact
+// tests come from the range's tally pass (the device runs each batch's tests behind
+// its tally, variant_scan.hpp), the chrX tests of a device batch from one more
+// launch (pgh_hwe_xchr_lnp_batch) -- the replacements for one plink2::HweLnP /
+// HweXchrLnP call per variant.
 #include "variant_scan.hpp"
 
 #include <cmath>
+#include <limits>
 
 namespace duckdb {
 
@@ -32,6 +34,7 @@ struct PlinkHardyBindData : public TableFunctionData {
 	PgenBindCommon c;
 	bool midp = false;
 	ParBounds par_bounds;
+	PloidyMap ploidy;
 	bool have_sex = false;
 };
 
@@ -49,9 +52,9 @@ struct PlinkHardyGlobalState : public GlobalTableFunctionState {
 
 struct PlinkHardyLocalState : public LocalTableFunctionState {
 	VariantScanLocal scan;
-	// ln p of every variant of the claimed device batch (autosomal rule; chrX rows overwritten)
-	uint32_t lnp_batch_begin = UINT32_MAX;
-	vector<double> lnp;
+	// ln p of the chrX rows of the claimed device batch, by (variant - batch_begin); NaN elsewhere
+	uint32_t x_batch_begin = UINT32_MAX;
+	vector<double> x_lnp;
 };
 
 static unique_ptr<FunctionData> PlinkHardyBind(ClientContext &context, TableFunctionBindInput &input,
@@ -68,6 +71,7 @@ static unique_ptr<FunctionData> PlinkHardyBind(ClientContext &context, TableFunc
 	bind_data->par_bounds = ResolveParBounds(build_str, "plink_hardy");
 	bind_data->c.Bind(context, input, "plink_hardy", false);
 	bind_data->have_sex = bind_data->c.has_sample_info && !bind_data->c.sample_info.sexes.empty();
+	bind_data->ploidy = PloidyMap(bind_data->c.variants, bind_data->par_bounds);
 	names = {"CHROM", "POS", "ID", "REF", "ALT", "A1", "HOM_REF_CT", "HET_CT", "HOM_ALT_CT", "O_HET", "E_HET", "P_HWE"};
 	return_types = {LogicalType::VARCHAR, LogicalType::INTEGER, LogicalType::VARCHAR, LogicalType::VARCHAR,
 	                LogicalType::VARCHAR, LogicalType::VARCHAR, LogicalType::INTEGER, LogicalType::INTEGER,
@@ -97,10 +101,13 @@ static unique_ptr<GlobalTableFunctionState> PlinkHardyInitGlobal(ClientContext &
 			state->scan.subset =
 			    make_uniq<DeviceSubset>(*state->scan.dataset, bind_data.c.sample_subset->sample_include, "plink_hardy");
 		}
-		if (bind_data.have_sex) {
-			BuildSexStrata(state->scan, bind_data.c.sample_info, bind_data.c.sample_subset.get(),
-			               bind_data.c.raw_sample_ct, "plink_hardy");
+		uint32_t products = bind_data.c.has_sample_subset ? 0u : static_cast<uint32_t>(PGH_TALLY_SAMPLE_MISSING);
+		if (state->need_p_hwe) {
+			products |= bind_data.midp ? PGH_TALLY_HWE_MIDP : PGH_TALLY_HWE;
 		}
+		state->scan.StartTallies(bind_data.c.sample_subset.get(), bind_data.have_sex ? &bind_data.c.sample_info : nullptr,
+		                         bind_data.c.raw_sample_ct, &bind_data.ploidy, products, false,
+		                         GetPlinkingTallyCache(context), "plink_hardy");
 	}
 	return std::move(state);
 }
@@ -110,27 +117,20 @@ static unique_ptr<LocalTableFunctionState> PlinkHardyInitLocal(ExecutionContext 
 	return make_uniq<PlinkHardyLocalState>();
 }
 
-//! The exact tests of the batch the thread has just claimed: the autosomal rule for every row in
-//! one launch, then the chrX rule for the rows it applies to (females' genotypes + males' alleles).
-static void PrepareBatchTests(const PlinkHardyBindData &bind_data, PlinkHardyLocalState &lstate) {
+//! The chrX exact tests of the batch the thread has just claimed (females' genotypes + males' alleles), in one
+//! launch; the autosomal rule's ln p of every row is already in the tally pass.
+static void PrepareXchrTests(const PlinkHardyBindData &bind_data, PlinkHardyLocalState &lstate) {
 	auto &scan = lstate.scan;
-	auto &variants = bind_data.c.variants;
 	const uint32_t n = scan.batch_end - scan.batch_begin;
-	lstate.lnp_batch_begin = scan.batch_begin;
-	lstate.lnp.assign(n, 0.0);
-	char errbuf[PGH_ERRBUF_LEN] = {0};
-	if (pgh_hwe_lnp_batch(reinterpret_cast<const uint32_t(*)[4]>(scan.counts.data()), n, bind_data.midp ? 1u : 0u,
-	                      lstate.lnp.data(), errbuf) != PGH_OK) {
-		throw IOException("plink_hardy: exact tests failed for variants [%u, %u): %s", scan.batch_begin,
-		                  scan.batch_end, string(errbuf));
-	}
+	lstate.x_batch_begin = scan.batch_begin;
+	lstate.x_lnp.assign(n, std::numeric_limits<double>::quiet_NaN());
 	if (!scan.have_strata) {
 		return;
 	}
 	vector<int32_t> strata;
 	vector<uint32_t> where;
 	for (uint32_t v = scan.batch_begin; v < scan.batch_end; v++) {
-		ChromPloidy ploidy = ClassifyChromPloidy(variants.GetChrom(v), variants.GetPos(v), bind_data.par_bounds);
+		const ChromPloidy ploidy = bind_data.ploidy.At(v);
 		if (ploidy == ChromPloidy::AUTOSOMAL) {
 			continue;
 		}
@@ -150,14 +150,15 @@ static void PrepareBatchTests(const PlinkHardyBindData &bind_data, PlinkHardyLoc
 	if (where.empty()) {
 		return;
 	}
-	vector<double> x_lnp(where.size());
+	vector<double> got(where.size());
+	char errbuf[PGH_ERRBUF_LEN] = {0};
 	if (pgh_hwe_xchr_lnp_batch(reinterpret_cast<const int32_t(*)[5]>(strata.data()), static_cast<uint32_t>(where.size()),
-	                           bind_data.midp ? 1u : 0u, x_lnp.data(), errbuf) != PGH_OK) {
+	                           bind_data.midp ? 1u : 0u, got.data(), errbuf) != PGH_OK) {
 		throw IOException("plink_hardy: chrX exact tests failed for variants [%u, %u): %s", scan.batch_begin,
 		                  scan.batch_end, string(errbuf));
 	}
 	for (size_t k = 0; k < where.size(); k++) {
-		lstate.lnp[where[k]] = x_lnp[k];
+		lstate.x_lnp[where[k]] = got[k];
 	}
 }
 
@@ -167,16 +168,6 @@ static void PlinkHardyScan(ClientContext &, TableFunctionInput &data_p, DataChun
 	auto &lstate = data_p.local_state->Cast<PlinkHardyLocalState>();
 	auto &column_ids = gstate.column_ids;
 	auto &variants = bind_data.c.variants;
-
-	auto needs_strata = [&](uint32_t begin, uint32_t end) {
-		for (uint32_t v = begin; v < end; v++) {
-			if (ClassifyChromPloidy(variants.GetChrom(v), variants.GetPos(v), bind_data.par_bounds) !=
-			    ChromPloidy::AUTOSOMAL) {
-				return true;
-			}
-		}
-		return false;
-	};
 
 	// The chunk's rows first (counts of the HWE-test stratum, heterozygosities, the batch's exact
 	// test), then one loop per projected column.
@@ -189,18 +180,23 @@ static void PlinkHardyScan(ClientContext &, TableFunctionInput &data_p, DataChun
 	vector<HardyRow> rows;
 	rows.reserve(STANDARD_VECTOR_SIZE);
 	uint32_t vidx;
-	while (rows.size() < STANDARD_VECTOR_SIZE && lstate.scan.Next(gstate.scan, "plink_hardy", needs_strata, vidx)) {
+	while (rows.size() < STANDARD_VECTOR_SIZE && lstate.scan.Next(gstate.scan, "plink_hardy", vidx)) {
 		HardyRow row;
 		row.vidx = vidx;
 		if (!gstate.need_genotype_counts) {
 			rows.push_back(row);
 			continue;
 		}
-		if (gstate.need_p_hwe && lstate.lnp_batch_begin != lstate.scan.batch_begin) {
-			PrepareBatchTests(bind_data, lstate);
+		if (gstate.need_p_hwe && lstate.scan.have_strata && lstate.x_batch_begin != lstate.scan.batch_begin) {
+			PrepareXchrTests(bind_data, lstate);
 		}
-		const double ln_p = gstate.need_p_hwe ? lstate.lnp[vidx - lstate.scan.batch_begin] : 0.0;
-		const ChromPloidy ploidy = ClassifyChromPloidy(variants.GetChrom(vidx), variants.GetPos(vidx), bind_data.par_bounds);
+		const ChromPloidy ploidy = bind_data.ploidy.At(vidx);
+		double ln_p = 0.0;
+		if (gstate.need_p_hwe) {
+			ln_p = ploidy == ChromPloidy::AUTOSOMAL || !lstate.scan.have_strata
+			           ? lstate.scan.LnP(vidx, bind_data.midp)
+			           : lstate.x_lnp[vidx - lstate.scan.batch_begin];
+		}
 		const uint32_t *gc = lstate.scan.Counts(vidx);
 		// O_HET / E_HET of a diploid stratum (src/plink_hardy.cpp:575-588)
 		auto diploid_stats = [&](uint32_t hom_ref, uint32_t het, uint32_t hom_alt, bool test_ok) {
@@ -219,10 +215,8 @@ static void PlinkHardyScan(ClientContext &, TableFunctionInput &data_p, DataChun
 		if (ploidy == ChromPloidy::AUTOSOMAL) {
 			diploid_stats(gc[0], gc[1], gc[2], true);
 		} else {
-			static const uint32_t zero[4] = {0, 0, 0, 0};
-			const bool strata = lstate.scan.have_strata;
-			SexAwareCounts sac = SexAwareFromStrata(ploidy, gc, strata ? lstate.scan.MaleCounts(vidx) : zero,
-			                                        strata ? lstate.scan.FemaleCounts(vidx) : zero, bind_data.have_sex);
+			SexAwareCounts sac = SexAwareFromStrata(ploidy, gc, lstate.scan.MaleCounts(vidx),
+			                                        lstate.scan.FemaleCounts(vidx), bind_data.have_sex);
 			if (sac.sex_unavailable) {
 				row.counts_are_null = true;
 			} else if (sac.hwe_defined) {

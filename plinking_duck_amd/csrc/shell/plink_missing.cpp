@@ -105,10 +105,12 @@ static unique_ptr<GlobalTableFunctionState> PlinkMissingInitGlobal(ClientContext
 	}
 	if (state->need_missingness) {
 		state->scan.dataset = DeviceDataset::Acquire(bind_data.c.pgen_path, "plink_missing");
-		if (bind_data.c.has_sample_subset) {
-			state->scan.subset = make_uniq<DeviceSubset>(*state->scan.dataset,
-			                                             bind_data.c.sample_subset->sample_include, "plink_missing");
-		}
+		// MISSING_CT per variant is column 3 of the range's tally pass, MISSING_CT per sample its per-sample
+		// product: whichever of plink_freq / plink_hardy / plink_missing (either mode) saw this file, subset and
+		// range first has already paid for the walk (src/plink_missing.cpp:479 and :593-609 are two more scans)
+		state->scan.StartTallies(bind_data.c.sample_subset.get(), nullptr, bind_data.c.raw_sample_ct, nullptr,
+		                         (bind_data.sample_mode || !bind_data.c.has_sample_subset) ? static_cast<uint32_t>(PGH_TALLY_SAMPLE_MISSING) : 0u,
+		                         bind_data.sample_mode, GetPlinkingTallyCache(context), "plink_missing");
 	}
 	if (bind_data.sample_mode) {
 		state->sample_missing_counts.assign(bind_data.c.effective_sample_ct, 0);
@@ -127,11 +129,10 @@ static unique_ptr<LocalTableFunctionState> PlinkMissingInitLocal(ExecutionContex
 static void PlinkMissingScanVariant(const PlinkMissingBindData &bind_data, PlinkMissingGlobalState &gstate,
                                     PlinkMissingLocalState &lstate, DataChunk &output) {
 	const uint32_t sample_ct = bind_data.c.effective_sample_ct;
-	auto no_strata = [](uint32_t, uint32_t) { return false; };
 	uint32_t vids[STANDARD_VECTOR_SIZE], missing[STANDARD_VECTOR_SIZE];
 	idx_t n_rows = 0;
 	uint32_t vidx;
-	while (n_rows < STANDARD_VECTOR_SIZE && lstate.scan.Next(gstate.scan, "plink_missing", no_strata, vidx)) {
+	while (n_rows < STANDARD_VECTOR_SIZE && lstate.scan.Next(gstate.scan, "plink_missing", vidx)) {
 		vids[n_rows] = vidx;
 		missing[n_rows] = gstate.need_missingness ? lstate.scan.Counts(vidx)[3] : 0;
 		n_rows++;
@@ -165,19 +166,12 @@ static void PlinkMissingScanSample(const PlinkMissingBindData &bind_data, PlinkM
                                    DataChunk &output) {
 	const uint32_t sample_ct = bind_data.c.effective_sample_ct;
 	{
-		// Phase 1: one device launch covers the whole variant range, so the first
-		// thread in does it; later threads find it done and go straight to phase 2.
+		// Phase 1: the range's tally pass (enqueued at init_global, or found in the dataset's cache) holds the
+		// per-sample tallies; the first thread in waits for them, later threads go straight to phase 2.
 		std::lock_guard<std::mutex> lock(gstate.phase1_mutex);
 		if (!gstate.variant_scan_done) {
-			if (gstate.need_missingness && gstate.total_variant_ct > 0) {
-				char errbuf[PGH_ERRBUF_LEN] = {0};
-				int rc = pgh_missing_per_sample(gstate.scan.dataset->handle,
-				                                gstate.scan.subset ? gstate.scan.subset->handle : nullptr,
-				                                gstate.scan.start_variant_idx, gstate.scan.end_variant_idx,
-				                                gstate.sample_missing_counts.data(), errbuf);
-				if (rc != PGH_OK) {
-					throw IOException("plink_missing: PgrGetMissingness failed: %s", string(errbuf));
-				}
+			if (gstate.need_missingness && gstate.total_variant_ct > 0 && sample_ct > 0) {
+				gstate.scan.tally->SampleMissing(gstate.sample_missing_counts.data(), "plink_missing");
 			}
 			gstate.variant_scan_done = true;
 		}

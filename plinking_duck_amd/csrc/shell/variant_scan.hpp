@@ -1,13 +1,17 @@
 // variant_scan.hpp -- the per-variant scan skeleton shared by plink_freq,
-// plink_hardy and plink_missing (variant mode).
+// plink_hardy, plink_missing (variant mode) and read_pgen.
 //
 // Reference shape (src/plink_freq.cpp:434-488): each scan thread claims 128
-// variants with fetch_add and calls PgrGetCounts once per variant.  Here a
-// thread claims a *device batch* (kDeviceBatch variants, a multiple of the
-// reference's 128), runs ONE tally launch for it on its own stream, copies the
-// 16 B/variant results back, and then serves its Scan calls (<= 2048 rows each)
-// out of that batch.  A GPU launch + wait always happens inside a Scan call,
-// never by yielding an empty chunk (scan protocol).
+// variants with fetch_add and calls PgrGetCounts once per variant, blocking on
+// the file.  Here the tallies of the WHOLE scanned range are enqueued once, at
+// init_global, as a tally pass (pgh_tally_*, shared per dataset / subset / range
+// across table functions and queries: DeviceDataset::AcquireTally): the device
+// walks the matrix batch by batch while the scan threads claim device batches
+// (kDeviceBatch variants, a multiple of the reference's 128), wait only for the
+// batch they are about to emit -- its rows are then in pinned host memory -- and
+// fill their chunks (<= 2048 rows each) while the batches behind are still being
+// tallied.  A wait always happens inside a Scan call, never by yielding an empty
+// chunk (scan protocol).
 #pragma once
 
 #include "plink_common.hpp"
@@ -24,35 +28,69 @@ struct VariantScanGlobal {
 	uint32_t start_variant_idx = 0;
 	uint32_t end_variant_idx = 0;
 	shared_ptr<DeviceDataset> dataset;     // null when no genotype-derived column is projected
-	unique_ptr<DeviceSubset> subset;       // samples := [...]
-	unique_ptr<DeviceSubset> male_subset;  // sex strata for chrX/Y/MT (intersected with the subset)
-	unique_ptr<DeviceSubset> female_subset;
+	unique_ptr<DeviceSubset> subset;       // samples := [...] (the per-variant calls of list mode, dosage sums)
 	uint32_t effective_sample_ct = 0;
 	bool want_counts = true;               // false: only the batch claim is needed (read_pgen without filters)
+	// The range's tallies (StartTallies): all included samples, and -- over the span that holds the chrX / chrY /
+	// chrMT variants, when the file has any and the samples' sexes are known -- the male and the female stratum.
+	shared_ptr<DeviceTally> tally, male_tally, female_tally;
+	uint32_t strata_begin = 0, strata_end = 0;
+	uint32_t wait_products = PGH_TALLY_COUNTS; // what a thread waits for per batch (plink_hardy adds the exact tests)
 	// read_pgen's `variants :=` list: the scan walks list positions (caller order, as the
 	// reference's effective_variant_indices does) and claims kListBatch of them at a time.
 	bool has_variant_list = false;
 	vector<uint32_t> variant_list;
+
+	//! Enqueue the range's tally pass(es).  `products`: PGH_TALLY_* beyond the counts; exact_range: the pass must
+	//! cover exactly the scanned range (the per-sample product sums over it).
+	void StartTallies(const SampleSubset *sample_subset, const SampleInfo *sexes_of, uint32_t raw_sample_ct,
+	                  const PloidyMap *ploidy, uint32_t products, bool exact_range, bool use_cache,
+	                  const string &func_name) {
+		if (!dataset || !want_counts || has_variant_list) {
+			return;
+		}
+		wait_products = PGH_TALLY_COUNTS | (products & (PGH_TALLY_HWE | PGH_TALLY_HWE_MIDP));
+		tally = dataset->AcquireTally(sample_subset ? &sample_subset->sample_include : nullptr, start_variant_idx,
+		                              end_variant_idx, PGH_TALLY_COUNTS | products, exact_range, use_cache, func_name);
+		if (!ploidy || !sexes_of || sexes_of->sexes.empty() ||
+		    !ploidy->NonAutosomalSpan(start_variant_idx, end_variant_idx, strata_begin, strata_end)) {
+			strata_begin = strata_end = 0;
+			return;
+		}
+		// sex strata masks (male / female, each ANDed with the sample subset if any)
+		vector<uint64_t> male((raw_sample_ct + 63) / 64, 0), female((raw_sample_ct + 63) / 64, 0);
+		for (uint32_t s = 0; s < raw_sample_ct && s < sexes_of->sexes.size(); s++) {
+			if (sample_subset && !((sample_subset->sample_include[s >> 6] >> (s & 63)) & 1ull)) {
+				continue;
+			}
+			if (sexes_of->sexes[s] == 1) {
+				male[s >> 6] |= 1ull << (s & 63);
+			} else if (sexes_of->sexes[s] == 2) {
+				female[s >> 6] |= 1ull << (s & 63);
+			}
+		}
+		male_tally = dataset->AcquireTally(&male, strata_begin, strata_end, PGH_TALLY_COUNTS, false, use_cache, func_name);
+		female_tally =
+		    dataset->AcquireTally(&female, strata_begin, strata_end, PGH_TALLY_COUNTS, false, use_cache, func_name);
+	}
 };
 
 constexpr uint32_t kListBatch = 128;
 
 struct VariantScanLocal {
 	uint32_t batch_begin = 0, batch_end = 0, cursor = 0;
-	vector<uint32_t> counts, male_counts, female_counts; // [batch][4]
-	bool have_strata = false;
+	bool have_strata = false; // the claimed batch reaches into the sex-strata span
 
-	//! Advance to the next variant of this thread; returns false when the range is drained.
-	//! needs_strata(begin, end) says whether any variant of the batch is on chrX/Y/MT.
 	//! True once every variant of the claimed batch has been handed out: callers that defer
 	//! work on a batch (read_pgen's chunk plan) stop here, because the next claim replaces
-	//! the batch's tallies.
+	//! the batch.
 	bool BatchDrained() const {
 		return cursor >= batch_end;
 	}
 
-	template <class NeedStrata>
-	bool Next(VariantScanGlobal &g, const string &func_name, NeedStrata &&needs_strata, uint32_t &vidx) {
+	//! Advance to the next variant of this thread; returns false when the range is drained.
+	bool Next(VariantScanGlobal &g, const string &func_name, uint32_t &vidx) {
+		g_ = &g;
 		if (g.has_variant_list) {
 			return NextListed(g, func_name, vidx);
 		}
@@ -66,11 +104,12 @@ struct VariantScanLocal {
 			batch_end = end;
 			cursor = begin;
 			have_strata = false;
-			if (g.dataset && g.want_counts) {
-				Tally(g, g.subset.get(), counts, func_name);
-				if (needs_strata(begin, end) && g.male_subset && g.female_subset) {
-					Tally(g, g.male_subset.get(), male_counts, func_name);
-					Tally(g, g.female_subset.get(), female_counts, func_name);
+			if (g.tally) {
+				g.tally->Wait(g.wait_products, begin, end, func_name);
+				const uint32_t sb = std::max(begin, g.strata_begin), se = std::min(end, g.strata_end);
+				if (g.male_tally && sb < se) {
+					g.male_tally->Wait(PGH_TALLY_COUNTS, sb, se, func_name);
+					g.female_tally->Wait(PGH_TALLY_COUNTS, sb, se, func_name);
 					have_strata = true;
 				}
 			}
@@ -81,19 +120,31 @@ struct VariantScanLocal {
 
 	const uint32_t *Counts(uint32_t vidx) const {
 		if (!list_slot.empty()) {
-			return counts.data() + 4 * static_cast<size_t>(list_slot.at(vidx));
+			return list_counts.data() + 4 * static_cast<size_t>(list_slot.at(vidx));
 		}
-		return counts.data() + 4 * static_cast<size_t>(vidx - batch_begin);
+		return g_->tally->Counts(vidx);
 	}
+	//! ln p of the variant's exact test (a pass that was asked for PGH_TALLY_HWE / _HWE_MIDP)
+	double LnP(uint32_t vidx, bool midp) const {
+		return g_->tally->LnP(vidx, midp);
+	}
+	//! Stratum tallies of a chrX / chrY / chrMT variant (zeros when the sexes are unknown)
 	const uint32_t *MaleCounts(uint32_t vidx) const {
-		return male_counts.data() + 4 * static_cast<size_t>(vidx - batch_begin);
+		return StratumCounts(g_->male_tally.get(), vidx);
 	}
 	const uint32_t *FemaleCounts(uint32_t vidx) const {
-		return female_counts.data() + 4 * static_cast<size_t>(vidx - batch_begin);
+		return StratumCounts(g_->female_tally.get(), vidx);
 	}
 
 private:
-	std::unordered_map<uint32_t, uint32_t> list_slot; // list mode: variant index -> row of `counts`
+	const VariantScanGlobal *g_ = nullptr;
+	vector<uint32_t> list_counts;                     // list mode: [batch][4]
+	std::unordered_map<uint32_t, uint32_t> list_slot; // list mode: variant index -> row of list_counts
+
+	const uint32_t *StratumCounts(const DeviceTally *t, uint32_t vidx) const {
+		static const uint32_t zero[4] = {0, 0, 0, 0};
+		return (t && have_strata && vidx >= g_->strata_begin && vidx < g_->strata_end) ? t->Counts(vidx) : zero;
+	}
 
 	bool NextListed(VariantScanGlobal &g, const string &func_name, uint32_t &vidx) {
 		if (cursor >= batch_end) {
@@ -108,13 +159,13 @@ private:
 			have_strata = false;
 			list_slot.clear();
 			if (g.dataset && g.want_counts) {
-				counts.resize(4 * static_cast<size_t>(batch_end - batch_begin));
+				list_counts.resize(4 * static_cast<size_t>(batch_end - batch_begin));
 				char errbuf[PGH_ERRBUF_LEN] = {0};
 				for (uint32_t pos = batch_begin; pos < batch_end; pos++) {
 					const uint32_t v = g.variant_list[pos];
 					list_slot[v] = pos - batch_begin;
 					int rc = pgh_counts_range(g.dataset->handle, g.subset ? g.subset->handle : nullptr, v, v + 1,
-					                          reinterpret_cast<uint32_t(*)[4]>(counts.data() + 4 * (pos - batch_begin)),
+					                          reinterpret_cast<uint32_t(*)[4]>(list_counts.data() + 4 * (pos - batch_begin)),
 					                          errbuf);
 					if (rc != PGH_OK) {
 						throw IOException("%s: PgrGetCounts failed for variant %u: %s", func_name, v, string(errbuf));
@@ -125,39 +176,7 @@ private:
 		vidx = g.variant_list[cursor++];
 		return true;
 	}
-
-	void Tally(VariantScanGlobal &g, DeviceSubset *ss, vector<uint32_t> &out, const string &func_name) {
-		out.resize(4 * static_cast<size_t>(batch_end - batch_begin));
-		char errbuf[PGH_ERRBUF_LEN] = {0};
-		int rc = pgh_counts_range(g.dataset->handle, ss ? ss->handle : nullptr, batch_begin, batch_end,
-		                          reinterpret_cast<uint32_t(*)[4]>(out.data()), errbuf);
-		if (rc != PGH_OK) {
-			throw IOException("%s: PgrGetCounts failed for variants [%u, %u): %s", func_name, batch_begin, batch_end,
-			                  string(errbuf));
-		}
-	}
 };
-
-//! Sex strata masks (male / female, each ANDed with the sample subset if any).
-inline void BuildSexStrata(VariantScanGlobal &g, const SampleInfo &sample_info, const SampleSubset *subset,
-                           uint32_t raw_sample_ct, const string &func_name) {
-	if (sample_info.sexes.empty() || !g.dataset) {
-		return;
-	}
-	vector<uint64_t> male((raw_sample_ct + 63) / 64, 0), female((raw_sample_ct + 63) / 64, 0);
-	for (uint32_t s = 0; s < raw_sample_ct && s < sample_info.sexes.size(); s++) {
-		if (subset && !((subset->sample_include[s >> 6] >> (s & 63)) & 1ull)) {
-			continue;
-		}
-		if (sample_info.sexes[s] == 1) {
-			male[s >> 6] |= 1ull << (s & 63);
-		} else if (sample_info.sexes[s] == 2) {
-			female[s >> 6] |= 1ull << (s & 63);
-		}
-	}
-	g.male_subset = make_uniq<DeviceSubset>(*g.dataset, male, func_name);
-	g.female_subset = make_uniq<DeviceSubset>(*g.dataset, female, func_name);
-}
 
 //! The five metadata columns every per-variant function emits first
 //! (src/plink_freq.cpp:576-607): ID empty -> NULL, ALT "" or "." -> NULL.

@@ -742,12 +742,13 @@ __global__ __launch_bounds__(256) void k_finish_tallies(uint4 *__restrict__ tall
 
 // out[s] = sum over slices of slabs[slice][s]
 __global__ __launch_bounds__(256) void k_sum_slabs(const uint32_t *__restrict__ slabs, uint32_t slab_stride,
-                                                   uint32_t n_slabs, uint32_t n, uint32_t *__restrict__ out) {
+                                                   uint32_t n_slabs, uint32_t n, uint32_t *__restrict__ out,
+                                                   uint32_t accumulate) {
 	const uint32_t s = blockIdx.x * 256u + threadIdx.x;
 	if (s >= n) {
 		return;
 	}
-	uint32_t acc = 0;
+	uint32_t acc = accumulate ? out[s] : 0u;
 	for (uint32_t k = 0; k < n_slabs; k++) {
 		acc += slabs[static_cast<uint64_t>(k) * slab_stride + s];
 	}
@@ -1046,9 +1047,10 @@ hipError_t LaunchClassCounts3(const RowView &view, uint32_t v_first, const uint3
 }
 
 hipError_t LaunchFusedTally(const RowView &view, uint32_t v_first, uint32_t v_count, uint32_t *scratch,
-                            uint32_t *counts, uint32_t *missing_per_sample, hipStream_t stream) {
+                            uint32_t *counts, uint32_t *missing_per_sample, hipStream_t stream, bool accumulate) {
 	if (v_count == 0) {
-		return hipMemsetAsync(missing_per_sample, 0, sizeof(uint32_t) * view.sample_ct, stream);
+		return accumulate ? hipSuccess
+		                  : hipMemsetAsync(missing_per_sample, 0, sizeof(uint32_t) * view.sample_ct, stream);
 	}
 	const uint32_t chunks = static_cast<uint32_t>((static_cast<uint64_t>(view.record_bytes) + 15) / 16);
 	const uint32_t col_blocks = (chunks + 255) / 256;
@@ -1066,7 +1068,7 @@ hipError_t LaunchFusedTally(const RowView &view, uint32_t v_first, uint32_t v_co
 	hipLaunchKernelGGL(k_finish_tallies, dim3((v_count + 255) / 256), dim3(256), 0, stream,
 	                   reinterpret_cast<uint4 *>(counts), v_count, view.sample_ct);
 	hipLaunchKernelGGL(k_sum_slabs, dim3((view.sample_ct + 255) / 256), dim3(256), 0, stream, scratch, stride, slices,
-	                   view.sample_ct, missing_per_sample);
+	                   view.sample_ct, missing_per_sample, accumulate ? 1u : 0u);
 	return hipGetLastError();
 }
 

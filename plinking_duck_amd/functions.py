@@ -57,9 +57,11 @@ class Result:
         self.threads = doc["threads"]
         self.timing_ms = {k: doc.get(k + "_ms") for k in ("bind", "init", "scan")}
         self.rows = [tuple(r) for r in doc["rows"]]
+        self.row_count = doc.get("row_count", len(self.rows))
+        self.checksum = doc.get("checksum")  # drain=True: order-independent sum over every projected cell
 
     def __len__(self):
-        return len(self.rows)
+        return self.row_count
 
     def column(self, name):
         i = self.names.index(name)
@@ -73,8 +75,11 @@ class Result:
         return sorted(self.rows, key=lambda r: tuple((r[i] is None, r[i]) for i in idx))
 
 
-def query(function: str, *args, columns=None, threads: int = 4, settings=None, **named) -> Result:
+def query(function: str, *args, columns=None, threads: int = 4, settings=None, drain: bool = False, **named) -> Result:
+    """drain=True: the chunks are consumed inside the harness (row count + checksum) instead of coming back as rows."""
     req = {"function": function, "args": list(args), "named": named, "threads": threads}
+    if drain:
+        req["drain"] = True
     if columns is not None:
         req["columns"] = list(columns)
     if settings:

@@ -29,6 +29,8 @@ EXPORTED_SYMBOLS = [
     "pgh_score_plan_destroy", "pgh_pca", "pgh_pca_sharded", "pgh_ld_pairs", "pgh_ld_pairs_dev", "pgh_ld_pairs_status", "pgh_sample_counts", "pgh_sample_counts_dev",
     "pgh_synth_add_dosage", "pgh_synth_write_dosage_files", "pgh_dosage_sums", "pgh_dosage_sums_dev", "pgh_dosage_unpack", "pgh_dosage_unpack_dev", "pgh_unpack_samples", "pgh_dosage_unpack_samples", "pgh_reader_create", "pgh_reader_destroy",
     "pgh_get_2bit", "pgh_get_counts", "pgh_get_missingness", "pgh_get_int8", "pgh_get_dosage_f64", "pgh_get_phased",
+    "pgh_tally_start", "pgh_tally_request", "pgh_tally_wait", "pgh_tally_counts", "pgh_tally_hwe_lnp",
+    "pgh_tally_sample_missing", "pgh_tally_destroy", "pgh_tally_passes_started", "pgh_host_alloc", "pgh_host_free",
     "pgh_reader_error", "pgh_hwe_lnp", "pgh_hwe_xchr_lnp", "pgh_hwe_lnp_batch", "pgh_hwe_lnp_batch_dev", "pgh_hwe_xchr_lnp_batch",
 ]
 
@@ -140,6 +142,16 @@ def _load():
         "pgh_hwe_lnp": (C.c_double, [i32, i32, i32, u32]),
         "pgh_hwe_xchr_lnp": (C.c_double, [i32, i32, i32, i32, i32, u32]),
         "pgh_hwe_lnp_batch": (C.c_int, [vp, u32, u32, vp, cp]),
+        "pgh_tally_start": (C.c_int, [vp, vp, u32, u32, u32, C.POINTER(vp), cp]),
+        "pgh_tally_request": (C.c_int, [vp, u32, cp]),
+        "pgh_tally_wait": (C.c_int, [vp, u32, u32, u32, cp]),
+        "pgh_tally_counts": (vp, [vp]),
+        "pgh_tally_hwe_lnp": (vp, [vp, u32]),
+        "pgh_tally_sample_missing": (C.c_int, [vp, vp, cp]),
+        "pgh_tally_destroy": (None, [vp]),
+        "pgh_tally_passes_started": (u64, []),
+        "pgh_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(vp), cp]),
+        "pgh_host_free": (None, [vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)
@@ -256,6 +268,70 @@ def synth_write_files(prefix: str, m: int, n: int, seed: int, missing_rate: floa
 def synth_write_dosage_files(prefix: str, m: int, n: int, seed: int, missing_rate: float, dosage_rate: float):
     eb = _errbuf()
     _check(_lib.pgh_synth_write_dosage_files(prefix.encode(), m, n, seed, missing_rate, dosage_rate, eb), eb)
+
+
+TALLY_COUNTS, TALLY_SAMPLE_MISSING, TALLY_HWE, TALLY_HWE_MIDP = 1, 2, 4, 8
+
+
+def tally_passes_started() -> int:
+    return int(_lib.pgh_tally_passes_started())
+
+
+class TallyPass:
+    """pgh_tally: one asynchronous walk of [v_begin, v_end) whose products land in pinned host memory."""
+
+    def __init__(self, ds: "Dataset", v_begin: int = 0, v_end: int | None = None, products: int = TALLY_COUNTS,
+                 subset: "Subset | None" = None):
+        self.ds, self.subset = ds, subset
+        self.v_begin = v_begin
+        self.v_end = ds.info.variant_end if v_end is None else v_end
+        self.n_out = subset.size if subset is not None else ds.info.raw_sample_ct
+        self._h = C.c_void_p()
+        eb = _errbuf()
+        _check(_lib.pgh_tally_start(ds._h, subset._h if subset is not None else None, self.v_begin, self.v_end,
+                                    products, C.byref(self._h), eb), eb)
+
+    def request(self, products: int):
+        eb = _errbuf()
+        _check(_lib.pgh_tally_request(self._h, products, eb), eb)
+
+    def wait(self, products: int = TALLY_COUNTS, v_begin: int | None = None, v_end: int | None = None):
+        eb = _errbuf()
+        _check(_lib.pgh_tally_wait(self._h, products, self.v_begin if v_begin is None else v_begin,
+                                   self.v_end if v_end is None else v_end, eb), eb)
+
+    def _view(self, addr, dtype, shape):
+        n = int(np.prod(shape))
+        if n == 0:
+            return np.zeros(shape, dtype=dtype)
+        buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(addr)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def counts(self) -> np.ndarray:
+        """uint32[v_end - v_begin][4], a copy of the pass's pinned array (everything waited for)."""
+        self.wait(TALLY_COUNTS)
+        return self._view(_lib.pgh_tally_counts(self._h), np.uint32, (self.v_end - self.v_begin, 4)).copy()
+
+    def hwe_lnp(self, midp: bool = False) -> np.ndarray:
+        bit = TALLY_HWE_MIDP if midp else TALLY_HWE
+        self.request(bit)
+        self.wait(bit)
+        return self._view(_lib.pgh_tally_hwe_lnp(self._h, 1 if midp else 0), np.float64,
+                          (self.v_end - self.v_begin,)).copy()
+
+    def sample_missing(self) -> np.ndarray:
+        out = np.zeros(self.n_out, dtype=np.uint32)
+        eb = _errbuf()
+        _check(_lib.pgh_tally_sample_missing(self._h, _ptr(out), eb), eb)
+        return out
+
+    def close(self):
+        if self._h:
+            _lib.pgh_tally_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        self.close()
 
 
 class Subset:

@@ -1,0 +1,219 @@
+"""The tally pass (pgh_tally_*): one asynchronous walk of the matrix that serves plink_freq, plink_hardy and
+plink_missing -- through the C ABI against the oracle, and through the shells (one pass for three functions,
+the `synth:` source against the same fileset on disk, config 1 at its stated shape)."""
+
+import numpy as np
+import pytest
+
+from conftest import data_path
+
+pytestmark = pytest.mark.gpu
+
+F = pytest.importorskip("plinking_duck_amd.functions")
+
+SEED = 20260807
+FIXTURES = ["pgen_example", "all_missing", "large_example", "rare_small", "pca_example", "dosage_example", "pgen_split"]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu(gpu_lib):
+    return gpu_lib
+
+
+def host_pgen(oracle, rows, n):
+    m = len(rows)
+    head = bytes([0x6c, 0x1b, 0x02]) + m.to_bytes(4, "little") + n.to_bytes(4, "little") + bytes([0x40])
+    return oracle.Pgen(mem=np.frombuffer(head + rows.tobytes(), dtype=np.uint8))
+
+
+# ---- C ABI -----------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_pass_over_the_reference_fixtures(gpu_lib, oracle, name):
+    L = gpu_lib
+    path = data_path(name + ".pgen")
+    ds, pg = L.Dataset.open(path), oracle.Pgen(path)
+    t = L.TallyPass(ds, products=L.TALLY_COUNTS | L.TALLY_SAMPLE_MISSING | L.TALLY_HWE)
+    counts = t.counts()
+    assert np.array_equal(counts, pg.counts_range())
+    assert np.array_equal(t.sample_missing(), pg.missing_per_sample())
+    for midp in (False, True):  # midp asked for after the start
+        lnp = t.hwe_lnp(midp)
+        for v in range(min(pg.M, 200)):
+            c = counts[v]
+            assert lnp[v] == pytest.approx(oracle.hwe_lnp(int(c[1]), int(c[0]), int(c[2]), midp), abs=1e-6)
+    t.close()
+
+
+@pytest.mark.parametrize("m,n", [(1, 1), (37, 257), (5000, 1003), (70_000, 131)])
+def test_pass_on_synthetic_matrices_with_subsets_and_ranges(gpu_lib, oracle, m, n):
+    L = gpu_lib
+    ds = L.Dataset.synth(0, m, n, SEED, 0.05)
+    pg = host_pgen(oracle, np.stack([L.synth_record_host(v, n, SEED, 0.05) for v in range(min(m, 6000))]), n)
+    mo = pg.M  # the oracle sees the first rows; the pass is checked there and against the library beyond
+    rng = np.random.default_rng(m * 1000 + n)
+    # whole range, no subset: counts and the per-sample tally come out of one kernel pass
+    t = L.TallyPass(ds, products=L.TALLY_SAMPLE_MISSING)
+    assert np.array_equal(t.counts()[:mo], pg.counts_range())
+    assert np.array_equal(t.counts(), ds.counts_range())
+    assert np.array_equal(t.sample_missing(), ds.missing_per_sample())
+    if mo == m:
+        assert np.array_equal(t.sample_missing(), pg.missing_per_sample())
+    # the per-sample product asked for after the start (a sweep of its own), and a sub-range
+    a, b = (0, m) if m < 3 else (m // 5, m - m // 7)
+    t2 = L.TallyPass(ds, a, b)
+    t2.wait(L.TALLY_COUNTS, a, min(b, a + 1))
+    with pytest.raises(ValueError):
+        t2.wait(L.TALLY_SAMPLE_MISSING)
+    assert np.array_equal(t2.sample_missing(), ds.missing_per_sample(a, b))
+    assert np.array_equal(t2.counts(), ds.counts_range(a, b))
+    # subsets
+    if n > 1:
+        mask = rng.random(n) < 0.4
+        mask[0] = True
+        ss = ds.subset(mask)
+        t3 = L.TallyPass(ds, a, b, products=L.TALLY_SAMPLE_MISSING | L.TALLY_HWE_MIDP, subset=ss)
+        assert np.array_equal(t3.counts(), ds.counts_range(a, b, subset=ss))
+        if b <= mo:
+            assert np.array_equal(t3.counts(), pg.counts_range(a, b, include=mask))
+            assert np.array_equal(t3.sample_missing(), pg.missing_per_sample(a, b, include=mask))
+        assert np.array_equal(t3.sample_missing(), ds.missing_per_sample(a, b, subset=ss))
+        assert np.allclose(t3.hwe_lnp(True), L.hwe_lnp_batch(t3.counts(), True), rtol=0, atol=1e-12)
+    with pytest.raises(ValueError):
+        L.TallyPass(ds, 0, m + 1)
+
+
+def test_pass_over_a_shard_group(gpu_lib):
+    L = gpu_lib
+    m, n = 9000, 1501
+    one = L.Dataset.synth(0, m, n, SEED, 0.03)
+    cuts = [0, 2000, 2001, 7000, m]
+    grp = L.Dataset.group([L.Dataset.synth(a, b, n, SEED, 0.03) for a, b in zip(cuts, cuts[1:])])
+    t = L.TallyPass(grp, 500, 8000, products=L.TALLY_SAMPLE_MISSING | L.TALLY_HWE)
+    assert np.array_equal(t.counts(), one.counts_range(500, 8000))
+    assert np.array_equal(t.sample_missing(), one.missing_per_sample(500, 8000))
+    assert np.array_equal(t.hwe_lnp(False), L.hwe_lnp_batch(one.counts_range(500, 8000), False))
+    mask = np.arange(n) % 3 != 0
+    t = L.TallyPass(grp, products=L.TALLY_SAMPLE_MISSING, subset=grp.subset(mask))
+    assert np.array_equal(t.counts(), one.counts_range(subset=one.subset(mask)))
+    assert np.array_equal(t.sample_missing(), one.missing_per_sample(subset=one.subset(mask)))
+
+
+def test_many_threads_read_one_pass(gpu_lib):
+    """Scan threads wait for different batches of one pass while it is still running."""
+    import threading
+    L = gpu_lib
+    m, n = 300_000, 4001  # several pass batches of 4096-variant granularity at this width
+    ds = L.Dataset.synth(0, m, n, SEED, 0.02)
+    expect = ds.counts_range()
+    t = L.TallyPass(ds, products=L.TALLY_SAMPLE_MISSING | L.TALLY_HWE)
+    base = t._view(L.raw().pgh_tally_counts(t._h), np.uint32, (m, 4))
+    bad = []
+
+    def worker(k):
+        for b in range(k * 16384, m, 8 * 16384):
+            e = min(m, b + 16384)
+            t.wait(L.TALLY_COUNTS | L.TALLY_HWE, b, e)
+            if not np.array_equal(base[b:e], expect[b:e]):
+                bad.append(b)
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(8)]
+    [x.start() for x in threads]
+    [x.join() for x in threads]
+    assert not bad
+    assert np.array_equal(t.sample_missing(), ds.missing_per_sample())
+
+
+# ---- shells ------------------------------------------------------------------------------------------------------
+
+def test_one_pass_serves_freq_hardy_and_missing(gpu_lib, oracle, tmp_path):
+    """BASELINE config 3 from SQL: three functions (four scans in the reference) for one walk of the matrix."""
+    L = gpu_lib
+    prefix = str(tmp_path / "c3")
+    m, n = 50_000, 2003
+    L.synth_write_files(prefix, m, n, SEED, 0.04)
+    path = prefix + ".pgen"
+    pg = oracle.Pgen(path)
+    counts = pg.counts_range()
+    key = lambda c, p: (int(c) - 1) * ((m + 21) // 22) + p // 100 - 1
+    before = L.tally_passes_started()
+    r = F.query("plink_freq", path, counts=True, threads=5, columns=["CHROM", "POS", "HOM_REF_CT", "HET_CT", "HOM_ALT_CT", "MISSING_CT"])
+    assert L.tally_passes_started() == before + 1
+    got = np.zeros((m, 4), dtype=np.uint32)
+    for c, p, *cc in r.rows:
+        got[key(c, p)] = cc
+    assert len(r) == m and np.array_equal(got, counts)
+    # ... and nothing of the matrix is read for these three
+    r = F.query("plink_hardy", path, threads=5, columns=["CHROM", "POS", "HET_CT", "P_HWE"])
+    for c, p, het, pv in r.rows[::97]:
+        v = key(c, p)
+        assert het == counts[v][1] and pv == pytest.approx(oracle.hardy_from_counts(counts[v])[2], rel=1e-6)
+    r = F.query("plink_missing", path, threads=5, columns=["CHROM", "POS", "MISSING_CT"])
+    assert all(counts[key(c, p)][3] == mc for c, p, mc in r.rows) and len(r) == m
+    r = F.query("plink_missing", path, mode="sample", threads=5, columns=["IID", "MISSING_CT", "OBS_CT"])
+    miss = pg.missing_per_sample()
+    assert len(r) == n and all(miss[int(i[1:])] == mc and oc == m - mc for i, mc, oc in r.rows)
+    r = F.query("plink_hardy", path, midp=True, region="3:1-100000000", threads=3, columns=["POS", "P_HWE"])
+    assert len(r) == (m + 21) // 22
+    assert L.tally_passes_started() == before + 1
+    # the option off: every call walks for itself, same answers
+    r2 = F.query("plink_missing", path, mode="sample", threads=2, settings={"plinking_tally_cache": False},
+                 columns=["IID", "MISSING_CT"])
+    assert L.tally_passes_started() == before + 2
+    assert dict(r2.rows) == {f"S{s}": int(miss[s]) for s in range(n)}
+    # a subset gets a pass of its own; a region inside a cached range does not
+    F.query("plink_freq", path, samples=[0, 5, 6], columns=["ID", "ALT_FREQ"])
+    assert L.tally_passes_started() == before + 3
+    r = F.query("plink_freq", path, region="2:1-100000000", counts=True, columns=["POS", "HET_CT"])
+    assert L.tally_passes_started() == before + 3
+    per = (m + 21) // 22
+    assert all(counts[per + p // 100 - 1][1] == h for p, h in r.rows) and len(r) == per
+
+
+def test_synth_source_equals_the_fileset_on_disk(gpu_lib, tmp_path):
+    L = gpu_lib
+    m, n = 20_000, 1003
+    prefix = str(tmp_path / "s")
+    L.synth_write_files(prefix, m, n, SEED, 0.02)
+    spec = f"synth:{m}x{n}:{SEED}:0.02"
+    w = [0.001 * ((i * 7919) % 2001 - 1000) for i in range(m)]
+    calls = [("plink_freq", dict(counts=True)), ("plink_hardy", dict(midp=True)), ("plink_missing", {}),
+             ("plink_missing", dict(mode="sample")), ("plink_score", dict(weights=w)),
+             ("read_pgen", dict(genotypes="counts", af_range={"min": 0.2})),
+             ("plink_freq", dict(region="5:1-50000", samples=[1, 2, 3, 500]))]
+    for fn, kw in calls:
+        a = F.query(fn, prefix + ".pgen", threads=4, **kw)
+        b = F.query(fn, spec, threads=4, **kw)
+        assert a.names == b.names and len(a) == len(b) > 0
+        key = lambda r: tuple(str(x) for x in r[:3])
+        ra, rb = sorted(a.rows, key=key), sorted(b.rows, key=key)
+        if fn == "plink_score":  # the contraction's last additions are FP64 atomics: equal to the order of the sums
+            for x, y in zip(ra, rb):
+                assert x[:4] == y[:4] and np.allclose(x[4:], y[4:], rtol=1e-12, atol=1e-9), fn
+        else:
+            assert ra == rb, fn
+        d = F.query(fn, spec, threads=4, drain=True, **kw)
+        assert len(d) == len(a) and d.rows == [] and d.checksum is not None
+    with pytest.raises(F.InvalidInputException):
+        F.query("plink_freq", "synth:12")
+
+
+def test_config_1_at_its_stated_shape(gpu_lib, oracle, tmp_path):
+    """BASELINE config 1: plink_freq on a synthetic 10,000-variant x 1,000-sample .pgen on disk -- the oracle's
+    multi-threaded scan of the file (the reference's scan structure) against plink_freq through the shell and
+    against pgh_counts_range, bit-exact / ALT_FREQ exact."""
+    L = gpu_lib
+    m, n = 10_000, 1_000
+    prefix = str(tmp_path / "cfg1")
+    L.synth_write_files(prefix, m, n, SEED, 0.02)
+    pg = oracle.Pgen(prefix + ".pgen")
+    want = pg.scan_counts_mt(0, m, 4)
+    assert np.array_equal(want, pg.counts_range())
+    assert np.array_equal(L.Dataset.open(prefix + ".pgen").counts_range(), want)
+    r = F.query("plink_freq", prefix + ".pgen", counts=True, threads=8,
+                columns=["ID", "ALT_FREQ", "OBS_CT", "HOM_REF_CT", "HET_CT", "HOM_ALT_CT", "MISSING_CT"])
+    assert len(r) == m
+    for vid, af, obs, *cc in r.rows:
+        v = int(vid[2:])
+        exp_af, exp_obs = oracle.freq_from_counts(want[v])
+        assert cc == [int(x) for x in want[v]] and obs == exp_obs and af == exp_af
