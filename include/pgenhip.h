@@ -268,6 +268,13 @@ enum { PGH_SCORE_MEAN_IMPUTE = 0, PGH_SCORE_NO_MEAN_IMPUTATION = 1, PGH_SCORE_CE
 int pgh_score(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_scored, const uint32_t *vidx,
               const double *weights, const uint8_t *flip, uint32_t n_cols, int mode, double *score_sum,
               double *dosage_sum, uint32_t *allele_ct, char *errbuf);
+/* pgh_score for a caller that already holds the scored variants' class tallies -- a tally pass's rows
+ * (pgh_tally_counts), as plink_score after plink_freq on the same file and subset does: counts[i] =
+ * {hom_ref, het, hom_alt, missing} of vidx[i] over the included samples.  The means / variances the reference
+ * derives per variant (src/plink_score.cpp:598-620) then cost no read of the rows; NULL = pgh_score. */
+int pgh_score_counts(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_scored, const uint32_t *vidx,
+                     const double *weights, const uint8_t *flip, uint32_t n_cols, int mode, const uint32_t (*counts)[4],
+                     double *score_sum, double *dosage_sum, uint32_t *allele_ct, char *errbuf);
 /* Device form: raw-sample order (no compaction), outputs are caller-owned device
  * buffers of raw_sample_ct rows, overwritten. */
 int pgh_score_dev(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_scored, const uint32_t *vidx,

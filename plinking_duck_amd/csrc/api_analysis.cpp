@@ -270,34 +270,41 @@ extern "C" int pgh_unpack_range(const pgh_dataset *ds, const pgh_subset *subset,
 	PGH_ENTER(ds);
 	const size_t out_pitch = (static_cast<size_t>(n_out) + 15) / 16 * 16;
 	const size_t val_words = (n_out + 63) / 64;
-	// chunk the range so the device staging stays bounded (output is 4x the input)
-	const size_t max_rows = std::max<size_t>(1, (512ull << 20) / out_pitch);
-	DevBuf d_out, d_val;
+	// chunk the range so the device staging stays bounded (output is 4x the input); the staging block is the
+	// calling thread's kept scratch (a scan thread unpacks chunk after chunk: no allocation per call), and a
+	// pinned `out` (pgh_host_alloc) takes the copy at the link's rate
+	const size_t max_rows = std::max<size_t>(1, (1024ull << 20) / out_pitch);
 	const size_t chunk_rows = std::min(rows, max_rows);
-	if (out) {
-		PGH_HIP(d_out.Alloc(chunk_rows * out_pitch), "hipMalloc(unpack)");
-	}
-	if (validity) {
-		PGH_HIP(d_val.Alloc(chunk_rows * val_words * 8), "hipMalloc(validity)");
-	}
+	hipStream_t st = PghThreadStream();
+	const size_t out_bytes = out ? (chunk_rows * out_pitch + 255) / 256 * 256 : 0;
+	const size_t val_bytes = validity ? chunk_rows * val_words * 8 : 0;
+	void *stage = nullptr;
+	PGH_HIP(PghThreadScratch(out_bytes + val_bytes, st, &stage), "unpack staging");
+	int8_t *d_out = out ? static_cast<int8_t *>(stage) : nullptr;
+	uint64_t *d_val = validity ? reinterpret_cast<uint64_t *>(static_cast<char *>(stage) + out_bytes) : nullptr;
 	for (size_t r0 = 0; r0 < rows; r0 += chunk_rows) {
 		const size_t r1 = std::min(rows, r0 + chunk_rows);
 		rc = pgh_unpack_range_dev(ds, subset, v_begin + static_cast<uint32_t>(r0), v_begin + static_cast<uint32_t>(r1),
-		                          d_out.p, out_pitch, d_val.p, missing_code, PghThreadStream(), errbuf);
+		                          d_out, out_pitch, d_val, missing_code, st, errbuf);
 		if (rc != PGH_OK) {
 			return rc;
 		}
 		if (out) {
-			PGH_HIP(hipMemcpy2DAsync(out + r0 * n_out, n_out, d_out.p, out_pitch, n_out, r1 - r0,
-			                         hipMemcpyDeviceToHost, PghThreadStream()),
-			        "unpack copy");
+			if (out_pitch == n_out) {
+				PGH_HIP(hipMemcpyAsync(out + r0 * n_out, d_out, (r1 - r0) * static_cast<size_t>(n_out),
+				                       hipMemcpyDeviceToHost, st),
+				        "unpack copy");
+			} else {
+				PGH_HIP(hipMemcpy2DAsync(out + r0 * n_out, n_out, d_out, out_pitch, n_out, r1 - r0, hipMemcpyDeviceToHost,
+				                         st),
+				        "unpack copy");
+			}
 		}
 		if (validity) {
-			PGH_HIP(hipMemcpyAsync(validity + r0 * val_words, d_val.p, (r1 - r0) * val_words * 8,
-			                       hipMemcpyDeviceToHost, PghThreadStream()),
+			PGH_HIP(hipMemcpyAsync(validity + r0 * val_words, d_val, (r1 - r0) * val_words * 8, hipMemcpyDeviceToHost, st),
 			        "validity copy");
 		}
-		PGH_HIP(hipStreamSynchronize(PghThreadStream()), "unpack sync");
+		PGH_HIP(hipStreamSynchronize(st), "unpack sync");
 	}
 	return PGH_OK;
 }
@@ -611,9 +618,11 @@ extern "C" void pgh_score_plan_destroy(pgh_score_plan *plan) {
 	delete plan;
 }
 
-extern "C" int pgh_score_plan_create(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_scored,
-                                     const uint32_t *vidx, const double *weights, const uint8_t *flip, uint32_t n_cols,
-                                     int mode, pgh_score_plan **out, char *errbuf) {
+//! pgh_score_plan_create; `counts` (optional, host): the scored variants' class tallies over the included samples,
+//! counts[i] for vidx[i] -- what a tally pass already holds -- in which case the plan does not read the rows for them.
+static int ScorePlanCreate(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_scored, const uint32_t *vidx,
+                           const double *weights, const uint8_t *flip, uint32_t n_cols, int mode,
+                           const uint32_t (*counts)[4], pgh_score_plan **out, char *errbuf) {
 	if (!ds || !out || (n_scored && (!vidx || !weights))) {
 		SetErr(errbuf, "null argument");
 		return PGH_ERR_ARG;
@@ -674,17 +683,34 @@ extern "C" int pgh_score_plan_create(const pgh_dataset *ds, const pgh_subset *su
 			order[i] = i;
 		}
 	}
-	std::vector<uint32_t> p_local(n_scored);
-	std::vector<double> p_weights(static_cast<size_t>(n_scored) * n_cols);
-	std::vector<uint8_t> p_flip(flip ? n_scored : 0);
-	for (uint32_t k = 0; k < n_scored; k++) {
-		p_local[k] = local[order[k]];
-		std::memcpy(&p_weights[static_cast<size_t>(k) * n_cols], weights + static_cast<size_t>(order[k]) * n_cols,
-		            sizeof(double) * n_cols);
-		if (flip) {
-			p_flip[k] = flip[order[k]];
+	// the plan's order of the list; a file without dosage tracks keeps the caller's (no copies: a million-variant
+	// list is several milliseconds of host loops per array)
+	const bool reorder = ds->dos_rows != 0;
+	std::vector<uint32_t> p_local;
+	std::vector<double> p_weights;
+	std::vector<uint8_t> p_flip;
+	std::vector<uint32_t> p_counts;
+	if (reorder) {
+		p_local.resize(n_scored);
+		p_weights.resize(static_cast<size_t>(n_scored) * n_cols);
+		p_flip.resize(flip ? n_scored : 0);
+		p_counts.resize(counts ? 4ull * n_hard : 0);
+		for (uint32_t k = 0; counts && k < n_hard; k++) {
+			std::memcpy(&p_counts[4ull * k], counts[order[k]], 16);
+		}
+		for (uint32_t k = 0; k < n_scored; k++) {
+			p_local[k] = local[order[k]];
+			std::memcpy(&p_weights[static_cast<size_t>(k) * n_cols], weights + static_cast<size_t>(order[k]) * n_cols,
+			            sizeof(double) * n_cols);
+			if (flip) {
+				p_flip[k] = flip[order[k]];
+			}
 		}
 	}
+	const uint32_t *up_local = reorder ? p_local.data() : local.data();
+	const double *up_weights = reorder ? p_weights.data() : weights;
+	const uint8_t *up_flip = reorder ? p_flip.data() : flip;
+	const uint32_t *up_counts = counts ? (reorder ? p_counts.data() : &counts[0][0]) : nullptr;
 	std::unique_ptr<pgh_score_plan, void (*)(pgh_score_plan *)> plan(new pgh_score_plan(), pgh_score_plan_destroy);
 	plan->ds = ds;
 	plan->n_scored = n_scored;
@@ -704,22 +730,25 @@ extern "C" int pgh_score_plan_create(const pgh_dataset *ds, const pgh_subset *su
 		PGH_HIP(hipMalloc(&plan->d_ts, 32ull * n_scored), "hipMalloc(score)");
 		PGH_HIP(hipMalloc(&plan->d_td, 32ull * n_scored), "hipMalloc(score)");
 		PGH_HIP(hipMalloc(&plan->d_ac, 4ull * n_scored), "hipMalloc(score)");
-		PGH_HIP(hipMemcpyAsync(plan->d_vlist, p_local.data(), sizeof(uint32_t) * n_scored, hipMemcpyHostToDevice, st),
+		PGH_HIP(hipMemcpyAsync(plan->d_vlist, up_local, sizeof(uint32_t) * n_scored, hipMemcpyHostToDevice, st),
 		        "score upload");
-		PGH_HIP(hipMemcpyAsync(plan->d_weights, p_weights.data(), sizeof(double) * n_scored * n_cols,
-		                       hipMemcpyHostToDevice, st),
+		PGH_HIP(hipMemcpyAsync(plan->d_weights, up_weights, sizeof(double) * n_scored * n_cols, hipMemcpyHostToDevice, st),
 		        "score upload");
 		if (flip) {
 			PGH_HIP(hipMalloc(&plan->d_flip, n_scored), "hipMalloc(score)");
-			PGH_HIP(hipMemcpyAsync(plan->d_flip, p_flip.data(), n_scored, hipMemcpyHostToDevice, st), "score upload");
+			PGH_HIP(hipMemcpyAsync(plan->d_flip, up_flip, n_scored, hipMemcpyHostToDevice, st), "score upload");
 		}
 		// per-variant statistics and contribution tables depend on the data only: once per plan
 		uint32_t *vlist = static_cast<uint32_t *>(plan->d_vlist);
 		uint8_t *d_flip = static_cast<uint8_t *>(plan->d_flip);
 		if (n_hard) {
-			PGH_HIP(pgh::LaunchCounts(ds->View(), 0, vlist, n_hard, subset ? subset->d_mask2 : nullptr,
-			                          subset ? subset->n_out : N, static_cast<uint32_t *>(plan->d_counts), st),
-			        "score counts kernel");
+			if (counts) {
+				PGH_HIP(hipMemcpyAsync(plan->d_counts, up_counts, 16ull * n_hard, hipMemcpyHostToDevice, st), "score upload");
+			} else {
+				PGH_HIP(pgh::LaunchCounts(ds->View(), 0, vlist, n_hard, subset ? subset->d_mask2 : nullptr,
+				                          subset ? subset->n_out : N, static_cast<uint32_t *>(plan->d_counts), st),
+				        "score counts kernel");
+			}
 			PGH_HIP(pgh::LaunchScoreTables(static_cast<uint32_t *>(plan->d_counts), d_flip, n_hard, mode,
 			                               static_cast<double *>(plan->d_ts), static_cast<double *>(plan->d_td),
 			                               static_cast<uint32_t *>(plan->d_ac), st),
@@ -786,6 +815,12 @@ extern "C" int pgh_score_plan_create(const pgh_dataset *ds, const pgh_subset *su
 	}
 	*out = plan.release();
 	return PGH_OK;
+}
+
+extern "C" int pgh_score_plan_create(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_scored,
+                                     const uint32_t *vidx, const double *weights, const uint8_t *flip, uint32_t n_cols,
+                                     int mode, pgh_score_plan **out, char *errbuf) {
+	return ScorePlanCreate(ds, subset, n_scored, vidx, weights, flip, n_cols, mode, nullptr, out, errbuf);
 }
 
 extern "C" int pgh_score_run_dev(const pgh_score_plan *plan, void *d_score_sum, void *d_dosage_sum, void *d_allele_ct,
@@ -882,13 +917,13 @@ extern "C" int pgh_score_run_dev(const pgh_score_plan *plan, void *d_score_sum, 
 	return PGH_OK;
 }
 
-extern "C" int pgh_score_dev(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_scored, const uint32_t *vidx,
-                             const double *weights, const uint8_t *flip, uint32_t n_cols, int mode, void *d_score_sum,
-                             void *d_dosage_sum, void *d_allele_ct, void *stream, char *errbuf) {
+int PghScoreDevCounts(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_scored, const uint32_t *vidx,
+                      const double *weights, const uint8_t *flip, uint32_t n_cols, int mode, const uint32_t (*counts)[4],
+                      void *d_score_sum, void *d_dosage_sum, void *d_allele_ct, void *stream, char *errbuf) {
 	PGH_ONE_DEVICE(ds);
 	PGH_ENTER(ds);
 	pgh_score_plan *plan = nullptr;
-	int rc = pgh_score_plan_create(ds, subset, n_scored, vidx, weights, flip, n_cols, mode, &plan, errbuf);
+	int rc = ScorePlanCreate(ds, subset, n_scored, vidx, weights, flip, n_cols, mode, counts, &plan, errbuf);
 	if (rc != PGH_OK) {
 		return rc;
 	}
@@ -903,18 +938,47 @@ extern "C" int pgh_score_dev(const pgh_dataset *ds, const pgh_subset *subset, ui
 	return rc;
 }
 
+extern "C" int pgh_score_dev(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_scored, const uint32_t *vidx,
+                             const double *weights, const uint8_t *flip, uint32_t n_cols, int mode, void *d_score_sum,
+                             void *d_dosage_sum, void *d_allele_ct, void *stream, char *errbuf) {
+	return PghScoreDevCounts(ds, subset, n_scored, vidx, weights, flip, n_cols, mode, nullptr, d_score_sum, d_dosage_sum,
+	                         d_allele_ct, stream, errbuf);
+}
+
 extern "C" int pgh_score(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_scored, const uint32_t *vidx,
                          const double *weights, const uint8_t *flip, uint32_t n_cols, int mode, double *score_sum,
                          double *dosage_sum, uint32_t *allele_ct, char *errbuf) {
+	return pgh_score_counts(ds, subset, n_scored, vidx, weights, flip, n_cols, mode, nullptr, score_sum, dosage_sum,
+	                        allele_ct, errbuf);
+}
+
+extern "C" int pgh_score_counts(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_scored, const uint32_t *vidx,
+                                const double *weights, const uint8_t *flip, uint32_t n_cols, int mode,
+                                const uint32_t (*counts)[4], double *score_sum, double *dosage_sum, uint32_t *allele_ct,
+                                char *errbuf) {
 	if (!ds) {
 		SetErr(errbuf, "null dataset");
 		return PGH_ERR_ARG;
 	}
 	if (ds->IsGroup()) {
-		return pgh_group::Score(ds, subset, n_scored, vidx, weights, flip, n_cols, mode, score_sum, dosage_sum, allele_ct,
-		                        errbuf);
+		return pgh_group::Score(ds, subset, n_scored, vidx, weights, flip, n_cols, mode, counts, score_sum, dosage_sum,
+		                        allele_ct, errbuf);
 	}
 	PGH_ENTER(ds);
+	// PGH_SCORE_TIMING=1: wall-clock of the call's phases on stderr
+	static const bool timing = [] {
+		const char *e = std::getenv("PGH_SCORE_TIMING");
+		return e && *e && *e != '0';
+	}();
+	auto t_last = std::chrono::steady_clock::now();
+	auto mark = [&](const char *what) {
+		if (timing) {
+			const auto now = std::chrono::steady_clock::now();
+			std::fprintf(stderr, "pgh_score: %-22s %8.2f ms\n", what,
+			             std::chrono::duration<double, std::milli>(now - t_last).count());
+			t_last = now;
+		}
+	};
 	const uint32_t N = ds->sample_ct;
 	DevBuf d_score, d_dos, d_ac;
 	PGH_HIP(d_score.Alloc(sizeof(double) * N * std::max<uint32_t>(1, n_cols)), "hipMalloc(score out)");
@@ -922,11 +986,26 @@ extern "C" int pgh_score(const pgh_dataset *ds, const pgh_subset *subset, uint32
 		PGH_HIP(d_dos.Alloc(sizeof(double) * N), "hipMalloc(score out)");
 	}
 	PGH_HIP(d_ac.Alloc(sizeof(uint32_t) * N), "hipMalloc(score out)");
-	int rc = pgh_score_dev(ds, subset, n_scored, vidx, weights, flip, n_cols, mode, d_score.p, d_dos.p, d_ac.p,
-	                       PghThreadStream(), errbuf);
+	mark("output buffers");
+	pgh_score_plan *plan = nullptr;
+	int rc = ScorePlanCreate(ds, subset, n_scored, vidx, weights, flip, n_cols, mode, counts, &plan, errbuf);
 	if (rc != PGH_OK) {
 		return rc;
 	}
+	mark("plan (tables, digits)");
+	rc = pgh_score_run_dev(plan, d_score.p, d_dos.p, d_ac.p, PghThreadStream(), errbuf);
+	if (rc == PGH_OK) {
+		hipError_t e = hipStreamSynchronize(PghThreadStream()); // the plan's buffers are freed next
+		if (e != hipSuccess) {
+			rc = DeviceFail(errbuf, "score sync", e);
+		}
+	}
+	mark("contraction");
+	pgh_score_plan_destroy(plan);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	mark("plan release");
 	std::vector<double> h_score(static_cast<size_t>(N) * n_cols), h_dos(N);
 	std::vector<uint32_t> h_ac(N);
 	PGH_HIP(hipMemcpy(h_score.data(), d_score.p, sizeof(double) * N * n_cols, hipMemcpyDeviceToHost), "score copy");
@@ -939,6 +1018,7 @@ extern "C" int pgh_score(const pgh_dataset *ds, const pgh_subset *subset, uint32
 		Compact<double>(subset, h_dos.data(), 1, dosage_sum, N);
 	}
 	Compact<uint32_t>(subset, h_ac.data(), 1, allele_ct, N);
+	mark("results to the host");
 	return PGH_OK;
 }
 

@@ -175,8 +175,8 @@ int UnpackSamples(const pgh_dataset *g, const pgh_subset *ss, uint32_t n_variant
 int DosageUnpackSamples(const pgh_dataset *g, const pgh_subset *ss, uint32_t n_variants, const uint32_t *vidx,
                         double *out, char *errbuf);
 int Score(const pgh_dataset *g, const pgh_subset *ss, uint32_t n_scored, const uint32_t *vidx, const double *weights,
-          const uint8_t *flip, uint32_t n_cols, int mode, double *score_sum, double *dosage_sum, uint32_t *allele_ct,
-          char *errbuf);
+          const uint8_t *flip, uint32_t n_cols, int mode, const uint32_t (*counts)[4], double *score_sum,
+          double *dosage_sum, uint32_t *allele_ct, char *errbuf);
 int Pca(const pgh_dataset *g, const pgh_subset *ss, uint32_t n_var, const uint32_t *vidx, const double *center,
         const double *inv_stdev, uint32_t n_pcs, const double *g1_init, double *eigenvalues, double *eigenvectors,
         char *errbuf);
@@ -190,6 +190,11 @@ void Close(pgh_dataset *g);
 //! The reader of the shard that holds vidx (created on first use), or nullptr with rd->err set.
 pgh_reader *ReaderFor(pgh_reader *rd, uint32_t vidx);
 } // namespace pgh_group
+
+// pgh_score_dev with the scored variants' class tallies supplied (api_analysis.cpp; counts may be NULL)
+int PghScoreDevCounts(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_scored, const uint32_t *vidx,
+                      const double *weights, const uint8_t *flip, uint32_t n_cols, int mode, const uint32_t (*counts)[4],
+                      void *d_score_sum, void *d_dosage_sum, void *d_allele_ct, void *stream, char *errbuf);
 
 // The calling thread's own stream on the current device: what every host-output entry point enqueues on.
 // A real stream handle created by the library (on first use per thread and device, destroyed when the thread ends)

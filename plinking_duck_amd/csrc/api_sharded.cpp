@@ -573,8 +573,8 @@ int SampleCounts(const pgh_dataset *g, const pgh_subset *ss, uint32_t variant_be
 }
 
 int Score(const pgh_dataset *g, const pgh_subset *ss, uint32_t n_scored, const uint32_t *vidx, const double *weights,
-          const uint8_t *flip, uint32_t n_cols, int mode, double *score_sum, double *dosage_sum, uint32_t *allele_ct,
-          char *errbuf) {
+          const uint8_t *flip, uint32_t n_cols, int mode, const uint32_t (*counts)[4], double *score_sum,
+          double *dosage_sum, uint32_t *allele_ct, char *errbuf) {
 	int rc = CheckGroupSubset(g, ss, errbuf);
 	if (rc != PGH_OK) {
 		return rc;
@@ -612,15 +612,21 @@ int Score(const pgh_dataset *g, const pgh_subset *ss, uint32_t n_scored, const u
 		}
 		std::vector<double> w_k(static_cast<size_t>(n_k) * n_cols);
 		std::vector<uint8_t> f_k(flip ? n_k : 0);
+		std::vector<uint32_t> c_k(counts ? 4ull * n_k : 0);
 		for (uint32_t i = 0; i < n_k; i++) {
 			std::memcpy(&w_k[static_cast<size_t>(i) * n_cols], weights + static_cast<size_t>(cut.pos[k][i]) * n_cols,
 			            sizeof(double) * n_cols);
 			if (flip) {
 				f_k[i] = flip[cut.pos[k][i]];
 			}
+			if (counts) {
+				std::memcpy(&c_k[4ull * i], counts[cut.pos[k][i]], 16);
+			}
 		}
-		int rck = pgh_score_dev(g->shards[k], PartOf(ss, k), n_k, cut.idx[k].data(), w_k.data(), flip ? f_k.data() : nullptr,
-		                        n_cols, mode, d_score[k].p, d_dos[k].p, d_ac[k].p, PghThreadStream(), eb);
+		int rck = PghScoreDevCounts(g->shards[k], PartOf(ss, k), n_k, cut.idx[k].data(), w_k.data(),
+		                            flip ? f_k.data() : nullptr, n_cols, mode,
+		                            counts ? reinterpret_cast<const uint32_t(*)[4]>(c_k.data()) : nullptr, d_score[k].p,
+		                            d_dos[k].p, d_ac[k].p, PghThreadStream(), eb);
 		if (rck != PGH_OK) {
 			return rck;
 		}

@@ -111,8 +111,13 @@ int NewEvents(std::vector<hipEvent_t> &list, uint32_t n, char *errbuf) {
 	return PGH_OK;
 }
 
-//! The exact tests of every batch, each behind its batch's counts, on the side stream.
+//! The exact tests of every batch, each behind its batch's counts, on the side stream.  k_hwe_batch gives a
+//! variant to a lane, so a launch wants some hundred thousand variants to fill the chip: batches are grouped into
+//! launches of >= kHweLaunch variants where their counts have already landed (a product asked of a finished pass:
+//! 31 launches of one 32,768-variant batch each took 22 ms at 1 M x 500 k, the kernel's time at full width is 5),
+//! and go one by one while the tallies are still coming (they hide under the next batch's tally).
 int EnqueueHwe(pgh_tally *t, TallyPart &p, int which, char *errbuf) {
+	constexpr uint32_t kHweLaunch = 262144;
 	DeviceScope scope(p.device);
 	const uint32_t midp = which == kHweMidp ? 1u : 0u;
 	const uint32_t n = p.v_end - p.v_begin;
@@ -121,14 +126,23 @@ int EnqueueHwe(pgh_tally *t, TallyPart &p, int which, char *errbuf) {
 	if (rc != PGH_OK) {
 		return rc;
 	}
-	for (uint32_t b = 0; b < p.n_batches; b++) {
-		const uint32_t r0 = b * p.batch, r1 = std::min(n, r0 + p.batch);
-		PGH_HIP(hipStreamWaitEvent(p.side, p.ev[kCounts][b], 0), "tally stream wait");
+	for (uint32_t b = 0; b < p.n_batches;) {
+		uint32_t last = b; // the launch covers batches [b, last]
+		while (last + 1 < p.n_batches && (last + 1 - b) * p.batch < kHweLaunch &&
+		       hipEventQuery(p.ev[kCounts][last + 1]) == hipSuccess) {
+			last++;
+		}
+		(void)hipGetLastError(); // hipErrorNotReady of the query above is not an error
+		const uint32_t r0 = b * p.batch, r1 = std::min<uint64_t>(n, static_cast<uint64_t>(last + 1) * p.batch);
+		PGH_HIP(hipStreamWaitEvent(p.side, p.ev[kCounts][last], 0), "tally stream wait");
 		PGH_HIP(pgh::LaunchHweBatch(p.d_counts + 4ull * r0, r1 - r0, midp, p.d_lnp[midp] + r0, p.side), "exact-test kernel");
 		PGH_HIP(hipMemcpyAsync(t->h_lnp[midp] + (p.v_begin - t->v_begin) + r0, p.d_lnp[midp] + r0,
 		                       sizeof(double) * (r1 - r0), hipMemcpyDeviceToHost, p.side),
 		        "tally ln p copy");
-		PGH_HIP(hipEventRecord(p.ev[which][b], p.side), "hipEventRecord(tally)");
+		for (uint32_t k = b; k <= last; k++) {
+			PGH_HIP(hipEventRecord(p.ev[which][k], p.side), "hipEventRecord(tally)");
+		}
+		b = last + 1;
 	}
 	return PGH_OK;
 }

@@ -360,6 +360,9 @@ public:
 	uint64_t *GetData() {
 		return bits_.data();
 	}
+	idx_t Capacity() const {
+		return bits_.size() * 64;
+	}
 
 private:
 	vector<uint64_t> bits_;
@@ -398,6 +401,16 @@ public:
 	}
 	void ReserveChild(idx_t n) { // LIST child growth
 		children[0]->GrowTo(n);
+	}
+	//! DataChunk::Reset: every row valid again, no strings, empty lists -- buffers (a LIST child's included)
+	//! are kept and not cleared, as DuckDB keeps a chunk's buffers across scan calls.
+	void ResetKeepingBuffers() {
+		validity.Reset(validity.Capacity());
+		heap.clear();
+		list_size = 0;
+		for (auto &ch : children) {
+			ch->ResetKeepingBuffers();
+		}
 	}
 
 	//! Store one (possibly nested) Value at row i.
@@ -536,7 +549,7 @@ public:
 	}
 	void Reset() {
 		for (auto &v : data) {
-			v.Initialize(v.type, STANDARD_VECTOR_SIZE);
+			v.ResetKeepingBuffers();
 		}
 		count_ = 0;
 	}

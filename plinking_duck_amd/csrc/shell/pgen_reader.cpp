@@ -194,6 +194,9 @@ unique_ptr<GlobalTableFunctionState> PgenInitGlobal(ClientContext &context, Tabl
 	state->need_counts = bind_data.count_filter.HasFilter() || bind_data.genotype_filter.active ||
 	                     (state->need_genotypes && IsAggregateGenotypeMode(bind_data.genotype_mode));
 	state->scan.want_counts = state->need_counts;
+	if (state->need_genotypes && !IsAggregateGenotypeMode(bind_data.genotype_mode)) {
+		state->scan.claim = kUnpackSpan; // one output chunk per claim: every scan thread gets rows to unpack
+	}
 	if (state->need_genotypes || state->need_counts) {
 		state->scan.dataset = DeviceDataset::Acquire(bind_data.c.pgen_path, bind_data.func);
 		if (bind_data.c.has_sample_subset) {
@@ -271,6 +274,10 @@ void PgenScan(ClientContext &, TableFunctionInput &data_p, DataChunk &output) {
 	const bool per_variant_decode = gstate.need_genotypes && !dosage_rows && phased_out;
 	const bool plain_hardcalls =
 	    gstate.need_genotypes && !IsAggregateGenotypeMode(mode) && !bind_data.include_dosages && !phased_out;
+	const auto t_plan0 = std::chrono::steady_clock::now();
+	auto ms_since = [](std::chrono::steady_clock::time_point a) {
+		return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
+	};
 	// 1. choose the variants of this chunk (filters run off the batched tallies).  A chunk
 	//    never straddles two claimed batches: their tallies and unpack span are per batch.
 	vector<RowPlan> plan;
@@ -300,13 +307,37 @@ void PgenScan(ClientContext &, TableFunctionInput &data_p, DataChunk &output) {
 		return;
 	}
 
+	lstate.plan_ms += ms_since(t_plan0);
+	const auto t_unpack0 = std::chrono::steady_clock::now();
 	// 2. unpack: one launch for the span the chunk covers, or one per listed variant
 	const uint32_t span_begin = plan.front().vidx;
 	const uint32_t span_end = plan.back().vidx + 1;
 	const size_t val_words = (n + 63) / 64;
+	// PLINKING_UNPACK_DIRECT=1: a LIST / ARRAY chunk without gaps is unpacked straight into the output vector's
+	// child buffer (pageable memory: the runtime stages the copy) instead of into this thread's pinned block and
+	// from there with a memcpy.  Which one wins is a property of the host: measured in tools/shell_bench.py.
+	static const bool direct_env = [] {
+		const char *e = std::getenv("PLINKING_UNPACK_DIRECT");
+		return e && *e == '1';
+	}();
+	int8_t *direct_dst = nullptr;
+	if (plain_hardcalls && direct_env && !listed && (mode == GenotypeMode::LIST || mode == GenotypeMode::ARRAY) &&
+	    plan.size() == span_end - span_begin) {
+		for (idx_t out_col = 0; out_col < column_ids.size(); out_col++) {
+			if (column_ids[out_col] == COL_GENOTYPES) {
+				auto &vec = output.data[out_col];
+				if (mode == GenotypeMode::LIST) {
+					ListVector::Reserve(vec, plan.size() * static_cast<idx_t>(n));
+				}
+				direct_dst = FlatVector::GetData<int8_t>(GenotypeChild(bind_data, vec)); // row r at r * n
+			}
+		}
+	}
 	if (plain_hardcalls) {
 		const size_t rows = listed ? plan.size() : span_end - span_begin;
-		lstate.bytes.resize(rows * n);
+		if (!direct_dst) {
+			lstate.bytes.resize(rows * n);
+		}
 		lstate.validity.resize(rows * val_words);
 		pgh_dataset *ds = gstate.scan.dataset->handle;
 		pgh_subset *ss = gstate.scan.subset ? gstate.scan.subset->handle : nullptr;
@@ -318,7 +349,8 @@ void PgenScan(ClientContext &, TableFunctionInput &data_p, DataChunk &output) {
 				                      lstate.validity.data() + r * val_words, 0, errbuf);
 			}
 		} else {
-			rc = pgh_unpack_range(ds, ss, span_begin, span_end, lstate.bytes.data(), lstate.validity.data(), 0, errbuf);
+			rc = pgh_unpack_range(ds, ss, span_begin, span_end, direct_dst ? direct_dst : lstate.bytes.data(),
+			                      lstate.validity.data(), 0, errbuf);
 		}
 		if (rc != PGH_OK) {
 			throw IOException("%s: PgrGet failed for variants [%u, %u): %s", fn, span_begin, span_end,
@@ -342,6 +374,8 @@ void PgenScan(ClientContext &, TableFunctionInput &data_p, DataChunk &output) {
 		}
 	}
 
+	lstate.unpack_ms += ms_since(t_unpack0);
+	const auto t_fill0 = std::chrono::steady_clock::now();
 	// per-call writers shared by the ARRAY / LIST / STRUCT / COLUMNS layouts: `slot` is the
 	// element index inside `dst` (child offset, or the output row for scalar layouts)
 	auto put_dosage = [&](Vector &dst, idx_t slot, uint32_t s) {
@@ -383,12 +417,19 @@ void PgenScan(ClientContext &, TableFunctionInput &data_p, DataChunk &output) {
 		}
 	};
 
-	// 3. fill the projected columns
+	// 3. fill the projected columns (a LIST child is sized for the whole chunk at once)
+	if (mode == GenotypeMode::LIST && gstate.need_genotypes) {
+		for (idx_t out_col = 0; out_col < column_ids.size(); out_col++) {
+			if (column_ids[out_col] == COL_GENOTYPES) {
+				ListVector::Reserve(output.data[out_col], plan.size() * static_cast<idx_t>(n));
+			}
+		}
+	}
 	for (idx_t row = 0; row < plan.size(); row++) {
 		const uint32_t v = plan[row].vidx;
 		const bool null_out = bind_data.genotype_filter.active && !plan[row].geno_range_all_pass;
 		const size_t src_row = listed ? row : v - span_begin;
-		const int8_t *src = plain_hardcalls ? lstate.bytes.data() + src_row * n : nullptr;
+		const int8_t *src = plain_hardcalls ? (direct_dst ? direct_dst : lstate.bytes.data()) + src_row * n : nullptr;
 		const uint64_t *val = plain_hardcalls ? lstate.validity.data() + src_row * val_words : nullptr;
 		dose = dosage_rows ? lstate.dosage_doubles.data() + row * static_cast<size_t>(n) : nullptr;
 		if (per_variant_decode) {
@@ -470,26 +511,27 @@ void PgenScan(ClientContext &, TableFunctionInput &data_p, DataChunk &output) {
 			} else {
 				auto &child_validity = FlatVector::Validity(child);
 				auto *dst = FlatVector::GetData<int8_t>(child);
-				std::memcpy(dst + base, src, n); // missing calls are already stored as 0
-				for (size_t w = 0; w < val_words; w++) {
-					uint64_t bits = val[w];
-					const uint32_t lim = static_cast<uint32_t>(std::min<size_t>(64, n - w * 64));
-					const uint64_t full = lim == 64 ? ~0ull : ((1ull << lim) - 1);
-					if (!null_out && (bits & full) == full) {
-						continue;
-					}
-					for (uint32_t b = 0; b < lim; b++) {
-						const uint32_t s = static_cast<uint32_t>(w * 64 + b);
-						if (!((bits >> b) & 1ull) ||
-						    (null_out && !bind_data.genotype_filter.AllowsCall(static_cast<double>(src[s])))) {
-							child_validity.SetInvalid(base + s);
-							dst[base + s] = 0;
+				if (dst + base != src) {
+					std::memcpy(dst + base, src, n); // missing calls are already stored as 0
+				}
+				// the row's validity bits, as the device wrote them, go into the child's mask whole words at a
+				// time (the reference sets them sample by sample, src/pgen_reader.cpp:1009-1047)
+				child_validity.EnsureCapacity(base + n);
+				CopyValidityBits(child_validity.GetData(), base, val, n);
+				if (null_out) {
+					// genotype_range / include_genotypes: calls outside the filter become NULL too
+					for (uint32_t s2 = 0; s2 < n; s2++) {
+						if (!bind_data.genotype_filter.AllowsCall(static_cast<double>(src[s2]))) {
+							child_validity.SetInvalid(base + s2);
+							dst[base + s2] = 0;
 						}
 					}
 				}
 			}
 		}
 	}
+	lstate.fill_ms += ms_since(t_fill0);
+	lstate.chunks++;
 	CompatSetOutputCardinality(output, plan.size());
 }
 

@@ -5,6 +5,10 @@
 
 #include "variant_scan.hpp"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 namespace duckdb {
 
 static constexpr idx_t COL_GENOTYPES = 5;
@@ -44,9 +48,16 @@ struct PgenLocalState : public LocalTableFunctionState {
 	PinnedBuffer<uint64_t> validity; // [rows][ceil(n_out/64)]
 	vector<double> dosage_doubles;
 	vector<uint64_t> genovec, phasepresent, phaseinfo;
+	// PLINKING_TIMING=1: where this thread's scan time went (printed when the thread's state goes)
+	double plan_ms = 0.0, unpack_ms = 0.0, fill_ms = 0.0;
+	uint64_t chunks = 0;
 	~PgenLocalState() override {
 		if (reader) {
 			pgh_reader_destroy(reader);
+		}
+		if (chunks && std::getenv("PLINKING_TIMING")) {
+			std::fprintf(stderr, "read_pgen thread: %llu chunks, plan %.1f ms, unpack %.1f ms, fill %.1f ms\n",
+			             static_cast<unsigned long long>(chunks), plan_ms, unpack_ms, fill_ms);
 		}
 	}
 };

@@ -1622,6 +1622,67 @@ DeviceDataset::~DeviceDataset() {
 	}
 }
 
+// ---- pinned host blocks ----------------------------------------------------------------------------
+
+namespace {
+struct PinnedBlock {
+	void *p;
+	size_t bytes;
+};
+std::mutex g_pinned_mutex;
+vector<PinnedBlock> g_pinned_free;
+size_t g_pinned_free_bytes = 0;
+size_t PinnedPoolLimit() {
+	const char *env = std::getenv("PLINKING_PINNED_POOL_GB");
+	const double gb = env ? std::atof(env) : 24.0;
+	return static_cast<size_t>(gb * 1e9);
+}
+} // namespace
+
+void *PinnedPoolAcquire(size_t bytes, size_t &got_bytes) {
+	{
+		// the smallest parked block that is large enough, and not more than twice what was asked for
+		std::lock_guard<std::mutex> lock(g_pinned_mutex);
+		size_t best = g_pinned_free.size();
+		for (size_t i = 0; i < g_pinned_free.size(); i++) {
+			if (g_pinned_free[i].bytes >= bytes && g_pinned_free[i].bytes <= 2 * bytes + (1u << 20) &&
+			    (best == g_pinned_free.size() || g_pinned_free[i].bytes < g_pinned_free[best].bytes)) {
+				best = i;
+			}
+		}
+		if (best < g_pinned_free.size()) {
+			PinnedBlock b = g_pinned_free[best];
+			g_pinned_free.erase(g_pinned_free.begin() + static_cast<std::ptrdiff_t>(best));
+			g_pinned_free_bytes -= b.bytes;
+			got_bytes = b.bytes;
+			return b.p;
+		}
+	}
+	void *q = nullptr;
+	char errbuf[PGH_ERRBUF_LEN] = {0};
+	if (pgh_host_alloc(bytes, &q, errbuf) != PGH_OK) {
+		throw IOException("cannot allocate %llu bytes of pinned host memory: %s", static_cast<unsigned long long>(bytes),
+		                  string(errbuf));
+	}
+	got_bytes = bytes;
+	return q;
+}
+
+void PinnedPoolRelease(void *p, size_t bytes) {
+	if (!p) {
+		return;
+	}
+	{
+		std::lock_guard<std::mutex> lock(g_pinned_mutex);
+		if (g_pinned_free_bytes + bytes <= PinnedPoolLimit()) {
+			g_pinned_free.push_back(PinnedBlock {p, bytes});
+			g_pinned_free_bytes += bytes;
+			return;
+		}
+	}
+	pgh_host_free(p);
+}
+
 // ---- tally passes ------------------------------------------------------------------------------
 
 bool GetPlinkingTallyCache(ClientContext &context) {
@@ -1677,6 +1738,18 @@ void DeviceTally::SampleMissing(uint32_t *out, const string &func_name) {
 	if (pgh_tally_sample_missing(handle, out, errbuf) != PGH_OK) {
 		throw IOException("%s: PgrGetMissingness failed: %s", func_name, string(errbuf));
 	}
+}
+
+shared_ptr<DeviceTally> DeviceDataset::FindTally(const vector<uint64_t> *sample_include, uint32_t begin, uint32_t end) {
+	static const vector<uint64_t> kAll;
+	const vector<uint64_t> &want_mask = sample_include ? *sample_include : kAll;
+	std::lock_guard<std::mutex> lock(tally_mutex_);
+	for (auto &t : tallies_) {
+		if (t->begin <= begin && t->end >= end && t->mask == want_mask) {
+			return t;
+		}
+	}
+	return nullptr;
 }
 
 shared_ptr<DeviceTally> DeviceDataset::AcquireTally(const vector<uint64_t> *sample_include, uint32_t begin,

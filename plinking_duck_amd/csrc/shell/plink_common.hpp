@@ -277,6 +277,9 @@ public:
 	//! plinking_tally_cache = false (or PLINKING_TALLY_CACHE=0) gives every call a pass of its own.
 	shared_ptr<DeviceTally> AcquireTally(const vector<uint64_t> *sample_include, uint32_t begin, uint32_t end,
 	                                     uint32_t products, bool exact_range, bool use_cache, const string &func_name);
+	//! A pass somebody already started that covers [begin, end) for this mask, or null: for callers that can use
+	//! the tallies but would not walk the whole range for them (plink_score, plink_pca's AF prepass).
+	shared_ptr<DeviceTally> FindTally(const vector<uint64_t> *sample_include, uint32_t begin, uint32_t end);
 
 private:
 	std::mutex tally_mutex_;
@@ -337,6 +340,12 @@ public:
 //! A grow-only buffer of page-locked host memory (pgh_host_alloc): what a scan thread hands to the host-buffer
 //! entry points chunk after chunk, so the device-to-host copies run at the link's rate with no staging hop
 //! (the reference's counterpart is the per-thread AlignedBuffer, src/plink_common.hpp:65-118).
+//! Blocks come from (and go back to) a process-wide pool: page-locking a gigabyte costs a few hundred
+//! milliseconds, more than a short query's whole scan, and sixteen scan threads locking at once serialise in the
+//! kernel.  The pool keeps what finished queries returned, up to PLINKING_PINNED_POOL_GB (default 24).
+void *PinnedPoolAcquire(size_t bytes, size_t &got_bytes);
+void PinnedPoolRelease(void *p, size_t bytes);
+
 template <class T>
 class PinnedBuffer {
 public:
@@ -344,24 +353,17 @@ public:
 	PinnedBuffer(const PinnedBuffer &) = delete;
 	PinnedBuffer &operator=(const PinnedBuffer &) = delete;
 	~PinnedBuffer() {
-		pgh_host_free(p_);
+		PinnedPoolRelease(p_, bytes_);
 	}
 	//! at least n elements; contents are not kept
 	void resize(size_t n) {
-		if (n <= cap_) {
+		if (n * sizeof(T) <= bytes_) {
 			return;
 		}
-		pgh_host_free(p_);
+		PinnedPoolRelease(p_, bytes_);
 		p_ = nullptr;
-		cap_ = 0;
-		void *q = nullptr;
-		char errbuf[PGH_ERRBUF_LEN] = {0};
-		if (pgh_host_alloc(n * sizeof(T), &q, errbuf) != PGH_OK) {
-			throw IOException("cannot allocate %llu bytes of pinned host memory: %s",
-			                  static_cast<unsigned long long>(n * sizeof(T)), string(errbuf));
-		}
-		p_ = static_cast<T *>(q);
-		cap_ = n;
+		bytes_ = 0;
+		p_ = static_cast<T *>(PinnedPoolAcquire(n * sizeof(T), bytes_));
 	}
 	T *data() {
 		return p_;
@@ -372,8 +374,31 @@ public:
 
 private:
 	T *p_ = nullptr;
-	size_t cap_ = 0;
+	size_t bytes_ = 0;
 };
+
+//! dst bits [dst_bit, dst_bit + n) = src bits [0, n) (bit set = valid), whole words at a time; the other bits
+//! of dst keep their values.  dst must hold ceil((dst_bit + n) / 64) words.
+inline void CopyValidityBits(uint64_t *dst, idx_t dst_bit, const uint64_t *src, idx_t n) {
+	if (n == 0) {
+		return;
+	}
+	const unsigned shift = static_cast<unsigned>(dst_bit & 63);
+	uint64_t *d = dst + (dst_bit >> 6);
+	const idx_t words = (n + 63) / 64;
+	const unsigned tail = static_cast<unsigned>(n & 63); // valid bits of the last source word (0 = all 64)
+	for (idx_t w = 0; w < words; w++) {
+		const unsigned nb = (w + 1 == words && tail) ? tail : 64u;
+		const uint64_t keep = nb == 64 ? ~0ull : ((1ull << nb) - 1);
+		const uint64_t bits = src[w] & keep;
+		// low part into d[w]
+		d[w] = (d[w] & ~(keep << shift)) | (bits << shift);
+		if (shift && nb + shift > 64) {
+			const uint64_t hi_keep = keep >> (64 - shift);
+			d[w + 1] = (d[w + 1] & ~hi_keep) | (bits >> (64 - shift));
+		}
+	}
+}
 
 //! Header probe (replaces the bind-time PgfiInitPhase1/2 of every function).
 pgh_info ProbePgen(const string &pgen_path, const string &func_name);

@@ -98,15 +98,14 @@ static unique_ptr<FunctionData> PlinkPcaBind(ClientContext &context, TableFuncti
 			bind_data->subset =
 			    make_shared<DeviceSubset>(*bind_data->dataset, c.sample_subset->sample_include, "plink_pca");
 		}
-		vector<uint32_t> counts(4 * static_cast<size_t>(range_end - range_start));
-		char errbuf[PGH_ERRBUF_LEN] = {0};
-		int rc = pgh_counts_range(bind_data->dataset->handle, bind_data->subset ? bind_data->subset->handle : nullptr,
-		                          range_start, range_end, reinterpret_cast<uint32_t(*)[4]>(counts.data()), errbuf);
-		if (rc != PGH_OK) {
-			throw IOException("plink_pca: PgrGetCounts failed: %s", string(errbuf));
-		}
+		// the range's tally pass: shared with plink_freq & co. and with the next plink_pca on this file and subset
+		// (the reference's prepass is a single-threaded PgrGetCounts loop in bind, src/plink_pca.cpp:392-416)
+		auto pass = bind_data->dataset->AcquireTally(c.has_sample_subset ? &c.sample_subset->sample_include : nullptr,
+		                                             range_start, range_end, PGH_TALLY_COUNTS, false,
+		                                             GetPlinkingTallyCache(context), "plink_pca");
+		pass->Wait(PGH_TALLY_COUNTS, range_start, range_end, "plink_pca");
 		for (uint32_t vidx = range_start; vidx < range_end; vidx++) {
-			const uint32_t *gc = counts.data() + 4 * static_cast<size_t>(vidx - range_start);
+			const uint32_t *gc = pass->Counts(vidx);
 			uint32_t obs = gc[0] + gc[1] + gc[2];
 			if (obs == 0) {
 				continue;
@@ -202,12 +201,26 @@ static unique_ptr<LocalTableFunctionState> PlinkPcaInitLocal(ExecutionContext &,
 
 static void RunAlgorithm(const PlinkPcaBindData &bind_data, PlinkPcaGlobalState &gs) {
 	// G1 seed: the exact libstdc++ stream the reference draws (src/plink_pca.cpp:517-523)
-	vector<double> g1(static_cast<size_t>(gs.N) * bind_data.pc_ct_x2);
-	std::mt19937_64 rng(12345);
-	std::normal_distribution<double> dist(0.0, 1.0);
-	for (auto &val : g1) {
-		val = dist(rng);
+	// The seed is fixed, so the matrix depends on its size only: the last one is kept (ten million sequential
+	// draws are ~0.1 s of a 0.5 s call at 500,000 samples).
+	static std::mutex seed_mutex;
+	static shared_ptr<const vector<double>> seed_cache;
+	const size_t g1_len = static_cast<size_t>(gs.N) * bind_data.pc_ct_x2;
+	shared_ptr<const vector<double>> g1_ptr;
+	{
+		std::lock_guard<std::mutex> lock(seed_mutex);
+		if (!seed_cache || seed_cache->size() != g1_len) {
+			auto fresh = make_shared<vector<double>>(g1_len);
+			std::mt19937_64 rng(12345);
+			std::normal_distribution<double> dist(0.0, 1.0);
+			for (auto &val : *fresh) {
+				val = dist(rng);
+			}
+			seed_cache = fresh;
+		}
+		g1_ptr = seed_cache;
 	}
+	const vector<double> &g1 = *g1_ptr;
 	char errbuf[PGH_ERRBUF_LEN] = {0};
 	int rc = pgh_pca(bind_data.dataset->handle, bind_data.subset ? bind_data.subset->handle : nullptr, gs.M,
 	                 bind_data.effective_variants.data(), bind_data.centers.data(), bind_data.inv_stdevs.data(),

@@ -8,6 +8,8 @@
 // and accumulate score / dosage sum / allele count per sample.
 #include "variant_scan.hpp"
 
+#include <cstring>
+
 #include <algorithm>
 #include <cmath>
 #include <mutex>
@@ -31,6 +33,9 @@ struct ScoredVariant {
 struct PlinkScoreBindData : public TableFunctionData {
 	PgenBindCommon c;
 	vector<ScoredVariant> scored_variants;
+	vector<uint32_t> scored_vidx; // the same list as the arrays pgh_score takes
+	vector<double> scored_weights;
+	vector<uint8_t> scored_flip;
 	bool center = false;
 	bool no_mean_imputation = false;
 	vector<uint32_t> sample_output_order; // output row -> original sample index
@@ -48,6 +53,7 @@ struct PlinkScoreGlobalState : public GlobalTableFunctionState {
 	vector<column_t> column_ids;
 	uint32_t db_thread_count = 1;
 	uint32_t max_threads_config = 0;
+	bool use_tally_cache = true;
 	shared_ptr<DeviceDataset> dataset;
 	unique_ptr<DeviceSubset> subset;
 
@@ -169,6 +175,17 @@ static unique_ptr<FunctionData> PlinkScoreBind(ClientContext &context, TableFunc
 		throw InvalidInputException("plink_score: weights parameter is required");
 	}
 	bind_data->scored_variants = ResolveWeights(weights_it->second, c.variants, c.RangeStart(), c.RangeEnd());
+	// the three arrays pgh_score takes, once per bind (a million scored variants: a few milliseconds of loops that
+	// the first scan thread would otherwise spend with fifteen others waiting on it)
+	const size_t n_scored = bind_data->scored_variants.size();
+	bind_data->scored_vidx.resize(n_scored);
+	bind_data->scored_weights.resize(n_scored);
+	bind_data->scored_flip.resize(n_scored);
+	for (size_t i = 0; i < n_scored; i++) {
+		bind_data->scored_vidx[i] = bind_data->scored_variants[i].variant_idx;
+		bind_data->scored_weights[i] = bind_data->scored_variants[i].weight;
+		bind_data->scored_flip[i] = bind_data->scored_variants[i].flip;
+	}
 
 	names = {"FID", "IID", "ALLELE_CT", "DENOM", "NAMED_ALLELE_DOSAGE_SUM", "SCORE_SUM", "SCORE_AVG"};
 	return_types = {LogicalType::VARCHAR, LogicalType::VARCHAR, LogicalType::INTEGER, LogicalType::INTEGER,
@@ -189,6 +206,7 @@ static unique_ptr<GlobalTableFunctionState> PlinkScoreInitGlobal(ClientContext &
 	state->column_ids = input.column_ids;
 	state->db_thread_count = static_cast<uint32_t>(context.db_threads);
 	state->max_threads_config = GetPlinkingMaxThreads(context);
+	state->use_tally_cache = GetPlinkingTallyCache(context);
 	bool need_scores = false;
 	for (auto col_id : input.column_ids) {
 		if (col_id != COLUMN_IDENTIFIER_ROW_ID && col_id >= COL_ALLELE_CT) {
@@ -223,21 +241,32 @@ static void PlinkScoreScan(ClientContext &, TableFunctionInput &data_p, DataChun
 				{
 					// hardcalls and dosage tracks alike: the library scores a dosage-bearing variant from its
 					// dosages, as PgrGetD hands them to the reference loop (src/plink_score.cpp:586-652)
-					size_t n_scored = bind_data.scored_variants.size();
-					vector<uint32_t> vidx(n_scored);
-					vector<double> weights(n_scored);
-					vector<uint8_t> flip(n_scored);
-					for (size_t i = 0; i < n_scored; i++) {
-						vidx[i] = bind_data.scored_variants[i].variant_idx;
-						weights[i] = bind_data.scored_variants[i].weight;
-						flip[i] = bind_data.scored_variants[i].flip;
-					}
+					const size_t n_scored = bind_data.scored_variants.size();
+					const vector<uint32_t> &vidx = bind_data.scored_vidx;
+					const vector<double> &weights = bind_data.scored_weights;
+					const vector<uint8_t> &flip = bind_data.scored_flip;
 					int mode = bind_data.center ? PGH_SCORE_CENTER
 					                            : (bind_data.no_mean_imputation ? PGH_SCORE_NO_MEAN_IMPUTATION
 					                                                            : PGH_SCORE_MEAN_IMPUTE);
+					// the scored variants' tallies, if a pass over this file and subset already holds them
+					// (plink_freq & co. ran before): the per-variant means then cost no read of the rows
+					vector<uint32_t> counts;
+					if (gstate.use_tally_cache) {
+						auto pass = gstate.dataset->FindTally(
+						    bind_data.c.has_sample_subset ? &bind_data.c.sample_subset->sample_include : nullptr,
+						    vidx.front(), vidx.back() + 1);
+						if (pass) {
+							pass->Wait(PGH_TALLY_COUNTS, vidx.front(), vidx.back() + 1, "plink_score");
+							counts.resize(4 * n_scored);
+							for (size_t i = 0; i < n_scored; i++) {
+								std::memcpy(&counts[4 * i], pass->Counts(vidx[i]), 16);
+							}
+						}
+					}
 					char errbuf[PGH_ERRBUF_LEN] = {0};
-					int rc = pgh_score(gstate.dataset->handle, gstate.subset ? gstate.subset->handle : nullptr,
+					int rc = pgh_score_counts(gstate.dataset->handle, gstate.subset ? gstate.subset->handle : nullptr,
 					                   static_cast<uint32_t>(n_scored), vidx.data(), weights.data(), flip.data(), 1, mode,
+					                   counts.empty() ? nullptr : reinterpret_cast<const uint32_t(*)[4]>(counts.data()),
 					                   gstate.score_sums.data(),
 					                   gstate.need_dosage_sum ? gstate.named_allele_dosage_sums.data() : nullptr,
 					                   gstate.allele_cts.data(), errbuf);

@@ -21,7 +21,10 @@
 
 namespace duckdb {
 
-constexpr uint32_t kDeviceBatch = 16384;
+//! Variants a scan thread claims at a time: two output chunks' worth -- the reference claims 128
+//! (src/plink_freq.cpp:413); nothing is launched per claim here (the range's pass is already running), so the
+//! claim only sets how finely the threads share the range.  read_pgen's genotype output claims one chunk's span.
+constexpr uint32_t kDeviceBatch = 4096;
 
 struct VariantScanGlobal {
 	std::atomic<uint32_t> next_variant_idx {0};
@@ -36,6 +39,7 @@ struct VariantScanGlobal {
 	shared_ptr<DeviceTally> tally, male_tally, female_tally;
 	uint32_t strata_begin = 0, strata_end = 0;
 	uint32_t wait_products = PGH_TALLY_COUNTS; // what a thread waits for per batch (plink_hardy adds the exact tests)
+	uint32_t claim = kDeviceBatch;             // variants per claim
 	// read_pgen's `variants :=` list: the scan walks list positions (caller order, as the
 	// reference's effective_variant_indices does) and claims kListBatch of them at a time.
 	bool has_variant_list = false;
@@ -95,11 +99,11 @@ struct VariantScanLocal {
 			return NextListed(g, func_name, vidx);
 		}
 		if (cursor >= batch_end) {
-			uint32_t begin = g.next_variant_idx.fetch_add(kDeviceBatch);
+			uint32_t begin = g.next_variant_idx.fetch_add(g.claim);
 			if (begin >= g.end_variant_idx) {
 				return false;
 			}
-			uint32_t end = std::min<uint64_t>(g.end_variant_idx, static_cast<uint64_t>(begin) + kDeviceBatch);
+			uint32_t end = std::min<uint64_t>(g.end_variant_idx, static_cast<uint64_t>(begin) + g.claim);
 			batch_begin = begin;
 			batch_end = end;
 			cursor = begin;

@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "pgh_synth_create", "pgh_synth_record_host", "pgh_synth_write_files", "pgh_copy_rows_to_host", "pgh_get_info", "pgh_device_rows",
     "pgh_close", "pgh_subset_create", "pgh_subset_size", "pgh_subset_destroy", "pgh_counts_range",
     "pgh_counts_range_dev", "pgh_freq_from_counts_dev", "pgh_fused_tally_dev", "pgh_missing_per_sample", "pgh_missing_per_sample_dev", "pgh_unpack_range",
-    "pgh_unpack_range_dev", "pgh_score", "pgh_score_dev", "pgh_score_plan_create", "pgh_score_run_dev",
+    "pgh_unpack_range_dev", "pgh_score", "pgh_score_counts", "pgh_score_dev", "pgh_score_plan_create", "pgh_score_run_dev",
     "pgh_score_plan_destroy", "pgh_pca", "pgh_pca_sharded", "pgh_ld_pairs", "pgh_ld_pairs_dev", "pgh_ld_pairs_status", "pgh_sample_counts", "pgh_sample_counts_dev",
     "pgh_synth_add_dosage", "pgh_synth_write_dosage_files", "pgh_dosage_sums", "pgh_dosage_sums_dev", "pgh_dosage_unpack", "pgh_dosage_unpack_dev", "pgh_unpack_samples", "pgh_dosage_unpack_samples", "pgh_reader_create", "pgh_reader_destroy",
     "pgh_get_2bit", "pgh_get_counts", "pgh_get_missingness", "pgh_get_int8", "pgh_get_dosage_f64", "pgh_get_phased",
@@ -111,6 +111,7 @@ def _load():
         "pgh_unpack_range_dev": (C.c_int, [vp, vp, u32, u32, vp, C.c_size_t, vp, C.c_int, vp, cp]),
         "pgh_score": (C.c_int, [vp, vp, u32, vp, vp, vp, u32, C.c_int, vp, vp, vp, cp]),
         "pgh_score_dev": (C.c_int, [vp, vp, u32, vp, vp, vp, u32, C.c_int, vp, vp, vp, vp, cp]),
+        "pgh_score_counts": (C.c_int, [vp, vp, u32, vp, vp, vp, u32, C.c_int, vp, vp, vp, vp, cp]),
         "pgh_score_plan_create": (C.c_int, [vp, vp, u32, vp, vp, vp, u32, C.c_int, C.POINTER(vp), cp]),
         "pgh_score_run_dev": (C.c_int, [vp, vp, vp, vp, vp, cp]),
         "pgh_score_plan_destroy": (None, [vp]),
@@ -499,7 +500,8 @@ class Dataset:
                                          d_validity, missing_code, stream, eb), eb)
 
     def score(self, vidx, weights, flip=None, mode: int = SCORE_MEAN_IMPUTE, subset: Subset | None = None,
-              want_dosage_sum: bool = True):
+              want_dosage_sum: bool = True, counts=None):
+        """counts (optional): uint32[n_scored][4], the scored variants' class tallies (pgh_score_counts)."""
         vidx = np.ascontiguousarray(vidx, dtype=np.uint32)
         weights = np.ascontiguousarray(weights, dtype=np.float64)
         if weights.ndim == 1:
@@ -512,6 +514,11 @@ class Dataset:
         dos = np.zeros(n_out, dtype=np.float64) if want_dosage_sum else None
         ac = np.zeros(n_out, dtype=np.uint32)
         eb = _errbuf()
+        if counts is not None:
+            counts = np.ascontiguousarray(counts, dtype=np.uint32).reshape(n_scored, 4)
+            _check(_lib.pgh_score_counts(self._h, subset._h if subset else None, n_scored, _ptr(vidx), _ptr(weights),
+                                         _ptr(flip_a), n_cols, mode, _ptr(counts), _ptr(score), _ptr(dos), _ptr(ac), eb), eb)
+            return score, dos, ac
         _check(_lib.pgh_score(self._h, subset._h if subset else None, n_scored, _ptr(vidx), _ptr(weights), _ptr(flip_a),
                               n_cols, mode, _ptr(score), _ptr(dos), _ptr(ac), eb), eb)
         return score, dos, ac

@@ -217,3 +217,27 @@ def test_config_1_at_its_stated_shape(gpu_lib, oracle, tmp_path):
         v = int(vid[2:])
         exp_af, exp_obs = oracle.freq_from_counts(want[v])
         assert cc == [int(x) for x in want[v]] and obs == exp_obs and af == exp_af
+
+
+def test_score_from_a_pass_s_counts(gpu_lib, oracle):
+    """pgh_score_counts: the tallies of a pass in the place of the plan's own read of the rows."""
+    L = gpu_lib
+    m, n = 3000, 2003
+    ds = L.Dataset.synth(0, m, n, SEED, 0.05)
+    pg = host_pgen(oracle, np.stack([L.synth_record_host(v, n, SEED, 0.05) for v in range(m)]), n)
+    rng = np.random.default_rng(11)
+    vidx = np.sort(rng.choice(m, 1200, replace=False)).astype(np.uint32)
+    w = rng.normal(size=(len(vidx), 3))
+    flip = (rng.random(len(vidx)) < 0.3).astype(np.uint8)
+    mask = rng.random(n) < 0.6
+    for subset, include in ((None, None), (ds.subset(mask), mask)):
+        t = L.TallyPass(ds, subset=subset)
+        counts = t.counts()[vidx]
+        for mode, name in ((L.SCORE_MEAN_IMPUTE, "default"), (L.SCORE_NO_MEAN_IMPUTATION, "no_mean_imputation"),
+                           (L.SCORE_CENTER, "center")):
+            a = ds.score(vidx, w, flip, mode, subset=subset)
+            b = ds.score(vidx, w, flip, mode, subset=subset, counts=counts)
+            assert np.allclose(a[0], b[0], rtol=1e-12, atol=1e-9) and np.allclose(a[1], b[1], rtol=1e-12, atol=1e-9)
+            assert np.array_equal(a[2], b[2])
+            exp = oracle.score(pg, vidx, w[:, 0], flip, name, include=include)
+            assert np.allclose(b[0][:, 0], exp[0][:, 0], rtol=1e-9, atol=1e-9) and np.array_equal(b[2], exp[2])

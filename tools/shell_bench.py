@@ -33,6 +33,9 @@ def main():
     ap.add_argument("--synth", default="", help="<variants>x<samples>: resident synthetic source, drained chunks")
     ap.add_argument("--pca-variants", type=int, default=100_000)
     ap.add_argument("--no-cache", action="store_true", help="plinking_tally_cache = false: every call walks the matrix")
+    ap.add_argument("--list-variants", type=int, default=131_072,
+                    help="--synth: variants of the separate resident source read_pgen's genotype lists are timed on")
+    ap.add_argument("--only", default="", help="comma-separated substrings of the labels to run")
     args = ap.parse_args()
     synth = bool(args.synth)
     if synth:
@@ -59,17 +62,26 @@ def main():
          dict(samples=list(range(0, n, max(1, n // 1000)))[:1000], columns=["ID", "ALT_FREQ", "OBS_CT"])),
         ("plink_score", "plink_score", m, dict(weights=w, columns=["IID", "SCORE_SUM"])),
         ("read_pgen counts", "read_pgen", m, dict(genotypes="counts", columns=["ID", "genotypes"])),
-        ("read_pgen list, chromosome 1", "read_pgen" if not synth else "read_pfile", per_chrom,
-         dict(genotypes="list", columns=["ID", "genotypes"], **({"region": "1:1-2000000000"} if synth else {}))),
+        ("read_pgen list", "read_pgen", m, dict(genotypes="list", columns=["ID", "genotypes"])),
         ("read_pfile sample counts", "read_pfile", m, dict(orient="sample", genotypes="counts", columns=["IID", "genotypes"])),
     ]
-    if not synth:
-        calls[8] = ("read_pgen list", "read_pgen", m, dict(genotypes="list", columns=["ID", "genotypes"]))
+    if synth:
+        # genotype lists: 4.5 bytes per genotype go to the host, so a source of their own size (twice: the second
+        # call finds the pinned blocks and staging of the first)
+        ml = min(args.list_variants, m)
+        calls[8:9] = [(f"read_pgen list ({ml} variants; first call)", "read_pgen", ml, dict(genotypes="list", columns=["ID", "genotypes"])),
+                      (f"read_pgen list ({ml} variants)", "read_pgen", ml, dict(genotypes="list", columns=["ID", "genotypes"]))]
     rec = (n + 3) // 4
+    only = [x for x in args.only.split(",") if x]
     for label, fn, variants, kw in calls:
-        target = prefix if fn == "read_pfile" else path
-        if fn == "read_pgen" and kw.get("genotypes") == "list" and not synth and m * n > 4e9:
+        if only and not any(x in label for x in only):
             continue
+        target = prefix if fn == "read_pfile" else path
+        if fn == "read_pgen" and kw.get("genotypes") == "list":
+            if not synth and m * n > 4e9:
+                continue
+            if synth:
+                target = f"synth:{variants}x{n}:20260807:0.02"
         t0 = time.perf_counter()
         r = F.query(fn, target, threads=args.threads, drain=synth, settings=settings, **kw)
         wall = time.perf_counter() - t0
@@ -81,8 +93,10 @@ def main():
             both = max(t["scan"] + t["init"], 1e-3) * 1e-3
             line += (f"  scan {variants * n / scan_s:9.3e} genotypes/s = {variants * rec / scan_s / 8e12:5.3f} of HBM;"
                      f" init+scan {variants * rec / both / 8e12:5.3f}")
+            if kw.get("genotypes") == "list":
+                line += f"; {variants * (n + (n + 63) // 64 * 8) / scan_s / 1e9:6.1f} GB/s to the host"
         print(line, flush=True)
-    if synth:
+    if synth and (not only or any("pca" in x for x in only)):
         # plink_pca at BASELINE config 5's shape: its own resident source
         mp = min(args.pca_variants, m)
         spec = f"synth:{mp}x{n}:20260807:0.02"
