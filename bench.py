@@ -76,6 +76,12 @@ def parse_args():
     ap.add_argument("--score-cols", type=int, default=16)
     ap.add_argument("--score-no-dosage-sum", action="store_true",
                     help="score workload without NAMED_ALLELE_DOSAGE_SUM (what SELECT IID, SCORE_SUM projects)")
+    ap.add_argument("--configs", choices=["auto", "all", "none"], default="auto",
+                    help="auto: the default single-GPU freq run at 1 M x 500 k also times BASELINE configs 2-5 "
+                         "(fused, unpack, score x16 / x1, pca) on the same matrix and attaches them as \"configs\"")
+    ap.add_argument("--config-steps", type=int, default=5, help="timed steps per extra config")
+    ap.add_argument("--no-sql", dest="sql", action="store_false",
+                    help="skip the table-function section (plink_freq / hardy / missing through the shells)")
     return ap.parse_args()
 
 
@@ -199,19 +205,43 @@ def host_tallies(np, rec, n):
     return np.bincount(codes.reshape(-1)[:n], minlength=4).astype(np.int64), codes.reshape(-1)[:n]
 
 
-def verify(args, L, np, torch, ds, env):
+def oracle_image(np, rows, n):
+    """The rows (uint8[k][ceil(N/4)]) as a fixed-width .pgen image (mode 0x02) the oracle opens from memory."""
+    from oracle import oracle
+    k = rows.shape[0]
+    head = bytes([0x6c, 0x1b, 0x02]) + int(k).to_bytes(4, "little") + int(n).to_bytes(4, "little") + b"\x40"
+    return oracle.Pgen(mem=np.concatenate([np.frombuffer(head, dtype=np.uint8), rows.reshape(-1)]))
+
+
+def recount_rows(np, ds, picks, v_begin, n):
+    """The oracle's tallies and calls of the listed rows AS THEY SIT IN HBM (copied back, not regenerated):
+    the check that can fail when a kernel drops or double-counts part of a row."""
+    rows = np.concatenate([ds.copy_rows_to_host(v_begin + int(r), v_begin + int(r) + 1) for r in picks])
+    pg = oracle_image(np, rows, n)
+    return pg, pg.scan_counts_mt(0, len(picks), min(8, os.cpu_count() or 1)).astype(np.int64)
+
+
+def verify(args, wl, C, env):
     """Size-independent checks on the LAST timed step's results (the timed region has ended and was
     synchronised).  True / False, or None for a workload without a check."""
+    L, np, torch, ds = C.L, C.np, C.torch, C.ds
     n, m = env["n"], env["m"]
     v_begin = env["v_begin"]
     if m == 0:
         return True
     picks = sorted({0, m // 2, m - 1})
-    wl = args.workload
+    rng = np.random.default_rng(SEED + 99)
     if wl in ("freq", "fused"):
         hc = env["h_counts"].numpy().astype(np.int64)
-        if not np.array_equal(hc.sum(axis=1), np.full(m, n)):
-            print("verify: rows do not tally to N", file=sys.stderr)
+        # (hom_ref is N minus the other three in every tally kernel, so "rows add up to N" cannot fail; what
+        # can is a recount:) 256 random rows plus the first and last, copied back from HBM and tallied by the
+        # oracle's multi-threaded scan, bit-exact
+        recount = sorted(set(rng.choice(m, size=min(m, 256), replace=False).tolist()) | set(picks))
+        _, want = recount_rows(np, ds, recount, v_begin, n)
+        if not np.array_equal(want, hc[recount]):
+            bad = [r for i, r in enumerate(recount) if not np.array_equal(want[i], hc[r])]
+            print(f"verify: {len(bad)} of {len(recount)} recounted rows differ from the oracle, first: variant "
+                  f"{v_begin + bad[0]}: {hc[bad[0]]} != {want[recount.index(bad[0])]}", file=sys.stderr)
             return False
         obs = hc[:, :3].sum(axis=1)
         af = (hc[:, 1] + 2 * hc[:, 2]) / np.where(obs > 0, 2.0 * obs, np.nan)
@@ -225,8 +255,16 @@ def verify(args, L, np, torch, ds, env):
                 print(f"verify: variant {v_begin + r}: {hc[r]} != host {want}", file=sys.stderr)
                 return False
         if wl == "fused":
-            if int(env["h_miss"].numpy().astype(np.int64).sum()) != int(hc[:, 3].sum()):
+            hm = env["h_miss"].numpy().astype(np.int64)
+            if int(hm.sum()) != int(hc[:, 3].sum()):
                 print("verify: per-sample missing counts do not add up to the per-variant ones", file=sys.stderr)
+                return False
+            # ... and 64 random samples' columns against a second kernel (k_class_cols1) -- the column tally of
+            # the fused pass and the per-sample pass share no code path below the loads
+            alone = ds.missing_per_sample(v_begin, v_begin + m).astype(np.int64)
+            cols = rng.choice(n, size=min(n, 64), replace=False)
+            if not np.array_equal(alone[cols], hm[cols]):
+                print("verify: per-sample missing counts differ from the per-sample kernel's", file=sys.stderr)
                 return False
         return True
     if wl == "unpack":
@@ -234,13 +272,16 @@ def verify(args, L, np, torch, ds, env):
         last0 = (m - 1) // chunk * chunk  # the rows of the last launch
         out = env["d_out"]
         val = env["d_val"]
-        for r in sorted({last0, m - 1}):
-            _, codes = host_tallies(np, L.synth_record_host(v_begin + r, n, SEED, MISSING_RATE), n)
+        # 64 random rows of the last launch plus its first and last, copied back from HBM and decoded by the oracle
+        rows = sorted(set((last0 + rng.choice(m - last0, size=min(m - last0, 64), replace=False)).tolist()) | {last0, m - 1})
+        pg, _ = recount_rows(np, ds, rows, v_begin, n)
+        for i, r in enumerate(rows):
+            codes = pg.geno(i)  # {0, 1, 2, -9}
             got = out[r - last0, :n].cpu().numpy()
-            want = np.where(codes == 3, 0, codes).astype(np.int8)
+            want = np.where(codes < 0, 0, codes).astype(np.int8)
             bits = np.unpackbits(val[r - last0].cpu().numpy().view(np.uint8), bitorder="little")[:n]
-            if not (np.array_equal(got, want) and np.array_equal(bits, (codes != 3).astype(np.uint8))):
-                print(f"verify: unpacked variant {v_begin + r} differs from the host decode", file=sys.stderr)
+            if not (np.array_equal(got, want) and np.array_equal(bits, (codes >= 0).astype(np.uint8))):
+                print(f"verify: unpacked variant {v_begin + r} differs from the oracle's decode", file=sys.stderr)
                 return False
         return True
     if wl in ("missingsample", "samplecounts"):
@@ -332,58 +373,23 @@ def verify(args, L, np, torch, ds, env):
     return None
 
 
-def main():
-    args = parse_args()
-    if args.gpus < 1:
-        raise SystemExit("--gpus must be at least 1")
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        return self_launch(args)
-    import numpy as np
-    import torch
-
-    import plinking_duck_amd.lib as L
-    from plinking_duck_amd import sharding
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but {world} rank(s) were launched (WORLD_SIZE={world})")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    if torch.cuda.device_count() <= local_rank:
-        raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank} but this node has {torch.cuda.device_count()}")
-    torch.cuda.set_device(local_rank)
-    L.set_device(local_rank)
-    dist = None
-    # under torch.distributed.run the process group comes up even for one rank, so the
-    # collective path of the N-rank run is the path that runs (and is rehearsed on one GPU)
-    if world > 1 or "RANK" in os.environ:
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    n = args.samples
-    if args.workload.startswith("dosage") and args.variants == 1_000_000:
-        args.variants = 250_000  # rows + presence bits + ranks + values of 1M variants do not fit one GPU
-    if args.workload == "pca" and args.variants == 1_000_000:
-        args.variants = 100_000  # BASELINE.json's plink_pca configuration: 100k variants x 500k samples
-    v_begin, v_end = sharding.shard_range(rank, world, args.variants, args.scaling)
-    m = v_end - v_begin
-    ds = L.Dataset.synth(v_begin, v_end, n, SEED, MISSING_RATE)
-    record_bytes = ds.info.record_bytes
-    stream = torch.cuda.current_stream()
-    st = stream.cuda_stream
-    dev = torch.device("cuda", local_rank)
-
+def build_workload(args, wl, C, score_cols=None, no_dosage_sum=None):
+    """Buffers, the step closure and the roofline inputs of one workload over the rank's resident matrix C.ds.
+    Returns a namespace: step(timed), kernel_events, kernel_name, metric, dtype, algo_bytes, algo_flops, i8_ops,
+    units_per_step, env (the locals verify() reads)."""
+    from types import SimpleNamespace
+    np, torch, L, sharding, ds, dist, dev = C.np, C.torch, C.L, C.sharding, C.ds, C.dist, C.dev
+    stream, st, n, m, v_begin, v_end, record_bytes = C.stream, C.st, C.n, C.m, C.v_begin, C.v_end, C.record_bytes
+    score_cols = args.score_cols if score_cols is None else score_cols
+    no_dosage_sum = args.score_no_dosage_sum if no_dosage_sum is None else no_dosage_sum
+    i8_ops = None
     kernel_events = []
     units_per_step = m * n  # genotypes
     algo_bytes = None
     algo_flops = None
     dtype = "u32"
 
-    if args.workload in ("freq", "fused"):
+    if wl in ("freq", "fused"):
         # Two sets of result buffers: while the tally of step i+1 streams the matrix, the results of step i
         # travel to pinned host memory on a side stream (the copy engine).
         side = torch.cuda.Stream(device=dev)
@@ -393,7 +399,7 @@ def main():
         h_counts = torch.empty((m, 4), dtype=torch.int32, pin_memory=True)
         h_freq = torch.empty(m, dtype=torch.float64, pin_memory=True)
         h_obs = torch.empty(m, dtype=torch.int32, pin_memory=True)
-        if args.workload == "fused":
+        if wl == "fused":
             d_lnp = [torch.empty(m, dtype=torch.float64, device=dev) for _ in range(2)]
             h_lnp = torch.empty(m, dtype=torch.float64, pin_memory=True)
             d_miss = [torch.empty((n + 63) // 64 * 64, dtype=torch.int32, device=dev) for _ in range(2)]
@@ -412,7 +418,7 @@ def main():
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
-            if args.workload == "fused":
+            if wl == "fused":
                 # row sums (class tallies) and column sums (per-sample missing) in ONE pass
                 ds.fused_tally_dev(v_begin, v_end, d_counts[b].data_ptr(), d_miss[b].data_ptr(), st)
             else:
@@ -423,7 +429,7 @@ def main():
             L.freq_from_counts_dev(d_counts[b].data_ptr(), m, d_freq[b].data_ptr(), d_obs[b].data_ptr(), st)
             tallied[b].record(stream)
             side.wait_event(tallied[b])
-            if args.workload == "fused":
+            if wl == "fused":
                 # plink_hardy: exact test per variant from the same counts.  A latency-bound compute kernel
                 # (one lane per variant): it runs on the side stream UNDER the next step's tally, which leaves
                 # most of every CU's issue slots free; plink_missing variant mode: counts[:,3]; sample mode:
@@ -433,15 +439,15 @@ def main():
                 h_counts.copy_(d_counts[b], non_blocking=True)
                 h_freq.copy_(d_freq[b], non_blocking=True)
                 h_obs.copy_(d_obs[b], non_blocking=True)
-                if args.workload == "fused":
+                if wl == "fused":
                     h_lnp.copy_(d_lnp[b], non_blocking=True)
                     h_miss.copy_(d_miss[b][:n], non_blocking=True)
                 drained[b] = torch.cuda.Event()
                 drained[b].record(side)
 
-        kernel_name = "k_counts_block" if args.workload == "freq" else "k_fused_tally"
-        metric = "plink_freq genotypes/s" if args.workload == "freq" else "plink_freq+hardy+missing genotypes/s"
-    elif args.workload == "unpack":
+        kernel_name = "k_counts_block" if wl == "freq" else "k_fused_tally"
+        metric = "plink_freq genotypes/s" if wl == "freq" else "plink_freq+hardy+missing genotypes/s"
+    elif wl == "unpack":
         # read_pgen genotype column: output is 4.5x the input, streamed in row chunks
         # the way DuckDB consumes it (2048-row vectors; here 8 vectors per launch)
         chunk = min(m, 16384)
@@ -466,7 +472,7 @@ def main():
         kernel_name = "k_unpack"
         metric = "read_pgen genotypes/s"
         dtype = "u8"
-    elif args.workload in ("dosagefreq", "dosagescore"):
+    elif wl in ("dosagefreq", "dosagescore"):
         # plink_freq(dosage := true) / plink_score over explicit dosages: synthetic 0x60-style tracks on every
         # variant, --dosage-rate of the samples carrying a value (the rest fall back to their hardcall)
         ds.synth_add_dosage(args.dosage_rate, SEED + 7)
@@ -474,17 +480,17 @@ def main():
         # 2-bit record + presence bits + the explicit values; the score's explicit-entry sweep also needs the
         # per-word ranks (its second read of the record, hardcall sweep then dosage sweep, is not counted)
         algo_bytes = m * record_bytes + m * words * 8 + 2 * int(ds.info.dosage_value_ct)
-        via_records = (args.workload == "dosagescore" and args.dosage_rate < 0.4
+        via_records = (wl == "dosagescore" and args.dosage_rate < 0.4
                        and os.environ.get("PGH_SCORE_DOSAGE_RECORDS", "1") != "0")
         if via_records:
             # sparse tracks: the hardcall contraction reads the 2-bit records, k_score_dosage_records the 4-byte entry
             # records (value, tile element, hardcall) and two ranks per 4096-sample tile -- no bits, no second
             # read of the rows
             algo_bytes = m * record_bytes + 4 * int(ds.info.dosage_value_ct) + m * ((words + 63) // 64) * 8
-        elif args.workload == "dosagescore":
+        elif wl == "dosagescore":
             algo_bytes += m * words * 4
         dtype = "u16"
-        if args.workload == "dosagefreq":
+        if wl == "dosagefreq":
             d_sums = torch.empty((m, 3), dtype=torch.int64, device=dev)
             h_sums = torch.empty((m, 3), dtype=torch.int64, pin_memory=True)
 
@@ -527,7 +533,7 @@ def main():
                            "k_score_dosage" if args.dosage_rate >= 0.42 else
                            "k_score_i8 + k_score_dosage_records" if via_records else "k_score_i8 + k_score_dosage_fix")
             metric = "plink_score(dosage) genotypes/s"
-    elif args.workload == "missingsample":
+    elif wl == "missingsample":
         # plink_missing mode := 'sample': per-sample missing tallies over every variant (column sums)
         padded = (n + 63) // 64 * 64
         d_miss = torch.empty(padded, dtype=torch.int32, device=dev)
@@ -547,7 +553,7 @@ def main():
 
         kernel_name = "k_class_cols1 + k_sum_cols1"
         metric = "plink_missing(sample) genotypes/s"
-    elif args.workload == "samplecounts":
+    elif wl == "samplecounts":
         # read_pfile orient := 'sample', genotypes := 'counts': per-sample {het, hom_alt, missing}
         # tallies over every variant (hom_ref by subtraction) -- one pass, three counter sets per lane
         padded = (n + 63) // 64 * 64
@@ -568,7 +574,7 @@ def main():
 
         kernel_name = "k_class_cols3 + k_sum_class_bits"
         metric = "read_pfile sample-orient counts genotypes/s"
-    elif args.workload == "ld":
+    elif wl == "ld":
         # plink_ld windowed shape: every anchor of the first --ld-variants rows against its next
         # --ld-window variants; one launch for all pairs, six integer sums per pair
         mv = min(m, args.ld_variants)
@@ -596,10 +602,11 @@ def main():
 
         kernel_name = "k_ld_pairs"
         metric = f"plink_ld sample pairs/s ({wdw} partners per anchor)"
-    elif args.workload == "pca":
+    elif wl == "pca":
         # BASELINE config 5 shape: plink_pca, k = n_pcs (qq = (k+1)*2k), all passes + orthonormalisation
         k = args.n_pcs
-        counts = ds.counts_range().astype(np.float64)
+        m_p = m if not getattr(C, "pca_variants", 0) else min(m, C.pca_variants)  # config 5 on a slice of the big matrix
+        counts = ds.counts_range(v_begin, v_begin + m_p).astype(np.float64)
         obs = counts[:, :3].sum(axis=1)
         af = (counts[:, 1] + 2 * counts[:, 2]) / (2 * np.maximum(obs, 1))
         keep = (obs > 0) & (af > 0) & (af < 1)
@@ -643,11 +650,12 @@ def main():
                 e1.record(stream)
                 kernel_events.append((e0, e1))
 
+        units_per_step = m_p * n
         kernel_name = "pgh_pca (k_score_i8 over rows and over the transposed matrix + orthonormalisation)"
         metric = f"plink_pca genotypes/s (n_pcs={k}, {k + 2} passes)"
         dtype = "i8 x i8 -> i32 (exact base-256 digits of the f64 factors), f64 elsewhere"
     else:  # score
-        ncol = args.score_cols
+        ncol = score_cols
         rng = np.random.default_rng(SEED + 1)
         vidx = np.arange(v_begin, v_end, dtype=np.uint32)
         w = rng.standard_normal((m, ncol))
@@ -667,35 +675,167 @@ def main():
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
-            plan.run_dev(d_score.data_ptr(), 0 if args.score_no_dosage_sum else d_dos.data_ptr(), d_ac.data_ptr(), st)
+            plan.run_dev(d_score.data_ptr(), 0 if no_dosage_sum else d_dos.data_ptr(), d_ac.data_ptr(), st)
             if timed:
                 e1.record(stream)
                 kernel_events.append((e0, e1))
             if dist is not None:
                 # per-sample partials of the variant shards: RCCL reduce over xGMI
-                sharding.reduce_partials(dist, [d_score, d_ac] if args.score_no_dosage_sum else [d_score, d_dos, d_ac])
+                sharding.reduce_partials(dist, [d_score, d_ac] if no_dosage_sum else [d_score, d_dos, d_ac])
 
         kernel_name = "k_score_i8"
-        metric = f"plink_score genotypes/s ({ncol} weight columns{', no dosage sum' if args.score_no_dosage_sum else ''})"
+        metric = f"plink_score genotypes/s ({ncol} weight columns{', no dosage sum' if no_dosage_sum else ''})"
         dtype = "i8 x i8 -> i32 (exact base-256 digits of the f64 coefficients), f64 out"
+
+    env = dict(locals())
+    return SimpleNamespace(step=step, kernel_events=kernel_events, kernel_name=kernel_name, metric=metric, dtype=dtype,
+                           algo_bytes=algo_bytes, algo_flops=algo_flops, i8_ops=i8_ops, units_per_step=units_per_step,
+                           env=env, workload=wl, score_cols=score_cols)
+
+def roofline_of(args, W, kern_avg_ms, n_launches, m, n, store_ceiling=None):
+    """The roofline object of one workload from its mean launch duration (HIP events on the launch stream)."""
+    wl = W.workload
+    if (wl == "score" and W.score_cols >= 2) or wl == "pca":
+        # The kernel issues v_mfma_i32_16x16x64_i8 over base-256 digits of the real factors: `frac` is the ISSUED
+        # int8 rate (7 digits per real column, tile padding included) over the dense int8 peak -- how busy the matrix
+        # pipe is kept, not useful work.  The algorithmic rate (SURVEY 8d: 2 flop per genotype and column) is given
+        # against the FP64 matrix peak the same contraction would be bound by without the digit form.
+        achieved = W.i8_ops / (kern_avg_ms * 1e-3) / 1e12
+        f64_eq = W.algo_flops / (kern_avg_ms * 1e-3) / 1e12
+        return {"bound": "mfma", "achieved": achieved, "peak": I8_PEAK_TOPS, "unit": "TFLOP/s",
+                "frac": achieved / I8_PEAK_TOPS, "frac_is": "issued int8 multiply-adds x 2 over the dense int8 peak "
+                "(matrix-pipe utilisation; 7 digit columns per real column)", "traffic": None, "kernel": W.kernel_name,
+                "kernel_ms_avg": kern_avg_ms, "launches_timed": n_launches, "ops": "int8 multiply-adds x 2",
+                "f64_equivalent_tflops": f64_eq, "algorithmic_flops_frac_of_fp64_peak": f64_eq / FP64_PEAK_TFLOPS,
+                "hbm_frac": W.algo_bytes / (kern_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    achieved = W.algo_bytes / (kern_avg_ms * 1e-3) / 1e9
+    r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+         "traffic": load_traffic("score1" if wl == "score" else wl, m, n), "kernel": W.kernel_name,
+         "kernel_ms_avg": kern_avg_ms, "launches_timed": n_launches, "algorithmic_bytes_per_launch": W.algo_bytes}
+    if wl == "unpack" and store_ceiling:
+        # 4.5 of every 5.5 bytes of this kernel are stores: what a bare kernel of the same traffic shape (16 B read ->
+        # 64 B + 8 B written per lane, no arithmetic) reaches on THIS box, measured in this run
+        r["store_ceiling"] = store_ceiling
+        r["frac_of_store_ceiling"] = achieved / store_ceiling["GB/s"]
+    return r
+
+
+def store_ceiling_probe(C):
+    """~50 ms of a bare kernel with the unpack's traffic shape (pgh_probe_unpack_shape_dev)."""
+    torch, L = C.torch, C.L
+    n_vec = (2 << 30) // 16  # 2 GB in -> 8 GB + 1 GB out per launch
+    src = torch.empty(n_vec * 16, dtype=torch.uint8, device=C.dev)
+    dst = torch.empty(n_vec * 64, dtype=torch.uint8, device=C.dev)
+    val = torch.empty(n_vec, dtype=torch.int64, device=C.dev)
+    src.zero_()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    L.probe_unpack_shape_dev(src.data_ptr(), n_vec, dst.data_ptr(), val.data_ptr(), C.st)
+    reps = 5
+    e0.record(C.stream)
+    for _ in range(reps):
+        L.probe_unpack_shape_dev(src.data_ptr(), n_vec, dst.data_ptr(), val.data_ptr(), C.st)
+    e1.record(C.stream)
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    del src, dst, val
+    return {"GB/s": n_vec * 88 / (ms * 1e-3) / 1e9, "ms": ms,
+            "shape": "16 B read -> 64 B + 8 B written per lane, non-temporal, no arithmetic"}
+
+
+def run_timed(W, steps, warmup, barrier):
+    for _ in range(warmup):
+        W.step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        W.step(True)
+    barrier()
+    return time.perf_counter() - t0
+
+
+def sql_section(args, n, threads=16):
+    """The same functions THROUGH THE TABLE-FUNCTION SHELLS (bind / init / scan threads, chunks drained as a
+    consumer would) over the same resident shape: what a SQL query costs, next to what the kernel costs."""
+    from plinking_duck_amd import functions as F
+    spec = f"synth:{args.variants}x{n}:{SEED}:{MISSING_RATE}"
+    rec = (n + 3) // 4
+    out = {}
+    calls = [("plink_freq (first call on the file: one tally pass)", "plink_freq", dict(columns=["ID", "ALT_FREQ", "OBS_CT"])),
+             ("plink_hardy (served by that pass)", "plink_hardy", dict(columns=["ID", "P_HWE"])),
+             ("plink_missing (served by that pass)", "plink_missing", dict(columns=["ID", "F_MISS"])),
+             ("plink_missing sample mode (served by that pass)", "plink_missing", dict(mode="sample", columns=["IID", "F_MISS"]))]
+    for label, fn, kw in calls:
+        r = F.query(fn, spec, threads=threads, drain=True, **kw)
+        scan_s = max(r.timing_ms["scan"], 1e-3) * 1e-3
+        out[label] = {"rows": len(r), "bind_ms": r.timing_ms["bind"], "init_ms": r.timing_ms["init"],
+                      "scan_ms": r.timing_ms["scan"], "threads": r.threads,
+                      "scan_genotypes_per_s": args.variants * n / scan_s,
+                      "scan_frac_of_hbm_roofline": args.variants * rec / scan_s / 1e9 / HBM_PEAK_GBPS}
+    return out
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
+    from types import SimpleNamespace
+
+    import numpy as np
+    import torch
+
+    import plinking_duck_amd.lib as L
+    from plinking_duck_amd import sharding
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but {world} rank(s) were launched (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank} but this node has {torch.cuda.device_count()}")
+    torch.cuda.set_device(local_rank)
+    L.set_device(local_rank)
+    dist = None
+    # under torch.distributed.run the process group comes up even for one rank, so the
+    # collective path of the N-rank run is the path that runs (and is rehearsed on one GPU)
+    if world > 1 or "RANK" in os.environ:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n = args.samples
+    if args.workload.startswith("dosage") and args.variants == 1_000_000:
+        args.variants = 250_000  # rows + presence bits + ranks + values of 1M variants do not fit one GPU
+    if args.workload == "pca" and args.variants == 1_000_000:
+        args.variants = 100_000  # BASELINE.json's plink_pca configuration: 100k variants x 500k samples
+    v_begin, v_end = sharding.shard_range(rank, world, args.variants, args.scaling)
+    m = v_end - v_begin
+    ds = L.Dataset.synth(v_begin, v_end, n, SEED, MISSING_RATE)
+    record_bytes = ds.info.record_bytes
+    stream = torch.cuda.current_stream()
+    st = stream.cuda_stream
+    dev = torch.device("cuda", local_rank)
+
+    C = SimpleNamespace(np=np, torch=torch, L=L, sharding=sharding, ds=ds, dist=dist, dev=dev, stream=stream, st=st, n=n,
+                        m=m, v_begin=v_begin, v_end=v_end, record_bytes=record_bytes, rank=rank, world=world,
+                        pca_variants=0)
+    W = build_workload(args, args.workload, C)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(False)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = run_timed(W, args.steps, args.warmup, barrier)
     if dist is not None:
         elapsed = sharding.max_over_ranks(dist, elapsed, dev)
 
-    verified = verify(args, L, np, torch, ds, locals())
+    verified = verify(args, args.workload, C, W.env)
     if dist is not None:
         ok = torch.tensor([0 if verified is False else 1], dtype=torch.int32, device=dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
@@ -704,37 +844,63 @@ def main():
     if verified is False:
         raise SystemExit("bench.py: the last step's results failed verification; no line reported")
 
-    kernel_ms = [a.elapsed_time(b) for a, b in kernel_events]
+    kernel_ms = [a.elapsed_time(b) for a, b in W.kernel_events]
     kern_avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
     total_units = sharding.total_variants(world, args.variants, args.scaling) * n
     if args.workload == "ld":
-        total_units = units_per_step * (world if args.scaling == "weak" else 1)  # sample pairs, every rank the same shape
+        total_units = W.units_per_step * (world if args.scaling == "weak" else 1)  # sample pairs, every rank the same shape
     value = total_units * args.steps / elapsed
+    store_ceiling = store_ceiling_probe(C) if (args.workload == "unpack" and world == 1) else None
+    roofline = roofline_of(args, W, kern_avg_ms, len(kernel_ms), m, n, store_ceiling)
+    W_metric, W_dtype = W.metric, W.dtype
 
-    if (args.workload == "score" and args.score_cols >= 2) or args.workload == "pca":
-        # priced against the dense int8 matrix peak (the instruction the kernel issues); the f64 FLOP rate the
-        # same contraction would need on the FP64 pipes is given beside it
-        achieved = i8_ops / (kern_avg_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "achieved": achieved, "peak": I8_PEAK_TOPS, "unit": "TFLOP/s",
-                    "frac": achieved / I8_PEAK_TOPS, "traffic": None, "kernel": kernel_name,
-                    "kernel_ms_avg": kern_avg_ms, "launches_timed": len(kernel_ms), "ops": "int8 multiply-adds x 2",
-                    "f64_equivalent_tflops": algo_flops / (kern_avg_ms * 1e-3) / 1e12,
-                    "hbm_frac": algo_bytes / (kern_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
-    else:
-        achieved = algo_bytes / (kern_avg_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBPS,
-                    "traffic": load_traffic("score1" if args.workload == "score" else args.workload, m, n),
-                    "kernel": kernel_name, "kernel_ms_avg": kern_avg_ms, "launches_timed": len(kernel_ms),
-                    "algorithmic_bytes_per_launch": algo_bytes}
+    # The default single-GPU run also times the other BASELINE configurations on the same resident matrix
+    # (configs 2-5: read_pgen's unpack, the fused freq + hardy + missing pass, plink_score with 16 columns and with
+    # one, plink_pca over the first 100,000 variants), each verified like its own --workload run, a few steps each.
+    configs = None
+    want_all = args.configs == "all" or (args.configs == "auto" and args.workload == "freq" and world == 1
+                                         and args.variants == 1_000_000 and n == 500_000)
+    if want_all and rank == 0:
+        configs = {}
+        primary_env = W.env
+        del W
+        ceiling = store_ceiling_probe(C)
+        plan = [("fused", "fused", {}), ("unpack", "unpack", {}), ("score16", "score", {"score_cols": 16}),
+                ("score1", "score", {"score_cols": 1}), ("pca", "pca", {})]
+        for name, wl, kw in plan:
+            C.pca_variants = 100_000 if wl == "pca" else 0
+            steps = 2 if wl == "pca" else args.config_steps
+            Wc = build_workload(args, wl, C, **kw)
+            el = run_timed(Wc, steps, 1, barrier)
+            ok = verify(args, wl, C, Wc.env)
+            if ok is False:
+                raise SystemExit(f"bench.py: config {name}: the last step's results failed verification; no line reported")
+            kms = [a.elapsed_time(b) for a, b in Wc.kernel_events]
+            kavg = float(np.mean(kms)) if kms else float("nan")
+            rf = roofline_of(args, Wc, kavg, len(kms), m, n, ceiling)
+            configs[name] = {"metric": Wc.metric, "ms_per_step": el / steps * 1e3, "steps": steps,
+                             "value": Wc.units_per_step * steps / el, "unit": "genotypes/s", "kernel": rf["kernel"],
+                             "kernel_ms_avg": kavg, "bound": rf["bound"], "frac": rf["frac"], "verified": ok,
+                             "roofline": rf}
+            del Wc
+            torch.cuda.empty_cache()
+        del primary_env
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         cpu = cpu_baseline(ds, n, args.cpu_seconds, args.cpu_sample_variants)
 
+    sql = None
+    if want_all and rank == 0 and args.sql:
+        # through the SQL shells, over a resident source of the same shape (the bench's own matrix goes first: two
+        # of them do not fit one GPU)
+        ds.close()
+        torch.cuda.empty_cache()
+        sql = sql_section(args, n)
+
     if rank == 0:
         line = {
-            "metric": metric,
+            "metric": W_metric,
             "value": value,
             "unit": "sample pairs/s" if args.workload == "ld" else "genotypes/s",
             "n_gpus": world,
@@ -744,9 +910,11 @@ def main():
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": dtype,
+            "dtype": W_dtype,
             "data": "synthetic",
             "verified": verified,
+            "verification": "recount of 258 random rows copied back from HBM by the oracle's multi-threaded scan, bit-exact"
+                            if args.workload in ("freq", "fused") else "see bench.py:verify",
             "config": {
                 "workload": f"{args.workload}: {args.variants} variants x {n} samples "
                             f"({'per GPU' if args.scaling == 'weak' else 'total'}), 2-bit hardcalls resident in HBM, "
@@ -762,6 +930,10 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
+        if configs is not None:
+            line["configs"] = configs
+        if sql is not None:
+            line["sql"] = sql
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -253,6 +253,11 @@ int pgh_unpack_range_dev(const pgh_dataset *ds, const pgh_subset *subset, uint32
                          void *d_out, size_t out_pitch, void *d_validity, int missing_code, void *stream,
                          char *errbuf);
 
+/* Measurement aid for pgh_unpack_range_dev: a bare kernel with that kernel's traffic shape -- a lane reads 16 bytes
+ * and writes 64 + 8 -- and no arithmetic, on the current device.  d_src: n_vec x 16 B, d_dst: n_vec x 64 B, d_val:
+ * n_vec x 8 B.  bench.py times it beside the unpack and reports it as roofline.store_ceiling. */
+int pgh_probe_unpack_shape_dev(const void *d_src, size_t n_vec, void *d_dst, void *d_val, void *stream, char *errbuf);
+
 /* plink_score phase 1 (src/plink_score.cpp:575-654) for n_scored variants and
  * n_cols weight columns (the reference has one; BASELINE config 4 uses 16).
  *   vidx[i]      variant index (ascending; src/plink_score.cpp:407-408)

@@ -250,6 +250,16 @@ extern "C" int pgh_unpack_range_dev(const pgh_dataset *ds, const pgh_subset *sub
 	return PGH_OK;
 }
 
+extern "C" int pgh_probe_unpack_shape_dev(const void *d_src, size_t n_vec, void *d_dst, void *d_val, void *stream,
+                                          char *errbuf) {
+	if (n_vec && (!d_src || !d_dst || !d_val)) {
+		SetErr(errbuf, "null argument");
+		return PGH_ERR_ARG;
+	}
+	PGH_HIP(pgh::LaunchUnpackShapeProbe(d_src, n_vec, d_dst, d_val, static_cast<hipStream_t>(stream)), "store probe");
+	return PGH_OK;
+}
+
 extern "C" int pgh_unpack_range(const pgh_dataset *ds, const pgh_subset *subset, uint32_t v_begin, uint32_t v_end,
                                 int8_t *out, uint64_t *validity, int missing_code, char *errbuf) {
 	int rc = CheckRange(ds, v_begin, v_end, errbuf);

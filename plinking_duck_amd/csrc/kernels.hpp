@@ -71,6 +71,9 @@ hipError_t LaunchFusedTally(const RowView &view, uint32_t v_first, uint32_t v_co
 // validity row i (optional): ceil(N/64) uint64 words, bit = non-missing.
 hipError_t LaunchUnpack(const RowView &view, uint32_t v_first, uint32_t v_count, int8_t *out, uint64_t out_pitch,
                         uint64_t *validity, int8_t fill, hipStream_t stream);
+// Measurement aid: the unpack's traffic shape (16 B read -> 64 B + 8 B written per lane) with no arithmetic;
+// src: n_vec x 16 B, dst: n_vec x 64 B, val: n_vec x 8 B.
+hipError_t LaunchUnpackShapeProbe(const void *src, size_t n_vec, void *dst, void *val, hipStream_t stream);
 // Subset form: sel[k] = raw index of the k-th included sample, n_out entries.
 hipError_t LaunchUnpackSubset(const RowView &view, uint32_t v_first, uint32_t v_count, const uint32_t *sel,
                               uint32_t n_out, int8_t *out, uint64_t out_pitch, uint64_t *validity, int8_t fill,

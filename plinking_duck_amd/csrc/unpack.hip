@@ -236,9 +236,36 @@ __global__ __launch_bounds__(256) void k_unpack_transposed(const uint8_t *__rest
 
 } // namespace
 
+// A bare kernel with the unpack's traffic shape and none of its arithmetic: a lane reads 16 bytes and writes
+// 4 x 16 bytes (1 KiB per wave-instruction) + 8 bytes.  What it reaches is the ceiling k_unpack_wide is measured
+// against in the same run (bench.py: roofline.store_ceiling); tools/store_peak.hip holds the other store forms.
+__global__ __launch_bounds__(256) void k_unpack_shape_probe(const u32x4 *__restrict__ src, u32x4 *__restrict__ dst,
+                                                            unsigned long long *__restrict__ val, size_t n_vec) {
+	const size_t stride = static_cast<size_t>(gridDim.x) * 256;
+	for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < n_vec; i += stride) {
+		const u32x4 w = __builtin_nontemporal_load(src + i);
+		const size_t wave0 = (i & ~static_cast<size_t>(63)) * 4, lane = i & 63;
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const u32x4 o = {w.x + k, w.y, w.z, w.w};
+			__builtin_nontemporal_store(o, dst + wave0 + 64 * k + lane);
+		}
+		val[i] = w.x;
+	}
+}
+
 // ---------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------
+
+hipError_t LaunchUnpackShapeProbe(const void *src, size_t n_vec, void *dst, void *val, hipStream_t stream) {
+	if (n_vec == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_unpack_shape_probe, dim3(16384), dim3(256), 0, stream, static_cast<const u32x4 *>(src),
+	                   static_cast<u32x4 *>(dst), static_cast<unsigned long long *>(val), n_vec);
+	return hipGetLastError();
+}
 
 hipError_t LaunchUnpack(const RowView &view, uint32_t v_first, uint32_t v_count, int8_t *out, uint64_t out_pitch,
                         uint64_t *validity, int8_t fill, hipStream_t stream) {

@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "pgh_synth_create", "pgh_synth_record_host", "pgh_synth_write_files", "pgh_copy_rows_to_host", "pgh_get_info", "pgh_device_rows",
     "pgh_close", "pgh_subset_create", "pgh_subset_size", "pgh_subset_destroy", "pgh_counts_range",
     "pgh_counts_range_dev", "pgh_freq_from_counts_dev", "pgh_fused_tally_dev", "pgh_missing_per_sample", "pgh_missing_per_sample_dev", "pgh_unpack_range",
-    "pgh_unpack_range_dev", "pgh_score", "pgh_score_counts", "pgh_score_dev", "pgh_score_plan_create", "pgh_score_run_dev",
+    "pgh_unpack_range_dev", "pgh_probe_unpack_shape_dev", "pgh_score", "pgh_score_counts", "pgh_score_dev", "pgh_score_plan_create", "pgh_score_run_dev",
     "pgh_score_plan_destroy", "pgh_pca", "pgh_pca_sharded", "pgh_ld_pairs", "pgh_ld_pairs_dev", "pgh_ld_pairs_status", "pgh_sample_counts", "pgh_sample_counts_dev",
     "pgh_synth_add_dosage", "pgh_synth_write_dosage_files", "pgh_dosage_sums", "pgh_dosage_sums_dev", "pgh_dosage_unpack", "pgh_dosage_unpack_dev", "pgh_unpack_samples", "pgh_dosage_unpack_samples", "pgh_reader_create", "pgh_reader_destroy",
     "pgh_get_2bit", "pgh_get_counts", "pgh_get_missingness", "pgh_get_int8", "pgh_get_dosage_f64", "pgh_get_phased",
@@ -109,6 +109,7 @@ def _load():
         "pgh_missing_per_sample_dev": (C.c_int, [vp, u32, u32, vp, vp, cp]),
         "pgh_unpack_range": (C.c_int, [vp, vp, u32, u32, vp, vp, C.c_int, cp]),
         "pgh_unpack_range_dev": (C.c_int, [vp, vp, u32, u32, vp, C.c_size_t, vp, C.c_int, vp, cp]),
+        "pgh_probe_unpack_shape_dev": (C.c_int, [vp, C.c_size_t, vp, vp, vp, cp]),
         "pgh_score": (C.c_int, [vp, vp, u32, vp, vp, vp, u32, C.c_int, vp, vp, vp, cp]),
         "pgh_score_dev": (C.c_int, [vp, vp, u32, vp, vp, vp, u32, C.c_int, vp, vp, vp, vp, cp]),
         "pgh_score_counts": (C.c_int, [vp, vp, u32, vp, vp, vp, u32, C.c_int, vp, vp, vp, vp, cp]),
@@ -251,6 +252,11 @@ def freq_from_counts_dev(d_counts: int, n: int, d_alt_freq: int, d_obs_ct: int, 
 def hwe_lnp_batch_dev(d_counts: int, n: int, d_ln_p: int, midp: bool = False, stream: int = 0):
     eb = _errbuf()
     _check(_lib.pgh_hwe_lnp_batch_dev(d_counts, n, 1 if midp else 0, d_ln_p, stream, eb), eb)
+
+
+def probe_unpack_shape_dev(d_src: int, n_vec: int, d_dst: int, d_val: int, stream: int = 0):
+    eb = _errbuf()
+    _check(_lib.pgh_probe_unpack_shape_dev(d_src, n_vec, d_dst, d_val, stream, eb), eb)
 
 
 def synth_record_host(v: int, n: int, seed: int, missing_rate: float) -> np.ndarray:

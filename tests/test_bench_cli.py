@@ -54,3 +54,21 @@ def test_default_line_is_strong_scaling_and_verified():
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["scaling"] == "strong" and line["verified"] is True
     assert line["roofline"]["bound"] == "hbm" and line["roofline"]["frac"] > 0
+
+
+@pytest.mark.gpu
+def test_all_configs_ride_the_default_line():
+    """--configs all on a small matrix: BASELINE configs 2-5 next to the freq headline, each verified, and the
+    table-function section."""
+    r = run_bench(["--variants", "30000", "--samples", "20000", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0",
+                   "--configs", "all", "--config-steps", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["metric"] == "plink_freq genotypes/s" and line["verified"] is True
+    cfg = line["configs"]
+    assert set(cfg) == {"fused", "unpack", "score16", "score1", "pca"}
+    assert all(c["verified"] is True and c["frac"] > 0 and c["kernel_ms_avg"] > 0 for c in cfg.values())
+    assert cfg["unpack"]["roofline"]["store_ceiling"]["GB/s"] > 0
+    assert "algorithmic_flops_frac_of_fp64_peak" in cfg["score16"]["roofline"]
+    sql = line["sql"]
+    assert len(sql) == 4 and all(v["rows"] in (30000, 20000) and v["scan_ms"] > 0 for v in sql.values())
