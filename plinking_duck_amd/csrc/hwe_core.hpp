@@ -104,7 +104,9 @@ PGH_HD inline double HweLnP(int32_t obs_hets, int32_t obs_hom1, int32_t obs_hom2
 	}
 	const double hi = p_obs * (1.0 + kHweTieEps);
 	const double lo = p_obs * (1.0 - kHweTieEps);
-	const double negligible = lo * 1e-30;
+	// a term 2^-64 of the sum it joins cannot change that sum's double: the walks stop there (they ran to 1e-30
+	// of the mode before: a third more steps for nothing a double can hold)
+	const double negligible = lo * 0x1p-64;
 	double total = 1.0;
 	double tail = 0.0;
 	double ties = 0.0;
@@ -125,7 +127,7 @@ PGH_HD inline double HweLnP(int32_t obs_hets, int32_t obs_hom1, int32_t obs_hom2
 				if (p >= lo) {
 					ties += p;
 				}
-				if (p < negligible && p < total * 1e-30) {
+				if (p < negligible && p < total * 0x1p-64) {
 					break;
 				}
 			}
@@ -144,7 +146,7 @@ PGH_HD inline double HweLnP(int32_t obs_hets, int32_t obs_hom1, int32_t obs_hom2
 				if (p >= lo) {
 					ties += p;
 				}
-				if (p < negligible && p < total * 1e-30) {
+				if (p < negligible && p < total * 0x1p-64) {
 					break;
 				}
 			}

@@ -213,10 +213,11 @@ __global__ __launch_bounds__(256) void k_counts_wave(const uint8_t *__restrict__
 // 2 -> 4 -> 8 -> 32 bits into 64 registers per lane; it streamed at the same 6.25 TB/s -- the column walk,
 // not the arithmetic, sets that -- with 3x the registers.)
 
+// carry-save adder: two v_bitop3_b32 (majority 0xe8, parity 0x96; the C form a ^ b, (a & b) | (u & c), u ^ c
+// compiled to three or four instructions)
 __device__ __forceinline__ void Csa(uint32_t &h, uint32_t &l, uint32_t a, uint32_t b, uint32_t c) {
-	const uint32_t u = a ^ b;
-	h = (a & b) | (u & c);
-	l = u ^ c;
+	h = __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8);
+	l = __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
 }
 
 // bit-sliced counter of one 32-bit word of indicator bits, fed four rows at a time
@@ -536,223 +537,167 @@ __global__ __launch_bounds__(256) void k_sum_class_bits(const uint32_t *__restri
 // fused pass: per-variant class tallies AND per-sample missing tallies
 // ---------------------------------------------------------------------------
 //
-// plink_freq + plink_hardy + plink_missing (both modes) need the row sums and the
-// column sums of the same matrix; this kernel reads every byte once for both.
-// Ownership is by column (as k_missing_cols): a lane keeps its 64 samples' missing
-// counters in registers.  The row sums cross lanes: each lane's per-row popcounts
-// go through an LDS tile [12 rows][256 lanes] (packed 10-bit fields), a 16-lane
-// shuffle tree finishes the row, and 36 lanes add the workgroup's partials to the
-// per-variant totals with one coalesced atomic instruction per 12 rows.
-constexpr uint32_t kFusedRows = 12;
-
-// column counters of the fused kernel: as MissAcc but the last level is 16-bit
-// (<= 65535 rows per slice), which keeps the kernel under 168 VGPRs
-struct MissAcc16 {
-	uint32_t a4[8];
-	uint32_t a8[16];
-	uint32_t a16[32];
-};
-
-__device__ __forceinline__ void Fold8To16(MissAcc16 &acc) {
-	// a16[2i + e] half h <- byte 2h + e of a8[i]
-#pragma unroll
-	for (int i = 0; i < 16; i++) {
-		acc.a16[2 * i] += acc.a8[i] & 0x00ff00ffu;
-		acc.a16[2 * i + 1] += (acc.a8[i] >> 8) & 0x00ff00ffu;
-		acc.a8[i] = 0;
-	}
-}
+// plink_freq + plink_hardy + plink_missing (both modes) need the row sums and the column sums of the same
+// matrix; this kernel reads every byte once for both.  Ownership is by column: a lane owns 16 bytes (64 samples)
+// of every row of its slice.
+//   * Column sums (missing calls per sample): k_class_cols1's positional population count -- the row's four
+//     missing-indicator words pack into two words of one bit per sample, and those feed two 16-plane bit-sliced
+//     counters through a Harley-Seal carry-save tree, sixteen rows per trip (a carry-save adder is two
+//     v_bitop3_b32); the slice's planes go to its slab and k_sum_cols1 adds the slices.
+//   * Row sums (class tallies per variant) cross lanes: each lane's per-row popcounts (lo | hi << 10 |
+//     both << 20) go through an LDS tile [16 rows][256 lanes], sixteen lanes per row add 8 + 8 packed entries
+//     (10-bit fields cannot overflow) and finish with a 16-lane shuffle tree, and the sixteenth-0 lanes add the
+//     workgroup's partials to a [column block][variant] array that k_finish_tallies sums.
+// Round 2's form kept SWAR fields for the columns (2 -> 4 -> 8 -> 16 bits, ~23 vector ops per row and lane) and
+// drained the memory counter before counting: 83 vector ops per 16 bytes, 73 % of the kernel's cycles in vector
+// issue, 0.63-0.69 of the HBM roofline.  This one spends ~7 on the columns (~50 in all), keeps eight rows' loads
+// in flight under the arithmetic of the previous eight, and pays one barrier per sixteen rows.
+constexpr uint32_t kFusedRows = 16;
 
 __global__ __launch_bounds__(256) void k_fused_tally(const uint8_t *__restrict__ rows, uint64_t pitch,
                                                      uint32_t chunks, uint32_t v_first, uint32_t v_count,
-                                                     uint32_t slice_len, uint32_t *__restrict__ tallies,
-                                                     uint32_t *__restrict__ slabs, uint32_t slab_stride) {
-	__shared__ uint32_t s_p[kFusedRows][256];
-	__shared__ uint32_t s_res[kFusedRows][3];
+                                                     uint32_t slice_len, uint4 *__restrict__ partials,
+                                                     uint32_t *__restrict__ slabs, uint64_t slab_stride) {
+	__shared__ uint32_t s_p[2][kFusedRows][256];
 	const uint32_t col = blockIdx.x * 256u + threadIdx.x;
 	const bool live = col < chunks;
 	const uint32_t i_begin = blockIdx.y * slice_len;
 	const uint32_t i_end = min(i_begin + slice_len, v_count);
-	MissAcc16 acc;
-#pragma unroll
-	for (int j = 0; j < 8; j++) {
-		acc.a4[j] = 0;
-	}
-#pragma unroll
-	for (int j = 0; j < 16; j++) {
-		acc.a8[j] = 0;
-	}
-#pragma unroll
-	for (int j = 0; j < 32; j++) {
-		acc.a16[j] = 0;
-	}
-	uint32_t n4 = 0, n8 = 0;
-	auto fold = [&](const uint32_t a2[4], uint32_t take) {
-#pragma unroll
-		for (int j = 0; j < 4; j++) {
-			acc.a4[2 * j] += a2[j] & 0x33333333u;
-			acc.a4[2 * j + 1] += (a2[j] >> 2) & 0x33333333u;
-		}
-		n4 += take;
-		if (n4 + 3 > 15) {
-#pragma unroll
-			for (int j = 0; j < 4; j++) {
-				acc.a8[4 * j + 0] += acc.a4[2 * j] & 0x0f0f0f0fu;
-				acc.a8[4 * j + 1] += (acc.a4[2 * j] >> 4) & 0x0f0f0f0fu;
-				acc.a8[4 * j + 2] += acc.a4[2 * j + 1] & 0x0f0f0f0fu;
-				acc.a8[4 * j + 3] += (acc.a4[2 * j + 1] >> 4) & 0x0f0f0f0fu;
-				acc.a4[2 * j] = 0;
-				acc.a4[2 * j + 1] = 0;
-			}
-			n8 += n4;
-			n4 = 0;
-			if (n8 + 15 > 255) {
-				Fold8To16(acc);
-				n8 = 0;
-			}
-		}
-	};
-	// one row: class popcounts packed as lo | hi << 10 | both << 20, missing bits into a2
-	auto one_row = [&](const uint4 &w, uint32_t a2[4]) -> uint32_t {
-		const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
-		// popc(low bits) + popc(high bits) = popc(word): the high-bit count comes from one subtraction per row
-		// instead of a shift-and-mask per word (this kernel is vector-issue bound next to its HBM stream)
-		uint32_t lo_ct = 0, all_ct = 0, both_ct = 0;
-#pragma unroll
-		for (int j = 0; j < 4; j++) {
-			const uint32_t lo = ws[j] & kLow;
-			const uint32_t both = lo & (ws[j] >> 1);
-			lo_ct += __popc(lo);
-			all_ct += __popc(ws[j]);
-			both_ct += __popc(both);
-			a2[j] += both;
-		}
-		return lo_ct | ((all_ct - lo_ct) << 10) | (both_ct << 20);
-	};
-	const uint4 zero4 = make_uint4(0, 0, 0, 0);
+	// Lanes past the row's last 16-byte column (the last column block only) re-read that column -- no branch around
+	// the loads, which would also keep the compiler from running them ahead of the arithmetic -- and their row
+	// popcounts are masked off; their column counters are never written.
+	const uint32_t col_c = live ? col : chunks - 1u;
+	const uint32_t live_mask = live ? 0xffffffffu : 0u;
+	BitCounter<kCols1Planes> ctr[2];
+	ctr[0].Clear();
+	ctr[1].Clear();
+	// rows past the slice's end read row i_end - 1 again and count nothing (their words are zeroed)
 	auto load_row = [&](uint32_t idx) {
-		return live ? LoadStream(reinterpret_cast<const uint4 *>(rows + static_cast<uint64_t>(v_first + idx) * pitch) +
-		                         col)
-		            : zero4;
+		const uint32_t r = idx < i_end ? idx : i_end - 1u;
+		const uint4 w = LoadStream(reinterpret_cast<const uint4 *>(rows + static_cast<uint64_t>(v_first + r) * pitch) + col_c);
+		const uint32_t keep = idx < i_end ? 0xffffffffu : 0u;
+		return make_uint4(w.x & keep, w.y & keep, w.z & keep, w.w & keep);
 	};
-	for (uint32_t i = i_begin; i < i_end; i += kFusedRows) {
-		const uint32_t nb = min(kFusedRows, i_end - i);
-		if (nb == kFusedRows) {
+	// the rows of a full slice interior need no clamp: chosen per tile (uniform)
+	auto load_row_in = [&](uint32_t idx) {
+		return LoadStream(reinterpret_cast<const uint4 *>(rows + static_cast<uint64_t>(v_first + idx) * pitch) + col_c);
+	};
+	// one row: packed class popcounts to the LDS tile; its two one-bit-per-sample missing words come back
+	auto one_row = [&](uint32_t *slot, const uint4 &w, uint32_t &m01, uint32_t &m23) {
+		const uint32_t b0 = w.x & (w.x >> 1) & kLow, b1 = w.y & (w.y >> 1) & kLow;
+		const uint32_t b2 = w.z & (w.z >> 1) & kLow, b3 = w.w & (w.w >> 1) & kLow;
+		m01 = b0 | (b1 << 1);
+		m23 = b2 | (b3 << 1);
+		const uint32_t both_ct = __popc(m01) + __popc(m23);
+		const uint32_t all_ct = __popc(w.x) + __popc(w.y) + __popc(w.z) + __popc(w.w);
+		// the low-bit planes of two words share a word: (x & m) | ((y << 1) & ~m)
+		const uint32_t l01 = (w.x & kLow) | ((w.y << 1) & ~kLow);
+		const uint32_t l23 = (w.z & kLow) | ((w.w << 1) & ~kLow);
+		const uint32_t lo_ct = __popc(l01) + __popc(l23);
+		*slot = (lo_ct | ((all_ct - lo_ct) << 10) | (both_ct << 20)) & live_mask;
+	};
+	// rows 4g .. 4g + 3 of a tile
+#define PGH_FUSED_GROUP(G, TILE, R0, R1, R2, R3)                                                                       \
+	{                                                                                                                  \
+		uint32_t x0, x1, x2, x3, y0, y1, y2, y3;                                                                       \
+		one_row(&TILE[4 * G + 0][threadIdx.x], R0, x0, y0);                                                            \
+		one_row(&TILE[4 * G + 1][threadIdx.x], R1, x1, y1);                                                            \
+		one_row(&TILE[4 * G + 2][threadIdx.x], R2, x2, y2);                                                            \
+		one_row(&TILE[4 * G + 3][threadIdx.x], R3, x3, y3);                                                            \
+		ctr[0].Add4<G>(x0, x1, x2, x3);                                                                                \
+		ctr[1].Add4<G>(y0, y1, y2, y3);                                                                                \
+	}
+	// row sums of a finished tile: lane t -> (row t >> 4, sixteenth t & 15) sums 16 packed lanes (8 + 8), a
+	// 16-lane shuffle tree over two words (lo | both << 16, hi), one atomic per sum
+	auto reduce_tile = [&](uint32_t (*tile)[256], uint32_t i) {
+		const uint32_t row = threadIdx.x >> 4, part = threadIdx.x & 15u;
+		const uint4 *src = reinterpret_cast<const uint4 *>(&tile[row][part * 16u]);
+		const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+		const uint32_t p0 = q0.x + q0.y + q0.z + q0.w + q1.x + q1.y + q1.z + q1.w;
+		const uint32_t p1 = q2.x + q2.y + q2.z + q2.w + q3.x + q3.y + q3.z + q3.w;
+		uint32_t lb = (p0 & 0x3ffu) + (p1 & 0x3ffu) + (((p0 >> 20) + (p1 >> 20)) << 16);
+		uint32_t hi = ((p0 >> 10) & 0x3ffu) + ((p1 >> 10) & 0x3ffu);
 #pragma unroll
-			for (uint32_t h = 0; h < kFusedRows; h += 6) {
-				const uint4 w0 = load_row(i + h), w1 = load_row(i + h + 1), w2 = load_row(i + h + 2);
-				const uint4 w3 = load_row(i + h + 3), w4 = load_row(i + h + 4), w5 = load_row(i + h + 5);
-				uint32_t a[4] = {0, 0, 0, 0};
-				s_p[h + 0][threadIdx.x] = one_row(w0, a);
-				s_p[h + 1][threadIdx.x] = one_row(w1, a);
-				s_p[h + 2][threadIdx.x] = one_row(w2, a);
-				fold(a, 3);
-				uint32_t b[4] = {0, 0, 0, 0};
-				s_p[h + 3][threadIdx.x] = one_row(w3, b);
-				s_p[h + 4][threadIdx.x] = one_row(w4, b);
-				s_p[h + 5][threadIdx.x] = one_row(w5, b);
-				fold(b, 3);
-			}
-		} else {
-			for (uint32_t r = 0; r < nb; r++) {
-				const uint4 w = load_row(i + r);
-				uint32_t a[4] = {0, 0, 0, 0};
-				s_p[r][threadIdx.x] = one_row(w, a);
-				fold(a, 1);
-			}
+		for (int off = 8; off > 0; off >>= 1) {
+			lb += __shfl_xor(lb, off, 64);
+			hi += __shfl_xor(hi, off, 64);
 		}
-		__syncthreads();
-		// row sums: lane t -> (row t >> 4, sixteenth t & 15) sums 16 packed lanes (8 + 8 so the
-		// 10-bit fields cannot overflow), then a 16-lane shuffle tree
-		{
-			const uint32_t row = threadIdx.x >> 4, part = threadIdx.x & 15u;
-			uint32_t lo = 0, hi = 0, both = 0;
-			if (row < nb) {
-				const uint4 *src = reinterpret_cast<const uint4 *>(&s_p[row][part * 16u]);
-				const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
-				const uint32_t p0 = q0.x + q0.y + q0.z + q0.w + q1.x + q1.y + q1.z + q1.w;
-				const uint32_t p1 = q2.x + q2.y + q2.z + q2.w + q3.x + q3.y + q3.z + q3.w;
-				lo = (p0 & 0x3ffu) + (p1 & 0x3ffu);
-				hi = ((p0 >> 10) & 0x3ffu) + ((p1 >> 10) & 0x3ffu);
-				both = (p0 >> 20) + (p1 >> 20);
-			}
-#pragma unroll
-			for (int off = 8; off > 0; off >>= 1) {
-				lo += __shfl_xor(lo, off, 64);
-				hi += __shfl_xor(hi, off, 64);
-				both += __shfl_xor(both, off, 64);
-			}
-			if (part == 0 && row < nb) {
-				s_res[row][0] = lo;
-				s_res[row][1] = hi;
-				s_res[row][2] = both;
-			}
+		if (part == 0 && i + row < i_end) {
+			// this column block's share of the row, with a plain store: sixteen consecutive 16-byte entries per
+			// tile.  (Device-scope atomics on the per-variant totals -- 93 million per pass at 500 k samples,
+			// from 31 column blocks on eight XCDs -- were what held this kernel at 24 ms whatever its arithmetic
+			// cost; k_finish_tallies adds the column blocks instead.)
+			partials[static_cast<uint64_t>(blockIdx.x) * v_count + i + row] = make_uint4(0u, lb & 0xffffu, hi, lb >> 16);
 		}
-		__syncthreads();
-		if (threadIdx.x < nb * 3u) {
-			const uint32_t r = threadIdx.x / 3u, f = threadIdx.x % 3u;
-			atomicAdd(tallies + 4ull * (i + r) + 1u + f, s_res[r][f]);
+	};
+	// Sixteen rows per trip in four groups over two register sets: while a group is counted the loads of the
+	// group after next are in flight.  The LDS tile is double-buffered, so a tile costs ONE barrier: no wave can
+	// reach tile k + 2's writes before every wave has passed tile k + 1's barrier, i.e. finished reading tile k.
+	uint32_t buf = 0;
+	if (i_begin < i_end) {
+		uint4 a0 = load_row(i_begin), a1 = load_row(i_begin + 1), a2 = load_row(i_begin + 2), a3 = load_row(i_begin + 3);
+		uint4 b0 = load_row(i_begin + 4), b1 = load_row(i_begin + 5), b2 = load_row(i_begin + 6), b3 = load_row(i_begin + 7);
+		for (uint32_t i = i_begin; i < i_end; i += kFusedRows) {
+			uint32_t (*tile)[256] = s_p[buf];
+			if (i + 2 * kFusedRows <= i_end) {
+				// every row this trip touches lies inside the slice: no clamps
+				PGH_FUSED_GROUP(0, tile, a0, a1, a2, a3)
+				a0 = load_row_in(i + 8), a1 = load_row_in(i + 9), a2 = load_row_in(i + 10), a3 = load_row_in(i + 11);
+				PGH_FUSED_GROUP(1, tile, b0, b1, b2, b3)
+				b0 = load_row_in(i + 12), b1 = load_row_in(i + 13), b2 = load_row_in(i + 14), b3 = load_row_in(i + 15);
+				PGH_FUSED_GROUP(2, tile, a0, a1, a2, a3)
+				a0 = load_row_in(i + 16), a1 = load_row_in(i + 17), a2 = load_row_in(i + 18), a3 = load_row_in(i + 19);
+				PGH_FUSED_GROUP(3, tile, b0, b1, b2, b3)
+				b0 = load_row_in(i + 20), b1 = load_row_in(i + 21), b2 = load_row_in(i + 22), b3 = load_row_in(i + 23);
+			} else {
+				PGH_FUSED_GROUP(0, tile, a0, a1, a2, a3)
+				a0 = load_row(i + 8), a1 = load_row(i + 9), a2 = load_row(i + 10), a3 = load_row(i + 11);
+				PGH_FUSED_GROUP(1, tile, b0, b1, b2, b3)
+				b0 = load_row(i + 12), b1 = load_row(i + 13), b2 = load_row(i + 14), b3 = load_row(i + 15);
+				PGH_FUSED_GROUP(2, tile, a0, a1, a2, a3)
+				a0 = load_row(i + 16), a1 = load_row(i + 17), a2 = load_row(i + 18), a3 = load_row(i + 19);
+				PGH_FUSED_GROUP(3, tile, b0, b1, b2, b3)
+				b0 = load_row(i + 20), b1 = load_row(i + 21), b2 = load_row(i + 22), b3 = load_row(i + 23);
+			}
+			__syncthreads();
+			reduce_tile(tile, i);
+			buf ^= 1u;
 		}
 	}
+#undef PGH_FUSED_GROUP
 	if (live) {
-		// drain the narrow levels, then unscramble: a16[2(4j+q)+e] half h counts sample
-		// 16j + 8h + 4e + {0,2,1,3}[q]
+		// planes of word k: slabs[slice][k][plane][col] (k_class_cols1's layout: k_sum_cols1 adds the slices)
+		uint32_t *dst = slabs + static_cast<uint64_t>(blockIdx.y) * slab_stride + col;
 #pragma unroll
-		for (int j = 0; j < 4; j++) {
-			acc.a8[4 * j + 0] += acc.a4[2 * j] & 0x0f0f0f0fu;
-			acc.a8[4 * j + 1] += (acc.a4[2 * j] >> 4) & 0x0f0f0f0fu;
-			acc.a8[4 * j + 2] += acc.a4[2 * j + 1] & 0x0f0f0f0fu;
-			acc.a8[4 * j + 3] += (acc.a4[2 * j + 1] >> 4) & 0x0f0f0f0fu;
-		}
-		Fold8To16(acc);
-		uint32_t *dst = slabs + static_cast<uint64_t>(blockIdx.y) * slab_stride + col * 64u;
+		for (uint32_t k = 0; k < 2; k++) {
 #pragma unroll
-		for (int j = 0; j < 4; j++) {
-#pragma unroll
-			for (int h = 0; h < 2; h++) {
-#pragma unroll
-				for (int e = 0; e < 2; e++) {
-					// samples 16j + 8h + 4e + {0,1,2,3}  <-  q = {0,2,1,3}
-					uint4 o;
-					o.x = (acc.a16[2 * (4 * j + 0) + e] >> (16 * h)) & 0xffffu;
-					o.y = (acc.a16[2 * (4 * j + 2) + e] >> (16 * h)) & 0xffffu;
-					o.z = (acc.a16[2 * (4 * j + 1) + e] >> (16 * h)) & 0xffffu;
-					o.w = (acc.a16[2 * (4 * j + 3) + e] >> (16 * h)) & 0xffffu;
-					reinterpret_cast<uint4 *>(dst)[4 * j + 2 * h + e] = o;
-				}
+			for (int pl = 0; pl < kCols1Planes; pl++) {
+				dst[(static_cast<uint64_t>(k) * kCols1Planes + pl) * chunks] = ctr[k].p[pl];
 			}
 		}
 	}
 }
 
-// (., lo, hi, both) -> (hom_ref, het, hom_alt, missing)
-__global__ __launch_bounds__(256) void k_finish_tallies(uint4 *__restrict__ tallies, uint32_t n, uint32_t n_eff) {
+// the column blocks' (., lo, hi, both) of a variant -> (hom_ref, het, hom_alt, missing)
+__global__ __launch_bounds__(256) void k_finish_tallies(const uint4 *__restrict__ partials, uint32_t col_blocks,
+                                                        uint4 *__restrict__ tallies, uint32_t n, uint32_t n_eff) {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= n) {
 		return;
 	}
-	const uint4 t = tallies[i];
+	uint32_t lo = 0, hi = 0, both = 0;
+	for (uint32_t cb = 0; cb < col_blocks; cb++) {
+		const uint4 t = partials[static_cast<uint64_t>(cb) * n + i];
+		lo += t.y;
+		hi += t.z;
+		both += t.w;
+	}
 	uint4 r;
-	r.y = t.y - t.w;
-	r.z = t.z - t.w;
-	r.w = t.w;
+	r.y = lo - both;
+	r.z = hi - both;
+	r.w = both;
 	r.x = n_eff - r.y - r.z - r.w;
 	tallies[i] = r;
-}
-
-// out[s] = sum over slices of slabs[slice][s]
-__global__ __launch_bounds__(256) void k_sum_slabs(const uint32_t *__restrict__ slabs, uint32_t slab_stride,
-                                                   uint32_t n_slabs, uint32_t n, uint32_t *__restrict__ out,
-                                                   uint32_t accumulate) {
-	const uint32_t s = blockIdx.x * 256u + threadIdx.x;
-	if (s >= n) {
-		return;
-	}
-	uint32_t acc = accumulate ? out[s] : 0u;
-	for (uint32_t k = 0; k < n_slabs; k++) {
-		acc += slabs[static_cast<uint64_t>(k) * slab_stride + s];
-	}
-	out[s] = acc;
 }
 
 // ---------------------------------------------------------------------------
@@ -922,18 +867,23 @@ hipError_t LaunchFreqFromCounts(const uint32_t *counts, uint32_t n, double *alt_
 void MissingPerSamplePlan(uint32_t record_bytes, uint32_t v_count, uint32_t *slice_len_out, uint32_t *slices_out) {
 	const uint32_t chunks = (record_bytes + 15) / 16;
 	const uint32_t col_blocks = (chunks + 255) / 256;
-	// enough row slices for >= ~2048 workgroups (256 CUs x 4 resident x 2), each a multiple of 6 rows
-	uint32_t want_slices = (2048 + col_blocks - 1) / col_blocks;
+	// row slices for ~kWant workgroups (768 fit the chip at three per CU: several rounds of them, so that the last,
+	// partly filled round is a small share of the launch), each a multiple of 16 rows
+	static const uint32_t want_wgs = [] {
+		const char *e = std::getenv("PGH_FUSED_WGS"); // tuning knob
+		return e && std::atoi(e) > 0 ? static_cast<uint32_t>(std::atoi(e)) : 2048u;
+	}();
+	uint32_t want_slices = (want_wgs + col_blocks - 1) / col_blocks;
 	if (want_slices > 1024) {
 		want_slices = 1024;
 	}
 	uint32_t slice_len = (v_count + want_slices - 1) / want_slices;
-	slice_len = ((slice_len + 5) / 6) * 6;
+	slice_len = ((slice_len + 15) / 16) * 16;
 	if (slice_len < 96) {
 		slice_len = 96;
 	}
 	if (slice_len > 65280u) {
-		slice_len = 65280u; // the fused kernel keeps 16-bit column counters; 65280 = 12 * 5440
+		slice_len = 65280u; // 16 planes of column counters
 	}
 	*slice_len_out = slice_len;
 	*slices_out = v_count ? (v_count + slice_len - 1) / slice_len : 0;
@@ -964,7 +914,9 @@ size_t MissingPerSampleScratchBytes(uint32_t record_bytes, uint32_t v_count) {
 	uint32_t slice_len, slices;
 	MissingPerSamplePlan(record_bytes, v_count, &slice_len, &slices);
 	const uint64_t chunks = (record_bytes + 15) / 16;
-	const uint64_t fused = static_cast<uint64_t>(slices) * chunks * 64 * sizeof(uint32_t);
+	// the fused kernel: plane slabs as below (its slices are never more) + 16 bytes per column block and variant
+	const uint64_t fused = static_cast<uint64_t>(slices) * chunks * 2 * kCols1Planes * sizeof(uint32_t) + 16 +
+	                       ((chunks + 255) / 256) * static_cast<uint64_t>(v_count) * 16;
 	ClassCols1Plan(record_bytes, v_count, &slice_len, &slices);
 	const uint64_t planes = static_cast<uint64_t>(slices) * chunks * 2 * kCols1Planes * sizeof(uint32_t);
 	return static_cast<size_t>(std::max(fused, planes));
@@ -1048,9 +1000,12 @@ hipError_t LaunchClassCounts3(const RowView &view, uint32_t v_first, const uint3
 
 hipError_t LaunchFusedTally(const RowView &view, uint32_t v_first, uint32_t v_count, uint32_t *scratch,
                             uint32_t *counts, uint32_t *missing_per_sample, hipStream_t stream, bool accumulate) {
-	if (v_count == 0) {
-		return accumulate ? hipSuccess
-		                  : hipMemsetAsync(missing_per_sample, 0, sizeof(uint32_t) * view.sample_ct, stream);
+	hipError_t e = hipSuccess;
+	if (!accumulate) {
+		e = hipMemsetAsync(missing_per_sample, 0, sizeof(uint32_t) * view.sample_ct, stream);
+	}
+	if (v_count == 0 || e != hipSuccess) {
+		return e;
 	}
 	const uint32_t chunks = static_cast<uint32_t>((static_cast<uint64_t>(view.record_bytes) + 15) / 16);
 	const uint32_t col_blocks = (chunks + 255) / 256;
@@ -1058,17 +1013,16 @@ hipError_t LaunchFusedTally(const RowView &view, uint32_t v_first, uint32_t v_co
 	MissingPerSamplePlan(view.record_bytes, v_count, &slice_len, &slices);
 	slice_len = (slice_len + kFusedRows - 1) / kFusedRows * kFusedRows; // <= 65280, so never more slices
 	slices = (v_count + slice_len - 1) / slice_len;
-	const uint32_t stride = chunks * 64u;
-	hipError_t e = hipMemsetAsync(counts, 0, 16ull * v_count, stream);
-	if (e != hipSuccess) {
-		return e;
-	}
+	const uint64_t stride = static_cast<uint64_t>(chunks) * 2 * kCols1Planes; // dwords per slice (k_class_cols1's slabs)
+	// scratch: the slices' planes, then the column blocks' row sums ([col_blocks][v_count] x 16 B)
+	uint4 *partials = reinterpret_cast<uint4 *>(scratch + (static_cast<uint64_t>(slices) * stride + 3) / 4 * 4);
 	hipLaunchKernelGGL(k_fused_tally, dim3(col_blocks, slices), dim3(256), 0, stream, view.rows, view.pitch, chunks,
-	                   v_first, v_count, slice_len, counts, scratch, stride);
-	hipLaunchKernelGGL(k_finish_tallies, dim3((v_count + 255) / 256), dim3(256), 0, stream,
+	                   v_first, v_count, slice_len, partials, scratch, stride);
+	hipLaunchKernelGGL(k_finish_tallies, dim3((v_count + 255) / 256), dim3(256), 0, stream, partials, col_blocks,
 	                   reinterpret_cast<uint4 *>(counts), v_count, view.sample_ct);
-	hipLaunchKernelGGL(k_sum_slabs, dim3((view.sample_ct + 255) / 256), dim3(256), 0, stream, scratch, stride, slices,
-	                   view.sample_ct, missing_per_sample, accumulate ? 1u : 0u);
+	// the slices' planes -> per-sample counts, added onto missing_per_sample
+	hipLaunchKernelGGL(k_sum_cols1, dim3((chunks + 255) / 256, (slices + kCols1SumGroup - 1) / kCols1SumGroup), dim3(256), 0,
+	                   stream, scratch, stride, chunks, slices, view.sample_ct, missing_per_sample);
 	return hipGetLastError();
 }
 

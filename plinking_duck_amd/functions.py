@@ -32,7 +32,9 @@ class BinderException(ValueError):
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: run plinking_duck_amd/csrc/build.sh")
-    # libpgenhip.so is found through the shell library's $ORIGIN rpath
+    # libpgenhip.so is found through the shell library's $ORIGIN rpath; lib.py loads it first, after torch where
+    # torch is installed (two HIP runtimes in one process leave the second without a device, see lib._load)
+    from . import lib as _pgenhip  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     lib.pdk_query.restype = C.c_void_p
     lib.pdk_query.argtypes = [C.c_char_p]

@@ -83,8 +83,9 @@ def test_pass_on_synthetic_matrices_with_subsets_and_ranges(gpu_lib, oracle, m, 
         L.TallyPass(ds, 0, m + 1)
 
 
-def test_pass_over_a_shard_group(gpu_lib):
+def test_pass_over_a_shard_group(gpu_lib, monkeypatch):
     L = gpu_lib
+    monkeypatch.setenv("PGH_TALLY_BATCH", "4096")
     m, n = 9000, 1501
     one = L.Dataset.synth(0, m, n, SEED, 0.03)
     cuts = [0, 2000, 2001, 7000, m]
@@ -99,11 +100,12 @@ def test_pass_over_a_shard_group(gpu_lib):
     assert np.array_equal(t.sample_missing(), one.missing_per_sample(subset=one.subset(mask)))
 
 
-def test_many_threads_read_one_pass(gpu_lib):
+def test_many_threads_read_one_pass(gpu_lib, monkeypatch):
     """Scan threads wait for different batches of one pass while it is still running."""
     import threading
     L = gpu_lib
-    m, n = 300_000, 4001  # several pass batches of 4096-variant granularity at this width
+    monkeypatch.setenv("PGH_TALLY_BATCH", "20480")  # 15 batches here (a batch is ~16 GB of rows otherwise)
+    m, n = 300_000, 4001
     ds = L.Dataset.synth(0, m, n, SEED, 0.02)
     expect = ds.counts_range()
     t = L.TallyPass(ds, products=L.TALLY_SAMPLE_MISSING | L.TALLY_HWE)
