@@ -140,9 +140,11 @@ void pgh_close(pgh_dataset *ds);
  * the same shape with devices in the place of threads: contiguous, ascending variant ranges of one file, one
  * resident dataset per device, behind ONE pgh_dataset handle.  Every host-buffer entry point of this header
  * accepts a group handle: per-variant outputs (pgh_counts_range, pgh_unpack_range, pgh_dosage_*, the pgh_get_*
- * reader calls) are filled shard by shard with no exchange; per-sample outputs (pgh_missing_per_sample,
- * pgh_sample_counts, pgh_score, pgh_pca) are reduced per shard on its device and the partials are summed on the
- * first shard's device after device-to-device copies (xGMI between the GPUs of a node); pgh_ld_pairs computes the
+ * reader calls) are filled shard by shard with no exchange; per-sample outputs are reduced per shard on its device
+ * and merged across devices -- pgh_score's partials by an RCCL reduce onto the first shard, pgh_pca's by an RCCL
+ * all-reduce per pass, each on the shards' own streams over xGMI (one communicator per shard, made at the first
+ * collective; shards that share a device fall back to device-to-device copies and a sum on the first shard's
+ * device), pgh_missing_per_sample / pgh_sample_counts (4 bytes per sample) on the host; pgh_ld_pairs computes the
  * pairs that straddle a shard boundary on a scratch dataset built from the rows they name.  Subsets and readers
  * created on a group handle are groups themselves.  The *_dev / plan entry points and pgh_device_rows take one
  * device's dataset: hand them pgh_shard(group, k).
@@ -154,6 +156,10 @@ void pgh_close(pgh_dataset *ds);
 int pgh_open_sharded(const char *pgen_path, const char *pgi_path, uint32_t variant_begin, uint32_t variant_end,
                      const int *devices, uint32_t n_devices, pgh_dataset **out, char *errbuf);
 int pgh_group_create(pgh_dataset *const *shards, uint32_t n_shards, pgh_dataset **out, char *errbuf);
+/* 1 when the group's per-sample merges run as RCCL collectives (one communicator per shard, made by this call if
+ * the group had none yet: shards on distinct devices and librccl loadable), 0 when they use device-to-device copies
+ * (shards sharing a device, PGH_GROUP_RCCL=0) or ds is not a group. */
+int pgh_group_uses_rccl(const pgh_dataset *ds);
 /* 0 for a plain dataset. */
 uint32_t pgh_shard_count(const pgh_dataset *ds);
 const pgh_dataset *pgh_shard(const pgh_dataset *ds, uint32_t k);

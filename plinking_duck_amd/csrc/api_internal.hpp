@@ -74,6 +74,9 @@ struct pgh_dataset {
 	// resident dataset per entry, each on its own device (api_sharded.cpp).  The group handle itself holds no
 	// rows (device == -1); [v_begin, v_end) is the union of its shards' ranges.
 	std::vector<pgh_dataset *> shards;
+	// the group's RCCL communicators, one per shard (api_sharded.cpp: created at the first collective when the
+	// shards sit on distinct devices; an opaque pointer so that rccl.h stays out of this header)
+	mutable void *group_comms = nullptr;
 	bool IsGroup() const {
 		return !shards.empty();
 	}

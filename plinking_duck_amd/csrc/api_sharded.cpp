@@ -13,12 +13,141 @@
 // Shards work concurrently, one host thread per shard for the duration of a call.
 #include "api_internal.hpp"
 
+#include <rccl/rccl.h> // types and enums only: the library is bound at run time (below)
+
+#include <array>
+#include <atomic>
 #include <condition_variable>
+#include <dlfcn.h>
 #include <functional>
+#include <set>
 
 namespace {
 
 using Shards = std::vector<pgh_dataset *>;
+
+// ---- RCCL inside a shard group ---------------------------------------------------------------------------------
+// The per-sample merges the reference runs under a mutex (src/plink_score.cpp:657-664: global += local;
+// src/plink_pca.cpp:921-959: MergePass) are, between the devices of a group, RCCL collectives over xGMI: a reduce
+// to the first shard for plink_score's partials, an all-reduce per pass for plink_pca -- enqueued on each shard's
+// own stream, no host rendezvous and no stream drain in between.  One communicator per shard (ncclCommInitAll over
+// the group's device list) is made at the first collective and kept until the group is closed.  librccl is bound
+// with dlopen at that moment rather than linked: a process that already holds one (PyTorch-ROCm bundles its own
+// next to its HIP runtime) keeps using that one, and a host without it keeps every other entry point.  A group
+// whose shards share a device (the one-GPU test shape) has no communicator -- RCCL wants distinct devices -- and
+// uses the device-to-device copies further down; PGH_GROUP_RCCL=0 forces that path everywhere (an A/B switch).
+struct RcclApi {
+	void *handle = nullptr;
+	ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+	ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+	ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t (*Reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t (*GroupStart)() = nullptr;
+	ncclResult_t (*GroupEnd)() = nullptr;
+	const char *(*GetErrorString)(ncclResult_t) = nullptr;
+	bool ok = false;
+};
+
+const RcclApi &Rccl() {
+	static const RcclApi api = [] {
+		RcclApi a;
+		const char *off = std::getenv("PGH_GROUP_RCCL");
+		if (off && *off == '0') {
+			return a;
+		}
+		for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+			a.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+			if (a.handle) {
+				break;
+			}
+		}
+		if (!a.handle) {
+			return a;
+		}
+#define PGH_RCCL_SYM(field, sym) a.field = reinterpret_cast<decltype(a.field)>(dlsym(a.handle, sym))
+		PGH_RCCL_SYM(CommInitAll, "ncclCommInitAll");
+		PGH_RCCL_SYM(CommDestroy, "ncclCommDestroy");
+		PGH_RCCL_SYM(CommAbort, "ncclCommAbort");
+		PGH_RCCL_SYM(AllReduce, "ncclAllReduce");
+		PGH_RCCL_SYM(Reduce, "ncclReduce");
+		PGH_RCCL_SYM(GroupStart, "ncclGroupStart");
+		PGH_RCCL_SYM(GroupEnd, "ncclGroupEnd");
+		PGH_RCCL_SYM(GetErrorString, "ncclGetErrorString");
+#undef PGH_RCCL_SYM
+		a.ok = a.CommInitAll && a.CommDestroy && a.CommAbort && a.AllReduce && a.Reduce && a.GroupStart && a.GroupEnd;
+		return a;
+	}();
+	return api;
+}
+
+struct GroupComms {
+	std::mutex mu;
+	bool tried = false;
+	std::vector<ncclComm_t> comms; // empty: no RCCL for this group
+};
+
+GroupComms *CommsOf(const pgh_dataset *g) {
+	static std::mutex create_mu;
+	std::lock_guard<std::mutex> lock(create_mu);
+	if (!g->group_comms) {
+		g->group_comms = new GroupComms();
+	}
+	return static_cast<GroupComms *>(g->group_comms);
+}
+
+//! The group's communicators (made on first use), or null when the group has none.
+const std::vector<ncclComm_t> *EnsureComms(const pgh_dataset *g) {
+	GroupComms *gc = CommsOf(g);
+	std::lock_guard<std::mutex> lock(gc->mu);
+	if (!gc->tried) {
+		gc->tried = true;
+		const RcclApi &api = Rccl();
+		std::vector<int> devices;
+		std::set<int> distinct;
+		for (const pgh_dataset *s : g->shards) {
+			devices.push_back(s->device);
+			distinct.insert(s->device);
+		}
+		if (api.ok && distinct.size() == devices.size()) {
+			std::vector<ncclComm_t> comms(devices.size(), nullptr);
+			if (api.CommInitAll(comms.data(), static_cast<int>(devices.size()), devices.data()) == ncclSuccess) {
+				gc->comms = std::move(comms);
+			}
+			(void)hipGetLastError();
+		}
+	}
+	return gc->comms.empty() ? nullptr : &gc->comms;
+}
+
+//! A rank failed while the others may be inside a collective: abort every communicator (their kernels end, the
+//! waiting streams drain) and forget them; the next collective makes new ones.
+void AbortComms(const pgh_dataset *g) {
+	GroupComms *gc = CommsOf(g);
+	std::lock_guard<std::mutex> lock(gc->mu);
+	for (ncclComm_t c : gc->comms) {
+		if (c) {
+			(void)Rccl().CommAbort(c);
+		}
+	}
+	gc->comms.clear();
+	gc->tried = false;
+}
+
+void DestroyComms(pgh_dataset *g) {
+	auto *gc = static_cast<GroupComms *>(g->group_comms);
+	if (!gc) {
+		return;
+	}
+	for (size_t k = 0; k < gc->comms.size(); k++) {
+		if (gc->comms[k]) {
+			DeviceScope scope(g->shards.size() > k ? g->shards[k]->device : -1);
+			(void)Rccl().CommDestroy(gc->comms[k]);
+		}
+	}
+	delete gc;
+	g->group_comms = nullptr;
+}
 
 const pgh_subset *PartOf(const pgh_subset *ss, size_t k) {
 	return ss ? ss->parts[k] : nullptr;
@@ -88,16 +217,27 @@ class Rendezvous {
 public:
 	explicit Rendezvous(size_t n) : n_(n) {
 	}
-	void Wait() {
+	//! false when the meeting was called off (Abort): a rank that will never arrive must not leave the others
+	//! waiting for it
+	bool Wait() {
 		std::unique_lock<std::mutex> lock(m_);
+		if (aborted_) {
+			return false;
+		}
 		const uint64_t gen = gen_;
 		if (++arrived_ == n_) {
 			arrived_ = 0;
 			gen_++;
 			cv_.notify_all();
 		} else {
-			cv_.wait(lock, [&] { return gen_ != gen; });
+			cv_.wait(lock, [&] { return gen_ != gen || aborted_; });
 		}
+		return !aborted_;
+	}
+	void Abort() {
+		std::lock_guard<std::mutex> lock(m_);
+		aborted_ = true;
+		cv_.notify_all();
 	}
 
 private:
@@ -105,12 +245,78 @@ private:
 	std::condition_variable cv_;
 	size_t n_, arrived_ = 0;
 	uint64_t gen_ = 0;
+	bool aborted_ = false;
 };
 
 //! Sum device buffers of K shards into the first one: peers send to staging blocks on the root device over the
 //! device-to-device path, a kernel adds.  The calling thread may have any device current.
+//! ncclReduce of the shards' buffers onto the first shard's, one grouped call from this thread (a buffer-less shard
+//! sends zeros).  false: the group has no communicators (or the collective failed to start) -- use the copies.
 template <class T>
-int SumToRoot(const Shards &shards, const std::vector<T *> &bufs, uint64_t count, char *errbuf) {
+bool ReduceToRootRccl(const pgh_dataset *g, const std::vector<T *> &bufs, uint64_t count, char *errbuf, int &rc_out) {
+	const std::vector<ncclComm_t> *comms = EnsureComms(g);
+	if (!comms) {
+		return false;
+	}
+	const RcclApi &api = Rccl();
+	const Shards &shards = g->shards;
+	const size_t K = shards.size();
+	std::vector<DevBuf> zeros(K);
+	std::vector<hipStream_t> streams(K, nullptr);
+	std::vector<const void *> send(K, nullptr);
+	for (size_t k = 0; k < K; k++) {
+		DeviceScope scope(shards[k]->device);
+		streams[k] = PghThreadStream();
+		send[k] = bufs[k];
+		if (!bufs[k]) {
+			if (zeros[k].Alloc(sizeof(T) * count) != hipSuccess ||
+			    hipMemsetAsync(zeros[k].p, 0, sizeof(T) * count, streams[k]) != hipSuccess) {
+				rc_out = DeviceFail(errbuf, "hipMalloc(shard partial)", hipGetLastError());
+				return true;
+			}
+			send[k] = zeros[k].p;
+		}
+	}
+	ncclResult_t r = api.GroupStart();
+	for (size_t k = 0; k < K && r == ncclSuccess; k++) {
+		DeviceScope scope(shards[k]->device);
+		r = api.Reduce(send[k], k == 0 ? static_cast<void *>(bufs[0]) : nullptr, count,
+		               sizeof(T) == 8 ? ncclDouble : ncclUint32, ncclSum, 0, (*comms)[k], streams[k]);
+	}
+	const ncclResult_t r_end = api.GroupEnd();
+	if (r == ncclSuccess) {
+		r = r_end;
+	}
+	hipError_t e = hipSuccess;
+	for (size_t k = 0; k < K; k++) {
+		DeviceScope scope(shards[k]->device);
+		const hipError_t ek = hipStreamSynchronize(streams[k]);
+		if (e == hipSuccess) {
+			e = ek;
+		}
+	}
+	if (r != ncclSuccess || e != hipSuccess) {
+		AbortComms(g);
+		SetErr(errbuf, std::string("RCCL reduce of the shard partials failed: ") +
+		                   (r != ncclSuccess && api.GetErrorString ? api.GetErrorString(r) : hipGetErrorString(e)));
+		rc_out = PGH_ERR_DEVICE;
+		return true;
+	}
+	rc_out = PGH_OK;
+	return true;
+}
+
+template <class T>
+int SumToRoot(const pgh_dataset *g, const std::vector<T *> &bufs, uint64_t count, char *errbuf) {
+	if (!bufs[0]) {
+		SetErr(errbuf, "internal: the first shard holds no partial");
+		return PGH_ERR_ARG;
+	}
+	int rc_rccl = PGH_OK;
+	if (ReduceToRootRccl<T>(g, bufs, count, errbuf, rc_rccl)) {
+		return rc_rccl;
+	}
+	const Shards &shards = g->shards;
 	const int root = shards[0]->device;
 	DeviceScope scope(root);
 	const size_t bytes = sizeof(T) * count;
@@ -272,9 +478,14 @@ extern "C" const pgh_dataset *pgh_shard(const pgh_dataset *ds, uint32_t k) {
 	return (ds && k < ds->shards.size()) ? ds->shards[k] : nullptr;
 }
 
+extern "C" int pgh_group_uses_rccl(const pgh_dataset *ds) {
+	return ds && ds->IsGroup() && EnsureComms(ds) != nullptr ? 1 : 0;
+}
+
 namespace pgh_group {
 
 void Close(pgh_dataset *g) {
+	DestroyComms(g);
 	for (pgh_dataset *s : g->shards) {
 		pgh_close(s);
 	}
@@ -640,12 +851,12 @@ int Score(const pgh_dataset *g, const pgh_subset *ss, uint32_t n_scored, const u
 		return rc;
 	}
 	// ... and the merge of src/plink_score.cpp:657-664 runs on the first shard's device
-	rc = SumToRoot<double>(g->shards, p_score, static_cast<uint64_t>(N) * n_cols, errbuf);
+	rc = SumToRoot<double>(g, p_score, static_cast<uint64_t>(N) * n_cols, errbuf);
 	if (rc == PGH_OK && dosage_sum) {
-		rc = SumToRoot<double>(g->shards, p_dos, N, errbuf);
+		rc = SumToRoot<double>(g, p_dos, N, errbuf);
 	}
 	if (rc == PGH_OK) {
-		rc = SumToRoot<uint32_t>(g->shards, p_ac, N, errbuf);
+		rc = SumToRoot<uint32_t>(g, p_ac, N, errbuf);
 	}
 	if (rc != PGH_OK) {
 		return rc;
@@ -667,16 +878,19 @@ int Score(const pgh_dataset *g, const pgh_subset *ss, uint32_t n_scored, const u
 }
 
 namespace {
-// The all-reduce pgh_pca_sharded asks its host for, between the shard threads of one process: every thread
-// brings its device buffer, the first shard's thread gathers the others' over the device-to-device path, adds,
-// and sends the sum back.
+// The all-reduce pgh_pca_sharded asks its host for, between the shard threads of one process.  With communicators
+// (shards on distinct devices) it is ncclAllReduce on the calling shard's own stream: nothing to meet for on the
+// host and no stream drain -- RCCL orders the exchange on the device.  Without them every thread brings its device
+// buffer, the first shard's thread gathers the others' over the device-to-device path, adds, and sends the sum back.
 struct InProcessAllReduce {
+	const pgh_dataset *group = nullptr;
 	const Shards *shards = nullptr;
+	const std::vector<ncclComm_t> *comms = nullptr;
 	Rendezvous *meet = nullptr;
 	std::vector<void *> bufs;
 	DevBuf stage; // on the root device
 	size_t stage_bytes = 0;
-	int failed = 0;
+	std::atomic<int> failed {0};
 };
 struct AllReduceRank {
 	InProcessAllReduce *shared;
@@ -687,12 +901,25 @@ int AllReduceCallback(void *ctx, void *d_buf, uint64_t count, void *stream) {
 	auto *rank = static_cast<AllReduceRank *>(ctx);
 	InProcessAllReduce *ar = rank->shared;
 	const Shards &shards = *ar->shards;
+	if (ar->failed.load()) {
+		return 1;
+	}
+	if (ar->comms) {
+		const ncclResult_t r = Rccl().AllReduce(d_buf, d_buf, count, ncclDouble, ncclSum, (*ar->comms)[rank->k],
+		                                        static_cast<hipStream_t>(stream));
+		if (r != ncclSuccess) {
+			ar->failed.store(1);
+		}
+		return ar->failed.load();
+	}
 	if (hipStreamSynchronize(static_cast<hipStream_t>(stream)) != hipSuccess) {
-		ar->failed = 1;
+		ar->failed.store(1);
 	}
 	ar->bufs[rank->k] = d_buf;
-	ar->meet->Wait();
-	if (rank->k == 0 && !ar->failed) {
+	if (!ar->meet->Wait()) {
+		return 1;
+	}
+	if (rank->k == 0 && !ar->failed.load()) {
 		const size_t bytes = sizeof(double) * count;
 		const int root = shards[0]->device;
 		hipError_t e = hipSuccess;
@@ -717,11 +944,13 @@ int AllReduceCallback(void *ctx, void *d_buf, uint64_t count, void *stream) {
 			e = hipStreamSynchronize(PghThreadStream());
 		}
 		if (e != hipSuccess) {
-			ar->failed = 1;
+			ar->failed.store(1);
 		}
 	}
-	ar->meet->Wait();
-	return ar->failed;
+	if (!ar->meet->Wait()) {
+		return 1;
+	}
+	return ar->failed.load();
 }
 } // namespace
 
@@ -745,7 +974,9 @@ int Pca(const pgh_dataset *g, const pgh_subset *ss, uint32_t n_var, const uint32
 	const size_t n_out = ss ? ss->n_out : g->sample_ct;
 	Rendezvous meet(K);
 	InProcessAllReduce ar;
+	ar.group = g;
 	ar.shards = &g->shards;
+	ar.comms = EnsureComms(g);
 	ar.meet = &meet;
 	ar.bufs.assign(K, nullptr);
 	std::vector<AllReduceRank> ranks(K);
@@ -757,6 +988,9 @@ int Pca(const pgh_dataset *g, const pgh_subset *ss, uint32_t n_var, const uint32
 		SetErr(errbuf, "too few variants or samples for the requested number of PCs");
 		return PGH_ERR_ARG;
 	}
+	// PGH_TEST_PCA_FAIL_SHARD=k: shard k gives up before its first exchange (tests: the others must not wait for it)
+	const char *fail_env = std::getenv("PGH_TEST_PCA_FAIL_SHARD");
+	const long fail_shard = fail_env ? std::atol(fail_env) : -1;
 	rc = ForShards(g, errbuf, [&](size_t k, char *eb) {
 		const uint32_t n_k = static_cast<uint32_t>(cut.idx[k].size());
 		std::vector<double> c_k(n_k), i_k(n_k);
@@ -767,8 +1001,24 @@ int Pca(const pgh_dataset *g, const pgh_subset *ss, uint32_t n_var, const uint32
 		ranks[k] = AllReduceRank {&ar, k};
 		ev[k].resize(n_pcs);
 		vec[k].resize(n_out * n_pcs);
-		return pgh_pca_sharded(g->shards[k], PartOf(ss, k), n_k, cut.idx[k].data(), c_k.data(), i_k.data(), n_var, n_pcs,
-		                       g1_init, AllReduceCallback, &ranks[k], ev[k].data(), vec[k].data(), eb);
+		int rck;
+		if (fail_shard == static_cast<long>(k)) {
+			SetErr(eb, "shard failure injected by PGH_TEST_PCA_FAIL_SHARD");
+			rck = PGH_ERR_DEVICE;
+		} else {
+			rck = pgh_pca_sharded(g->shards[k], PartOf(ss, k), n_k, cut.idx[k].data(), c_k.data(), i_k.data(), n_var,
+			                      n_pcs, g1_init, AllReduceCallback, &ranks[k], ev[k].data(), vec[k].data(), eb);
+		}
+		if (rck != PGH_OK && !ar.failed.exchange(1)) {
+			// This rank is out -- an allocation that failed on a fuller device, a launch error, anything that made
+			// pgh_pca_sharded return between two exchanges -- and will not come to the next one: call the meeting
+			// off (the copy path), or abort the collectives the others may already be inside (RCCL).
+			meet.Abort();
+			if (ar.comms) {
+				AbortComms(g);
+			}
+		}
+		return rck;
 	});
 	{
 		DeviceScope scope(g->shards[0]->device);

@@ -21,7 +21,7 @@ SCORE_MEAN_IMPUTE, SCORE_NO_MEAN_IMPUTATION, SCORE_CENTER = 0, 1, 2
 # every symbol include/pgenhip.h declares (tests/test_abi.py checks the .so exports each)
 EXPORTED_SYMBOLS = [
     "pgh_version", "pgh_device_count", "pgh_set_device", "pgh_open", "pgh_probe", "pgh_normalize_range_host",
-    "pgh_from_host_rows", "pgh_open_sharded", "pgh_group_create", "pgh_shard_count", "pgh_shard",
+    "pgh_from_host_rows", "pgh_open_sharded", "pgh_group_create", "pgh_group_uses_rccl", "pgh_shard_count", "pgh_shard",
     "pgh_synth_create", "pgh_synth_record_host", "pgh_synth_write_files", "pgh_copy_rows_to_host", "pgh_get_info", "pgh_device_rows",
     "pgh_close", "pgh_subset_create", "pgh_subset_size", "pgh_subset_destroy", "pgh_counts_range",
     "pgh_counts_range_dev", "pgh_freq_from_counts_dev", "pgh_fused_tally_dev", "pgh_missing_per_sample", "pgh_missing_per_sample_dev", "pgh_unpack_range",
@@ -90,6 +90,7 @@ def _load():
         "pgh_open_sharded": (C.c_int, [cp, cp, u32, u32, vp, u32, C.POINTER(vp), cp]),
         "pgh_group_create": (C.c_int, [vp, u32, C.POINTER(vp), cp]),
         "pgh_shard_count": (u32, [vp]),
+        "pgh_group_uses_rccl": (C.c_int, [vp]),
         "pgh_shard": (vp, [vp, u32]),
         "pgh_synth_record_host": (C.c_int, [u32, u32, u64, C.c_double, vp]),
         "pgh_synth_write_files": (C.c_int, [cp, u32, u32, u64, C.c_double, cp]),
@@ -401,6 +402,11 @@ class Dataset:
         for s in shards:
             s._h = None  # owned by the group now
         return cls(h)
+
+    @property
+    def uses_rccl(self) -> bool:
+        """The group's per-sample merges are RCCL collectives (shards on distinct devices)."""
+        return bool(_lib.pgh_group_uses_rccl(self._h))
 
     @property
     def shard_count(self) -> int:

@@ -90,5 +90,27 @@ int main(int argc, char **argv) {
 		std::printf("eigenvalue %u: %.12g (plain) %.12g (RCCL all-reduce, 1 rank)\n", k, ev_plain[k], ev_rccl[k]);
 	}
 	std::printf("worst relative difference %.3g over %zu effective variants\n", worst, vidx.size());
+	// ... and the in-library form of the same exchange: a shard group on distinct devices (one here) all-reduces
+	// through communicators the library makes itself (pgh_open_sharded -> ncclCommInitAll at the first collective)
+	pgh_dataset *group = nullptr;
+	if (pgh_open_sharded(path.c_str(), nullptr, 0, UINT32_MAX, &dev, 1, &group, err) != PGH_OK) {
+		std::fprintf(stderr, "pgh_open_sharded: %s\n", err);
+		return 1;
+	}
+	if (!pgh_group_uses_rccl(group)) {
+		std::fprintf(stderr, "the group did not get RCCL communicators\n");
+		return 1;
+	}
+	std::vector<double> ev_group(n_pcs), vec_group(static_cast<size_t>(n) * n_pcs);
+	if (pgh_pca(group, nullptr, static_cast<uint32_t>(vidx.size()), vidx.data(), center.data(), inv_stdev.data(), n_pcs,
+	            g1.data(), ev_group.data(), vec_group.data(), err) != PGH_OK) {
+		std::fprintf(stderr, "pgh_pca over the group: %s\n", err);
+		return 1;
+	}
+	pgh_close(group);
+	for (uint32_t k = 0; k < n_pcs; k++) {
+		worst = std::fmax(worst, std::fabs(ev_group[k] - ev_plain[k]) / ev_plain[k]);
+		std::printf("eigenvalue %u: %.12g (in-library RCCL all-reduce, shard group of 1)\n", k, ev_group[k]);
+	}
 	return worst < 1e-12 ? 0 : 1;
 }

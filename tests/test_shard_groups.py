@@ -149,6 +149,70 @@ def test_pca_over_shards_equals_one_dataset(gpu_lib):
         assert np.allclose(vec1[:, j], sgn * vec2[:, j], atol=1e-7)
 
 
+def _pca_inputs(whole, n, k):
+    c = whole.counts_range().astype(np.float64)
+    obs = c[:, :3].sum(axis=1)
+    af = (c[:, 1] + 2 * c[:, 2]) / (2 * np.maximum(obs, 1))
+    keep = np.flatnonzero((obs > 0) & (af > 0) & (af < 1)).astype(np.uint32)
+    return keep, 2 * af[keep], 1.0 / np.sqrt(2 * af[keep] * (1 - af[keep])), np.random.default_rng(4).standard_normal((n, 2 * k))
+
+
+def test_a_group_on_distinct_devices_merges_over_rccl(gpu_lib):
+    """One shard on one device is the largest group of DISTINCT devices this box has: its merges run through the
+    in-library RCCL path (ncclCommInitAll over the group's devices, ncclReduce for plink_score's partials,
+    ncclAllReduce per plink_pca pass on the shard's own stream) -- the code an 8-GPU node runs with 8 ranks.
+    Shards that share a device (every other test of this file) have no communicator and use the copies."""
+    L = gpu_lib
+    m, n, k = 900, 2100, 4
+    whole = L.Dataset.synth(0, m, n, SEED + 11, 0.03)
+    solo = L.Dataset.group([L.Dataset.synth(0, m, n, SEED + 11, 0.03)])
+    shared = L.Dataset.group([L.Dataset.synth(0, 400, n, SEED + 11, 0.03), L.Dataset.synth(400, m, n, SEED + 11, 0.03)])
+    assert solo.uses_rccl and not shared.uses_rccl and not whole.uses_rccl
+    rng = np.random.default_rng(5)
+    vidx = np.sort(rng.choice(m, 500, replace=False)).astype(np.uint32)
+    w = rng.normal(size=(500, 3))
+    for mode in (L.SCORE_MEAN_IMPUTE, L.SCORE_NO_MEAN_IMPUTATION, L.SCORE_CENTER):
+        a, b = whole.score(vidx, w, mode=mode), solo.score(vidx, w, mode=mode)
+        assert np.allclose(a[0], b[0], rtol=1e-12, atol=1e-9) and np.allclose(a[1], b[1], rtol=1e-12, atol=1e-9)
+        assert np.array_equal(a[2], b[2])
+    keep, center, inv, g1 = _pca_inputs(whole, n, k)
+    ev1, vec1 = whole.pca(keep, center, inv, k, g1)
+    ev2, vec2 = solo.pca(keep, center, inv, k, g1)
+    assert np.allclose(ev1, ev2, rtol=1e-9)
+    for j in range(k):
+        assert np.allclose(vec1[:, j], np.sign(np.dot(vec1[:, j], vec2[:, j])) * vec2[:, j], atol=1e-7)
+
+
+def test_a_failing_shard_does_not_leave_the_others_waiting(gpu_lib, monkeypatch):
+    """pgh_pca over a group: a shard that gives up between two exchanges (a failed allocation, a launch error) used
+    to leave the other shard threads in the rendezvous forever; now the meeting is called off and the call fails."""
+    import threading
+    L = gpu_lib
+    m, n, k = 900, 2100, 4
+    whole, group = make_pair(L, m, n, [300, 650], missing=0.03, seed=SEED + 11)
+    keep, center, inv, g1 = _pca_inputs(whole, n, k)
+    for victim in (0, 1, 2):
+        monkeypatch.setenv("PGH_TEST_PCA_FAIL_SHARD", str(victim))
+        result = {}
+
+        def run():
+            try:
+                group.pca(keep, center, inv, k, g1)
+                result["ok"] = True
+            except IOError as e:
+                result["err"] = str(e)
+
+        t = threading.Thread(target=run, daemon=True)
+        t.start()
+        t.join(timeout=60)
+        assert not t.is_alive(), "the surviving shard threads are still waiting"
+        assert "err" in result
+    monkeypatch.delenv("PGH_TEST_PCA_FAIL_SHARD")
+    ev1, _ = whole.pca(keep, center, inv, k, g1)
+    ev2, _ = group.pca(keep, center, inv, k, g1)  # and the group still works afterwards
+    assert np.allclose(ev1, ev2, rtol=1e-9)
+
+
 def test_ld_pairs_across_a_shard_boundary(gpu_lib):
     m, n = 300, 4500
     whole, group = make_pair(gpu_lib, m, n, [100, 200], missing=0.05)
