@@ -545,6 +545,8 @@ struct pgh_score_plan {
 	int mode = 0;
 	void *d_vlist = nullptr, *d_weights = nullptr, *d_flip = nullptr, *d_counts = nullptr, *d_ts = nullptr,
 	     *d_td = nullptr, *d_ac = nullptr, *d_lin = nullptr;
+	void *d_special = nullptr; // non-finite weights (pgh::ScoreSpecial), scored apart in plain double arithmetic
+	uint32_t n_special = 0;
 };
 
 // The entry records of every sparse dosage track of the dataset (dosage.hpp), built once -- by the first plan that
@@ -613,7 +615,7 @@ extern "C" void pgh_score_plan_destroy(pgh_score_plan *plan) {
 		return;
 	}
 	for (void *p : {plan->d_vlist, plan->d_weights, plan->d_flip, plan->d_counts, plan->d_ts, plan->d_td, plan->d_ac,
-	                plan->d_lin}) {
+	                plan->d_lin, plan->d_special}) {
 		if (p) {
 			(void)hipFree(p);
 		}
@@ -719,6 +721,37 @@ static int ScorePlanCreate(const pgh_dataset *ds, const pgh_subset *subset, uint
 	}
 	const uint32_t *up_local = reorder ? p_local.data() : local.data();
 	const double *up_weights = reorder ? p_weights.data() : weights;
+	// Non-finite weights: the fixed-point digits of the matrix-core contraction cannot hold them (llrint of a NaN or
+	// an infinity is undefined: round 2 returned finite garbage for such a column).  They are zeroed for the
+	// contraction and scored apart, term by term in double arithmetic as the reference does
+	// (src/plink_score.cpp:621-651): NaN / +-Inf come out where the reference's sums have them.
+	std::vector<pgh::ScoreSpecial> special;
+	{
+		double probe = 0.0;
+		const size_t total = static_cast<size_t>(n_scored) * n_cols;
+		for (size_t j = 0; j < total; j++) {
+			probe += up_weights[j] * 0.0; // NaN as soon as one weight is not finite
+		}
+		if (!(probe == 0.0)) {
+			if (!reorder) {
+				p_weights.assign(weights, weights + total);
+			}
+			for (uint32_t k = 0; k < n_scored; k++) {
+				for (uint32_t c = 0; c < n_cols; c++) {
+					double &w = p_weights[static_cast<size_t>(k) * n_cols + c];
+					if (!std::isfinite(w)) {
+						if (k >= n_hard) {
+							SetErr(errbuf, "non-finite weight on a variant that carries a dosage track");
+							return PGH_ERR_ARG;
+						}
+						special.push_back(pgh::ScoreSpecial {k, c, w});
+						w = 0.0;
+					}
+				}
+			}
+			up_weights = p_weights.data();
+		}
+	}
 	const uint8_t *up_flip = reorder ? p_flip.data() : flip;
 	const uint32_t *up_counts = counts ? (reorder ? p_counts.data() : &counts[0][0]) : nullptr;
 	std::unique_ptr<pgh_score_plan, void (*)(pgh_score_plan *)> plan(new pgh_score_plan(), pgh_score_plan_destroy);
@@ -821,6 +854,13 @@ static int ScorePlanCreate(const pgh_dataset *ds, const pgh_subset *subset, uint
 				        "score digit kernels");
 			}
 		}
+		if (!special.empty()) {
+			plan->n_special = static_cast<uint32_t>(special.size());
+			PGH_HIP(hipMalloc(&plan->d_special, sizeof(pgh::ScoreSpecial) * special.size()), "hipMalloc(score)");
+			PGH_HIP(hipMemcpyAsync(plan->d_special, special.data(), sizeof(pgh::ScoreSpecial) * special.size(),
+			                       hipMemcpyHostToDevice, st),
+			        "score upload");
+		}
 		PGH_HIP(hipStreamSynchronize(st), "score plan sync"); // host staging vectors die with this frame
 	}
 	*out = plan.release();
@@ -918,6 +958,10 @@ extern "C" int pgh_score_run_dev(const pgh_score_plan *plan, void *d_score_sum, 
 		                               static_cast<double *>(plan->d_lin) + 4ull * (n_dos + n_gaps), ac + at, plan->mode,
 		                               static_cast<double *>(d_score_sum), plan->n_cols,
 		                               track ? static_cast<double *>(d_dosage_sum) : nullptr, st);
+	}
+	if (e == hipSuccess && plan->n_special) {
+		e = pgh::LaunchScoreNonFinite(ds->View(), vlist, ts, ac, static_cast<const pgh::ScoreSpecial *>(plan->d_special),
+		                              plan->n_special, plan->n_cols, static_cast<double *>(d_score_sum), st);
 	}
 	if (e == hipSuccess) {
 		e = pgh::LaunchAlleleCt(ac, plan->n_scored, static_cast<uint32_t *>(miss), N,

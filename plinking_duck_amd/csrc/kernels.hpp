@@ -91,6 +91,16 @@ hipError_t LaunchUnpackTransposed(const RowView &view, const uint32_t *vlist, ui
 // byte 1: g==3).  Skipped variants get all-zero tables.
 hipError_t LaunchScoreTables(const uint32_t *counts, const uint8_t *flip, uint32_t n_scored, int mode, double *ts,
                              double *td, uint32_t *ac, hipStream_t stream);
+// One non-finite weight of a plan: position in the plan's variant list, weight column, the weight itself.
+struct ScoreSpecial {
+	uint32_t pos, col;
+	double weight;
+};
+// score[s * n_cols + col] += weight * ts[pos][call of s] in plain double arithmetic, for the plan's non-finite
+// weights (vlist: local row of each list position; ts / ac: the plan's tables)
+hipError_t LaunchScoreNonFinite(const RowView &view, const uint32_t *vlist, const double *ts, const uint32_t *ac,
+                                const ScoreSpecial *special, uint32_t n_special, uint32_t n_cols, double *score,
+                                hipStream_t stream);
 // allele_ct[s] = sum_i (ac[i] & 0xff) - 2 * miss[s]   (miss == NULL: every sample gets the full sum)
 hipError_t LaunchAlleleCt(const uint32_t *ac, uint32_t n_scored, const uint32_t *miss, uint32_t sample_ct,
                           uint32_t *allele_ct, hipStream_t stream);

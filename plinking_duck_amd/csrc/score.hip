@@ -92,11 +92,50 @@ __global__ __launch_bounds__(256) void k_allele_ct(const uint32_t *__restrict__ 
 	}
 }
 
+// Non-finite weights (NaN, +-Inf) cannot be cut into fixed-point digits; the plan zeroes them for the matrix-core
+// contraction and hands them here: the reference's own double arithmetic, score[s][c] += w * scored(s)
+// (src/plink_score.cpp:621-651), term by term -- NaN where the scored value is 0 or w is NaN, +-Inf elsewhere,
+// nothing for a sample or a variant the mode skips.  special[j] = {position in the plan's list, column, weight}.
+__global__ __launch_bounds__(256) void k_score_nonfinite(const uint8_t *__restrict__ rows, uint64_t pitch,
+                                                         uint32_t sample_ct, const uint32_t *__restrict__ vlist,
+                                                         const double *__restrict__ ts, const uint32_t *__restrict__ ac,
+                                                         const ScoreSpecial *__restrict__ special, uint32_t n_cols,
+                                                         double *__restrict__ score) {
+	const ScoreSpecial sp = special[blockIdx.y];
+	const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+	if (s >= sample_ct) {
+		return;
+	}
+	const uint32_t inc = ac[sp.pos];
+	if ((inc & 0xffu) == 0) {
+		return; // the variant is skipped (no observation, or zero variance in center mode)
+	}
+	const uint32_t code = (rows[static_cast<uint64_t>(vlist[sp.pos]) * pitch + (s >> 2)] >> (2u * (s & 3u))) & 3u;
+	if (code == 3u && ((inc >> 8) & 0xffu) == 0) {
+		return; // a missing call contributes only under mean imputation
+	}
+	atomicAdd(score + static_cast<uint64_t>(s) * n_cols + sp.col, sp.weight * ts[4ull * sp.pos + code]);
+}
+
 } // namespace
 
 // ---------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------
+
+hipError_t LaunchScoreNonFinite(const RowView &view, const uint32_t *vlist, const double *ts, const uint32_t *ac,
+                                const ScoreSpecial *special, uint32_t n_special, uint32_t n_cols, double *score,
+                                hipStream_t stream) {
+	if (n_special == 0 || view.sample_ct == 0) {
+		return hipSuccess;
+	}
+	for (uint32_t j0 = 0; j0 < n_special; j0 += 65535u) { // grid.y limit
+		const uint32_t nj = n_special - j0 < 65535u ? n_special - j0 : 65535u;
+		hipLaunchKernelGGL(k_score_nonfinite, dim3((view.sample_ct + 255) / 256, nj), dim3(256), 0, stream, view.rows,
+		                   view.pitch, view.sample_ct, vlist, ts, ac, special + j0, n_cols, score);
+	}
+	return hipGetLastError();
+}
 
 hipError_t LaunchScoreTables(const uint32_t *counts, const uint8_t *flip, uint32_t n_scored, int mode, double *ts,
                              double *td, uint32_t *ac, hipStream_t stream) {

@@ -12,7 +12,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpgenhip.so")
+# PGENHIP_LIB: another build of the library (tools/i8_experiment.sh's knock-out builds live under /tmp and never
+# replace the in-tree file)
+LIB_PATH = os.environ.get("PGENHIP_LIB") or os.path.join(_HERE, "libpgenhip.so")
 
 ERRBUF_LEN = 256
 PGH_OK, PGH_ERR_OPEN, PGH_ERR_FORMAT, PGH_ERR_ARG, PGH_ERR_DEVICE, PGH_ERR_NOMEM, PGH_ERR_UNSUPPORTED = range(7)

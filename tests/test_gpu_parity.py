@@ -701,3 +701,35 @@ def test_rccl_host_runs_on_one_rank(tmp_path):
     run = subprocess.run([str(exe), str(tmp_path / "pcs")], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, (run.stdout[-1500:], run.stderr[-1500:])
     assert "worst relative difference" in run.stdout
+
+
+@pytest.mark.parametrize("mode,name", [(0, "default"), (1, "no_mean_imputation"), (2, "center")])
+def test_score_with_non_finite_weights_matches_the_reference_arithmetic(gpu_lib, oracle, mode, name):
+    """A NaN or infinite coefficient: the reference accumulates w * scored in doubles (src/plink_score.cpp:621-651), so
+    the column comes out NaN / +-Inf sample by sample.  (Round 2's fixed-point digits turned such a weight into finite
+    garbage.)  The other columns, the dosage sum and ALLELE_CT are untouched."""
+    L = gpu_lib
+    m, n = 300, 1003
+    rows = np.stack([L.synth_record_host(v, n, SEED, 0.1) for v in range(m)])
+    ds = L.Dataset.from_host_rows(rows, n)
+    head = bytes([0x6c, 0x1b, 0x02]) + m.to_bytes(4, "little") + n.to_bytes(4, "little") + bytes([0x40])
+    pg = oracle.Pgen(mem=np.frombuffer(head + rows.tobytes(), dtype=np.uint8))
+    rng = np.random.default_rng(17)
+    vidx = np.arange(m, dtype=np.uint32)
+    w = rng.normal(size=(m, 3))
+    w[7, 0] = np.nan
+    w[120, 1] = np.inf
+    w[121, 1] = np.inf
+    w[200, 2] = -np.inf
+    flip = (rng.random(m) < 0.3).astype(np.uint8)
+    got = ds.score(vidx, w, flip, mode)
+    with np.errstate(invalid="ignore"):
+        exp = [oracle.score(pg, vidx, w[:, c], flip, name)[0][:, 0] for c in range(3)]
+    for c in range(3):
+        g, e = got[0][:, c], exp[c]
+        assert np.array_equal(np.isnan(g), np.isnan(e)), (c, int(np.isnan(g).sum()), int(np.isnan(e).sum()))
+        assert np.array_equal(np.isposinf(g), np.isposinf(e)) and np.array_equal(np.isneginf(g), np.isneginf(e))
+        fin = np.isfinite(e)
+        assert np.allclose(g[fin], e[fin], rtol=1e-9, atol=1e-9)
+    clean = ds.score(vidx, np.nan_to_num(w, nan=0.0, posinf=0.0, neginf=0.0), flip, mode)
+    assert np.array_equal(got[2], clean[2]) and np.allclose(got[1], clean[1])

@@ -37,9 +37,12 @@ def pmc_means(path):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--round", type=int, default=2)
-    ap.add_argument("src", nargs="?", default=None)
+    ap.add_argument("--round", type=int, default=3)
+    ap.add_argument("src", nargs="?", default=None, help="directory the collection left its files in (default: gpurun_out/profiles)")
     args = ap.parse_args()
+    global SRC
+    if args.src:
+        SRC = args.src
     tag = f"r{args.round:02d}"
     for name in ("freq", "fused", "unpack", "score", "score1", "score2", "score4", "score8", "pca", "ld", "samplecounts", "missingsample", "dosagefreq", "dosagescore", "dosagefull", "dosagegaps"):
         src = os.path.join(SRC, f"bench_{name}.json")
