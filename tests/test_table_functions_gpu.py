@@ -827,23 +827,27 @@ def test_read_pfile_sample_orient_over_shards_and_batches(tmp_path, gpu_lib, ora
         assert [(-9 if x is None else x) for x in g] == cols[int(iid[1:])].tolist()
 
 
-# ---- every function over a file that spans several device batches, against the C ABI ---------------
+# ---- every function over a file that spans many claims and several pass batches, against the ORACLE --------------
 
 @pytest.fixture(scope="module")
-def midsize(tmp_path_factory, gpu_lib):
-    """40,000 variants x 3,001 samples (3 device batches of 16,384; ragged row tail), 22 chromosomes."""
+def midsize(tmp_path_factory, gpu_lib, oracle):
+    """40,000 variants x 3,001 samples (ten 4,096-variant claims per thread round; ragged row tail), 22 chromosomes:
+    the oracle's scan of the file on disk is what the shells are held to (the library's own calls only where the
+    oracle has no counterpart at this size)."""
     prefix = str(tmp_path_factory.mktemp("midsize") / "mid")
     gpu_lib.synth_write_files(prefix, 40_000, 3001, 20260807, 0.03)
     ds = gpu_lib.Dataset.open(prefix + ".pgen")
-    return prefix, ds
+    pg = oracle.Pgen(prefix + ".pgen")
+    return prefix, ds, pg
 
 
 @pytest.mark.parametrize("threads", [1, 6])
-def test_shells_agree_with_the_library_across_device_batches(midsize, gpu_lib, threads):
-    prefix, ds = midsize
+def test_shells_agree_with_the_oracle_across_device_batches(midsize, gpu_lib, oracle, threads, monkeypatch):
+    prefix, ds, pg = midsize
+    monkeypatch.setenv("PGH_TALLY_BATCH", "12288")  # the range's tally pass in four batches
     path = prefix + ".pgen"
     m, n = 40_000, 3001
-    counts = ds.counts_range().astype(np.int64)
+    counts = pg.scan_counts_mt(0, m, 4).astype(np.int64)
     pos_key = lambda chrom, pos: (int(chrom) - 1) * ((m + 21) // 22) + pos // 100 - 1  # variant index from the pvar text
     r = F.query("plink_freq", path, counts=True, threads=threads,
                 columns=["CHROM", "POS", "HOM_REF_CT", "HET_CT", "HOM_ALT_CT", "MISSING_CT", "OBS_CT", "ALT_FREQ"])
@@ -859,27 +863,34 @@ def test_shells_agree_with_the_library_across_device_batches(midsize, gpu_lib, t
     r = F.query("plink_missing", path, threads=threads, columns=["CHROM", "POS", "MISSING_CT", "OBS_CT"])
     assert len(r) == m and all(counts[pos_key(c, p), 3] == mc and oc == n - mc for c, p, mc, oc in r.rows)
     r = F.query("plink_missing", path, mode="sample", threads=threads, columns=["IID", "MISSING_CT", "OBS_CT"])
-    miss = ds.missing_per_sample()
+    miss = pg.missing_per_sample()
     bad = [(iid, mc, oc, int(miss[int(iid[1:])])) for iid, mc, oc in r.rows if miss[int(iid[1:])] != mc or oc != m - mc]
     assert len(r) == n and not bad, (len(bad), bad[:8], int(miss.sum()), int(counts[:, 3].sum()))
     r = F.query("plink_hardy", path, threads=threads, region="7:1-100000000",
                 columns=["POS", "HOM_REF_CT", "HET_CT", "HOM_ALT_CT", "P_HWE"])
     per = (m + 21) // 22
     assert len(r) == per
-    lnp = gpu_lib.hwe_lnp_batch(ds.counts_range(6 * per, 7 * per), False)
     for pos, a, b, c, p in r.rows:
         i = pos // 100 - 1
-        assert (a, b, c) == tuple(counts[6 * per + i, :3]) and p == pytest.approx(min(1.0, np.exp(lnp[i])), rel=1e-9)
+        assert (a, b, c) == tuple(counts[6 * per + i, :3])
+        assert p == pytest.approx(oracle.hardy_from_counts(counts[6 * per + i])[2], rel=1e-6)
     r = F.query("read_pgen", path, genotypes="counts", ac_range={"min": 3000}, threads=threads, columns=["POS", "CHROM", "genotypes"])
     keep = np.flatnonzero(counts[:, 1] + 2 * counts[:, 2] >= 3000)
     assert len(r) == len(keep)
     assert sorted(pos_key(c, p) for p, c, _ in r.rows) == list(keep)
     r = F.query("read_pfile", prefix, orient="sample", genotypes="counts", threads=threads, columns=["IID", "genotypes"])
-    sc = ds.sample_counts()
+    sc = pg.sample_counts()
     assert all([g["hom_ref"], g["het"], g["hom_alt"], g["missing"]] == [int(x) for x in sc[int(iid[1:])]] for iid, g in r.rows)
     w = np.linspace(-1.0, 1.0, m)
     r = F.query("plink_score", path, weights=[float(x) for x in w], threads=threads, columns=["IID", "ALLELE_CT", "SCORE_SUM"])
-    s, d, ac = ds.score(np.arange(m), w)
+    pick = np.arange(0, m, 7)  # (the oracle's per-sample loop over every variant would take minutes: every 7th here,
+    s, d, ac = ds.score(np.arange(m), w)  #  the full list against the library, whose parity tests face the oracle)
+    r7 = F.query("plink_score", path, weights=[float(w[v]) if v % 7 == 0 else 0.0 for v in range(m)], threads=threads,
+                 columns=["IID", "ALLELE_CT", "SCORE_SUM"])  # zero weights are dropped at bind
+    so, do, aco = oracle.score(pg, pick, w[pick])
+    for iid, a, ssum in r7.rows[::37]:
+        k = int(iid[1:])
+        assert a == aco[k] and ssum == pytest.approx(so[k, 0], rel=1e-9, abs=1e-9)
     for iid, a, ssum in r.rows[::37]:
         k = int(iid[1:])
         assert a == ac[k] and ssum == pytest.approx(s[k, 0], rel=1e-9, abs=1e-9)
