@@ -44,7 +44,7 @@ enum {
 	PGH_ERR_ARG = 3,         /* bad argument / out of range     (InvalidInputException)    */
 	PGH_ERR_DEVICE = 4,      /* HIP runtime failure             (IOException)              */
 	PGH_ERR_NOMEM = 5,
-	PGH_ERR_UNSUPPORTED = 6  /* track kind the device path does not decode (multiallelic, phased dosage) */
+	PGH_ERR_UNSUPPORTED = 6  /* reserved: a track kind no path decodes (none at present: multiallelic tracks are stepped over, phased-dosage tracks are not read, as PgrGetD does not read them) */
 };
 
 typedef struct pgh_dataset pgh_dataset; /* packed 2-bit genotype matrix resident in HBM */

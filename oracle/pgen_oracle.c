@@ -47,6 +47,7 @@ typedef struct {
 	uint64_t *fpos;    /* M+1 record offsets into body */
 	uint32_t sid_bytes;
 	int has_dosage, has_phase, has_multiallelic;
+	uint32_t *allele_ct; /* REF + ALTs per variant when the header carries ALT allele counts, else NULL */
 	char err[256];
 } pgo_file;
 
@@ -99,6 +100,7 @@ void pgo_close(pgo_file *h) {
 	}
 	free(h->vrtype);
 	free(h->fpos);
+	free(h->allele_ct);
 	free(h);
 }
 
@@ -107,6 +109,8 @@ void pgo_close(pgo_file *h) {
  *   u64 body offset per 65536-variant block,
  *   then per block: vrtypes (4- or 8-bit), record byte lengths (1-4 B),
  *   [alt allele counts], [nonref flag bits]. */
+static uint32_t rd_sid(const uint8_t *p, uint32_t nbytes);
+
 static pgo_file *pgo_parse(uint8_t *body, size_t body_len, uint8_t *index, size_t index_len, int owns_body) {
 	pgo_file *h = (pgo_file *)calloc(1, sizeof(pgo_file));
 	h->body = body;
@@ -185,6 +189,17 @@ static pgo_file *pgo_parse(uint8_t *body, size_t body_len, uint8_t *index, size_
 			}
 			h->fpos[v0 + cnt] = fp;
 			pos += (size_t)cnt * len_bytes;
+			if (ac_bytes) { /* ALT allele counts */
+				if (!h->allele_ct) {
+					h->allele_ct = (uint32_t *)malloc(sizeof(uint32_t) * (h->M ? h->M : 1));
+					for (uint32_t i = 0; i < h->M; i++) {
+						h->allele_ct[i] = 2;
+					}
+				}
+				for (uint32_t i = 0; i < cnt && pos + (size_t)(i + 1) * ac_bytes <= index_len; i++) {
+					h->allele_ct[v0 + i] = 1 + rd_sid(index + pos + (size_t)i * ac_bytes, ac_bytes);
+				}
+			}
 			pos += (size_t)cnt * ac_bytes;
 			if (nonref_mode == 3) {
 				pos += (cnt + 7) / 8;
@@ -553,7 +568,59 @@ int pgo_get_missingness(const pgo_file *h, uint32_t v, const uint8_t *include, u
 	return rc;
 }
 
-/* Skip aux track 1 (multiallelic) is not supported: no fixture carries it. */
+/* Aux track 1 (vrtype bit 0x08, multiallelic patches) sits between the main track and the phase / dosage
+ * tracks.  PgrGet / PgrGetCounts / PgrGetD collapse the ALT alleles (the main track as stored), so it is only
+ * measured here.  Layout from the PLINK 2 .pgen specification -- NO reference fixture holds such a record, so
+ * this is parity unpinned: 1 byte of modes (low nibble part a: patches of genotype-1 calls, high nibble part b:
+ * patches of genotype-2 calls; 0 = a bit per such call, 1 = id list in difflist layout, 15 = none); part a's
+ * patched calls carry one allele code each (0 / 1 / 2 / 4 / 8 bits for 3 / 4 / 5-6 / 7-18 / more alleles), part
+ * b's two (1 bit per call for 3 alleles, then 2+2 / 4+4 / 8+8 bits for 4-5 / 6-17 / more).  Returns NULL when
+ * malformed. */
+static const uint8_t *skip_aux1(const pgo_file *h, uint32_t v, const uint8_t *g, const uint8_t *p, const uint8_t *end) {
+	uint32_t alleles = h->allele_ct ? h->allele_ct[v] : 2;
+	if (alleles < 3 || p >= end) {
+		return NULL;
+	}
+	uint32_t calls[2] = {0, 0};
+	for (uint32_t s = 0; s < h->N; s++) {
+		calls[0] += g[s] == 1;
+		calls[1] += g[s] == 2;
+	}
+	uint8_t modes = *p++;
+	for (int part = 0; part < 2; part++) {
+		uint32_t mode = part == 0 ? (modes & 15u) : (modes >> 4), n = 0;
+		if (mode == 0) {
+			uint32_t nb = (calls[part] + 7) / 8;
+			if (p + nb > end) {
+				return NULL;
+			}
+			for (uint32_t i = 0; i < calls[part]; i++) {
+				n += (p[i / 8] >> (i & 7)) & 1;
+			}
+			p += nb;
+		} else if (mode == 1) {
+			uint32_t *ids = (uint32_t *)malloc(sizeof(uint32_t) * (h->N ? h->N : 1));
+			int rc = apply_difflist(h, &p, end, NULL, ids, &n);
+			free(ids);
+			if (rc) {
+				return NULL;
+			}
+		} else if (mode != 15) {
+			return NULL;
+		}
+		uint32_t bits;
+		if (part == 0) {
+			bits = alleles == 3 ? 0 : alleles == 4 ? 1 : alleles <= 6 ? 2 : alleles <= 18 ? 4 : 8;
+		} else {
+			bits = alleles == 3 ? 1 : alleles <= 5 ? 4 : alleles <= 17 ? 8 : 16;
+		}
+		p += ((uint64_t)n * bits + 7) / 8;
+		if (p > end) {
+			return NULL;
+		}
+	}
+	return p;
+}
 
 /* Phase track (vrtype bit 0x10).  Outputs per included sample. */
 int pgo_get_phase(const pgo_file *h, uint32_t v, const uint8_t *include, int8_t *geno_out, uint8_t *phasepresent_out,
@@ -571,8 +638,11 @@ int pgo_get_phase(const pgo_file *h, uint32_t v, const uint8_t *include, int8_t 
 	}
 	uint8_t t = h->vrtype[v];
 	if (t & 0x08) {
-		free(g);
-		return -2;
+		p = skip_aux1(h, v, g, p, h->body + h->fpos[v + 1]);
+		if (!p) {
+			free(g);
+			return -2;
+		}
 	}
 	uint8_t *pp = (uint8_t *)calloc(N ? N : 1, 1);
 	uint8_t *pi = (uint8_t *)calloc(N ? N : 1, 1);
@@ -633,11 +703,12 @@ static int decode_dosage16(const pgo_file *h, uint32_t v, uint8_t *g, uint16_t *
 		dos[s] = 0xffff;
 	}
 	if (t & 0x08) {
-		return -2;
+		p = skip_aux1(h, v, g, p, end);
+		if (!p) {
+			return -2;
+		}
 	}
-	if (t & 0x80) {
-		return -2;
-	}
+	/* (a phased-dosage track, 0x80, lies behind the dosage track: PgrGetD does not read it, nor does this) */
 	if (t & 0x10) {
 		uint32_t het_ct = 0;
 		for (uint32_t s = 0; s < N; s++) {

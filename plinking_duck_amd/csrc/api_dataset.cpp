@@ -525,10 +525,6 @@ extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t va
 		return err.find("cannot open") != std::string::npos ? PGH_ERR_OPEN : PGH_ERR_FORMAT;
 	}
 	const PgenIndex &ix = ds->index;
-	if (ix.has_multiallelic) {
-		SetErr(errbuf, "multiallelic hardcall tracks are not supported");
-		return PGH_ERR_UNSUPPORTED;
-	}
 	if (variant_end == UINT32_MAX) {
 		variant_end = ix.variant_ct;
 	}
@@ -674,12 +670,17 @@ extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t va
 			// how many records fit as raw bytes + their tables?
 			uint32_t n = 0;
 			uint64_t raw = 0;
-			if (!host_only && !(is_ld(v) && last_base < 0)) {
+			// A multiallelic record (0x08) keeps its ALT patches between the main track and the phase / dosage tracks.
+			// The device kernels do not measure that track, the host parser does (Normalizer::SkipAux1): a record that
+			// has both goes through the host-rows path by itself (a multiallelic record WITHOUT further tracks is
+			// expanded on the device like any other -- its main track is PgrGet's answer).
+			auto host_tracks = [&](uint32_t r) { return (ix.vrtype[r] & 0x08) != 0 && (has_track(r) || has_phase(r)); };
+			if (!host_only && !(is_ld(v) && last_base < 0) && !host_tracks(v)) {
 				// the stage holds file bytes here, not rows: only its byte budget limits the run
 				const uint32_t left = variant_end - v;
 				while (n < left) {
 					const uint32_t r = v + n;
-					if (n > 0 && plain_run[r - variant_begin] >= kMinPlainRun) {
+					if (n > 0 && (plain_run[r - variant_begin] >= kMinPlainRun || host_tracks(r))) {
 						break;
 					}
 					const uint64_t len = ix.offset[r + 1] - ix.offset[r];

@@ -276,6 +276,15 @@ bool ParsePgenIndex(const std::string &pgen_path, const std::string &pgi_path, P
 			pos += type_bits == 4 ? (cnt + 1) / 2 : cnt;
 			const uint8_t *lens = tab.data() + pos;
 			pos += static_cast<uint64_t>(cnt) * len_bytes;
+			if (allele_ct_bytes) {
+				// ALT allele counts of the block's variants
+				if (out.allele_ct.empty()) {
+					out.allele_ct.assign(M, 2);
+				}
+				for (uint32_t i = 0; i < cnt; i++) {
+					out.allele_ct[v0 + i] = 1u + LoadLe(tab.data() + pos + static_cast<size_t>(i) * allele_ct_bytes, allele_ct_bytes);
+				}
+			}
 			pos += static_cast<uint64_t>(cnt) * allele_ct_bytes;
 			if (nonref_flags) {
 				pos += (cnt + 7) / 8;
@@ -531,9 +540,69 @@ bool Normalizer::ExpandWithAux(uint32_t v, std::vector<uint8_t> &rec, std::vecto
 		return false;
 	}
 	if (index_.vrtype[v] & 0x08) {
-		err = "multiallelic hardcall track is not supported";
+		return SkipAux1(v, rec, row2bit, aux_off, err);
+	}
+	return true;
+}
+
+bool Normalizer::SkipAux1(uint32_t v, const std::vector<uint8_t> &rec, const std::vector<uint8_t> &row2bit, size_t &aux_off,
+                          std::string &err) const {
+	// Layout (PLINK 2 .pgen specification; no reference fixture holds such a record -- parity unpinned):
+	//   1 byte: low nibble = mode of part a (patches of the ref/ALT calls, genotype 1: which of them carry an ALT
+	//           other than ALT1), high nibble = mode of part b (patches of the two-ALT calls, genotype 2: which are
+	//           not ALT1/ALT1).  Mode 0: a bit per such call; 1: a list of sample ids (difflist layout without
+	//           values); 15: no patches.
+	//   part a: [bit array | id list], then the patched calls' allele codes: none with 3 alleles, 1 bit each with 4,
+	//           2 bits with 5-6, 4 bits with 7-18, a byte beyond;
+	//   part b: [bit array | id list], then two codes per patched call: 1 bit per call with 3 alleles, 2 + 2 bits
+	//           with 4-5, 4 + 4 with 6-17, 8 + 8 beyond.
+	const uint32_t N = index_.sample_ct;
+	const uint32_t alleles = index_.allele_ct.empty() ? 2u : index_.allele_ct[v];
+	if (alleles < 3) {
+		err = "variant " + std::to_string(v) + " has a multiallelic track but fewer than three alleles";
 		return false;
 	}
+	uint32_t n_01 = 0, n_10 = 0;
+	for (uint32_t s = 0; s < N; s++) {
+		const uint32_t g = (row2bit[s >> 2] >> (2 * (s & 3))) & 3u;
+		n_01 += g == 1u;
+		n_10 += g == 2u;
+	}
+	ByteCursor cur {rec.data() + aux_off, rec.data() + rec.size()};
+	const uint8_t modes = cur.Byte();
+	auto patches = [&](uint32_t mode, uint32_t calls, uint32_t &count) {
+		count = 0;
+		if (mode == 15) {
+			return true;
+		}
+		if (mode == 0) {
+			const uint8_t *bits = cur.Take((calls + 7) / 8);
+			for (uint32_t i = 0; bits && i < calls; i++) {
+				count += (bits[i >> 3] >> (i & 7)) & 1u;
+			}
+			return bits != nullptr || calls == 0;
+		}
+		if (mode == 1) {
+			return WalkDifflist(cur, N, index_.sample_id_bytes, false, [](uint32_t, uint32_t, uint32_t) {}, &count);
+		}
+		return false;
+	};
+	uint32_t n_a = 0, n_b = 0;
+	bool ok = cur.ok && patches(modes & 15u, n_01, n_a);
+	if (ok) {
+		const uint32_t bits_a = alleles == 3 ? 0u : alleles == 4 ? 1u : alleles <= 6 ? 2u : alleles <= 18 ? 4u : 8u;
+		ok = cur.Take((static_cast<uint64_t>(n_a) * bits_a + 7) / 8) != nullptr || n_a * bits_a == 0;
+	}
+	ok = ok && patches(modes >> 4, n_10, n_b);
+	if (ok) {
+		const uint32_t bits_b = alleles == 3 ? 1u : alleles <= 5 ? 4u : alleles <= 17 ? 8u : 16u;
+		ok = cur.Take((static_cast<uint64_t>(n_b) * bits_b + 7) / 8) != nullptr || n_b == 0;
+	}
+	if (!ok || !cur.ok) {
+		err = "malformed multiallelic track in variant " + std::to_string(v);
+		return false;
+	}
+	aux_off = static_cast<size_t>(cur.p - rec.data());
 	return true;
 }
 

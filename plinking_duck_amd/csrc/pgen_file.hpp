@@ -25,6 +25,9 @@ struct PgenIndex {
 	bool has_dosage = false;
 	bool has_phase = false;
 	bool has_multiallelic = false;
+	// alleles per variant (REF + ALTs) when the header carries ALT allele counts, else empty (every variant has two);
+	// needed only to size a multiallelic record's aux track (SkipAux1)
+	std::vector<uint32_t> allele_ct;
 	uint32_t vrtype_hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
 	uint32_t RecordBytes() const {
@@ -77,6 +80,12 @@ private:
 	bool ResolveLdBase(uint32_t v, std::string &err);
 	bool ExpandWithAux(uint32_t v, std::vector<uint8_t> &rec, std::vector<uint8_t> &row2bit, size_t &aux_off,
 	                   std::string &err);
+	// Steps over the multiallelic track (vrtype bit 0x08) that follows the main track.  PgrGet / PgrGetCounts /
+	// PgrGetD read a multiallelic variant with its ALT alleles collapsed (0 hom-ref, 1 ref + any ALT, 2 two ALTs --
+	// the main track as stored, src/pgen_reader.cpp:727, src/plink_freq.cpp:482), so this track is never
+	// decoded here, only measured, to find the phase / dosage tracks behind it.
+	bool SkipAux1(uint32_t v, const std::vector<uint8_t> &rec, const std::vector<uint8_t> &row2bit, size_t &aux_off,
+	              std::string &err) const;
 
 	const PgenIndex &index_;
 	const RecordFile &file_;

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <fstream>
+#include <functional>
 #include <limits>
 #include <sstream>
 #include <climits>
@@ -832,52 +833,55 @@ SampleInfo LoadSampleMetadata(ClientContext &, const string &path) {
 // samples parameter
 // ---------------------------------------------------------------------------
 
+// `samples :=` -- file indices of the named samples, in the caller's order.  Behaviour and messages are the
+// reference's (src/plink_common.cpp:1161-1216: integers are 0-based file positions, strings are IIDs looked up in
+// the .psam, a repeated sample is an error reported after every entry has resolved); the shape is this repo's: one
+// resolver per element kind, picked once, and a bitmap over the file's samples for the repeats.
 vector<uint32_t> ResolveSampleIndices(const Value &samples_val, uint32_t raw_sample_ct, const SampleInfo *sample_info,
                                       const string &func_name) {
-	if (samples_val.IsNull()) {
+	const bool is_list = !samples_val.IsNull() && samples_val.type().id() == LogicalTypeId::LIST;
+	if (samples_val.IsNull() || (is_list && ListValue::GetChildren(samples_val).empty())) {
 		throw InvalidInputException("%s: samples list must not be empty", func_name);
 	}
-	if (samples_val.type().id() != LogicalTypeId::LIST) {
-		throw InvalidInputException("%s: samples parameter must be LIST(VARCHAR) or LIST(INTEGER)", func_name);
-	}
-	auto &child_type = ListType::GetChildType(samples_val.type());
-	auto &children = ListValue::GetChildren(samples_val);
-	if (children.empty()) {
-		throw InvalidInputException("%s: samples list must not be empty", func_name);
-	}
-	vector<uint32_t> indices;
-	if (child_type.id() == LogicalTypeId::INTEGER || child_type.id() == LogicalTypeId::BIGINT) {
-		for (auto &child : children) {
-			int64_t idx = child.GetValue<int64_t>();
+	const LogicalTypeId kind = is_list ? ListType::GetChildType(samples_val.type()).id() : LogicalTypeId::SQLNULL;
+	std::function<uint32_t(const Value &)> resolve;
+	if (kind == LogicalTypeId::INTEGER || kind == LogicalTypeId::BIGINT) {
+		resolve = [&](const Value &entry) {
+			const int64_t idx = entry.GetValue<int64_t>();
 			if (idx < 0 || static_cast<uint64_t>(idx) >= raw_sample_ct) {
 				throw InvalidInputException("%s: sample index %lld out of range (sample count: %u)", func_name,
 				                            static_cast<long long>(idx), raw_sample_ct);
 			}
-			indices.push_back(static_cast<uint32_t>(idx));
-		}
-	} else if (child_type.id() == LogicalTypeId::VARCHAR) {
+			return static_cast<uint32_t>(idx);
+		};
+	} else if (kind == LogicalTypeId::VARCHAR) {
 		if (!sample_info) {
 			throw InvalidInputException("%s: samples parameter requires LIST(INTEGER) when no .psam "
 			                            "is available (no sample IDs to match against)",
 			                            func_name);
 		}
 		const_cast<SampleInfo *>(sample_info)->EnsureIidMap(func_name);
-		for (auto &child : children) {
-			auto iid = child.GetValue<string>();
-			auto it = sample_info->iid_to_idx.find(iid);
-			if (it == sample_info->iid_to_idx.end()) {
+		resolve = [&](const Value &entry) {
+			const string iid = entry.GetValue<string>();
+			const auto hit = sample_info->iid_to_idx.find(iid);
+			if (hit == sample_info->iid_to_idx.end()) {
 				throw InvalidInputException("%s: sample '%s' not found in .psam", func_name, iid);
 			}
-			indices.push_back(static_cast<uint32_t>(it->second));
-		}
+			return static_cast<uint32_t>(hit->second);
+		};
 	} else {
 		throw InvalidInputException("%s: samples parameter must be LIST(VARCHAR) or LIST(INTEGER)", func_name);
 	}
-	std::unordered_set<uint32_t> seen;
-	for (auto idx : indices) {
-		if (!seen.insert(idx).second) {
+	vector<uint32_t> indices;
+	for (const Value &entry : ListValue::GetChildren(samples_val)) {
+		indices.push_back(resolve(entry));
+	}
+	vector<bool> taken(raw_sample_ct, false);
+	for (const uint32_t idx : indices) {
+		if (taken[idx]) {
 			throw InvalidInputException("%s: duplicate sample index %u in samples list", func_name, idx);
 		}
+		taken[idx] = true;
 	}
 	return indices;
 }
@@ -1189,45 +1193,51 @@ void GenotypeRangeFilter::SetFromRange(const RangeFilter &r, bool inc_missing) {
 	active = r.active;
 }
 
+// af_range / ac_range / genotype_range: a STRUCT of optional bounds (and, for genotype_range, include_missing).
+// Contract and messages are the reference's (src/plink_common.cpp:1340-1391); here the accepted fields are a table
+// and the walk over the STRUCT looks each one up.
 RangeFilter ParseRangeFilter(const Value &val, const string &param_name, double valid_min, double valid_max,
                              const string &func_name, bool *include_missing_out) {
-	RangeFilter result;
 	if (val.type().id() != LogicalTypeId::STRUCT) {
 		throw InvalidInputException("%s: %s must be a STRUCT (e.g. {min: 0.0, max: 0.5})", func_name, param_name);
 	}
-	auto &child_types = StructType::GetChildTypes(val.type());
-	auto &children = StructValue::GetChildren(val);
-	if (children.empty()) {
+	RangeFilter result;
+	enum class Field { LOWER, UPPER, MISSING_FLAG };
+	struct Accepted {
+		const char *name;
+		Field what;
+	};
+	static const Accepted kBounds[] = {{"min", Field::LOWER}, {"max", Field::UPPER}, {"include_missing", Field::MISSING_FLAG}};
+	const size_t n_accepted = include_missing_out ? 3 : 2; // the flag belongs to genotype_range only
+	const auto &names = StructType::GetChildTypes(val.type());
+	const auto &values = StructValue::GetChildren(val);
+	if (values.empty()) {
 		return result;
 	}
-	for (idx_t i = 0; i < child_types.size(); i++) {
-		auto &field_name = child_types[i].first;
-		auto &child_val = children[i];
-		if (include_missing_out && field_name == "include_missing") {
-			if (!child_val.IsNull()) {
-				*include_missing_out = child_val.GetValue<bool>();
-			}
-			continue;
+	for (idx_t i = 0; i < names.size(); i++) {
+		const string &field = names[i].first;
+		const Accepted *hit = nullptr;
+		for (size_t k = 0; k < n_accepted && !hit; k++) {
+			hit = field == kBounds[k].name ? &kBounds[k] : nullptr;
 		}
-		if (field_name != "min" && field_name != "max") {
-			throw InvalidInputException("%s: %s has unknown field '%s' (expected %s)", func_name, param_name,
-			                            field_name,
+		if (!hit) {
+			throw InvalidInputException("%s: %s has unknown field '%s' (expected %s)", func_name, param_name, field,
 			                            include_missing_out ? "'min', 'max', and/or 'include_missing'"
 			                                                : "'min' and/or 'max'");
 		}
-		if (child_val.IsNull()) {
+		if (values[i].IsNull()) {
 			continue;
 		}
-		double v = child_val.GetValue<double>();
-		if (v < valid_min || v > valid_max) {
-			throw InvalidInputException("%s: %s.%s value %g is out of range [%g, %g]", func_name, param_name,
-			                            field_name, v, valid_min, valid_max);
+		if (hit->what == Field::MISSING_FLAG) {
+			*include_missing_out = values[i].GetValue<bool>();
+			continue;
 		}
-		if (field_name == "min") {
-			result.min = v;
-		} else {
-			result.max = v;
+		const double bound = values[i].GetValue<double>();
+		if (bound < valid_min || bound > valid_max) {
+			throw InvalidInputException("%s: %s.%s value %g is out of range [%g, %g]", func_name, param_name, field, bound,
+			                            valid_min, valid_max);
 		}
+		(hit->what == Field::LOWER ? result.min : result.max) = bound;
 	}
 	if (result.min > result.max) {
 		throw InvalidInputException("%s: %s min (%g) > max (%g)", func_name, param_name, result.min, result.max);
@@ -1236,6 +1246,7 @@ RangeFilter ParseRangeFilter(const Value &val, const string &param_name, double 
 	return result;
 }
 
+// include_genotypes := ['het', ...] (src/plink_common.cpp:1393-1436): category names, case and blanks ignored
 void ParseIncludeGenotypes(const Value &val, GenotypeRangeFilter &out, const string &func_name) {
 	if (val.IsNull()) {
 		return;
@@ -1245,21 +1256,19 @@ void ParseIncludeGenotypes(const Value &val, GenotypeRangeFilter &out, const str
 		                            "(e.g. ['het', 'hom_alt'])",
 		                            func_name);
 	}
-	auto &children = ListValue::GetChildren(val);
-	if (children.empty()) {
-		return;
-	}
-	for (auto &child : children) {
-		if (child.IsNull()) {
+	static const char *const kCalls[3] = {"hom_ref", "het", "hom_alt"};
+	bool any = false;
+	for (const Value &entry : ListValue::GetChildren(val)) {
+		if (entry.IsNull()) {
 			throw InvalidInputException("%s: include_genotypes contains a NULL category name", func_name);
 		}
-		string label = Lower(Trim(child.GetValue<string>()));
-		if (label == "hom_ref") {
-			out.allowed[0] = true;
-		} else if (label == "het") {
-			out.allowed[1] = true;
-		} else if (label == "hom_alt") {
-			out.allowed[2] = true;
+		const string label = Lower(Trim(entry.GetValue<string>()));
+		int call = -1;
+		for (int g = 0; g < 3 && call < 0; g++) {
+			call = label == kCalls[g] ? g : -1;
+		}
+		if (call >= 0) {
+			out.allowed[call] = true;
 		} else if (label == "missing") {
 			out.include_missing = true;
 		} else {
@@ -1267,8 +1276,9 @@ void ParseIncludeGenotypes(const Value &val, GenotypeRangeFilter &out, const str
 			                            "(expected 'hom_ref', 'het', 'hom_alt', and/or 'missing')",
 			                            func_name, label);
 		}
+		any = true;
 	}
-	out.active = true;
+	out.active = out.active || any;
 }
 
 PreDecompFilterResult CheckPreDecompFilters(const CountFilter &count_filter, const GenotypeRangeFilter &genotype_filter,

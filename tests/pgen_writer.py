@@ -142,11 +142,57 @@ def dosage_track(kind: int, dos16: np.ndarray, n: int) -> bytes:
     raise ValueError(kind)
 
 
+def _bits(values: np.ndarray, width: int) -> bytes:
+    """values packed LSB-first at `width` bits each (width in 0, 1, 2, 4, 8, 16)."""
+    if width == 0 or len(values) == 0:
+        return b""
+    v = values.astype(np.uint64)
+    bits = ((v[:, None] >> np.arange(width, dtype=np.uint64)) & np.uint64(1)).astype(np.uint8).reshape(-1)
+    return np.packbits(bits, bitorder="little").tobytes()
+
+
+def multiallelic_track(g: np.ndarray, alleles: int, rng: np.random.Generator) -> bytes:
+    """vrtype bit 0x08, as this repo reads the PLINK 2 specification (parity unpinned -- no reference fixture):
+    one byte of modes (low nibble: patches of the genotype-1 calls, high nibble: of the genotype-2 calls; 0 = a bit
+    per such call, 1 = sample-id list, 15 = none), then per part its selector and the patched calls' allele codes."""
+    n = len(g)
+    out = bytearray()
+    parts = []
+    modes = 0
+    for part, code in ((0, 1), (1, 2)):
+        calls = np.flatnonzero(g == code)
+        mode = int(rng.choice([0, 1, 15])) if len(calls) else 15
+        patched = rng.random(len(calls)) < 0.4 if mode != 15 else np.zeros(len(calls), dtype=bool)
+        if mode == 0:
+            sel = np.packbits(patched.astype(np.uint8), bitorder="little").tobytes()
+        elif mode == 1:
+            sel = _difflist(calls[patched], None, n)
+        else:
+            sel = b""
+        k = int(patched.sum())
+        if part == 0:
+            width = 0 if alleles == 3 else 1 if alleles == 4 else 2 if alleles <= 6 else 4 if alleles <= 18 else 8
+            vals = _bits(rng.integers(0, max(1, alleles - 2), k), width)
+        else:
+            width = 1 if alleles == 3 else 4 if alleles <= 5 else 8 if alleles <= 17 else 16
+            vals = _bits(rng.integers(0, 1 << min(width, 8), k), width)
+        modes |= mode << (4 * part)
+        parts.append(sel + vals)
+    out.append(modes)
+    for p in parts:
+        out += p
+    return bytes(out)
+
+
 def write_pgen(path: str, geno: np.ndarray, kinds: list[int], dosage: np.ndarray | None = None,
-               dosage_kinds: list[int] | None = None, phase_rng: np.random.Generator | None = None) -> None:
+               dosage_kinds: list[int] | None = None, phase_rng: np.random.Generator | None = None,
+               allele_cts: list[int] | None = None, aux1_rng: np.random.Generator | None = None) -> None:
     """geno: [M][N] codes.  Writes mode 0x10 with 8-bit vrtypes and 4-byte record lengths.
     dosage: [M][N] uint16 (65535 = no explicit dosage), written per variant as dosage_kinds[v] (0 = no track).
-    phase_rng: give every variant with a het a phase track (bit 0x10) of random content."""
+    phase_rng: give every variant with a het a phase track (bit 0x10) of random content.
+    allele_cts: alleles per variant (REF + ALTs); a variant with more than two gets a multiallelic track (0x08)
+    behind its main track -- geno holds its calls with the ALT alleles collapsed, which is what PgrGet returns --
+    and the header carries one byte of ALT allele count per variant."""
     m, n = geno.shape
     records = []
     kinds = list(kinds)
@@ -157,6 +203,9 @@ def write_pgen(path: str, geno: np.ndarray, kinds: list[int], dosage: np.ndarray
         rec = encode_record(k, g, base)
         if k not in (2, 3):
             base = g
+        if allele_cts is not None and allele_cts[v] > 2:
+            rec += multiallelic_track(g, allele_cts[v], aux1_rng or np.random.default_rng(v))
+            kinds[v] |= 0x08
         if phase_rng is not None and (g == 1).any():
             rec += phase_track(g, phase_rng)
             kinds[v] |= 0x10
@@ -166,9 +215,10 @@ def write_pgen(path: str, geno: np.ndarray, kinds: list[int], dosage: np.ndarray
         records.append(rec)
     blocks = (m + 65535) // 65536
     head = bytearray([0x6C, 0x1B, 0x10]) + int(m).to_bytes(4, "little") + int(n).to_bytes(4, "little")
-    head.append(0x40 | 4 | 3)  # no nonref flags; 8-bit vrtypes; 4-byte record lengths
+    ac_bytes = 1 if allele_cts is not None else 0
+    head.append(0x40 | (ac_bytes << 4) | 4 | 3)  # no nonref flags; ALT allele counts; 8-bit vrtypes; 4-byte lengths
     tables = bytearray()
-    table_len = blocks * 8 + sum(min(65536, m - b * 65536) * 5 for b in range(blocks))
+    table_len = blocks * 8 + sum(min(65536, m - b * 65536) * (5 + ac_bytes) for b in range(blocks))
     body_at = len(head) + table_len
     offsets = []
     fp = body_at
@@ -179,6 +229,8 @@ def write_pgen(path: str, geno: np.ndarray, kinds: list[int], dosage: np.ndarray
         for v in range(lo, hi):
             tables += len(records[v]).to_bytes(4, "little")
             fp += len(records[v])
+        if ac_bytes:
+            tables += bytes(int(a) - 1 for a in allele_cts[lo:hi])
     with open(path, "wb") as f:
         f.write(head)
         for o in offsets:
