@@ -165,6 +165,7 @@ def test_device_decoder_survives_corrupt_record_bytes(written, gpu_lib, tmp_path
 
 # ---- multiallelic records (vrtype bit 0x08) ----------------------------------------------------------------------
 
+@pytest.mark.gpu
 @pytest.mark.parametrize("n", [37, 300, 5003])
 def test_multiallelic_records_are_read_with_their_alt_alleles_collapsed(gpu_lib, oracle, tmp_path, n, monkeypatch):
     """A file with multiallelic variants used to be refused whole (PGH_ERR_UNSUPPORTED).  PgrGet / PgrGetCounts /
