@@ -216,3 +216,30 @@ def test_multiallelic_records_are_read_with_their_alt_alleles_collapsed(gpu_lib,
             have = dos[v] != 0xFFFF
             assert np.array_equal(d_all[v][have], dos[v][have] / 16384.0)
     monkeypatch.delenv("PGH_HOST_NORMALIZE")
+
+
+def test_multiallelic_records_on_the_host(lib, oracle, tmp_path):
+    """The CPU half of the test above: the oracle and the product's host normaliser read a file with multiallelic
+    records (every allele count class, both selector forms) and find the dosage track behind the multiallelic one."""
+    rng = np.random.default_rng(11)
+    m, n = 60, 700
+    geno = rng.integers(0, 4, size=(m, n), dtype=np.uint8)
+    kinds = W.choose_kinds(geno, rng)
+    alleles = [int(rng.choice([2, 3, 4, 5, 7, 18, 19, 40])) for _ in range(m)]
+    dos = np.full((m, n), 0xFFFF, dtype=np.uint16)
+    dkinds = [int(rng.choice([0, 0x20, 0x60])) for _ in range(m)]
+    for v in range(m):
+        if dkinds[v]:
+            hit = rng.random(n) < 0.2
+            dos[v, hit] = rng.integers(0, 32769, hit.sum())
+    path = str(tmp_path / "multi_host.pgen")
+    W.write_pgen(path, geno, kinds, dosage=dos, dosage_kinds=dkinds, allele_cts=alleles, aux1_rng=np.random.default_rng(3))
+    pg = oracle.Pgen(path)
+    assert lib.probe(path).raw_variant_ct == m
+    assert np.array_equal(lib.normalize_range_host(path), _pack_rows(geno))
+    for v in range(m):
+        assert np.array_equal(pg.geno(v), np.where(geno[v] == 3, -9, geno[v].astype(np.int8)))
+        d = pg.dosage(v)
+        have = dos[v] != 0xFFFF
+        assert np.array_equal(d[have], dos[v][have] / 16384.0)
+        assert np.array_equal(d[~have], np.where(geno[v][~have] == 3, -9.0, geno[v][~have].astype(np.float64)))
