@@ -547,6 +547,7 @@ struct pgh_score_plan {
 	     *d_td = nullptr, *d_ac = nullptr, *d_lin = nullptr;
 	void *d_special = nullptr; // non-finite weights (pgh::ScoreSpecial), scored apart in plain double arithmetic
 	uint32_t n_special = 0;
+	void *d_tiles = nullptr;   // tile-major copy of the table-scored rows (kept plans with many columns)
 };
 
 // The entry records of every sparse dosage track of the dataset (dosage.hpp), built once -- by the first plan that
@@ -615,7 +616,7 @@ extern "C" void pgh_score_plan_destroy(pgh_score_plan *plan) {
 		return;
 	}
 	for (void *p : {plan->d_vlist, plan->d_weights, plan->d_flip, plan->d_counts, plan->d_ts, plan->d_td, plan->d_ac,
-	                plan->d_lin, plan->d_special}) {
+	                plan->d_lin, plan->d_special, plan->d_tiles}) {
 		if (p) {
 			(void)hipFree(p);
 		}
@@ -632,9 +633,12 @@ extern "C" void pgh_score_plan_destroy(pgh_score_plan *plan) {
 
 //! pgh_score_plan_create; `counts` (optional, host): the scored variants' class tallies over the included samples,
 //! counts[i] for vidx[i] -- what a tally pass already holds -- in which case the plan does not read the rows for them.
+//! keep_tiles: the plan will be run more than once (pgh_score_plan_create): with many weight columns it keeps a
+//! tile-major copy of the scored rows (score_i8.hpp) when HBM has room -- a pass over the rows to build, contiguous
+//! genotype DMA in every run.  A one-shot call (pgh_score) would pay more for the copy than it saves.
 static int ScorePlanCreate(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_scored, const uint32_t *vidx,
                            const double *weights, const uint8_t *flip, uint32_t n_cols, int mode,
-                           const uint32_t (*counts)[4], pgh_score_plan **out, char *errbuf) {
+                           const uint32_t (*counts)[4], bool keep_tiles, pgh_score_plan **out, char *errbuf) {
 	if (!ds || !out || (n_scored && (!vidx || !weights))) {
 		SetErr(errbuf, "null argument");
 		return PGH_ERR_ARG;
@@ -830,6 +834,18 @@ static int ScorePlanCreate(const pgh_dataset *ds, const pgh_subset *subset, uint
 			}
 		}
 		if (plan->n_table) {
+			const char *tiles_env = std::getenv("PGH_SCORE_TILES"); // A/B switch
+			if (keep_tiles && !(tiles_env && *tiles_env == '0') &&
+			    pgh::ScoreI8UsesTiles(std::min(pgh::kI8MaxCols, n_cols), true)) {
+				size_t free_b = 0, total_b = 0;
+				(void)hipMemGetInfo(&free_b, &total_b);
+				const size_t need = pgh::ScoreI8TiledBytes(plan->n_table, N);
+				if (free_b > need + (8ull << 30)) {
+					PGH_HIP(hipMalloc(&plan->d_tiles, need), "hipMalloc(score tiles)");
+					PGH_HIP(pgh::LaunchScoreI8TileMajor(ds->View(), vlist, plan->n_table, static_cast<uint8_t *>(plan->d_tiles), st),
+					        "score tiles");
+				}
+			}
 			for (uint32_t c0 = 0; c0 < n_cols; c0 += pgh::kI8MaxCols) {
 				plan->i8.emplace_back();
 				ScoreI8Pass &pass = plan->i8.back();
@@ -847,6 +863,7 @@ static int ScorePlanCreate(const pgh_dataset *ds, const pgh_subset *subset, uint
 				pass.buf.colmax = static_cast<unsigned long long *>(pass.d_small);
 				pass.buf.k0 = reinterpret_cast<double *>(pass.buf.colmax + (pass.n_cols + 2));
 				pass.buf.scale_exp = pass.buf.k0 + (pass.n_cols + 2);
+				pass.buf.tiled = static_cast<const uint8_t *>(plan->d_tiles);
 				PGH_HIP(pgh::LaunchScoreI8Prepare(vlist, plan->n_table, static_cast<double *>(plan->d_weights) + c0, n_cols,
 				                                  pass.n_cols, static_cast<double *>(plan->d_ts),
 				                                  static_cast<double *>(plan->d_td), static_cast<uint32_t *>(plan->d_ac),
@@ -870,7 +887,7 @@ static int ScorePlanCreate(const pgh_dataset *ds, const pgh_subset *subset, uint
 extern "C" int pgh_score_plan_create(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_scored,
                                      const uint32_t *vidx, const double *weights, const uint8_t *flip, uint32_t n_cols,
                                      int mode, pgh_score_plan **out, char *errbuf) {
-	return ScorePlanCreate(ds, subset, n_scored, vidx, weights, flip, n_cols, mode, nullptr, out, errbuf);
+	return ScorePlanCreate(ds, subset, n_scored, vidx, weights, flip, n_cols, mode, nullptr, true, out, errbuf);
 }
 
 extern "C" int pgh_score_run_dev(const pgh_score_plan *plan, void *d_score_sum, void *d_dosage_sum, void *d_allele_ct,
@@ -977,7 +994,7 @@ int PghScoreDevCounts(const pgh_dataset *ds, const pgh_subset *subset, uint32_t 
 	PGH_ONE_DEVICE(ds);
 	PGH_ENTER(ds);
 	pgh_score_plan *plan = nullptr;
-	int rc = ScorePlanCreate(ds, subset, n_scored, vidx, weights, flip, n_cols, mode, counts, &plan, errbuf);
+	int rc = ScorePlanCreate(ds, subset, n_scored, vidx, weights, flip, n_cols, mode, counts, false, &plan, errbuf);
 	if (rc != PGH_OK) {
 		return rc;
 	}
@@ -1042,7 +1059,7 @@ extern "C" int pgh_score_counts(const pgh_dataset *ds, const pgh_subset *subset,
 	PGH_HIP(d_ac.Alloc(sizeof(uint32_t) * N), "hipMalloc(score out)");
 	mark("output buffers");
 	pgh_score_plan *plan = nullptr;
-	int rc = ScorePlanCreate(ds, subset, n_scored, vidx, weights, flip, n_cols, mode, counts, &plan, errbuf);
+	int rc = ScorePlanCreate(ds, subset, n_scored, vidx, weights, flip, n_cols, mode, counts, false, &plan, errbuf);
 	if (rc != PGH_OK) {
 		return rc;
 	}
@@ -1214,7 +1231,7 @@ extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, 
 	// Both contractions run on the int8 matrix cores (score_i8.hip): the dense factor of each pass is cut into
 	// exact fixed-point digits, <= 18 columns per pass.  X^T (...) walks the resident rows; X G1 walks the
 	// transposed packed matrix, built here once (pca_i8.hip).
-	DevBuf d_xt, d_iota, d_a, d_mm, d_colsum, i8_bmat, i8_rowidx, i8_cols, i8_small;
+	DevBuf d_xt, d_iota, d_a, d_mm, d_colsum, i8_bmat, i8_rowidx, i8_cols, i8_small, d_tiles_x, d_tiles_xt;
 	pgh::ScoreI8Buffers i8;
 	RowView view_t {nullptr, 0, M, (M + 3) / 4};
 	{
@@ -1241,6 +1258,27 @@ extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, 
 			PGH_HIP(d_xt.Alloc(view_t.pitch * N), "hipMalloc(transposed genotypes)");
 			PGH_HIP(pgh::LaunchTranspose2bit(view, d_vlist.As<uint32_t>(), M, d_xt.As<uint8_t>(), st), "pca transpose");
 			view_t.rows = d_xt.As<uint8_t>();
+			// Tile-major copies of both matrices for the many-column passes (score_i8.hpp): every pass over X or X^T
+			// then streams its genotype bytes as contiguous 8 KB tile images.  One pass over each matrix to build
+			// (~1 ms per GB), n_pcs + 1 resp. n_pcs + 10-ish contractions to use; skipped when the shapes of this
+			// call do not use tiles (few PCs) or HBM is short (the contractions then read the rows as before).
+			// PGH_PCA_TILES=0 turns it off (an A/B switch).
+			const char *tiles_env = std::getenv("PGH_PCA_TILES");
+			const bool want_tiles = !(tiles_env && *tiles_env == '0');
+			const bool step_tiles = pgh::ScoreI8UsesTiles(std::min(pgh::kI8MaxColsBare, k2), false);
+			const bool final_tiles = pgh::ScoreI8UsesTiles(std::min<uint32_t>(pgh::kI8MaxColsBare, qq), false);
+			size_t free_b = 0, total_b = 0;
+			(void)hipMemGetInfo(&free_b, &total_b);
+			const size_t need_x = pgh::ScoreI8TiledBytes(M, N), need_xt = pgh::ScoreI8TiledBytes(N, M);
+			if (want_tiles && (step_tiles || final_tiles) && free_b > need_x + need_xt + (2ull << 30)) {
+				PGH_HIP(d_tiles_x.Alloc(need_x), "hipMalloc(pca tiles)");
+				PGH_HIP(pgh::LaunchScoreI8TileMajor(view, d_vlist.As<uint32_t>(), M, d_tiles_x.As<uint8_t>(), st), "pca tiles");
+				if (step_tiles) {
+					PGH_HIP(d_tiles_xt.Alloc(need_xt), "hipMalloc(pca tiles)");
+					PGH_HIP(pgh::LaunchScoreI8TileMajor(view_t, d_iota.As<uint32_t>(), N, d_tiles_xt.As<uint8_t>(), st),
+					        "pca tiles");
+				}
+			}
 		}
 	}
 	mark("i8 buffers + transpose");
@@ -1250,6 +1288,7 @@ extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, 
 		hipError_t e = hipSuccess;
 		for (uint32_t c0 = 0; c0 < n_cols && e == hipSuccess; c0 += pgh::kI8MaxColsBare) {
 			const uint32_t nc = std::min(pgh::kI8MaxColsBare, n_cols - c0);
+			i8.tiled = d_tiles_x.As<uint8_t>();
 			e = pgh::LaunchScoreI8Prepare(d_vlist.As<uint32_t>(), M, w + c0, w_stride, nc, d_ts.As<double>(), nullptr, nullptr,
 			                              false, false, pgh::kI8Tables, i8, st);
 			if (e == hipSuccess) {
@@ -1269,6 +1308,7 @@ extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, 
 			double *dst = plane == pgh::kI8CodePlane ? d_a.As<double>() : d_mm.As<double>();
 			for (uint32_t c0 = 0; c0 < k2 && e == hipSuccess; c0 += pgh::kI8MaxColsBare) {
 				const uint32_t nc = std::min(pgh::kI8MaxColsBare, k2 - c0);
+				i8.tiled = d_tiles_xt.As<uint8_t>();
 				e = pgh::LaunchScoreI8Prepare(d_iota.As<uint32_t>(), N, g + c0, k2, nc, nullptr, nullptr, nullptr, false, false,
 				                              plane, i8, st);
 				if (e == hipSuccess) {

@@ -287,7 +287,14 @@ constexpr uint32_t RingSlots() {
 // Knock-out builds (tools/i8_experiment.sh, profiles/r02_i8_knockout.txt): -DPGH_I8_NO_BUILD takes the operand
 // building out of the loop, -DPGH_I8_NO_DMA / _NO_DMA_G / _NO_DMA_B the LDS-DMA (all of it / the genotype piece /
 // the digit pieces) after the first tiles.  Results are then wrong; only the launch time is read.
-template <int NT, int TS, int PLANES>
+//
+// TILED: `rows` is the tile-major copy of the matrix (k_i8_tile_major below) -- for every (64-variant tile, sample
+// group) the 8 KB the ring slot wants, contiguous and already swizzled -- instead of the variant-major rows.  Every
+// genotype DMA instruction then reads ONE contiguous kilobyte instead of 64 bytes of each of 16 rows (128 of 8
+// with eight waves), which was most of what kept the matrix pipe of the many-column shapes a third idle
+// (profiles/r02_i8_knockout.txt: the single genotype piece cost 17 of the DMA's 23 ms, a contiguous one 4.5),
+// and the tile's row numbers need not travel at all.  TS = 4 shapes only (five digit tiles and more).
+template <int NT, int TS, int PLANES, bool TILED>
 __global__ __launch_bounds__((I8Shape<NT, TS>::kThreads)) void k_score_i8(const uint8_t *__restrict__ rows, uint64_t pitch, uint32_t sample_ct,
                                                   const uint32_t *__restrict__ rowidx, uint32_t n_tiles,
                                                   uint32_t tiles_per_slice, const int8_t *__restrict__ bmat,
@@ -338,7 +345,7 @@ __global__ __launch_bounds__((I8Shape<NT, TS>::kThreads)) void k_score_i8(const 
 #elif defined(PGH_I8_NO_DMA_G)
 	constexpr uint32_t kPieces = kBPieces + 1u;
 #else
-	constexpr uint32_t kPieces = kGenoPieces + kBPieces + 1u;  // + the row numbers
+	constexpr uint32_t kPieces = kGenoPieces + kBPieces + (TILED ? 0u : 1u); // + the row numbers
 #endif
 	constexpr uint32_t kRowAhead = 2u * kRing - 2u;            // tiles between a row-number DMA and its use
 	static_assert(kPieces * (kRing - 2) < 64, "vmcnt field");
@@ -359,12 +366,18 @@ __global__ __launch_bounds__((I8Shape<NT, TS>::kThreads)) void k_score_i8(const 
 	const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(LdsAddress(&s_ring[0][0]));
 	const uint32_t rows_lds = __builtin_amdgcn_readfirstlane(LdsAddress(&s_rows[0][0]));
 	auto issue_rows = [&](uint32_t tile) {
+		if (TILED) {
+			return;
+		}
 		const uint32_t t = min(tile, last_tile);
 		Glds4(rowidx + static_cast<uint64_t>(t) * kTileVariants + lane, rows_lds + ((tile - tile_begin) & 15u) * 256u);
 	};
 	// the resident rows this lane fetches for `tile` (plain LDS reads: the numbers landed trips ago).  The loop asks
 	// for them one trip before the DMA that needs them, so the read's latency is not in front of that DMA.
 	auto read_rows = [&](uint32_t tile, uint32_t(&r)[kGenoPieces]) {
+		if (TILED) {
+			return;
+		}
 		const uint32_t *rp = &s_rows[(tile - tile_begin) & 15u][0];
 #pragma unroll
 		for (uint32_t n = 0; n < kGenoPieces; n++) {
@@ -397,8 +410,12 @@ __global__ __launch_bounds__((I8Shape<NT, TS>::kThreads)) void k_score_i8(const 
 		// (the genotype piece goes last: 16 rows x 64 B per instruction with TS = 4, the slow one of the batch)
 #pragma unroll
 		for (uint32_t n = 0; n < kGenoPieces; n++) {
-			const uint8_t *src = rows + static_cast<uint64_t>(r[n]) * pitch + st_col[n];
-			Glds16Stream(src, base + (S::kWaves * n + wave_u) * 1024u);
+			const uint32_t piece = S::kWaves * n + wave_u;
+			const uint8_t *src =
+			    TILED ? rows + (static_cast<uint64_t>(min(tile, last_tile)) * gridDim.x + blockIdx.x) * S::kGenoBytes +
+			                1024u * piece + 16u * lane
+			          : rows + static_cast<uint64_t>(r[n]) * pitch + st_col[n];
+			Glds16Stream(src, base + piece * 1024u);
 		}
 #endif
 	};
@@ -555,7 +572,7 @@ __global__ __launch_bounds__((I8Shape<NT, TS>::kThreads)) void k_score_i8(const 
 	}
 	PGH_WAIT_VM(0);
 	__builtin_amdgcn_s_barrier();
-	uint32_t r_cur[kGenoPieces], r_nxt[kGenoPieces];
+	uint32_t r_cur[kGenoPieces] = {}, r_nxt[kGenoPieces] = {};
 #pragma unroll
 	for (uint32_t d = 0; d + 1 < kRing; d++) {
 		read_rows(tile_begin + d, r_cur);
@@ -662,7 +679,62 @@ __global__ __launch_bounds__(256) void k_i8_rowidx(const uint32_t *__restrict__ 
 	}
 }
 
+// The tile-major copy: image (tile, group) = the eight 1 KB pieces of k_score_i8<., 4>'s ring slot -- piece p, lane l
+// holds bytes [16 q', 16 q' + 16) of the group's 128-byte stripe of listed row 64 tile + 8 p + l / 8, with
+// q' = (l % 8) ^ 4 [row >= 16 within its k-group pair], the bank swizzle the kernel's reads undo.
+__global__ __launch_bounds__(512) void k_i8_tile_major(const uint8_t *__restrict__ rows, uint64_t pitch,
+                                                       const uint32_t *__restrict__ vlist, uint32_t n_var,
+                                                       uint8_t *__restrict__ out) {
+	using S = I8Shape<5, 4>; // every TS = 4 shape shares the stripe geometry
+	const uint32_t group = blockIdx.x, tile = blockIdx.y;
+	const uint32_t row = threadIdx.x / S::kChunksPerRow, pos = threadIdx.x % S::kChunksPerRow;
+	const uint32_t logical = pos ^ (((row >> 4) & 1u) * S::kSwizzleChunks);
+	const uint32_t i = tile * kTileVariants + row;
+	const uint32_t v = vlist[i < n_var ? i : n_var - 1u]; // padding rows carry all-zero digits
+	const uint64_t col = static_cast<uint64_t>(group) * S::kRowBytes + 16ull * logical;
+	uint4 w = make_uint4(0, 0, 0, 0);
+	if (col + 16 <= pitch) {
+		w = LoadStream(reinterpret_cast<const uint4 *>(rows + static_cast<uint64_t>(v) * pitch + col));
+	}
+	StoreStream(reinterpret_cast<uint4 *>(out + (static_cast<uint64_t>(tile) * gridDim.x + group) * S::kGenoBytes) +
+	                threadIdx.x,
+	            w);
+}
+
 } // namespace
+
+bool ScoreI8UsesTiles(uint32_t n_cols, bool extras) {
+	return ScoreI8Tiles16(n_cols, extras) >= 5u; // the TS = 4 shapes of LaunchI8Shape
+}
+
+size_t ScoreI8TiledBytes(uint32_t n_var, uint32_t sample_ct) {
+	using S = I8Shape<5, 4>;
+	const uint64_t n_tiles = ((static_cast<uint64_t>(n_var) + kTileVariants - 1) / kTileVariants + 1u) & ~1ull;
+	const uint64_t groups = (static_cast<uint64_t>(sample_ct) + S::kSamplesPerGroup - 1) / S::kSamplesPerGroup;
+	return static_cast<size_t>(n_tiles * groups * S::kGenoBytes);
+}
+
+hipError_t LaunchScoreI8TileMajor(const RowView &view, const uint32_t *vlist, uint32_t n_var, uint8_t *out,
+                                  hipStream_t stream) {
+	using S = I8Shape<5, 4>;
+	if (n_var == 0) {
+		return hipSuccess;
+	}
+	const uint32_t n_tiles = ((n_var + kTileVariants - 1) / kTileVariants + 1u) & ~1u;
+	const uint32_t groups = (view.sample_ct + S::kSamplesPerGroup - 1) / S::kSamplesPerGroup;
+	if (n_tiles > 65535u * 16u) {
+		return hipErrorInvalidValue;
+	}
+	// grid.y <= 65535: a launch per 65,535 tiles (4 M variants)
+	for (uint32_t t0 = 0; t0 < n_tiles; t0 += 65535u) {
+		const uint32_t nt = n_tiles - t0 < 65535u ? n_tiles - t0 : 65535u;
+		hipLaunchKernelGGL(k_i8_tile_major, dim3(groups, nt), dim3(512), 0, stream, view.rows, view.pitch,
+		                   vlist + static_cast<uint64_t>(t0) * kTileVariants,
+		                   n_var > t0 * kTileVariants ? n_var - t0 * kTileVariants : 1u,
+		                   out + static_cast<uint64_t>(t0) * groups * S::kGenoBytes);
+	}
+	return hipGetLastError();
+}
 
 uint32_t ScoreI8Tiles16(uint32_t n_cols, bool extras) {
 	return (DigitColumns(n_cols, extras) + 15u) / 16u;
@@ -742,7 +814,13 @@ static hipError_t LaunchI8(const RowView &view, uint32_t n_tiles, uint32_t n_col
 	if (slices > 65535u) {
 		return hipErrorInvalidValue;
 	}
-	hipLaunchKernelGGL((k_score_i8<NT, TS, PLANES>), dim3(groups, slices), dim3(S::kThreads), 0, stream, view.rows, view.pitch,
+	if (TS == 4 && b.tiled) {
+		hipLaunchKernelGGL((k_score_i8<NT, TS, PLANES, TS == 4>), dim3(groups, slices), dim3(S::kThreads), 0, stream, b.tiled,
+		                   view.pitch, view.sample_ct, b.rowidx, n_tiles, tps, b.bmat, b.mult, b.target, n_cols, score,
+		                   out_stride, dosage_sum, missing_ct);
+		return hipGetLastError();
+	}
+	hipLaunchKernelGGL((k_score_i8<NT, TS, PLANES, false>), dim3(groups, slices), dim3(S::kThreads), 0, stream, view.rows, view.pitch,
 	                   view.sample_ct, b.rowidx, n_tiles, tps, b.bmat, b.mult, b.target, n_cols, score, out_stride,
 	                   dosage_sum, missing_ct);
 	return hipGetLastError();

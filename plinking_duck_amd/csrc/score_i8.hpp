@@ -38,7 +38,20 @@ struct ScoreI8Buffers {
 	unsigned long long *colmax = nullptr;
 	double *k0 = nullptr;
 	double *scale_exp = nullptr;
+	// optional: the tile-major copy of the listed rows (LaunchScoreI8TileMajor over the SAME list and view the
+	// pass was prepared with); used by the shapes ScoreI8UsesTiles names, ignored by the others
+	const uint8_t *tiled = nullptr;
 };
+
+// The many-column shapes (five 16-column digit tiles and more: a lane holds four samples, a workgroup a 128-byte
+// stripe of every row) stream the genotype bytes of a 64-variant tile as one contiguous 8 KB image per workgroup
+// when the caller keeps a TILE-MAJOR copy of the listed rows: ScoreI8TiledBytes bytes (the rows' own size, rounded
+// up to 128-byte stripes and 128-variant pairs of tiles), filled by LaunchScoreI8TileMajor in one pass over the
+// rows.  Worth it where the same list is contracted several times (plink_pca: every pass; a kept score plan).
+bool ScoreI8UsesTiles(uint32_t n_cols, bool extras);
+size_t ScoreI8TiledBytes(uint32_t n_var, uint32_t sample_ct);
+hipError_t LaunchScoreI8TileMajor(const RowView &view, const uint32_t *vlist, uint32_t n_var, uint8_t *out,
+                                  hipStream_t stream);
 
 // Cuts the coefficients of n_cols (<= kI8MaxCols) weight columns, of the dosage sum (td) and of the
 // missing-call count into digits.  ts / td: the per-variant tables of LaunchScoreTables (four doubles each);

@@ -733,3 +733,51 @@ def test_score_with_non_finite_weights_matches_the_reference_arithmetic(gpu_lib,
         assert np.allclose(g[fin], e[fin], rtol=1e-9, atol=1e-9)
     clean = ds.score(vidx, np.nan_to_num(w, nan=0.0, posinf=0.0, neginf=0.0), flip, mode)
     assert np.array_equal(got[2], clean[2]) and np.allclose(got[1], clean[1])
+
+
+@pytest.mark.parametrize("ncols", [10, 16, 22, 30])
+def test_kept_score_plans_stream_tile_major_copies(gpu_lib, oracle, ncols, monkeypatch):
+    """A kept plan with many weight columns contracts a tile-major copy of its rows (contiguous 8 KB tile images per
+    workgroup instead of 128 bytes of each of 64 rows); a one-shot pgh_score reads the rows themselves.  Same sums --
+    the integer digit sums are exact, only the final FP64 additions may differ in order -- over a list with gaps, a
+    ragged last tile, several slices, and a sample count that leaves a partial last stripe."""
+    import torch
+    L = gpu_lib
+    m, n = 9000, 5003
+    ds = L.Dataset.synth(0, m, n, SEED, 0.05)
+    rng = np.random.default_rng(ncols)
+    vidx = np.sort(rng.choice(m, 6001, replace=False)).astype(np.uint32)
+    w = rng.normal(size=(len(vidx), ncols))
+    flip = (rng.random(len(vidx)) < 0.3).astype(np.uint8)
+    monkeypatch.setenv("PGH_I8_TPS_MAX", "16")
+    for mode in (L.SCORE_MEAN_IMPUTE, L.SCORE_NO_MEAN_IMPUTATION, L.SCORE_CENTER):
+        want = ds.score(vidx, w, flip, mode)
+        plan = ds.score_plan(vidx, w, flip, mode)
+        d_score = torch.zeros((n, ncols), dtype=torch.float64, device="cuda")
+        d_dos = torch.zeros(n, dtype=torch.float64, device="cuda")
+        d_ac = torch.zeros(n, dtype=torch.int32, device="cuda")
+        plan.run_dev(d_score.data_ptr(), d_dos.data_ptr(), d_ac.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        scale = np.abs(w).sum(axis=0) * 2.0 + 1.0
+        assert np.all(np.abs(d_score.cpu().numpy() - want[0]) <= 1e-12 * scale)
+        assert np.allclose(d_dos.cpu().numpy(), want[1], rtol=1e-12, atol=1e-9)
+        assert np.array_equal(d_ac.cpu().numpy().astype(np.uint32), want[2])
+        plan.close()
+
+
+def test_pca_with_and_without_tile_major_copies(gpu_lib, monkeypatch):
+    L = gpu_lib
+    m, n, k = 3000, 2100, 7  # 2k = 14 columns: the many-column shape
+    ds = L.Dataset.synth(0, m, n, SEED + 3, 0.03)
+    c = ds.counts_range().astype(np.float64)
+    obs = c[:, :3].sum(axis=1)
+    af = (c[:, 1] + 2 * c[:, 2]) / (2 * np.maximum(obs, 1))
+    keep = np.flatnonzero((obs > 0) & (af > 0) & (af < 1)).astype(np.uint32)
+    center, inv = 2 * af[keep], 1.0 / np.sqrt(2 * af[keep] * (1 - af[keep]))
+    g1 = np.random.default_rng(4).standard_normal((n, 2 * k))
+    ev1, vec1 = ds.pca(keep, center, inv, k, g1)
+    monkeypatch.setenv("PGH_PCA_TILES", "0")
+    ev2, vec2 = ds.pca(keep, center, inv, k, g1)
+    assert np.allclose(ev1, ev2, rtol=1e-10)
+    for j in range(k):
+        assert np.allclose(vec1[:, j], np.sign(np.dot(vec1[:, j], vec2[:, j])) * vec2[:, j], atol=1e-7)

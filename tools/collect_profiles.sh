@@ -1,6 +1,7 @@
 #!/bin/bash
 # Runs on the MI355X box (via gpurun): the round's benches + rocprofv3 summaries.
-# Outputs under gpurun_out/profiles/; the judged copies are committed under profiles/ (r02_ prefix).
+# Outputs under gpurun_out/profiles/; the judged copies are committed under profiles/ (rNN_ prefix,
+# tools/summarise_profiles.py --round NN).
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/profiles
@@ -38,7 +39,7 @@ run_bench dosagefreq --workload dosagefreq --steps 5 --warmup 2 --cpu-seconds 0
 run_bench dosagescore --workload dosagescore --steps 3 --warmup 1 --cpu-seconds 0
 run_bench dosagefull --workload dosagescore --dosage-rate 1.0 --variants 50000 --steps 3 --warmup 1 --cpu-seconds 0
 run_bench dosagegaps --workload dosagescore --dosage-rate 0.8 --variants 50000 --steps 3 --warmup 1 --cpu-seconds 0
-stats freq --steps 10 --warmup 2
+stats freq --steps 10 --warmup 2 --configs none
 stats fused --workload fused --steps 5 --warmup 1
 stats unpack --workload unpack --steps 3 --warmup 1
 stats score --workload score --steps 3 --warmup 1
@@ -50,7 +51,7 @@ stats ld --workload ld --variants 20000 --steps 3 --warmup 1
 stats samplecounts --workload samplecounts --steps 3 --warmup 1
 stats missingsample --workload missingsample --steps 3 --warmup 1
 for c in FETCH_SIZE WRITE_SIZE; do
-	pmc freq $c $c --steps 3 --warmup 1
+	pmc freq $c $c --steps 3 --warmup 1 --configs none
 	pmc fused $c $c --workload fused --steps 3 --warmup 1
 	pmc unpack $c $c --workload unpack --steps 2 --warmup 1
 	pmc score1 $c $c --workload score --score-cols 1 --steps 2 --warmup 1
@@ -62,5 +63,13 @@ MF="SQ_INSTS_VALU_MFMA_I8 SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ
 pmc score mfma "$MF" --workload score --steps 2 --warmup 1
 pmc score1 mfma "$MF" --workload score --score-cols 1 --steps 2 --warmup 1
 pmc pca mfma "$MF" --workload pca --variants 100000 --steps 1 --warmup 0
+# the table functions at BASELINE's shape through the SQL shells, and the kernels a plink_hardy call launches when a
+# plink_freq call on the same file came first (none that reads the matrix: the tally pass is shared)
+python3 tools/shell_bench.py --synth 1000000x500000 --threads 16 > $OUT/shell_bench.txt 2> $OUT/shell_bench.err
+echo "shell bench exit $?"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_hardy_after_freq -- python3 tools/hardy_after_freq.py > $OUT/hardy_after_freq.txt 2> $OUT/hardy_after_freq.err
+cp $OUT/stats_hardy_after_freq/*/*_kernel_trace.csv $OUT/hardy_after_freq_kernel_trace.csv 2>/dev/null
+echo "hardy-after-freq trace exit $?"
+python3 tools/fused_time.py > $OUT/tally_kernels_alone.txt 2>&1
 ls $OUT | head -80 > $OUT/summary.txt
 tail -40 $OUT/summary.txt
