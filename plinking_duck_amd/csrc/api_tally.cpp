@@ -194,6 +194,7 @@ int StartPart(pgh_tally *t, TallyPart &p, size_t part_idx, uint32_t products, ch
 	const uint32_t n = p.v_end - p.v_begin;
 	p.batch = ChooseBatch(p.ds->pitch, n);
 	p.n_batches = n ? (n + p.batch - 1) / p.batch : 0;
+	// (stream priorities -- tallies high, exact tests low -- were tried: no measurable difference at 1 M x 500 k)
 	PGH_HIP(hipStreamCreateWithFlags(&p.main, hipStreamNonBlocking), "hipStreamCreate(tally)");
 	PGH_HIP(hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking), "hipStreamCreate(tally)");
 	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&p.d_counts), 16ull * (n ? n : 1)), "hipMalloc(tally counts)");
