@@ -429,6 +429,15 @@ int pgh_get_dosage_f64(pgh_reader *rd, uint32_t vidx, double *out);
  * phasepresent / phaseinfo bitarrays (ceil(n_out/64) words each, zero for
  * variants without a phase track).  The track was expanded into two resident bit rows at pgh_open. */
 int pgh_get_phased(pgh_reader *rd, uint32_t vidx, uint64_t *genovec, uint64_t *phasepresent, uint64_t *phaseinfo);
+/* PgrGet + GenoarrToBytesMinus9 over a range (pgh_unpack_range), enqueue-and-return on the reader's stream: calls
+ * and validity words of [v_begin, v_end) go to the caller's PAGE-LOCKED buffers (pgh_host_alloc), which must stay
+ * untouched until pgh_reader_unpack_wait(rd, slot).  `slot` (0 or 1) names which of the reader's two staging blocks
+ * the launch uses: a scan thread keeps chunk k + 1 on its way (kernel + copy over the host link) while it fills
+ * its output vector from chunk k -- the reference's scan decodes and copies one variant at a time
+ * (src/pgen_reader.cpp:727-733, :1009-1047).  A slot is reused only after it has been waited for. */
+int pgh_reader_unpack_start(pgh_reader *rd, int slot, uint32_t v_begin, uint32_t v_end, int8_t *out, uint64_t *validity,
+                            int missing_code);
+int pgh_reader_unpack_wait(pgh_reader *rd, int slot);
 const char *pgh_reader_error(const pgh_reader *rd);
 
 /* ---- HWE exact tests (host) --------------------------------------------- */

@@ -124,6 +124,11 @@ struct pgh_reader {
 	double *d_dosage = nullptr;   // one dosage row, allocated by the first pgh_get_dosage_f64
 	double *h_dosage = nullptr;   // pinned
 	uint64_t *h_phase = nullptr;  // pinned: phasepresent + phaseinfo words of one variant
+	// pgh_reader_unpack_start / _wait: two staging blocks on the device, an event each
+	void *d_unpack[2] = {nullptr, nullptr};
+	size_t unpack_bytes[2] = {0, 0};
+	hipEvent_t unpack_done[2] = {nullptr, nullptr};
+	bool unpack_pending[2] = {false, false};
 	std::string err;
 	std::vector<pgh_reader *> parts; // reader of a shard group: one per shard, created on first use
 };

@@ -65,6 +65,14 @@ extern "C" void pgh_reader_destroy(pgh_reader *rd) {
 	if (rd->h_row) {
 		(void)hipHostFree(rd->h_row);
 	}
+	for (int k = 0; k < 2; k++) {
+		if (rd->d_unpack[k]) {
+			(void)hipFree(rd->d_unpack[k]);
+		}
+		if (rd->unpack_done[k]) {
+			(void)hipEventDestroy(rd->unpack_done[k]);
+		}
+	}
 	if (rd->d_dosage) {
 		(void)hipFree(rd->d_dosage);
 	}
@@ -431,5 +439,105 @@ extern "C" int pgh_hwe_xchr_lnp_batch(const int32_t (*strata)[5], uint32_t n, ui
 	        "chrX hwe kernel");
 	PGH_HIP(hipMemcpyAsync(ln_p, d_lnp.p, 8ull * n, hipMemcpyDeviceToHost, PghThreadStream()), "hwe copy");
 	PGH_HIP(hipStreamSynchronize(PghThreadStream()), "hwe sync");
+	return PGH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// PgrGet over a range, enqueue-and-return (read_pgen's chunk pipeline)
+// ---------------------------------------------------------------------------
+
+extern "C" int pgh_reader_unpack_start(pgh_reader *rd, int slot, uint32_t v_begin, uint32_t v_end, int8_t *out,
+                                       uint64_t *validity, int missing_code) {
+	if (!rd || slot < 0 || slot > 1 || !out) {
+		if (rd) {
+			rd->err = "bad argument";
+		}
+		return PGH_ERR_ARG;
+	}
+	char errbuf[PGH_ERRBUF_LEN] = {0};
+	const pgh_dataset *ds = rd->ds;
+	rd->unpack_pending[slot] = false;
+	if (ds->IsGroup()) {
+		// a shard group fills the caller's buffer shard by shard on its own threads: nothing left to wait for
+		int rc = pgh_unpack_range(ds, rd->subset, v_begin, v_end, out, validity, missing_code, errbuf);
+		rd->err = errbuf;
+		return rc;
+	}
+	int rc = CheckRange(ds, v_begin, v_end, errbuf);
+	if (rc != PGH_OK) {
+		rd->err = errbuf;
+		return rc;
+	}
+	const uint32_t n_out = rd->subset ? rd->subset->n_out : ds->sample_ct;
+	const size_t rows = v_end - v_begin;
+	if (rows == 0 || n_out == 0) {
+		return PGH_OK;
+	}
+	DeviceScope scope(rd->device);
+	const size_t out_pitch = (static_cast<size_t>(n_out) + 15) / 16 * 16;
+	const size_t val_words = (n_out + 63) / 64;
+	const size_t out_bytes = (rows * out_pitch + 255) / 256 * 256;
+	const size_t need = out_bytes + (validity ? rows * val_words * 8 : 0);
+	auto fail = [&](const char *what, hipError_t e) {
+		rd->err = std::string(what) + ": " + hipGetErrorString(e);
+		return static_cast<int>(PGH_ERR_DEVICE);
+	};
+	hipError_t e = hipSuccess;
+	if (!rd->unpack_done[slot]) {
+		e = hipEventCreateWithFlags(&rd->unpack_done[slot], hipEventDisableTiming);
+		if (e != hipSuccess) {
+			return fail("hipEventCreate(unpack)", e);
+		}
+	}
+	if (rd->unpack_bytes[slot] < need) {
+		// (the slot's previous launch has been waited for: the caller consumed that chunk before reusing the slot)
+		(void)hipFree(rd->d_unpack[slot]);
+		rd->d_unpack[slot] = nullptr;
+		rd->unpack_bytes[slot] = 0;
+		e = hipMalloc(&rd->d_unpack[slot], need);
+		if (e != hipSuccess) {
+			return fail("hipMalloc(unpack staging)", e);
+		}
+		rd->unpack_bytes[slot] = need;
+	}
+	int8_t *d_out = static_cast<int8_t *>(rd->d_unpack[slot]);
+	uint64_t *d_val = validity ? reinterpret_cast<uint64_t *>(static_cast<char *>(rd->d_unpack[slot]) + out_bytes) : nullptr;
+	rc = pgh_unpack_range_dev(ds, rd->subset, v_begin, v_end, d_out, out_pitch, d_val, missing_code, rd->stream, errbuf);
+	if (rc != PGH_OK) {
+		rd->err = errbuf;
+		return rc;
+	}
+	if (out_pitch == n_out) {
+		e = hipMemcpyAsync(out, d_out, rows * static_cast<size_t>(n_out), hipMemcpyDeviceToHost, rd->stream);
+	} else {
+		e = hipMemcpy2DAsync(out, n_out, d_out, out_pitch, n_out, rows, hipMemcpyDeviceToHost, rd->stream);
+	}
+	if (e == hipSuccess && validity) {
+		e = hipMemcpyAsync(validity, d_val, rows * val_words * 8, hipMemcpyDeviceToHost, rd->stream);
+	}
+	if (e == hipSuccess) {
+		e = hipEventRecord(rd->unpack_done[slot], rd->stream);
+	}
+	if (e != hipSuccess) {
+		return fail("unpack copy", e);
+	}
+	rd->unpack_pending[slot] = true;
+	return PGH_OK;
+}
+
+extern "C" int pgh_reader_unpack_wait(pgh_reader *rd, int slot) {
+	if (!rd || slot < 0 || slot > 1) {
+		return PGH_ERR_ARG;
+	}
+	if (!rd->unpack_pending[slot]) {
+		return PGH_OK;
+	}
+	DeviceScope scope(rd->device);
+	const hipError_t e = hipEventSynchronize(rd->unpack_done[slot]);
+	rd->unpack_pending[slot] = false;
+	if (e != hipSuccess) {
+		rd->err = std::string("unpack wait: ") + hipGetErrorString(e);
+		return PGH_ERR_DEVICE;
+	}
 	return PGH_OK;
 }

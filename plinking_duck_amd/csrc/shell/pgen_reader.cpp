@@ -217,6 +217,15 @@ unique_ptr<LocalTableFunctionState> PgenInitLocal(ExecutionContext &, TableFunct
 	auto &gstate = global_state->Cast<PgenGlobalState>();
 	auto state = make_uniq<PgenLocalState>();
 	const bool phased_out = bind_data.include_phased && bind_data.genotype_mode != GenotypeMode::COLUMNS;
+	const bool pipelined = gstate.need_genotypes && !IsAggregateGenotypeMode(bind_data.genotype_mode) &&
+	                       !bind_data.include_dosages && !phased_out && !gstate.scan.has_variant_list;
+	if (pipelined) {
+		char errbuf[PGH_ERRBUF_LEN] = {0};
+		if (pgh_reader_create(gstate.scan.dataset->handle, gstate.scan.subset ? gstate.scan.subset->handle : nullptr,
+		                      &state->reader, errbuf) != PGH_OK) {
+			throw IOException("%s: thread init failed: %s", fn, string(errbuf));
+		}
+	}
 	if (gstate.need_genotypes && (bind_data.include_dosages || phased_out)) {
 		char errbuf[PGH_ERRBUF_LEN] = {0};
 		int rc = pgh_reader_create(gstate.scan.dataset->handle, gstate.scan.subset ? gstate.scan.subset->handle : nullptr,
@@ -234,11 +243,6 @@ unique_ptr<LocalTableFunctionState> PgenInitLocal(ExecutionContext &, TableFunct
 }
 
 namespace {
-
-struct RowPlan {
-	uint32_t vidx;
-	bool geno_range_all_pass;
-};
 
 // child element slot for row `row`: ARRAY rows are fixed stride, LIST rows append
 idx_t BeginGenotypeRow(const PgenBindData &bind_data, Vector &vec, idx_t row, uint32_t n) {
@@ -278,30 +282,70 @@ void PgenScan(ClientContext &, TableFunctionInput &data_p, DataChunk &output) {
 	auto ms_since = [](std::chrono::steady_clock::time_point a) {
 		return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
 	};
-	// 1. choose the variants of this chunk (filters run off the batched tallies).  A chunk
-	//    never straddles two claimed batches: their tallies and unpack span are per batch.
-	vector<RowPlan> plan;
-	plan.reserve(STANDARD_VECTOR_SIZE);
-	uint32_t vidx = 0;
-	while (plan.size() < STANDARD_VECTOR_SIZE) {
-		if (!plan.empty() &&
-		    (lstate.scan.BatchDrained() || (!listed && vidx + 1 - plan.front().vidx >= kUnpackSpan))) {
-			break; // the next Scan call continues
-		}
-		if (!lstate.scan.Next(gstate.scan, bind_data.func, vidx)) {
-			break;
-		}
-		bool all_pass = true;
-		if (bind_data.count_filter.HasFilter() || bind_data.genotype_filter.active) {
-			auto pf = CheckPreDecompFilters(bind_data.count_filter, bind_data.genotype_filter, lstate.scan.Counts(vidx),
-			                                n);
-			if (pf.skip) {
-				continue;
+	// 1. choose the variants of a chunk (filters run off the range's tallies).  A chunk never straddles
+	//    two claims: its unpack span is one launch.
+	auto plan_chunk = [&](vector<RowPlan> &plan) {
+		plan.clear();
+		plan.reserve(STANDARD_VECTOR_SIZE);
+		uint32_t vidx = 0;
+		while (plan.size() < STANDARD_VECTOR_SIZE) {
+			if (!plan.empty() &&
+			    (lstate.scan.BatchDrained() || (!listed && vidx + 1 - plan.front().vidx >= kUnpackSpan))) {
+				break; // the next chunk continues
 			}
-			all_pass = pf.all_pass;
+			if (!lstate.scan.Next(gstate.scan, bind_data.func, vidx)) {
+				break;
+			}
+			bool all_pass = true;
+			if (bind_data.count_filter.HasFilter() || bind_data.genotype_filter.active) {
+				auto pf = CheckPreDecompFilters(bind_data.count_filter, bind_data.genotype_filter,
+				                                lstate.scan.Counts(vidx), n);
+				if (pf.skip) {
+					continue;
+				}
+				all_pass = pf.all_pass;
+			}
+			plan.push_back({vidx, all_pass});
 		}
-		plan.push_back({vidx, all_pass});
+	};
+	const size_t val_words = (n + 63) / 64;
+	static const bool direct_env = [] {
+		const char *e = std::getenv("PLINKING_UNPACK_DIRECT");
+		return e && *e == '1';
+	}();
+	// PLINKING_UNPACK_PIPELINE=1: chunk k + 1 is unpacked and copied (pgh_reader_unpack_start) while chunk k is
+	// filled.  Off by default: with sixteen scan threads the host side is the limit either way -- 21 GB/s with the
+	// pipeline (two pinned gigabytes per thread) against 25-28 without at 500,000 samples -- it pays with few threads.
+	const char *pipeline_env = std::getenv("PLINKING_UNPACK_PIPELINE");
+	const bool pipelined = plain_hardcalls && !listed && !direct_env && pipeline_env && *pipeline_env == '1' &&
+	                       lstate.reader != nullptr;
+	auto launch_slot = [&](int k) {
+		auto &sl = lstate.slot[k];
+		if (sl.plan.empty()) {
+			return;
+		}
+		const uint32_t b = sl.plan.front().vidx, e = sl.plan.back().vidx + 1;
+		sl.bytes.resize(static_cast<size_t>(e - b) * n);
+		sl.validity.resize(static_cast<size_t>(e - b) * val_words);
+		if (pgh_reader_unpack_start(lstate.reader, k, b, e, sl.bytes.data(), sl.validity.data(), 0) != PGH_OK) {
+			throw IOException("%s: PgrGet failed for variants [%u, %u): %s", fn, b, e,
+			                  string(pgh_reader_error(lstate.reader)));
+		}
+	};
+	vector<RowPlan> plan_one;
+	if (pipelined) {
+		if (!lstate.primed) {
+			plan_chunk(lstate.slot[lstate.cur].plan);
+			launch_slot(lstate.cur);
+			lstate.primed = true;
+		}
+		// the chunk after this one goes on its way before this one is waited for
+		plan_chunk(lstate.slot[lstate.cur ^ 1].plan);
+		launch_slot(lstate.cur ^ 1);
+	} else {
+		plan_chunk(plan_one);
 	}
+	const vector<RowPlan> &plan = pipelined ? lstate.slot[lstate.cur].plan : plan_one;
 	if (plan.empty()) {
 		CompatSetOutputCardinality(output, 0);
 		return;
@@ -312,14 +356,11 @@ void PgenScan(ClientContext &, TableFunctionInput &data_p, DataChunk &output) {
 	// 2. unpack: one launch for the span the chunk covers, or one per listed variant
 	const uint32_t span_begin = plan.front().vidx;
 	const uint32_t span_end = plan.back().vidx + 1;
-	const size_t val_words = (n + 63) / 64;
+	const int8_t *chunk_bytes = nullptr;     // row r of the span at chunk_bytes + r * n
+	const uint64_t *chunk_validity = nullptr;
 	// PLINKING_UNPACK_DIRECT=1: a LIST / ARRAY chunk without gaps is unpacked straight into the output vector's
 	// child buffer (pageable memory: the runtime stages the copy) instead of into this thread's pinned block and
 	// from there with a memcpy.  Which one wins is a property of the host: measured in tools/shell_bench.py.
-	static const bool direct_env = [] {
-		const char *e = std::getenv("PLINKING_UNPACK_DIRECT");
-		return e && *e == '1';
-	}();
 	int8_t *direct_dst = nullptr;
 	if (plain_hardcalls && direct_env && !listed && (mode == GenotypeMode::LIST || mode == GenotypeMode::ARRAY) &&
 	    plan.size() == span_end - span_begin) {
@@ -333,7 +374,14 @@ void PgenScan(ClientContext &, TableFunctionInput &data_p, DataChunk &output) {
 			}
 		}
 	}
-	if (plain_hardcalls) {
+	if (pipelined) {
+		if (pgh_reader_unpack_wait(lstate.reader, lstate.cur) != PGH_OK) {
+			throw IOException("%s: PgrGet failed for variants [%u, %u): %s", fn, span_begin, span_end,
+			                  string(pgh_reader_error(lstate.reader)));
+		}
+		chunk_bytes = lstate.slot[lstate.cur].bytes.data();
+		chunk_validity = lstate.slot[lstate.cur].validity.data();
+	} else if (plain_hardcalls) {
 		const size_t rows = listed ? plan.size() : span_end - span_begin;
 		if (!direct_dst) {
 			lstate.bytes.resize(rows * n);
@@ -356,6 +404,8 @@ void PgenScan(ClientContext &, TableFunctionInput &data_p, DataChunk &output) {
 			throw IOException("%s: PgrGet failed for variants [%u, %u): %s", fn, span_begin, span_end,
 			                  string(errbuf));
 		}
+		chunk_bytes = direct_dst ? direct_dst : lstate.bytes.data();
+		chunk_validity = lstate.validity.data();
 	}
 
 	const double *dose = nullptr; // the current row of the chunk's dosages
@@ -429,8 +479,8 @@ void PgenScan(ClientContext &, TableFunctionInput &data_p, DataChunk &output) {
 		const uint32_t v = plan[row].vidx;
 		const bool null_out = bind_data.genotype_filter.active && !plan[row].geno_range_all_pass;
 		const size_t src_row = listed ? row : v - span_begin;
-		const int8_t *src = plain_hardcalls ? (direct_dst ? direct_dst : lstate.bytes.data()) + src_row * n : nullptr;
-		const uint64_t *val = plain_hardcalls ? lstate.validity.data() + src_row * val_words : nullptr;
+		const int8_t *src = plain_hardcalls ? chunk_bytes + src_row * n : nullptr;
+		const uint64_t *val = plain_hardcalls ? chunk_validity + src_row * val_words : nullptr;
 		dose = dosage_rows ? lstate.dosage_doubles.data() + row * static_cast<size_t>(n) : nullptr;
 		if (per_variant_decode) {
 			if (pgh_get_phased(lstate.reader, v, lstate.genovec.data(), lstate.phasepresent.data(),
@@ -533,6 +583,9 @@ void PgenScan(ClientContext &, TableFunctionInput &data_p, DataChunk &output) {
 	lstate.fill_ms += ms_since(t_fill0);
 	lstate.chunks++;
 	CompatSetOutputCardinality(output, plan.size());
+	if (pipelined) {
+		lstate.cur ^= 1; // (the slot just consumed is planned and launched again by the next call)
+	}
 }
 
 void RegisterPgenReader(ExtensionLoader &loader) {

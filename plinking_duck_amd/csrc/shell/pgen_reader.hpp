@@ -41,11 +41,27 @@ struct PgenGlobalState : public GlobalTableFunctionState {
 	}
 };
 
+struct RowPlan {
+	uint32_t vidx;
+	bool geno_range_all_pass;
+};
+
 struct PgenLocalState : public LocalTableFunctionState {
 	VariantScanLocal scan;
 	pgh_reader *reader = nullptr;
 	PinnedBuffer<int8_t> bytes;      // unpacked span [rows][n_out]; page-locked: the device copies straight into it
 	PinnedBuffer<uint64_t> validity; // [rows][ceil(n_out/64)]
+	// The genotype-list pipeline (plain hardcalls over a variant range): while a Scan call fills its output vector
+	// from chunk k, chunk k + 1 -- already planned -- is being unpacked and copied over the host link into the other
+	// slot's pinned block (pgh_reader_unpack_start / _wait).
+	struct ChunkSlot {
+		vector<RowPlan> plan;
+		PinnedBuffer<int8_t> bytes;
+		PinnedBuffer<uint64_t> validity;
+	};
+	ChunkSlot slot[2];
+	int cur = 0;
+	bool primed = false;
 	vector<double> dosage_doubles;
 	vector<uint64_t> genovec, phasepresent, phaseinfo;
 	// PLINKING_TIMING=1: where this thread's scan time went (printed when the thread's state goes)

@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = [
     "pgh_unpack_range_dev", "pgh_probe_unpack_shape_dev", "pgh_score", "pgh_score_counts", "pgh_score_dev", "pgh_score_plan_create", "pgh_score_run_dev",
     "pgh_score_plan_destroy", "pgh_pca", "pgh_pca_sharded", "pgh_ld_pairs", "pgh_ld_pairs_dev", "pgh_ld_pairs_status", "pgh_sample_counts", "pgh_sample_counts_dev",
     "pgh_synth_add_dosage", "pgh_synth_write_dosage_files", "pgh_dosage_sums", "pgh_dosage_sums_dev", "pgh_dosage_unpack", "pgh_dosage_unpack_dev", "pgh_unpack_samples", "pgh_dosage_unpack_samples", "pgh_reader_create", "pgh_reader_destroy",
-    "pgh_get_2bit", "pgh_get_counts", "pgh_get_missingness", "pgh_get_int8", "pgh_get_dosage_f64", "pgh_get_phased",
+    "pgh_reader_unpack_start", "pgh_reader_unpack_wait", "pgh_get_2bit", "pgh_get_counts", "pgh_get_missingness", "pgh_get_int8", "pgh_get_dosage_f64", "pgh_get_phased",
     "pgh_tally_start", "pgh_tally_request", "pgh_tally_wait", "pgh_tally_counts", "pgh_tally_hwe_lnp",
     "pgh_tally_sample_missing", "pgh_tally_destroy", "pgh_tally_passes_started", "pgh_host_alloc", "pgh_host_free",
     "pgh_reader_error", "pgh_hwe_lnp", "pgh_hwe_xchr_lnp", "pgh_hwe_lnp_batch", "pgh_hwe_lnp_batch_dev", "pgh_hwe_xchr_lnp_batch",
@@ -137,6 +137,8 @@ def _load():
         "pgh_pca_sharded": (C.c_int, [vp, vp, u32, vp, vp, vp, C.c_uint64, u32, vp, ALLREDUCE_FN, vp, vp, vp, cp]),
         "pgh_reader_create": (C.c_int, [vp, vp, C.POINTER(vp), cp]),
         "pgh_reader_destroy": (None, [vp]),
+        "pgh_reader_unpack_start": (C.c_int, [vp, C.c_int, u32, u32, vp, vp, C.c_int]),
+        "pgh_reader_unpack_wait": (C.c_int, [vp, C.c_int]),
         "pgh_get_2bit": (C.c_int, [vp, u32, vp]),
         "pgh_get_counts": (C.c_int, [vp, u32, vp]),
         "pgh_get_missingness": (C.c_int, [vp, u32, vp]),

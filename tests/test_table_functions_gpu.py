@@ -1062,7 +1062,7 @@ def test_host_calls_next_to_scan_threads_repeat_exactly(midsize, gpu_lib, thread
     its scratch from hipMallocAsync, pgh_missing_per_sample returned sums 9 % short about once in thirty calls made
     right after table-function queries (scan threads coming and going).  Scratch now lives in per-thread blocks from
     hipMalloc; every repetition must be identical, and equal to the per-variant tallies' total."""
-    prefix, ds = midsize
+    prefix, ds, _ = midsize
     path = prefix + ".pgen"
     want = int(ds.counts_range()[:, 3].astype(np.int64).sum())
     for _ in range(2):
@@ -1073,3 +1073,20 @@ def test_host_calls_next_to_scan_threads_repeat_exactly(midsize, gpu_lib, thread
         F.query("plink_missing", path, mode="sample", threads=threads, columns=["IID", "MISSING_CT"])
         cls = [ds.sample_counts().astype(np.int64).sum(axis=0) for _ in range(3)]
         assert all(np.array_equal(c, cls[0]) for c in cls) and int(cls[0][3]) == want
+
+
+def test_read_pgen_chunk_pipeline_gives_the_same_rows(gpu_lib, tmp_path, monkeypatch):
+    """PLINKING_UNPACK_PIPELINE=1: a scan thread keeps chunk k + 1 on its way (pgh_reader_unpack_start) while it fills
+    its output from chunk k.  Same rows as one chunk at a time, filters and subsets included."""
+    prefix = str(tmp_path / "pipe")
+    m, n = 9000, 301
+    gpu_lib.synth_write_files(prefix, m, n, 20260807, 0.05)
+    path = prefix + ".pgen"
+    calls = [dict(genotypes="list"), dict(genotypes="array", samples=[0, 5, 299]),
+             dict(genotypes="list", af_range={"min": 0.3}), dict(genotypes="list", genotype_range={"min": 1})]
+    for kw in calls:
+        monkeypatch.setenv("PLINKING_UNPACK_PIPELINE", "0")
+        a = F.query("read_pgen", path, threads=3, columns=["ID", "genotypes"], **kw)
+        monkeypatch.setenv("PLINKING_UNPACK_PIPELINE", "1")
+        b = F.query("read_pgen", path, threads=3, columns=["ID", "genotypes"], **kw)
+        assert len(a) == len(b) > 0 and sorted(a.rows) == sorted(b.rows)
