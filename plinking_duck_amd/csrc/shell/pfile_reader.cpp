@@ -474,7 +474,7 @@ static unique_ptr<FunctionData> PfileBind(ClientContext &context, TableFunctionB
 						run_end++;
 					}
 					tallies.resize(4 * static_cast<size_t>(run_end - run_begin));
-					if (pgh_counts_range(dataset->handle, subset ? subset->handle : nullptr, candidates[run_begin],
+					if (pgh_counts_range(dataset->Resident("read_pfile"), subset ? subset->handle : nullptr, candidates[run_begin],
 					                     candidates[run_end - 1] + 1, reinterpret_cast<uint32_t(*)[4]>(tallies.data()),
 					                     errbuf) != PGH_OK) {
 						throw IOException("read_pfile: PgrGetCounts failed for variant %u during count filter: %s",
@@ -692,7 +692,7 @@ static void RunSampleMatrixPhase1(const PfileBindData &bind_data, PfileGlobalSta
 		if (eff.empty()) {
 			continue;
 		}
-		pgh_dataset *ds = gstate.datasets[si]->handle;
+		pgh_dataset *ds = gstate.datasets[si]->Resident("read_pfile");
 		pgh_subset *ss = gstate.subsets[si] ? gstate.subsets[si]->handle : nullptr;
 		const uint32_t n_var = static_cast<uint32_t>(eff.size());
 		const bool whole = bind_data.sources.size() == 1; // one source: the call fills the matrix in place
@@ -755,7 +755,7 @@ static void RunSamplePhase1(const PfileBindData &bind_data, PfileGlobalState &gs
 	for (size_t si = 0; si < bind_data.sources.size(); si++) {
 		const auto &src = bind_data.sources[si];
 		const auto &c = src.c;
-		pgh_dataset *ds = gstate.datasets[si]->handle;
+		pgh_dataset *ds = gstate.datasets[si]->Resident("read_pfile");
 		pgh_subset *ss = gstate.subsets[si] ? gstate.subsets[si]->handle : nullptr;
 		vector<uint32_t> list;
 		bool listed = src.has_variant_list;
@@ -870,7 +870,7 @@ static void GenotypeOrientScan(const PfileBindData &bind_data, PfileGlobalState 
 			lstate.cur_sample = 0;
 			if (gstate.need_genotypes) {
 				const uint32_t si = bind_data.flat_source[begin];
-				pgh_dataset *ds = gstate.datasets[si]->handle;
+				pgh_dataset *ds = gstate.datasets[si]->Resident("read_pfile");
 				pgh_subset *ss = gstate.subsets[si] ? gstate.subsets[si]->handle : nullptr;
 				char errbuf[PGH_ERRBUF_LEN] = {0};
 				int rc = PGH_OK;

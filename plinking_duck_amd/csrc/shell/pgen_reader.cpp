@@ -221,14 +221,14 @@ unique_ptr<LocalTableFunctionState> PgenInitLocal(ExecutionContext &, TableFunct
 	                       !bind_data.include_dosages && !phased_out && !gstate.scan.has_variant_list;
 	if (pipelined) {
 		char errbuf[PGH_ERRBUF_LEN] = {0};
-		if (pgh_reader_create(gstate.scan.dataset->handle, gstate.scan.subset ? gstate.scan.subset->handle : nullptr,
+		if (pgh_reader_create(gstate.scan.dataset->Resident(bind_data.func), gstate.scan.subset ? gstate.scan.subset->handle : nullptr,
 		                      &state->reader, errbuf) != PGH_OK) {
 			throw IOException("%s: thread init failed: %s", fn, string(errbuf));
 		}
 	}
 	if (gstate.need_genotypes && (bind_data.include_dosages || phased_out)) {
 		char errbuf[PGH_ERRBUF_LEN] = {0};
-		int rc = pgh_reader_create(gstate.scan.dataset->handle, gstate.scan.subset ? gstate.scan.subset->handle : nullptr,
+		int rc = pgh_reader_create(gstate.scan.dataset->Resident(bind_data.func), gstate.scan.subset ? gstate.scan.subset->handle : nullptr,
 		                           &state->reader, errbuf);
 		if (rc != PGH_OK) {
 			throw IOException("%s: thread init failed: %s", fn, string(errbuf));
@@ -387,7 +387,7 @@ void PgenScan(ClientContext &, TableFunctionInput &data_p, DataChunk &output) {
 			lstate.bytes.resize(rows * n);
 		}
 		lstate.validity.resize(rows * val_words);
-		pgh_dataset *ds = gstate.scan.dataset->handle;
+		pgh_dataset *ds = gstate.scan.dataset->Resident(bind_data.func);
 		pgh_subset *ss = gstate.scan.subset ? gstate.scan.subset->handle : nullptr;
 		char errbuf[PGH_ERRBUF_LEN] = {0};
 		int rc = PGH_OK;
@@ -417,7 +417,7 @@ void PgenScan(ClientContext &, TableFunctionInput &data_p, DataChunk &output) {
 		}
 		lstate.dosage_doubles.resize(plan.size() * static_cast<size_t>(n));
 		char errbuf[PGH_ERRBUF_LEN] = {0};
-		if (pgh_dosage_unpack(gstate.scan.dataset->handle, gstate.scan.subset ? gstate.scan.subset->handle : nullptr, 0,
+		if (pgh_dosage_unpack(gstate.scan.dataset->Resident(bind_data.func), gstate.scan.subset ? gstate.scan.subset->handle : nullptr, 0,
 		                      static_cast<uint32_t>(plan.size()), chunk_vidx.data(), lstate.dosage_doubles.data(),
 		                      errbuf) != PGH_OK) {
 			throw IOException("%s: PgrGetD failed for variants [%u, %u): %s", fn, span_begin, span_end, string(errbuf));

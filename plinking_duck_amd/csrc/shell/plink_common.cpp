@@ -11,6 +11,7 @@
 #include <functional>
 #include <limits>
 #include <sstream>
+#include <thread>
 #include <climits>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -1632,6 +1633,10 @@ DeviceDataset::~DeviceDataset() {
 	}
 }
 
+namespace {
+uint64_t CacheBudgetBytes();
+}
+
 // ---- pinned host blocks ----------------------------------------------------------------------------
 
 namespace {
@@ -1707,11 +1712,53 @@ bool GetPlinkingTallyCache(ClientContext &context) {
 	return true;
 }
 
+struct DeviceTally::Streamed {
+	std::thread producer;
+	std::mutex m;
+	std::condition_variable cv;
+	uint32_t done_upto = 0; // variants below this have landed
+	bool stop = false, failed = false;
+	string error;
+	vector<uint32_t> counts;  // [end - begin][4]
+	vector<double> lnp[2];    // [end - begin]
+	vector<uint32_t> missing; // per included sample, summed over the windows
+};
+
 DeviceTally::DeviceTally(DeviceDataset &ds, const vector<uint64_t> *sample_include, uint32_t begin_p, uint32_t end_p,
                          uint32_t products, const string &func_name)
     : begin(begin_p), end(end_p) {
 	if (sample_include) {
 		mask = *sample_include;
+	}
+	if (ds.streamed) {
+		// every product, always: next to reading the file a second time for a later request they cost nothing
+		streamed_ = make_uniq<Streamed>();
+		Streamed &st = *streamed_;
+		const size_t n = end - begin;
+		st.done_upto = begin;
+		st.counts.assign(4 * n, 0);
+		st.lnp[0].assign(n, 0.0);
+		st.lnp[1].assign(n, 0.0);
+		uint32_t n_out = ds.info.raw_sample_ct;
+		if (sample_include) {
+			n_out = 0;
+			for (uint64_t w : mask) {
+				n_out += static_cast<uint32_t>(__builtin_popcountll(w));
+			}
+		}
+		st.missing.assign(n_out, 0);
+		counts_ = reinterpret_cast<const uint32_t(*)[4]>(st.counts.data());
+		lnp_[0] = st.lnp[0].data();
+		lnp_[1] = st.lnp[1].data();
+		// a window: half the HBM budget (the other half is the pass's and the ingest's working room), whole variants
+		const uint64_t pitch = std::max<uint64_t>(16, (static_cast<uint64_t>(ds.info.record_bytes) + 127) / 128 * 128);
+		const uint64_t window = std::max<uint64_t>(1, CacheBudgetBytes() / 2 / pitch);
+		const string path = ds.path, fn = func_name;
+		const uint32_t sample_ct = ds.info.raw_sample_ct;
+		st.producer = std::thread([this, path, sample_ct, window, fn] { RunStream(path, sample_ct, window, fn); });
+		return;
+	}
+	if (sample_include) {
 		subset_ = make_uniq<DeviceSubset>(ds, mask, func_name);
 	}
 	char errbuf[PGH_ERRBUF_LEN] = {0};
@@ -1720,22 +1767,110 @@ DeviceTally::DeviceTally(DeviceDataset &ds, const vector<uint64_t> *sample_inclu
 		throw IOException("%s: PgrGetCounts failed for variants [%u, %u): %s", func_name, begin, end, string(errbuf));
 	}
 	counts_ = pgh_tally_counts(handle);
+	lnp_[0] = pgh_tally_hwe_lnp(handle, 0);
+	lnp_[1] = pgh_tally_hwe_lnp(handle, 1);
+}
+
+void DeviceTally::RunStream(const string &path, uint32_t sample_ct, uint64_t window_variants, const string &func_name) {
+	Streamed &st = *streamed_;
+	auto fail = [&](const string &msg) {
+		std::lock_guard<std::mutex> lock(st.m);
+		st.failed = true;
+		st.error = msg;
+		st.cv.notify_all();
+	};
+	const uint32_t all = PGH_TALLY_COUNTS | PGH_TALLY_SAMPLE_MISSING | PGH_TALLY_HWE | PGH_TALLY_HWE_MIDP;
+	vector<uint32_t> part(st.missing.size());
+	for (uint64_t v0 = begin; v0 < end; v0 += window_variants) {
+		{
+			std::lock_guard<std::mutex> lock(st.m);
+			if (st.stop) {
+				return;
+			}
+		}
+		const uint32_t v1 = static_cast<uint32_t>(std::min<uint64_t>(end, v0 + window_variants));
+		char errbuf[PGH_ERRBUF_LEN] = {0};
+		pgh_dataset *win = nullptr;
+		pgh_subset *ss = nullptr;
+		pgh_tally *pass = nullptr;
+		int rc = pgh_open(path.c_str(), nullptr, static_cast<uint32_t>(v0), v1, &win, errbuf);
+		if (rc == PGH_OK && !mask.empty()) {
+			rc = pgh_subset_create(win, mask.data(), &ss, errbuf);
+		}
+		if (rc == PGH_OK) {
+			rc = pgh_tally_start(win, ss, static_cast<uint32_t>(v0), v1, all, &pass, errbuf);
+		}
+		if (rc == PGH_OK) {
+			rc = pgh_tally_wait(pass, all, static_cast<uint32_t>(v0), v1, errbuf);
+		}
+		if (rc == PGH_OK) {
+			const size_t at = v0 - begin, n = v1 - v0;
+			std::memcpy(st.counts.data() + 4 * at, pgh_tally_counts(pass), 16 * n);
+			std::memcpy(st.lnp[0].data() + at, pgh_tally_hwe_lnp(pass, 0), 8 * n);
+			std::memcpy(st.lnp[1].data() + at, pgh_tally_hwe_lnp(pass, 1), 8 * n);
+			rc = pgh_tally_sample_missing(pass, part.data(), errbuf);
+			for (size_t k = 0; rc == PGH_OK && k < part.size(); k++) {
+				st.missing[k] += part[k];
+			}
+		}
+		pgh_tally_destroy(pass);
+		pgh_subset_destroy(ss);
+		if (win) {
+			pgh_close(win);
+		}
+		if (rc != PGH_OK) {
+			fail(func_name + ": streaming variants [" + std::to_string(v0) + ", " + std::to_string(v1) + ") of '" + path +
+			     "' failed: " + errbuf);
+			return;
+		}
+		(void)sample_ct;
+		std::lock_guard<std::mutex> lock(st.m);
+		st.done_upto = v1;
+		st.cv.notify_all();
+	}
+	std::lock_guard<std::mutex> lock(st.m);
+	st.done_upto = end;
+	st.cv.notify_all();
 }
 
 DeviceTally::~DeviceTally() {
+	if (streamed_) {
+		{
+			std::lock_guard<std::mutex> lock(streamed_->m);
+			streamed_->stop = true;
+		}
+		if (streamed_->producer.joinable()) {
+			streamed_->producer.join();
+		}
+	}
 	if (handle) {
 		pgh_tally_destroy(handle); // drains the pass before the subset below goes
 	}
 }
 
 void DeviceTally::Request(uint32_t products, const string &func_name) {
+	if (streamed_) {
+		return; // a streamed pass makes every product
+	}
 	char errbuf[PGH_ERRBUF_LEN] = {0};
 	if (pgh_tally_request(handle, products, errbuf) != PGH_OK) {
 		throw IOException("%s: tally pass over variants [%u, %u) failed: %s", func_name, begin, end, string(errbuf));
 	}
+	lnp_[0] = pgh_tally_hwe_lnp(handle, 0);
+	lnp_[1] = pgh_tally_hwe_lnp(handle, 1);
 }
 
 void DeviceTally::Wait(uint32_t products, uint32_t v_begin, uint32_t v_end, const string &func_name) {
+	if (streamed_) {
+		Streamed &st = *streamed_;
+		const uint32_t need = (products & PGH_TALLY_SAMPLE_MISSING) ? end : v_end;
+		std::unique_lock<std::mutex> lock(st.m);
+		st.cv.wait(lock, [&] { return st.failed || st.done_upto >= need; });
+		if (st.failed) {
+			throw IOException("%s", st.error);
+		}
+		return;
+	}
 	char errbuf[PGH_ERRBUF_LEN] = {0};
 	if (pgh_tally_wait(handle, products, v_begin, v_end, errbuf) != PGH_OK) {
 		throw IOException("%s: PgrGetCounts failed for variants [%u, %u): %s", func_name, v_begin, v_end,
@@ -1744,10 +1879,27 @@ void DeviceTally::Wait(uint32_t products, uint32_t v_begin, uint32_t v_end, cons
 }
 
 void DeviceTally::SampleMissing(uint32_t *out, const string &func_name) {
+	if (streamed_) {
+		Wait(PGH_TALLY_SAMPLE_MISSING, begin, end, func_name);
+		std::memcpy(out, streamed_->missing.data(), sizeof(uint32_t) * streamed_->missing.size());
+		return;
+	}
 	char errbuf[PGH_ERRBUF_LEN] = {0};
 	if (pgh_tally_sample_missing(handle, out, errbuf) != PGH_OK) {
 		throw IOException("%s: PgrGetMissingness failed: %s", func_name, string(errbuf));
 	}
+}
+
+pgh_dataset *DeviceDataset::Resident(const string &func_name) const {
+	if (streamed) {
+		throw IOException("%s: '%s' does not fit the HBM budget (%.1f GB of rows, budget %.1f GB: PLINKING_HBM_CACHE_GB); "
+		                  "only the tallies of plink_freq / plink_hardy / plink_missing / read_pgen counts stream a file "
+		                  "of this size",
+		                  func_name, path,
+		                  static_cast<double>(info.raw_variant_ct) * static_cast<double>(info.record_bytes) / 1e9,
+		                  static_cast<double>(CacheBudgetBytes()) / 1e9);
+	}
+	return handle;
 }
 
 shared_ptr<DeviceTally> DeviceDataset::FindTally(const vector<uint64_t> *sample_include, uint32_t begin, uint32_t end) {
@@ -1965,7 +2117,21 @@ shared_ptr<DeviceDataset> DeviceDataset::Acquire(const string &pgen_path, const 
 	// one resident matrix on the current device, or one contiguous variant shard per listed device behind one
 	// handle: every pgh_* call the table functions make accepts either
 	int rc;
-	if (is_synth) {
+	if (!is_synth) {
+		// a file whose rows exceed the HBM budget is not made resident: its tallies stream (DeviceTally)
+		pgh_info probe;
+		if (pgh_probe(pgen_path.c_str(), nullptr, &probe, errbuf) == PGH_OK) {
+			const uint64_t pitch = (static_cast<uint64_t>(probe.record_bytes) + 127) / 128 * 128;
+			if (pitch * probe.raw_variant_ct > CacheBudgetBytes() * std::max<size_t>(1, devices.size())) {
+				ds->streamed = true;
+				ds->info = probe;
+				ds->info.variant_end = probe.raw_variant_ct;
+			}
+		}
+	}
+	if (ds->streamed) {
+		rc = PGH_OK;
+	} else if (is_synth) {
 		rc = OpenSynth(synth, devices, &ds->handle, errbuf);
 	} else {
 		rc = devices.empty() ? pgh_open(pgen_path.c_str(), nullptr, 0, UINT32_MAX, &ds->handle, errbuf)
@@ -1988,13 +2154,16 @@ shared_ptr<DeviceDataset> DeviceDataset::Acquire(const string &pgen_path, const 
 		g_cache_opened.notify_all();
 		throw IOException("%s: failed to open '%s': %s", func_name, pgen_path, string(errbuf));
 	}
-	pgh_get_info(ds->handle, &ds->info);
+	if (!ds->streamed) {
+		pgh_get_info(ds->handle, &ds->info);
+	}
 	// what the dataset holds in HBM: the 2-bit rows, and per dosage-bearing variant a presence bit and a 4-byte rank
 	// per 64 samples, 2 bytes per explicit value and up to 4 more once plink_score has built the entry records of
 	// the sparse tracks (phase tracks, two bit rows per phased variant, are not reported by pgh_get_info: not counted)
 	const uint64_t words = (static_cast<uint64_t>(ds->info.raw_sample_ct) + 63) / 64;
-	const uint64_t bytes = ds->info.pitch_bytes * (ds->info.variant_end - ds->info.variant_begin) +
-	                       12ull * words * ds->info.dosage_variant_ct + 6ull * ds->info.dosage_value_ct;
+	const uint64_t bytes = ds->streamed ? 0
+	                                    : ds->info.pitch_bytes * (ds->info.variant_end - ds->info.variant_begin) +
+	                                          12ull * words * ds->info.dosage_variant_ct + 6ull * ds->info.dosage_value_ct;
 	if (mine < g_cache.size()) {
 		g_cache[mine].ds = ds;
 		g_cache[mine].bytes = bytes;
@@ -2022,6 +2191,9 @@ shared_ptr<DeviceDataset> DeviceDataset::Acquire(const string &pgen_path, const 
 }
 
 DeviceSubset::DeviceSubset(const DeviceDataset &ds, const vector<uint64_t> &include, const string &func_name) {
+	if (ds.streamed) {
+		return; // nothing resident to stage a mask next to: the streamed pass stages it per window
+	}
 	char errbuf[PGH_ERRBUF_LEN] = {0};
 	int rc = pgh_subset_create(ds.handle, include.data(), &handle, errbuf);
 	ThrowOnPghError(rc, errbuf, func_name, "sample subset");

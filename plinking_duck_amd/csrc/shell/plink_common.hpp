@@ -266,6 +266,13 @@ public:
 	pgh_dataset *handle = nullptr;
 	pgh_info info;
 	string path;
+	//! The file's rows do not fit the HBM budget (PLINKING_HBM_CACHE_GB): nothing is resident, `handle` is null, and
+	//! the functions whose reference counterpart streams the file anyway -- plink_freq, plink_hardy, plink_missing in
+	//! both modes, read_pgen's counts / stats / filters -- get their tallies from a pass that walks the file window
+	//! by window through HBM (DeviceTally, streamed form).  Everything that needs the matrix itself (genotype output,
+	//! plink_score, plink_pca, plink_ld, read_pfile's sample orient) reports that it does not fit: Resident().
+	bool streamed = false;
+	pgh_dataset *Resident(const string &func_name) const;
 	static shared_ptr<DeviceDataset> Acquire(const string &pgen_path, const string &func_name);
 
 	//! The tally pass over [begin, end) for this sample mask (nullptr = every sample), started if nobody has one:
@@ -301,17 +308,26 @@ public:
 		return counts_[vidx - begin];
 	}
 	double LnP(uint32_t vidx, bool midp) const {
-		return pgh_tally_hwe_lnp(handle, midp ? 1u : 0u)[vidx - begin];
+		return lnp_[midp ? 1 : 0][vidx - begin];
 	}
 	void SampleMissing(uint32_t *out, const string &func_name);
 
-	pgh_tally *handle = nullptr;
+	pgh_tally *handle = nullptr; // null for the streamed form
 	uint32_t begin = 0, end = 0;
 	vector<uint64_t> mask; // empty = all samples
 
 private:
 	unique_ptr<DeviceSubset> subset_;
 	const uint32_t (*counts_)[4] = nullptr;
+	const double *lnp_[2] = {nullptr, nullptr};
+
+	// Streamed form (DeviceDataset::streamed): a producer thread opens the file window by window (pgh_open of a
+	// variant range: the ingest's 50 GB/s is the pace), runs a resident tally pass over each window with every
+	// product, keeps the results on the host and closes the window.  Scan threads wait on a condition variable
+	// for the variants they are about to emit -- the same contract as the resident form's event waits.
+	struct Streamed;
+	unique_ptr<Streamed> streamed_;
+	void RunStream(const string &path, uint32_t sample_ct, uint64_t window_variants, const string &func_name);
 };
 
 //! The extension option `plinking_devices` (next to plinking_max_threads, the reference's only option:

@@ -214,7 +214,7 @@ static void PlinkFreqScan(ClientContext &, TableFunctionInput &data_p, DataChunk
 		// PgrGetDCounts for the chunk's rows at once (src/plink_freq.cpp:475-480, :525-535)
 		vector<uint64_t> moments(3 * dosage_rows.size());
 		char errbuf[PGH_ERRBUF_LEN] = {0};
-		if (pgh_dosage_sums(gstate.scan.dataset->handle, gstate.scan.subset ? gstate.scan.subset->handle : nullptr, 0,
+		if (pgh_dosage_sums(gstate.scan.dataset->Resident("plink_freq"), gstate.scan.subset ? gstate.scan.subset->handle : nullptr, 0,
 		                    static_cast<uint32_t>(dosage_vidx.size()), dosage_vidx.data(),
 		                    reinterpret_cast<uint64_t(*)[3]>(moments.data()), errbuf) != PGH_OK) {
 			throw IOException("plink_freq: PgrGetDCounts failed for variants [%u, %u]: %s", dosage_vidx.front(),

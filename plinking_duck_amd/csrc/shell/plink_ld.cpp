@@ -244,7 +244,7 @@ static void RunPairs(PlinkLdGlobalState &gstate, PlinkLdLocalState &lstate) {
 	const size_t n = lstate.pair_a.size();
 	lstate.sums.resize(6 * n);
 	char errbuf[PGH_ERRBUF_LEN] = {0};
-	int rc = pgh_ld_pairs(gstate.dataset->handle, gstate.subset ? gstate.subset->handle : nullptr,
+	int rc = pgh_ld_pairs(gstate.dataset->Resident("plink_ld"), gstate.subset ? gstate.subset->handle : nullptr,
 	                      static_cast<uint32_t>(n), lstate.pair_a.data(), lstate.pair_b.data(),
 	                      reinterpret_cast<uint32_t(*)[6]>(lstate.sums.data()), errbuf);
 	if (rc != PGH_OK) {

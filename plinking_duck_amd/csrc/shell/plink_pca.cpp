@@ -94,6 +94,7 @@ static unique_ptr<FunctionData> PlinkPcaBind(ClientContext &context, TableFuncti
 	uint32_t range_start = c.RangeStart(), range_end = c.RangeEnd();
 	if (range_end > range_start) {
 		bind_data->dataset = DeviceDataset::Acquire(c.pgen_path, "plink_pca");
+		bind_data->dataset->Resident("plink_pca"); // the passes walk the matrix a dozen times: it has to fit
 		if (c.has_sample_subset) {
 			bind_data->subset =
 			    make_shared<DeviceSubset>(*bind_data->dataset, c.sample_subset->sample_include, "plink_pca");
@@ -222,7 +223,7 @@ static void RunAlgorithm(const PlinkPcaBindData &bind_data, PlinkPcaGlobalState 
 	}
 	const vector<double> &g1 = *g1_ptr;
 	char errbuf[PGH_ERRBUF_LEN] = {0};
-	int rc = pgh_pca(bind_data.dataset->handle, bind_data.subset ? bind_data.subset->handle : nullptr, gs.M,
+	int rc = pgh_pca(bind_data.dataset->Resident("plink_pca"), bind_data.subset ? bind_data.subset->handle : nullptr, gs.M,
 	                 bind_data.effective_variants.data(), bind_data.centers.data(), bind_data.inv_stdevs.data(),
 	                 bind_data.n_pcs, g1.data(), gs.eigenvalues.data(), gs.eigenvectors.data(), errbuf);
 	if (rc != PGH_OK) {

@@ -216,6 +216,7 @@ static unique_ptr<GlobalTableFunctionState> PlinkScoreInitGlobal(ClientContext &
 	}
 	if (need_scores && !bind_data.scored_variants.empty()) {
 		state->dataset = DeviceDataset::Acquire(bind_data.c.pgen_path, "plink_score");
+		state->dataset->Resident("plink_score");
 		if (bind_data.c.has_sample_subset) {
 			state->subset =
 			    make_uniq<DeviceSubset>(*state->dataset, bind_data.c.sample_subset->sample_include, "plink_score");
@@ -264,7 +265,7 @@ static void PlinkScoreScan(ClientContext &, TableFunctionInput &data_p, DataChun
 						}
 					}
 					char errbuf[PGH_ERRBUF_LEN] = {0};
-					int rc = pgh_score_counts(gstate.dataset->handle, gstate.subset ? gstate.subset->handle : nullptr,
+					int rc = pgh_score_counts(gstate.dataset->Resident("plink_score"), gstate.subset ? gstate.subset->handle : nullptr,
 					                   static_cast<uint32_t>(n_scored), vidx.data(), weights.data(), flip.data(), 1, mode,
 					                   counts.empty() ? nullptr : reinterpret_cast<const uint32_t(*)[4]>(counts.data()),
 					                   gstate.score_sums.data(),

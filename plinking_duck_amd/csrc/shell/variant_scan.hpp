@@ -168,7 +168,7 @@ private:
 				for (uint32_t pos = batch_begin; pos < batch_end; pos++) {
 					const uint32_t v = g.variant_list[pos];
 					list_slot[v] = pos - batch_begin;
-					int rc = pgh_counts_range(g.dataset->handle, g.subset ? g.subset->handle : nullptr, v, v + 1,
+					int rc = pgh_counts_range(g.dataset->Resident(func_name), g.subset ? g.subset->handle : nullptr, v, v + 1,
 					                          reinterpret_cast<uint32_t(*)[4]>(list_counts.data() + 4 * (pos - batch_begin)),
 					                          errbuf);
 					if (rc != PGH_OK) {

@@ -243,3 +243,31 @@ def test_score_from_a_pass_s_counts(gpu_lib, oracle):
             assert np.array_equal(a[2], b[2])
             exp = oracle.score(pg, vidx, w[:, 0], flip, name, include=include)
             assert np.allclose(b[0][:, 0], exp[0][:, 0], rtol=1e-9, atol=1e-9) and np.array_equal(b[2], exp[2])
+
+
+def test_a_file_beyond_the_hbm_budget_streams_its_tallies(gpu_lib, oracle, tmp_path, monkeypatch):
+    """A file whose rows exceed the HBM budget is not made resident: plink_freq / plink_hardy / plink_missing (both
+    modes) / read_pgen's counts get their tallies from a pass that walks the file window by window through HBM --
+    the reference's own functions stream the file too -- and everything that needs the matrix itself says that it
+    does not fit instead of failing in an allocation."""
+    L = gpu_lib
+    m, n = 6000, 2003
+    small = str(tmp_path / "fits")
+    big = str(tmp_path / "too_big")
+    L.synth_write_files(small, m, n, SEED, 0.04)
+    L.synth_write_files(big, m, n, SEED, 0.04)
+    calls = [("plink_freq", dict(counts=True)), ("plink_hardy", dict(midp=True)), ("plink_hardy", {}), ("plink_missing", {}),
+             ("plink_missing", dict(mode="sample")), ("plink_freq", dict(samples=[0, 3, 700, 2002], region="4:1-1000000")),
+             ("read_pgen", dict(genotypes="counts", af_range={"max": 0.2}))]
+    want = [F.query(fn, small + ".pgen", threads=3, **kw) for fn, kw in calls]
+    monkeypatch.setenv("PLINKING_HBM_CACHE_GB", "0.0005")  # 500 KB: windows of ~240 variants
+    passes = L.tally_passes_started()
+    for (fn, kw), w in zip(calls, want):
+        got = F.query(fn, big + ".pgen", threads=3, **kw)
+        key = lambda r: tuple(str(x) for x in r[:3])
+        assert got.names == w.names and sorted(got.rows, key=key) == sorted(w.rows, key=key), fn
+    assert L.tally_passes_started() > passes + 8  # one resident pass per window of the file
+    for fn, kw in (("plink_score", dict(weights=[0.5] * m)), ("plink_pca", dict(n_pcs=2)), ("read_pgen", dict(genotypes="list")),
+                   ("plink_ld", {})):
+        with pytest.raises(F.IOException, match="does not fit the HBM budget"):
+            F.query(fn, big + ".pgen", threads=2, **kw)
