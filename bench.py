@@ -753,9 +753,11 @@ def run_timed(W, steps, warmup, barrier):
     return time.perf_counter() - t0
 
 
-def sql_section(args, n, threads=16):
+def sql_section(args, n, expect, threads=16):
     """The same functions THROUGH THE TABLE-FUNCTION SHELLS (bind / init / scan threads, chunks drained as a
-    consumer would) over the same resident shape: what a SQL query costs, next to what the kernel costs."""
+    consumer would) over the same resident shape: what a SQL query costs, next to what the kernel costs.
+    expect: column sums of the bench's own (verified) tallies of the same seeded matrix; every function's integer
+    columns, drained through the shells, must add up to them -- a checksum of checksums over all million rows."""
     from plinking_duck_amd import functions as F
     spec = f"synth:{args.variants}x{n}:{SEED}:{MISSING_RATE}"
     rec = (n + 3) // 4
@@ -771,6 +773,18 @@ def sql_section(args, n, threads=16):
                       "scan_ms": r.timing_ms["scan"], "threads": r.threads,
                       "scan_genotypes_per_s": args.variants * n / scan_s,
                       "scan_frac_of_hbm_roofline": args.variants * rec / scan_s / 1e9 / HBM_PEAK_GBPS}
+    # the rows themselves: integer columns only (their drained checksum is the plain sum of the cells)
+    checks = [("plink_freq", {}, "OBS_CT", 2 * (expect["hom_ref"] + expect["het"] + expect["hom_alt"])),
+              ("plink_freq", {"counts": True}, "HET_CT", expect["het"]),
+              ("plink_hardy", {}, "HOM_ALT_CT", expect["hom_alt"]),
+              ("plink_missing", {}, "MISSING_CT", expect["missing"]),
+              ("plink_missing", {"mode": "sample"}, "MISSING_CT", expect["missing"])]
+    for fn, kw, col, want in checks:
+        r = F.query(fn, spec, threads=threads, drain=True, columns=[col], **kw)
+        if int(r.checksum) != int(want):
+            raise SystemExit(f"bench.py: {fn}({kw}) through the shells: sum of {col} = {r.checksum}, the tallies say {want}; "
+                             f"no line reported")
+    out["verified"] = True
     return out
 
 
@@ -858,6 +872,10 @@ def main():
     # (configs 2-5: read_pgen's unpack, the fused freq + hardy + missing pass, plink_score with 16 columns and with
     # one, plink_pca over the first 100,000 variants), each verified like its own --workload run, a few steps each.
     configs = None
+    sql_expect = None
+    if args.workload in ("freq", "fused") and m:
+        hc = W.env["h_counts"].numpy().astype(np.int64).sum(axis=0)
+        sql_expect = {"hom_ref": int(hc[0]), "het": int(hc[1]), "hom_alt": int(hc[2]), "missing": int(hc[3])}
     want_all = args.configs == "all" or (args.configs == "auto" and args.workload == "freq" and world == 1
                                          and args.variants == 1_000_000 and n == 500_000)
     if want_all and rank == 0:
@@ -891,12 +909,12 @@ def main():
         cpu = cpu_baseline(ds, n, args.cpu_seconds, args.cpu_sample_variants)
 
     sql = None
-    if want_all and rank == 0 and args.sql:
+    if want_all and rank == 0 and args.sql and sql_expect is not None:
         # through the SQL shells, over a resident source of the same shape (the bench's own matrix goes first: two
         # of them do not fit one GPU)
         ds.close()
         torch.cuda.empty_cache()
-        sql = sql_section(args, n)
+        sql = sql_section(args, n, sql_expect)
 
     if rank == 0:
         line = {

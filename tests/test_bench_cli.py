@@ -71,4 +71,5 @@ def test_all_configs_ride_the_default_line():
     assert cfg["unpack"]["roofline"]["store_ceiling"]["GB/s"] > 0
     assert "algorithmic_flops_frac_of_fp64_peak" in cfg["score16"]["roofline"]
     sql = line["sql"]
+    assert sql.pop("verified") is True
     assert len(sql) == 4 and all(v["rows"] in (30000, 20000) and v["scan_ms"] > 0 for v in sql.values())
