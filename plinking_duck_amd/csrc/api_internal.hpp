@@ -77,6 +77,7 @@ struct pgh_dataset {
 	// the group's RCCL communicators, one per shard (api_sharded.cpp: created at the first collective when the
 	// shards sit on distinct devices; an opaque pointer so that rccl.h stays out of this header)
 	mutable void *group_comms = nullptr;
+	mutable void *group_workers = nullptr; // the group's persistent per-shard worker threads (api_sharded.cpp)
 	bool IsGroup() const {
 		return !shards.empty();
 	}

@@ -153,23 +153,91 @@ const pgh_subset *PartOf(const pgh_subset *ss, size_t k) {
 	return ss ? ss->parts[k] : nullptr;
 }
 
-//! fn(k, errbuf_k) for every shard, each on its own thread and device; the first failure is reported.
+// One persistent worker thread per shard, kept in the group handle: a worker sets its shard's device once and then
+// runs what ForShards hands it, so the per-thread stream, scratch block and pinned task buffers the entry points
+// keep (api_internal.hpp: PghThreadStream / PghThreadScratch) live across calls.  (Round 2 started K fresh threads
+// per call and tore their streams and scratch down at its end: milliseconds per call, paid by every window of a
+// plink_ld scan over a group.)  Calls on one group are serialised through the pool -- the shards' devices are
+// busy with one call's work anyway.
+class ShardWorkers {
+public:
+	explicit ShardWorkers(const std::vector<int> &devices) : tasks_(devices.size()) {
+		for (size_t k = 0; k < devices.size(); k++) {
+			threads_.emplace_back([this, k, dev = devices[k]] { Loop(k, dev); });
+		}
+	}
+	~ShardWorkers() {
+		{
+			std::lock_guard<std::mutex> lock(m_);
+			stop_ = true;
+		}
+		cv_.notify_all();
+		for (auto &t : threads_) {
+			t.join();
+		}
+	}
+	//! fn(k) on worker k for every k; returns when all are done
+	void Run(const std::function<void(size_t)> &fn) {
+		std::lock_guard<std::mutex> one_call(call_m_);
+		std::unique_lock<std::mutex> lock(m_);
+		fn_ = &fn;
+		pending_ = tasks_.size();
+		tasks_.assign(tasks_.size(), 1);
+		cv_.notify_all();
+		done_cv_.wait(lock, [&] { return pending_ == 0; });
+		fn_ = nullptr;
+	}
+
+private:
+	void Loop(size_t k, int device) {
+		(void)hipSetDevice(device);
+		std::unique_lock<std::mutex> lock(m_);
+		for (;;) {
+			cv_.wait(lock, [&] { return stop_ || tasks_[k]; });
+			if (stop_) {
+				return;
+			}
+			tasks_[k] = 0;
+			const std::function<void(size_t)> *fn = fn_;
+			lock.unlock();
+			(*fn)(k);
+			lock.lock();
+			if (--pending_ == 0) {
+				done_cv_.notify_all();
+			}
+		}
+	}
+	std::mutex m_, call_m_;
+	std::condition_variable cv_, done_cv_;
+	std::vector<char> tasks_;
+	std::vector<std::thread> threads_;
+	const std::function<void(size_t)> *fn_ = nullptr;
+	size_t pending_ = 0;
+	bool stop_ = false;
+};
+
+ShardWorkers *WorkersOf(const pgh_dataset *g) {
+	static std::mutex create_mu;
+	std::lock_guard<std::mutex> lock(create_mu);
+	if (!g->group_workers) {
+		std::vector<int> devices;
+		for (const pgh_dataset *s : g->shards) {
+			devices.push_back(s->device);
+		}
+		g->group_workers = new ShardWorkers(devices);
+	}
+	return static_cast<ShardWorkers *>(g->group_workers);
+}
+
+//! fn(k, errbuf_k) for every shard, each on its shard's worker thread and device; the first failure is reported.
 int ForShards(const pgh_dataset *g, char *errbuf, const std::function<int(size_t, char *)> &fn) {
 	const size_t K = g->shards.size();
 	std::vector<int> rc(K, PGH_OK);
 	std::vector<std::array<char, PGH_ERRBUF_LEN>> eb(K);
-	std::vector<std::thread> threads;
-	threads.reserve(K);
 	for (size_t k = 0; k < K; k++) {
 		eb[k][0] = 0;
-		threads.emplace_back([&, k] {
-			DeviceScope scope(g->shards[k]->device);
-			rc[k] = fn(k, eb[k].data());
-		});
 	}
-	for (auto &t : threads) {
-		t.join();
-	}
+	WorkersOf(g)->Run([&](size_t k) { rc[k] = fn(k, eb[k].data()); });
 	for (size_t k = 0; k < K; k++) {
 		if (rc[k] != PGH_OK) {
 			SetErr(errbuf, eb[k].data());
@@ -485,6 +553,8 @@ extern "C" int pgh_group_uses_rccl(const pgh_dataset *ds) {
 namespace pgh_group {
 
 void Close(pgh_dataset *g) {
+	delete static_cast<ShardWorkers *>(g->group_workers); // (joins the workers: their streams and scratch go with them)
+	g->group_workers = nullptr;
 	DestroyComms(g);
 	for (pgh_dataset *s : g->shards) {
 		pgh_close(s);
@@ -1088,11 +1158,17 @@ int LdPairs(const pgh_dataset *g, const pgh_subset *ss, uint32_t n_pairs, const 
 	need.erase(std::unique(need.begin(), need.end()), need.end());
 	const size_t rb = g->record_bytes;
 	std::vector<uint8_t> host(need.size() * rb);
-	for (size_t i = 0; i < need.size(); i++) {
-		rc = CopyRowsToHost(g, need[i], need[i] + 1, host.data() + i * rb, rb, errbuf);
+	for (size_t i = 0; i < need.size();) {
+		// (runs of consecutive rows -- a window's anchors and partners mostly are -- in one copy each)
+		size_t j = i + 1;
+		while (j < need.size() && need[j] == need[j - 1] + 1 && ShardOf(g, need[j]) == ShardOf(g, need[i])) {
+			j++;
+		}
+		rc = CopyRowsToHost(g, need[i], need[j - 1] + 1, host.data() + i * rb, rb, errbuf);
 		if (rc != PGH_OK) {
 			return rc;
 		}
+		i = j;
 	}
 	DeviceScope scope(g->shards[0]->device);
 	pgh_dataset *scratch = nullptr;
