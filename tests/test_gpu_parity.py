@@ -593,6 +593,28 @@ def test_full_size_matrix_properties(gpu_lib):
     for r in range(8):
         row = np.where(geno[r] == -9, 3, geno[r])
         assert [int((row == c).sum()) for c in range(4)] == [int(x) for x in counts[cut + r]]
+    # ("rows add up to N" holds by construction -- hom-ref is N minus the rest -- so:) 300 random rows copied back from
+    # HBM and tallied by the oracle's scan, bit-exact; 40 of them decoded by the oracle against the unpack kernel
+    from oracle import oracle
+    rng = np.random.default_rng(99)
+    picks = np.sort(rng.choice(m, size=300, replace=False))
+    rows = np.concatenate([ds.copy_rows_to_host(int(v), int(v) + 1) for v in picks])
+    head = bytes([0x6c, 0x1b, 0x02]) + len(picks).to_bytes(4, "little") + n.to_bytes(4, "little") + bytes([0x40])
+    pg = oracle.Pgen(mem=np.concatenate([np.frombuffer(head, dtype=np.uint8), rows.reshape(-1)]))
+    assert np.array_equal(pg.scan_counts_mt(0, len(picks), 8), counts[picks])
+    for i in range(0, 300, 8):
+        g, _ = ds.unpack_range(int(picks[i]), int(picks[i]) + 1)
+        assert np.array_equal(g[0], pg.geno(i))
+    # the tally pass the SQL functions share, at full size (eight 131,072-variant batches): every product
+    t = gpu_lib.TallyPass(ds, products=gpu_lib.TALLY_SAMPLE_MISSING | gpu_lib.TALLY_HWE)
+    assert np.array_equal(t.counts(), counts)
+    assert np.array_equal(t.sample_missing(), miss)
+    lnp = t.hwe_lnp(False)
+    assert np.array_equal(lnp[picks], gpu_lib.hwe_lnp_batch(counts[picks], False))
+    for v in picks[:12]:
+        c = counts[v]
+        assert lnp[v] == pytest.approx(oracle.hwe_lnp(int(c[1]), int(c[0]), int(c[2]), False), abs=1e-6)
+    t.close()
 
 
 def test_hwe_xchr_batch_matches_host_and_oracle(gpu_lib, oracle):
