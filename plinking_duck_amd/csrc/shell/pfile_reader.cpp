@@ -335,9 +335,9 @@ static unique_ptr<FunctionData> PfileBind(ClientContext &context, TableFunctionB
 			}
 			same_samples(have, want, src);
 			if (i && check_iids) {
-				CheckIdenticalSamples(bind_data->sources[0].variant_bind->Cast<PgenBindData>().c.sample_info,
+				CheckIdenticalSamples(bind_data->sources[0].variant_bind->Cast<PgenBindData>().c.sample_info(),
 				                      bind_data->sources[0].pgen_path,
-				                      src.variant_bind->Cast<PgenBindData>().c.sample_info, src.pgen_path);
+				                      src.variant_bind->Cast<PgenBindData>().c.sample_info(), src.pgen_path);
 			}
 		}
 		return std::move(bind_data);
@@ -376,7 +376,7 @@ static unique_ptr<FunctionData> PfileBind(ClientContext &context, TableFunctionB
 		src.c.Bind(context, src.inner, "read_pfile", i == 0);
 		same_samples(src.c.raw_sample_ct, bind_data->sources[0].c.raw_sample_ct, src);
 		if (i && check_iids) {
-			CheckIdenticalSamples(bind_data->sources[0].c.sample_info, bind_data->sources[0].pgen_path, src.c.sample_info,
+			CheckIdenticalSamples(bind_data->sources[0].c.sample_info(), bind_data->sources[0].pgen_path, src.c.sample_info(),
 			                      src.pgen_path);
 		}
 		total_variants += src.c.raw_variant_ct;
@@ -514,8 +514,8 @@ static unique_ptr<FunctionData> PfileBind(ClientContext &context, TableFunctionB
 			names = {"CHROM", "POS", "ID", "REF", "ALT"};
 			return_types = {LogicalType::VARCHAR, LogicalType::INTEGER, LogicalType::VARCHAR, LogicalType::VARCHAR,
 			                LogicalType::VARCHAR};
-			for (idx_t i = 0; i < c.sample_info.column_names.size(); i++) {
-				const string &name = c.sample_info.column_names[i];
+			for (idx_t i = 0; i < c.sample_info().column_names.size(); i++) {
+				const string &name = c.sample_info().column_names[i];
 				names.push_back(name);
 				if (name == "SEX") {
 					return_types.push_back(LogicalType::INTEGER);
@@ -551,8 +551,8 @@ static unique_ptr<FunctionData> PfileBind(ClientContext &context, TableFunctionB
 		}
 	}
 	// schema: every psam column of source 0 (SEX is INTEGER, the rest VARCHAR), then the genotypes
-	for (idx_t i = 0; i < c.sample_info.column_names.size(); i++) {
-		const string &name = c.sample_info.column_names[i];
+	for (idx_t i = 0; i < c.sample_info().column_names.size(); i++) {
+		const string &name = c.sample_info().column_names[i];
 		names.push_back(name);
 		if (name == "SEX") {
 			return_types.push_back(LogicalType::INTEGER);
@@ -822,7 +822,7 @@ static void RunSamplePhase1(const PfileBindData &bind_data, PfileGlobalState &gs
 //! FillSampleMetadataValue (src/pfile_reader.cpp:2846-2885): SEX is an integer with 0 / NA -> NULL,
 //! PAT / MAT "0" -> NULL, the usual missing tokens -> NULL.
 static void PutSampleField(const PfileBindData &bind_data, idx_t psam_col, uint32_t sample, Vector &vec, idx_t r) {
-	const auto &fields = bind_data.sources[0].c.sample_info.rows[sample];
+	const auto &fields = bind_data.sources[0].c.sample_info().rows[sample];
 	const string val = psam_col < fields.size() ? fields[psam_col] : string();
 	if (psam_col == bind_data.sex_col) {
 		char *end = nullptr;
@@ -997,7 +997,7 @@ static void PfileScan(ClientContext &context, TableFunctionInput &data_p, DataCh
 			gstate.phase1_done = true;
 		}
 	}
-	const auto &info = bind_data.sources[0].c.sample_info;
+	const auto &info = bind_data.sources[0].c.sample_info();
 	const uint32_t total = gstate.use_keep ? static_cast<uint32_t>(gstate.keep.size())
 	                                       : static_cast<uint32_t>(bind_data.output_samples.size());
 	// a run of output rows per call, one loop per projected column

@@ -131,7 +131,7 @@ unique_ptr<FunctionData> PgenBindNamed(ClientContext &context, TableFunctionBind
 		// the subset is a mask, so fields come out in ascending file order whatever order was asked for
 		for (uint32_t s = 0; s < c.raw_sample_ct; s++) {
 			if (!c.has_sample_subset || ((c.sample_subset->sample_include[s >> 6] >> (s & 63)) & 1ull)) {
-				bind_data->genotype_column_names.push_back(c.sample_info.iids[s]);
+				bind_data->genotype_column_names.push_back(c.sample_info().iids[s]);
 			}
 		}
 	}

@@ -730,6 +730,8 @@ VariantMetadataIndex LoadVariantMetadata(ClientContext &, const string &path, co
 // ---------------------------------------------------------------------------
 
 void SampleInfo::EnsureIidMap(const string &source_label) {
+	static std::mutex build_mutex; // the object may be the cache's shared one: one builder, then read-only
+	std::lock_guard<std::mutex> lock(build_mutex);
 	if (!iid_to_idx.empty() || iids.empty()) {
 		return;
 	}
@@ -744,7 +746,48 @@ static bool IsMissingValue(const string &s) {
 	return s.empty() || s == "NA" || s == "na" || s == "." || s == "-9" || s == "nan" || s == "NaN";
 }
 
-SampleInfo LoadSampleMetadata(ClientContext &, const string &path) {
+static SampleInfo ParseSampleMetadata(const string &path);
+
+namespace {
+struct PsamCacheEntry {
+	string path;
+	int64_t mtime_ns = 0, size = 0;
+	shared_ptr<const SampleInfo> info;
+};
+std::mutex g_psam_cache_mutex;
+vector<PsamCacheEntry> g_psam_cache; // most recently used last
+} // namespace
+
+shared_ptr<const SampleInfo> LoadSampleMetadata(ClientContext &, const string &path) {
+	struct stat st;
+	SynthSpec synth;
+	const bool is_synth = ParseSynthPath(path, synth);
+	const bool have_stat = !is_synth && ::stat(path.c_str(), &st) == 0;
+	const int64_t mtime_ns = have_stat ? static_cast<int64_t>(st.st_mtim.tv_sec) * 1000000000LL + st.st_mtim.tv_nsec : 0;
+	const int64_t size = have_stat ? static_cast<int64_t>(st.st_size) : -1;
+	if (have_stat || is_synth) {
+		std::lock_guard<std::mutex> lock(g_psam_cache_mutex);
+		for (size_t i = 0; i < g_psam_cache.size(); i++) {
+			if (g_psam_cache[i].path == path && g_psam_cache[i].mtime_ns == mtime_ns && g_psam_cache[i].size == size) {
+				PsamCacheEntry hit = g_psam_cache[i];
+				g_psam_cache.erase(g_psam_cache.begin() + static_cast<std::ptrdiff_t>(i));
+				g_psam_cache.push_back(hit);
+				return hit.info;
+			}
+		}
+	}
+	auto parsed = make_shared<SampleInfo>(ParseSampleMetadata(path)); // outside the lock
+	if (have_stat || is_synth) {
+		std::lock_guard<std::mutex> lock(g_psam_cache_mutex);
+		g_psam_cache.push_back(PsamCacheEntry {path, mtime_ns, size, parsed});
+		if (g_psam_cache.size() > kPvarCacheEntries) {
+			g_psam_cache.erase(g_psam_cache.begin());
+		}
+	}
+	return parsed;
+}
+
+static SampleInfo ParseSampleMetadata(const string &path) {
 	SynthSpec synth;
 	if (ParseSynthPath(path, synth)) {
 		// '#FID IID SEX' rows of WriteSynthCompanions: F<s/4>, S<s>, 1 + (s & 1)

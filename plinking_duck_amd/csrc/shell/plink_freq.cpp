@@ -61,7 +61,7 @@ static unique_ptr<FunctionData> PlinkFreqBind(ClientContext &context, TableFunct
 	}
 	bind_data->par_bounds = ResolveParBounds(build_str, "plink_freq");
 	bind_data->c.Bind(context, input, "plink_freq", false);
-	bind_data->have_sex = bind_data->c.has_sample_info && !bind_data->c.sample_info.sexes.empty();
+	bind_data->have_sex = bind_data->c.has_sample_info && !bind_data->c.sample_info().sexes.empty();
 	bind_data->ploidy = PloidyMap(bind_data->c.variants, bind_data->par_bounds);
 
 	names = {"CHROM", "POS", "ID", "REF", "ALT", "ALT_FREQ", "OBS_CT"};
@@ -110,7 +110,7 @@ static unique_ptr<GlobalTableFunctionState> PlinkFreqInitGlobal(ClientContext &c
 		// subset the same pass tallies missing calls per sample too, so plink_hardy / plink_missing on this file
 		// need no pass of their own (the reference scans three times: src/plink_freq.cpp:482,
 		// src/plink_hardy.cpp:510, src/plink_missing.cpp:479,593-609)
-		state->scan.StartTallies(bind_data.c.sample_subset.get(), bind_data.have_sex ? &bind_data.c.sample_info : nullptr,
+		state->scan.StartTallies(bind_data.c.sample_subset.get(), bind_data.have_sex ? &bind_data.c.sample_info() : nullptr,
 		                         bind_data.c.raw_sample_ct, &bind_data.ploidy,
 		                         bind_data.c.has_sample_subset ? 0u : static_cast<uint32_t>(PGH_TALLY_SAMPLE_MISSING), false,
 		                         GetPlinkingTallyCache(context), "plink_freq");

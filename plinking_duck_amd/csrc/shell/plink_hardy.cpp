@@ -70,7 +70,7 @@ static unique_ptr<FunctionData> PlinkHardyBind(ClientContext &context, TableFunc
 	}
 	bind_data->par_bounds = ResolveParBounds(build_str, "plink_hardy");
 	bind_data->c.Bind(context, input, "plink_hardy", false);
-	bind_data->have_sex = bind_data->c.has_sample_info && !bind_data->c.sample_info.sexes.empty();
+	bind_data->have_sex = bind_data->c.has_sample_info && !bind_data->c.sample_info().sexes.empty();
 	bind_data->ploidy = PloidyMap(bind_data->c.variants, bind_data->par_bounds);
 	names = {"CHROM", "POS", "ID", "REF", "ALT", "A1", "HOM_REF_CT", "HET_CT", "HOM_ALT_CT", "O_HET", "E_HET", "P_HWE"};
 	return_types = {LogicalType::VARCHAR, LogicalType::INTEGER, LogicalType::VARCHAR, LogicalType::VARCHAR,
@@ -105,7 +105,7 @@ static unique_ptr<GlobalTableFunctionState> PlinkHardyInitGlobal(ClientContext &
 		if (state->need_p_hwe) {
 			products |= bind_data.midp ? PGH_TALLY_HWE_MIDP : PGH_TALLY_HWE;
 		}
-		state->scan.StartTallies(bind_data.c.sample_subset.get(), bind_data.have_sex ? &bind_data.c.sample_info : nullptr,
+		state->scan.StartTallies(bind_data.c.sample_subset.get(), bind_data.have_sex ? &bind_data.c.sample_info() : nullptr,
 		                         bind_data.c.raw_sample_ct, &bind_data.ploidy, products, false,
 		                         GetPlinkingTallyCache(context), "plink_hardy");
 	}

@@ -194,7 +194,7 @@ static void PlinkMissingScanSample(const PlinkMissingBindData &bind_data, PlinkM
 		auto &vec = output.data[out_col];
 		if (file_col == SCOL_FID || file_col == SCOL_IID) {
 			for (idx_t r = 0; r < n_rows; r++) {
-				FillSampleIdColumn(bind_data.c.sample_info, file_col == SCOL_FID, file_index(r), vec, r);
+				FillSampleIdColumn(bind_data.c.sample_info(), file_col == SCOL_FID, file_index(r), vec, r);
 			}
 		} else if (file_col == SCOL_F_MISS) {
 			auto *dst = FlatVector::GetData<double>(vec);

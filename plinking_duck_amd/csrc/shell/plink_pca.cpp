@@ -256,7 +256,7 @@ static void PlinkPcaScan(ClientContext &, TableFunctionInput &data_p, DataChunk 
 			auto &vec = output.data[out_col];
 			if (file_col < SCOL_PC_START) {
 				for (idx_t r = 0; r < rows_emitted; r++) {
-					FillSampleIdColumn(bind_data.c.sample_info, file_col == SCOL_FID,
+					FillSampleIdColumn(bind_data.c.sample_info(), file_col == SCOL_FID,
 					                   bind_data.sample_output_order[first + r], vec, r, false);
 				}
 			} else if (file_col < SCOL_PC_START + bind_data.n_pcs) {
@@ -300,14 +300,14 @@ static void PlinkPcaScan(ClientContext &, TableFunctionInput &data_p, DataChunk 
 	} else {
 		// 'both': one row {EIGENVEC: LIST(STRUCT(FID, IID, PC1..)), EIGENVAL: LIST(DOUBLE)}
 		if (gs.next_emit_idx.fetch_add(1) == 0) {
-			const bool has_fid = !bind_data.c.sample_info.fids.empty();
+			const bool has_fid = !bind_data.c.sample_info().fids.empty();
 			vector<Value> eigenvec_entries;
 			for (uint32_t sidx = 0; sidx < gs.N; sidx++) {
 				uint32_t orig_idx = bind_data.sample_output_order[sidx];
 				vector<std::pair<string, Value>> fields;
-				fields.emplace_back("FID", has_fid ? Value::VARCHAR(bind_data.c.sample_info.fids[orig_idx])
+				fields.emplace_back("FID", has_fid ? Value::VARCHAR(bind_data.c.sample_info().fids[orig_idx])
 				                                   : Value(LogicalType::VARCHAR));
-				fields.emplace_back("IID", Value::VARCHAR(bind_data.c.sample_info.iids[orig_idx]));
+				fields.emplace_back("IID", Value::VARCHAR(bind_data.c.sample_info().iids[orig_idx]));
 				for (uint32_t pc = 0; pc < gs.n_pcs; pc++) {
 					fields.emplace_back("PC" + std::to_string(pc + 1),
 					                    Value::DOUBLE(gs.eigenvectors[static_cast<size_t>(sidx) * gs.n_pcs + pc]));

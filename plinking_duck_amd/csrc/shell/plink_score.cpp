@@ -294,7 +294,7 @@ static void PlinkScoreScan(ClientContext &, TableFunctionInput &data_p, DataChun
 		auto &vec = output.data[out_col];
 		if (file_col == COL_FID || file_col == COL_IID) {
 			for (idx_t r = 0; r < n_rows; r++) {
-				FillSampleIdColumn(bind_data.c.sample_info, file_col == COL_FID, bind_data.sample_output_order[first + r],
+				FillSampleIdColumn(bind_data.c.sample_info(), file_col == COL_FID, bind_data.sample_output_order[first + r],
 				                   vec, r, false);
 			}
 		} else if (file_col == COL_ALLELE_CT || file_col == COL_DENOM) {

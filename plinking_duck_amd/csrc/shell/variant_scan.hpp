@@ -235,7 +235,10 @@ inline void FillSampleIdColumn(const SampleInfo &info, bool fid, uint32_t file_i
 struct PgenBindCommon {
 	string pgen_path, pvar_path, psam_path;
 	VariantMetadataIndex variants;
-	SampleInfo sample_info;
+	shared_ptr<const SampleInfo> sample_info_ptr = make_shared<SampleInfo>(); // shared with the process-wide cache
+	const SampleInfo &sample_info() const {
+		return *sample_info_ptr;
+	}
 	bool has_sample_info = false;
 	uint32_t raw_variant_ct = 0, raw_sample_ct = 0;
 	bool file_has_dosage = false, file_has_phase = false;
@@ -285,20 +288,20 @@ struct PgenBindCommon {
 			                            static_cast<unsigned long long>(variants.variant_ct));
 		}
 		if (!psam_path.empty()) {
-			sample_info = LoadSampleMetadata(context, psam_path);
+			sample_info_ptr = LoadSampleMetadata(context, psam_path);
 			has_sample_info = true;
-			if (static_cast<uint32_t>(sample_info.sample_ct) != raw_sample_ct) {
+			if (static_cast<uint32_t>(sample_info().sample_ct) != raw_sample_ct) {
 				throw InvalidInputException("%s: sample count mismatch: .pgen has %u samples, "
 				                            ".psam/.fam '%s' has %llu samples",
 				                            func_name, raw_sample_ct, psam_path,
-				                            static_cast<unsigned long long>(sample_info.sample_ct));
+				                            static_cast<unsigned long long>(sample_info().sample_ct));
 			}
 		}
 		effective_sample_ct = raw_sample_ct;
 		auto samples_it = input.named_parameters.find("samples");
 		if (samples_it != input.named_parameters.end()) {
 			auto indices = ResolveSampleIndices(samples_it->second, raw_sample_ct,
-			                                    has_sample_info ? &sample_info : nullptr, func_name);
+			                                    has_sample_info ? &sample_info() : nullptr, func_name);
 			sample_subset = make_uniq<SampleSubset>(BuildSampleSubset(raw_sample_ct, indices));
 			has_sample_subset = true;
 			effective_sample_ct = sample_subset->subset_sample_ct;
