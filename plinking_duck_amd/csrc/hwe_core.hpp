@@ -114,13 +114,21 @@ PGH_HD inline double HweLnP(int32_t obs_hets, int32_t obs_hom1, int32_t obs_hom2
 		tail = 1.0;
 		ties = 1.0 >= lo ? 1.0 : 0.0;
 	}
+	// The two long walks advance numerator and denominator of the step ratio by their (exact, integer-valued)
+	// differences instead of recomputing the products: up,  A = 4 hr hc -> A - S, S = 4 (hr + hc) - 4 -> S - 8 and
+	// B = (k+2)(k+1) -> B + T, T = 4 k + 10 -> T + 8; down, C = k (k-1) -> C - U, U = 4 k - 6 -> U - 8 and
+	// D = 4 (hr+1)(hc+1) -> D + V, V = 4 (hr + hc) + 12 -> V + 8.  Four additions per step where there were three
+	// updates, three multiplications and two additions; every value stays an integer below 2^53.
 	{
-		double p = 1.0, k = kd0, hr = hr0, hc = hc0;
+		double p = 1.0;
+		double a = 4.0 * hr0 * hc0, s_ = 4.0 * (hr0 + hc0) - 4.0;
+		double b = (kd0 + 2.0) * (kd0 + 1.0), t_ = 4.0 * kd0 + 10.0;
 		for (int64_t it = (rare - mode) >> 1; it > 0; it--) {
-			p *= HweRatio(4.0 * hr * hc, (k + 2.0) * (k + 1.0));
-			k += 2.0;
-			hr -= 1.0;
-			hc -= 1.0;
+			p *= HweRatio(a, b);
+			a -= s_;
+			s_ -= 8.0;
+			b += t_;
+			t_ += 8.0;
 			total += p;
 			if (p <= hi) {
 				tail += p;
@@ -134,12 +142,15 @@ PGH_HD inline double HweLnP(int32_t obs_hets, int32_t obs_hom1, int32_t obs_hom2
 		}
 	}
 	{
-		double p = 1.0, k = kd0, hr = hr0, hc = hc0;
+		double p = 1.0;
+		double c = kd0 * (kd0 - 1.0), u_ = 4.0 * kd0 - 6.0;
+		double d = 4.0 * (hr0 + 1.0) * (hc0 + 1.0), v_ = 4.0 * (hr0 + hc0) + 12.0;
 		for (int64_t it = mode >> 1; it > 0; it--) {
-			p *= HweRatio(k * (k - 1.0), 4.0 * (hr + 1.0) * (hc + 1.0));
-			k -= 2.0;
-			hr += 1.0;
-			hc += 1.0;
+			p *= HweRatio(c, d);
+			c -= u_;
+			u_ -= 8.0;
+			d += v_;
+			v_ += 8.0;
 			total += p;
 			if (p <= hi) {
 				tail += p;
