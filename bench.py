@@ -860,6 +860,8 @@ def main():
 
     kernel_ms = [a.elapsed_time(b) for a, b in W.kernel_events]
     kern_avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+    if os.environ.get("PGH_BENCH_STEP_TIMES"):  # every timed launch, for a look at drift across the steps
+        print("step kernel ms:", " ".join(f"{t:.1f}" for t in kernel_ms), file=sys.stderr, flush=True)
     total_units = sharding.total_variants(world, args.variants, args.scaling) * n
     if args.workload == "ld":
         total_units = W.units_per_step * (world if args.scaling == "weak" else 1)  # sample pairs, every rank the same shape

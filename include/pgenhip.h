@@ -246,6 +246,14 @@ uint64_t pgh_tally_passes_started(void);
 int pgh_host_alloc(size_t bytes, void **out, char *errbuf);
 void pgh_host_free(void *p);
 
+/* Call-scoped device work blocks of 64 MB and more (plink_pca's transposed and tile-major matrices, wide score
+ * outputs) are kept on a per-device free list between calls instead of going back to the driver -- hipMalloc of
+ * tens of gigabytes costs seconds once a process has done it a few times.  The list holds at
+ * most PGH_BLOCK_CACHE_GB (environment, default 64, 0 = keep nothing) per device, is emptied by pgh_close and
+ * whenever an allocation of the library fails, and by this call: a host that wants the memory back for its own
+ * allocations right now.  No reference counterpart (the reference allocates no device memory). */
+void pgh_trim_device_cache(void);
+
 /* PgrGet + GenoarrToBytesMinus9 over a variant range (src/pgen_reader.cpp:727-733)
  * plus the validity fill of the ARRAY/LIST child (src/pgen_reader.cpp:1009-1047).
  * out: int8 [v_end-v_begin][n_out] with n_out = subset size or N; a missing call is

@@ -578,13 +578,13 @@ static int EnsureDosageRecords(const pgh_dataset *ds, hipStream_t st, char *errb
 	}
 	uint32_t *d_rec = nullptr, *d_row_variant = nullptr;
 	uint64_t *d_off = nullptr;
-	if (hipMalloc(reinterpret_cast<void **>(&d_rec), 4ull * off[rows] + 64) != hipSuccess) {
+	if (PghMalloc(reinterpret_cast<void **>(&d_rec), 4ull * off[rows] + 64) != hipSuccess) {
 		(void)hipGetLastError(); // no room: not an error
 		return PGH_OK;
 	}
-	hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_off), 8ull * (rows + 1));
+	hipError_t e = PghMalloc(reinterpret_cast<void **>(&d_off), 8ull * (rows + 1));
 	if (e == hipSuccess) {
-		e = hipMalloc(reinterpret_cast<void **>(&d_row_variant), 4ull * rows);
+		e = PghMalloc(reinterpret_cast<void **>(&d_row_variant), 4ull * rows);
 	}
 	if (e == hipSuccess) {
 		e = hipMemcpyAsync(d_off, off.data(), 8ull * (rows + 1), hipMemcpyHostToDevice, st);
@@ -771,18 +771,18 @@ static int ScorePlanCreate(const pgh_dataset *ds, const pgh_subset *subset, uint
 		const uint32_t n_dos = n_scored - n_hard;
 		hipStream_t st = PghThreadStream();
 		HostSourceFence fence(st); // p_local / p_weights / p_flip feed asynchronous uploads
-		PGH_HIP(hipMalloc(&plan->d_vlist, sizeof(uint32_t) * n_scored), "hipMalloc(score)");
-		PGH_HIP(hipMalloc(&plan->d_weights, sizeof(double) * n_scored * n_cols), "hipMalloc(score)");
-		PGH_HIP(hipMalloc(&plan->d_counts, 24ull * n_scored), "hipMalloc(score)"); // counts[4] u32, or dosage sums[3] u64
-		PGH_HIP(hipMalloc(&plan->d_ts, 32ull * n_scored), "hipMalloc(score)");
-		PGH_HIP(hipMalloc(&plan->d_td, 32ull * n_scored), "hipMalloc(score)");
-		PGH_HIP(hipMalloc(&plan->d_ac, 4ull * n_scored), "hipMalloc(score)");
+		PGH_HIP(PghMalloc(&plan->d_vlist, sizeof(uint32_t) * n_scored), "hipMalloc(score)");
+		PGH_HIP(PghMalloc(&plan->d_weights, sizeof(double) * n_scored * n_cols), "hipMalloc(score)");
+		PGH_HIP(PghMalloc(&plan->d_counts, 24ull * n_scored), "hipMalloc(score)"); // counts[4] u32, or dosage sums[3] u64
+		PGH_HIP(PghMalloc(&plan->d_ts, 32ull * n_scored), "hipMalloc(score)");
+		PGH_HIP(PghMalloc(&plan->d_td, 32ull * n_scored), "hipMalloc(score)");
+		PGH_HIP(PghMalloc(&plan->d_ac, 4ull * n_scored), "hipMalloc(score)");
 		PGH_HIP(hipMemcpyAsync(plan->d_vlist, up_local, sizeof(uint32_t) * n_scored, hipMemcpyHostToDevice, st),
 		        "score upload");
 		PGH_HIP(hipMemcpyAsync(plan->d_weights, up_weights, sizeof(double) * n_scored * n_cols, hipMemcpyHostToDevice, st),
 		        "score upload");
 		if (flip) {
-			PGH_HIP(hipMalloc(&plan->d_flip, n_scored), "hipMalloc(score)");
+			PGH_HIP(PghMalloc(&plan->d_flip, n_scored), "hipMalloc(score)");
 			PGH_HIP(hipMemcpyAsync(plan->d_flip, up_flip, n_scored, hipMemcpyHostToDevice, st), "score upload");
 		}
 		// per-variant statistics and contribution tables depend on the data only: once per plan
@@ -802,7 +802,7 @@ static int ScorePlanCreate(const pgh_dataset *ds, const pgh_subset *subset, uint
 			        "score table kernel");
 		}
 		if (n_dos) {
-			PGH_HIP(hipMalloc(&plan->d_lin, 32ull * n_dos), "hipMalloc(score)");
+			PGH_HIP(PghMalloc(&plan->d_lin, 32ull * n_dos), "hipMalloc(score)");
 			uint64_t *sums = reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(plan->d_counts) + 16ull * n_hard);
 			PGH_HIP(pgh::LaunchDosageSums(ds->View(), ds->Dosage(), 0, vlist + n_hard, n_dos,
 			                              subset ? subset->d_include : nullptr, sums, st),
@@ -837,11 +837,10 @@ static int ScorePlanCreate(const pgh_dataset *ds, const pgh_subset *subset, uint
 			const char *tiles_env = std::getenv("PGH_SCORE_TILES"); // A/B switch
 			if (keep_tiles && !(tiles_env && *tiles_env == '0') &&
 			    pgh::ScoreI8UsesTiles(std::min(pgh::kI8MaxCols, n_cols), true)) {
-				size_t free_b = 0, total_b = 0;
-				(void)hipMemGetInfo(&free_b, &total_b);
+				const size_t free_b = PghDeviceFreeBytes();
 				const size_t need = pgh::ScoreI8TiledBytes(plan->n_table, N);
 				if (free_b > need + (8ull << 30)) {
-					PGH_HIP(hipMalloc(&plan->d_tiles, need), "hipMalloc(score tiles)");
+					PGH_HIP(PghMalloc(&plan->d_tiles, need), "hipMalloc(score tiles)");
 					PGH_HIP(pgh::LaunchScoreI8TileMajor(ds->View(), vlist, plan->n_table, static_cast<uint8_t *>(plan->d_tiles), st),
 					        "score tiles");
 				}
@@ -852,10 +851,10 @@ static int ScorePlanCreate(const pgh_dataset *ds, const pgh_subset *subset, uint
 				pass.c0 = c0;
 				pass.n_cols = std::min(pgh::kI8MaxCols, n_cols - c0);
 				const pgh::ScoreI8Sizes z = pgh::ScoreI8Bytes(plan->n_table, pass.n_cols, true);
-				PGH_HIP(hipMalloc(&pass.d_bmat, z.bmat), "hipMalloc(score digits)");
-				PGH_HIP(hipMalloc(&pass.d_rowidx, z.rowidx), "hipMalloc(score digits)");
-				PGH_HIP(hipMalloc(&pass.d_cols, z.cols), "hipMalloc(score digits)");
-				PGH_HIP(hipMalloc(&pass.d_small, z.small), "hipMalloc(score digits)");
+				PGH_HIP(PghMalloc(&pass.d_bmat, z.bmat), "hipMalloc(score digits)");
+				PGH_HIP(PghMalloc(&pass.d_rowidx, z.rowidx), "hipMalloc(score digits)");
+				PGH_HIP(PghMalloc(&pass.d_cols, z.cols), "hipMalloc(score digits)");
+				PGH_HIP(PghMalloc(&pass.d_small, z.small), "hipMalloc(score digits)");
 				pass.buf.bmat = static_cast<int8_t *>(pass.d_bmat);
 				pass.buf.rowidx = static_cast<uint32_t *>(pass.d_rowidx);
 				pass.buf.mult = static_cast<double *>(pass.d_cols);
@@ -873,7 +872,7 @@ static int ScorePlanCreate(const pgh_dataset *ds, const pgh_subset *subset, uint
 		}
 		if (!special.empty()) {
 			plan->n_special = static_cast<uint32_t>(special.size());
-			PGH_HIP(hipMalloc(&plan->d_special, sizeof(pgh::ScoreSpecial) * special.size()), "hipMalloc(score)");
+			PGH_HIP(PghMalloc(&plan->d_special, sizeof(pgh::ScoreSpecial) * special.size()), "hipMalloc(score)");
 			PGH_HIP(hipMemcpyAsync(plan->d_special, special.data(), sizeof(pgh::ScoreSpecial) * special.size(),
 			                       hipMemcpyHostToDevice, st),
 			        "score upload");
@@ -1267,8 +1266,7 @@ extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, 
 			const bool want_tiles = !(tiles_env && *tiles_env == '0');
 			const bool step_tiles = pgh::ScoreI8UsesTiles(std::min(pgh::kI8MaxColsBare, k2), false);
 			const bool final_tiles = pgh::ScoreI8UsesTiles(std::min<uint32_t>(pgh::kI8MaxColsBare, qq), false);
-			size_t free_b = 0, total_b = 0;
-			(void)hipMemGetInfo(&free_b, &total_b);
+			const size_t free_b = PghDeviceFreeBytes();
 			const size_t need_x = pgh::ScoreI8TiledBytes(M, N), need_xt = pgh::ScoreI8TiledBytes(N, M);
 			if (want_tiles && (step_tiles || final_tiles) && free_b > need_x + need_xt + (2ull << 30)) {
 				PGH_HIP(d_tiles_x.Alloc(need_x), "hipMalloc(pca tiles)");
@@ -1594,9 +1592,9 @@ extern "C" int pgh_ld_pairs_dev(const pgh_dataset *ds, const pgh_subset *subset,
 		buf.Release();
 		buf.device = ds->device;
 		const size_t cap = std::max<size_t>(2 * need, 64u << 10);
-		PGH_HIP(hipMalloc(&buf.d, cap), "hipMalloc(ld tasks)");
+		PGH_HIP(PghMalloc(&buf.d, cap), "hipMalloc(ld tasks)");
 		PGH_HIP(hipHostMalloc(&buf.h, cap, hipHostMallocDefault), "hipHostMalloc(ld tasks)");
-		PGH_HIP(hipMalloc(reinterpret_cast<void **>(&buf.d_bad), sizeof(uint32_t)), "hipMalloc(ld tasks)");
+		PGH_HIP(PghMalloc(reinterpret_cast<void **>(&buf.d_bad), sizeof(uint32_t)), "hipMalloc(ld tasks)");
 		PGH_HIP(hipHostMalloc(reinterpret_cast<void **>(&buf.h_bad), sizeof(uint32_t), hipHostMallocDefault),
 		        "hipHostMalloc(ld tasks)");
 		PGH_HIP(hipEventCreateWithFlags(&buf.done, hipEventDisableTiming), "ld task event");

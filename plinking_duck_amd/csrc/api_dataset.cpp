@@ -61,7 +61,7 @@ hipError_t PghThreadScratch(size_t bytes, hipStream_t st, void **out) {
 		slot->bytes = 0;
 	}
 	void *p = nullptr;
-	e = hipMalloc(&p, bytes);
+	e = PghMalloc(&p, bytes);
 	if (e != hipSuccess) {
 		return e;
 	}
@@ -80,6 +80,140 @@ hipError_t PghThreadScratch(size_t bytes, hipStream_t st, void **out) {
 	}
 	*out = p;
 	return hipSuccess;
+}
+
+// ---- the block cache (api_internal.hpp) ----
+namespace {
+struct CachedBlock {
+	int device;
+	void *p;
+	size_t bytes;
+};
+std::mutex g_block_mu;
+std::vector<CachedBlock> g_block_free;                 // oldest first
+std::vector<CachedBlock> g_block_live;                 // cacheable blocks handed out: device and size
+size_t BlockCacheCap() {
+	static const size_t cap = [] {
+		const char *e = std::getenv("PGH_BLOCK_CACHE_GB");
+		const double gb = e && *e ? std::atof(e) : 64.0;
+		return gb > 0 ? static_cast<size_t>(gb * 1073741824.0) : size_t(0);
+	}();
+	return cap;
+}
+} // namespace
+
+void PghTrimBlockCache() {
+	std::vector<CachedBlock> drop;
+	{
+		std::lock_guard<std::mutex> lk(g_block_mu);
+		drop.swap(g_block_free);
+	}
+	for (auto &b : drop) {
+		DeviceScope scope(b.device);
+		(void)hipFree(b.p);
+	}
+}
+
+hipError_t PghBlockAlloc(void **out, size_t bytes) {
+	int device = 0;
+	hipError_t e = hipGetDevice(&device);
+	if (e != hipSuccess) {
+		return e;
+	}
+	if (bytes >= kBlockCacheMin && BlockCacheCap()) {
+		std::lock_guard<std::mutex> lk(g_block_mu);
+		size_t best = g_block_free.size();
+		for (size_t i = 0; i < g_block_free.size(); i++) {
+			const CachedBlock &b = g_block_free[i];
+			if (b.device == device && b.bytes >= bytes && b.bytes - bytes <= bytes / 4 &&
+			    (best == g_block_free.size() || b.bytes < g_block_free[best].bytes)) {
+				best = i;
+			}
+		}
+		if (best != g_block_free.size()) {
+			*out = g_block_free[best].p;
+			g_block_live.push_back(CachedBlock {device, *out, g_block_free[best].bytes});
+			g_block_free.erase(g_block_free.begin() + static_cast<ptrdiff_t>(best));
+			return hipSuccess;
+		}
+	}
+	e = hipMalloc(out, bytes);
+	if (e != hipSuccess) {
+		(void)hipGetLastError();
+		PghTrimBlockCache(); // what the list holds may be exactly what is missing
+		e = hipMalloc(out, bytes);
+	}
+	if (e == hipSuccess && bytes >= kBlockCacheMin && BlockCacheCap()) {
+		std::lock_guard<std::mutex> lk(g_block_mu);
+		g_block_live.push_back(CachedBlock {device, *out, bytes});
+	}
+	return e;
+}
+
+void PghBlockFree(void *p) {
+	if (!p) {
+		return;
+	}
+	size_t bytes = 0;
+	int device = -1;
+	{
+		std::lock_guard<std::mutex> lk(g_block_mu);
+		for (size_t i = 0; i < g_block_live.size(); i++) {
+			if (g_block_live[i].p == p) {
+				bytes = g_block_live[i].bytes;
+				device = g_block_live[i].device;
+				g_block_live.erase(g_block_live.begin() + static_cast<ptrdiff_t>(i));
+				break;
+			}
+		}
+	}
+	if (bytes == 0 || bytes > BlockCacheCap()) {
+		(void)hipFree(p);
+		return;
+	}
+	DeviceScope scope(device); // (the block's device, whatever the caller's current one is)
+	// hipFree waits for the device before the memory can be handed out again; so does this
+	if (hipDeviceSynchronize() != hipSuccess) {
+		(void)hipGetLastError();
+		(void)hipFree(p);
+		return;
+	}
+	std::vector<CachedBlock> drop;
+	{
+		std::lock_guard<std::mutex> lk(g_block_mu);
+		size_t held = bytes;
+		for (const auto &b : g_block_free) {
+			held += b.device == device ? b.bytes : 0;
+		}
+		for (size_t i = 0; held > BlockCacheCap() && i < g_block_free.size();) {
+			if (g_block_free[i].device == device) {
+				held -= g_block_free[i].bytes;
+				drop.push_back(g_block_free[i]);
+				g_block_free.erase(g_block_free.begin() + static_cast<ptrdiff_t>(i));
+			} else {
+				i++;
+			}
+		}
+		g_block_free.push_back(CachedBlock {device, p, bytes});
+	}
+	for (auto &b : drop) {
+		(void)hipFree(b.p);
+	}
+}
+
+size_t PghDeviceFreeBytes() {
+	size_t free_b = 0, total_b = 0;
+	if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+		(void)hipGetLastError();
+		return 0;
+	}
+	int device = 0;
+	(void)hipGetDevice(&device);
+	std::lock_guard<std::mutex> lk(g_block_mu);
+	for (const auto &b : g_block_free) {
+		free_b += b.device == device ? b.bytes : 0;
+	}
+	return free_b;
 }
 
 hipStream_t PghThreadStream() {
@@ -200,7 +334,7 @@ static hipError_t AcquireStage(uint64_t bytes, int device_id, bool want_device, 
 			e = hipHostMalloc(reinterpret_cast<void **>(&out.pinned[i]), bytes, hipHostMallocDefault);
 		}
 		if (e == hipSuccess && want_device && !out.device[i]) {
-			e = hipMalloc(reinterpret_cast<void **>(&out.device[i]), std::max(bytes, out.bytes));
+			e = PghMalloc(reinterpret_cast<void **>(&out.device[i]), std::max(bytes, out.bytes));
 		}
 	}
 	out.bytes = std::max(bytes, out.bytes);
@@ -337,12 +471,12 @@ static int PrepareDosage(pgh_dataset *ds, DosageStaging &stg, char *errbuf) {
 		ds->dos_row_of.clear();
 		return PGH_OK;
 	}
-	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_dos_row_of), sizeof(int32_t) * range), "hipMalloc(dosage)");
-	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_dos_present), 8ull * rows * words), "hipMalloc(dosage)");
-	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_dos_rank), 4ull * rows * words), "hipMalloc(dosage)");
-	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_dos_val_off), 8ull * (rows + 1)), "hipMalloc(dosage)");
-	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_dos_values), 2 * stg.capacity + 32), "hipMalloc(dosage)");
-	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&stg.d_total), 8), "hipMalloc(dosage)");
+	PGH_HIP(PghMalloc(reinterpret_cast<void **>(&ds->d_dos_row_of), sizeof(int32_t) * range), "hipMalloc(dosage)");
+	PGH_HIP(PghMalloc(reinterpret_cast<void **>(&ds->d_dos_present), 8ull * rows * words), "hipMalloc(dosage)");
+	PGH_HIP(PghMalloc(reinterpret_cast<void **>(&ds->d_dos_rank), 4ull * rows * words), "hipMalloc(dosage)");
+	PGH_HIP(PghMalloc(reinterpret_cast<void **>(&ds->d_dos_val_off), 8ull * (rows + 1)), "hipMalloc(dosage)");
+	PGH_HIP(PghMalloc(reinterpret_cast<void **>(&ds->d_dos_values), 2 * stg.capacity + 32), "hipMalloc(dosage)");
+	PGH_HIP(PghMalloc(reinterpret_cast<void **>(&stg.d_total), 8), "hipMalloc(dosage)");
 	PGH_HIP(hipMemset(ds->d_dos_present, 0, 8ull * rows * words), "dosage memset");
 	PGH_HIP(hipMemset(ds->d_dos_rank, 0, 4ull * rows * words), "dosage memset");
 	PGH_HIP(hipMemset(ds->d_dos_val_off, 0, 8ull * (rows + 1)), "dosage memset");
@@ -465,8 +599,8 @@ static int PreparePhase(pgh_dataset *ds, char *errbuf) {
 		ds->ph_row_of.clear();
 		return PGH_OK;
 	}
-	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_ph_present), 8ull * rows * words), "hipMalloc(phase)");
-	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_ph_info), 8ull * rows * words), "hipMalloc(phase)");
+	PGH_HIP(PghMalloc(reinterpret_cast<void **>(&ds->d_ph_present), 8ull * rows * words), "hipMalloc(phase)");
+	PGH_HIP(PghMalloc(reinterpret_cast<void **>(&ds->d_ph_info), 8ull * rows * words), "hipMalloc(phase)");
 	PGH_HIP(hipMemset(ds->d_ph_present, 0, 8ull * rows * words), "phase memset");
 	PGH_HIP(hipMemset(ds->d_ph_info, 0, 8ull * rows * words), "phase memset");
 	ds->ph_rows = rows;
@@ -620,7 +754,7 @@ extern "C" int pgh_open(const char *pgen_path, const char *pgi_path, uint32_t va
 	uint8_t *const *stage = staging.pinned;
 	uint8_t *const *d_stage = staging.device;
 	if (e == hipSuccess && device_decode) {
-		e = hipMalloc(reinterpret_cast<void **>(&d_error), sizeof(int));
+		e = PghMalloc(reinterpret_cast<void **>(&d_error), sizeof(int));
 		if (e == hipSuccess) {
 			e = hipMemsetAsync(d_error, 0, sizeof(int), stream);
 		}
@@ -1027,10 +1161,10 @@ extern "C" int pgh_synth_add_dosage(pgh_dataset *ds, double rate, uint64_t seed,
 	for (uint32_t i = 0; i < rows; i++) {
 		ds->dos_row_of[i] = static_cast<int32_t>(i);
 	}
-	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_dos_row_of), sizeof(int32_t) * rows), "hipMalloc(dosage)");
-	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_dos_present), 8ull * rows * words), "hipMalloc(dosage)");
-	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_dos_rank), 4ull * rows * words), "hipMalloc(dosage)");
-	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_dos_val_off), 8ull * (rows + 1)), "hipMalloc(dosage)");
+	PGH_HIP(PghMalloc(reinterpret_cast<void **>(&ds->d_dos_row_of), sizeof(int32_t) * rows), "hipMalloc(dosage)");
+	PGH_HIP(PghMalloc(reinterpret_cast<void **>(&ds->d_dos_present), 8ull * rows * words), "hipMalloc(dosage)");
+	PGH_HIP(PghMalloc(reinterpret_cast<void **>(&ds->d_dos_rank), 4ull * rows * words), "hipMalloc(dosage)");
+	PGH_HIP(PghMalloc(reinterpret_cast<void **>(&ds->d_dos_val_off), 8ull * (rows + 1)), "hipMalloc(dosage)");
 	PGH_HIP(hipMemcpyAsync(ds->d_dos_row_of, ds->dos_row_of.data(), sizeof(int32_t) * rows, hipMemcpyHostToDevice, st),
 	        "dosage upload");
 	PGH_HIP(pgh::LaunchSynthDosageBits(ds->d_dos_present, rows, words, ds->sample_ct, ds->v_begin, seed, rate, st),
@@ -1047,7 +1181,7 @@ extern "C" int pgh_synth_add_dosage(pgh_dataset *ds, double rate, uint64_t seed,
 		total += c;
 	}
 	off[rows] = total;
-	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_dos_values), 2 * total + 32), "hipMalloc(dosage)");
+	PGH_HIP(PghMalloc(reinterpret_cast<void **>(&ds->d_dos_values), 2 * total + 32), "hipMalloc(dosage)");
 	PGH_HIP(hipMemsetAsync(ds->d_dos_values, 0, 2 * total + 32, st), "dosage memset");
 	PGH_HIP(hipMemcpyAsync(ds->d_dos_val_off, off.data(), 8ull * (rows + 1), hipMemcpyHostToDevice, st), "dosage upload");
 	PGH_HIP(pgh::LaunchSynthDosageValues(ds->d_dos_present, ds->d_dos_rank, ds->d_dos_val_off, ds->d_dos_values, rows, words,
@@ -1341,6 +1475,11 @@ extern "C" void pgh_close(pgh_dataset *ds) {
 		}
 	}
 	delete ds;
+	PghTrimBlockCache(); // cached work blocks were shaped by this dataset's calls
+}
+
+extern "C" void pgh_trim_device_cache(void) {
+	PghTrimBlockCache();
 }
 
 // ---------------------------------------------------------------------------
@@ -1371,18 +1510,18 @@ extern "C" int pgh_subset_create(const pgh_dataset *ds, const uint64_t *sample_i
 		}
 	}
 	ss->n_out = static_cast<uint32_t>(ss->sel.size());
-	hipError_t e = hipMalloc(reinterpret_cast<void **>(&ss->d_mask2), ds->pitch);
+	hipError_t e = PghMalloc(reinterpret_cast<void **>(&ss->d_mask2), ds->pitch);
 	if (e == hipSuccess) {
 		e = hipMemcpy(ss->d_mask2, mask2.data(), ds->pitch, hipMemcpyHostToDevice);
 	}
 	if (e == hipSuccess) {
-		e = hipMalloc(reinterpret_cast<void **>(&ss->d_sel), sizeof(uint32_t) * std::max<uint32_t>(1, ss->n_out));
+		e = PghMalloc(reinterpret_cast<void **>(&ss->d_sel), sizeof(uint32_t) * std::max<uint32_t>(1, ss->n_out));
 	}
 	if (e == hipSuccess && ss->n_out) {
 		e = hipMemcpy(ss->d_sel, ss->sel.data(), sizeof(uint32_t) * ss->n_out, hipMemcpyHostToDevice);
 	}
 	if (e == hipSuccess) {
-		e = hipMalloc(reinterpret_cast<void **>(&ss->d_include), 8 * std::max<size_t>(1, ss->include.size()));
+		e = PghMalloc(reinterpret_cast<void **>(&ss->d_include), 8 * std::max<size_t>(1, ss->include.size()));
 	}
 	if (e == hipSuccess && !ss->include.empty()) {
 		e = hipMemcpy(ss->d_include, ss->include.data(), 8 * ss->include.size(), hipMemcpyHostToDevice);

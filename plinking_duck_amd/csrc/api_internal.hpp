@@ -223,6 +223,35 @@ hipStream_t PghThreadStream();
 // pool.
 hipError_t PghThreadScratch(size_t bytes, hipStream_t st, void **out);
 
+// Call-scoped device blocks (DevBuf).  hipMalloc / hipFree of multi-gigabyte blocks is not cheap on this runtime and
+// gets dearer with use: plink_pca's three 12.5 GB work matrices (100 k variants x 500 k samples) cost 40 ms of
+// allocation in the first call of a process and 0.7 - 3.4 s in every second or third call after that (eight
+// back-to-back calls: 400 ms each for the kernels, 1.1 - 3.8 s for the whole call; profiles/r03_pca_alloc_stalls.txt).
+// So blocks of kBlockCacheMin bytes and more go back to a per-device free list instead of the driver and the next
+// call of the same shape takes them from there (a block up to a quarter larger than asked for is accepted).
+// The list holds at most PGH_BLOCK_CACHE_GB (default 64) per device, oldest out first; it is emptied when a
+// dataset closes (pgh_close), when any allocation of the library fails (then retried once) and by
+// pgh_trim_device_cache().  PghBlockFree waits for the device like hipFree does before the block can be handed on.
+// PghDeviceFreeBytes: hipMemGetInfo's free bytes plus what the list holds on the current device -- what the
+// "is there room for a tile-major copy" decisions read.
+constexpr size_t kBlockCacheMin = 64ull << 20;
+hipError_t PghBlockAlloc(void **out, size_t bytes);
+void PghBlockFree(void *p);
+void PghTrimBlockCache();
+size_t PghDeviceFreeBytes();
+// hipMalloc for blocks that live longer than a call (dataset rows, plans, readers): a failure empties the block
+// cache and tries once more.
+template <class T>
+hipError_t PghMalloc(T **out, size_t bytes) {
+	hipError_t e = hipMalloc(reinterpret_cast<void **>(out), bytes);
+	if (e != hipSuccess) {
+		(void)hipGetLastError();
+		PghTrimBlockCache();
+		e = hipMalloc(reinterpret_cast<void **>(out), bytes);
+	}
+	return e;
+}
+
 
 namespace {
 
@@ -257,11 +286,11 @@ struct DevBuf {
 	void *p = nullptr;
 	~DevBuf() {
 		if (p) {
-			(void)hipFree(p);
+			PghBlockFree(p);
 		}
 	}
 	hipError_t Alloc(size_t bytes) {
-		return hipMalloc(&p, bytes ? bytes : 16);
+		return PghBlockAlloc(&p, bytes ? bytes : 16);
 	}
 	template <class T>
 	T *As() {
@@ -326,7 +355,7 @@ template <class T>
 [[maybe_unused]] int AllocRows(pgh_dataset *ds, char *errbuf) {
 	const uint64_t rows = ds->v_end - ds->v_begin;
 	const uint64_t bytes = rows * ds->pitch;
-	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&ds->d_rows), bytes ? bytes : 16), "hipMalloc(genotype rows)");
+	PGH_HIP(PghMalloc(reinterpret_cast<void **>(&ds->d_rows), bytes ? bytes : 16), "hipMalloc(genotype rows)");
 	return PGH_OK;
 }
 

@@ -29,7 +29,7 @@ extern "C" int pgh_reader_create(const pgh_dataset *ds, const pgh_subset *subset
 	rd->device = ds->device;
 	hipError_t e = hipStreamCreateWithFlags(&rd->stream, hipStreamNonBlocking);
 	if (e == hipSuccess) {
-		e = hipMalloc(reinterpret_cast<void **>(&rd->d_counts), 16 * pgh_reader::kWindow);
+		e = PghMalloc(reinterpret_cast<void **>(&rd->d_counts), 16 * pgh_reader::kWindow);
 	}
 	if (e == hipSuccess) {
 		e = hipHostMalloc(reinterpret_cast<void **>(&rd->h_counts), 16 * pgh_reader::kWindow, hipHostMallocDefault);
@@ -354,7 +354,7 @@ extern "C" int pgh_get_dosage_f64(pgh_reader *rd, uint32_t vidx, double *out) {
 	}
 	hipError_t e = hipSuccess;
 	if (!rd->d_dosage) {
-		e = hipMalloc(reinterpret_cast<void **>(&rd->d_dosage), sizeof(double) * n_out);
+		e = PghMalloc(reinterpret_cast<void **>(&rd->d_dosage), sizeof(double) * n_out);
 		if (e == hipSuccess) {
 			e = hipHostMalloc(reinterpret_cast<void **>(&rd->h_dosage), sizeof(double) * n_out, hipHostMallocDefault);
 		}
@@ -494,7 +494,7 @@ extern "C" int pgh_reader_unpack_start(pgh_reader *rd, int slot, uint32_t v_begi
 		(void)hipFree(rd->d_unpack[slot]);
 		rd->d_unpack[slot] = nullptr;
 		rd->unpack_bytes[slot] = 0;
-		e = hipMalloc(&rd->d_unpack[slot], need);
+		e = PghMalloc(&rd->d_unpack[slot], need);
 		if (e != hipSuccess) {
 			return fail("hipMalloc(unpack staging)", e);
 		}

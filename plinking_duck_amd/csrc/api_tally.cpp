@@ -129,7 +129,7 @@ int EnqueueHwe(pgh_tally *t, TallyPart &p, int which, char *errbuf) {
 	DeviceScope scope(p.device);
 	const uint32_t midp = which == kHweMidp ? 1u : 0u;
 	const uint32_t n = p.v_end - p.v_begin;
-	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&p.d_lnp[midp]), sizeof(double) * (n ? n : 1)), "hipMalloc(tally ln p)");
+	PGH_HIP(PghMalloc(reinterpret_cast<void **>(&p.d_lnp[midp]), sizeof(double) * (n ? n : 1)), "hipMalloc(tally ln p)");
 	int rc = NewEvents(p.ev[which], p.n_batches, errbuf);
 	if (rc != PGH_OK) {
 		return rc;
@@ -160,7 +160,7 @@ int EnqueueMissingSweep(pgh_tally *t, TallyPart &p, size_t part_idx, char *errbu
 	DeviceScope scope(p.device);
 	const uint32_t n = p.v_end - p.v_begin;
 	if (!p.d_missing) {
-		PGH_HIP(hipMalloc(reinterpret_cast<void **>(&p.d_missing), sizeof(uint32_t) * t->padded), "hipMalloc(tally missing)");
+		PGH_HIP(PghMalloc(reinterpret_cast<void **>(&p.d_missing), sizeof(uint32_t) * t->padded), "hipMalloc(tally missing)");
 	}
 	const size_t need = pgh::MissingPerSampleScratchBytes(p.ds->record_bytes, n);
 	if (need > p.scratch_bytes) {
@@ -171,7 +171,7 @@ int EnqueueMissingSweep(pgh_tally *t, TallyPart &p, size_t part_idx, char *errbu
 		(void)hipFree(p.d_scratch);
 		p.d_scratch = nullptr;
 		p.scratch_bytes = 0;
-		PGH_HIP(hipMalloc(&p.d_scratch, need), "hipMalloc(tally scratch)");
+		PGH_HIP(PghMalloc(&p.d_scratch, need), "hipMalloc(tally scratch)");
 		p.scratch_bytes = need;
 	}
 	// behind everything the main stream holds, so the scratch block has one user at a time
@@ -197,12 +197,12 @@ int StartPart(pgh_tally *t, TallyPart &p, size_t part_idx, uint32_t products, ch
 	// (stream priorities -- tallies high, exact tests low -- were tried: no measurable difference at 1 M x 500 k)
 	PGH_HIP(hipStreamCreateWithFlags(&p.main, hipStreamNonBlocking), "hipStreamCreate(tally)");
 	PGH_HIP(hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking), "hipStreamCreate(tally)");
-	PGH_HIP(hipMalloc(reinterpret_cast<void **>(&p.d_counts), 16ull * (n ? n : 1)), "hipMalloc(tally counts)");
+	PGH_HIP(PghMalloc(reinterpret_cast<void **>(&p.d_counts), 16ull * (n ? n : 1)), "hipMalloc(tally counts)");
 	p.fused = !p.subset && (products & PGH_TALLY_SAMPLE_MISSING) != 0;
 	if (p.fused) {
 		p.scratch_bytes = pgh::MissingPerSampleScratchBytes(p.ds->record_bytes, p.batch);
-		PGH_HIP(hipMalloc(&p.d_scratch, p.scratch_bytes), "hipMalloc(tally scratch)");
-		PGH_HIP(hipMalloc(reinterpret_cast<void **>(&p.d_missing), sizeof(uint32_t) * t->padded), "hipMalloc(tally missing)");
+		PGH_HIP(PghMalloc(&p.d_scratch, p.scratch_bytes), "hipMalloc(tally scratch)");
+		PGH_HIP(PghMalloc(reinterpret_cast<void **>(&p.d_missing), sizeof(uint32_t) * t->padded), "hipMalloc(tally missing)");
 		PGH_HIP(hipMemsetAsync(p.d_missing, 0, sizeof(uint32_t) * t->padded, p.main), "tally memset");
 	}
 	int rc = NewEvents(p.ev[kCounts], p.n_batches, errbuf);

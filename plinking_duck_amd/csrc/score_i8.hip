@@ -275,9 +275,21 @@ __device__ __forceinline__ uint32_t LdsAddress(const void *p) {
 // LDS slots per workgroup: the tile being multiplied + the ones on their way from HBM.  Four where the workgroups
 // of a CU (two of four waves, or one of eight) still fit its 160 KB, else three (the many-column shapes are
 // matrix-bound: a trip is long).
-template <int NT, int TS>
+// Which shapes run the software-pipelined loop (k_score_i8): the matrix-bound ones, where a second set of operand
+// registers still fits next to the accumulators (both planes with nine or ten tiles: 106 registers spilled).
+template <int NT, int TS, int PLANES>
+constexpr bool I8Pipelined() {
+	return TS == 4 && (PLANES != 3 || NT <= 8);
+}
+
+template <int NT, int TS, int PLANES>
 constexpr uint32_t RingSlots() {
 	using S = I8Shape<NT, TS>;
+	if (I8Pipelined<NT, TS, PLANES>()) {
+		// the software-pipelined loop reads TWO landed tiles per trip (this tile's digit bytes, the next tile's
+		// genotype words): a fifth slot keeps three tiles on their way as before (<= 5 x 28 KB + row numbers)
+		return 5u;
+	}
 	return 4u * (S::kGenoBytes + S::kBBytes) + 4096u <= (S::kWaves == 8 ? 160u : 80u) * 1024u ? 4u : 3u;
 }
 
@@ -304,7 +316,7 @@ __global__ __launch_bounds__((I8Shape<NT, TS>::kThreads)) void k_score_i8(const 
                                                   double *__restrict__ dosage_sum,
                                                   uint32_t *__restrict__ missing_ct) {
 	using S = I8Shape<NT, TS>;
-	constexpr uint32_t kRing = RingSlots<NT, TS>();
+	constexpr uint32_t kRing = RingSlots<NT, TS, PLANES>();
 	constexpr uint32_t kSlotBytes = S::kGenoBytes + S::kBBytes;
 	__shared__ __attribute__((aligned(16))) uint8_t s_ring[kRing][kSlotBytes];
 	const uint32_t tid = threadIdx.x;
@@ -363,6 +375,8 @@ __global__ __launch_bounds__((I8Shape<NT, TS>::kThreads)) void k_score_i8(const 
 		st_col[n] = want < pitch ? want : 0ull; // past the row: some valid bytes; such samples are never stored
 	}
 	const uint32_t last_tile = tile_end - 1u;
+	// (pinned in a scalar register: re-read from the dispatch packet inside the loop, its wait drained the LDS queue)
+	const uint32_t n_groups = __builtin_amdgcn_readfirstlane(gridDim.x);
 	const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(LdsAddress(&s_ring[0][0]));
 	const uint32_t rows_lds = __builtin_amdgcn_readfirstlane(LdsAddress(&s_rows[0][0]));
 	auto issue_rows = [&](uint32_t tile) {
@@ -412,7 +426,7 @@ __global__ __launch_bounds__((I8Shape<NT, TS>::kThreads)) void k_score_i8(const 
 		for (uint32_t n = 0; n < kGenoPieces; n++) {
 			const uint32_t piece = S::kWaves * n + wave_u;
 			const uint8_t *src =
-			    TILED ? rows + (static_cast<uint64_t>(min(tile, last_tile)) * gridDim.x + blockIdx.x) * S::kGenoBytes +
+			    TILED ? rows + (static_cast<uint64_t>(min(tile, last_tile)) * n_groups + blockIdx.x) * S::kGenoBytes +
 			                1024u * piece + 16u * lane
 			          : rows + static_cast<uint64_t>(r[n]) * pitch + st_col[n];
 			Glds16Stream(src, base + piece * 1024u);
@@ -560,6 +574,137 @@ __global__ __launch_bounds__((I8Shape<NT, TS>::kThreads)) void k_score_i8(const 
 		}
 	};
 
+	// ---- the matrix-bound shapes (I8Pipelined: TS = 4, five digit tiles and more): the software-pipelined loop ----
+	// In the loop further down a trip is [read words, issue DMA, build operands, multiply, barrier]: the barrier puts
+	// the two waves of a SIMD in step, so both build (vector pipe, ~50 instructions each) while the matrix pipe has
+	// nothing queued, then both multiply -- a third of the cycles of the 16-column launch had no matrix instruction
+	// in flight.  Here trip t multiplies tile t with operands that trip t-1 built, and builds tile t+1's between its
+	// own matrix instructions (a quarter of the build after every group of them); the first digit registers of tile
+	// t+1 are asked for before the barrier.  Ring: slot t = tile t (digit bytes), slot t+1 = tile t+1 (words), tiles
+	// t+2 .. t+kRing-2 on their way, tile t+kRing-1 issued into the slot trip t-1 finished with.
+	if constexpr (I8Pipelined<NT, TS, PLANES>()) {
+#define PGH_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+		static_assert(kRing >= 4, "two landed tiles + two on their way");
+		auto build_part = [&](const uint32_t(&wd)[16], int q, v4i(&U)[TS], v4i(&Mi)[TS]) {
+			const uint32_t pa = __builtin_amdgcn_perm(wd[4 * q + 1], wd[4 * q + 0], sel_first);
+			const uint32_t qa = __builtin_amdgcn_perm(wd[4 * q + 3], wd[4 * q + 2], sel_first);
+			const uint32_t gq = __builtin_amdgcn_perm(qa, pa, 0x05040100u);
+			const uint32_t h1 = gq >> 1, h2 = gq >> 2;
+#pragma unroll
+			for (int e = 0; e < 3; e++) {
+				U[e][q] = static_cast<int>(gq & (0x03030303u << (2 * e)));
+				Mi[e][q] = static_cast<int>(gq & h1 & (0x01010101u << (2 * e)));
+			}
+			U[3][q] = static_cast<int>(h1 & 0x60606060u);
+			Mi[3][q] = static_cast<int>(h1 & h2 & 0x20202020u);
+		};
+		constexpr int kHold = 2;
+		constexpr int kGroups = (NT + kHold - 1) / kHold; // groups of matrix instructions per trip
+		auto load_b = [&](uint32_t slot, v4i *dg, v4i *dm, int nt_first) {
+			const v4i *bp = reinterpret_cast<const v4i *>(&s_ring[slot][S::kGenoBytes]);
+#pragma unroll
+			for (int h = 0; h < kHold; h++) {
+				if (nt_first + h < NT) {
+					if (PLANES & 1) {
+						dg[h] = bp[((0 * NT + nt_first + h) * 4 + g) * 16 + x];
+					}
+					if (PLANES & 2) {
+						dm[h] = bp[((1 * NT + nt_first + h) * 4 + g) * 16 + x];
+					}
+				}
+			}
+		};
+		uint32_t r_cur[kGenoPieces] = {}, r_nxt[kGenoPieces] = {};
+		v4i bg[kHold] = {}, bm[kHold] = {};
+		auto trip = [&](uint32_t tile, uint32_t slot, v4i(&Uc)[TS], v4i(&Mc)[TS], v4i(&Un)[TS], v4i(&Mn)[TS]) {
+			const uint32_t nslot = slot + 1u == kRing ? 0u : slot + 1u;
+			uint32_t wd[16];
+			load_words(nslot, wd);
+			read_rows(tile + kRing, r_nxt);
+			issue(tile + (kRing - 1), slot == 0u ? kRing - 1u : slot - 1u, r_cur);
+#pragma unroll
+			for (int gi = 0; gi < kGroups; gi++) {
+				const int nt0 = gi * kHold;
+				v4i ng[kHold] = {}, nm[kHold] = {};
+				if (gi + 1 < kGroups) {
+					load_b(slot, ng, nm, nt0 + kHold);
+				} else {
+					load_b(nslot, ng, nm, 0); // the next trip's first digit registers
+				}
+#pragma unroll
+				for (int t = 0; t < TS; t++) {
+#pragma unroll
+					for (int h = 0; h < kHold; h++) {
+						if (nt0 + h < NT) {
+							if (PLANES & 1) {
+								acc[t][nt0 + h] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Uc[t], bg[h], acc[t][nt0 + h], 0, 0, 0);
+							}
+							if (PLANES & 2) {
+								acc[t][nt0 + h] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Mc[t], bm[h], acc[t][nt0 + h], 0, 0, 0);
+							}
+						}
+					}
+				}
+				// this group's share of the next tile's operands: quarter gi, the last group takes what is left
+#pragma unroll
+				for (int q = 0; q < 4; q++) {
+					if (q == gi || (gi == kGroups - 1 && q > gi)) {
+						build_part(wd, q, Un, Mn);
+					}
+				}
+#ifndef PGH_I8_FREE_SCHEDULE
+				__builtin_amdgcn_sched_barrier(0); // keep the groups in this order: the build rides under the multiplies
+#endif
+#pragma unroll
+				for (int h = 0; h < kHold; h++) {
+					bg[h] = ng[h];
+					bm[h] = nm[h];
+				}
+			}
+			PGH_WAIT_VM(kPieces * (kRing - 3));
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+			__builtin_amdgcn_s_barrier();
+#pragma unroll
+			for (uint32_t n = 0; n < kGenoPieces; n++) {
+				r_cur[n] = r_nxt[n];
+			}
+		};
+#pragma unroll
+		for (uint32_t d = 0; d < kRowAhead; d++) {
+			issue_rows(tile_begin + d);
+		}
+		PGH_WAIT_VM(0);
+		__builtin_amdgcn_s_barrier();
+#pragma unroll
+		for (uint32_t d = 0; d + 1 < kRing; d++) {
+			read_rows(tile_begin + d, r_cur);
+			issue(tile_begin + d, d, r_cur);
+		}
+		read_rows(tile_begin + (kRing - 1), r_cur);
+		PGH_WAIT_VM(kPieces * (kRing - 3)); // tiles 0 and 1 of the slice have landed
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		__builtin_amdgcn_s_barrier();
+		v4i Ua[TS], Ma[TS], Ub[TS], Mb[TS];
+		{
+			uint32_t wd[16];
+			load_words(0, wd);
+#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				build_part(wd, q, Ua, Ma);
+			}
+			load_b(0, bg, bm, 0);
+		}
+		// (slices hold an even number of tiles: LaunchI8 rounds tiles per slice up, ScoreI8Bytes the tile count)
+		uint32_t slot = 0;
+		for (uint32_t tile = tile_begin; tile < tile_end; tile += 2) {
+			trip(tile, slot, Ua, Ma, Ub, Mb);
+			slot = slot + 1u == kRing ? 0u : slot + 1u;
+			trip(tile + 1u, slot, Ub, Mb, Ua, Ma);
+			slot = slot + 1u == kRing ? 0u : slot + 1u;
+		}
+		PGH_WAIT_VM(0); // the tail's repeats must land before the LDS is handed back
+#undef PGH_WAIT_VM
+	} else {
 	// Ring protocol (kRing = 4).  Trip t multiplies slot t % 4 while the DMAs of tiles t+1 .. t+3 are in flight or landed;
 	// it first issues tile t+3 into the slot trip t-1 finished with (every wave passed that trip's barrier).
 	// At the end each wave waits until all but its 2 x kPieces youngest DMAs have landed -- its share of tile
@@ -600,6 +745,7 @@ __global__ __launch_bounds__((I8Shape<NT, TS>::kThreads)) void k_score_i8(const 
 	}
 	PGH_WAIT_VM(0); // the tail's repeats must land before the LDS is handed back
 #undef PGH_WAIT_VM
+	}
 
 	// ---- epilogue: lane (j = lane & 15, g) holds digit column 16 nt + j of the sample slots 4 g + r ----
 	// The digits of one output column sit in up to seven NEIGHBOURING lanes of a 16-lane row: they are scaled,

@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = [
     "pgh_synth_add_dosage", "pgh_synth_write_dosage_files", "pgh_dosage_sums", "pgh_dosage_sums_dev", "pgh_dosage_unpack", "pgh_dosage_unpack_dev", "pgh_unpack_samples", "pgh_dosage_unpack_samples", "pgh_reader_create", "pgh_reader_destroy",
     "pgh_reader_unpack_start", "pgh_reader_unpack_wait", "pgh_get_2bit", "pgh_get_counts", "pgh_get_missingness", "pgh_get_int8", "pgh_get_dosage_f64", "pgh_get_phased",
     "pgh_tally_start", "pgh_tally_request", "pgh_tally_wait", "pgh_tally_counts", "pgh_tally_hwe_lnp",
-    "pgh_tally_sample_missing", "pgh_tally_destroy", "pgh_tally_passes_started", "pgh_host_alloc", "pgh_host_free",
+    "pgh_tally_sample_missing", "pgh_tally_destroy", "pgh_tally_passes_started", "pgh_host_alloc", "pgh_host_free", "pgh_trim_device_cache",
     "pgh_reader_error", "pgh_hwe_lnp", "pgh_hwe_xchr_lnp", "pgh_hwe_lnp_batch", "pgh_hwe_lnp_batch_dev", "pgh_hwe_xchr_lnp_batch",
 ]
 
@@ -159,6 +159,7 @@ def _load():
         "pgh_tally_passes_started": (u64, []),
         "pgh_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(vp), cp]),
         "pgh_host_free": (None, [vp]),
+        "pgh_trim_device_cache": (None, []),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)
@@ -283,6 +284,11 @@ def synth_write_dosage_files(prefix: str, m: int, n: int, seed: int, missing_rat
 
 
 TALLY_COUNTS, TALLY_SAMPLE_MISSING, TALLY_HWE, TALLY_HWE_MIDP = 1, 2, 4, 8
+
+
+def trim_device_cache():
+    """Hand the call-scoped work blocks the library keeps between calls back to the driver."""
+    raw().pgh_trim_device_cache()
 
 
 def tally_passes_started() -> int:

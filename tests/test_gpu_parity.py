@@ -803,3 +803,36 @@ def test_pca_with_and_without_tile_major_copies(gpu_lib, monkeypatch):
     assert np.allclose(ev1, ev2, rtol=1e-10)
     for j in range(k):
         assert np.allclose(vec1[:, j], np.sign(np.dot(vec1[:, j], vec2[:, j])) * vec2[:, j], atol=1e-7)
+
+
+def test_work_blocks_are_kept_between_calls_and_given_back(gpu_lib):
+    """plink_pca's big work matrices go to a per-device free list when a call ends (hipMalloc of tens of GB costs
+    seconds in a long-lived process); the next call takes them from there and gives the same answer, and
+    pgh_trim_device_cache() / pgh_close() hand them back to the driver."""
+    import torch
+
+    L = gpu_lib
+    m, n, k = 24000, 24000, 7  # the transposed matrix and each tile-major copy: 144 MB = 137 MiB
+    ds = L.Dataset.synth(0, m, n, SEED + 9, 0.02)
+    c = ds.counts_range().astype(np.float64)
+    obs = c[:, :3].sum(axis=1)
+    af = (c[:, 1] + 2 * c[:, 2]) / (2 * np.maximum(obs, 1))
+    keep = np.flatnonzero((obs > 0) & (af > 0) & (af < 1)).astype(np.uint32)
+    center, inv = 2 * af[keep], 1.0 / np.sqrt(2 * af[keep] * (1 - af[keep]))
+    g1 = np.random.default_rng(5).standard_normal((n, 2 * k))
+    L.trim_device_cache()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    ev1, vec1 = ds.pca(keep, center, inv, k, g1)
+    held = free0 - torch.cuda.mem_get_info(0)[0]
+    assert held >= 3 * 130 * 2**20  # X^T and the two tile-major copies (137 MiB each) at least
+    ev2, vec2 = ds.pca(keep, center, inv, k, g1)
+    assert free0 - torch.cuda.mem_get_info(0)[0] <= held + (64 << 20)  # the second call re-used them
+    assert np.allclose(ev1, ev2, rtol=1e-10)
+    for j in range(k):
+        assert np.allclose(vec1[:, j], np.sign(np.dot(vec1[:, j], vec2[:, j])) * vec2[:, j], atol=1e-7)
+    L.trim_device_cache()
+    assert free0 - torch.cuda.mem_get_info(0)[0] <= (64 << 20)
+    ev3, _ = ds.pca(keep, center, inv, k, g1)
+    assert np.allclose(ev1, ev3, rtol=1e-10)
+    ds.close()
+    assert torch.cuda.mem_get_info(0)[0] >= free0  # pgh_close emptied the list too
