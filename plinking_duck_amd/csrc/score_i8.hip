@@ -32,6 +32,8 @@
 #include "device_utils.hpp"
 #include "score_i8.hpp"
 
+#include <type_traits>
+
 namespace pgh {
 
 namespace {
@@ -276,19 +278,23 @@ __device__ __forceinline__ uint32_t LdsAddress(const void *p) {
 // of a CU (two of four waves, or one of eight) still fit its 160 KB, else three (the many-column shapes are
 // matrix-bound: a trip is long).
 // Which shapes run the software-pipelined loop (k_score_i8): the matrix-bound ones, where a second set of operand
-// registers still fits next to the accumulators (both planes with nine or ten tiles: 106 registers spilled).
-template <int NT, int TS, int PLANES>
+// registers still fits next to the accumulators (both planes, ten tiles, row-major words: 34 registers spilled).
+template <int NT, int TS, int PLANES, bool TILED>
 constexpr bool I8Pipelined() {
-	return TS == 4 && (PLANES != 3 || NT <= 8);
+	return TS == 4 && (TILED || PLANES != 3 || NT <= 9);
 }
 
-template <int NT, int TS, int PLANES>
+template <int NT, int TS, int PLANES, bool TILED>
 constexpr uint32_t RingSlots() {
 	using S = I8Shape<NT, TS>;
-	if (I8Pipelined<NT, TS, PLANES>()) {
+	if (I8Pipelined<NT, TS, PLANES, TILED>()) {
 		// the software-pipelined loop reads TWO landed tiles per trip (this tile's digit bytes, the next tile's
 		// genotype words): a fifth slot keeps three tiles on their way as before (<= 5 x 28 KB + row numbers)
+#ifdef PGH_I8_RING
+		return PGH_I8_RING * (S::kGenoBytes + S::kBBytes) + 4096u <= 160u * 1024u ? PGH_I8_RING : 5u;
+#else
 		return 5u;
+#endif
 	}
 	return 4u * (S::kGenoBytes + S::kBBytes) + 4096u <= (S::kWaves == 8 ? 160u : 80u) * 1024u ? 4u : 3u;
 }
@@ -316,7 +322,7 @@ __global__ __launch_bounds__((I8Shape<NT, TS>::kThreads)) void k_score_i8(const 
                                                   double *__restrict__ dosage_sum,
                                                   uint32_t *__restrict__ missing_ct) {
 	using S = I8Shape<NT, TS>;
-	constexpr uint32_t kRing = RingSlots<NT, TS, PLANES>();
+	constexpr uint32_t kRing = RingSlots<NT, TS, PLANES, TILED>();
 	constexpr uint32_t kSlotBytes = S::kGenoBytes + S::kBBytes;
 	__shared__ __attribute__((aligned(16))) uint8_t s_ring[kRing][kSlotBytes];
 	const uint32_t tid = threadIdx.x;
@@ -441,7 +447,12 @@ __global__ __launch_bounds__((I8Shape<NT, TS>::kThreads)) void k_score_i8(const 
 	constexpr uint32_t kLanesPerWord = 16u / TS;
 	const uint32_t word = wave * TS + x / kLanesPerWord;
 	const uint32_t word_phys = word ^ ((g & 1u) * S::kSwizzleChunks * 4u);
-	const uint32_t geno_off = (16u * g) * S::kRowBytes + 4u * word_phys;
+	// TILED: the slot holds the BYTE-MAJOR image of the tile (k_i8_tile_major): the sixteen bytes "byte column b of
+	// variants 16 g .. 16 g + 15" are contiguous, at b * 64 + 16 * ((g + b / 4) % 4) -- the rotation spreads the
+	// sixteen lanes of a k-group over all banks.  This lane's byte column is 16 * wave + x.
+	const uint32_t byte_col = 16u * wave + x;
+	const uint32_t geno_off =
+	    TILED ? byte_col * 64u + 16u * ((g + (byte_col >> 2)) & 3u) : (16u * g) * S::kRowBytes + 4u * word_phys;
 
 	v4i acc[TS][NT];
 #pragma unroll
@@ -471,6 +482,15 @@ __global__ __launch_bounds__((I8Shape<NT, TS>::kThreads)) void k_score_i8(const 
 	// the LDS round trip runs under the issue's scalar work instead of after it
 	auto load_words = [&](uint32_t slot, uint32_t(&wd)[16]) {
 		const uint8_t *gp = &s_ring[slot][geno_off];
+		if (TILED) {
+#ifdef PGH_I8_NO_BUILD
+			wd[0] = lane, wd[1] = lane * 3u, wd[2] = lane * 5u, wd[3] = lane * 7u;
+#else
+			const uint4 w = *reinterpret_cast<const uint4 *>(gp); // wd[q] is already G[q]: byte j = variant 4 q + j
+			wd[0] = w.x, wd[1] = w.y, wd[2] = w.z, wd[3] = w.w;
+#endif
+			return;
+		}
 #pragma unroll
 		for (int k = 0; k < 16; k++) {
 #ifdef PGH_I8_NO_BUILD
@@ -485,6 +505,10 @@ __global__ __launch_bounds__((I8Shape<NT, TS>::kThreads)) void k_score_i8(const 
 		uint32_t G[4][kBytesPerLane];
 #pragma unroll
 		for (int q = 0; q < 4; q++) {
+			if (TILED) {
+				G[q][0] = wd[q];
+				continue;
+			}
 			const uint32_t w0 = wd[4 * q + 0], w1 = wd[4 * q + 1], w2 = wd[4 * q + 2], w3 = wd[4 * q + 3];
 			if (TS == 16) {
 				const uint32_t pa = __builtin_amdgcn_perm(w1, w0, 0x05010400u), pb = __builtin_amdgcn_perm(w1, w0, 0x07030602u);
@@ -582,13 +606,53 @@ __global__ __launch_bounds__((I8Shape<NT, TS>::kThreads)) void k_score_i8(const 
 	// own matrix instructions (a quarter of the build after every group of them); the first digit registers of tile
 	// t+1 are asked for before the barrier.  Ring: slot t = tile t (digit bytes), slot t+1 = tile t+1 (words), tiles
 	// t+2 .. t+kRing-2 on their way, tile t+kRing-1 issued into the slot trip t-1 finished with.
-	if constexpr (I8Pipelined<NT, TS, PLANES>()) {
+	if constexpr (I8Pipelined<NT, TS, PLANES, TILED>()) {
 #define PGH_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
-		static_assert(kRing >= 4, "two landed tiles + two on their way");
+		// tuning knobs of this loop (tools/i8_variants.sh builds and times the combinations)
+#ifndef PGH_I8_SKEW
+#define PGH_I8_SKEW 0 // 1: waves 4 .. 7 run half a trip behind waves 0 .. 3
+#endif
+#ifndef PGH_I8_HOLD
+#define PGH_I8_HOLD 1 // digit tiles per group of matrix instructions
+#endif
+#ifndef PGH_I8_FILL
+#define PGH_I8_FILL 1 // vector instructions scheduled behind every matrix instruction (0: the compiler's order)
+#endif
+#ifndef PGH_I8_JITW
+#define PGH_I8_JITW 1 // genotype words read a quarter at a time, one group ahead of their use
+#endif
+#ifndef PGH_I8_ISSUE_AT
+#define PGH_I8_ISSUE_AT 2 // the early waves' DMA pieces go out behind this group (-1: at the top of the trip)
+#endif
+		constexpr bool kSkew = PGH_I8_SKEW != 0;
+		static_assert(kRing >= (kSkew ? 5u : 4u), "two landed tiles + their successors on the way");
+		auto load_words_part = [&](uint32_t slot, int q, uint32_t(&wd)[16]) {
+			if (TILED) {
+				if (q == 0) {
+					load_words(slot, wd); // one 16-byte read holds all four quarters
+				}
+				return;
+			}
+			const uint8_t *gp = &s_ring[slot][geno_off];
+#pragma unroll
+			for (int k = 4 * q; k < 4 * q + 4; k++) {
+#ifdef PGH_I8_NO_BUILD
+				wd[k] = lane * (k + 3u);
+				(void)gp;
+#else
+				wd[k] = *reinterpret_cast<const uint32_t *>(gp + k * S::kRowBytes);
+#endif
+			}
+		};
 		auto build_part = [&](const uint32_t(&wd)[16], int q, v4i(&U)[TS], v4i(&Mi)[TS]) {
-			const uint32_t pa = __builtin_amdgcn_perm(wd[4 * q + 1], wd[4 * q + 0], sel_first);
-			const uint32_t qa = __builtin_amdgcn_perm(wd[4 * q + 3], wd[4 * q + 2], sel_first);
-			const uint32_t gq = __builtin_amdgcn_perm(qa, pa, 0x05040100u);
+			uint32_t gq;
+			if (TILED) {
+				gq = wd[q];
+			} else {
+				const uint32_t pa = __builtin_amdgcn_perm(wd[4 * q + 1], wd[4 * q + 0], sel_first);
+				const uint32_t qa = __builtin_amdgcn_perm(wd[4 * q + 3], wd[4 * q + 2], sel_first);
+				gq = __builtin_amdgcn_perm(qa, pa, 0x05040100u);
+			}
 			const uint32_t h1 = gq >> 1, h2 = gq >> 2;
 #pragma unroll
 			for (int e = 0; e < 3; e++) {
@@ -598,7 +662,7 @@ __global__ __launch_bounds__((I8Shape<NT, TS>::kThreads)) void k_score_i8(const 
 			U[3][q] = static_cast<int>(h1 & 0x60606060u);
 			Mi[3][q] = static_cast<int>(h1 & h2 & 0x20202020u);
 		};
-		constexpr int kHold = 2;
+		constexpr int kHold = PGH_I8_HOLD;
 		constexpr int kGroups = (NT + kHold - 1) / kHold; // groups of matrix instructions per trip
 		auto load_b = [&](uint32_t slot, v4i *dg, v4i *dm, int nt_first) {
 			const v4i *bp = reinterpret_cast<const v4i *>(&s_ring[slot][S::kGenoBytes]);
@@ -616,15 +680,43 @@ __global__ __launch_bounds__((I8Shape<NT, TS>::kThreads)) void k_score_i8(const 
 		};
 		uint32_t r_cur[kGenoPieces] = {}, r_nxt[kGenoPieces] = {};
 		v4i bg[kHold] = {}, bm[kHold] = {};
-		auto trip = [&](uint32_t tile, uint32_t slot, v4i(&Uc)[TS], v4i(&Mc)[TS], v4i(&Un)[TS], v4i(&Mn)[TS]) {
+		// Early and late waves (kSkew).  A workgroup's barrier puts the two waves of a SIMD (waves w and w + 4) in
+		// step: both read words and issue their DMA pieces right behind it, both wait in front of it.  With kSkew
+		// waves 4 .. 7 run half a trip behind: their barrier sits in the MIDDLE of their groups of matrix
+		// instructions and their DMA issue behind that, while waves 0 .. 3 have theirs at the trip's end and start.
+		// The late waves read tile t - 1's digits until barrier t, so its slot is free for tile t + kRing - 1 only
+		// behind that barrier: the late waves issue that tile in the second half of their trip t, the early waves
+		// in their trip t + 1 (each trip of theirs issues tile + kRing - 2).  Either way a wave has issued up to
+		// tile t + kRing - 2 when it reaches barrier t and waits for all but the youngest kRing - 4 of them: tile
+		// t + 2 has landed, which is what the half trips behind the barrier read.  Without kSkew every wave is an
+		// "early" one that issues tile t + kRing - 1 in trip t and waits for all but kRing - 3 tiles.
+		auto trip = [&](auto late_c, uint32_t tile, uint32_t slot, v4i(&Uc)[TS], v4i(&Mc)[TS], v4i(&Un)[TS], v4i(&Mn)[TS]) {
+			constexpr bool kLate = decltype(late_c)::value;
+			constexpr int kMid = kGroups / 2;
+			constexpr int kIssueAfter = kLate ? kMid : PGH_I8_ISSUE_AT; // the DMA pieces go out behind this group
+			constexpr uint32_t kAhead = (kLate || !kSkew) ? kRing - 1u : kRing - 2u;
+			constexpr uint32_t kKeep = kSkew ? kRing - 4u : kRing - 3u; // tiles still on their way behind the barrier
 			const uint32_t nslot = slot + 1u == kRing ? 0u : slot + 1u;
 			uint32_t wd[16];
-			load_words(nslot, wd);
-			read_rows(tile + kRing, r_nxt);
-			issue(tile + (kRing - 1), slot == 0u ? kRing - 1u : slot - 1u, r_cur);
+			read_rows(tile + 1u + kAhead, r_nxt);
+			if (kIssueAfter < 0) {
+				issue(tile + kAhead, (slot + kAhead) % kRing, r_cur);
+			}
 #pragma unroll
 			for (int gi = 0; gi < kGroups; gi++) {
 				const int nt0 = gi * kHold;
+#pragma unroll
+				for (int q = 0; q < 4; q++) {
+					const int build_group = (q * kGroups) / 4;
+					if (gi == (PGH_I8_JITW && build_group > 0 ? build_group - 1 : 0)) {
+						load_words_part(nslot, q, wd);
+					}
+				}
+				if (kLate && gi == kMid) {
+					PGH_WAIT_VM(kPieces * kKeep);
+					asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+					__builtin_amdgcn_s_barrier();
+				}
 				v4i ng[kHold] = {}, nm[kHold] = {};
 				if (gi + 1 < kGroups) {
 					load_b(slot, ng, nm, nt0 + kHold);
@@ -645,25 +737,44 @@ __global__ __launch_bounds__((I8Shape<NT, TS>::kThreads)) void k_score_i8(const 
 						}
 					}
 				}
-				// this group's share of the next tile's operands: quarter gi, the last group takes what is left
+				// the next tile's operands, a quarter behind each of four groups spread over the trip
 #pragma unroll
 				for (int q = 0; q < 4; q++) {
-					if (q == gi || (gi == kGroups - 1 && q > gi)) {
+					if (gi == (q * kGroups) / 4) {
 						build_part(wd, q, Un, Mn);
 					}
 				}
 #ifndef PGH_I8_FREE_SCHEDULE
+				// PGH_I8_FILL vector instructions of the build (and one LDS read, while there are any) behind every
+				// matrix instruction: an MFMA holds the SIMD's vector issue for 8 of its 16 cycles and the two waves
+				// of a SIMD alternate, so a gap has room for about two fillers per wave -- clustered fillers cost
+				// their full issue time (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost').
+				if (PGH_I8_FILL > 0) {
+#pragma unroll
+					for (int i = 0; i < 8 * kHold; i++) {
+						__builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // MFMA
+						__builtin_amdgcn_sched_group_barrier(0x002, PGH_I8_FILL, 0); // VALU
+						if (i < 6) {
+							__builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // DS read
+						}
+					}
+				}
 				__builtin_amdgcn_sched_barrier(0); // keep the groups in this order: the build rides under the multiplies
 #endif
+				if (gi == kIssueAfter) {
+					issue(tile + kAhead, (slot + kAhead) % kRing, r_cur);
+				}
 #pragma unroll
 				for (int h = 0; h < kHold; h++) {
 					bg[h] = ng[h];
 					bm[h] = nm[h];
 				}
 			}
-			PGH_WAIT_VM(kPieces * (kRing - 3));
-			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-			__builtin_amdgcn_s_barrier();
+			if (!kLate) {
+				PGH_WAIT_VM(kPieces * kKeep);
+				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+				__builtin_amdgcn_s_barrier();
+			}
 #pragma unroll
 			for (uint32_t n = 0; n < kGenoPieces; n++) {
 				r_cur[n] = r_nxt[n];
@@ -675,13 +786,22 @@ __global__ __launch_bounds__((I8Shape<NT, TS>::kThreads)) void k_score_i8(const 
 		}
 		PGH_WAIT_VM(0);
 		__builtin_amdgcn_s_barrier();
+		const bool late = kSkew && (wave_u & 4u) != 0u;
+		constexpr uint32_t kFill = kSkew ? kRing - 2u : kRing - 1u; // tiles every wave issues before the loop
 #pragma unroll
-		for (uint32_t d = 0; d + 1 < kRing; d++) {
+		for (uint32_t d = 0; d < kFill; d++) {
 			read_rows(tile_begin + d, r_cur);
 			issue(tile_begin + d, d, r_cur);
 		}
-		read_rows(tile_begin + (kRing - 1), r_cur);
-		PGH_WAIT_VM(kPieces * (kRing - 3)); // tiles 0 and 1 of the slice have landed
+		if (late) { // (the early waves issue tile kRing - 2 in their first trip)
+			read_rows(tile_begin + kFill, r_cur);
+			issue(tile_begin + kFill, kFill, r_cur);
+			read_rows(tile_begin + kFill + 1u, r_cur);
+			PGH_WAIT_VM(kPieces * (kRing - 3)); // tiles 0 and 1 of the slice have landed
+		} else {
+			read_rows(tile_begin + kFill, r_cur);
+			PGH_WAIT_VM(kPieces * (kFill - 2u));
+		}
 		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 		__builtin_amdgcn_s_barrier();
 		v4i Ua[TS], Ma[TS], Ub[TS], Mb[TS];
@@ -696,11 +816,20 @@ __global__ __launch_bounds__((I8Shape<NT, TS>::kThreads)) void k_score_i8(const 
 		}
 		// (slices hold an even number of tiles: LaunchI8 rounds tiles per slice up, ScoreI8Bytes the tile count)
 		uint32_t slot = 0;
-		for (uint32_t tile = tile_begin; tile < tile_end; tile += 2) {
-			trip(tile, slot, Ua, Ma, Ub, Mb);
-			slot = slot + 1u == kRing ? 0u : slot + 1u;
-			trip(tile + 1u, slot, Ub, Mb, Ua, Ma);
-			slot = slot + 1u == kRing ? 0u : slot + 1u;
+		if (late) {
+			for (uint32_t tile = tile_begin; tile < tile_end; tile += 2) {
+				trip(std::true_type {}, tile, slot, Ua, Ma, Ub, Mb);
+				slot = slot + 1u == kRing ? 0u : slot + 1u;
+				trip(std::true_type {}, tile + 1u, slot, Ub, Mb, Ua, Ma);
+				slot = slot + 1u == kRing ? 0u : slot + 1u;
+			}
+		} else {
+			for (uint32_t tile = tile_begin; tile < tile_end; tile += 2) {
+				trip(std::false_type {}, tile, slot, Ua, Ma, Ub, Mb);
+				slot = slot + 1u == kRing ? 0u : slot + 1u;
+				trip(std::false_type {}, tile + 1u, slot, Ub, Mb, Ua, Ma);
+				slot = slot + 1u == kRing ? 0u : slot + 1u;
+			}
 		}
 		PGH_WAIT_VM(0); // the tail's repeats must land before the LDS is handed back
 #undef PGH_WAIT_VM
@@ -825,26 +954,44 @@ __global__ __launch_bounds__(256) void k_i8_rowidx(const uint32_t *__restrict__ 
 	}
 }
 
-// The tile-major copy: image (tile, group) = the eight 1 KB pieces of k_score_i8<., 4>'s ring slot -- piece p, lane l
-// holds bytes [16 q', 16 q' + 16) of the group's 128-byte stripe of listed row 64 tile + 8 p + l / 8, with
-// q' = (l % 8) ^ 4 [row >= 16 within its k-group pair], the bank swizzle the kernel's reads undo.
+// The tile-major copy: image (tile, group) = the 8 KB a ring slot of k_score_i8<., 4, ., true> holds, BYTE-MAJOR: for
+// byte column b (0 .. 127) of the group's 128-byte stripe and k-group g (variants 16 g .. 16 g + 15 of the tile) the
+// sixteen bytes [listed row 64 tile + 16 g + i][128 group + b], i = 0 .. 15, sit together at
+// b * 64 + 16 * ((g + b / 4) % 4).  A lane of the contraction wants exactly those sixteen bytes (one sample quartet
+// of sixteen variants): one 16-byte LDS read and no byte permutes, where the row-major image costs sixteen word
+// reads and twelve permutes per lane and tile.
 __global__ __launch_bounds__(512) void k_i8_tile_major(const uint8_t *__restrict__ rows, uint64_t pitch,
                                                        const uint32_t *__restrict__ vlist, uint32_t n_var,
                                                        uint8_t *__restrict__ out) {
 	using S = I8Shape<5, 4>; // every TS = 4 shape shares the stripe geometry
+	__shared__ __attribute__((aligned(16))) uint8_t s_tile[kTileVariants][S::kRowBytes + 16]; // (+16: rows on different banks)
 	const uint32_t group = blockIdx.x, tile = blockIdx.y;
-	const uint32_t row = threadIdx.x / S::kChunksPerRow, pos = threadIdx.x % S::kChunksPerRow;
-	const uint32_t logical = pos ^ (((row >> 4) & 1u) * S::kSwizzleChunks);
-	const uint32_t i = tile * kTileVariants + row;
-	const uint32_t v = vlist[i < n_var ? i : n_var - 1u]; // padding rows carry all-zero digits
-	const uint64_t col = static_cast<uint64_t>(group) * S::kRowBytes + 16ull * logical;
-	uint4 w = make_uint4(0, 0, 0, 0);
-	if (col + 16 <= pitch) {
-		w = LoadStream(reinterpret_cast<const uint4 *>(rows + static_cast<uint64_t>(v) * pitch + col));
+	{
+		const uint32_t row = threadIdx.x / S::kChunksPerRow, pos = threadIdx.x % S::kChunksPerRow;
+		const uint32_t i = tile * kTileVariants + row;
+		const uint64_t col = static_cast<uint64_t>(group) * S::kRowBytes + 16ull * pos;
+		uint4 w = make_uint4(0, 0, 0, 0);
+		if (i < n_var && col + 16 <= pitch) { // padding rows carry all-zero digits; so do the bytes past the row
+			w = LoadStream(reinterpret_cast<const uint4 *>(rows + static_cast<uint64_t>(vlist[i]) * pitch + col));
+		}
+		*reinterpret_cast<uint4 *>(&s_tile[row][16u * pos]) = w;
+	}
+	__syncthreads();
+	const uint32_t b = threadIdx.x >> 2, slot = threadIdx.x & 3u;
+	const uint32_t g = (slot - (b >> 2)) & 3u;
+	uint32_t o[4];
+#pragma unroll
+	for (int q = 0; q < 4; q++) {
+		uint32_t v = 0;
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			v |= static_cast<uint32_t>(s_tile[16u * g + 4u * q + j][b]) << (8 * j);
+		}
+		o[q] = v;
 	}
 	StoreStream(reinterpret_cast<uint4 *>(out + (static_cast<uint64_t>(tile) * gridDim.x + group) * S::kGenoBytes) +
 	                threadIdx.x,
-	            w);
+	            make_uint4(o[0], o[1], o[2], o[3]));
 }
 
 } // namespace

@@ -12,7 +12,7 @@ for v in ${VARIANTS:-NONE NO_BUILD NO_DMA NO_DMA_B NO_DMA_G HOT_B}; do
   /opt/rocm/bin/hipcc $FLAGS -DPGH_I8_$v -c score_i8.hip -o /tmp/score_i8_x.o 2>/dev/null || { echo "compile failed: $v"; continue; }
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $X $OBJS /tmp/score_i8_x.o || { echo "link failed: $v"; continue; }
   cd "$GRAFT_REPO_ROOT"
-  PGENHIP_LIB=$X rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/i8x -- python3 bench.py ${BENCH_ARGS:---workload score --score-cols ${COLS:-16}} --steps ${STEPS:-3} --warmup 1 --cpu-seconds 0 > /dev/null 2> /tmp/i8x_err.txt
+  PGENHIP_LIB=$X rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/i8x -- python3 bench.py ${BENCH_ARGS:---workload score --score-cols ${COLS:-16}} --steps ${STEPS:-3} --warmup 1 --cpu-seconds 0 --configs none --no-sql > /dev/null 2> /tmp/i8x_err.txt
   f=$(ls -t /tmp/i8x/*/*_kernel_stats.csv 2>/dev/null | head -1)
   printf "%-28s " "$v"; python3 - "$f" <<'PY'
 import csv, sys
