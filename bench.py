@@ -304,9 +304,15 @@ def verify(args, wl, C, env):
         per_variant = np.where(nonmiss > 0, alt + hc[:, 3] * mean, 0.0)
         want = per_variant @ env["w"]
         got = env["d_score"].cpu().numpy().sum(axis=0)
-        if env["dist"] is not None:
-            return None  # rank 0 holds the reduced sums of every shard; the single-GPU line carries the check
         scale = np.abs(per_variant[:, None] * env["w"]).sum(axis=0)
+        if env["dist"] is not None:
+            # rank 0 holds the reduced sums of every shard: what they must add up to is the sum of the shards' own
+            # expectations (every rank takes part in the all-reduce; ranks other than 0 have nothing to compare)
+            t = torch.tensor(np.concatenate([want, scale]), dtype=torch.float64, device=C.dev)
+            env["dist"].all_reduce(t)
+            want, scale = np.split(t.cpu().numpy(), 2)
+            if C.rank != 0:
+                return True
         ok = bool(np.all(np.abs(got - want) <= 1e-9 * scale))
         if not ok:
             print(f"verify: score column sums {got} != {want} from the tallies", file=sys.stderr)
@@ -327,7 +333,7 @@ def verify(args, wl, C, env):
                 return False
         return True
     if wl == "pca":
-        if env["dist"] is not None or not env["pca_vec"]:
+        if not env["pca_vec"]:
             return None
         # identities that hold at any size: orthonormal eigenvectors, positive descending eigenvalues that repeat from
         # step to step, and their sum bounded by the total variance of the normalised matrix (from the tallies)
@@ -339,6 +345,10 @@ def verify(args, wl, C, env):
         counts = env["counts"][env["keep"]]
         c, inv = env["p_center"], env["p_inv"]
         total = sum((counts[:, g] * ((g - c) * inv) ** 2).sum() for g in range(3))
+        if env["dist"] is not None:  # the variance of the whole matrix: every shard's share (all ranks hold the same PCs)
+            t = torch.tensor([total], dtype=torch.float64, device=C.dev)
+            env["dist"].all_reduce(t)
+            total = float(t.item())
         ok = ok and bool(evs[-1].sum() <= total / env["m_total"] * (1 + 1e-9))
         if not ok:
             print(f"verify: plink_pca identities fail: eigenvalues {evs[-1]}, total variance / M {total / env['m_total']}",
@@ -809,6 +819,12 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but {world} rank(s) were launched (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # PGH_BENCH_ONE_GPU_REHEARSAL=1: every rank on GPU 0 and the process group over gloo (RCCL refuses two ranks on
+    # one device) -- the rank logic of an N-GPU run (shard ranges, reductions, max-over-ranks timing, rank-0 line) on
+    # a one-GPU box; the line says so in `config` and its value means nothing
+    rehearsal = os.environ.get("PGH_BENCH_ONE_GPU_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank} but this node has {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
@@ -820,7 +836,10 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     n = args.samples
     if args.workload.startswith("dosage") and args.variants == 1_000_000:
@@ -940,7 +959,8 @@ def main():
                             f"({'per GPU' if args.scaling == 'weak' else 'total'}), 2-bit hardcalls resident in HBM, "
                             f"seed {SEED}, {MISSING_RATE:.0%} missing"
                             + (f", dosage tracks on every variant with {args.dosage_rate:.0%} of samples explicit"
-                               if args.workload.startswith("dosage") else ""),
+                               if args.workload.startswith("dosage") else "")
+                            + (" [ONE-GPU REHEARSAL: all ranks on GPU 0 over gloo; not a measurement]" if rehearsal else ""),
                 "variants_per_rank": m,
                 "samples": n,
                 "record_bytes": record_bytes,

@@ -73,3 +73,33 @@ def test_all_configs_ride_the_default_line():
     sql = line["sql"]
     assert sql.pop("verified") is True
     assert len(sql) == 4 and all(v["rows"] in (30000, 20000) and v["scan_ms"] > 0 for v in sql.values())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["freq", "score", "pca"])
+def test_two_rank_run_rehearsed_on_one_gpu(workload):
+    """The N-rank logic of bench.py (shard ranges, the reduction of per-sample partials, max-over-ranks timing, the
+    verification vote, rank 0's line) under the driver's own launcher with two ranks -- both on GPU 0 and over gloo,
+    since this box has one GPU and RCCL refuses two ranks on one device.  The line says it is a rehearsal."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PGH_BENCH_ONE_GPU_REHEARSAL="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    shape = {"freq": ["--variants", "40000", "--samples", "30000"],
+             "score": ["--workload", "score", "--variants", "20000", "--samples", "20000"],
+             "pca": ["--workload", "pca", "--variants", "6000", "--samples", "5000"]}[workload]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "2", "--steps", "2",
+                        "--warmup", "1", "--cpu-seconds", "0"] + shape, env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # rank 0 alone prints
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["verified"] is True and line["value"] > 0
+    assert "REHEARSAL" in line["config"]["workload"]
+    assert line["cpu_baseline"] is None and "configs" not in line  # N = 1 only
