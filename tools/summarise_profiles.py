@@ -101,6 +101,43 @@ def main():
             for (k, c), (n, total) in means.items():
                 if k.startswith("k_score_i8"):
                     f.write(f"\"{k}\",{c},{n},{total:.6g},{total / n:.6g}\n")
+    # text outputs: the full-size shell bench, the tally kernels alone, and the per-call kernel list of
+    # tools/hardy_after_freq.py's trace (calls separated by torch's marker kernel)
+    for name in ("shell_bench", "tally_kernels_alone"):
+        src = os.path.join(SRC, f"{name}.txt")
+        if os.path.exists(src):
+            with open(os.path.join(DST, f"{tag}_{name}.txt"), "w") as f:
+                f.writelines(ln for ln in open(src) if "amdgpu.ids" not in ln)
+    trace, phases = os.path.join(SRC, "hardy_after_freq_kernel_trace.csv"), os.path.join(SRC, "hardy_after_freq.txt")
+    if os.path.exists(trace) and os.path.exists(phases):
+        rows = sorted(csv.DictReader(open(trace)), key=lambda r: int(r["Start_Timestamp"]))
+        calls, cur = [], None
+        for r in rows:
+            if "at::native" in r["Kernel_Name"]:
+                if "add" in r["Kernel_Name"]:  # marker.add_(1.0): a call begins (the fill is the marker's creation)
+                    cur = collections.OrderedDict()
+                    calls.append(cur)
+                continue
+            if cur is not None:
+                e = cur.setdefault(short(r["Kernel_Name"]).split("<")[0], [0, 0])
+                e[0] += 1
+                e[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        titles = ["plink_freq (the first call on the source: generator + ONE tally pass)", "plink_hardy", "plink_missing",
+                  "plink_missing mode := 'sample'"]
+        with open(os.path.join(DST, f"{tag}_hardy_after_freq_kernels.txt"), "w") as f:
+            f.write("# rocprofv3 --kernel-trace over tools/hardy_after_freq.py (synth:1000000x500000:20260807:0.02, 16 scan threads, "
+                    "chunks drained):\n# the kernels each table-function call launched; the calls are separated in the trace by a "
+                    "marker kernel of torch's.\n# plink_freq pays for the one walk of the matrix -- k_fused_tally per 131,072-variant "
+                    "batch (16.4 GB) with its two small\n# epilogues -- plink_hardy launches the exact tests over the pass's resident "
+                    "counts and NOTHING that reads the matrix,\n# plink_missing in either mode launches no kernel at all (tally passes "
+                    "started by the process: 1 throughout).\n\n")
+            f.writelines(ln for ln in open(phases) if "amdgpu.ids" not in ln)
+            for title, call in zip(titles, calls):
+                f.write(f"\n## {title}\n")
+                for k, (n, ns) in sorted(call.items(), key=lambda kv: -kv[1][1]):
+                    f.write(f"   {k:36s} {n:3d} launches {ns / 1e6:10.3f} ms in all\n")
+                if not call:
+                    f.write("   (no kernel launched)\n")
     with open(os.path.join(DST, "traffic.json"), "w") as f:
         json.dump(traffic, f, indent=1)
         f.write("\n")
