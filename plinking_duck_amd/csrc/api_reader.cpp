@@ -395,8 +395,12 @@ extern "C" int pgh_hwe_lnp_batch_dev(const void *d_counts, uint32_t n, uint32_t 
 		SetErr(errbuf, "null argument");
 		return PGH_ERR_ARG;
 	}
+	void *order = nullptr;
+	if (const size_t bytes = pgh::HweOrderScratchBytes(n)) {
+		PGH_HIP(PghThreadScratch(bytes, static_cast<hipStream_t>(stream), &order), "hipMalloc(hwe order)");
+	}
 	PGH_HIP(pgh::LaunchHweBatch(static_cast<const uint32_t *>(d_counts), n, midp, static_cast<double *>(d_ln_p),
-	                            static_cast<hipStream_t>(stream)),
+	                            static_cast<hipStream_t>(stream), order),
 	        "hwe kernel");
 	return PGH_OK;
 }
@@ -409,12 +413,15 @@ extern "C" int pgh_hwe_lnp_batch(const uint32_t (*counts)[4], uint32_t n, uint32
 		SetErr(errbuf, "null argument");
 		return PGH_ERR_ARG;
 	}
-	DevBuf d_counts, d_lnp;
+	DevBuf d_counts, d_lnp, d_order;
 	HostSourceFence fence(PghThreadStream()); // the caller's `counts` / `ln_p` are in flight until the stream drains
 	PGH_HIP(d_counts.Alloc(16ull * n), "hipMalloc(hwe)");
 	PGH_HIP(d_lnp.Alloc(8ull * n), "hipMalloc(hwe)");
+	if (const size_t bytes = pgh::HweOrderScratchBytes(n)) {
+		PGH_HIP(d_order.Alloc(bytes), "hipMalloc(hwe)");
+	}
 	PGH_HIP(hipMemcpyAsync(d_counts.p, counts, 16ull * n, hipMemcpyHostToDevice, PghThreadStream()), "hwe upload");
-	PGH_HIP(pgh::LaunchHweBatch(d_counts.As<uint32_t>(), n, midp, d_lnp.As<double>(), PghThreadStream()),
+	PGH_HIP(pgh::LaunchHweBatch(d_counts.As<uint32_t>(), n, midp, d_lnp.As<double>(), PghThreadStream(), d_order.p),
 	        "hwe kernel");
 	PGH_HIP(hipMemcpyAsync(ln_p, d_lnp.p, 8ull * n, hipMemcpyDeviceToHost, PghThreadStream()), "hwe copy");
 	PGH_HIP(hipStreamSynchronize(PghThreadStream()), "hwe sync");

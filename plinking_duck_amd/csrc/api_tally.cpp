@@ -31,6 +31,7 @@ struct TallyPart {
 	double *d_lnp[2] = {nullptr, nullptr};
 	uint32_t *d_missing = nullptr; // uint32[padded N], raw sample order
 	void *d_scratch = nullptr;     // per-slice partial rows of the column tally
+	void *d_hwe_order = nullptr;   // the exact tests' ordering scratch (side stream; kernels.hpp: LaunchHweBatch)
 	size_t scratch_bytes = 0;
 	bool fused = false; // the per-sample tally rides the counts kernel
 	bool missing_enqueued = false;
@@ -106,6 +107,7 @@ void ReleasePart(TallyPart &p) {
 	(void)hipFree(p.d_lnp[1]);
 	(void)hipFree(p.d_missing);
 	(void)hipFree(p.d_scratch);
+	(void)hipFree(p.d_hwe_order);
 	p = TallyPart();
 }
 
@@ -130,6 +132,10 @@ int EnqueueHwe(pgh_tally *t, TallyPart &p, int which, char *errbuf) {
 	const uint32_t midp = which == kHweMidp ? 1u : 0u;
 	const uint32_t n = p.v_end - p.v_begin;
 	PGH_HIP(PghMalloc(reinterpret_cast<void **>(&p.d_lnp[midp]), sizeof(double) * (n ? n : 1)), "hipMalloc(tally ln p)");
+	if (!p.d_hwe_order) { // (every launch of this part runs on p.side, one after the other: one block serves them all)
+		const size_t bytes = pgh::HweOrderScratchBytes(std::max<uint32_t>(n, pgh::kHweOrderMin));
+		PGH_HIP(PghMalloc(&p.d_hwe_order, bytes), "hipMalloc(tally exact-test order)");
+	}
 	int rc = NewEvents(p.ev[which], p.n_batches, errbuf);
 	if (rc != PGH_OK) {
 		return rc;
@@ -143,7 +149,8 @@ int EnqueueHwe(pgh_tally *t, TallyPart &p, int which, char *errbuf) {
 		(void)hipGetLastError(); // hipErrorNotReady of the query above is not an error
 		const uint32_t r0 = b * p.batch, r1 = std::min<uint64_t>(n, static_cast<uint64_t>(last + 1) * p.batch);
 		PGH_HIP(hipStreamWaitEvent(p.side, p.ev[kCounts][last], 0), "tally stream wait");
-		PGH_HIP(pgh::LaunchHweBatch(p.d_counts + 4ull * r0, r1 - r0, midp, p.d_lnp[midp] + r0, p.side), "exact-test kernel");
+		PGH_HIP(pgh::LaunchHweBatch(p.d_counts + 4ull * r0, r1 - r0, midp, p.d_lnp[midp] + r0, p.side, p.d_hwe_order),
+		        "exact-test kernel");
 		PGH_HIP(hipMemcpyAsync(t->h_lnp[midp] + (p.v_begin - t->v_begin) + r0, p.d_lnp[midp] + r0,
 		                       sizeof(double) * (r1 - r0), hipMemcpyDeviceToHost, p.side),
 		        "tally ln p copy");

@@ -146,7 +146,13 @@ hipError_t LaunchAddF64(double *dst, const double *src, uint64_t n, hipStream_t 
 hipError_t LaunchAddU32(uint32_t *dst, const uint32_t *src, uint64_t n, hipStream_t stream);
 
 // ---- HWE --------------------------------------------------------------------
-hipError_t LaunchHweBatch(const uint32_t *counts, uint32_t n, uint32_t midp, double *ln_p, hipStream_t stream);
+// order_scratch: HweOrderScratchBytes(n) bytes the launch may use on `stream`, or NULL.  With it, batches of
+// kHweOrderMin variants and more are tested in order of their minor-allele fraction (waves of equally long walks:
+// tally.hip); the results are the same doubles at the same positions either way.
+constexpr uint32_t kHweOrderMin = 8192;
+size_t HweOrderScratchBytes(uint32_t n);
+hipError_t LaunchHweBatch(const uint32_t *counts, uint32_t n, uint32_t midp, double *ln_p, hipStream_t stream,
+                          void *order_scratch = nullptr);
 // chrX: strata[i] = {female_hets, female_hom1, female_hom2, male1, male2}; one workgroup per variant
 hipError_t LaunchHweXchrBatch(const int32_t *strata, uint32_t n, uint32_t midp, double *ln_p, hipStream_t stream);
 

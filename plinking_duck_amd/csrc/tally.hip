@@ -732,6 +732,79 @@ __global__ __launch_bounds__(64) void k_hwe_batch(const uint32_t *__restrict__ c
 	                 static_cast<int32_t>(counts[4 * i + 2]), midp);
 }
 
+// The exact test's walks are as long as the het-count distribution is wide: ~ sqrt(N) * 2pq steps either side of
+// the mode, so a lane with a common variant runs four times as long as its neighbour with a rare one and the wave
+// waits for its longest lane (a third of k_hwe_batch's lane-cycles at uniform allele frequencies).  Large batches
+// are therefore tested in order of the minor-allele fraction -- a counting sort into 1,024 classes, longest walks
+// first -- so that the 64 variants of a wave walk about equally far.  Results land at the variants' own positions;
+// the order inside a class is whatever the atomics made it and changes nothing.
+constexpr uint32_t kHweClasses = 1024;
+
+__device__ __forceinline__ uint32_t HweClass(const uint32_t *__restrict__ counts, uint32_t i) {
+	const uint64_t hom1 = counts[4 * i], hets = counts[4 * i + 1], hom2 = counts[4 * i + 2];
+	const uint64_t n2 = 2 * (hom1 + hets + hom2);
+	if (n2 == 0) {
+		return kHweClasses - 1u; // nothing to walk: with the shortest
+	}
+	const uint64_t rare = 2 * (hom1 < hom2 ? hom1 : hom2) + hets; // <= n2 / 2
+	const uint32_t c = static_cast<uint32_t>(rare * (2 * kHweClasses - 2) / n2); // 0 .. 1023, widest distribution last
+	return kHweClasses - 1u - c;                                                   // ... first
+}
+
+__global__ __launch_bounds__(256) void k_hwe_classes(const uint32_t *__restrict__ counts, uint32_t n,
+                                                     uint32_t *__restrict__ bins) {
+	__shared__ uint32_t s_bins[kHweClasses];
+	for (uint32_t k = threadIdx.x; k < kHweClasses; k += 256u) {
+		s_bins[k] = 0;
+	}
+	__syncthreads();
+	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+		atomicAdd(&s_bins[HweClass(counts, i)], 1u);
+	}
+	__syncthreads();
+	for (uint32_t k = threadIdx.x; k < kHweClasses; k += 256u) {
+		if (s_bins[k]) {
+			atomicAdd(&bins[k], s_bins[k]);
+		}
+	}
+}
+
+// bins -> first position of every class (one workgroup of kHweClasses lanes)
+__global__ __launch_bounds__(1024) void k_hwe_class_starts(uint32_t *__restrict__ bins) {
+	__shared__ uint32_t s_scan[kHweClasses];
+	const uint32_t k = threadIdx.x;
+	const uint32_t mine = bins[k];
+	s_scan[k] = mine;
+	__syncthreads();
+	for (uint32_t d = 1; d < kHweClasses; d <<= 1) {
+		const uint32_t add = k >= d ? s_scan[k - d] : 0u;
+		__syncthreads();
+		s_scan[k] += add;
+		__syncthreads();
+	}
+	bins[k] = s_scan[k] - mine;
+}
+
+__global__ __launch_bounds__(256) void k_hwe_order(const uint32_t *__restrict__ counts, uint32_t n,
+                                                   uint32_t *__restrict__ cursor, uint32_t *__restrict__ order) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i < n) {
+		order[atomicAdd(&cursor[HweClass(counts, i)], 1u)] = i;
+	}
+}
+
+__global__ __launch_bounds__(64) void k_hwe_batch_ordered(const uint32_t *__restrict__ counts,
+                                                          const uint32_t *__restrict__ order, uint32_t n, uint32_t midp,
+                                                          double *__restrict__ ln_p) {
+	const uint32_t slot = blockIdx.x * 64u + threadIdx.x;
+	if (slot >= n) {
+		return;
+	}
+	const uint32_t i = order[slot];
+	ln_p[i] = HweLnP(static_cast<int32_t>(counts[4 * i + 1]), static_cast<int32_t>(counts[4 * i]),
+	                 static_cast<int32_t>(counts[4 * i + 2]), midp);
+}
+
 // chrX exact test, one workgroup per variant: lanes share out the table columns (male A-allele
 // counts), each walks the female het distribution of its columns, and the three sums meet in a
 // block reduction.  strata[i] = {female_hets, female_hom1, female_hom2, male1, male2}.
@@ -1026,9 +1099,27 @@ hipError_t LaunchFusedTally(const RowView &view, uint32_t v_first, uint32_t v_co
 	return hipGetLastError();
 }
 
-hipError_t LaunchHweBatch(const uint32_t *counts, uint32_t n, uint32_t midp, double *ln_p, hipStream_t stream) {
+size_t HweOrderScratchBytes(uint32_t n) {
+	return n >= kHweOrderMin ? sizeof(uint32_t) * (static_cast<size_t>(n) + kHweClasses) : 0;
+}
+
+hipError_t LaunchHweBatch(const uint32_t *counts, uint32_t n, uint32_t midp, double *ln_p, hipStream_t stream,
+                          void *order_scratch) {
 	if (n == 0) {
 		return hipSuccess;
+	}
+	if (order_scratch && n >= kHweOrderMin) {
+		uint32_t *bins = static_cast<uint32_t *>(order_scratch), *order = bins + kHweClasses;
+		hipError_t e = hipMemsetAsync(bins, 0, sizeof(uint32_t) * kHweClasses, stream);
+		if (e != hipSuccess) {
+			return e;
+		}
+		const uint32_t blocks = (n + 255u) / 256u;
+		hipLaunchKernelGGL(k_hwe_classes, dim3(blocks < 1024u ? blocks : 1024u), dim3(256), 0, stream, counts, n, bins);
+		hipLaunchKernelGGL(k_hwe_class_starts, dim3(1), dim3(kHweClasses), 0, stream, bins);
+		hipLaunchKernelGGL(k_hwe_order, dim3(blocks), dim3(256), 0, stream, counts, n, bins, order);
+		hipLaunchKernelGGL(k_hwe_batch_ordered, dim3((n + 63) / 64), dim3(64), 0, stream, counts, order, n, midp, ln_p);
+		return hipGetLastError();
 	}
 	hipLaunchKernelGGL(k_hwe_batch, dim3((n + 63) / 64), dim3(64), 0, stream, counts, n, midp, ln_p);
 	return hipGetLastError();

@@ -836,3 +836,24 @@ def test_work_blocks_are_kept_between_calls_and_given_back(gpu_lib):
     assert np.allclose(ev1, ev3, rtol=1e-10)
     ds.close()
     assert torch.cuda.mem_get_info(0)[0] >= free0  # pgh_close emptied the list too
+
+
+def test_hwe_batches_tested_in_allele_fraction_order_give_the_same_doubles(gpu_lib):
+    """Batches of 8,192 variants and more are tested in order of their minor-allele fraction (waves of equally long
+    walks); every variant's double must be the one the plain launch gives, at the variant's own position."""
+    rng = np.random.default_rng(77)
+    m, n = 50_000, 120_000
+    p = rng.uniform(0.0, 0.5, size=m)
+    counts = np.zeros((m, 4), dtype=np.uint32)
+    for i0 in range(0, m, 10_000):
+        pp = p[i0:i0 + 10_000, None]
+        probs = np.concatenate([(1 - pp) ** 2 * 0.98, 2 * pp * (1 - pp) * 0.98, pp ** 2 * 0.98, np.full_like(pp, 0.02)], axis=1)
+        counts[i0:i0 + 10_000] = np.array([rng.multinomial(n, q) for q in probs], dtype=np.uint32)
+    counts[17] = 0  # an empty variant
+    counts[18] = (n, 0, 0, 0)  # monomorphic
+    for midp in (False, True):
+        ordered = gpu_lib.hwe_lnp_batch(counts, midp)
+        plain = np.concatenate([gpu_lib.hwe_lnp_batch(counts[i:i + 4096], midp) for i in range(0, m, 4096)])
+        assert np.array_equal(ordered, plain, equal_nan=True)
+        # nothing observed: ln 1; one table possible: p = 1, and half of it under mid-p
+        assert ordered[17] == 0.0 and ordered[18] == (np.log(0.5) if midp else 0.0)
