@@ -1090,3 +1090,144 @@ def test_read_pgen_chunk_pipeline_gives_the_same_rows(gpu_lib, tmp_path, monkeyp
         monkeypatch.setenv("PLINKING_UNPACK_PIPELINE", "1")
         b = F.query("read_pgen", path, threads=3, columns=["ID", "genotypes"], **kw)
         assert len(a) == len(b) > 0 and sorted(a.rows) == sorted(b.rows)
+
+
+# ---- read_pfile_sample_counts_streaming.test, mirrored query by query -----------------------------------
+
+def test_read_pfile_sample_counts_streaming_test_mirror():
+    """orient := 'sample' with genotypes := 'counts' | 'stats' is a per-sample tally, not a matrix: the matrix guard
+    does not apply to it, empty regions give zero rows of counts for every sample, include_genotypes skips samples."""
+    S1 = data_path("shard1")
+    cts = lambda g: (g["hom_ref"], g["het"], g["hom_alt"], g["missing"])
+    q = lambda *a, **k: F.query("read_pfile", *a, orient="sample", **k)
+    r = q(S1, genotypes="counts", columns=["IID", "genotypes"])  # :12-16
+    assert cts(dict(r.rows)["SAMP1"]) == (250, 250, 250, 250)
+    assert (sum(g["het"] for _, g in r.rows), sum(g["missing"] for _, g in r.rows)) == (2000, 2000)  # :18-22
+    tiny = {"plinking_max_matrix_elements": 1}  # :26-33
+    r = q(S1, genotypes="counts", columns=["genotypes"], settings=tiny)
+    assert (len(r), sum(g["het"] for (g,) in r.rows)) == (8, 2000)
+    with pytest.raises(Exception, match="plinking_max_matrix_elements"):  # :36-39 (array / list mode stays guarded)
+        q(S1, columns=["IID"], settings=tiny)
+    r = q(S1, genotypes="stats", columns=["IID", "genotypes"])  # :45-50
+    g = dict(r.rows)["SAMP1"]
+    assert (g["n"], g["af"], g["maf"], g["carrier_count"], round(g["het_rate"], 6)) == (750, 0.5, 0.5, 500, 0.333333)
+    r = q([S1, data_path("shard2"), data_path("shard3")], genotypes="counts", columns=["genotypes"])  # :53-57
+    assert tuple(sum(g[k] for (g,) in r.rows) for k in ("het", "missing", "hom_ref")) == (6000, 6000, 6000)
+    r = q(S1, genotypes="counts", region="chr16:1-2", columns=["genotypes"])  # :60-64
+    assert (len(r), sum(g["het"] for (g,) in r.rows), sum(g["hom_ref"] for (g,) in r.rows)) == (8, 0, 0)
+    assert len(q(S1, genotypes="counts", include_genotypes=["het", "hom_alt"], columns=["IID"])) == 8  # :68-71
+    AM = data_path("all_missing")
+    assert len(q(AM, genotypes="counts", include_genotypes=["het"], columns=["IID"])) == 0  # :74-77
+    r = q(AM, genotypes="counts", include_genotypes=["missing"], columns=["genotypes"])  # :79-82
+    assert (len(r), sum(g["missing"] for (g,) in r.rows)) == (2, 4)
+    r = q(S1, genotypes="counts", samples=["SAMP1", "SAMP2"], columns=["genotypes"])  # :85-88
+    assert (len(r), sum(g["het"] for (g,) in r.rows)) == (2, 500)
+
+
+# ---- edge_cases.test: the queries that reach the .pgen readers -------------------------------------------
+
+def test_edge_cases_test_mirror():
+    """edge_cases.test:58-104 (all-missing genotypes through read_pgen / read_pfile), :133-152 (genotype column
+    types), :154-175 (a .pgen without a .psam), :178-199 (empty regions, unknown variants).  The read_pvar / read_psam
+    queries of that file are the text parsers', outside this path."""
+    AM = data_path("all_missing")
+    r = F.query("read_pgen", AM + ".pgen", columns=["ID", "POS", "genotypes"])
+    assert [(i, g) for i, _, g in r.sorted("POS")] == [("rs_miss1", [None, None]), ("rs_miss2", [None, None])]
+    r = F.query("read_pfile", AM, columns=["ID", "POS", "genotypes"])
+    assert len(r) == 2 and [(i, g) for i, _, g in r.sorted("POS")] == [("rs_miss1", [None, None]), ("rs_miss2", [None, None])]
+    r = F.query("read_pfile", AM, orient="genotype", columns=["genotype"])
+    assert len(r) == 4 and all(g is None for (g,) in r.rows)
+    PE = data_path("pgen_example.pgen")
+    assert F.query("read_pgen", PE, columns=["genotypes"]).types == ["TINYINT[4]"]
+    assert F.query("read_pfile", data_path("pfile_example"), columns=["genotypes"]).types == ["TINYINT[4]"]
+    assert F.query("read_pfile", data_path("pfile_example"), orient="genotype", columns=["genotype"]).types == ["TINYINT"]
+    OR = data_path("pgen_orphan.pgen")
+    r = F.query("read_pgen", OR, columns=["ID", "POS", "genotypes"])
+    assert len(r) == 4 and [i for i, p, _ in r.rows if p == 10000] == ["rs1"] and len(r.rows[0][2]) == 4
+    assert len(F.query("read_pfile", data_path("pfile_example"), region="99:1-100", columns=["ID"])) == 0
+    assert len(F.query("read_pfile", data_path("pfile_example"), orient="genotype", region="99:1-100", columns=["ID"])) == 0
+    with pytest.raises(Exception, match="variant 'nonexistent' not found"):
+        F.query("read_pfile", data_path("pfile_example"), variants=["nonexistent"], columns=["ID"])
+
+
+# ---- integration.test: the cross-reader consistency queries, with Python standing in for the SQL joins -----
+
+def test_integration_test_mirror(oracle):
+    """integration.test: read_pgen and read_pfile agree with each other and with the companion files -- row counts
+    (:11-17), variant metadata (:23-41, :155-165), genotype arrays (:47-53, :108-113), column types (:65-83), the
+    genotype orient against the array form (:89-102, :118-150) and against the .psam (:170-193)."""
+    PG, PF = data_path("pgen_example.pgen"), data_path("pfile_example")
+    meta = ["CHROM", "POS", "ID", "REF", "ALT"]
+    pvar = oracle.load_pvar(data_path("pgen_example.pvar"))
+    want_meta = sorted(zip(pvar["chrom"], pvar["pos"], pvar["id"], pvar["ref"], pvar["alt"]))
+    a = F.query("read_pgen", PG, columns=meta + ["genotypes"])
+    b = F.query("read_pfile", PF, columns=meta + ["genotypes"])
+    assert len(a) == len(b) == len(want_meta) == 4
+    assert sorted(tuple(r[:5]) for r in a.rows) == sorted(tuple(r[:5]) for r in b.rows) == [tuple(w) for w in want_meta]
+    assert sorted((r[2], tuple(r[5])) for r in a.rows) == sorted((r[2], tuple(r[5])) for r in b.rows)
+    assert a.types == b.types == ["VARCHAR", "INTEGER", "VARCHAR", "VARCHAR", "VARCHAR", "TINYINT[4]"]
+    assert [tuple(r[:5]) for r in a.sorted("CHROM", "POS")] == [("1", 10000, "rs1", "A", "G"), ("1", 20000, "rs2", "C", "T"),
+                                                                ("1", 30000, "rs3", "G", "A"), ("2", 15000, "rs4", "T", "C")]
+    g = F.query("read_pfile", PF, orient="genotype", columns=["FID", "IID", "ID", "genotype"])
+    assert g.types[3] == "TINYINT" and len(g) == 16 and len({r[1] for r in g.rows}) == 4
+    assert [(r[1], r[3]) for r in g.sorted("IID") if r[2] == "rs1"] == [("SAMPLE1", 0), ("SAMPLE2", 1), ("SAMPLE3", 2), ("SAMPLE4", None)]
+    psam = oracle.load_psam(PF + ".psam")
+    pos = {iid: k for k, iid in enumerate(sorted(psam["iid"]))}  # ROW_NUMBER() OVER (ORDER BY IID)
+    arrays = {r[2]: r[5] for r in b.rows}
+    assert all(arrays[vid][pos[iid]] == gt for _, iid, vid, gt in g.rows)
+    fid_of = dict(zip(psam["iid"], psam["fid"]))
+    assert [(r[0], r[1], r[3]) for r in g.sorted("IID") if r[2] == "rs1"] == [("FAM001", "SAMPLE1", 0), ("FAM001", "SAMPLE2", 1),
+                                                                            ("FAM002", "SAMPLE3", 2), ("FAM002", "SAMPLE4", None)]
+    assert {(r[0], r[1]) for r in g.rows} == {(fid_of[i], i) for i in psam["iid"]}
+
+
+# ---- tutorial.test: every query of docs/tutorial.md that reaches a .pgen ------------------------------------
+
+def test_tutorial_test_mirror():
+    """tutorial.test sections 2-6 (section 1 is read_pvar / read_psam: the text parsers, outside this path)."""
+    PG, PF, PS = data_path("pgen_example.pgen"), data_path("pfile_example"), data_path("pfile_example.psam")
+    r = F.query("read_pgen", PG, columns=["CHROM", "POS", "ID", "REF", "ALT"])  # :43-49
+    assert sorted(r.rows) == [("1", 10000, "rs1", "A", "G"), ("1", 20000, "rs2", "C", "T"), ("1", 30000, "rs3", "G", "A"),
+                              ("2", 15000, "rs4", "T", "C")]
+    g = F.query("read_pfile", PF, orient="genotype", columns=["CHROM", "POS", "ID", "IID", "genotype"])  # :52-72
+    want = {"rs1": [0, 1, 2, None], "rs2": [1, 1, 0, 2], "rs3": [2, None, 1, 0], "rs4": [0, 0, 1, 2]}
+    where = {"rs1": ("1", 10000), "rs2": ("1", 20000), "rs3": ("1", 30000), "rs4": ("2", 15000)}
+    assert g.sorted("ID", "IID") == [(*where[v], v, f"SAMPLE{k + 1}", gt) for v in sorted(want) for k, gt in enumerate(want[v])]
+    alt = {}
+    for *_, iid, gt in g.rows:  # :75-85
+        alt[iid] = alt.get(iid, 0) + (gt or 0)
+    assert alt == {"SAMPLE1": 3, "SAMPLE2": 2, "SAMPLE3": 4, "SAMPLE4": 4}
+    assert sorted((v, i) for *_, v, i, gt in g.rows if gt == 1) == [("rs1", "SAMPLE2"), ("rs2", "SAMPLE1"), ("rs2", "SAMPLE2"),
+                                                                     ("rs3", "SAMPLE3"), ("rs4", "SAMPLE3")]  # :88-98
+    r = F.query("plink_missing", PG, columns=["ID", "MISSING_CT", "OBS_CT", "F_MISS"])  # :102-109
+    assert r.sorted("ID") == [("rs1", 1, 3, 0.25), ("rs2", 0, 4, 0.0), ("rs3", 1, 3, 0.25), ("rs4", 0, 4, 0.0)]
+    r = F.query("plink_missing", PG, mode="sample", psam=PS, columns=["IID", "MISSING_CT", "OBS_CT", "F_MISS"])  # :112-120
+    assert r.sorted("IID") == [("SAMPLE1", 0, 4, 0.0), ("SAMPLE2", 1, 3, 0.25), ("SAMPLE3", 0, 4, 0.0), ("SAMPLE4", 1, 3, 0.25)]
+    freq = F.query("plink_freq", PG, columns=["ID", "ALT_FREQ", "OBS_CT"])  # :123-130
+    assert freq.sorted("ID") == [("rs1", 0.5, 6), ("rs2", 0.5, 8), ("rs3", 0.5, 6), ("rs4", 0.375, 8)]
+    r = F.query("plink_freq", PG, counts=True, columns=["ID", "HOM_REF_CT", "HET_CT", "HOM_ALT_CT", "MISSING_CT"])  # :133-140
+    assert r.sorted("ID") == [("rs1", 1, 1, 1, 1), ("rs2", 1, 2, 1, 0), ("rs3", 1, 1, 1, 1), ("rs4", 2, 1, 1, 0)]
+    hw = F.query("plink_hardy", PG, columns=["ID", "HOM_REF_CT", "HET_CT", "HOM_ALT_CT", "P_HWE"])  # :143-151
+    assert [(a, b, c, d, round(p, 4)) for a, b, c, d, p in hw.sorted("ID")] == [("rs1", 1, 1, 1, 1.0), ("rs2", 1, 2, 1, 1.0),
+                                                                                ("rs3", 1, 1, 1, 1.0), ("rs4", 2, 1, 1, 0.4286)]
+    assert dict((r[0], r[4]) for r in hw.rows)["rs4"] == pytest.approx(0.4285714285714286, rel=1e-12)  # :154-167
+    r = F.query("plink_ld", PG, variant1="rs1", variant2="rs2", columns=["ID_A", "ID_B", "R2", "OBS_CT"])  # :171-176
+    assert [(a, b, round(x, 4), n) for a, b, x, n in r.rows] == [("rs1", "rs2", 0.75, 3)]
+    r = F.query("plink_ld", PG, r2_threshold=0.0, columns=["ID_A", "ID_B", "R2", "D_PRIME", "OBS_CT"])  # :179-187
+    assert [(a, b, round(x, 4), round(d, 4), n) for a, b, x, d, n in r.sorted("ID_A", "ID_B")] == [
+        ("rs1", "rs2", 0.75, 0.5, 3), ("rs1", "rs3", 1.0, 1.0, 2), ("rs2", "rs3", 0.25, 0.3333, 3)]
+    r = F.query("plink_ld", PG, r2_threshold=0.0, inter_chr=True, columns=["ID_A", "ID_B", "R2", "OBS_CT"])  # :190-200
+    assert [(a, b, round(x, 4), n) for a, b, x, n in r.sorted("ID_A", "ID_B")] == [
+        ("rs1", "rs2", 0.75, 3), ("rs1", "rs3", 1.0, 2), ("rs1", "rs4", 0.75, 3), ("rs2", "rs3", 0.25, 3),
+        ("rs2", "rs4", 0.1818, 4), ("rs3", "rs4", 1.0, 3)]
+    r = F.query("plink_score", PG, psam=PS, weights=[0.5, -0.3, 1.2, 0.8], columns=["IID", "SCORE_SUM", "SCORE_AVG"])  # :204-212
+    got = {i: (s, a) for i, s, a in r.rows}
+    for iid, s, a in (("SAMPLE1", 2.1, 0.2625), ("SAMPLE2", 1.4, 0.175), ("SAMPLE3", 3.0, 0.375), ("SAMPLE4", 1.5, 0.1875)):
+        assert got[iid] == (pytest.approx(s, abs=1e-12), pytest.approx(a, abs=1e-12))
+    r = F.query("plink_score", PG, psam=PS, columns=["IID", "SCORE_SUM", "SCORE_AVG"],  # :215-229
+                weights=[{"id": "rs1", "allele": "G", "weight": 0.5}, {"id": "rs2", "allele": "T", "weight": -0.3},
+                         {"id": "rs4", "allele": "C", "weight": 0.8}])
+    assert [(i, round(s, 2), round(a, 4)) for i, s, a in r.sorted("IID")] == [
+        ("SAMPLE1", -0.3, -0.05), ("SAMPLE2", 0.2, 0.0333), ("SAMPLE3", 1.8, 0.3), ("SAMPLE4", 1.5, 0.25)]
+    r = F.query("plink_freq", data_path("large_example.pgen"), region="1:1-50000", columns=["ALT_FREQ"])  # :249-262
+    assert len(r) == 500 and round(sum(x for (x,) in r.rows) / 500, 4) == 0.5
