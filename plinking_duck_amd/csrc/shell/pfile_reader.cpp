@@ -174,8 +174,9 @@ struct PfileLocalState : public LocalTableFunctionState {
 //! Paths of one fileset (src/pfile_reader.cpp:670-760): `prefix`.pgen or a full .pgen path, the
 //! companions next to it unless named explicitly; returns the (pgen; named...) input the shared binds take.
 static PfileSource ResolveSource(const string &prefix, const string &pgen_override, const TableFunctionBindInput &input,
-                                 bool take_pvar_override) {
+                                 bool take_pvar_override, bool need_psam) {
 	PfileSource src;
+	SynthSpec synth_unused;
 	src.pgen_path = pgen_override;
 	string eff_prefix = prefix;
 	if (src.pgen_path.empty()) {
@@ -208,19 +209,42 @@ static PfileSource ResolveSource(const string &prefix, const string &pgen_overri
 			src.inner.named_parameters[kv.first] = kv.second;
 		}
 	}
+	// companions: next to the prefix, else next to the .pgen itself with its extension replaced (a full .pgen path
+	// given as the prefix or through pgen :=); src/pfile_reader.cpp:715-756
+	string pgen_stem = src.pgen_path;
+	if (pgen_stem.size() > 5 && pgen_stem.compare(pgen_stem.size() - 5, 5, ".pgen") == 0) {
+		pgen_stem.resize(pgen_stem.size() - 5);
+	}
 	auto companion = [&](const char *param, std::initializer_list<const char *> exts) {
-		if (src.inner.named_parameters.count(param) || eff_prefix.empty()) {
+		if (src.inner.named_parameters.count(param)) {
 			return;
 		}
-		for (const char *ext : exts) {
-			if (FileExists(eff_prefix + ext)) {
-				src.inner.named_parameters[param] = Value::VARCHAR(eff_prefix + ext);
-				return;
+		for (const string &stem : {eff_prefix, pgen_stem}) {
+			for (const char *ext : exts) {
+				if (!stem.empty() && FileExists(stem + ext)) {
+					src.inner.named_parameters[param] = Value::VARCHAR(stem + ext);
+					return;
+				}
 			}
 		}
 	};
+	const bool synthetic = ParseSynthPath(src.pgen_path, synth_unused);
+	const string shown = prefix.empty() ? src.pgen_path : prefix;
 	companion("pvar", {".pvar", ".bim"});
+	if (!synthetic && (take_pvar_override || !input.named_parameters.count("pvar")) &&
+	    !src.inner.named_parameters.count("pvar")) {
+		throw InvalidInputException("read_pfile: cannot find .pvar or .bim file for '%s' "
+		                            "(use pvar := 'path' to specify explicitly)",
+		                            shown);
+	}
 	companion("psam", {".psam", ".fam"});
+	// read_pfile is the fileset reader: unlike read_pgen it does not go on without sample metadata (the first source
+	// always needs it, every source under combine_samples := 'identical' without a psam override)
+	if (need_psam && !synthetic && !src.inner.named_parameters.count("psam")) {
+		throw InvalidInputException("read_pfile: cannot find .psam or .fam file for '%s' "
+		                            "(use psam := 'path' to specify explicitly)",
+		                            shown);
+	}
 	return src;
 }
 
@@ -304,7 +328,9 @@ static unique_ptr<FunctionData> PfileBind(ClientContext &context, TableFunctionB
 		}
 	}
 	for (size_t i = 0; i < prefixes.size(); i++) {
-		bind_data->sources.push_back(ResolveSource(prefixes[i], i == 0 ? pgen_override : string(), input, !multi_file));
+		const bool need_psam = i == 0 || (combine == "identical" && !input.named_parameters.count("psam"));
+		bind_data->sources.push_back(
+		    ResolveSource(prefixes[i], i == 0 ? pgen_override : string(), input, !multi_file, need_psam));
 	}
 
 	string genotypes_str = "auto";

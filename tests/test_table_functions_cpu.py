@@ -451,3 +451,38 @@ def test_pvar_side_cache_serves_a_fresh_process(tmp_path):
     assert renamed["first"][2].startswith("qv") and renamed["n"] == first["n"]
     assert glob.glob(str(cache / "*.pvarc")) == files and os.path.getmtime(files[0]) >= stamp
     assert not glob.glob(str(cache / "*.tmp"))
+
+
+def negative_cases():
+    import json
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "negative_cases.json")) as f:
+        return json.load(f)["cases"]
+
+
+def _localise(v):
+    """test/data/x -> this repo's copy of the fixture (paths that do not exist stay nonexistent)."""
+    if isinstance(v, str) and v.startswith("test/data/"):
+        return data_path(v[len("test/data/"):])
+    if isinstance(v, list):
+        return [_localise(x) for x in v]
+    return v
+
+
+def run_negative_case(case, have_device):
+    args = [_localise(a) for a in case["args"]]
+    named = {k: (_localise(v) if k in ("pvar", "psam", "pgen", "sex_file") else v) for k, v in case["named"].items()}
+    with pytest.raises((F.InvalidInputException, F.BinderException, F.IOException)) as e:
+        F.query(case["function"], *args, columns=case.get("columns"), settings=case.get("settings"), **named)
+    if not have_device and "no ROCm-capable device" in str(e.value):
+        pytest.skip("this check sits behind the open of the file on the device; the -m gpu twin runs it")
+    assert case["error_contains"] in str(e.value)
+
+
+@pytest.mark.parametrize("case", negative_cases(), ids=lambda c: c["source"].split("/")[-1])
+def test_reference_negative_cases(case):
+    """Every `statement error` of the reference's *_negative.test files for the eight table functions
+    (tests/golden/negative_cases.json, extracted by tests/golden/make_negative_cases.py): the call must fail, with the
+    substring the reference's test requires in the message.  Most fail before any device call; the few that sit behind
+    the open of the file are skipped here and run by test_table_functions_gpu.py's twin of this test."""
+    run_negative_case(case, have_device=False)

@@ -1231,3 +1231,20 @@ def test_tutorial_test_mirror():
         ("SAMPLE1", -0.3, -0.05), ("SAMPLE2", 0.2, 0.0333), ("SAMPLE3", 1.8, 0.3), ("SAMPLE4", 1.5, 0.25)]
     r = F.query("plink_freq", data_path("large_example.pgen"), region="1:1-50000", columns=["ALT_FREQ"])  # :249-262
     assert len(r) == 500 and round(sum(x for (x,) in r.rows) / 500, 4) == 0.5
+
+
+# ---- every `statement error` of the reference's *_negative.test files (tests/golden/negative_cases.json) ----------
+
+def _all_negative_cases():
+    import test_table_functions_cpu as cpu
+
+    return cpu.negative_cases()
+
+
+@pytest.mark.parametrize("case", _all_negative_cases(), ids=lambda c: c["source"].split("/")[-1])
+def test_reference_negative_cases_on_the_device(case):
+    """The twin of test_table_functions_cpu.py::test_reference_negative_cases with a device present: no case is
+    skipped, including the checks that sit behind the open of the file."""
+    import test_table_functions_cpu as cpu
+
+    cpu.run_negative_case(case, have_device=True)
