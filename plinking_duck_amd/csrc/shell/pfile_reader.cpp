@@ -23,7 +23,7 @@
 //                        columns and the scalar call (or dosage); threads claim runs of <= 64 variants,
 //                        the device unpacks a run in one call, the genotype filter decides which rows
 //                        exist (src/pfile_reader.cpp:2342-2760).
-// Not carried over: phased output outside orient := 'variant', combine_samples other than the
+// Not carried over: combine_samples other than the
 // implicit one, parquet companions.
 
 #include "pgen_reader.hpp"
@@ -119,6 +119,7 @@ struct PfileBindData : public TableFunctionData {
 	// orient := 'sample', per-element modes (ARRAY / LIST / COLUMNS / STRUCT of the effective variants)
 	bool element_mode = false;
 	bool dosages = false;
+	bool phased = false; // cells carry code 3 for a het the phase track reads ALT|REF; elements are TINYINT[2]
 	uint32_t effective_total = 0;
 	vector<uint8_t> all_pass; // per effective variant, list order: no call of it falls outside the genotype filter
 	idx_t first_geno_col = 0; // COLUMNS: the first per-variant column
@@ -418,11 +419,8 @@ static unique_ptr<FunctionData> PfileBind(ClientContext &context, TableFunctionB
 		if (dosages) {
 			throw InvalidInputException("read_pfile: genotypes := '%s' is incompatible with dosages := true", label);
 		}
-	} else if (phased) {
-		throw InvalidInputException("read_pfile: orient := '%s' with phased := true is not available in this build "
-		                            "(use orient := 'variant')",
-		                            bind_data->genotype_orient ? "genotype" : "sample");
 	}
+	bind_data->phased = phased;
 	auto variants_it = input.named_parameters.find("variants");
 	if (variants_it != input.named_parameters.end()) { // single source only (guarded above)
 		auto &src = bind_data->sources[0];
@@ -555,7 +553,9 @@ static unique_ptr<FunctionData> PfileBind(ClientContext &context, TableFunctionB
 			}
 			bind_data->genotypes_col = names.size();
 			names.push_back("genotype");
-			return_types.push_back(dosages ? LogicalType(LogicalType::DOUBLE) : LogicalType(LogicalType::TINYINT));
+			return_types.push_back(phased    ? LogicalType::ARRAY(LogicalType::TINYINT, 2)
+			                       : dosages ? LogicalType(LogicalType::DOUBLE)
+			                                 : LogicalType(LogicalType::TINYINT));
 			return std::move(bind_data);
 		}
 		bind_data->genotype_mode = ResolveGenotypeMode(genotypes_str, bind_data->effective_total, "read_pfile");
@@ -597,7 +597,10 @@ static unique_ptr<FunctionData> PfileBind(ClientContext &context, TableFunctionB
 		                                                                         : MakeGenotypeStatsType());
 		return std::move(bind_data);
 	}
-	const LogicalType elem = dosages ? LogicalType(LogicalType::DOUBLE) : LogicalType(LogicalType::TINYINT);
+	// (scalar columns carry hardcalls or dosages: phase is not representable there, src/pfile_reader.cpp:1488)
+	const LogicalType elem = phased && bind_data->genotype_mode != GenotypeMode::COLUMNS
+	                             ? LogicalType::ARRAY(LogicalType::TINYINT, 2)
+	                             : dosages ? LogicalType(LogicalType::DOUBLE) : LogicalType(LogicalType::TINYINT);
 	if (bind_data->genotype_mode == GenotypeMode::COLUMNS || bind_data->genotype_mode == GenotypeMode::STRUCT) {
 		// one column / field per effective variant, named by its ID, else CHROM:POS (src/pfile_reader.cpp:1443-1512)
 		const char *label = bind_data->genotype_mode == GenotypeMode::COLUMNS ? "columns" : "struct";
@@ -697,6 +700,54 @@ static unique_ptr<LocalTableFunctionState> PfileInitLocal(ExecutionContext &cont
 	return std::move(state);
 }
 
+//! phased := true outside orient := 'variant' (UnpackPhasedGenotypes, src/plink_common.cpp:1549-1584): a het whose
+//! phase track reads ALT|REF becomes code 3 in a matrix of calls {0, 1, 2, -9}; cell(j, k) is the j-th listed
+//! variant's call of output sample k.  Every other het stays 1 = REF|ALT, the canonical order of an unphased one.
+template <class Cell>
+static void MarkAltFirstHets(pgh_dataset *ds, pgh_subset *ss, const uint32_t *variants, uint32_t n_var, uint32_t n_out,
+                             Cell &&cell) {
+	char errbuf[PGH_ERRBUF_LEN] = {0};
+	pgh_reader *rd = nullptr;
+	if (pgh_reader_create(ds, ss, &rd, errbuf) != PGH_OK) {
+		throw IOException("read_pfile: PgrInit failed: %s", string(errbuf));
+	}
+	vector<uint64_t> genovec((n_out + 31) / 32 + 1), present((n_out + 63) / 64 + 1), info((n_out + 63) / 64 + 1);
+	for (uint32_t j = 0; j < n_var; j++) {
+		if (pgh_get_phased(rd, variants[j], genovec.data(), present.data(), info.data()) != PGH_OK) {
+			pgh_reader_destroy(rd);
+			throw IOException("read_pfile: PgrGetP failed for variant %u", variants[j]);
+		}
+		for (uint32_t w = 0; w < (n_out + 63) / 64; w++) {
+			uint64_t bits = present[w] & info[w];
+			while (bits) {
+				const uint32_t k = w * 64 + static_cast<uint32_t>(__builtin_ctzll(bits));
+				bits &= bits - 1;
+				if (k < n_out && cell(j, k) == 1) {
+					cell(j, k) = 3;
+				}
+			}
+		}
+	}
+	pgh_reader_destroy(rd);
+}
+
+//! One element of a phased output: dst is ARRAY(TINYINT, 2); code as in MarkAltFirstHets, -9 = NULL.
+static void PutPhasedPair(Vector &dst, idx_t slot, int8_t code) {
+	auto *alleles = FlatVector::GetData<int8_t>(ArrayVector::GetEntry(dst));
+	int8_t a0 = 0, a1 = 0;
+	if (code == -9) {
+		FlatVector::Validity(dst).SetInvalid(slot);
+	} else if (code == 2) {
+		a0 = a1 = 1;
+	} else if (code == 1) {
+		a1 = 1;
+	} else if (code == 3) {
+		a0 = 1;
+	}
+	alleles[2 * slot] = a0;
+	alleles[2 * slot + 1] = a1;
+}
+
 //! Per-element modes, phase 1 (the reference's pre-read, src/pfile_reader.cpp:1560-1835): every source's
 //! effective variants, sample-major, side by side in list order; then the genotype filter -- a sample stays
 //! if any of its calls is allowed (or it has a missing call and missing is included), and calls outside the
@@ -768,6 +819,18 @@ static void RunSampleMatrixPhase1(const PfileBindData &bind_data, PfileGlobalSta
 			if (in_range || (gf.include_missing && has_missing)) {
 				gstate.keep.push_back(k);
 			}
+		}
+	}
+	if (bind_data.phased && !bind_data.dosages && bind_data.genotype_mode != GenotypeMode::COLUMNS) {
+		size_t first = 0;
+		for (size_t si = 0; si < bind_data.sources.size(); si++) {
+			const auto &eff = bind_data.sources[si].effective;
+			if (!eff.empty()) {
+				MarkAltFirstHets(gstate.datasets[si]->Resident("read_pfile"), gstate.subsets[si] ? gstate.subsets[si]->handle : nullptr,
+				                 eff.data(), static_cast<uint32_t>(eff.size()), static_cast<uint32_t>(n_out),
+				                 [&](uint32_t j, uint32_t k) -> int8_t & { return gstate.calls[k * total + first + j]; });
+			}
+			first += eff.size();
 		}
 	}
 }
@@ -921,6 +984,11 @@ static void GenotypeOrientScan(const PfileBindData &bind_data, PfileGlobalState 
 					throw IOException("read_pfile: %s failed for variant %u: %s", bind_data.dosages ? "PgrGetD" : "PgrGet",
 					                  bind_data.flat_variant[begin], string(errbuf));
 				}
+				if (bind_data.phased && !bind_data.dosages) {
+					MarkAltFirstHets(ds, ss, bind_data.flat_variant.data() + begin, cnt, n_out, [&](uint32_t j, uint32_t k) -> int8_t & {
+						return lstate.batch_calls[static_cast<size_t>(j) * n_out + k];
+					});
+				}
 			}
 		}
 		while (lstate.cur_variant < lstate.batch_cnt && row_variant.size() < STANDARD_VECTOR_SIZE) {
@@ -933,8 +1001,8 @@ static void GenotypeOrientScan(const PfileBindData &bind_data, PfileGlobalState 
 					dose = lstate.batch_dosages[static_cast<size_t>(j) * n_out + k];
 				} else {
 					call = lstate.batch_calls[static_cast<size_t>(j) * n_out + k];
-					if (gf.active) {
-						keep = call == -9 ? gf.include_missing : gf.AllowsCall(static_cast<double>(call));
+					if (gf.active) { // (3: a het read ALT|REF)
+						keep = call == -9 ? gf.include_missing : gf.AllowsCall(static_cast<double>(call == 3 ? 1 : call));
 					}
 				}
 			}
@@ -973,6 +1041,10 @@ static void GenotypeOrientScan(const PfileBindData &bind_data, PfileGlobalState 
 				} else {
 					FlatVector::GetData<double>(vec)[r] = row_dosage[r];
 				}
+			}
+		} else if (bind_data.phased) {
+			for (idx_t r = 0; r < n_rows; r++) {
+				PutPhasedPair(vec, r, row_call[r]);
 			}
 		} else {
 			for (idx_t r = 0; r < n_rows; r++) {
@@ -1073,6 +1145,8 @@ static void PfileScan(ClientContext &context, TableFunctionInput &data_p, DataCh
 					} else {
 						FlatVector::GetData<double>(dst)[slot] = d;
 					}
+				} else if (bind_data.phased && bind_data.genotype_mode != GenotypeMode::COLUMNS) {
+					PutPhasedPair(dst, slot, gstate.calls[static_cast<size_t>(sample_pos) * total + j]);
 				} else {
 					const int8_t g = gstate.calls[static_cast<size_t>(sample_pos) * total + j];
 					if (g == -9) {

@@ -1,0 +1,675 @@
+"""A small evaluator for the SQL around a table-function call in the reference's .test files: select lists of columns,
+struct fields, list elements, a few scalar functions and aggregates; WHERE with comparisons, IS NULL, IN, AND / OR;
+ORDER BY; LIMIT -- over the rows the shells return (dicts of Python values).  Test infrastructure: it stands in for
+DuckDB's executor so that the reference's own queries and expected rows (tests/golden/query_cases.json) can be run
+against the GPU shells.  Anything outside its grammar raises Unsupported and the case is not extracted."""
+import math
+import re
+
+
+class Unsupported(Exception):
+    pass
+
+
+TOKEN = re.compile(r"\s*(?:(?P<num>\d+\.\d*(?:[eE][-+]?\d+)?|\.\d+|\d+(?:[eE][-+]?\d+)?)|(?P<str>'(?:[^']|'')*')|"
+                   r"(?P<id>[A-Za-z_][A-Za-z_0-9]*|\"[^\"]+\")|(?P<op><>|!=|<=|>=|::|[-+*/%(),.\[\]<>=]))")
+AGGREGATES = {"count", "sum", "min", "max", "avg", "bool_and", "bool_or", "list", "first", "any_value"}
+
+
+def tokenize(text):
+    out, i = [], 0
+    text = text.strip()
+    while i < len(text):
+        m = TOKEN.match(text, i)
+        if not m or m.end() == i:
+            raise Unsupported("token at " + text[i:i + 20])
+        kind = m.lastgroup
+        out.append((kind, m.group(kind)))
+        i = m.end()
+    return out
+
+
+class Parser:
+    def __init__(self, text):
+        self.t = tokenize(text)
+        self.i = 0
+
+    def peek(self, k=0):
+        return self.t[self.i + k] if self.i + k < len(self.t) else (None, None)
+
+    def kw(self, *words):
+        kind, v = self.peek()
+        return kind == "id" and v.lower() in words
+
+    def take(self, kind=None, val=None):
+        k, v = self.peek()
+        if (kind and k != kind) or (val is not None and (v or "").lower() != val):
+            raise Unsupported(f"expected {val or kind} at {v}")
+        self.i += 1
+        return v
+
+    def done(self):
+        return self.i >= len(self.t)
+
+    # expression grammar: or > and > not > comparison > additive > multiplicative > unary > postfix > primary
+    def expr(self):
+        left = self.and_()
+        while self.kw("or"):
+            self.take()
+            left = ("or", left, self.and_())
+        return left
+
+    def and_(self):
+        left = self.not_()
+        while self.kw("and"):
+            self.take()
+            left = ("and", left, self.not_())
+        return left
+
+    def not_(self):
+        if self.kw("not"):
+            self.take()
+            return ("not", self.not_())
+        return self.cmp()
+
+    def cmp(self):
+        left = self.add()
+        k, v = self.peek()
+        if k == "op" and v in ("=", "<>", "!=", "<", "<=", ">", ">="):
+            self.take()
+            return ("cmp", v, left, self.add())
+        if self.kw("is"):
+            self.take()
+            neg = False
+            if self.kw("not"):
+                self.take()
+                neg = True
+            if self.kw("null"):
+                self.take()
+                return ("isnull", neg, left)
+            if self.kw("distinct"):
+                self.take()
+                self.take("id", "from")
+                return ("distinct", not neg, left, self.add())
+            raise Unsupported("IS ...")
+        neg = False
+        if self.kw("not") and self.peek(1)[1] and self.peek(1)[1].lower() in ("in", "like"):
+            self.take()
+            neg = True
+        if self.kw("in"):
+            self.take()
+            self.take("op", "(")
+            items = [self.expr()]
+            while self.peek()[1] == ",":
+                self.take()
+                items.append(self.expr())
+            self.take("op", ")")
+            return ("in", neg, left, items)
+        if self.kw("like"):
+            self.take()
+            return ("like", neg, left, self.add())
+        if self.kw("between"):
+            self.take()
+            lo = self.add()
+            self.take("id", "and")
+            return ("and", ("cmp", ">=", left, lo), ("cmp", "<=", left, self.add()))
+        return left
+
+    def add(self):
+        left = self.mul()
+        while self.peek()[0] == "op" and self.peek()[1] in ("+", "-"):
+            op = self.take()
+            left = ("arith", op, left, self.mul())
+        return left
+
+    def mul(self):
+        left = self.unary()
+        while self.peek()[0] == "op" and self.peek()[1] in ("*", "/", "%"):
+            op = self.take()
+            left = ("arith", op, left, self.unary())
+        return left
+
+    def unary(self):
+        if self.peek() == ("op", "-"):
+            self.take()
+            return ("neg", self.unary())
+        return self.postfix()
+
+    def postfix(self):
+        node = self.primary()
+        while True:
+            k, v = self.peek()
+            if v == "." and self.peek(1)[0] == "id":
+                self.take()
+                node = ("field", node, self.take("id").strip('"'))
+            elif v == "[":
+                self.take()
+                idx = self.expr()
+                self.take("op", "]")
+                node = ("index", node, idx)
+            elif v == "::":
+                self.take()
+                node = ("cast", node, self.type_name())
+            else:
+                return node
+
+    def type_name(self):
+        name = self.take("id").upper()
+        while self.peek()[1] in ("[", "("):
+            close = "]" if self.take() == "[" else ")"
+            depth = 1
+            while depth:
+                _, v = self.peek()
+                if v is None:
+                    raise Unsupported("type")
+                self.take()
+                depth += v in ("[", "(")
+                depth -= v in ("]", ")")
+            name += "[]" if close == "]" else ""
+        return name
+
+    def primary(self):
+        k, v = self.peek()
+        if k == "num":
+            self.take()
+            return ("lit", float(v) if re.search(r"[.eE]", v) else int(v))
+        if k == "str":
+            self.take()
+            return ("lit", v[1:-1].replace("''", "'"))
+        if v == "(":
+            self.take()
+            e = self.expr()
+            self.take("op", ")")
+            return e
+        if v == "[":
+            self.take()
+            items = []
+            while self.peek()[1] != "]":
+                items.append(self.expr())
+                if self.peek()[1] == ",":
+                    self.take()
+            self.take()
+            return ("list", items)
+        if v == "*":
+            self.take()
+            return ("star",)
+        if k == "id":
+            low = v.lower()
+            if low in ("true", "false"):
+                self.take()
+                return ("lit", low == "true")
+            if low == "null":
+                self.take()
+                return ("lit", None)
+            if low == "cast" and self.peek(1)[1] == "(":
+                self.take()
+                self.take()
+                e = self.expr()
+                self.take("id", "as")
+                t = self.type_name()
+                self.take("op", ")")
+                return ("cast", e, t)
+            if low == "case":
+                raise Unsupported("CASE")
+            if self.peek(1)[1] == "(":
+                self.take()
+                self.take()
+                args = []
+                if self.kw("distinct"):
+                    raise Unsupported("DISTINCT")
+                while self.peek()[1] != ")":
+                    args.append(self.expr())
+                    if self.peek()[1] == ",":
+                        self.take()
+                self.take()
+                if self.kw("filter") or self.kw("over"):
+                    raise Unsupported("FILTER / OVER")
+                return ("call", low, args)
+            self.take()
+            return ("col", v.strip('"'))
+        raise Unsupported(f"primary at {v}")
+
+
+def split_top(text):
+    """Select-list / order-by items: split at top-level commas."""
+    items, depth, cur, quote = [], 0, [], False
+    for ch in text:
+        if ch == "'":
+            quote = not quote
+        if not quote:
+            depth += ch in "([{"
+            depth -= ch in ")]}"
+            if ch == "," and depth == 0:
+                items.append("".join(cur).strip())
+                cur = []
+                continue
+        cur.append(ch)
+    items.append("".join(cur).strip())
+    return items
+
+
+def has_aggregate(node):
+    if not isinstance(node, tuple):
+        return False
+    if node[0] == "call" and node[1] in AGGREGATES:
+        return True
+    return any(has_aggregate(x) if isinstance(x, tuple) else any(has_aggregate(y) for y in x) if isinstance(x, list) else False
+               for x in node[1:])
+
+
+SCALARS = {"round", "abs", "typeof", "len", "length", "array_length", "list_sum", "list_count", "list_contains", "lower", "upper",
+           "floor", "ceil", "coalesce", "isnan", "list_min", "list_max", "array_extract", "list_extract", "struct_extract", "sqrt",
+           "ln", "exp", "greatest", "least"}
+
+
+def check(node):
+    if not isinstance(node, tuple):
+        return
+    if node[0] == "call" and node[1] not in SCALARS and node[1] not in AGGREGATES:
+        raise Unsupported("function " + node[1])
+    for x in node[1:]:
+        if isinstance(x, tuple):
+            check(x)
+        elif isinstance(x, list):
+            for y in x:
+                check(y)
+
+
+def compile_query(select, where, order):
+    items = []
+    for text in split_top(select):
+        text = re.sub(r"(?i)\s+AS\s+\"?[A-Za-z_][A-Za-z_0-9]*\"?\s*$", "", text)
+        p = Parser(text)
+        node = p.expr()
+        if not p.done():  # an alias without AS
+            k, v = p.peek()
+            if k == "id" and p.i == len(p.t) - 1:
+                pass
+            else:
+                raise Unsupported("select item: " + text[:30])
+        check(node)
+        items.append(node)
+    aggs = [has_aggregate(n) for n in items]
+    if any(aggs) and not all(aggs):
+        raise Unsupported("aggregates next to plain columns")
+    w = None
+    if where:
+        p = Parser(where)
+        w = p.expr()
+        if not p.done():
+            raise Unsupported("where")
+        check(w)
+    o = []
+    if order:
+        for text in split_top(order):
+            m = re.match(r"(?is)^(.*?)(?:\s+(ASC|DESC))?(?:\s+NULLS\s+(FIRST|LAST))?$", text)
+            p = Parser(m.group(1))
+            node = p.expr()
+            if not p.done():
+                raise Unsupported("order by")
+            check(node)
+            o.append((node, (m.group(2) or "ASC").upper() == "DESC", (m.group(3) or "").upper()))
+    return items, w, o, any(aggs)
+
+
+# ---- evaluation ----
+
+def type_of(v, declared=None):
+    return declared
+
+
+def ev(node, row, types):
+    kind = node[0]
+    if kind == "lit":
+        return node[1]
+    if kind == "col":
+        for name in (node[1], node[1].upper(), node[1].lower()):
+            if name in row:
+                return row[name]
+        for name in row:
+            if name.lower() == node[1].lower():
+                return row[name]
+        raise KeyError(node[1])
+    if kind == "field":
+        base = ev(node[1], row, types)
+        return None if base is None else base[node[2]]
+    if kind == "index":
+        base, idx = ev(node[1], row, types), ev(node[2], row, types)
+        if base is None or idx is None:
+            return None
+        if isinstance(base, dict):
+            return base[idx]
+        return base[idx - 1] if 1 <= idx <= len(base) else None
+    if kind == "list":
+        return [ev(x, row, types) for x in node[1]]
+    if kind == "neg":
+        v = ev(node[1], row, types)
+        return None if v is None else -v
+    if kind == "arith":
+        a, b = ev(node[2], row, types), ev(node[3], row, types)
+        if a is None or b is None:
+            return None
+        if node[1] == "+":
+            return a + b
+        if node[1] == "-":
+            return a - b
+        if node[1] == "*":
+            return a * b
+        if node[1] == "/":
+            return a / b if b else None
+        return a % b
+    if kind == "cmp":
+        a, b = ev(node[2], row, types), ev(node[3], row, types)
+        if a is None or b is None:
+            return None
+        if isinstance(a, tuple):
+            a = list(a)
+        op = node[1]
+        return (a == b if op == "=" else a != b if op in ("<>", "!=") else a < b if op == "<" else a <= b if op == "<=" else
+                a > b if op == ">" else a >= b)
+    if kind == "distinct":
+        a, b = ev(node[2], row, types), ev(node[3], row, types)
+        return (a != b) == node[1]
+    if kind == "isnull":
+        return (ev(node[2], row, types) is None) != node[1]
+    if kind == "in":
+        a = ev(node[2], row, types)
+        if a is None:
+            return None
+        hit = a in [ev(x, row, types) for x in node[3]]
+        return hit != node[1]
+    if kind == "like":
+        a, pat = ev(node[2], row, types), ev(node[3], row, types)
+        if a is None:
+            return None
+        rx = "^" + "".join(".*" if c == "%" else "." if c == "_" else re.escape(c) for c in pat) + "$"
+        return (re.match(rx, a) is not None) != node[1]
+    if kind == "and":
+        a, b = ev(node[1], row, types), ev(node[2], row, types)
+        return False if a is False or b is False else None if a is None or b is None else True
+    if kind == "or":
+        a, b = ev(node[1], row, types), ev(node[2], row, types)
+        return True if a is True or b is True else None if a is None or b is None else False
+    if kind == "not":
+        a = ev(node[1], row, types)
+        return None if a is None else not a
+    if kind == "cast":
+        v, t = ev(node[1], row, types), node[2]
+        if v is None:
+            return None
+        if t in ("VARCHAR", "TEXT", "STRING"):
+            return duck_str(v)
+        if t in ("INTEGER", "BIGINT", "INT", "UINTEGER", "SMALLINT", "TINYINT", "UBIGINT", "HUGEINT"):
+            return int(round(v)) if isinstance(v, float) else int(v)
+        if t in ("DOUBLE", "FLOAT", "REAL"):
+            return float(v)
+        if t == "BOOLEAN":
+            return bool(v)
+        if t.endswith("[]"):  # a list / array type: the value is the list
+            return list(v)
+        raise Unsupported("cast to " + t)
+    if kind == "call":
+        name = node[1]
+        if name == "typeof":
+            return types_of(node[2][0], types)
+        a = [ev(x, row, types) for x in node[2]]
+        if name == "coalesce":
+            return next((x for x in a if x is not None), None)
+        if a and a[0] is None:
+            return None
+        if name == "round":
+            nd = a[1] if len(a) > 1 else 0
+            q = 10 ** nd
+            v = a[0] * q
+            r = math.floor(abs(v) + 0.5) * (1 if v >= 0 else -1) / q  # half away from zero, as DuckDB rounds
+            return r if nd > 0 or isinstance(a[0], float) else int(r)
+        if name == "abs":
+            return abs(a[0])
+        if name in ("len", "length", "array_length", "list_count"):
+            return len(a[0]) if name != "list_count" else sum(x is not None for x in a[0])
+        if name == "list_sum":
+            vals = [x for x in a[0] if x is not None]
+            return sum(vals) if vals else None
+        if name == "list_min":
+            vals = [x for x in a[0] if x is not None]
+            return min(vals) if vals else None
+        if name == "list_max":
+            vals = [x for x in a[0] if x is not None]
+            return max(vals) if vals else None
+        if name == "list_contains":
+            return a[1] in a[0]
+        if name in ("array_extract", "list_extract"):
+            return a[0][a[1] - 1] if 1 <= a[1] <= len(a[0]) else None
+        if name == "struct_extract":
+            return a[0][a[1]]
+        if name == "lower":
+            return a[0].lower()
+        if name == "upper":
+            return a[0].upper()
+        if name == "floor":
+            return math.floor(a[0])
+        if name == "ceil":
+            return math.ceil(a[0])
+        if name == "isnan":
+            return isinstance(a[0], float) and math.isnan(a[0])
+        if name == "sqrt":
+            return math.sqrt(a[0])
+        if name == "ln":
+            return math.log(a[0])
+        if name == "exp":
+            return math.exp(a[0])
+        if name == "greatest":
+            return max(a)
+        if name == "least":
+            return min(a)
+    raise Unsupported("eval " + kind)
+
+
+def types_of(node, types):
+    """typeof(expr) for a column, a struct field or a list element of one."""
+    if node[0] == "col":
+        for name, t in types.items():
+            if name.lower() == node[1].lower():
+                return t
+        raise KeyError(node[1])
+    if node[0] == "field":
+        base = types_of(node[1], types)
+        m = re.search(r"[(,]\s*\"?" + re.escape(node[2]) + r"\"?\s+([A-Z]+(?:\([^()]*\))?(?:\[\d*\])*)", base)
+        if m:
+            return m.group(1)
+    if node[0] == "index":
+        base = types_of(node[1], types)
+        m = re.match(r"^(.*)\[\d*\]$", base)
+        if m:
+            return m.group(1)
+    raise Unsupported("typeof of an expression")
+
+
+def agg(node, rows, types):
+    if node[0] == "call" and node[1] in AGGREGATES:
+        name, args = node[1], node[2]
+        if name == "count":
+            if not args or args[0] == ("star",):
+                return len(rows)
+            return sum(ev(args[0], r, types) is not None for r in rows)
+        vals = [ev(args[0], r, types) for r in rows]
+        if name == "list":
+            return vals
+        vals = [v for v in vals if v is not None]
+        if name in ("first", "any_value"):
+            return vals[0] if vals else None
+        if not vals:
+            return None
+        if name == "sum":
+            return math.fsum(vals) if any(isinstance(v, float) for v in vals) else sum(vals)
+        if name == "min":
+            return min(vals)
+        if name == "max":
+            return max(vals)
+        if name == "avg":
+            return math.fsum(vals) / len(vals)
+        if name == "bool_and":
+            return all(vals)
+        if name == "bool_or":
+            return any(vals)
+    if node[0] in ("lit",):
+        return node[1]
+    # an expression over aggregates: evaluate the aggregates first
+    if node[0] == "arith":
+        a, b = agg(node[2], rows, types), agg(node[3], rows, types)
+        if a is None or b is None:
+            return None
+        return ev(("arith", node[1], ("lit", a), ("lit", b)), {}, types)
+    if node[0] == "cmp":
+        return ev(("cmp", node[1], ("lit", agg(node[2], rows, types)), ("lit", agg(node[3], rows, types))), {}, types)
+    if node[0] == "cast":
+        return ev(("cast", ("lit", agg(node[1], rows, types)), node[2]), {}, types)
+    if node[0] == "call":
+        return ev(("call", node[1], [("lit", agg(x, rows, types)) for x in node[2]]), {}, types)
+    if node[0] == "neg":
+        v = agg(node[1], rows, types)
+        return None if v is None else -v
+    raise Unsupported("aggregate expression")
+
+
+def run(compiled, rows, names, types, limit=None):
+    """rows: tuples in `names` order -> list of result tuples."""
+    items, where, order, is_agg = compiled
+    tmap = dict(zip(names, types))
+    dicts = [dict(zip(names, r)) for r in rows]
+    if where is not None:
+        dicts = [d for d in dicts if ev(where, d, tmap) is True]
+    if order:
+        def key(d):
+            out = []
+            for node, desc, nulls in order:
+                v = ev(node, d, tmap)
+                null_last = (nulls == "LAST") if nulls else True  # DuckDB: NULLS LAST by default for ASC and DESC alike
+                out.append((v is None) == null_last)
+                out.append(Rev(v) if desc else Fwd(v))
+            return tuple(out)
+        dicts.sort(key=key)
+    if is_agg:
+        return [tuple(agg(n, dicts, tmap) for n in items)]
+    if limit is not None:
+        dicts = dicts[:limit]
+    out = []
+    for d in dicts:
+        row = []
+        for n in items:
+            if n == ("star",):
+                row.extend(d[c] for c in names)
+            else:
+                row.append(ev(n, d, tmap))
+        out.append(tuple(row))
+    return out
+
+
+class Fwd:
+    def __init__(self, v):
+        self.v = v
+
+    def __lt__(self, o):
+        return False if self.v is None or o.v is None else self.v < o.v
+
+    def __eq__(self, o):
+        return self.v == o.v
+
+
+class Rev(Fwd):
+    def __lt__(self, o):
+        return False if self.v is None or o.v is None else self.v > o.v
+
+
+def referenced_columns(compiled):
+    """Column names the query reads, or None when it reads every column (`*`)."""
+    items, where, order, _ = compiled
+    cols, star = set(), False
+
+    def walk(n):
+        nonlocal star
+        if isinstance(n, tuple):
+            if n[0] == "col":
+                cols.add(n[1])
+            if n == ("star",):
+                star = True
+            for x in n[1:]:
+                walk(x)
+        elif isinstance(n, list):
+            for x in n:
+                walk(x)
+
+    for n in items:
+        if n == ("star",):
+            star = True
+        elif n[0] == "call" and n[1] == "count" and (not n[2] or n[2][0] == ("star",)):
+            continue
+        else:
+            walk(n)
+    walk(where)
+    for node, _, _ in order:
+        walk(node)
+    return None if star else cols
+
+
+def duck_str(v):
+    """DuckDB's text rendering of a value (what a T column of a sqllogictest shows)."""
+    if v is None:
+        return "NULL"
+    if isinstance(v, bool):
+        return "true" if v else "false"
+    if isinstance(v, float):
+        if math.isnan(v):
+            return "nan"
+        if math.isinf(v):
+            return "inf" if v > 0 else "-inf"
+        if v == int(v) and abs(v) < 1e15:
+            return f"{v:.1f}"
+        return repr(v)
+    if isinstance(v, (list, tuple)):
+        return "[" + ", ".join(duck_str(x) for x in v) + "]"
+    if isinstance(v, dict):
+        return "{" + ", ".join(f"'{k}': {duck_str(x)}" for k, x in v.items()) + "}"
+    return str(v)
+
+
+NUMBER = re.compile(r"-?\d+\.\d+(?:[eE][-+]?\d+)?|-?\d+[eE][-+]?\d+|-?\d+")
+
+
+def same_text(got, want, rel=1e-9, abs_tol=1e-12):
+    """Equal texts, numbers inside compared with a tolerance (a double's last digits depend on summation order)."""
+    if got == want:
+        return True
+    g_parts, w_parts = NUMBER.split(got), NUMBER.split(want)
+    if g_parts != w_parts:
+        return False
+    g_num, w_num = NUMBER.findall(got), NUMBER.findall(want)
+    return all(math.isclose(float(a), float(b), rel_tol=rel, abs_tol=abs_tol) for a, b in zip(g_num, w_num))
+
+
+def matches(value, want, type_char):
+    """One cell against the expected text of the reference's test."""
+    if want == "NULL":
+        return value is None
+    if value is None:
+        return False
+    if type_char == "I":
+        if isinstance(value, bool):
+            return want in ("1", "true") if value else want in ("0", "false")
+        try:
+            if re.fullmatch(r"-?\d+", want):
+                return int(round(float(value))) == int(want) and (not isinstance(value, float) or abs(value - round(value)) < 1e-9)
+            return math.isclose(float(value), float(want), rel_tol=1e-6, abs_tol=1e-9)  # (a real under an I: compared as one)
+        except (TypeError, ValueError):
+            return same_text(duck_str(value), want)
+    if type_char == "R":
+        try:
+            if isinstance(value, bool):
+                return False
+            w = float(want)
+            v = float(value)
+            return (math.isnan(v) and math.isnan(w)) or math.isclose(v, w, rel_tol=1e-6, abs_tol=1e-9)
+        except (TypeError, ValueError):
+            return same_text(duck_str(value), want)
+    text = duck_str(value)
+    return same_text(text, want) or (want == "(empty)" and text == "")

@@ -265,7 +265,6 @@ def test_read_pfile_sample_orient_schemas():
     assert F.query("read_pfile", P, orient="genotype", dosages=True, columns=["IID"]).all_types[-1] == "DOUBLE"
     for mode in ("columns", "struct"):
         assert "genotype mode already produces scalar output" in err("read_pfile", P, orient="genotype", genotypes=mode)
-    assert "phased := true is not available in this build" in err("read_pfile", P, orient="genotype", phased=True)
 
 
 def test_read_pfile_sample_multifile_bind():
@@ -324,7 +323,6 @@ def test_read_pfile_bind():
     assert "incompatible with dosages" in err("read_pfile", PFX, orient="sample", genotypes="stats", dosages=True)
     assert "dosages and phased cannot both be true" in err("read_pfile", PFX, dosages=True, phased=True)
     assert "read_pfile: invalid genotypes value" in err("read_pfile", PFX, genotypes="matrix")
-    assert "phased := true is not available in this build" in err("read_pfile", PFX, orient="sample", phased=True)
     assert "Invalid named parameter" in err("read_pgen", EX, region="1:1-2", exc=F.BinderException)
     # read_pfile_negative.test:113-131 and the open forms of its region grammar
     assert "invalid region" in err("read_pfile", PFX, region="invalid:abc-def")
