@@ -264,11 +264,11 @@ def test_score_matches_oracle(gpu_lib, oracle, mode, ncols):
         assert np.all(np.abs(s2 - es) <= REL * np.maximum(np.abs(es), 1e-9 * scale))
 
 
-@pytest.mark.parametrize("ncols", [2, 3, 5, 15, 17, 20, 21, 24, 25, 28, 29, 33, 52])
+@pytest.mark.parametrize("ncols", [2, 3, 5, 9, 11, 13, 15, 17, 18, 20, 21, 24, 25, 28, 29, 33, 52])
 def test_score_any_number_of_columns(gpu_lib, oracle, ncols):
     """Every count of weight columns: 7 digit columns each + 6 for the dosage sum and the missing count fill
-    1..8 sixteen-column tiles of the int8 contraction (k_score_i8<NT, TS>); more than 17 columns take a second
-    pass."""
+    1..10 sixteen-column tiles of the int8 contraction (k_score_i8<NT, TS>: 9, 11, 13, 16-17, 18, 20-22 columns are the
+    software-pipelined shapes of 5 .. 10 tiles); more than 22 columns take a second pass."""
     m, n = 150, 1500
     host = np.stack([gpu_lib.synth_record_host(v, n, SEED + 3, 0.05) for v in range(m)])
     ds = gpu_lib.Dataset.from_host_rows(host, n)
@@ -398,7 +398,7 @@ def test_pca_at_baseline_width(gpu_lib):
         assert ev[pc] * (1 - 1e-9) <= rayleigh <= trace_over_m
 
 
-@pytest.mark.parametrize("n_pcs,m,n", [(2, 700, 2100), (9, 700, 2100), (10, 700, 2100), (11, 700, 2100),
+@pytest.mark.parametrize("n_pcs,m,n", [(2, 700, 2100), (5, 700, 2100), (6, 700, 2100), (9, 700, 2100), (10, 700, 2100), (11, 700, 2100),
                                        (13, 700, 2100), (2, 300, 20000), (10, 900, 20000)])
 def test_pca_matches_oracle_on_wide_rows(gpu_lib, oracle, n_pcs, m, n):
     """pgh_pca against the numpy restatement with rows wide enough (>= 512 B) for the MFMA Step A;
@@ -757,7 +757,7 @@ def test_score_with_non_finite_weights_matches_the_reference_arithmetic(gpu_lib,
     assert np.array_equal(got[2], clean[2]) and np.allclose(got[1], clean[1])
 
 
-@pytest.mark.parametrize("ncols", [10, 16, 22, 30])
+@pytest.mark.parametrize("ncols", [10, 12, 14, 16, 18, 22, 30])
 def test_kept_score_plans_stream_tile_major_copies(gpu_lib, oracle, ncols, monkeypatch):
     """A kept plan with many weight columns contracts a tile-major copy of its rows (contiguous 8 KB tile images per
     workgroup instead of 128 bytes of each of 64 rows); a one-shot pgh_score reads the rows themselves.  Same sums --
