@@ -1,6 +1,6 @@
-"""Extracts the `query` blocks of the reference's test/sql/*.test files that are ONE call of one of this path's table
-functions with a select list, WHERE, ORDER BY and LIMIT simple enough for tests/sqlmini.py to evaluate, into
-tests/golden/query_cases.json: the call (function, arguments), the clauses as text, the column-type string and the
+"""Extracts the `query` blocks of the reference's test/sql/*.test files whose relations are all calls of this path's
+table functions and whose SQL tests/sqlmini.py can evaluate (select lists, WHERE, GROUP BY, ORDER BY, LIMIT, subqueries
+in FROM and as scalars, DESCRIBE) into tests/golden/query_cases.json: the statement, the column-type string and the
 expected rows exactly as the reference's test states them.  Run in the build container (reads /root/reference/test/sql
 as text); the fixture is what the tests load.
 
@@ -25,38 +25,13 @@ SKIP_FILES = re.compile(r"^(plink_glm|read_plink_vcf|read_pvar|read_psam|parquet
                         r"read_file_search_path|flexible_companions)")
 
 
-def split_call(sql):
-    m = re.search(r"(?is)\bFROM\s+(" + "|".join(FUNCTIONS) + r")\s*\(", sql)
-    if not m:
-        raise Unparsed("no call of this path")
-    if len(re.findall(r"(?i)\bFROM\b", sql)) != 1 or re.search(r"(?i)\b(JOIN|GROUP\s+BY|UNION|EXCEPT|WITH|HAVING|OVER|DISTINCT|UNNEST)\b", sql):
-        raise Unparsed("more than one relation / grouping")
-    fn, i, args, named = m.group(1), m.end(), [], {}
-    while True:
-        while sql[i].isspace():
-            i += 1
-        if sql[i] == ")":
-            break
-        k = re.match(r"([A-Za-z_][A-Za-z_0-9]*)\s*:=", sql[i:])
-        if k:
-            v, i = parse_value(sql, i + len(k.group(0)))
-            named[k.group(1)] = v
-        else:
-            v, i = parse_value(sql, i)
-            args.append(v)
-        while sql[i].isspace():
-            i += 1
-        if sql[i] == ",":
-            i += 1
-    head = re.match(r"(?is)\s*SELECT\s+(.*)$", sql[:m.start()])
-    if not head:
-        raise Unparsed("no select list")
-    tail = sql[i + 1:].strip().rstrip(";").strip()
-    tail = re.sub(r"(?is)^(AS\s+)?[a-z_][a-z_0-9]*\s*(?=(WHERE|ORDER|LIMIT|$))", "", tail) if not re.match(r"(?i)(WHERE|ORDER|LIMIT)\b", tail) else tail
-    mm = re.match(r"(?is)^(?:WHERE\s+(?P<where>.*?))?\s*(?:ORDER\s+BY\s+(?P<order>.*?))?\s*(?:LIMIT\s+(?P<limit>\d+))?\s*$", tail)
-    if not mm:
-        raise Unparsed("tail: " + tail[:40])
-    return fn, args, named, head.group(1).strip(), mm.group("where"), mm.group("order"), mm.group("limit")
+def call_paths(calls):
+    out = []
+    for _, _, args, named in calls:
+        for node in list(args) + [v for k, v in named.items() if k in ("pvar", "psam", "pgen", "sex_file")]:
+            v = sqlmini.literal(node)
+            out.extend(x for x in (v if isinstance(v, list) else [v]) if isinstance(x, str))
+    return out
 
 
 def main():
@@ -102,21 +77,19 @@ def main():
             if not re.search(r"\b(" + "|".join(FUNCTIONS) + r")\s*\(", sql):
                 continue
             try:
-                fn, args, named, select, where, order, limit = split_call(sql)
-                sqlmini.compile_query(select, where, order)  # raises sqlmini.Unsupported
-            except (Unparsed, IndexError, sqlmini.Unsupported) as e:
+                q = sqlmini.parse_sql(sql)
+                calls = sqlmini.check_select(q, FUNCTIONS)
+                paths = call_paths(calls)
+            except (Unparsed, IndexError, sqlmini.Unsupported, KeyError, TypeError) as e:
                 skipped.append(f"{name}:{at}: {e}")
                 continue
-            paths = [a for a in args if isinstance(a, str)] + [x for a in args if isinstance(a, list) for x in a if isinstance(x, str)]
-            missing = [q for q in paths if q.startswith("test/data/") and not (
-                os.path.exists(os.path.join(HERE, "data", q[10:])) or os.path.exists(os.path.join(HERE, "data", q[10:] + ".pgen")))]
+            missing = [q_ for q_ in paths if q_.startswith("test/data/") and not (
+                os.path.exists(os.path.join(HERE, "data", q_[10:])) or os.path.exists(os.path.join(HERE, "data", q_[10:] + ".pgen")))]
             if missing:
                 skipped.append(f"{name}:{at}: fixture not in the reference tree: {missing[0]}")
                 continue
-            case = {"source": f"test/sql/{name}:{at}", "function": fn, "args": args, "named": named, "select": select,
-                    "types": types, "expected": rows}
-            for key, val in (("where", where), ("order_by", order), ("limit", int(limit) if limit else None),
-                             ("rowsort", rowsort or None), ("settings", dict(settings) or None)):
+            case = {"source": f"test/sql/{name}:{at}", "sql": sql, "types": types, "expected": rows}
+            for key, val in (("rowsort", rowsort or None), ("settings", dict(settings) or None)):
                 if val:
                     case[key] = val
             cases.append(case)

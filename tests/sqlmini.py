@@ -12,8 +12,8 @@ class Unsupported(Exception):
 
 
 TOKEN = re.compile(r"\s*(?:(?P<num>\d+\.\d*(?:[eE][-+]?\d+)?|\.\d+|\d+(?:[eE][-+]?\d+)?)|(?P<str>'(?:[^']|'')*')|"
-                   r"(?P<id>[A-Za-z_][A-Za-z_0-9]*|\"[^\"]+\")|(?P<op><>|!=|<=|>=|::|[-+*/%(),.\[\]<>=]))")
-AGGREGATES = {"count", "sum", "min", "max", "avg", "bool_and", "bool_or", "list", "first", "any_value"}
+                   r"(?P<id>[A-Za-z_][A-Za-z_0-9]*|\"[^\"]+\")|(?P<op><>|!=|<=|>=|::|:=|[-+*/%(),.\[\]<>={}:;]))")
+AGGREGATES = {"count", "count_distinct", "sum", "min", "max", "avg", "bool_and", "bool_or", "list", "first", "any_value"}
 
 
 def tokenize(text):
@@ -178,9 +178,25 @@ class Parser:
             return ("lit", v[1:-1].replace("''", "'"))
         if v == "(":
             self.take()
+            if self.kw("select"):
+                q = self.select()
+                self.take("op", ")")
+                return ("subq", q)
             e = self.expr()
             self.take("op", ")")
             return e
+        if v == "{":
+            self.take()
+            fields = []
+            while self.peek()[1] != "}":
+                key = self.take()
+                key = key[1:-1] if key.startswith("'") else key
+                self.take("op", ":")
+                fields.append((key, self.expr()))
+                if self.peek()[1] == ",":
+                    self.take()
+            self.take()
+            return ("struct", fields)
         if v == "[":
             self.take()
             items = []
@@ -216,7 +232,8 @@ class Parser:
                 self.take()
                 args = []
                 if self.kw("distinct"):
-                    raise Unsupported("DISTINCT")
+                    self.take()
+                    low += "_distinct"
                 while self.peek()[1] != ")":
                     args.append(self.expr())
                     if self.peek()[1] == ",":
@@ -228,6 +245,293 @@ class Parser:
             self.take()
             return ("col", v.strip('"'))
         raise Unsupported(f"primary at {v}")
+
+
+CLAUSE_WORDS = ("from", "where", "group", "order", "limit", "having", "union", "except", "intersect", "join", "on", "as")
+
+
+def _select(self):
+    """SELECT items FROM relation [WHERE] [GROUP BY] [ORDER BY] [LIMIT] -> dict."""
+    self.take("id", "select")
+    q = {"items": [], "from": None, "where": None, "group": [], "order": [], "limit": None, "distinct": False}
+    if self.kw("distinct"):
+        self.take()
+        q["distinct"] = True
+    while True:
+        node = self.expr()
+        alias = None
+        if self.kw("as"):
+            self.take()
+            alias = self.take("id").strip('"')
+        elif self.peek()[0] == "id" and self.peek()[1].lower() not in CLAUSE_WORDS:
+            alias = self.take("id").strip('"')
+        q["items"].append((node, alias))
+        if self.peek()[1] == ",":
+            self.take()
+            continue
+        break
+    if self.kw("from"):
+        self.take()
+        q["from"] = self.relation()
+        if self.kw("as"):
+            self.take()
+            q["alias"] = self.take("id")
+        elif self.peek()[0] == "id" and self.peek()[1].lower() not in CLAUSE_WORDS:
+            q["alias"] = self.take("id")
+    if self.kw("join") or self.peek()[1] == ",":
+        raise Unsupported("more than one relation")
+    if self.kw("where"):
+        self.take()
+        q["where"] = self.expr()
+    if self.kw("group"):
+        self.take()
+        self.take("id", "by")
+        q["group"].append(self.expr())
+        while self.peek()[1] == ",":
+            self.take()
+            q["group"].append(self.expr())
+    if self.kw("having") or self.kw("union") or self.kw("except") or self.kw("intersect"):
+        raise Unsupported("HAVING / set operation")
+    if self.kw("order"):
+        self.take()
+        self.take("id", "by")
+        while True:
+            node = self.expr()
+            desc, nulls = False, ""
+            if self.kw("asc") or self.kw("desc"):
+                desc = self.take().lower() == "desc"
+            if self.kw("nulls"):
+                self.take()
+                nulls = self.take().upper()
+            q["order"].append((node, desc, nulls))
+            if self.peek()[1] == ",":
+                self.take()
+                continue
+            break
+    if self.kw("limit"):
+        self.take()
+        q["limit"] = int(self.take("num"))
+    return q
+
+
+def _relation(self):
+    if self.peek()[1] == "(":
+        self.take()
+        if self.kw("describe"):
+            self.take()
+            rel = ("describe", self.select())
+        else:
+            rel = ("select", self.select())
+        self.take("op", ")")
+        return rel
+    name = self.take("id")
+    if self.peek()[1] != "(":
+        raise Unsupported("table " + name)
+    self.take()
+    args, named = [], {}
+    while self.peek()[1] != ")":
+        if self.peek()[0] == "id" and self.peek(1)[1] == ":=":
+            key = self.take()
+            self.take()
+            named[key] = self.expr()
+        else:
+            args.append(self.expr())
+        if self.peek()[1] == ",":
+            self.take()
+    self.take()
+    return ("call", name.lower(), args, named)
+
+
+Parser.select = _select
+Parser.relation = _relation
+
+
+def parse_sql(sql):
+    p = Parser(sql.strip().rstrip(";"))
+    q = p.select()
+    if p.peek()[1] == ";":
+        p.take()
+    if not p.done():
+        raise Unsupported("text behind the statement: " + str(p.peek()[1]))
+    return q
+
+
+def walk_selects(q, fn):
+    """fn(select dict) for the statement and every subquery in it."""
+    fn(q)
+
+    def in_node(n):
+        if isinstance(n, tuple):
+            if n[0] == "subq":
+                walk_selects(n[1], fn)
+            for x in n[1:]:
+                in_node(x)
+        elif isinstance(n, list):
+            for x in n:
+                in_node(x)
+        elif isinstance(n, dict):
+            for x in n.values():
+                in_node(x)
+
+    for node, _ in q["items"]:
+        in_node(node)
+    in_node(q["where"])
+    in_node(q["group"])
+    for node, _, _ in q["order"]:
+        in_node(node)
+    rel = q["from"]
+    if rel and rel[0] in ("select", "describe"):
+        walk_selects(rel[1], fn)
+    if rel and rel[0] == "call":
+        in_node(rel[2])
+        in_node(rel[3])
+
+
+def check_select(q, functions):
+    """Raises Unsupported unless every relation is one of `functions` and every function call is known."""
+    calls = []
+
+    def one(sel):
+        rel = sel["from"]
+        if rel and rel[0] == "call":
+            if rel[1] not in functions:
+                raise Unsupported("relation " + rel[1])
+            calls.append(rel)
+            for node in list(rel[2]) + list(rel[3].values()):
+                check(node)
+        for node, _ in sel["items"]:
+            check(node)
+        check(sel["where"])
+        for g in sel["group"]:
+            check(g)
+        for node, _, _ in sel["order"]:
+            check(node)
+        aggs = [has_aggregate(n) for n, _ in sel["items"]]
+        if any(aggs) and not all(aggs) and not sel["group"]:
+            raise Unsupported("aggregates next to plain columns")
+
+    walk_selects(q, one)
+    if not calls:
+        raise Unsupported("no call of this path")
+    return calls
+
+
+def literal(node):
+    """The Python value of a literal argument expression (lists, structs, casts of them)."""
+    return ev(node, {}, {})
+
+
+def item_name(node, alias):
+    if alias:
+        return alias
+    if node[0] == "col":
+        return node[1]
+    if node[0] == "field":
+        return node[2]
+    if node[0] == "call":
+        return node[1] + "(...)"
+    return "?"
+
+
+def run_select(q, provider):
+    """-> (names, types, rows).  provider(function, args, named) -> object with .names, .types, .rows."""
+    rel = q["from"]
+    if rel is None:
+        names, types, rows = [], [], [()]
+    elif rel[0] == "call":
+        r = provider(rel[1], [literal(a) for a in rel[2]], {k: literal(v) for k, v in rel[3].items()})
+        names, types, rows = list(r.names), list(r.types), list(r.rows)
+    elif rel[0] == "describe":
+        n, t, _ = run_select(rel[1], provider)
+        names, types, rows = ["column_name", "column_type"], ["VARCHAR", "VARCHAR"], list(zip(n, t))
+    else:
+        names, types, rows = run_select(rel[1], provider)
+    tmap = dict(zip(names, types))
+    tmap["__provider__"] = provider
+    dicts = [dict(zip(names, r)) for r in rows]
+    for d in dicts:
+        d["__provider__"] = provider
+    if q["where"] is not None:
+        dicts = [d for d in dicts if ev(q["where"], d, tmap) is True]
+    items = q["items"]
+    out_names = []
+    for node, alias in items:
+        out_names.extend(names if node == ("star",) else [item_name(node, alias)])
+    is_agg = any(has_aggregate(n) for n, _ in items)
+    if q["group"]:
+        groups = {}
+        for d in dicts:
+            key = tuple(_hashable(ev(g, d, tmap)) for g in q["group"])
+            groups.setdefault(key, []).append(d)
+        out = []
+        for key, members in groups.items():
+            row = tuple(agg(n, members, tmap) if has_aggregate(n) else ev(n, members[0], tmap) for n, _ in items)
+            out.append((members[0], row))
+        alias_of = {a: k for k, (_, a) in enumerate(items) if a}
+        if q["order"]:
+            out.sort(key=lambda t: _order_key(q["order"], t[0], tmap, dict(zip(out_names, t[1]))))
+        rows_out = [r for _, r in out]
+    elif is_agg:
+        rows_out = [tuple(agg(n, dicts, tmap) for n, _ in items)]
+    else:
+        if q["order"]:
+            dicts.sort(key=lambda d: _order_key(q["order"], d, tmap, None, items))
+        rows_out = []
+        for d in dicts:
+            row = []
+            for n, _ in items:
+                if n == ("star",):
+                    row.extend(d[c] for c in names)
+                else:
+                    row.append(ev(n, d, tmap))
+            rows_out.append(tuple(row))
+        if q["distinct"]:
+            seen, uniq = set(), []
+            for r in rows_out:
+                k = _hashable(r)
+                if k not in seen:
+                    seen.add(k)
+                    uniq.append(r)
+            rows_out = uniq
+    if q["limit"] is not None:
+        rows_out = rows_out[:q["limit"]]
+    out_types = []
+    for node, alias in items:
+        if node == ("star",):
+            out_types.extend(types)
+        else:
+            try:
+                out_types.append(types_of(node, tmap))
+            except (Unsupported, KeyError):
+                out_types.append("?")
+    return out_names, out_types, rows_out
+
+
+def _hashable(v):
+    if isinstance(v, (list, tuple)):
+        return tuple(_hashable(x) for x in v)
+    if isinstance(v, dict):
+        return tuple((k, _hashable(x)) for k, x in v.items())
+    return v
+
+
+def _order_key(order, d, tmap, computed=None, items=None):
+    out = []
+    for node, desc, nulls in order:
+        if computed is not None and node[0] == "col" and node[1] in computed:
+            v = computed[node[1]]
+        else:
+            if items and node[0] == "col" and not any(k.lower() == node[1].lower() for k in d):
+                hit = next((n for n, a in items if a and a.lower() == node[1].lower()), None)
+                v = ev(hit, d, tmap) if hit else ev(node, d, tmap)
+            elif node[0] == "lit" and isinstance(node[1], int) and items:
+                v = ev(items[node[1] - 1][0], d, tmap)  # ORDER BY 1
+            else:
+                v = ev(node, d, tmap)
+        null_last = (nulls == "LAST") if nulls else True
+        out.append((v is None) == null_last)
+        out.append(Rev(v) if desc else Fwd(v))
+    return tuple(out)
 
 
 def split_top(text):
@@ -342,6 +646,11 @@ def ev(node, row, types):
         return base[idx - 1] if 1 <= idx <= len(base) else None
     if kind == "list":
         return [ev(x, row, types) for x in node[1]]
+    if kind == "struct":
+        return {k: ev(x, row, types) for k, x in node[1]}
+    if kind == "subq":
+        _, _, rows = run_select(node[1], row.get("__provider__") or types.get("__provider__"))
+        return rows[0][0] if rows else None
     if kind == "neg":
         v = ev(node[1], row, types)
         return None if v is None else -v
@@ -493,6 +802,8 @@ def agg(node, rows, types):
                 return len(rows)
             return sum(ev(args[0], r, types) is not None for r in rows)
         vals = [ev(args[0], r, types) for r in rows]
+        if name == "count_distinct":
+            return len({_hashable(v) for v in vals if v is not None})
         if name == "list":
             return vals
         vals = [v for v in vals if v is not None]
