@@ -23,8 +23,8 @@
 //                        columns and the scalar call (or dosage); threads claim runs of <= 64 variants,
 //                        the device unpacks a run in one call, the genotype filter decides which rows
 //                        exist (src/pfile_reader.cpp:2342-2760).
-// Not carried over: combine_samples other than the
-// implicit one, parquet companions.
+// Not carried over: parquet companions (combine_samples := 'union' | 'intersect' | 'concatenate' are "not yet
+// implemented" in the reference as well).
 
 #include "pgen_reader.hpp"
 
