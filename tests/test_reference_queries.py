@@ -34,18 +34,18 @@ def localise(v):
     return v
 
 
-def provider(settings):
+def provider(settings, threads):
     def call(function, args, named):
         args = [localise(a) for a in args]
         named = {k: (localise(v) if k in PATH_PARAMS else v) for k, v in named.items()}
-        return F.query(function, *args, settings=settings, **named)
+        return F.query(function, *args, settings=settings, threads=threads, **named)
 
     return call
 
 
-def run_case(case):
+def run_case(case, threads=4):
     q = sqlmini.parse_sql(case["sql"])
-    _, _, got = sqlmini.run_select(q, provider(case.get("settings")))
+    _, _, got = sqlmini.run_select(q, provider(case.get("settings"), threads))
     want = case["expected"]
     types = case["types"]
     assert len(got) == len(want), f"{len(got)} rows, the reference's test expects {len(want)}"
@@ -72,3 +72,13 @@ def run_case(case):
 @pytest.mark.parametrize("case", CASES, ids=lambda c: c["source"].split("/")[-1])
 def test_reference_query(case):
     run_case(case)
+
+
+@pytest.mark.parametrize("threads", [1, 13])
+@pytest.mark.parametrize("case", CASES[::4], ids=lambda c: c["source"].split("/")[-1])
+def test_reference_query_at_other_thread_counts(case, threads):
+    """Every fourth query again with one scan thread and with thirteen: the rows must not depend on how the scan is cut
+    (streaming_threading.test's point, over the whole suite)."""
+    if "plinking_max_threads" in (case.get("settings") or {}):
+        pytest.skip("the case sets its own thread cap")
+    run_case(case, threads)
