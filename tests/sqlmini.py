@@ -178,8 +178,8 @@ class Parser:
             return ("lit", v[1:-1].replace("''", "'"))
         if v == "(":
             self.take()
-            if self.kw("select"):
-                q = self.select()
+            if self.kw("select") or self.kw("with"):
+                q = self.query()
                 self.take("op", ")")
                 return ("subq", q)
             e = self.expr()
@@ -247,7 +247,8 @@ class Parser:
         raise Unsupported(f"primary at {v}")
 
 
-CLAUSE_WORDS = ("from", "where", "group", "order", "limit", "having", "union", "except", "intersect", "join", "on", "as")
+CLAUSE_WORDS = ("from", "where", "group", "order", "limit", "having", "union", "except", "intersect", "join", "on", "as", "inner",
+                "left", "right", "full", "cross", "natural", "using")
 
 
 def _select(self):
@@ -270,16 +271,38 @@ def _select(self):
             self.take()
             continue
         break
+    q["joins"] = []
     if self.kw("from"):
         self.take()
         q["from"] = self.relation()
-        if self.kw("as"):
+        q["alias"] = self.table_alias()
+        while True:
+            if self.peek()[1] == ",":
+                self.take()
+                rel = self.relation()
+                q["joins"].append((rel, self.table_alias(), None))
+                continue
+            if self.kw("inner"):
+                self.take()
+            if self.kw("left") or self.kw("right") or self.kw("full") or self.kw("cross") or self.kw("natural"):
+                raise Unsupported("outer / cross join")
+            if not self.kw("join"):
+                break
             self.take()
-            q["alias"] = self.take("id")
-        elif self.peek()[0] == "id" and self.peek()[1].lower() not in CLAUSE_WORDS:
-            q["alias"] = self.take("id")
-    if self.kw("join") or self.peek()[1] == ",":
-        raise Unsupported("more than one relation")
+            rel = self.relation()
+            alias = self.table_alias()
+            if self.kw("using"):
+                self.take()
+                self.take("op", "(")
+                cols = [self.take("id")]
+                while self.peek()[1] == ",":
+                    self.take()
+                    cols.append(self.take("id"))
+                self.take("op", ")")
+                q["joins"].append((rel, alias, ("using", cols)))
+            else:
+                self.take("id", "on")
+                q["joins"].append((rel, alias, self.expr()))
     if self.kw("where"):
         self.take()
         q["where"] = self.expr()
@@ -290,8 +313,9 @@ def _select(self):
         while self.peek()[1] == ",":
             self.take()
             q["group"].append(self.expr())
-    if self.kw("having") or self.kw("union") or self.kw("except") or self.kw("intersect"):
-        raise Unsupported("HAVING / set operation")
+    if self.kw("having"):
+        self.take()
+        q["having"] = self.expr()
     if self.kw("order"):
         self.take()
         self.take("id", "by")
@@ -314,19 +338,65 @@ def _select(self):
     return q
 
 
+def _table_alias(self):
+    if self.kw("as"):
+        self.take()
+        return self.take("id").strip('"')
+    if self.peek()[0] == "id" and self.peek()[1].lower() not in CLAUSE_WORDS:
+        return self.take("id").strip('"')
+    return None
+
+
+def _query(self):
+    """[WITH name AS (query), ...] term {UNION [ALL] | EXCEPT | INTERSECT term}; term = SELECT ... | ( query )."""
+    ctes = []
+    if self.kw("with"):
+        self.take()
+        while True:
+            name = self.take("id")
+            self.take("id", "as")
+            self.take("op", "(")
+            ctes.append((name, self.query()))
+            self.take("op", ")")
+            if self.peek()[1] == ",":
+                self.take()
+                continue
+            break
+
+    def term():
+        if self.peek()[1] == "(":
+            self.take()
+            q = self.query()
+            self.take("op", ")")
+            return q
+        return self.select()
+
+    node = term()
+    while self.kw("union") or self.kw("except") or self.kw("intersect"):
+        op = self.take().lower()
+        keep_all = False
+        if self.kw("all"):
+            self.take()
+            keep_all = True
+        node = {"setop": op, "all": keep_all, "left": node, "right": term()}
+    if ctes:
+        node = {"with": ctes, "body": node}
+    return node
+
+
 def _relation(self):
     if self.peek()[1] == "(":
         self.take()
         if self.kw("describe"):
             self.take()
-            rel = ("describe", self.select())
+            rel = ("describe", self.query())
         else:
-            rel = ("select", self.select())
+            rel = ("select", self.query())
         self.take("op", ")")
         return rel
     name = self.take("id")
     if self.peek()[1] != "(":
-        raise Unsupported("table " + name)
+        return ("table", name)
     self.take()
     args, named = [], {}
     while self.peek()[1] != ")":
@@ -344,11 +414,13 @@ def _relation(self):
 
 Parser.select = _select
 Parser.relation = _relation
+Parser.query = _query
+Parser.table_alias = _table_alias
 
 
 def parse_sql(sql):
     p = Parser(sql.strip().rstrip(";"))
-    q = p.select()
+    q = p.query()
     if p.peek()[1] == ";":
         p.take()
     if not p.done():
@@ -358,6 +430,15 @@ def parse_sql(sql):
 
 def walk_selects(q, fn):
     """fn(select dict) for the statement and every subquery in it."""
+    if "setop" in q:
+        walk_selects(q["left"], fn)
+        walk_selects(q["right"], fn)
+        return
+    if "with" in q:
+        for _, sub in q["with"]:
+            walk_selects(sub, fn)
+        walk_selects(q["body"], fn)
+        return
     fn(q)
 
     def in_node(n):
@@ -379,26 +460,50 @@ def walk_selects(q, fn):
     in_node(q["group"])
     for node, _, _ in q["order"]:
         in_node(node)
-    rel = q["from"]
-    if rel and rel[0] in ("select", "describe"):
-        walk_selects(rel[1], fn)
-    if rel and rel[0] == "call":
-        in_node(rel[2])
-        in_node(rel[3])
+    in_node(q.get("having"))
+    for rel in [q["from"]] + [j[0] for j in q["joins"]]:
+        if rel and rel[0] in ("select", "describe"):
+            walk_selects(rel[1], fn)
+        if rel and rel[0] == "call":
+            in_node(rel[2])
+            in_node(rel[3])
+    for _, _, on in q["joins"]:
+        if isinstance(on, tuple) and on[0] != "using":
+            in_node(on)
 
 
 def check_select(q, functions):
     """Raises Unsupported unless every relation is one of `functions` and every function call is known."""
     calls = []
 
+    cte_names = set()
+
+    def names_of(node):
+        if "with" in node:
+            cte_names.update(n.lower() for n, _ in node["with"])
+            for _, sub in node["with"]:
+                names_of(sub)
+            names_of(node["body"])
+        elif "setop" in node:
+            names_of(node["left"])
+            names_of(node["right"])
+
+    names_of(q)
+
     def one(sel):
-        rel = sel["from"]
-        if rel and rel[0] == "call":
-            if rel[1] not in functions:
-                raise Unsupported("relation " + rel[1])
-            calls.append(rel)
-            for node in list(rel[2]) + list(rel[3].values()):
-                check(node)
+        for rel in [sel["from"]] + [j[0] for j in sel["joins"]]:
+            if rel and rel[0] == "table" and rel[1].lower() not in cte_names:
+                raise Unsupported("table " + rel[1])
+            if rel and rel[0] == "call":
+                if rel[1] not in functions:
+                    raise Unsupported("relation " + rel[1])
+                calls.append(rel)
+                for node in list(rel[2]) + list(rel[3].values()):
+                    check(node)
+        for _, _, on in sel["joins"]:
+            if isinstance(on, tuple) and on[0] != "using":
+                check(on)
+        check(sel.get("having"))
         for node, _ in sel["items"]:
             check(node)
         check(sel["where"])
@@ -433,24 +538,113 @@ def item_name(node, alias):
     return "?"
 
 
-def run_select(q, provider):
+def run_select(q, provider, ctes=None):
     """-> (names, types, rows).  provider(function, args, named) -> object with .names, .types, .rows."""
+    ctes = dict(ctes or {})
+    if "with" in q:
+        for name, sub in q["with"]:
+            ctes[name.lower()] = run_select(sub, provider, ctes)
+        return run_select(q["body"], provider, ctes)
+    if "setop" in q:
+        ln, lt, lrows = run_select(q["left"], provider, ctes)
+        _, _, rrows = run_select(q["right"], provider, ctes)
+        lk, rk = [_hashable(r) for r in lrows], [_hashable(r) for r in rrows]
+        if q["setop"] == "union":
+            rows = list(lrows) + list(rrows)
+            if not q["all"]:
+                rows = _dedupe(rows)
+        elif q["setop"] == "except":
+            gone = set(rk)
+            rows = _dedupe([r for r, k in zip(lrows, lk) if k not in gone])
+        else:
+            keep = set(rk)
+            rows = _dedupe([r for r, k in zip(lrows, lk) if k in keep])
+        return ln, lt, rows
+
+    def relation(rel):
+        if rel[0] == "call":
+            r = provider(rel[1], [literal(a) for a in rel[2]], {k: literal(v) for k, v in rel[3].items()})
+            return list(r.names), list(r.types), list(r.rows)
+        if rel[0] == "table":
+            n, t, rows = ctes[rel[1].lower()]
+            return list(n), list(t), list(rows)
+        if rel[0] == "describe":
+            n, t, _ = run_select(rel[1], provider, ctes)
+            return ["column_name", "column_type"], ["VARCHAR", "VARCHAR"], list(zip(n, t))
+        return run_select(rel[1], provider, ctes)
+
+    extra = {"__provider__": provider, "__ctes__": ctes,
+             "__aliases__": {a.lower(): n for n, a in q["items"] if a and not has_aggregate(n)}}
     rel = q["from"]
     if rel is None:
-        names, types, rows = [], [], [()]
-    elif rel[0] == "call":
-        r = provider(rel[1], [literal(a) for a in rel[2]], {k: literal(v) for k, v in rel[3].items()})
-        names, types, rows = list(r.names), list(r.types), list(r.rows)
-    elif rel[0] == "describe":
-        n, t, _ = run_select(rel[1], provider)
-        names, types, rows = ["column_name", "column_type"], ["VARCHAR", "VARCHAR"], list(zip(n, t))
+        names, types, dicts = [], [], [dict(extra)]
     else:
-        names, types, rows = run_select(rel[1], provider)
+        names, types, rows = relation(rel)
+        dicts = []
+        first_alias = q.get("alias") or (rel[1] if rel[0] == "table" else None)
+        for r in rows:
+            d = dict(zip(names, r))
+            if first_alias:
+                d[first_alias] = dict(zip(names, r))
+            d.update(extra)
+            dicts.append(d)
+        for jrel, jalias, on in q["joins"]:
+            jalias = jalias or (jrel[1] if jrel[0] == "table" else None)
+            jn, jt, jrows = relation(jrel)
+            jd = [dict(zip(jn, r)) for r in jrows]
+            joined = []
+            key_l = key_r = None
+            if isinstance(on, tuple) and on[0] == "using":
+                key_l = [("col", c) for c in on[1]]
+                key_r = key_l
+            elif isinstance(on, tuple) and on[0] == "cmp" and on[1] == "=":
+                key_l, key_r = [on[2]], [on[3]]
+            tmap0 = dict(zip(names + jn, types + jt))
+            tmap0.update(extra)
+
+            def right_row(d):
+                out = dict(d)
+                if jalias:
+                    out = {jalias: dict(d)}
+                    out.update({k: v for k, v in d.items()})
+                return out
+
+            if key_l is not None:
+                # an equality join: hash one side (whichever side of the = names the joined relation)
+                def try_keys(dl, dr, kl, kr):
+                    return tuple(_hashable(ev(k, dl, tmap0)) for k in kl), tuple(_hashable(ev(k, dr, tmap0)) for k in kr)
+                index = None
+                for kl, kr in ((key_l, key_r), (key_r, key_l)):
+                    try:
+                        index = {}
+                        for d in jd:
+                            index.setdefault(tuple(_hashable(ev(k, right_row(d), tmap0)) for k in kr), []).append(d)
+                        probe = kl
+                        if dicts:
+                            tuple(_hashable(ev(k, dicts[0], tmap0)) for k in probe)
+                        break
+                    except (KeyError, TypeError):
+                        index = None
+                if index is None:
+                    raise Unsupported("join keys")
+                for d in dicts:
+                    for m in index.get(tuple(_hashable(ev(k, d, tmap0)) for k in probe), []):
+                        merged = dict(right_row(m))
+                        merged.update(d)  # the left side wins an unqualified name clash, as the first relation does
+                        joined.append(merged)
+            else:
+                if len(dicts) * len(jd) > 4_000_000:
+                    raise Unsupported("join too large for the nested loop")
+                for d in dicts:
+                    for m in jd:
+                        merged = dict(right_row(m))
+                        merged.update(d)
+                        if on is None or ev(on, merged, tmap0) is True:
+                            joined.append(merged)
+            dicts = joined
+            names, types = names + [n for n in jn if n not in names], types + [t for n, t in zip(jn, jt) if n not in names]
     tmap = dict(zip(names, types))
-    tmap["__provider__"] = provider
-    dicts = [dict(zip(names, r)) for r in rows]
-    for d in dicts:
-        d["__provider__"] = provider
+    tmap.update(extra)
     if q["where"] is not None:
         dicts = [d for d in dicts if ev(q["where"], d, tmap) is True]
     items = q["items"]
@@ -466,11 +660,15 @@ def run_select(q, provider):
         out = []
         for key, members in groups.items():
             row = tuple(agg(n, members, tmap) if has_aggregate(n) else ev(n, members[0], tmap) for n, _ in items)
-            out.append((members[0], row))
-        alias_of = {a: k for k, (_, a) in enumerate(items) if a}
+            if q.get("having") is not None:
+                named = dict(members[0])
+                named.update({a: v for (_, a), v in zip(items, row) if a})
+                if agg(q["having"], [named] if not has_aggregate(q["having"]) else members, tmap) is not True:
+                    continue
+            out.append((members[0], row, members))
         if q["order"]:
-            out.sort(key=lambda t: _order_key(q["order"], t[0], tmap, dict(zip(out_names, t[1]))))
-        rows_out = [r for _, r in out]
+            out.sort(key=lambda t: _order_key(q["order"], t[0], tmap, dict(zip(out_names, t[1])), None, t[2]))
+        rows_out = [t[1] for t in out]
     elif is_agg:
         rows_out = [tuple(agg(n, dicts, tmap) for n, _ in items)]
     else:
@@ -486,13 +684,7 @@ def run_select(q, provider):
                     row.append(ev(n, d, tmap))
             rows_out.append(tuple(row))
         if q["distinct"]:
-            seen, uniq = set(), []
-            for r in rows_out:
-                k = _hashable(r)
-                if k not in seen:
-                    seen.add(k)
-                    uniq.append(r)
-            rows_out = uniq
+            rows_out = _dedupe(rows_out)
     if q["limit"] is not None:
         rows_out = rows_out[:q["limit"]]
     out_types = []
@@ -507,6 +699,16 @@ def run_select(q, provider):
     return out_names, out_types, rows_out
 
 
+def _dedupe(rows):
+    seen, out = set(), []
+    for r in rows:
+        k = _hashable(r)
+        if k not in seen:
+            seen.add(k)
+            out.append(r)
+    return out
+
+
 def _hashable(v):
     if isinstance(v, (list, tuple)):
         return tuple(_hashable(x) for x in v)
@@ -515,11 +717,13 @@ def _hashable(v):
     return v
 
 
-def _order_key(order, d, tmap, computed=None, items=None):
+def _order_key(order, d, tmap, computed=None, items=None, members=None):
     out = []
     for node, desc, nulls in order:
         if computed is not None and node[0] == "col" and node[1] in computed:
             v = computed[node[1]]
+        elif members is not None and has_aggregate(node):
+            v = agg(node, members, tmap)
         else:
             if items and node[0] == "col" and not any(k.lower() == node[1].lower() for k in d):
                 hit = next((n for n, a in items if a and a.lower() == node[1].lower()), None)
@@ -633,6 +837,9 @@ def ev(node, row, types):
         for name in row:
             if name.lower() == node[1].lower():
                 return row[name]
+        alias = (row.get("__aliases__") or {}).get(node[1].lower())
+        if alias is not None and alias != node:
+            return ev(alias, row, types)
         raise KeyError(node[1])
     if kind == "field":
         base = ev(node[1], row, types)
@@ -649,7 +856,8 @@ def ev(node, row, types):
     if kind == "struct":
         return {k: ev(x, row, types) for k, x in node[1]}
     if kind == "subq":
-        _, _, rows = run_select(node[1], row.get("__provider__") or types.get("__provider__"))
+        _, _, rows = run_select(node[1], row.get("__provider__") or types.get("__provider__"),
+                                row.get("__ctes__") or types.get("__ctes__"))
         return rows[0][0] if rows else None
     if kind == "neg":
         v = ev(node[1], row, types)
@@ -840,6 +1048,10 @@ def agg(node, rows, types):
     if node[0] == "neg":
         v = agg(node[1], rows, types)
         return None if v is None else -v
+    if node[0] in ("and", "or"):
+        return ev((node[0], ("lit", agg(node[1], rows, types)), ("lit", agg(node[2], rows, types))), {}, types)
+    if node[0] in ("col", "field", "index", "subq"):
+        return ev(node, rows[0], types) if rows else None
     raise Unsupported("aggregate expression")
 
 

@@ -50,7 +50,10 @@ def run_case(case, threads=4):
     types = case["types"]
     assert len(got) == len(want), f"{len(got)} rows, the reference's test expects {len(want)}"
     rows = [tuple(sqlmini.duck_str(v) for v in g) for g in got]
-    ordered = bool(q["order"]) and not case.get("rowsort")
+    top = q
+    while "body" in top:
+        top = top["body"]
+    ordered = bool(top.get("order")) and not case.get("rowsort")
     pairs = list(zip(got, want))
     if not ordered:
         pairs = list(zip([g for _, g in sorted(zip(rows, got), key=lambda t: t[0])], sorted(want)))
