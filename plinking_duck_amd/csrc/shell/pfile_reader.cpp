@@ -844,19 +844,29 @@ static void RunSamplePhase1(const PfileBindData &bind_data, PfileGlobalState &gs
 	for (size_t si = 0; si < bind_data.sources.size(); si++) {
 		const auto &src = bind_data.sources[si];
 		const auto &c = src.c;
-		pgh_dataset *ds = gstate.datasets[si]->Resident("read_pfile");
-		pgh_subset *ss = gstate.subsets[si] ? gstate.subsets[si]->handle : nullptr;
+		vector<uint32_t> all_listed;
+		if (src.has_variant_list) {
+			for (auto v : src.variant_indices) {
+				if (!c.variant_range.has_filter || (v >= c.RangeStart() && v < c.RangeEnd())) {
+					all_listed.push_back(v);
+				}
+			}
+		}
+		// the tallies of the candidates in [w_begin, w_end) on `ds`: the whole range on a resident file, one window
+		// at a time on a file beyond the HBM budget (per-sample tallies simply add over the windows, as they do over
+		// the sources -- the reference streams this mode too, src/pfile_reader.cpp:3287-3460)
+		auto tally_window = [&](pgh_dataset *ds, pgh_subset *ss, uint32_t w_begin, uint32_t w_end) {
 		vector<uint32_t> list;
 		bool listed = src.has_variant_list;
 		if (listed) {
-			for (auto v : src.variant_indices) {
-				if (!c.variant_range.has_filter || (v >= c.RangeStart() && v < c.RangeEnd())) {
+			for (auto v : all_listed) {
+				if (v >= w_begin && v < w_end) {
 					list.push_back(v);
 				}
 			}
 		}
-		const uint32_t begin = c.RangeStart();
-		uint32_t n_var = listed ? static_cast<uint32_t>(list.size()) : c.RangeEnd() - c.RangeStart();
+		const uint32_t begin = w_begin;
+		uint32_t n_var = listed ? static_cast<uint32_t>(list.size()) : w_end - w_begin;
 		if (bind_data.count_filter.HasFilter() && n_var) {
 			// per-variant tallies of the candidates decide which of them stay
 			vector<uint32_t> vc(4 * static_cast<size_t>(n_var));
@@ -882,6 +892,9 @@ static void RunSamplePhase1(const PfileBindData &bind_data, PfileGlobalState &gs
 			listed = true;
 			n_var = static_cast<uint32_t>(list.size());
 		}
+		if (n_var == 0) {
+			return; // nothing of this window is a candidate
+		}
 		if (pgh_sample_counts(ds, ss, listed ? 0 : begin, n_var, listed ? list.data() : nullptr,
 		                      reinterpret_cast<uint32_t(*)[4]>(part.data()), errbuf) != PGH_OK) {
 			throw IOException("read_pfile: PgrGet failed during sample-orient aggregation: %s", string(errbuf));
@@ -890,6 +903,19 @@ static void RunSamplePhase1(const PfileBindData &bind_data, PfileGlobalState &gs
 			gstate.counts[k] += part[k];
 		}
 		gstate.effective_variants += n_var;
+		};
+		if (c.RangeEnd() <= c.RangeStart()) {
+			continue;
+		}
+		if (gstate.datasets[si]->streamed) {
+			const auto &first = bind_data.sources[0].c; // (the sources share their samples: the subset is source 0's)
+			gstate.datasets[si]->ForEachWindow(c.RangeStart(), c.RangeEnd(),
+			                                   first.has_sample_subset ? &first.sample_subset->sample_include : nullptr,
+			                                   "read_pfile", tally_window);
+		} else {
+			tally_window(gstate.datasets[si]->Resident("read_pfile"), gstate.subsets[si] ? gstate.subsets[si]->handle : nullptr,
+			             c.RangeStart(), c.RangeEnd());
+		}
 	}
 	if (bind_data.genotype_filter.active) {
 		// keep a sample if any of its calls is allowed (src/pfile_reader.cpp:3452-3462)

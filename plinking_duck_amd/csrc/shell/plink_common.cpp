@@ -1936,13 +1936,46 @@ void DeviceTally::SampleMissing(uint32_t *out, const string &func_name) {
 pgh_dataset *DeviceDataset::Resident(const string &func_name) const {
 	if (streamed) {
 		throw IOException("%s: '%s' does not fit the HBM budget (%.1f GB of rows, budget %.1f GB: PLINKING_HBM_CACHE_GB); "
-		                  "only the tallies of plink_freq / plink_hardy / plink_missing / read_pgen counts stream a file "
-		                  "of this size",
+		                  "only the tallies of plink_freq / plink_hardy / plink_missing / read_pgen counts and read_pfile's "
+		                  "per-sample counts stream a file of this size",
 		                  func_name, path,
 		                  static_cast<double>(info.raw_variant_ct) * static_cast<double>(info.record_bytes) / 1e9,
 		                  static_cast<double>(CacheBudgetBytes()) / 1e9);
 	}
 	return handle;
+}
+
+void DeviceDataset::ForEachWindow(uint32_t begin, uint32_t end, const vector<uint64_t> *sample_include,
+                                  const string &func_name,
+                                  const std::function<void(pgh_dataset *, pgh_subset *, uint32_t, uint32_t)> &fn) const {
+	const uint64_t pitch = std::max<uint64_t>(16, (static_cast<uint64_t>(info.record_bytes) + 127) / 128 * 128);
+	const uint64_t window = std::max<uint64_t>(1, CacheBudgetBytes() / 2 / pitch);
+	for (uint64_t v0 = begin; v0 < end; v0 += window) {
+		const uint32_t v1 = static_cast<uint32_t>(std::min<uint64_t>(end, v0 + window));
+		char errbuf[PGH_ERRBUF_LEN] = {0};
+		pgh_dataset *win = nullptr;
+		pgh_subset *ss = nullptr;
+		int rc = pgh_open(path.c_str(), nullptr, static_cast<uint32_t>(v0), v1, &win, errbuf);
+		if (rc == PGH_OK && sample_include && !sample_include->empty()) {
+			rc = pgh_subset_create(win, sample_include->data(), &ss, errbuf);
+		}
+		if (rc != PGH_OK) {
+			if (win) {
+				pgh_close(win);
+			}
+			throw IOException("%s: streaming variants [%llu, %u) of '%s' failed: %s", func_name,
+			                  static_cast<unsigned long long>(v0), v1, path, string(errbuf));
+		}
+		try {
+			fn(win, ss, static_cast<uint32_t>(v0), v1);
+		} catch (...) {
+			pgh_subset_destroy(ss);
+			pgh_close(win);
+			throw;
+		}
+		pgh_subset_destroy(ss);
+		pgh_close(win);
+	}
 }
 
 shared_ptr<DeviceTally> DeviceDataset::FindTally(const vector<uint64_t> *sample_include, uint32_t begin, uint32_t end) {

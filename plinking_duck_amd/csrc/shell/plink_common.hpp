@@ -275,6 +275,11 @@ public:
 	//! plink_score, plink_pca, plink_ld, read_pfile's sample orient) reports that it does not fit: Resident().
 	bool streamed = false;
 	pgh_dataset *Resident(const string &func_name) const;
+	//! A streamed file (see `streamed`) window by window through HBM: opens variants [v0, v1) -- half the HBM budget
+	//! each -- as a dataset of their own (rows keyed by the file's variant numbers), stages `sample_include` next to
+	//! them when given, hands both to fn and closes them.  Throws IOException when a window cannot be opened.
+	void ForEachWindow(uint32_t begin, uint32_t end, const vector<uint64_t> *sample_include, const string &func_name,
+	                   const std::function<void(pgh_dataset *, pgh_subset *, uint32_t, uint32_t)> &fn) const;
 	static shared_ptr<DeviceDataset> Acquire(const string &pgen_path, const string &func_name);
 
 	//! The tally pass over [begin, end) for this sample mask (nullptr = every sample), started if nobody has one:

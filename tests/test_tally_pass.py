@@ -258,16 +258,23 @@ def test_a_file_beyond_the_hbm_budget_streams_its_tallies(gpu_lib, oracle, tmp_p
     L.synth_write_files(big, m, n, SEED, 0.04)
     calls = [("plink_freq", dict(counts=True)), ("plink_hardy", dict(midp=True)), ("plink_hardy", {}), ("plink_missing", {}),
              ("plink_missing", dict(mode="sample")), ("plink_freq", dict(samples=[0, 3, 700, 2002], region="4:1-1000000")),
-             ("read_pgen", dict(genotypes="counts", af_range={"max": 0.2}))]
-    want = [F.query(fn, small + ".pgen", threads=3, **kw) for fn, kw in calls]
+             ("read_pgen", dict(genotypes="counts", af_range={"max": 0.2})),
+             # read_pfile's per-sample tallies (the reference streams this mode: no matrix, src/pfile_reader.cpp:3287):
+             # they add over the windows, with subsets, regions, count filters, variant lists and carrier row-skips
+             ("read_pfile", dict(orient="sample", genotypes="counts")),
+             ("read_pfile", dict(orient="sample", genotypes="stats", samples=[5, 0, 1999], region="3:1-900000")),
+             ("read_pfile", dict(orient="sample", genotypes="counts", af_range={"min": 0.1, "max": 0.4})),
+             ("read_pfile", dict(orient="sample", genotypes="counts", variants={"start": 100, "stop": 4100},
+                                 include_genotypes=["hom_alt"]))]
+    want = [F.query(fn, small + (".pgen" if fn != "read_pfile" else ""), threads=3, **kw) for fn, kw in calls]
     monkeypatch.setenv("PLINKING_HBM_CACHE_GB", "0.0005")  # 500 KB: windows of ~240 variants
     passes = L.tally_passes_started()
     for (fn, kw), w in zip(calls, want):
-        got = F.query(fn, big + ".pgen", threads=3, **kw)
+        got = F.query(fn, big + (".pgen" if fn != "read_pfile" else ""), threads=3, **kw)
         key = lambda r: tuple(str(x) for x in r[:3])
         assert got.names == w.names and sorted(got.rows, key=key) == sorted(w.rows, key=key), fn
     assert L.tally_passes_started() > passes + 8  # one resident pass per window of the file
     for fn, kw in (("plink_score", dict(weights=[0.5] * m)), ("plink_pca", dict(n_pcs=2)), ("read_pgen", dict(genotypes="list")),
-                   ("plink_ld", {})):
+                   ("plink_ld", {}), ("read_pfile", dict(orient="sample"))):
         with pytest.raises(F.IOException, match="does not fit the HBM budget"):
-            F.query(fn, big + ".pgen", threads=2, **kw)
+            F.query(fn, big + (".pgen" if fn != "read_pfile" else ""), threads=2, **kw)
