@@ -219,7 +219,7 @@ unique_ptr<LocalTableFunctionState> PgenInitLocal(ExecutionContext &, TableFunct
 	const bool phased_out = bind_data.include_phased && bind_data.genotype_mode != GenotypeMode::COLUMNS;
 	const bool pipelined = gstate.need_genotypes && !IsAggregateGenotypeMode(bind_data.genotype_mode) &&
 	                       !bind_data.include_dosages && !phased_out && !gstate.scan.has_variant_list;
-	if (pipelined) {
+	if (pipelined && !gstate.scan.dataset->streamed) { // (a streamed file's hardcalls come window by window: LeaseRows)
 		char errbuf[PGH_ERRBUF_LEN] = {0};
 		if (pgh_reader_create(gstate.scan.dataset->Resident(bind_data.func), gstate.scan.subset ? gstate.scan.subset->handle : nullptr,
 		                      &state->reader, errbuf) != PGH_OK) {
@@ -387,17 +387,22 @@ void PgenScan(ClientContext &, TableFunctionInput &data_p, DataChunk &output) {
 			lstate.bytes.resize(rows * n);
 		}
 		lstate.validity.resize(rows * val_words);
-		pgh_dataset *ds = gstate.scan.dataset->Resident(bind_data.func);
-		pgh_subset *ss = gstate.scan.subset ? gstate.scan.subset->handle : nullptr;
+		const vector<uint64_t> *mask = bind_data.c.has_sample_subset ? &bind_data.c.sample_subset->sample_include : nullptr;
+		auto rows_of = [&](uint32_t b, uint32_t e) {
+			return LeaseRows(*gstate.scan.dataset, gstate.scan.subset.get(), gstate.scan.row_windows, mask, b, e,
+			                 bind_data.c.raw_variant_ct, bind_data.func);
+		};
 		char errbuf[PGH_ERRBUF_LEN] = {0};
 		int rc = PGH_OK;
 		if (listed) {
 			for (size_t r = 0; r < plan.size() && rc == PGH_OK; r++) {
-				rc = pgh_unpack_range(ds, ss, plan[r].vidx, plan[r].vidx + 1, lstate.bytes.data() + r * n,
+				RowLease rows_r = rows_of(plan[r].vidx, plan[r].vidx + 1);
+				rc = pgh_unpack_range(rows_r.ds, rows_r.ss, plan[r].vidx, plan[r].vidx + 1, lstate.bytes.data() + r * n,
 				                      lstate.validity.data() + r * val_words, 0, errbuf);
 			}
 		} else {
-			rc = pgh_unpack_range(ds, ss, span_begin, span_end, direct_dst ? direct_dst : lstate.bytes.data(),
+			RowLease span = rows_of(span_begin, span_end);
+			rc = pgh_unpack_range(span.ds, span.ss, span_begin, span_end, direct_dst ? direct_dst : lstate.bytes.data(),
 			                      lstate.validity.data(), 0, errbuf);
 		}
 		if (rc != PGH_OK) {

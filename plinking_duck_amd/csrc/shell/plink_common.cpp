@@ -1936,8 +1936,8 @@ void DeviceTally::SampleMissing(uint32_t *out, const string &func_name) {
 pgh_dataset *DeviceDataset::Resident(const string &func_name) const {
 	if (streamed) {
 		throw IOException("%s: '%s' does not fit the HBM budget (%.1f GB of rows, budget %.1f GB: PLINKING_HBM_CACHE_GB); "
-		                  "only the tallies of plink_freq / plink_hardy / plink_missing / read_pgen counts and read_pfile's "
-		                  "per-sample counts stream a file of this size",
+		                  "the tallies of plink_freq / plink_hardy / plink_missing / read_pgen counts, read_pfile's per-sample "
+		                  "counts and hardcall output stream a file of this size; this call needs the matrix resident",
 		                  func_name, path,
 		                  static_cast<double>(info.raw_variant_ct) * static_cast<double>(info.record_bytes) / 1e9,
 		                  static_cast<double>(CacheBudgetBytes()) / 1e9);
@@ -1945,11 +1945,81 @@ pgh_dataset *DeviceDataset::Resident(const string &func_name) const {
 	return handle;
 }
 
+uint64_t DeviceDataset::WindowVariants() const {
+	const uint64_t pitch = std::max<uint64_t>(16, (static_cast<uint64_t>(info.record_bytes) + 127) / 128 * 128);
+	return std::max<uint64_t>(1, CacheBudgetBytes() / 2 / pitch);
+}
+
+RowWindows::~RowWindows() {
+	if (ss) {
+		pgh_subset_destroy(ss);
+	}
+	if (ds) {
+		pgh_close(ds);
+	}
+}
+
+RowLease::~RowLease() {
+	if (windows) {
+		std::lock_guard<std::mutex> lock(windows->m);
+		windows->users--;
+		windows->cv.notify_all();
+	}
+}
+
+RowLease LeaseRows(DeviceDataset &dataset, DeviceSubset *subset, RowWindows &w, const vector<uint64_t> *sample_include,
+                   uint32_t span_begin, uint32_t span_end, uint32_t file_end, const string &func_name) {
+	RowLease lease;
+	if (!dataset.streamed) {
+		lease.ds = dataset.Resident(func_name);
+		lease.ss = subset ? subset->handle : nullptr;
+		return lease;
+	}
+	std::unique_lock<std::mutex> lock(w.m);
+	while (!(w.ds && span_begin >= w.begin && span_end <= w.end)) {
+		if (w.users > 0) {
+			w.cv.wait(lock); // the window in place is still being read
+			continue;
+		}
+		if (w.ss) {
+			pgh_subset_destroy(w.ss);
+			w.ss = nullptr;
+		}
+		if (w.ds) {
+			pgh_close(w.ds);
+			w.ds = nullptr;
+		}
+		const uint64_t len = std::max<uint64_t>(dataset.WindowVariants(), span_end - span_begin);
+		const uint32_t w_end = static_cast<uint32_t>(std::min<uint64_t>(file_end, span_begin + len));
+		char errbuf[PGH_ERRBUF_LEN] = {0};
+		int rc = pgh_open(dataset.path.c_str(), nullptr, span_begin, w_end, &w.ds, errbuf);
+		if (rc == PGH_OK && sample_include && !sample_include->empty()) {
+			rc = pgh_subset_create(w.ds, sample_include->data(), &w.ss, errbuf);
+		}
+		if (rc != PGH_OK) {
+			if (w.ds) {
+				pgh_close(w.ds);
+				w.ds = nullptr;
+			}
+			w.cv.notify_all();
+			throw IOException("%s: streaming variants [%u, %u) of '%s' failed: %s", func_name, span_begin, w_end, dataset.path,
+			                  string(errbuf));
+		}
+		w.begin = span_begin;
+		w.end = w_end;
+		w.opened++;
+	}
+	w.users++;
+	lease.ds = w.ds;
+	lease.ss = w.ss;
+	lease.windows = &w;
+	return lease;
+}
+
 void DeviceDataset::ForEachWindow(uint32_t begin, uint32_t end, const vector<uint64_t> *sample_include,
                                   const string &func_name,
                                   const std::function<void(pgh_dataset *, pgh_subset *, uint32_t, uint32_t)> &fn) const {
-	const uint64_t pitch = std::max<uint64_t>(16, (static_cast<uint64_t>(info.record_bytes) + 127) / 128 * 128);
-	const uint64_t window = std::max<uint64_t>(1, CacheBudgetBytes() / 2 / pitch);
+	const uint64_t window = WindowVariants();
 	for (uint64_t v0 = begin; v0 < end; v0 += window) {
 		const uint32_t v1 = static_cast<uint32_t>(std::min<uint64_t>(end, v0 + window));
 		char errbuf[PGH_ERRBUF_LEN] = {0};

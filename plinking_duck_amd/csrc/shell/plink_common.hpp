@@ -9,6 +9,8 @@
 #include "../../../include/pgenhip.h"
 #include "duck_api.hpp"
 
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <unordered_map>
 
@@ -271,8 +273,10 @@ public:
 	//! The file's rows do not fit the HBM budget (PLINKING_HBM_CACHE_GB): nothing is resident, `handle` is null, and
 	//! the functions whose reference counterpart streams the file anyway -- plink_freq, plink_hardy, plink_missing in
 	//! both modes, read_pgen's counts / stats / filters -- get their tallies from a pass that walks the file window
-	//! by window through HBM (DeviceTally, streamed form).  Everything that needs the matrix itself (genotype output,
-	//! plink_score, plink_pca, plink_ld, read_pfile's sample orient) reports that it does not fit: Resident().
+	//! by window through HBM (DeviceTally, streamed form); read_pfile's per-sample counts add over the windows
+	//! (ForEachWindow) and hardcall output unpacks one window at a time (LeaseRows).  What needs the whole matrix at
+	//! once (plink_score, plink_pca, plink_ld, read_pfile's per-element sample orient) and the dosage / phase tracks
+	//! report that it does not fit: Resident().
 	bool streamed = false;
 	pgh_dataset *Resident(const string &func_name) const;
 	//! A streamed file (see `streamed`) window by window through HBM: opens variants [v0, v1) -- half the HBM budget
@@ -280,6 +284,8 @@ public:
 	//! them when given, hands both to fn and closes them.  Throws IOException when a window cannot be opened.
 	void ForEachWindow(uint32_t begin, uint32_t end, const vector<uint64_t> *sample_include, const string &func_name,
 	                   const std::function<void(pgh_dataset *, pgh_subset *, uint32_t, uint32_t)> &fn) const;
+	//! Variants per window of a streamed file: half the HBM budget.
+	uint64_t WindowVariants() const;
 	static shared_ptr<DeviceDataset> Acquire(const string &pgen_path, const string &func_name);
 
 	//! The tally pass over [begin, end) for this sample mask (nullptr = every sample), started if nobody has one:
@@ -359,6 +365,40 @@ public:
 	DeviceSubset(const DeviceSubset &) = delete;
 	pgh_subset *handle = nullptr;
 };
+
+//! The rows of a dataset for a scan that unpacks them span by span.  A resident dataset hands out its own handle; a
+//! streamed one (DeviceDataset::streamed) keeps ONE window of the file resident at a time -- opened on demand at the
+//! span a scan thread asks for, half the HBM budget long, with the sample subset staged next to it -- and replaces it
+//! when a thread asks for rows beyond it and nobody holds the old one any more.  Claims move forward through the file,
+//! so the windows do too; a straggler that still needs the previous window waits its turn and has it re-opened.
+struct RowWindows {
+	std::mutex m;
+	std::condition_variable cv;
+	pgh_dataset *ds = nullptr;
+	pgh_subset *ss = nullptr;
+	uint32_t begin = 0, end = 0;
+	int users = 0;
+	uint64_t opened = 0; // windows opened so far (a diagnostic)
+	~RowWindows();
+};
+
+struct RowLease {
+	pgh_dataset *ds = nullptr;
+	pgh_subset *ss = nullptr;
+	RowWindows *windows = nullptr;
+	RowLease() = default;
+	RowLease(const RowLease &) = delete;
+	RowLease &operator=(const RowLease &) = delete;
+	RowLease(RowLease &&o) noexcept : ds(o.ds), ss(o.ss), windows(o.windows) {
+		o.windows = nullptr;
+	}
+	~RowLease();
+};
+
+//! Rows [span_begin, span_end) of `dataset`: resident -> its handle and `subset`; streamed -> a lease on the window
+//! that holds them (`sample_include`: the subset's mask, NULL for all samples).
+RowLease LeaseRows(DeviceDataset &dataset, DeviceSubset *subset, RowWindows &windows, const vector<uint64_t> *sample_include,
+                   uint32_t span_begin, uint32_t span_end, uint32_t file_end, const string &func_name);
 
 //! A grow-only buffer of page-locked host memory (pgh_host_alloc): what a scan thread hands to the host-buffer
 //! entry points chunk after chunk, so the device-to-host copies run at the link's rate with no staging hop

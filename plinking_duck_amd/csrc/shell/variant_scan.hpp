@@ -44,6 +44,7 @@ struct VariantScanGlobal {
 	// reference's effective_variant_indices does) and claims kListBatch of them at a time.
 	bool has_variant_list = false;
 	vector<uint32_t> variant_list;
+	RowWindows row_windows; // read_pgen's genotype output over a file beyond the HBM budget (LeaseRows)
 
 	//! Enqueue the range's tally pass(es).  `products`: PGH_TALLY_* beyond the counts; exact_range: the pass must
 	//! cover exactly the scanned range (the per-sample product sums over it).

@@ -247,9 +247,11 @@ def test_score_from_a_pass_s_counts(gpu_lib, oracle):
 
 def test_a_file_beyond_the_hbm_budget_streams_its_tallies(gpu_lib, oracle, tmp_path, monkeypatch):
     """A file whose rows exceed the HBM budget is not made resident: plink_freq / plink_hardy / plink_missing (both
-    modes) / read_pgen's counts get their tallies from a pass that walks the file window by window through HBM --
-    the reference's own functions stream the file too -- and everything that needs the matrix itself says that it
-    does not fit instead of failing in an allocation."""
+    modes) / read_pgen's counts get their tallies from a pass that walks the file window by window through HBM,
+    read_pfile's per-sample counts add over the windows, read_pgen's / read_pfile's hardcall output unpacks one window
+    at a time -- the reference's own functions stream the file too -- and what needs the whole matrix at once (scores,
+    PCA, LD, the sample-orient matrix, dosage and phase tracks) says that it does not fit instead of failing in an
+    allocation."""
     L = gpu_lib
     m, n = 6000, 2003
     small = str(tmp_path / "fits")
@@ -265,7 +267,14 @@ def test_a_file_beyond_the_hbm_budget_streams_its_tallies(gpu_lib, oracle, tmp_p
              ("read_pfile", dict(orient="sample", genotypes="stats", samples=[5, 0, 1999], region="3:1-900000")),
              ("read_pfile", dict(orient="sample", genotypes="counts", af_range={"min": 0.1, "max": 0.4})),
              ("read_pfile", dict(orient="sample", genotypes="counts", variants={"start": 100, "stop": 4100},
-                                 include_genotypes=["hom_alt"]))]
+                                 include_genotypes=["hom_alt"])),
+             # genotype output: the hardcalls of a window at a time (LeaseRows), every layout, subsets, regions, filters
+             ("read_pgen", dict(genotypes="list")),
+             ("read_pfile", dict(genotypes="array", samples=[1, 5, 9, 2002], region="2:1-800000")),
+             ("read_pgen", dict(genotypes="columns", samples=[0, 2])),
+             ("read_pgen", dict(genotypes="struct", samples=[7, 3], af_range={"max": 0.3})),
+             ("read_pfile", dict(genotypes="list", include_genotypes=["hom_alt", "missing"], region="5:1-2000000")),
+             ("read_pgen", dict(genotypes="list", variants=[5, 4000, 17, 5999]))]
     want = [F.query(fn, small + (".pgen" if fn != "read_pfile" else ""), threads=3, **kw) for fn, kw in calls]
     monkeypatch.setenv("PLINKING_HBM_CACHE_GB", "0.0005")  # 500 KB: windows of ~240 variants
     passes = L.tally_passes_started()
@@ -274,7 +283,7 @@ def test_a_file_beyond_the_hbm_budget_streams_its_tallies(gpu_lib, oracle, tmp_p
         key = lambda r: tuple(str(x) for x in r[:3])
         assert got.names == w.names and sorted(got.rows, key=key) == sorted(w.rows, key=key), fn
     assert L.tally_passes_started() > passes + 8  # one resident pass per window of the file
-    for fn, kw in (("plink_score", dict(weights=[0.5] * m)), ("plink_pca", dict(n_pcs=2)), ("read_pgen", dict(genotypes="list")),
-                   ("plink_ld", {}), ("read_pfile", dict(orient="sample"))):
+    for fn, kw in (("plink_score", dict(weights=[0.5] * m)), ("plink_pca", dict(n_pcs=2)), ("read_pgen", dict(dosages=True)),
+                   ("read_pgen", dict(phased=True)), ("plink_ld", {}), ("read_pfile", dict(orient="sample"))):
         with pytest.raises(F.IOException, match="does not fit the HBM budget"):
             F.query(fn, big + (".pgen" if fn != "read_pfile" else ""), threads=2, **kw)
