@@ -274,9 +274,9 @@ public:
 	//! the functions whose reference counterpart streams the file anyway -- plink_freq, plink_hardy, plink_missing in
 	//! both modes, read_pgen's counts / stats / filters -- get their tallies from a pass that walks the file window
 	//! by window through HBM (DeviceTally, streamed form); read_pfile's per-sample counts add over the windows
-	//! (ForEachWindow) and hardcall output unpacks one window at a time (LeaseRows).  What needs the whole matrix at
-	//! once (plink_score, plink_pca, plink_ld, read_pfile's per-element sample orient) and the dosage / phase tracks
-	//! report that it does not fit: Resident().
+	//! (ForEachWindow), as do plink_score's partial sums, and hardcall output unpacks one window at a time
+	//! (LeaseRows).  What needs the whole matrix at once (plink_pca, plink_ld, read_pfile's per-element sample orient)
+	//! and read_pgen's dosage / phase output report that it does not fit: Resident().
 	bool streamed = false;
 	pgh_dataset *Resident(const string &func_name) const;
 	//! A streamed file (see `streamed`) window by window through HBM: opens variants [v0, v1) -- half the HBM budget

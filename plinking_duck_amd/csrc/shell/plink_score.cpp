@@ -216,7 +216,6 @@ static unique_ptr<GlobalTableFunctionState> PlinkScoreInitGlobal(ClientContext &
 	}
 	if (need_scores && !bind_data.scored_variants.empty()) {
 		state->dataset = DeviceDataset::Acquire(bind_data.c.pgen_path, "plink_score");
-		state->dataset->Resident("plink_score");
 		if (bind_data.c.has_sample_subset) {
 			state->subset =
 			    make_uniq<DeviceSubset>(*state->dataset, bind_data.c.sample_subset->sample_include, "plink_score");
@@ -264,6 +263,38 @@ static void PlinkScoreScan(ClientContext &, TableFunctionInput &data_p, DataChun
 							}
 						}
 					}
+					if (gstate.dataset->streamed) {
+						// A file beyond the HBM budget: the score is a sum over variants, so the windows' partial sums
+						// add (the scored variants are in file order, src/plink_score.cpp:407-408) -- one window of
+						// the file resident at a time, as the reference's own scan streams the file.
+						const size_t n_out = gstate.score_sums.size();
+						vector<double> part_score(n_out), part_dosage(n_out);
+						vector<uint32_t> part_ct(n_out);
+						gstate.dataset->ForEachWindow(
+						    vidx.front(), vidx.back() + 1,
+						    bind_data.c.has_sample_subset ? &bind_data.c.sample_subset->sample_include : nullptr, "plink_score",
+						    [&](pgh_dataset *win, pgh_subset *ss, uint32_t v0, uint32_t v1) {
+							    const size_t lo = std::lower_bound(vidx.begin(), vidx.end(), v0) - vidx.begin();
+							    const size_t hi = std::lower_bound(vidx.begin(), vidx.end(), v1) - vidx.begin();
+							    if (lo == hi) {
+								    return;
+							    }
+							    char werr[PGH_ERRBUF_LEN] = {0};
+							    if (pgh_score_counts(win, ss, static_cast<uint32_t>(hi - lo), vidx.data() + lo, weights.data() + lo,
+							                         flip.data() + lo, 1, mode, nullptr, part_score.data(),
+							                         gstate.need_dosage_sum ? part_dosage.data() : nullptr, part_ct.data(),
+							                         werr) != PGH_OK) {
+								    throw IOException("plink_score: scoring variants [%u, %u) failed: %s", v0, v1, string(werr));
+							    }
+							    for (size_t k = 0; k < n_out; k++) {
+								    gstate.score_sums[k] += part_score[k];
+								    gstate.allele_cts[k] += part_ct[k];
+								    if (gstate.need_dosage_sum) {
+									    gstate.named_allele_dosage_sums[k] += part_dosage[k];
+								    }
+							    }
+						    });
+					} else {
 					char errbuf[PGH_ERRBUF_LEN] = {0};
 					int rc = pgh_score_counts(gstate.dataset->Resident("plink_score"), gstate.subset ? gstate.subset->handle : nullptr,
 					                   static_cast<uint32_t>(n_scored), vidx.data(), weights.data(), flip.data(), 1, mode,
@@ -273,6 +304,7 @@ static void PlinkScoreScan(ClientContext &, TableFunctionInput &data_p, DataChun
 					                   gstate.allele_cts.data(), errbuf);
 					if (rc != PGH_OK) {
 						throw IOException("plink_score: scoring failed: %s", string(errbuf));
+					}
 					}
 				}
 			}

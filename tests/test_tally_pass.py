@@ -274,16 +274,27 @@ def test_a_file_beyond_the_hbm_budget_streams_its_tallies(gpu_lib, oracle, tmp_p
              ("read_pgen", dict(genotypes="columns", samples=[0, 2])),
              ("read_pgen", dict(genotypes="struct", samples=[7, 3], af_range={"max": 0.3})),
              ("read_pfile", dict(genotypes="list", include_genotypes=["hom_alt", "missing"], region="5:1-2000000")),
-             ("read_pgen", dict(genotypes="list", variants=[5, 4000, 17, 5999]))]
+             ("read_pgen", dict(genotypes="list", variants=[5, 4000, 17, 5999])),
+             # plink_score: a sum over variants, so the windows' partial sums add (compared with a tolerance below)
+             ("plink_score", dict(weights=[((7 * i) % 13 - 6) / 5.0 for i in range(m)])),
+             ("plink_score", dict(weights=[((3 * i) % 7) / 3.0 for i in range(m)], samples=[4, 9, 1500], center=True)),
+             ("plink_score", dict(weights=[{"id": f"sv{i}", "allele": "G" if i % 3 else "A", "weight": 0.25 * (i % 5 + 1)} for i in range(100, 5000, 37)],
+                                  no_mean_imputation=True))]
     want = [F.query(fn, small + (".pgen" if fn != "read_pfile" else ""), threads=3, **kw) for fn, kw in calls]
     monkeypatch.setenv("PLINKING_HBM_CACHE_GB", "0.0005")  # 500 KB: windows of ~240 variants
     passes = L.tally_passes_started()
     for (fn, kw), w in zip(calls, want):
         got = F.query(fn, big + (".pgen" if fn != "read_pfile" else ""), threads=3, **kw)
         key = lambda r: tuple(str(x) for x in r[:3])
+        if fn == "plink_score":  # (sums of doubles in another order)
+            key = lambda r: str(r[1])
+            assert got.names == w.names and len(got) == len(w)
+            for a, b in zip(sorted(got.rows, key=key), sorted(w.rows, key=key)):
+                assert all(x == y if not isinstance(x, float) else abs(x - y) <= 1e-9 * max(1.0, abs(y)) for x, y in zip(a, b)), fn
+            continue
         assert got.names == w.names and sorted(got.rows, key=key) == sorted(w.rows, key=key), fn
     assert L.tally_passes_started() > passes + 8  # one resident pass per window of the file
-    for fn, kw in (("plink_score", dict(weights=[0.5] * m)), ("plink_pca", dict(n_pcs=2)), ("read_pgen", dict(dosages=True)),
+    for fn, kw in (("plink_pca", dict(n_pcs=2)), ("read_pgen", dict(dosages=True)),
                    ("read_pgen", dict(phased=True)), ("plink_ld", {}), ("read_pfile", dict(orient="sample"))):
         with pytest.raises(F.IOException, match="does not fit the HBM budget"):
             F.query(fn, big + (".pgen" if fn != "read_pfile" else ""), threads=2, **kw)
