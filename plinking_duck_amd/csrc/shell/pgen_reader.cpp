@@ -227,11 +227,13 @@ unique_ptr<LocalTableFunctionState> PgenInitLocal(ExecutionContext &, TableFunct
 		}
 	}
 	if (gstate.need_genotypes && (bind_data.include_dosages || phased_out)) {
-		char errbuf[PGH_ERRBUF_LEN] = {0};
-		int rc = pgh_reader_create(gstate.scan.dataset->Resident(bind_data.func), gstate.scan.subset ? gstate.scan.subset->handle : nullptr,
-		                           &state->reader, errbuf);
-		if (rc != PGH_OK) {
-			throw IOException("%s: thread init failed: %s", fn, string(errbuf));
+		if (!gstate.scan.dataset->streamed) { // (streamed: the scan makes its reader on the window it leases)
+			char errbuf[PGH_ERRBUF_LEN] = {0};
+			int rc = pgh_reader_create(gstate.scan.dataset->Resident(bind_data.func),
+			                           gstate.scan.subset ? gstate.scan.subset->handle : nullptr, &state->reader, errbuf);
+			if (rc != PGH_OK) {
+				throw IOException("%s: thread init failed: %s", fn, string(errbuf));
+			}
 		}
 		uint32_t n = bind_data.output_sample_ct;
 		state->dosage_doubles.resize(n);
@@ -374,6 +376,12 @@ void PgenScan(ClientContext &, TableFunctionInput &data_p, DataChunk &output) {
 			}
 		}
 	}
+	const vector<uint64_t> *mask = bind_data.c.has_sample_subset ? &bind_data.c.sample_subset->sample_include : nullptr;
+	auto rows_of = [&](uint32_t b, uint32_t e) {
+		return LeaseRows(*gstate.scan.dataset, gstate.scan.subset.get(), gstate.scan.row_windows, mask, b, e,
+		                 bind_data.c.raw_variant_ct, bind_data.func);
+	};
+	const bool streamed = gstate.scan.dataset && gstate.scan.dataset->streamed;
 	if (pipelined) {
 		if (pgh_reader_unpack_wait(lstate.reader, lstate.cur) != PGH_OK) {
 			throw IOException("%s: PgrGet failed for variants [%u, %u): %s", fn, span_begin, span_end,
@@ -387,11 +395,6 @@ void PgenScan(ClientContext &, TableFunctionInput &data_p, DataChunk &output) {
 			lstate.bytes.resize(rows * n);
 		}
 		lstate.validity.resize(rows * val_words);
-		const vector<uint64_t> *mask = bind_data.c.has_sample_subset ? &bind_data.c.sample_subset->sample_include : nullptr;
-		auto rows_of = [&](uint32_t b, uint32_t e) {
-			return LeaseRows(*gstate.scan.dataset, gstate.scan.subset.get(), gstate.scan.row_windows, mask, b, e,
-			                 bind_data.c.raw_variant_ct, bind_data.func);
-		};
 		char errbuf[PGH_ERRBUF_LEN] = {0};
 		int rc = PGH_OK;
 		if (listed) {
@@ -422,9 +425,19 @@ void PgenScan(ClientContext &, TableFunctionInput &data_p, DataChunk &output) {
 		}
 		lstate.dosage_doubles.resize(plan.size() * static_cast<size_t>(n));
 		char errbuf[PGH_ERRBUF_LEN] = {0};
-		if (pgh_dosage_unpack(gstate.scan.dataset->Resident(bind_data.func), gstate.scan.subset ? gstate.scan.subset->handle : nullptr, 0,
-		                      static_cast<uint32_t>(plan.size()), chunk_vidx.data(), lstate.dosage_doubles.data(),
-		                      errbuf) != PGH_OK) {
+		int rc = PGH_OK;
+		if (streamed && listed) { // (a list need not be in file order: a window per variant, re-used while it lasts)
+			for (size_t r = 0; r < plan.size() && rc == PGH_OK; r++) {
+				RowLease rows_r = rows_of(chunk_vidx[r], chunk_vidx[r] + 1);
+				rc = pgh_dosage_unpack(rows_r.ds, rows_r.ss, 0, 1, &chunk_vidx[r], lstate.dosage_doubles.data() + r * static_cast<size_t>(n),
+				                       errbuf);
+			}
+		} else {
+			RowLease span = rows_of(span_begin, span_end);
+			rc = pgh_dosage_unpack(span.ds, span.ss, 0, static_cast<uint32_t>(plan.size()), chunk_vidx.data(),
+			                       lstate.dosage_doubles.data(), errbuf);
+		}
+		if (rc != PGH_OK) {
 			throw IOException("%s: PgrGetD failed for variants [%u, %u): %s", fn, span_begin, span_end, string(errbuf));
 		}
 	}
@@ -488,6 +501,20 @@ void PgenScan(ClientContext &, TableFunctionInput &data_p, DataChunk &output) {
 		const uint64_t *val = plain_hardcalls ? chunk_validity + src_row * val_words : nullptr;
 		dose = dosage_rows ? lstate.dosage_doubles.data() + row * static_cast<size_t>(n) : nullptr;
 		if (per_variant_decode) {
+			// streamed: variant v's window is held while its calls are read, and the thread's reader is one made
+			// on that window (a new one when the window has changed)
+			RowLease rows_v = streamed ? rows_of(v, v + 1) : RowLease();
+			if (streamed && (!lstate.reader || lstate.reader_window != rows_v.window_id)) {
+				if (lstate.reader) {
+					pgh_reader_destroy(lstate.reader);
+					lstate.reader = nullptr;
+				}
+				char errbuf[PGH_ERRBUF_LEN] = {0};
+				if (pgh_reader_create(rows_v.ds, rows_v.ss, &lstate.reader, errbuf) != PGH_OK) {
+					throw IOException("%s: thread init failed: %s", fn, string(errbuf));
+				}
+				lstate.reader_window = rows_v.window_id;
+			}
 			if (pgh_get_phased(lstate.reader, v, lstate.genovec.data(), lstate.phasepresent.data(),
 			                          lstate.phaseinfo.data()) != PGH_OK) {
 				throw IOException("%s: PgrGetP failed for variant %u: %s", fn, v,

@@ -49,6 +49,7 @@ struct RowPlan {
 struct PgenLocalState : public LocalTableFunctionState {
 	VariantScanLocal scan;
 	pgh_reader *reader = nullptr;
+	uint64_t reader_window = 0; // streamed files: the window `reader` was made on (RowLease::window_id)
 	PinnedBuffer<int8_t> bytes;      // unpacked span [rows][n_out]; page-locked: the device copies straight into it
 	PinnedBuffer<uint64_t> validity; // [rows][ceil(n_out/64)]
 	// The genotype-list pipeline (plain hardcalls over a variant range): while a Scan call fills its output vector

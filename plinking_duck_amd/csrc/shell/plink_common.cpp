@@ -2014,6 +2014,7 @@ RowLease LeaseRows(DeviceDataset &dataset, DeviceSubset *subset, RowWindows &w, 
 	lease.ds = w.ds;
 	lease.ss = w.ss;
 	lease.windows = &w;
+	lease.window_id = w.opened;
 	return lease;
 }
 

@@ -275,8 +275,8 @@ public:
 	//! both modes, read_pgen's counts / stats / filters -- get their tallies from a pass that walks the file window
 	//! by window through HBM (DeviceTally, streamed form); read_pfile's per-sample counts add over the windows
 	//! (ForEachWindow), as do plink_score's partial sums, and hardcall output unpacks one window at a time
-	//! (LeaseRows).  What needs the whole matrix at once (plink_pca, plink_ld, read_pfile's per-element sample orient)
-	//! and read_pgen's dosage / phase output report that it does not fit: Resident().
+	//! (LeaseRows), dosage and phased output included.  What needs the whole matrix at once (plink_pca, plink_ld,
+	//! read_pfile's per-element sample orient, plink_freq's dosage mode) reports that it does not fit: Resident().
 	bool streamed = false;
 	pgh_dataset *Resident(const string &func_name) const;
 	//! A streamed file (see `streamed`) window by window through HBM: opens variants [v0, v1) -- half the HBM budget
@@ -386,10 +386,11 @@ struct RowLease {
 	pgh_dataset *ds = nullptr;
 	pgh_subset *ss = nullptr;
 	RowWindows *windows = nullptr;
+	uint64_t window_id = 0; // which window of a streamed file (0: a resident dataset): a reader made on it is good until this changes
 	RowLease() = default;
 	RowLease(const RowLease &) = delete;
 	RowLease &operator=(const RowLease &) = delete;
-	RowLease(RowLease &&o) noexcept : ds(o.ds), ss(o.ss), windows(o.windows) {
+	RowLease(RowLease &&o) noexcept : ds(o.ds), ss(o.ss), windows(o.windows), window_id(o.window_id) {
 		o.windows = nullptr;
 	}
 	~RowLease();

@@ -275,6 +275,9 @@ def test_a_file_beyond_the_hbm_budget_streams_its_tallies(gpu_lib, oracle, tmp_p
              ("read_pgen", dict(genotypes="struct", samples=[7, 3], af_range={"max": 0.3})),
              ("read_pfile", dict(genotypes="list", include_genotypes=["hom_alt", "missing"], region="5:1-2000000")),
              ("read_pgen", dict(genotypes="list", variants=[5, 4000, 17, 5999])),
+             # the dosage and phase forms of the output (no tracks in this file: hardcall dosages, REF|ALT hets)
+             ("read_pgen", dict(dosages=True, samples=[3, 2, 1000])), ("read_pgen", dict(phased=True, samples=[0, 1, 2])),
+             ("read_pgen", dict(dosages=True, variants=[5000, 12, 4999])), ("read_pfile", dict(phased=True, region="6:1-300000")),
              # plink_score: a sum over variants, so the windows' partial sums add (compared with a tolerance below)
              ("plink_score", dict(weights=[((7 * i) % 13 - 6) / 5.0 for i in range(m)])),
              ("plink_score", dict(weights=[((3 * i) % 7) / 3.0 for i in range(m)], samples=[4, 9, 1500], center=True)),
@@ -294,7 +297,57 @@ def test_a_file_beyond_the_hbm_budget_streams_its_tallies(gpu_lib, oracle, tmp_p
             continue
         assert got.names == w.names and sorted(got.rows, key=key) == sorted(w.rows, key=key), fn
     assert L.tally_passes_started() > passes + 8  # one resident pass per window of the file
-    for fn, kw in (("plink_pca", dict(n_pcs=2)), ("read_pgen", dict(dosages=True)),
-                   ("read_pgen", dict(phased=True)), ("plink_ld", {}), ("read_pfile", dict(orient="sample"))):
+    for fn, kw in (("plink_pca", dict(n_pcs=2)), ("plink_ld", {}), ("read_pfile", dict(orient="sample"))):
         with pytest.raises(F.IOException, match="does not fit the HBM budget"):
             F.query(fn, big + (".pgen" if fn != "read_pfile" else ""), threads=2, **kw)
+
+
+def test_dosage_tracks_stream_with_the_rows(gpu_lib, tmp_path, monkeypatch):
+    """A file WITH dosage tracks beyond the HBM budget: the windows are opened with their share of the tracks, so
+    read_pgen(dosages := true) and plink_score (which scores a dosage-bearing variant from its dosages) give what the
+    resident route gives."""
+    L = gpu_lib
+    m, n = 3000, 1501
+    small, big = str(tmp_path / "fits"), str(tmp_path / "too_big")
+    for prefix in (small, big):
+        L.synth_write_dosage_files(prefix, m, n, SEED + 5, 0.03, 0.3)
+    calls = [("read_pgen", dict(dosages=True)), ("read_pgen", dict(dosages=True, samples=[1500, 7, 8], variants=[2999, 0, 1400])),
+             ("read_pgen", dict(genotypes="list")), ("plink_score", dict(weights=[((5 * i) % 11 - 5) / 4.0 for i in range(m)]))]
+    want = [F.query(fn, small + ".pgen", threads=3, **kw) for fn, kw in calls]
+    monkeypatch.setenv("PLINKING_HBM_CACHE_GB", "0.0005")
+    for (fn, kw), w in zip(calls, want):
+        got = F.query(fn, big + ".pgen", threads=3, **kw)
+        assert got.names == w.names and len(got) == len(w)
+        key = (lambda r: str(r[1])) if fn == "plink_score" else (lambda r: (str(r[0]), r[1]))
+        for a, b in zip(sorted(got.rows, key=key), sorted(w.rows, key=key)):
+            if fn == "plink_score":
+                assert all(x == y if not isinstance(x, float) else abs(x - y) <= 1e-9 * max(1.0, abs(y)) for x, y in zip(a, b))
+            else:
+                assert a == b, fn
+
+
+def test_phase_tracks_stream_with_the_rows(gpu_lib, tmp_path, monkeypatch):
+    """Phased output over a file beyond the HBM budget: every variant's phase track travels with its window, and a scan
+    thread makes its PgrGetP reader on the window it holds (compressed record types included)."""
+    import pgen_writer as W
+
+    rng = np.random.default_rng(12)
+    m, n = 900, 700
+    geno = rng.choice(np.array([0, 1, 2, 3], dtype=np.uint8), size=(m, n), p=[0.55, 0.3, 0.1, 0.05])
+    kinds = W.choose_kinds(geno, rng)
+    for tag in ("fits", "too_big"):
+        prefix = str(tmp_path / tag)
+        W.write_pgen(prefix + ".pgen", geno, kinds, phase_rng=np.random.default_rng(8))
+        with open(prefix + ".pvar", "w") as f:
+            f.write("#CHROM\tPOS\tID\tREF\tALT\n" + "".join(f"{1 + v // 300}\t{100 * (v % 300 + 1)}\tp{v}\tA\tC\n" for v in range(m)))
+        with open(prefix + ".psam", "w") as f:
+            f.write("#IID\tSEX\n" + "".join(f"I{s}\t{1 + s % 2}\n" for s in range(n)))
+    small, big = str(tmp_path / "fits"), str(tmp_path / "too_big")
+    calls = [("read_pgen", dict(phased=True)), ("read_pgen", dict(phased=True, samples=[699, 0, 350], variants=[899, 3, 450])),
+             ("read_pfile", dict(phased=True, genotypes="list", region="2:1-20000"))]
+    want = [F.query(fn, small + (".pgen" if fn == "read_pgen" else ""), threads=3, columns=["ID", "genotypes"], **kw) for fn, kw in calls]
+    assert any([1, 0] in g for _, g in want[0].rows)  # the file does carry ALT|REF hets
+    monkeypatch.setenv("PLINKING_HBM_CACHE_GB", "0.00002")  # 20 KB: windows of ~40 variants
+    for (fn, kw), w in zip(calls, want):
+        got = F.query(fn, big + (".pgen" if fn == "read_pgen" else ""), threads=3, columns=["ID", "genotypes"], **kw)
+        assert sorted(got.rows) == sorted(w.rows), fn
