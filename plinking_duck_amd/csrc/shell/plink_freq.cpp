@@ -214,7 +214,11 @@ static void PlinkFreqScan(ClientContext &, TableFunctionInput &data_p, DataChunk
 		// PgrGetDCounts for the chunk's rows at once (src/plink_freq.cpp:475-480, :525-535)
 		vector<uint64_t> moments(3 * dosage_rows.size());
 		char errbuf[PGH_ERRBUF_LEN] = {0};
-		if (pgh_dosage_sums(gstate.scan.dataset->Resident("plink_freq"), gstate.scan.subset ? gstate.scan.subset->handle : nullptr, 0,
+		// (a file beyond the HBM budget: the window that holds the chunk's variants -- they are one claim's, ascending)
+		RowLease span = LeaseRows(*gstate.scan.dataset, gstate.scan.subset.get(), gstate.scan.row_windows,
+		                          bind_data.c.has_sample_subset ? &bind_data.c.sample_subset->sample_include : nullptr,
+		                          dosage_vidx.front(), dosage_vidx.back() + 1, bind_data.c.raw_variant_ct, "plink_freq");
+		if (pgh_dosage_sums(span.ds, span.ss, 0,
 		                    static_cast<uint32_t>(dosage_vidx.size()), dosage_vidx.data(),
 		                    reinterpret_cast<uint64_t(*)[3]>(moments.data()), errbuf) != PGH_OK) {
 			throw IOException("plink_freq: PgrGetDCounts failed for variants [%u, %u]: %s", dosage_vidx.front(),

@@ -304,15 +304,16 @@ def test_a_file_beyond_the_hbm_budget_streams_its_tallies(gpu_lib, oracle, tmp_p
 
 def test_dosage_tracks_stream_with_the_rows(gpu_lib, tmp_path, monkeypatch):
     """A file WITH dosage tracks beyond the HBM budget: the windows are opened with their share of the tracks, so
-    read_pgen(dosages := true) and plink_score (which scores a dosage-bearing variant from its dosages) give what the
-    resident route gives."""
+    read_pgen(dosages := true), plink_freq(dosage := true) and plink_score (which scores a dosage-bearing variant from
+    its dosages) give what the resident route gives."""
     L = gpu_lib
     m, n = 3000, 1501
     small, big = str(tmp_path / "fits"), str(tmp_path / "too_big")
     for prefix in (small, big):
         L.synth_write_dosage_files(prefix, m, n, SEED + 5, 0.03, 0.3)
     calls = [("read_pgen", dict(dosages=True)), ("read_pgen", dict(dosages=True, samples=[1500, 7, 8], variants=[2999, 0, 1400])),
-             ("read_pgen", dict(genotypes="list")), ("plink_score", dict(weights=[((5 * i) % 11 - 5) / 4.0 for i in range(m)]))]
+             ("read_pgen", dict(genotypes="list")), ("plink_score", dict(weights=[((5 * i) % 11 - 5) / 4.0 for i in range(m)])),
+             ("plink_freq", dict(dosage=True)), ("plink_freq", dict(dosage=True, samples=[2, 900, 901], region="3:1-50000"))]
     want = [F.query(fn, small + ".pgen", threads=3, **kw) for fn, kw in calls]
     monkeypatch.setenv("PLINKING_HBM_CACHE_GB", "0.0005")
     for (fn, kw), w in zip(calls, want):
