@@ -140,6 +140,7 @@ struct PfileGlobalState : public GlobalTableFunctionState {
 	uint32_t max_threads_config = 0;
 	vector<shared_ptr<DeviceDataset>> datasets;
 	vector<unique_ptr<DeviceSubset>> subsets;
+	vector<unique_ptr<RowWindows>> row_windows; // per source: a file beyond the HBM budget, one window at a time
 	std::mutex phase1_mutex;
 	bool phase1_done = false;
 	vector<uint32_t> counts;     // [output sample][4]
@@ -488,32 +489,43 @@ static unique_ptr<FunctionData> PfileBind(ClientContext &context, TableFunctionB
 				if (c.has_sample_subset) {
 					subset = make_uniq<DeviceSubset>(*dataset, c.sample_subset->sample_include, "read_pfile");
 				}
-				char errbuf[PGH_ERRBUF_LEN] = {0};
-				uint32_t gc[4];
-				uint32_t run_begin = 0;
-				vector<uint32_t> tallies;
-				while (run_begin < candidates.size()) { // one device call per run of consecutive candidates
-					uint32_t run_end = run_begin + 1;
-					while (run_end < candidates.size() && candidates[run_end] == candidates[run_end - 1] + 1) {
-						run_end++;
-					}
-					tallies.resize(4 * static_cast<size_t>(run_end - run_begin));
-					if (pgh_counts_range(dataset->Resident("read_pfile"), subset ? subset->handle : nullptr, candidates[run_begin],
-					                     candidates[run_end - 1] + 1, reinterpret_cast<uint32_t(*)[4]>(tallies.data()),
-					                     errbuf) != PGH_OK) {
-						throw IOException("read_pfile: PgrGetCounts failed for variant %u during count filter: %s",
-						                  candidates[run_begin], string(errbuf));
-					}
-					for (uint32_t i = run_begin; i < run_end; i++) {
-						std::memcpy(gc, tallies.data() + 4 * static_cast<size_t>(i - run_begin), sizeof gc);
-						auto pf = CheckPreDecompFilters(bind_data->count_filter, bind_data->genotype_filter, gc,
-						                                c.effective_sample_ct);
-						if (!pf.skip) {
-							src.effective.push_back(candidates[i]);
-							bind_data->all_pass.push_back(pf.all_pass);
+				// the candidates (ascending) inside [w0, w1) on `ds`: the whole file when it is resident, one window
+				// at a time when it is beyond the HBM budget
+				auto tally_candidates = [&](pgh_dataset *ds, pgh_subset *ss, uint32_t w0, uint32_t w1) {
+					char errbuf[PGH_ERRBUF_LEN] = {0};
+					uint32_t gc[4];
+					uint32_t run_begin = static_cast<uint32_t>(std::lower_bound(candidates.begin(), candidates.end(), w0) - candidates.begin());
+					const uint32_t stop = static_cast<uint32_t>(std::lower_bound(candidates.begin(), candidates.end(), w1) - candidates.begin());
+					vector<uint32_t> tallies;
+					while (run_begin < stop) { // one device call per run of consecutive candidates
+						uint32_t run_end = run_begin + 1;
+						while (run_end < stop && candidates[run_end] == candidates[run_end - 1] + 1) {
+							run_end++;
 						}
+						tallies.resize(4 * static_cast<size_t>(run_end - run_begin));
+						if (pgh_counts_range(ds, ss, candidates[run_begin], candidates[run_end - 1] + 1,
+						                     reinterpret_cast<uint32_t(*)[4]>(tallies.data()), errbuf) != PGH_OK) {
+							throw IOException("read_pfile: PgrGetCounts failed for variant %u during count filter: %s",
+							                  candidates[run_begin], string(errbuf));
+						}
+						for (uint32_t i = run_begin; i < run_end; i++) {
+							std::memcpy(gc, tallies.data() + 4 * static_cast<size_t>(i - run_begin), sizeof gc);
+							auto pf = CheckPreDecompFilters(bind_data->count_filter, bind_data->genotype_filter, gc,
+							                                c.effective_sample_ct);
+							if (!pf.skip) {
+								src.effective.push_back(candidates[i]);
+								bind_data->all_pass.push_back(pf.all_pass);
+							}
+						}
+						run_begin = run_end;
 					}
-					run_begin = run_end;
+				};
+				if (dataset->streamed) {
+					dataset->ForEachWindow(candidates.front(), candidates.back() + 1,
+					                       c.has_sample_subset ? &c.sample_subset->sample_include : nullptr, "read_pfile",
+					                       tally_candidates);
+				} else {
+					tally_candidates(dataset->Resident("read_pfile"), subset ? subset->handle : nullptr, 0u, 0xffffffffu);
 				}
 			} else {
 				src.effective = std::move(candidates);
@@ -675,6 +687,7 @@ static unique_ptr<GlobalTableFunctionState> PfileInitGlobal(ClientContext &conte
 	if (state->need_genotypes || bind_data.genotype_filter.active) {
 		for (auto &src : bind_data.sources) {
 			state->datasets.push_back(DeviceDataset::Acquire(src.c.pgen_path, "read_pfile"));
+			state->row_windows.push_back(make_uniq<RowWindows>());
 			state->subsets.push_back(nullptr);
 			if (bind_data.sources[0].c.has_sample_subset) {
 				state->subsets.back() = make_uniq<DeviceSubset>(
@@ -769,35 +782,52 @@ static void RunSampleMatrixPhase1(const PfileBindData &bind_data, PfileGlobalSta
 		if (eff.empty()) {
 			continue;
 		}
-		pgh_dataset *ds = gstate.datasets[si]->Resident("read_pfile");
-		pgh_subset *ss = gstate.subsets[si] ? gstate.subsets[si]->handle : nullptr;
-		const uint32_t n_var = static_cast<uint32_t>(eff.size());
-		const bool whole = bind_data.sources.size() == 1; // one source: the call fills the matrix in place
-		int rc;
-		if (bind_data.dosages) {
-			double *dst = gstate.dosage_rows.data();
-			if (!whole) {
-				dpart.resize(n_out * eff.size());
-				dst = dpart.data();
+		// the effective variants [lo, hi) of this source on `ds`, into matrix columns at + lo ..: all of them on a
+		// resident file (one source: straight into the matrix), a window's share on a file beyond the HBM budget
+		auto read_columns = [&](pgh_dataset *ds, pgh_subset *ss, size_t lo, size_t hi) {
+			const uint32_t n_var = static_cast<uint32_t>(hi - lo);
+			if (n_var == 0) {
+				return;
 			}
-			rc = pgh_dosage_unpack_samples(ds, ss, n_var, eff.data(), dst, errbuf);
-			for (size_t k = 0; !whole && rc == PGH_OK && k < n_out; k++) {
-				std::memcpy(gstate.dosage_rows.data() + k * total + at, dpart.data() + k * eff.size(), 8 * eff.size());
+			const bool whole = bind_data.sources.size() == 1 && lo == 0 && hi == eff.size();
+			int rc;
+			if (bind_data.dosages) {
+				double *dst = gstate.dosage_rows.data();
+				if (!whole) {
+					dpart.resize(n_out * n_var);
+					dst = dpart.data();
+				}
+				rc = pgh_dosage_unpack_samples(ds, ss, n_var, eff.data() + lo, dst, errbuf);
+				for (size_t k = 0; !whole && rc == PGH_OK && k < n_out; k++) {
+					std::memcpy(gstate.dosage_rows.data() + k * total + at + lo, dpart.data() + k * n_var, 8 * static_cast<size_t>(n_var));
+				}
+			} else {
+				int8_t *dst = gstate.calls.data();
+				if (!whole) {
+					part.resize(n_out * n_var);
+					dst = part.data();
+				}
+				rc = pgh_unpack_samples(ds, ss, n_var, eff.data() + lo, dst, -9, errbuf);
+				for (size_t k = 0; !whole && rc == PGH_OK && k < n_out; k++) {
+					std::memcpy(gstate.calls.data() + k * total + at + lo, part.data() + k * n_var, n_var);
+				}
 			}
+			if (rc != PGH_OK) {
+				throw IOException("read_pfile: %s failed during sample-orient pre-read: %s",
+				                  bind_data.dosages ? "PgrGetD" : "PgrGet", string(errbuf));
+			}
+		};
+		if (gstate.datasets[si]->streamed) {
+			const auto &first = bind_data.sources[0].c;
+			gstate.datasets[si]->ForEachWindow(
+			    eff.front(), eff.back() + 1, first.has_sample_subset ? &first.sample_subset->sample_include : nullptr, "read_pfile",
+			    [&](pgh_dataset *ds, pgh_subset *ss, uint32_t w0, uint32_t w1) {
+				    read_columns(ds, ss, std::lower_bound(eff.begin(), eff.end(), w0) - eff.begin(),
+				                 std::lower_bound(eff.begin(), eff.end(), w1) - eff.begin());
+			    });
 		} else {
-			int8_t *dst = gstate.calls.data();
-			if (!whole) {
-				part.resize(n_out * eff.size());
-				dst = part.data();
-			}
-			rc = pgh_unpack_samples(ds, ss, n_var, eff.data(), dst, -9, errbuf);
-			for (size_t k = 0; !whole && rc == PGH_OK && k < n_out; k++) {
-				std::memcpy(gstate.calls.data() + k * total + at, part.data() + k * eff.size(), eff.size());
-			}
-		}
-		if (rc != PGH_OK) {
-			throw IOException("read_pfile: %s failed during sample-orient pre-read: %s",
-			                  bind_data.dosages ? "PgrGetD" : "PgrGet", string(errbuf));
+			read_columns(gstate.datasets[si]->Resident("read_pfile"), gstate.subsets[si] ? gstate.subsets[si]->handle : nullptr, 0,
+			             eff.size());
 		}
 		at += eff.size();
 	}
@@ -825,7 +855,17 @@ static void RunSampleMatrixPhase1(const PfileBindData &bind_data, PfileGlobalSta
 		size_t first = 0;
 		for (size_t si = 0; si < bind_data.sources.size(); si++) {
 			const auto &eff = bind_data.sources[si].effective;
-			if (!eff.empty()) {
+			if (!eff.empty() && gstate.datasets[si]->streamed) {
+				const auto &c0 = bind_data.sources[0].c;
+				gstate.datasets[si]->ForEachWindow(
+				    eff.front(), eff.back() + 1, c0.has_sample_subset ? &c0.sample_subset->sample_include : nullptr, "read_pfile",
+				    [&](pgh_dataset *ds, pgh_subset *ss, uint32_t w0, uint32_t w1) {
+					    const size_t lo = std::lower_bound(eff.begin(), eff.end(), w0) - eff.begin();
+					    const size_t hi = std::lower_bound(eff.begin(), eff.end(), w1) - eff.begin();
+					    MarkAltFirstHets(ds, ss, eff.data() + lo, static_cast<uint32_t>(hi - lo), static_cast<uint32_t>(n_out),
+					                     [&](uint32_t j, uint32_t k) -> int8_t & { return gstate.calls[k * total + first + lo + j]; });
+				    });
+			} else if (!eff.empty()) {
 				MarkAltFirstHets(gstate.datasets[si]->Resident("read_pfile"), gstate.subsets[si] ? gstate.subsets[si]->handle : nullptr,
 				                 eff.data(), static_cast<uint32_t>(eff.size()), static_cast<uint32_t>(n_out),
 				                 [&](uint32_t j, uint32_t k) -> int8_t & { return gstate.calls[k * total + first + j]; });
@@ -985,35 +1025,51 @@ static void GenotypeOrientScan(const PfileBindData &bind_data, PfileGlobalState 
 			lstate.cur_sample = 0;
 			if (gstate.need_genotypes) {
 				const uint32_t si = bind_data.flat_source[begin];
-				pgh_dataset *ds = gstate.datasets[si]->Resident("read_pfile");
-				pgh_subset *ss = gstate.subsets[si] ? gstate.subsets[si]->handle : nullptr;
+				// The batch (<= 64 ascending variants of one source) in pieces whose span fits a window of a file beyond
+				// the HBM budget -- one piece on a resident file, or where the effective variants lie close together.
+				const auto &c0 = bind_data.sources[0].c;
+				const uint64_t reach = gstate.datasets[si]->streamed ? gstate.datasets[si]->WindowVariants() : ~0ull;
 				char errbuf[PGH_ERRBUF_LEN] = {0};
 				int rc = PGH_OK;
 				if (bind_data.dosages) {
 					lstate.batch_dosages.resize(static_cast<size_t>(cnt) * n_out);
-					rc = pgh_dosage_unpack(ds, ss, 0, cnt, bind_data.flat_variant.data() + begin, lstate.batch_dosages.data(),
-					                       errbuf);
 				} else {
 					lstate.batch_calls.resize(static_cast<size_t>(cnt) * n_out);
-					uint32_t k = 0;
-					while (k < cnt && rc == PGH_OK) { // one device call per run of consecutive variants
-						uint32_t e = k + 1;
-						while (e < cnt && bind_data.flat_variant[begin + e] == bind_data.flat_variant[begin + e - 1] + 1) {
-							e++;
-						}
-						rc = pgh_unpack_range(ds, ss, bind_data.flat_variant[begin + k], bind_data.flat_variant[begin + e - 1] + 1,
-						                      lstate.batch_calls.data() + static_cast<size_t>(k) * n_out, nullptr, -9, errbuf);
-						k = e;
+				}
+				const uint32_t *fv = bind_data.flat_variant.data() + begin;
+				for (uint32_t p0 = 0; p0 < cnt && rc == PGH_OK;) {
+					uint32_t p1 = p0 + 1;
+					while (p1 < cnt && static_cast<uint64_t>(fv[p1]) + 1 - fv[p0] <= reach) {
+						p1++;
 					}
+					RowLease rows = LeaseRows(*gstate.datasets[si], gstate.subsets[si].get(), *gstate.row_windows[si],
+					                          c0.has_sample_subset ? &c0.sample_subset->sample_include : nullptr, fv[p0],
+					                          fv[p1 - 1] + 1, bind_data.sources[si].c.raw_variant_ct, "read_pfile");
+					if (bind_data.dosages) {
+						rc = pgh_dosage_unpack(rows.ds, rows.ss, 0, p1 - p0, fv + p0,
+						                       lstate.batch_dosages.data() + static_cast<size_t>(p0) * n_out, errbuf);
+					} else {
+						uint32_t k = p0;
+						while (k < p1 && rc == PGH_OK) { // one device call per run of consecutive variants
+							uint32_t e = k + 1;
+							while (e < p1 && fv[e] == fv[e - 1] + 1) {
+								e++;
+							}
+							rc = pgh_unpack_range(rows.ds, rows.ss, fv[k], fv[e - 1] + 1,
+							                      lstate.batch_calls.data() + static_cast<size_t>(k) * n_out, nullptr, -9, errbuf);
+							k = e;
+						}
+						if (rc == PGH_OK && bind_data.phased) {
+							MarkAltFirstHets(rows.ds, rows.ss, fv + p0, p1 - p0, n_out, [&](uint32_t j, uint32_t k2) -> int8_t & {
+								return lstate.batch_calls[static_cast<size_t>(p0 + j) * n_out + k2];
+							});
+						}
+					}
+					p0 = p1;
 				}
 				if (rc != PGH_OK) {
 					throw IOException("read_pfile: %s failed for variant %u: %s", bind_data.dosages ? "PgrGetD" : "PgrGet",
 					                  bind_data.flat_variant[begin], string(errbuf));
-				}
-				if (bind_data.phased && !bind_data.dosages) {
-					MarkAltFirstHets(ds, ss, bind_data.flat_variant.data() + begin, cnt, n_out, [&](uint32_t j, uint32_t k) -> int8_t & {
-						return lstate.batch_calls[static_cast<size_t>(j) * n_out + k];
-					});
 				}
 			}
 		}

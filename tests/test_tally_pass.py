@@ -278,6 +278,15 @@ def test_a_file_beyond_the_hbm_budget_streams_its_tallies(gpu_lib, oracle, tmp_p
              # the dosage and phase forms of the output (no tracks in this file: hardcall dosages, REF|ALT hets)
              ("read_pgen", dict(dosages=True, samples=[3, 2, 1000])), ("read_pgen", dict(phased=True, samples=[0, 1, 2])),
              ("read_pgen", dict(dosages=True, variants=[5000, 12, 4999])), ("read_pfile", dict(phased=True, region="6:1-300000")),
+             # read_pfile's other orients: the sample-major matrix is filled a window's columns at a time, a genotype-orient
+             # batch leases the window(s) that hold it; count filters settle the effective variants window by window at bind
+             ("read_pfile", dict(orient="sample", samples=[9, 1, 1200], region="2:1-20000")),
+             ("read_pfile", dict(orient="sample", genotypes="columns", samples=[0, 5], af_range={"min": 0.3, "max": 0.5},
+                                 region="1:1-27000")),
+             ("read_pfile", dict(orient="sample", genotypes="list", samples=[3, 4, 5, 6], variants=[10, 3000, 5990],
+                                 include_genotypes=["het"])),
+             ("read_pfile", dict(orient="genotype", samples=[11, 12], region="4:1-9000", include_genotypes=["hom_alt", "missing"])),
+             ("read_pfile", dict(orient="genotype", samples=[2, 40], ac_range={"max": 1})),
              # plink_score: a sum over variants, so the windows' partial sums add (compared with a tolerance below)
              ("plink_score", dict(weights=[((7 * i) % 13 - 6) / 5.0 for i in range(m)])),
              ("plink_score", dict(weights=[((3 * i) % 7) / 3.0 for i in range(m)], samples=[4, 9, 1500], center=True)),
@@ -288,7 +297,7 @@ def test_a_file_beyond_the_hbm_budget_streams_its_tallies(gpu_lib, oracle, tmp_p
     passes = L.tally_passes_started()
     for (fn, kw), w in zip(calls, want):
         got = F.query(fn, big + (".pgen" if fn != "read_pfile" else ""), threads=3, **kw)
-        key = lambda r: tuple(str(x) for x in r[:3])
+        key = lambda r: tuple(str(x) for x in r[:3]) + ((str(r[-2]),) if kw.get("orient") == "genotype" else ())
         if fn == "plink_score":  # (sums of doubles in another order)
             key = lambda r: str(r[1])
             assert got.names == w.names and len(got) == len(w)
@@ -297,7 +306,7 @@ def test_a_file_beyond_the_hbm_budget_streams_its_tallies(gpu_lib, oracle, tmp_p
             continue
         assert got.names == w.names and sorted(got.rows, key=key) == sorted(w.rows, key=key), fn
     assert L.tally_passes_started() > passes + 8  # one resident pass per window of the file
-    for fn, kw in (("plink_pca", dict(n_pcs=2)), ("plink_ld", {}), ("read_pfile", dict(orient="sample"))):
+    for fn, kw in (("plink_pca", dict(n_pcs=2)), ("plink_ld", {})):
         with pytest.raises(F.IOException, match="does not fit the HBM budget"):
             F.query(fn, big + (".pgen" if fn != "read_pfile" else ""), threads=2, **kw)
 
@@ -345,10 +354,13 @@ def test_phase_tracks_stream_with_the_rows(gpu_lib, tmp_path, monkeypatch):
             f.write("#IID\tSEX\n" + "".join(f"I{s}\t{1 + s % 2}\n" for s in range(n)))
     small, big = str(tmp_path / "fits"), str(tmp_path / "too_big")
     calls = [("read_pgen", dict(phased=True)), ("read_pgen", dict(phased=True, samples=[699, 0, 350], variants=[899, 3, 450])),
-             ("read_pfile", dict(phased=True, genotypes="list", region="2:1-20000"))]
-    want = [F.query(fn, small + (".pgen" if fn == "read_pgen" else ""), threads=3, columns=["ID", "genotypes"], **kw) for fn, kw in calls]
+             ("read_pfile", dict(phased=True, genotypes="list", region="2:1-20000")),
+             ("read_pfile", dict(phased=True, orient="sample", samples=[5, 6, 7], region="1:1-12000")),
+             ("read_pfile", dict(phased=True, orient="genotype", samples=[100, 101], region="3:1-30000"))]
+    cols = lambda kw: ["IID", "genotypes"] if kw.get("orient") == "sample" else ["ID", "IID", "genotype"] if kw.get("orient") else ["ID", "genotypes"]
+    want = [F.query(fn, small + (".pgen" if fn == "read_pgen" else ""), threads=3, columns=cols(kw), **kw) for fn, kw in calls]
     assert any([1, 0] in g for _, g in want[0].rows)  # the file does carry ALT|REF hets
     monkeypatch.setenv("PLINKING_HBM_CACHE_GB", "0.00002")  # 20 KB: windows of ~40 variants
     for (fn, kw), w in zip(calls, want):
-        got = F.query(fn, big + (".pgen" if fn == "read_pgen" else ""), threads=3, columns=["ID", "genotypes"], **kw)
-        assert sorted(got.rows) == sorted(w.rows), fn
+        got = F.query(fn, big + (".pgen" if fn == "read_pgen" else ""), threads=3, columns=cols(kw), **kw)
+        assert sorted(got.rows, key=repr) == sorted(w.rows, key=repr), fn
