@@ -114,6 +114,26 @@ void PghTrimBlockCache() {
 	}
 }
 
+void PghMakeRoom(size_t bytes) {
+	if (bytes < (256ull << 20)) {
+		return;
+	}
+	{
+		std::lock_guard<std::mutex> lk(g_block_mu);
+		if (g_block_free.empty()) {
+			return;
+		}
+	}
+	size_t free_b = 0, total_b = 0;
+	if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+		(void)hipGetLastError();
+		return;
+	}
+	if (free_b < bytes + (1ull << 30)) {
+		PghTrimBlockCache();
+	}
+}
+
 hipError_t PghBlockAlloc(void **out, size_t bytes) {
 	int device = 0;
 	hipError_t e = hipGetDevice(&device);
@@ -137,6 +157,7 @@ hipError_t PghBlockAlloc(void **out, size_t bytes) {
 			return hipSuccess;
 		}
 	}
+	PghMakeRoom(bytes);
 	e = hipMalloc(out, bytes);
 	if (e != hipSuccess) {
 		(void)hipGetLastError();

@@ -241,8 +241,12 @@ void PghTrimBlockCache();
 size_t PghDeviceFreeBytes();
 // hipMalloc for blocks that live longer than a call (dataset rows, plans, readers): a failure empties the block
 // cache and tries once more.
+// (a failing hipMalloc of a hundred gigabytes takes seconds to say so: a large request that the driver's free memory
+// cannot cover has the list emptied BEFORE it is made)
+void PghMakeRoom(size_t bytes);
 template <class T>
 hipError_t PghMalloc(T **out, size_t bytes) {
+	PghMakeRoom(bytes);
 	hipError_t e = hipMalloc(reinterpret_cast<void **>(out), bytes);
 	if (e != hipSuccess) {
 		(void)hipGetLastError();
