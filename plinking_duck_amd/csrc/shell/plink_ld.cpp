@@ -91,6 +91,7 @@ struct PlinkLdGlobalState : public GlobalTableFunctionState {
 	uint32_t max_threads_config = 0;
 	shared_ptr<DeviceDataset> dataset;
 	unique_ptr<DeviceSubset> subset;
+	RowWindows row_windows; // a file beyond the HBM budget: the window that holds a call's pairs (LeaseRows)
 
 	idx_t MaxThreads() const override {
 		if (mode == LdMode::PAIRWISE) {
@@ -240,11 +241,32 @@ static void ListPartners(const PlinkLdBindData &bind_data, uint32_t anchor, uint
 	}
 }
 
-static void RunPairs(PlinkLdGlobalState &gstate, PlinkLdLocalState &lstate) {
+static void RunPairs(const PlinkLdBindData &bind_data, PlinkLdGlobalState &gstate, PlinkLdLocalState &lstate) {
 	const size_t n = lstate.pair_a.size();
 	lstate.sums.resize(6 * n);
+	if (n == 0) {
+		return;
+	}
+	// Both rows of a pair have to be resident together.  A file beyond the HBM budget keeps one window of its rows
+	// resident at a time: the one that holds every variant this call names -- a claim's anchors and their partners
+	// inside the LD window, so a few thousand neighbours -- or, when the pairs reach further than a window (inter_chr,
+	// a far-apart variant1 / variant2), nothing: that does not fit.
+	uint32_t lo = lstate.pair_a[0], hi = lstate.pair_a[0];
+	for (size_t i = 0; i < n; i++) {
+		lo = std::min({lo, lstate.pair_a[i], lstate.pair_b[i]});
+		hi = std::max({hi, lstate.pair_a[i], lstate.pair_b[i]});
+	}
+	if (gstate.dataset->streamed && static_cast<uint64_t>(hi) + 1 - lo > gstate.dataset->WindowVariants()) {
+		throw IOException("plink_ld: '%s' does not fit the HBM budget, and the pairs over variants %u..%u reach further than "
+		                  "one window of it (%llu variants: PLINKING_HBM_CACHE_GB) -- both rows of a pair must be resident "
+		                  "together",
+		                  gstate.dataset->path, lo, hi, static_cast<unsigned long long>(gstate.dataset->WindowVariants()));
+	}
+	RowLease rows = LeaseRows(*gstate.dataset, gstate.subset.get(), gstate.row_windows,
+	                          bind_data.c.has_sample_subset ? &bind_data.c.sample_subset->sample_include : nullptr, lo, hi + 1,
+	                          bind_data.c.raw_variant_ct, "plink_ld");
 	char errbuf[PGH_ERRBUF_LEN] = {0};
-	int rc = pgh_ld_pairs(gstate.dataset->Resident("plink_ld"), gstate.subset ? gstate.subset->handle : nullptr,
+	int rc = pgh_ld_pairs(rows.ds, rows.ss,
 	                      static_cast<uint32_t>(n), lstate.pair_a.data(), lstate.pair_b.data(),
 	                      reinterpret_cast<uint32_t(*)[6]>(lstate.sums.data()), errbuf);
 	if (rc != PGH_OK) {
@@ -265,7 +287,7 @@ static void PlinkLdScan(ClientContext &, TableFunctionInput &data_p, DataChunk &
 		}
 		lstate.pair_a.assign(1, bind_data.pairwise_vidx_a);
 		lstate.pair_b.assign(1, bind_data.pairwise_vidx_b);
-		RunPairs(gstate, lstate);
+		RunPairs(bind_data, gstate, lstate);
 		EmitRow(output, 0, bind_data,
 		        PendingRow {bind_data.pairwise_vidx_a, bind_data.pairwise_vidx_b, LdFromSums(lstate.sums.data())});
 		CompatSetOutputCardinality(output, 1);
@@ -297,7 +319,7 @@ static void PlinkLdScan(ClientContext &, TableFunctionInput &data_p, DataChunk &
 				}
 				continue;
 			}
-			RunPairs(gstate, lstate);
+			RunPairs(bind_data, gstate, lstate);
 			for (size_t p = 0; p < lstate.pair_a.size(); p++) {
 				LdResult result = LdFromSums(lstate.sums.data() + 6 * p);
 				if (result.is_valid && result.r2 >= bind_data.r2_threshold) {

@@ -287,6 +287,9 @@ def test_a_file_beyond_the_hbm_budget_streams_its_tallies(gpu_lib, oracle, tmp_p
                                  include_genotypes=["het"])),
              ("read_pfile", dict(orient="genotype", samples=[11, 12], region="4:1-9000", include_genotypes=["hom_alt", "missing"])),
              ("read_pfile", dict(orient="genotype", samples=[2, 40], ac_range={"max": 1})),
+             # plink_ld: a claim's anchors and their partners inside a small LD window lie within one window of the file
+             ("plink_ld", dict(window_kb=2, r2_threshold=0.0, region="7:1-20000")),
+             ("plink_ld", dict(variant1="sv100", variant2="sv190")),
              # plink_score: a sum over variants, so the windows' partial sums add (compared with a tolerance below)
              ("plink_score", dict(weights=[((7 * i) % 13 - 6) / 5.0 for i in range(m)])),
              ("plink_score", dict(weights=[((3 * i) % 7) / 3.0 for i in range(m)], samples=[4, 9, 1500], center=True)),
