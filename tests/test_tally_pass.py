@@ -245,7 +245,8 @@ def test_score_from_a_pass_s_counts(gpu_lib, oracle):
             assert np.allclose(b[0][:, 0], exp[0][:, 0], rtol=1e-9, atol=1e-9) and np.array_equal(b[2], exp[2])
 
 
-def test_a_file_beyond_the_hbm_budget_streams_its_tallies(gpu_lib, oracle, tmp_path, monkeypatch):
+@pytest.mark.parametrize("threads", [3, 11])
+def test_a_file_beyond_the_hbm_budget_streams_its_tallies(gpu_lib, oracle, tmp_path, monkeypatch, threads):
     """A file whose rows exceed the HBM budget is not made resident: plink_freq / plink_hardy / plink_missing (both
     modes) / read_pgen's counts get their tallies from a pass that walks the file window by window through HBM,
     read_pfile's per-sample counts add over the windows, read_pgen's / read_pfile's hardcall output unpacks one window
@@ -295,11 +296,11 @@ def test_a_file_beyond_the_hbm_budget_streams_its_tallies(gpu_lib, oracle, tmp_p
              ("plink_score", dict(weights=[((3 * i) % 7) / 3.0 for i in range(m)], samples=[4, 9, 1500], center=True)),
              ("plink_score", dict(weights=[{"id": f"sv{i}", "allele": "G" if i % 3 else "A", "weight": 0.25 * (i % 5 + 1)} for i in range(100, 5000, 37)],
                                   no_mean_imputation=True))]
-    want = [F.query(fn, small + (".pgen" if fn != "read_pfile" else ""), threads=3, **kw) for fn, kw in calls]
+    want = [F.query(fn, small + (".pgen" if fn != "read_pfile" else ""), threads=threads, **kw) for fn, kw in calls]
     monkeypatch.setenv("PLINKING_HBM_CACHE_GB", "0.0005")  # 500 KB: windows of ~240 variants
     passes = L.tally_passes_started()
     for (fn, kw), w in zip(calls, want):
-        got = F.query(fn, big + (".pgen" if fn != "read_pfile" else ""), threads=3, **kw)
+        got = F.query(fn, big + (".pgen" if fn != "read_pfile" else ""), threads=threads, **kw)
         key = lambda r: tuple(str(x) for x in r[:3]) + ((str(r[-2]),) if kw.get("orient") == "genotype" else ())
         if fn == "plink_score":  # (sums of doubles in another order)
             key = lambda r: str(r[1])
