@@ -417,6 +417,18 @@ int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_
                     const double *g1_init, pgh_allreduce_fn allreduce, void *allreduce_ctx, double *eigenvalues,
                     double *eigenvectors, char *errbuf);
 
+/* pgh_pca over a .pgen that is NOT resident -- a file beyond the HBM budget: the effective variants (ascending) are cut
+ * into windows whose file span is at most `window_variants`, and every pass of the algorithm (n_pcs + 1 power
+ * iterations, then phase 3: the reference walks its 240-variant blocks once per pass too, src/plink_pca.cpp:632-676)
+ * opens the windows one after the other on the current device, uses each for that pass's two contractions and closes
+ * it; the Krylov block (n_var x (n_pcs + 1) 2 n_pcs doubles) stays on the device throughout.  The file is therefore
+ * read n_pcs + 2 times.  sample_include: the subset's bit mask over the raw samples, or NULL.  Same results as
+ * pgh_pca on a resident dataset of the same variants up to the order of FP64 additions. */
+int pgh_pca_streamed(const char *pgen_path, const char *pgi_path, const uint64_t *sample_include, uint32_t n_var,
+                     const uint32_t *vidx, const double *center, const double *inv_stdev, uint32_t n_pcs,
+                     const double *g1_init, uint64_t window_variants, double *eigenvalues, double *eigenvectors,
+                     char *errbuf);
+
 /* ---- per-variant calls mirroring pgenlib -------------------------------- */
 
 /* PgrInit + PgrSetSampleSubsetIndex per scan thread (src/plink_freq.cpp:381-397). */

@@ -1107,25 +1107,108 @@ extern "C" int pgh_pca(const pgh_dataset *ds, const pgh_subset *subset, uint32_t
 	                       eigenvalues, eigenvectors, errbuf);
 }
 
-extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_var, const uint32_t *vidx,
-                               const double *center, const double *inv_stdev, uint64_t n_var_total, uint32_t n_pcs,
-                               const double *g1_init, pgh_allreduce_fn allreduce, void *allreduce_ctx,
-                               double *eigenvalues, double *eigenvectors, char *errbuf) {
-	if (!ds || !g1_init || !eigenvalues || !eigenvectors || n_pcs == 0 ||
-	    (n_var && (!vidx || !center || !inv_stdev))) {
-		SetErr(errbuf, "null or empty argument");
-		return PGH_ERR_ARG;
+namespace {
+
+//! A block of the rows of X that pgh_pca works on while it is resident.
+struct PcaBlock {
+	RowView view {nullptr, 0, 0, 0};
+	const uint32_t *local = nullptr; // host: the block's effective variants as rows of `view`
+	uint32_t row0 = 0, rows = 0;     // which of the call's effective variants
+};
+
+//! Where the rows come from: a resident dataset (one block, kept for the whole call) or a file beyond the HBM budget
+//! (one window after the other; Acquire opens it, Release closes it).
+struct PcaSource {
+	uint32_t sample_ct = 0;
+	virtual ~PcaSource() = default;
+	virtual uint32_t Count() const = 0;
+	virtual uint32_t MaxRows() const = 0;
+	virtual bool Keep() const = 0;
+	virtual int Acquire(uint32_t i, PcaBlock &out, char *errbuf) = 0;
+	virtual void Release(uint32_t i) = 0;
+};
+
+struct ResidentPcaSource : PcaSource {
+	const pgh_dataset *ds;
+	std::vector<uint32_t> local;
+	ResidentPcaSource(const pgh_dataset *d, std::vector<uint32_t> rows) : ds(d), local(std::move(rows)) {
+		sample_ct = d->sample_ct;
 	}
-	if (n_var_total < n_var || (!allreduce && n_var_total != n_var)) {
-		SetErr(errbuf, "n_var_total must cover this shard's variants (and equal them without an all-reduce)");
-		return PGH_ERR_ARG;
+	uint32_t Count() const override {
+		return 1;
 	}
-	PGH_ONE_DEVICE(ds);
-	PGH_ENTER(ds);
-	int rc = CheckSubset(ds, subset, errbuf);
-	if (rc != PGH_OK) {
-		return rc;
+	uint32_t MaxRows() const override {
+		return static_cast<uint32_t>(local.size());
 	}
+	bool Keep() const override {
+		return true;
+	}
+	int Acquire(uint32_t, PcaBlock &out, char *) override {
+		out.view = ds->View();
+		out.local = local.data();
+		out.row0 = 0;
+		out.rows = static_cast<uint32_t>(local.size());
+		return PGH_OK;
+	}
+	void Release(uint32_t) override {
+	}
+};
+
+//! Windows of a .pgen: consecutive runs of the (ascending) effective variants whose file span fits `window` variants.
+struct WindowPcaSource : PcaSource {
+	std::string path, pgi;
+	int device = -1;
+	const uint32_t *vidx;
+	struct Win {
+		uint32_t first, count; // into vidx
+	};
+	std::vector<Win> wins;
+	uint32_t max_rows = 0;
+	pgh_dataset *open = nullptr;
+	std::vector<uint32_t> local;
+	uint32_t Count() const override {
+		return static_cast<uint32_t>(wins.size());
+	}
+	uint32_t MaxRows() const override {
+		return max_rows;
+	}
+	bool Keep() const override {
+		return false;
+	}
+	int Acquire(uint32_t i, PcaBlock &out, char *errbuf) override {
+		const Win &w = wins[i];
+		const uint32_t v0 = vidx[w.first], v1 = vidx[w.first + w.count - 1] + 1;
+		int rc = pgh_open(path.c_str(), pgi.empty() ? nullptr : pgi.c_str(), v0, v1, &open, errbuf);
+		if (rc != PGH_OK) {
+			open = nullptr;
+			return rc;
+		}
+		local.resize(w.count);
+		for (uint32_t k = 0; k < w.count; k++) {
+			local[k] = vidx[w.first + k] - v0;
+		}
+		out.view = open->View();
+		out.local = local.data();
+		out.row0 = w.first;
+		out.rows = w.count;
+		return PGH_OK;
+	}
+	void Release(uint32_t) override {
+		if (open) {
+			pgh_close(open);
+			open = nullptr;
+		}
+	}
+	~WindowPcaSource() override {
+		Release(0);
+	}
+};
+
+} // namespace
+
+static int PcaRun(PcaSource &src, const pgh_subset *subset, uint32_t n_var, const double *center, const double *inv_stdev,
+                  uint64_t n_var_total, uint32_t n_pcs, const double *g1_init, pgh_allreduce_fn allreduce,
+                  void *allreduce_ctx, double *eigenvalues, double *eigenvectors, char *errbuf) {
 	// PGH_PCA_TIMING=1: wall-clock of the call's phases on stderr (each mark drains the stream first)
 	static const bool timing = [] {
 		const char *e = std::getenv("PGH_PCA_TIMING");
@@ -1144,7 +1227,7 @@ extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, 
 		std::fprintf(stderr, "pca %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
 		t_last = now;
 	};
-	const uint32_t N = ds->sample_ct;
+	const uint32_t N = src.sample_ct;
 	const uint32_t n_out = subset ? subset->n_out : N;
 	const uint32_t M = n_var; // this shard's rows of X; every 1/M and the eigenvalue divisor use the total
 	const double m_total = static_cast<double>(n_var_total);
@@ -1153,14 +1236,6 @@ extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, 
 	if (n_var_total < qq || n_out < qq) {
 		SetErr(errbuf, "too few variants or samples for the requested number of PCs");
 		return PGH_ERR_ARG;
-	}
-	std::vector<uint32_t> local(M);
-	for (uint32_t i = 0; i < M; i++) {
-		if (vidx[i] < ds->v_begin || vidx[i] >= ds->v_end) {
-			SetErr(errbuf, "effective variant index outside the resident range");
-			return PGH_ERR_ARG;
-		}
-		local[i] = vidx[i] - ds->v_begin;
 	}
 	// A stream of the call's own (not the per-thread default): the all-reduce callback is handed a real stream
 	// handle that a host framework can wrap and order against its own streams with events.
@@ -1197,8 +1272,7 @@ extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, 
 		}                                                                                                              \
 	} while (0)
 	const size_t m_alloc = std::max<uint32_t>(M, 1);
-	DevBuf d_vlist, d_center, d_inv, d_ts, d_g1, d_g2, d_qq, d_bb;
-	PGH_HIP(d_vlist.Alloc(sizeof(uint32_t) * m_alloc), "hipMalloc(pca)");
+	DevBuf d_center, d_inv, d_ts, d_g1, d_g2, d_qq, d_bb;
 	PGH_HIP(d_center.Alloc(sizeof(double) * m_alloc), "hipMalloc(pca)");
 	PGH_HIP(d_inv.Alloc(sizeof(double) * m_alloc), "hipMalloc(pca)");
 	PGH_HIP(d_ts.Alloc(32ull * m_alloc), "hipMalloc(pca)");
@@ -1206,7 +1280,6 @@ extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, 
 	PGH_HIP(d_g2.Alloc(sizeof(double) * N * k2), "hipMalloc(pca)");
 	PGH_HIP(d_qq.Alloc(sizeof(double) * m_alloc * qq), "hipMalloc(pca)");
 	if (M) {
-		PGH_HIP(hipMemcpy(d_vlist.p, local.data(), sizeof(uint32_t) * M, hipMemcpyHostToDevice), "pca upload");
 		PGH_HIP(hipMemcpy(d_center.p, center, sizeof(double) * M, hipMemcpyHostToDevice), "pca upload");
 		PGH_HIP(hipMemcpy(d_inv.p, inv_stdev, sizeof(double) * M, hipMemcpyHostToDevice), "pca upload");
 	}
@@ -1225,16 +1298,15 @@ extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, 
 	if (M) {
 		PGH_HIP(pgh::LaunchNormTables(d_center.As<double>(), d_inv.As<double>(), M, d_ts.As<double>(), st), "pca tables");
 	}
-	const RowView view = ds->View();
 	mark("allocations + uploads");
 	// Both contractions run on the int8 matrix cores (score_i8.hip): the dense factor of each pass is cut into
 	// exact fixed-point digits, <= 18 columns per pass.  X^T (...) walks the resident rows; X G1 walks the
 	// transposed packed matrix, built here once (pca_i8.hip).
-	DevBuf d_xt, d_iota, d_a, d_mm, d_colsum, i8_bmat, i8_rowidx, i8_cols, i8_small, d_tiles_x, d_tiles_xt;
+	DevBuf d_iota, d_a, d_mm, d_colsum, i8_bmat, i8_rowidx, i8_cols, i8_small;
 	pgh::ScoreI8Buffers i8;
-	RowView view_t {nullptr, 0, M, (M + 3) / 4};
+	const uint32_t block_rows = std::max<uint32_t>(src.MaxRows(), 1);
 	{
-		const uint32_t longest = std::max(M, N);
+		const uint32_t longest = std::max(block_rows, N);
 		const pgh::ScoreI8Sizes z = pgh::ScoreI8Bytes(longest, pgh::kI8MaxColsBare, false);
 		PGH_HIP(i8_bmat.Alloc(z.bmat), "hipMalloc(pca digits)");
 		PGH_HIP(i8_rowidx.Alloc(z.rowidx), "hipMalloc(pca digits)");
@@ -1249,68 +1321,153 @@ extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, 
 		i8.scale_exp = i8.k0 + (pgh::kI8MaxColsBare + 2);
 		PGH_HIP(d_iota.Alloc(sizeof(uint32_t) * N), "hipMalloc(pca)");
 		PGH_HIP(pgh::LaunchIota(d_iota.As<uint32_t>(), N, st), "pca iota");
-		PGH_HIP(d_a.Alloc(sizeof(double) * m_alloc * k2), "hipMalloc(pca)");
-		PGH_HIP(d_mm.Alloc(sizeof(double) * m_alloc * k2), "hipMalloc(pca)");
+		PGH_HIP(d_a.Alloc(sizeof(double) * block_rows * k2), "hipMalloc(pca)");
+		PGH_HIP(d_mm.Alloc(sizeof(double) * block_rows * k2), "hipMalloc(pca)");
 		PGH_HIP(d_colsum.Alloc(sizeof(double) * k2), "hipMalloc(pca)");
-		if (M) {
-			view_t.pitch = pgh::TransposedPitch(M);
-			PGH_HIP(d_xt.Alloc(view_t.pitch * N), "hipMalloc(transposed genotypes)");
-			PGH_HIP(pgh::LaunchTranspose2bit(view, d_vlist.As<uint32_t>(), M, d_xt.As<uint8_t>(), st), "pca transpose");
-			view_t.rows = d_xt.As<uint8_t>();
-			// Tile-major copies of both matrices for the many-column passes (score_i8.hpp): every pass over X or X^T
-			// then streams its genotype bytes as contiguous 8 KB tile images.  One pass over each matrix to build
-			// (~1 ms per GB), n_pcs + 1 resp. n_pcs + 10-ish contractions to use; skipped when the shapes of this
-			// call do not use tiles (few PCs) or HBM is short (the contractions then read the rows as before).
-			// PGH_PCA_TILES=0 turns it off (an A/B switch).
-			const char *tiles_env = std::getenv("PGH_PCA_TILES");
-			const bool want_tiles = !(tiles_env && *tiles_env == '0');
-			const bool step_tiles = pgh::ScoreI8UsesTiles(std::min(pgh::kI8MaxColsBare, k2), false);
-			const bool final_tiles = pgh::ScoreI8UsesTiles(std::min<uint32_t>(pgh::kI8MaxColsBare, qq), false);
-			const size_t free_b = PghDeviceFreeBytes();
-			const size_t need_x = pgh::ScoreI8TiledBytes(M, N), need_xt = pgh::ScoreI8TiledBytes(N, M);
-			if (want_tiles && (step_tiles || final_tiles) && free_b > need_x + need_xt + (2ull << 30)) {
-				PGH_HIP(d_tiles_x.Alloc(need_x), "hipMalloc(pca tiles)");
-				PGH_HIP(pgh::LaunchScoreI8TileMajor(view, d_vlist.As<uint32_t>(), M, d_tiles_x.As<uint8_t>(), st), "pca tiles");
-				if (step_tiles) {
-					PGH_HIP(d_tiles_xt.Alloc(need_xt), "hipMalloc(pca tiles)");
-					PGH_HIP(pgh::LaunchScoreI8TileMajor(view_t, d_iota.As<uint32_t>(), N, d_tiles_xt.As<uint8_t>(), st),
-					        "pca tiles");
+	}
+	// The rows of X come in blocks (PcaSource): ONE for a resident dataset -- its transposed copy and tile images are
+	// built once, here, and serve every pass -- or the windows of a file beyond the HBM budget, each opened, transposed,
+	// used for a pass's Step A and Step B (or for phase 3) and closed again.  Rows row0 .. row0 + rows of the call's
+	// per-variant arrays (centre, 1 / sd, tables, QQ) belong to the block.
+	struct BlockState {
+		PcaBlock blk;
+		DevBuf d_vlist, d_xt, d_tiles_x, d_tiles_xt;
+		RowView view_t {nullptr, 0, 0, 0};
+		bool ready = false;
+	};
+	std::vector<BlockState> states(src.Count());
+	struct BlockGuard { // (an early return between acquire and release must not leave a window open)
+		PcaSource &s;
+		std::vector<BlockState> &st;
+		~BlockGuard() {
+			for (uint32_t i = 0; i < st.size(); i++) {
+				if (st[i].ready) {
+					s.Release(i);
 				}
 			}
+		}
+	} block_guard {src, states};
+	auto prepare_block = [&](uint32_t i, int &rc_out) -> hipError_t {
+		BlockState &b = states[i];
+		rc_out = PGH_OK;
+		if (b.ready) {
+			return hipSuccess;
+		}
+		b = BlockState();
+		rc_out = src.Acquire(i, b.blk, errbuf);
+		if (rc_out != PGH_OK) {
+			return hipSuccess;
+		}
+		b.ready = true;
+		const uint32_t rows = b.blk.rows;
+		if (rows == 0) {
+			return hipSuccess;
+		}
+		hipError_t e = b.d_vlist.Alloc(sizeof(uint32_t) * rows);
+		if (e == hipSuccess) {
+			e = hipMemcpyAsync(b.d_vlist.p, b.blk.local, sizeof(uint32_t) * rows, hipMemcpyHostToDevice, st);
+		}
+		if (e == hipSuccess) {
+			e = hipStreamSynchronize(st); // (blk.local is the source's; a streamed one reuses it for the next window)
+		}
+		b.view_t = RowView {nullptr, pgh::TransposedPitch(rows), rows, (rows + 3) / 4};
+		if (e == hipSuccess) {
+			e = b.d_xt.Alloc(b.view_t.pitch * N);
+		}
+		if (e == hipSuccess) {
+			e = pgh::LaunchTranspose2bit(b.blk.view, b.d_vlist.As<uint32_t>(), rows, b.d_xt.As<uint8_t>(), st);
+		}
+		b.view_t.rows = b.d_xt.As<uint8_t>();
+		// Tile-major copies of both matrices for the many-column passes (score_i8.hpp): every pass over X or X^T
+		// then streams its genotype bytes as contiguous 8 KB tile images.  One pass over each matrix to build
+		// (~1 ms per GB), n_pcs + 1 resp. n_pcs + 10-ish contractions to use; skipped when the shapes of this
+		// call do not use tiles (few PCs), when HBM is short, or when the block is a window that serves one pass
+		// only (the contractions then read the rows as before).  PGH_PCA_TILES=0 turns it off (an A/B switch).
+		const char *tiles_env = std::getenv("PGH_PCA_TILES");
+		const bool want_tiles = src.Keep() && !(tiles_env && *tiles_env == '0');
+		const bool step_tiles = pgh::ScoreI8UsesTiles(std::min(pgh::kI8MaxColsBare, k2), false);
+		const bool final_tiles = pgh::ScoreI8UsesTiles(std::min<uint32_t>(pgh::kI8MaxColsBare, qq), false);
+		const size_t free_b = want_tiles ? PghDeviceFreeBytes() : 0;
+		const size_t need_x = pgh::ScoreI8TiledBytes(rows, N), need_xt = pgh::ScoreI8TiledBytes(N, rows);
+		if (e == hipSuccess && want_tiles && (step_tiles || final_tiles) && free_b > need_x + need_xt + (2ull << 30)) {
+			e = b.d_tiles_x.Alloc(need_x);
+			if (e == hipSuccess) {
+				e = pgh::LaunchScoreI8TileMajor(b.blk.view, b.d_vlist.As<uint32_t>(), rows, b.d_tiles_x.As<uint8_t>(), st);
+			}
+			if (e == hipSuccess && step_tiles) {
+				e = b.d_tiles_xt.Alloc(need_xt);
+				if (e == hipSuccess) {
+					e = pgh::LaunchScoreI8TileMajor(b.view_t, d_iota.As<uint32_t>(), N, b.d_tiles_xt.As<uint8_t>(), st);
+				}
+			}
+		}
+		return e;
+	};
+	// a window is done with: its kernels drain, its device copies and the window itself go
+	auto drop_block = [&](uint32_t i) -> hipError_t {
+		if (src.Keep() || !states[i].ready) {
+			return hipSuccess;
+		}
+		hipError_t e = hipStreamSynchronize(st);
+		states[i] = BlockState();
+		src.Release(i);
+		return e;
+	};
+#define PGH_BLOCK(i)                                                                                                   \
+	do {                                                                                                               \
+		int rc_blk_ = PGH_OK;                                                                                          \
+		hipError_t e_blk_ = prepare_block((i), rc_blk_);                                                               \
+		if (rc_blk_ != PGH_OK) {                                                                                       \
+			return rc_blk_;                                                                                            \
+		}                                                                                                              \
+		PGH_HIP(e_blk_, "pca block (transpose / tiles)");                                                              \
+	} while (0)
+	if (src.Keep()) {
+		for (uint32_t i = 0; i < src.Count(); i++) {
+			PGH_BLOCK(i);
 		}
 	}
 	mark("i8 buffers + transpose");
 	// out[s][c] += sum_v t_v[g(v,s)] W[v][c] over this shard's variants (Step B, phase 3); out zeroed by the caller
-	auto contract_variants = [&](const double *w, uint32_t w_stride, uint32_t n_cols, double *out,
+	// (w: the block's rows of the factor, i.e. already offset by blk.row0 * w_stride)
+	auto contract_variants = [&](BlockState &b, const double *w, uint32_t w_stride, uint32_t n_cols, double *out,
 	                             uint32_t out_stride) -> hipError_t {
 		hipError_t e = hipSuccess;
-		for (uint32_t c0 = 0; c0 < n_cols && e == hipSuccess; c0 += pgh::kI8MaxColsBare) {
+		const uint32_t rows = b.blk.rows;
+		for (uint32_t c0 = 0; c0 < n_cols && e == hipSuccess && rows; c0 += pgh::kI8MaxColsBare) {
 			const uint32_t nc = std::min(pgh::kI8MaxColsBare, n_cols - c0);
-			i8.tiled = d_tiles_x.As<uint8_t>();
-			e = pgh::LaunchScoreI8Prepare(d_vlist.As<uint32_t>(), M, w + c0, w_stride, nc, d_ts.As<double>(), nullptr, nullptr,
-			                              false, false, pgh::kI8Tables, i8, st);
+			i8.tiled = b.d_tiles_x.As<uint8_t>();
+			e = pgh::LaunchScoreI8Prepare(b.d_vlist.As<uint32_t>(), rows, w + c0, w_stride, nc,
+			                              d_ts.As<double>() + 4ull * b.blk.row0, nullptr, nullptr, false, false, pgh::kI8Tables,
+			                              i8, st);
 			if (e == hipSuccess) {
-				e = pgh::LaunchScoreI8(view, M, nc, false, pgh::kI8Tables, i8, out + c0, out_stride, nullptr, nullptr, st);
+				e = pgh::LaunchScoreI8(b.blk.view, rows, nc, false, pgh::kI8Tables, i8, out + c0, out_stride, nullptr, nullptr,
+				                       st);
 			}
 		}
 		return e;
 	};
 	// y[v][c] = sum_s x(v,s) G[s][c] for this shard's variants (Step A): the two integer planes over the transposed
 	// matrix, then the per-variant normalisation
-	auto contract_samples = [&](const double *g, double *y_out) -> hipError_t {
-		hipError_t e = hipMemsetAsync(d_a.p, 0, sizeof(double) * m_alloc * k2, st);
+	// (y_out: the block's rows of QQ, i.e. already offset by blk.row0 * qq)
+	auto contract_samples = [&](BlockState &b, const double *g, double *y_out) -> hipError_t {
+		const uint32_t rows = b.blk.rows;
+		if (rows == 0) {
+			return hipSuccess;
+		}
+		hipError_t e = hipMemsetAsync(d_a.p, 0, sizeof(double) * rows * k2, st);
 		if (e == hipSuccess) {
-			e = hipMemsetAsync(d_mm.p, 0, sizeof(double) * m_alloc * k2, st);
+			e = hipMemsetAsync(d_mm.p, 0, sizeof(double) * rows * k2, st);
 		}
 		for (int plane = pgh::kI8CodePlane; plane <= pgh::kI8MissingPlane && e == hipSuccess; plane++) {
 			double *dst = plane == pgh::kI8CodePlane ? d_a.As<double>() : d_mm.As<double>();
 			for (uint32_t c0 = 0; c0 < k2 && e == hipSuccess; c0 += pgh::kI8MaxColsBare) {
 				const uint32_t nc = std::min(pgh::kI8MaxColsBare, k2 - c0);
-				i8.tiled = d_tiles_xt.As<uint8_t>();
+				i8.tiled = b.d_tiles_xt.As<uint8_t>();
 				e = pgh::LaunchScoreI8Prepare(d_iota.As<uint32_t>(), N, g + c0, k2, nc, nullptr, nullptr, nullptr, false, false,
 				                              plane, i8, st);
 				if (e == hipSuccess) {
-					e = pgh::LaunchScoreI8(view_t, N, nc, false, plane, i8, dst + c0, k2, nullptr, nullptr, st);
+					e = pgh::LaunchScoreI8(b.view_t, N, nc, false, plane, i8, dst + c0, k2, nullptr, nullptr, st);
 				}
 			}
 		}
@@ -1318,8 +1475,8 @@ extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, 
 			e = pgh::LaunchColumnSums(g, N, k2, k2, d_colsum.As<double>(), st);
 		}
 		if (e == hipSuccess) {
-			e = pgh::LaunchPcaCombine(d_a.As<double>(), d_mm.As<double>(), d_colsum.As<double>(), d_center.As<double>(),
-			                          d_inv.As<double>(), M, k2, y_out, qq, st);
+			e = pgh::LaunchPcaCombine(d_a.As<double>(), d_mm.As<double>(), d_colsum.As<double>(),
+			                          d_center.As<double>() + b.blk.row0, d_inv.As<double>() + b.blk.row0, rows, k2, y_out, qq, st);
 		}
 		return e;
 	};
@@ -1328,16 +1485,23 @@ extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, 
 	const uint8_t *mask2 = subset ? subset->d_mask2 : nullptr;
 	for (uint32_t pass = 0; pass <= n_pcs; pass++) {
 		double *y = d_qq.As<double>() + static_cast<size_t>(pass) * k2;
-		// Step A: QQ[:, pass*2k : (pass+1)*2k] = X * G1   (rows of this shard only)
-		if (M) {
-			PGH_HIP(contract_samples(g1, y), "pca step A");
+		if (pass < n_pcs) {
+			PGH_HIP(hipMemsetAsync(g2, 0, sizeof(double) * N * k2, st), "pca memset");
+		}
+		for (uint32_t bi = 0; bi < src.Count(); bi++) {
+			PGH_BLOCK(bi);
+			BlockState &b = states[bi];
+			double *y_b = y + static_cast<size_t>(b.blk.row0) * qq;
+			// Step A: QQ[:, pass*2k : (pass+1)*2k] = X * G1   (rows of this block only)
+			PGH_HIP(contract_samples(b, g1, y_b), "pca step A");
+			if (pass < n_pcs) {
+				// Step B: G2 += X^T Y over the block's rows
+				PGH_HIP(contract_variants(b, y_b, qq, k2, g2, k2), "pca step B");
+			}
+			PGH_HIP(drop_block(bi), "pca block release");
 		}
 		if (pass < n_pcs) {
-			// Step B + merge: G1 = X^T Y / M, summed over shards
-			PGH_HIP(hipMemsetAsync(g2, 0, sizeof(double) * N * k2, st), "pca memset");
-			if (M) {
-				PGH_HIP(contract_variants(y, qq, k2, g2, k2), "pca step B");
-			}
+			// merge: G1 = X^T Y / M, summed over shards
 			PGH_SUM(g2, static_cast<uint64_t>(N) * k2);
 			PGH_HIP(pgh::LaunchMaskRows(g2, N, k2, k2, mask2, st), "pca mask");
 			PGH_HIP(pgh::LaunchScale(g2, static_cast<uint64_t>(N) * k2, 1.0 / m_total, st), "pca scale");
@@ -1407,8 +1571,12 @@ extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, 
 	// Phase 3: BB = X^T U   (src/plink_pca.cpp:664-676)
 	PGH_HIP(d_bb.Alloc(sizeof(double) * static_cast<size_t>(N) * qq), "hipMalloc(pca)");
 	PGH_HIP(hipMemsetAsync(d_bb.p, 0, sizeof(double) * static_cast<size_t>(N) * qq, st), "pca memset");
-	if (M) {
-		PGH_HIP(contract_variants(d_qq.As<double>(), qq, qq, d_bb.As<double>(), qq), "pca phase 3");
+	for (uint32_t bi = 0; bi < src.Count(); bi++) {
+		PGH_BLOCK(bi);
+		BlockState &b = states[bi];
+		PGH_HIP(contract_variants(b, d_qq.As<double>() + static_cast<size_t>(b.blk.row0) * qq, qq, qq, d_bb.As<double>(), qq),
+		        "pca phase 3");
+		PGH_HIP(drop_block(bi), "pca block release");
 	}
 	PGH_SUM(d_bb.As<double>(), static_cast<uint64_t>(N) * qq);
 	PGH_HIP(pgh::LaunchMaskRows(d_bb.As<double>(), N, qq, qq, mask2, st), "pca mask");
@@ -1465,6 +1633,87 @@ extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, 
 	}
 	return PGH_OK;
 #undef PGH_SUM
+#undef PGH_BLOCK
+}
+
+extern "C" int pgh_pca_sharded(const pgh_dataset *ds, const pgh_subset *subset, uint32_t n_var, const uint32_t *vidx,
+                               const double *center, const double *inv_stdev, uint64_t n_var_total, uint32_t n_pcs,
+                               const double *g1_init, pgh_allreduce_fn allreduce, void *allreduce_ctx,
+                               double *eigenvalues, double *eigenvectors, char *errbuf) {
+	if (!ds || !g1_init || !eigenvalues || !eigenvectors || n_pcs == 0 ||
+	    (n_var && (!vidx || !center || !inv_stdev))) {
+		SetErr(errbuf, "null or empty argument");
+		return PGH_ERR_ARG;
+	}
+	if (n_var_total < n_var || (!allreduce && n_var_total != n_var)) {
+		SetErr(errbuf, "n_var_total must cover this shard's variants (and equal them without an all-reduce)");
+		return PGH_ERR_ARG;
+	}
+	PGH_ONE_DEVICE(ds);
+	PGH_ENTER(ds);
+	int rc = CheckSubset(ds, subset, errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	std::vector<uint32_t> local(n_var);
+	for (uint32_t i = 0; i < n_var; i++) {
+		if (vidx[i] < ds->v_begin || vidx[i] >= ds->v_end) {
+			SetErr(errbuf, "effective variant index outside the resident range");
+			return PGH_ERR_ARG;
+		}
+		local[i] = vidx[i] - ds->v_begin;
+	}
+	ResidentPcaSource src(ds, std::move(local));
+	return PcaRun(src, subset, n_var, center, inv_stdev, n_var_total, n_pcs, g1_init, allreduce, allreduce_ctx, eigenvalues,
+	              eigenvectors, errbuf);
+}
+
+extern "C" int pgh_pca_streamed(const char *pgen_path, const char *pgi_path, const uint64_t *sample_include,
+                                uint32_t n_var, const uint32_t *vidx, const double *center, const double *inv_stdev,
+                                uint32_t n_pcs, const double *g1_init, uint64_t window_variants, double *eigenvalues,
+                                double *eigenvectors, char *errbuf) {
+	if (!pgen_path || !g1_init || !eigenvalues || !eigenvectors || n_pcs == 0 || n_var == 0 || !vidx || !center ||
+	    !inv_stdev || window_variants == 0) {
+		SetErr(errbuf, "null or empty argument");
+		return PGH_ERR_ARG;
+	}
+	for (uint32_t i = 1; i < n_var; i++) {
+		if (vidx[i] <= vidx[i - 1]) {
+			SetErr(errbuf, "the effective variants of a streamed pgh_pca must be in ascending file order");
+			return PGH_ERR_ARG;
+		}
+	}
+	WindowPcaSource src;
+	src.path = pgen_path;
+	src.pgi = pgi_path ? pgi_path : "";
+	src.vidx = vidx;
+	for (uint32_t i = 0; i < n_var;) {
+		uint32_t j = i + 1;
+		while (j < n_var && static_cast<uint64_t>(vidx[j]) + 1 - vidx[i] <= window_variants) {
+			j++;
+		}
+		src.wins.push_back({i, j - i});
+		src.max_rows = std::max(src.max_rows, j - i);
+		i = j;
+	}
+	// the sample count, and the staged form of the subset (it outlives the window it is made on): the first window
+	pgh_dataset *first = nullptr;
+	pgh_subset *ss = nullptr;
+	int rc = pgh_open(pgen_path, pgi_path, vidx[0], vidx[src.wins[0].count - 1] + 1, &first, errbuf);
+	if (rc != PGH_OK) {
+		return rc;
+	}
+	src.sample_ct = first->sample_ct;
+	if (sample_include) {
+		rc = pgh_subset_create(first, sample_include, &ss, errbuf);
+	}
+	pgh_close(first);
+	if (rc == PGH_OK) {
+		rc = PcaRun(src, ss, n_var, center, inv_stdev, n_var, n_pcs, g1_init, nullptr, nullptr, eigenvalues, eigenvectors,
+		            errbuf);
+	}
+	pgh_subset_destroy(ss);
+	return rc;
 }
 
 // ---------------------------------------------------------------------------

@@ -1936,8 +1936,8 @@ void DeviceTally::SampleMissing(uint32_t *out, const string &func_name) {
 pgh_dataset *DeviceDataset::Resident(const string &func_name) const {
 	if (streamed) {
 		throw IOException("%s: '%s' does not fit the HBM budget (%.1f GB of rows, budget %.1f GB: PLINKING_HBM_CACHE_GB); "
-		                  "read_pgen, read_pfile, plink_freq, plink_hardy, plink_missing, plink_score and plink_ld stream a file of this "
-		                  "size window by window; this call needs the matrix resident",
+		                  "every function streams a file of this size window by window; this call needs rows resident together "
+		                  "that lie further apart than a window",
 		                  func_name, path,
 		                  static_cast<double>(info.raw_variant_ct) * static_cast<double>(info.record_bytes) / 1e9,
 		                  static_cast<double>(CacheBudgetBytes()) / 1e9);

@@ -275,8 +275,9 @@ public:
 	//! both modes, read_pgen's counts / stats / filters -- get their tallies from a pass that walks the file window
 	//! by window through HBM (DeviceTally, streamed form); read_pfile's per-sample counts add over the windows
 	//! (ForEachWindow), as do plink_score's partial sums, and hardcall output unpacks one window at a time
-	//! (LeaseRows), dosage and phased output, read_pfile's sample / genotype orients and plink_ld's pairs included.  What
-	//! needs the whole matrix at once (plink_pca; LD pairs further apart than a window) reports that it does not fit.
+	//! (LeaseRows), dosage and phased output, read_pfile's sample / genotype orients and plink_ld's pairs included;
+	//! plink_pca walks the windows once per pass (pgh_pca_streamed).  LD pairs further apart than a window report that
+	//! the file does not fit.
 	bool streamed = false;
 	pgh_dataset *Resident(const string &func_name) const;
 	//! A streamed file (see `streamed`) window by window through HBM: opens variants [v0, v1) -- half the HBM budget

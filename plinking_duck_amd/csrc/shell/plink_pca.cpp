@@ -94,7 +94,7 @@ static unique_ptr<FunctionData> PlinkPcaBind(ClientContext &context, TableFuncti
 	uint32_t range_start = c.RangeStart(), range_end = c.RangeEnd();
 	if (range_end > range_start) {
 		bind_data->dataset = DeviceDataset::Acquire(c.pgen_path, "plink_pca");
-		bind_data->dataset->Resident("plink_pca"); // the passes walk the matrix a dozen times: it has to fit
+		// (a file beyond the HBM budget is walked window by window, once per pass: RunAlgorithm)
 		if (c.has_sample_subset) {
 			bind_data->subset =
 			    make_shared<DeviceSubset>(*bind_data->dataset, c.sample_subset->sample_include, "plink_pca");
@@ -223,9 +223,20 @@ static void RunAlgorithm(const PlinkPcaBindData &bind_data, PlinkPcaGlobalState 
 	}
 	const vector<double> &g1 = *g1_ptr;
 	char errbuf[PGH_ERRBUF_LEN] = {0};
-	int rc = pgh_pca(bind_data.dataset->Resident("plink_pca"), bind_data.subset ? bind_data.subset->handle : nullptr, gs.M,
-	                 bind_data.effective_variants.data(), bind_data.centers.data(), bind_data.inv_stdevs.data(),
-	                 bind_data.n_pcs, g1.data(), gs.eigenvalues.data(), gs.eigenvectors.data(), errbuf);
+	int rc;
+	if (bind_data.dataset->streamed) {
+		// the reference's passes stream the file as well, 240 variants at a time (src/plink_pca.cpp:632-676); here a
+		// window is half the HBM budget and every pass opens the windows one after the other (n_pcs + 2 reads of the file)
+		rc = pgh_pca_streamed(bind_data.dataset->path.c_str(), nullptr,
+		                      bind_data.c.has_sample_subset ? bind_data.c.sample_subset->sample_include.data() : nullptr, gs.M,
+		                      bind_data.effective_variants.data(), bind_data.centers.data(), bind_data.inv_stdevs.data(),
+		                      bind_data.n_pcs, g1.data(), bind_data.dataset->WindowVariants(), gs.eigenvalues.data(),
+		                      gs.eigenvectors.data(), errbuf);
+	} else {
+		rc = pgh_pca(bind_data.dataset->Resident("plink_pca"), bind_data.subset ? bind_data.subset->handle : nullptr, gs.M,
+		             bind_data.effective_variants.data(), bind_data.centers.data(), bind_data.inv_stdevs.data(),
+		             bind_data.n_pcs, g1.data(), gs.eigenvalues.data(), gs.eigenvectors.data(), errbuf);
+	}
 	if (rc != PGH_OK) {
 		throw IOException("plink_pca: %s", string(errbuf));
 	}

@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "pgh_close", "pgh_subset_create", "pgh_subset_size", "pgh_subset_destroy", "pgh_counts_range",
     "pgh_counts_range_dev", "pgh_freq_from_counts_dev", "pgh_fused_tally_dev", "pgh_missing_per_sample", "pgh_missing_per_sample_dev", "pgh_unpack_range",
     "pgh_unpack_range_dev", "pgh_probe_unpack_shape_dev", "pgh_score", "pgh_score_counts", "pgh_score_dev", "pgh_score_plan_create", "pgh_score_run_dev",
-    "pgh_score_plan_destroy", "pgh_pca", "pgh_pca_sharded", "pgh_ld_pairs", "pgh_ld_pairs_dev", "pgh_ld_pairs_status", "pgh_sample_counts", "pgh_sample_counts_dev",
+    "pgh_score_plan_destroy", "pgh_pca", "pgh_pca_sharded", "pgh_pca_streamed", "pgh_ld_pairs", "pgh_ld_pairs_dev", "pgh_ld_pairs_status", "pgh_sample_counts", "pgh_sample_counts_dev",
     "pgh_synth_add_dosage", "pgh_synth_write_dosage_files", "pgh_dosage_sums", "pgh_dosage_sums_dev", "pgh_dosage_unpack", "pgh_dosage_unpack_dev", "pgh_unpack_samples", "pgh_dosage_unpack_samples", "pgh_reader_create", "pgh_reader_destroy",
     "pgh_reader_unpack_start", "pgh_reader_unpack_wait", "pgh_get_2bit", "pgh_get_counts", "pgh_get_missingness", "pgh_get_int8", "pgh_get_dosage_f64", "pgh_get_phased",
     "pgh_tally_start", "pgh_tally_request", "pgh_tally_wait", "pgh_tally_counts", "pgh_tally_hwe_lnp",
@@ -135,6 +135,7 @@ def _load():
         "pgh_ld_pairs_dev": (C.c_int, [vp, vp, u32, vp, vp, vp, vp, cp]),
         "pgh_ld_pairs_status": (C.c_int, [cp]),
         "pgh_pca_sharded": (C.c_int, [vp, vp, u32, vp, vp, vp, C.c_uint64, u32, vp, ALLREDUCE_FN, vp, vp, vp, cp]),
+        "pgh_pca_streamed": (C.c_int, [C.c_char_p, C.c_char_p, vp, u32, vp, vp, vp, u32, vp, C.c_uint64, vp, vp, cp]),
         "pgh_reader_create": (C.c_int, [vp, vp, C.POINTER(vp), cp]),
         "pgh_reader_destroy": (None, [vp]),
         "pgh_reader_unpack_start": (C.c_int, [vp, C.c_int, u32, u32, vp, vp, C.c_int]),
@@ -284,6 +285,26 @@ def synth_write_dosage_files(prefix: str, m: int, n: int, seed: int, missing_rat
 
 
 TALLY_COUNTS, TALLY_SAMPLE_MISSING, TALLY_HWE, TALLY_HWE_MIDP = 1, 2, 4, 8
+
+
+def pca_streamed(path: str, vidx, center, inv_stdev, n_pcs: int, g1_init, window_variants: int, sample_include=None,
+                 pgi_path: str | None = None):
+    """pgh_pca over a .pgen that is not made resident: windows of at most `window_variants` variants, one at a time.
+    sample_include: uint64 words of the subset's bit mask over the raw samples (None: everybody)."""
+    vidx = np.ascontiguousarray(vidx, dtype=np.uint32)
+    center = np.ascontiguousarray(center, dtype=np.float64)
+    inv_stdev = np.ascontiguousarray(inv_stdev, dtype=np.float64)
+    g1_init = np.ascontiguousarray(g1_init, dtype=np.float64)
+    n_out = g1_init.shape[0]
+    mask = None if sample_include is None else np.ascontiguousarray(sample_include, dtype=np.uint64)
+    ev = np.zeros(n_pcs, dtype=np.float64)
+    vec = np.zeros((n_out, n_pcs), dtype=np.float64)
+    eb = _errbuf()
+    rc = raw().pgh_pca_streamed(path.encode(), pgi_path.encode() if pgi_path else None, None if mask is None else _ptr(mask),
+                                len(vidx), _ptr(vidx), _ptr(center), _ptr(inv_stdev), n_pcs, _ptr(g1_init),
+                                int(window_variants), _ptr(ev), _ptr(vec), eb)
+    _check(rc, eb)
+    return ev, vec
 
 
 def trim_device_cache():

@@ -291,6 +291,8 @@ def test_a_file_beyond_the_hbm_budget_streams_its_tallies(gpu_lib, oracle, tmp_p
              # plink_ld: a claim's anchors and their partners inside a small LD window lie within one window of the file
              ("plink_ld", dict(window_kb=2, r2_threshold=0.0, region="7:1-20000")),
              ("plink_ld", dict(variant1="sv100", variant2="sv190")),
+             # plink_pca: every pass walks the windows (eigenvalues compared with a tolerance below)
+             ("plink_pca", dict(n_pcs=3)), ("plink_pca", dict(n_pcs=2, samples=list(range(0, 2003, 3)), region="2:1-27000")),
              # plink_score: a sum over variants, so the windows' partial sums add (compared with a tolerance below)
              ("plink_score", dict(weights=[((7 * i) % 13 - 6) / 5.0 for i in range(m)])),
              ("plink_score", dict(weights=[((3 * i) % 7) / 3.0 for i in range(m)], samples=[4, 9, 1500], center=True)),
@@ -302,6 +304,12 @@ def test_a_file_beyond_the_hbm_budget_streams_its_tallies(gpu_lib, oracle, tmp_p
     for (fn, kw), w in zip(calls, want):
         got = F.query(fn, big + (".pgen" if fn != "read_pfile" else ""), threads=threads, **kw)
         key = lambda r: tuple(str(x) for x in r[:3]) + ((str(r[-2]),) if kw.get("orient") == "genotype" else ())
+        if fn == "plink_pca":  # (sums of doubles in another order; PC signs are the SVD's)
+            assert got.names == w.names and len(got) == len(w)
+            for a, b in zip(sorted(got.rows, key=lambda r: str(r[:2])), sorted(w.rows, key=lambda r: str(r[:2]))):
+                for x, y in zip(a, b):
+                    assert x == y if not isinstance(x, float) else min(abs(x - y), abs(x + y)) <= 1e-7 * max(1.0, abs(y)), (a, b)
+            continue
         if fn == "plink_score":  # (sums of doubles in another order)
             key = lambda r: str(r[1])
             assert got.names == w.names and len(got) == len(w)
@@ -310,7 +318,7 @@ def test_a_file_beyond_the_hbm_budget_streams_its_tallies(gpu_lib, oracle, tmp_p
             continue
         assert got.names == w.names and sorted(got.rows, key=key) == sorted(w.rows, key=key), fn
     assert L.tally_passes_started() > passes + 8  # one resident pass per window of the file
-    for fn, kw in (("plink_pca", dict(n_pcs=2)), ("plink_ld", {})):
+    for fn, kw in (("plink_ld", {}),):  # (pairs a megabase apart reach further than a 240-variant window)
         with pytest.raises(F.IOException, match="does not fit the HBM budget"):
             F.query(fn, big + (".pgen" if fn != "read_pfile" else ""), threads=2, **kw)
 
@@ -368,3 +376,34 @@ def test_phase_tracks_stream_with_the_rows(gpu_lib, tmp_path, monkeypatch):
     for (fn, kw), w in zip(calls, want):
         got = F.query(fn, big + (".pgen" if fn == "read_pgen" else ""), threads=3, columns=cols(kw), **kw)
         assert sorted(got.rows, key=repr) == sorted(w.rows, key=repr), fn
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_pca_over_windows_of_a_file_equals_pca_over_the_resident_rows(gpu_lib, tmp_path, masked):
+    """pgh_pca_streamed: the effective variants cut into windows, every pass opening them one after the other, against
+    pgh_pca on the same file made resident -- eigenvalues to 1e-10, eigenvectors up to their sign."""
+    L = gpu_lib
+    m, n, k = 5000, 1403, 5
+    prefix = str(tmp_path / "x")
+    L.synth_write_files(prefix, m, n, SEED + 21, 0.03)
+    ds = L.Dataset.open(prefix + ".pgen")
+    rng = np.random.default_rng(3)
+    keep_mask = rng.random(n) < 0.8 if masked else np.ones(n, dtype=bool)
+    ss = ds.subset(keep_mask) if masked else None
+    c = ds.counts_range(subset=ss).astype(np.float64) if masked else ds.counts_range().astype(np.float64)
+    obs = c[:, :3].sum(axis=1)
+    af = (c[:, 1] + 2 * c[:, 2]) / (2 * np.maximum(obs, 1))
+    keep = np.flatnonzero((obs > 0) & (af > 0) & (af < 1)).astype(np.uint32)
+    keep = keep[rng.random(len(keep)) < 0.7]  # gaps in the list: windows of uneven row counts
+    center, inv = 2 * af[keep], 1.0 / np.sqrt(2 * af[keep] * (1 - af[keep]))
+    n_out = int(keep_mask.sum())
+    g1 = np.random.default_rng(4).standard_normal((n_out, 2 * k))
+    ev1, vec1 = ds.pca(keep, center, inv, k, g1, subset=ss)
+    words = np.zeros((n + 63) // 64, dtype=np.uint64)
+    for s in np.flatnonzero(keep_mask):
+        words[s >> 6] |= np.uint64(1) << np.uint64(s & 63)
+    for window in (700, 100000):  # eight windows; one
+        ev2, vec2 = L.pca_streamed(prefix + ".pgen", keep, center, inv, k, g1, window, sample_include=words if masked else None)
+        assert np.allclose(ev1, ev2, rtol=1e-10)
+        for j in range(k):
+            assert np.allclose(vec1[:, j], np.sign(np.dot(vec1[:, j], vec2[:, j])) * vec2[:, j], atol=1e-7)
