@@ -256,6 +256,41 @@ static void RunPairs(const PlinkLdBindData &bind_data, PlinkLdGlobalState &gstat
 		lo = std::min({lo, lstate.pair_a[i], lstate.pair_b[i]});
 		hi = std::max({hi, lstate.pair_a[i], lstate.pair_b[i]});
 	}
+	if (gstate.dataset->streamed && static_cast<uint64_t>(hi) + 1 - lo > gstate.dataset->WindowVariants() && n == 1) {
+		// variant1 / variant2 far apart in a file beyond the HBM budget: each row through a one-variant window of its
+		// own, the two of them side by side in a scratch dataset of two rows
+		const uint32_t rec = (bind_data.c.raw_sample_ct + 3) / 4;
+		vector<uint8_t> two(2 * static_cast<size_t>(rec));
+		const vector<uint64_t> *mask = bind_data.c.has_sample_subset ? &bind_data.c.sample_subset->sample_include : nullptr;
+		char errbuf[PGH_ERRBUF_LEN] = {0};
+		const uint32_t want[2] = {lstate.pair_a[0], lstate.pair_b[0]};
+		for (int k = 0; k < 2; k++) {
+			RowLease one = LeaseRows(*gstate.dataset, nullptr, gstate.row_windows, nullptr, want[k], want[k] + 1,
+			                         bind_data.c.raw_variant_ct, "plink_ld");
+			if (pgh_copy_rows_to_host(one.ds, want[k], want[k] + 1, two.data() + static_cast<size_t>(k) * rec, rec, errbuf) !=
+			    PGH_OK) {
+				throw IOException("plink_ld: PgrGet failed for variant %u: %s", want[k], string(errbuf));
+			}
+		}
+		pgh_dataset *scratch = nullptr;
+		pgh_subset *ss = nullptr;
+		int rc = pgh_from_host_rows(two.data(), rec, 2, bind_data.c.raw_sample_ct, &scratch, errbuf);
+		if (rc == PGH_OK && mask) {
+			rc = pgh_subset_create(scratch, mask->data(), &ss, errbuf);
+		}
+		const uint32_t a = 0, b = 1;
+		if (rc == PGH_OK) {
+			rc = pgh_ld_pairs(scratch, ss, 1, &a, &b, reinterpret_cast<uint32_t(*)[6]>(lstate.sums.data()), errbuf);
+		}
+		pgh_subset_destroy(ss);
+		if (scratch) {
+			pgh_close(scratch);
+		}
+		if (rc != PGH_OK) {
+			throw IOException("plink_ld: PgrGet failed for variants %u..%u: %s", want[0], want[1], string(errbuf));
+		}
+		return;
+	}
 	if (gstate.dataset->streamed && static_cast<uint64_t>(hi) + 1 - lo > gstate.dataset->WindowVariants()) {
 		throw IOException("plink_ld: '%s' does not fit the HBM budget, and the pairs over variants %u..%u reach further than "
 		                  "one window of it (%llu variants: PLINKING_HBM_CACHE_GB) -- both rows of a pair must be resident "

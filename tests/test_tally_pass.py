@@ -291,6 +291,7 @@ def test_a_file_beyond_the_hbm_budget_streams_its_tallies(gpu_lib, oracle, tmp_p
              # plink_ld: a claim's anchors and their partners inside a small LD window lie within one window of the file
              ("plink_ld", dict(window_kb=2, r2_threshold=0.0, region="7:1-20000")),
              ("plink_ld", dict(variant1="sv100", variant2="sv190")),
+             ("plink_ld", dict(variant1="sv17", variant2="sv5801", samples=[5, 6, 7, 8, 900, 901, 1500, 2000])),  # windows apart
              # plink_pca: every pass walks the windows (eigenvalues compared with a tolerance below)
              ("plink_pca", dict(n_pcs=3)), ("plink_pca", dict(n_pcs=2, samples=list(range(0, 2003, 3)), region="2:1-27000")),
              # plink_score: a sum over variants, so the windows' partial sums add (compared with a tolerance below)
