@@ -1,6 +1,8 @@
 // plink_common.cpp -- see plink_common.hpp.
 #include "plink_common.hpp"
 
+#include <future>
+
 #include <algorithm>
 #include <cerrno>
 #include <condition_variable>
@@ -1755,6 +1757,43 @@ bool GetPlinkingTallyCache(ClientContext &context) {
 	return true;
 }
 
+namespace {
+//! One window of a streamed file, opened (pgh_open of the variant range, the sample subset staged next to it).
+struct OpenedWindow {
+	pgh_dataset *ds = nullptr;
+	pgh_subset *ss = nullptr;
+	uint32_t v0 = 0, v1 = 0;
+	int rc = PGH_OK;
+	string error;
+	void Close() {
+		if (ss) {
+			pgh_subset_destroy(ss);
+			ss = nullptr;
+		}
+		if (ds) {
+			pgh_close(ds);
+			ds = nullptr;
+		}
+	}
+};
+
+OpenedWindow OpenWindow(const string &path, const vector<uint64_t> *sample_include, uint32_t v0, uint32_t v1) {
+	OpenedWindow w;
+	w.v0 = v0;
+	w.v1 = v1;
+	char errbuf[PGH_ERRBUF_LEN] = {0};
+	w.rc = pgh_open(path.c_str(), nullptr, v0, v1, &w.ds, errbuf);
+	if (w.rc == PGH_OK && sample_include && !sample_include->empty()) {
+		w.rc = pgh_subset_create(w.ds, sample_include->data(), &w.ss, errbuf);
+	}
+	if (w.rc != PGH_OK) {
+		w.error = errbuf;
+		w.Close();
+	}
+	return w;
+}
+} // namespace
+
 struct DeviceTally::Streamed {
 	std::thread producer;
 	std::mutex m;
@@ -1824,24 +1863,41 @@ void DeviceTally::RunStream(const string &path, uint32_t sample_ct, uint64_t win
 	};
 	const uint32_t all = PGH_TALLY_COUNTS | PGH_TALLY_SAMPLE_MISSING | PGH_TALLY_HWE | PGH_TALLY_HWE_MIDP;
 	vector<uint32_t> part(st.missing.size());
-	for (uint64_t v0 = begin; v0 < end; v0 += window_variants) {
+	// the next window is read from the file while this one is tallied (two in flight: half a window each)
+	const uint64_t window = std::max<uint64_t>(1, window_variants / 2);
+	const vector<uint64_t> *mask_ptr = mask.empty() ? nullptr : &mask;
+	auto open_from = [&](uint64_t v0) {
+		const uint32_t v1 = static_cast<uint32_t>(std::min<uint64_t>(end, v0 + window));
+		return std::async(std::launch::async, OpenWindow, path, mask_ptr, static_cast<uint32_t>(v0), v1);
+	};
+	std::future<OpenedWindow> next;
+	if (begin < end) {
+		next = open_from(begin);
+	}
+	for (uint64_t v0 = begin; v0 < end; v0 += window) {
+		OpenedWindow w = next.get();
+		const bool more = v0 + window < end;
+		bool stop;
 		{
 			std::lock_guard<std::mutex> lock(st.m);
-			if (st.stop) {
-				return;
-			}
+			stop = st.stop;
 		}
-		const uint32_t v1 = static_cast<uint32_t>(std::min<uint64_t>(end, v0 + window_variants));
+		if (more && w.rc == PGH_OK && !stop) {
+			next = open_from(v0 + window);
+		}
+		if (stop) {
+			w.Close();
+			return;
+		}
+		const uint32_t v1 = w.v1;
 		char errbuf[PGH_ERRBUF_LEN] = {0};
-		pgh_dataset *win = nullptr;
-		pgh_subset *ss = nullptr;
 		pgh_tally *pass = nullptr;
-		int rc = pgh_open(path.c_str(), nullptr, static_cast<uint32_t>(v0), v1, &win, errbuf);
-		if (rc == PGH_OK && !mask.empty()) {
-			rc = pgh_subset_create(win, mask.data(), &ss, errbuf);
+		int rc = w.rc;
+		if (rc != PGH_OK) {
+			std::snprintf(errbuf, sizeof errbuf, "%s", w.error.c_str());
 		}
 		if (rc == PGH_OK) {
-			rc = pgh_tally_start(win, ss, static_cast<uint32_t>(v0), v1, all, &pass, errbuf);
+			rc = pgh_tally_start(w.ds, w.ss, static_cast<uint32_t>(v0), v1, all, &pass, errbuf);
 		}
 		if (rc == PGH_OK) {
 			rc = pgh_tally_wait(pass, all, static_cast<uint32_t>(v0), v1, errbuf);
@@ -1857,11 +1913,11 @@ void DeviceTally::RunStream(const string &path, uint32_t sample_ct, uint64_t win
 			}
 		}
 		pgh_tally_destroy(pass);
-		pgh_subset_destroy(ss);
-		if (win) {
-			pgh_close(win);
-		}
+		w.Close();
 		if (rc != PGH_OK) {
+			if (more && next.valid()) {
+				next.get().Close();
+			}
 			fail(func_name + ": streaming variants [" + std::to_string(v0) + ", " + std::to_string(v1) + ") of '" + path +
 			     "' failed: " + errbuf);
 			return;
@@ -2017,35 +2073,45 @@ RowLease LeaseRows(DeviceDataset &dataset, DeviceSubset *subset, RowWindows &w, 
 	return lease;
 }
 
+
+// Two windows are in flight -- the one being worked on and the next one being read from the file by a helper thread
+// (the ingest runs at the host link's rate, the work on a window mostly far above it: without the overlap a pass over
+// the file took the sum of the two) -- so a window is a quarter of the budget here, half of WindowVariants().
 void DeviceDataset::ForEachWindow(uint32_t begin, uint32_t end, const vector<uint64_t> *sample_include,
                                   const string &func_name,
                                   const std::function<void(pgh_dataset *, pgh_subset *, uint32_t, uint32_t)> &fn) const {
-	const uint64_t window = WindowVariants();
-	for (uint64_t v0 = begin; v0 < end; v0 += window) {
+	if (begin >= end) {
+		return;
+	}
+	const uint64_t window = std::max<uint64_t>(1, WindowVariants() / 2);
+	auto open_from = [&](uint64_t v0) {
 		const uint32_t v1 = static_cast<uint32_t>(std::min<uint64_t>(end, v0 + window));
-		char errbuf[PGH_ERRBUF_LEN] = {0};
-		pgh_dataset *win = nullptr;
-		pgh_subset *ss = nullptr;
-		int rc = pgh_open(path.c_str(), nullptr, static_cast<uint32_t>(v0), v1, &win, errbuf);
-		if (rc == PGH_OK && sample_include && !sample_include->empty()) {
-			rc = pgh_subset_create(win, sample_include->data(), &ss, errbuf);
+		return std::async(std::launch::async, OpenWindow, path, sample_include, static_cast<uint32_t>(v0), v1);
+	};
+	std::future<OpenedWindow> next = open_from(begin);
+	for (uint64_t v0 = begin; v0 < end; v0 += window) {
+		OpenedWindow w = next.get();
+		const bool more = v0 + window < end;
+		if (more && w.rc == PGH_OK) {
+			next = open_from(v0 + window);
 		}
-		if (rc != PGH_OK) {
-			if (win) {
-				pgh_close(win);
+		auto drain = [&] { // an error: whatever the helper is reading must not stay open
+			if (more && next.valid()) {
+				next.get().Close();
 			}
-			throw IOException("%s: streaming variants [%llu, %u) of '%s' failed: %s", func_name,
-			                  static_cast<unsigned long long>(v0), v1, path, string(errbuf));
+		};
+		if (w.rc != PGH_OK) {
+			drain();
+			throw IOException("%s: streaming variants [%u, %u) of '%s' failed: %s", func_name, w.v0, w.v1, path, w.error);
 		}
 		try {
-			fn(win, ss, static_cast<uint32_t>(v0), v1);
+			fn(w.ds, w.ss, w.v0, w.v1);
 		} catch (...) {
-			pgh_subset_destroy(ss);
-			pgh_close(win);
+			w.Close();
+			drain();
 			throw;
 		}
-		pgh_subset_destroy(ss);
-		pgh_close(win);
+		w.Close();
 	}
 }
 
