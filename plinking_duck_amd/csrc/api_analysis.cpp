@@ -548,6 +548,12 @@ struct pgh_score_plan {
 	void *d_special = nullptr; // non-finite weights (pgh::ScoreSpecial), scored apart in plain double arithmetic
 	uint32_t n_special = 0;
 	void *d_tiles = nullptr;   // tile-major copy of the table-scored rows (kept plans with many columns)
+	// A weight column whose every coefficient is exactly 1.0 (-1: none).  w * scored is then `scored` itself, so in the
+	// reference SCORE_SUM and NAMED_ALLELE_DOSAGE_SUM of such a column are the same doubles added in the same order
+	// (src/plink_score.cpp:621-651; streaming_threading.test:226-233 asserts the equality).  Here the two are separate
+	// columns of the contraction, equal as real numbers but cut into digits and added up apart: the run copies the
+	// column into the dosage sum instead of leaving the last bits to the order of the atomic additions.
+	int unit_col = -1;
 };
 
 // The entry records of every sparse dosage track of the dataset (dosage.hpp), built once -- by the first plan that
@@ -766,6 +772,15 @@ static int ScorePlanCreate(const pgh_dataset *ds, const pgh_subset *subset, uint
 	plan->n_gaps = n_gaps;
 	plan->n_cols = n_cols;
 	plan->mode = mode;
+	for (uint32_t c = 0; c < n_cols && plan->unit_col < 0 && n_scored; c++) {
+		bool unit = true;
+		for (uint32_t k = 0; k < n_scored && unit; k++) {
+			unit = up_weights[static_cast<size_t>(k) * n_cols + c] == 1.0;
+		}
+		if (unit) {
+			plan->unit_col = static_cast<int>(c);
+		}
+	}
 	if (n_scored) {
 		const uint32_t N = ds->sample_ct;
 		const uint32_t n_dos = n_scored - n_hard;
@@ -982,6 +997,10 @@ extern "C" int pgh_score_run_dev(const pgh_score_plan *plan, void *d_score_sum, 
 	if (e == hipSuccess) {
 		e = pgh::LaunchAlleleCt(ac, plan->n_scored, static_cast<uint32_t *>(miss), N,
 		                        static_cast<uint32_t *>(d_allele_ct), st);
+	}
+	if (e == hipSuccess && track && plan->unit_col >= 0) { // (pgh_score_plan::unit_col)
+		e = pgh::LaunchCopyCols(static_cast<const double *>(d_score_sum) + plan->unit_col, plan->n_cols,
+		                        static_cast<double *>(d_dosage_sum), 1, 1, N, st);
 	}
 	PGH_HIP(e, "score kernels");
 	return PGH_OK;

@@ -41,11 +41,19 @@ def main():
         if SKIP_FILES.match(name):
             continue
         lines = open(path).read().splitlines()
-        settings, i = {}, 0
+        settings, variables, i = {}, {}, 0
         while i < len(lines):
             head = lines[i].strip()
             if head == "statement ok":
                 stmt = lines[i + 1].strip()
+                var = re.match(r"(?i)SET\s+VARIABLE\s+(\w+)\s*=\s*(.+?);?$", stmt)
+                if var:
+                    try:
+                        variables[var.group(1)] = parse_value(var.group(2), 0)[0]
+                    except Unparsed:
+                        pass
+                    i += 2
+                    continue
                 m = re.match(r"(?i)SET\s+(\w+)\s*=\s*(.+?);?$", stmt)
                 r = re.match(r"(?i)RESET\s+(\w+)", stmt)
                 try:
@@ -78,7 +86,9 @@ def main():
                 continue
             try:
                 q = sqlmini.parse_sql(sql)
-                calls = sqlmini.check_select(q, FUNCTIONS)
+                calls = sqlmini.check_select(q, FUNCTIONS + ("read_pvar", "read_psam"))
+                if all(c[1] in ("read_pvar", "read_psam") for c in calls):
+                    raise sqlmini.Unsupported("no call of this path")
                 paths = call_paths(calls)
             except (Unparsed, IndexError, sqlmini.Unsupported, KeyError, TypeError) as e:
                 skipped.append(f"{name}:{at}: {e}")
@@ -89,7 +99,8 @@ def main():
                 skipped.append(f"{name}:{at}: fixture not in the reference tree: {missing[0]}")
                 continue
             case = {"source": f"test/sql/{name}:{at}", "sql": sql, "types": types, "expected": rows}
-            for key, val in (("rowsort", rowsort or None), ("settings", dict(settings) or None)):
+            for key, val in (("rowsort", rowsort or None), ("settings", dict(settings) or None),
+                             ("variables", dict(variables) if "getvariable" in sql else None)):
                 if val:
                     case[key] = val
             cases.append(case)

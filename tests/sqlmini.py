@@ -12,7 +12,7 @@ class Unsupported(Exception):
 
 
 TOKEN = re.compile(r"\s*(?:(?P<num>\d+\.\d*(?:[eE][-+]?\d+)?|\.\d+|\d+(?:[eE][-+]?\d+)?)|(?P<str>'(?:[^']|'')*')|"
-                   r"(?P<id>[A-Za-z_][A-Za-z_0-9]*|\"[^\"]+\")|(?P<op><>|!=|<=|>=|::|:=|[-+*/%(),.\[\]<>={}:;]))")
+                   r"(?P<id>[A-Za-z_][A-Za-z_0-9]*|\"[^\"]+\")|(?P<op><>|!=|<=|>=|->|::|:=|[-+*/%(),.\[\]<>={}:;]))")
 AGGREGATES = {"count", "count_distinct", "sum", "min", "max", "avg", "bool_and", "bool_or", "list", "first", "any_value"}
 
 
@@ -99,6 +99,10 @@ class Parser:
         if self.kw("in"):
             self.take()
             self.take("op", "(")
+            if self.kw("select") or self.kw("with"):
+                q = self.query()
+                self.take("op", ")")
+                return ("in_subq", neg, left, q)
             items = [self.expr()]
             while self.peek()[1] == ",":
                 self.take()
@@ -145,8 +149,14 @@ class Parser:
             elif v == "[":
                 self.take()
                 idx = self.expr()
-                self.take("op", "]")
-                node = ("index", node, idx)
+                if self.peek()[1] == ":":
+                    self.take()
+                    hi = self.expr()
+                    self.take("op", "]")
+                    node = ("slice", node, idx, hi)
+                else:
+                    self.take("op", "]")
+                    node = ("index", node, idx)
             elif v == "::":
                 self.take()
                 node = ("cast", node, self.type_name())
@@ -235,7 +245,12 @@ class Parser:
                     self.take()
                     low += "_distinct"
                 while self.peek()[1] != ")":
-                    args.append(self.expr())
+                    if self.peek()[0] == "id" and self.peek(1)[1] == "->":
+                        var = self.take()
+                        self.take()
+                        args.append(("lambda", var, self.expr()))
+                    else:
+                        args.append(self.expr())
                     if self.peek()[1] == ",":
                         self.take()
                 self.take()
@@ -521,9 +536,9 @@ def check_select(q, functions):
     return calls
 
 
-def literal(node):
-    """The Python value of a literal argument expression (lists, structs, casts of them)."""
-    return ev(node, {}, {})
+def literal(node, env=None):
+    """The Python value of a literal argument expression (lists, structs, casts of them; session variables from env)."""
+    return ev(node, env or {}, env or {})
 
 
 def item_name(node, alias):
@@ -563,7 +578,8 @@ def run_select(q, provider, ctes=None):
 
     def relation(rel):
         if rel[0] == "call":
-            r = provider(rel[1], [literal(a) for a in rel[2]], {k: literal(v) for k, v in rel[3].items()})
+            env = {"__variables__": getattr(provider, "variables", None)}
+            r = provider(rel[1], [literal(a, env) for a in rel[2]], {k: literal(v, env) for k, v in rel[3].items()})
             return list(r.names), list(r.types), list(r.rows)
         if rel[0] == "table":
             n, t, rows = ctes[rel[1].lower()]
@@ -573,7 +589,7 @@ def run_select(q, provider, ctes=None):
             return ["column_name", "column_type"], ["VARCHAR", "VARCHAR"], list(zip(n, t))
         return run_select(rel[1], provider, ctes)
 
-    extra = {"__provider__": provider, "__ctes__": ctes,
+    extra = {"__provider__": provider, "__ctes__": ctes, "__variables__": getattr(provider, "variables", None),
              "__aliases__": {a.lower(): n for n, a in q["items"] if a and not has_aggregate(n)}}
     rel = q["from"]
     if rel is None:
@@ -767,7 +783,7 @@ def has_aggregate(node):
 
 SCALARS = {"round", "abs", "typeof", "len", "length", "array_length", "list_sum", "list_count", "list_contains", "lower", "upper",
            "floor", "ceil", "coalesce", "isnan", "list_min", "list_max", "array_extract", "list_extract", "struct_extract", "sqrt",
-           "ln", "exp", "greatest", "least"}
+           "ln", "exp", "greatest", "least", "range", "list_transform", "concat", "concat_ws", "getvariable"}
 
 
 def check(node):
@@ -855,6 +871,16 @@ def ev(node, row, types):
         return [ev(x, row, types) for x in node[1]]
     if kind == "struct":
         return {k: ev(x, row, types) for k, x in node[1]}
+    if kind == "slice":
+        base, lo, hi = ev(node[1], row, types), ev(node[2], row, types), ev(node[3], row, types)
+        return None if base is None else list(base[lo - 1:hi])
+    if kind == "in_subq":
+        a = ev(node[2], row, types)
+        if a is None:
+            return None
+        _, _, rows = run_select(node[3], row.get("__provider__") or types.get("__provider__"),
+                                row.get("__ctes__") or types.get("__ctes__"))
+        return (_hashable(a) in {_hashable(r[0]) for r in rows}) != node[1]
     if kind == "subq":
         _, _, rows = run_select(node[1], row.get("__provider__") or types.get("__provider__"),
                                 row.get("__ctes__") or types.get("__ctes__"))
@@ -929,7 +955,23 @@ def ev(node, row, types):
         name = node[1]
         if name == "typeof":
             return types_of(node[2][0], types)
+        if name == "list_transform":
+            base, lam = ev(node[2][0], row, types), node[2][1]
+            out = []
+            for item in base:
+                scope = dict(row)
+                scope[lam[1]] = item
+                out.append(ev(lam[2], scope, types))
+            return out
+        if name == "getvariable":
+            return (row.get("__variables__") or types.get("__variables__") or {})[ev(node[2][0], row, types)]
         a = [ev(x, row, types) for x in node[2]]
+        if name == "range":
+            return list(range(*a))
+        if name == "concat":
+            return "".join(duck_str(x) for x in a if x is not None)
+        if name == "concat_ws":
+            return a[0].join(duck_str(x) for x in a[1:] if x is not None)
         if name == "coalesce":
             return next((x for x in a if x is not None), None)
         if a and a[0] is None:

@@ -857,3 +857,22 @@ def test_hwe_batches_tested_in_allele_fraction_order_give_the_same_doubles(gpu_l
         assert np.array_equal(ordered, plain, equal_nan=True)
         # nothing observed: ln 1; one table possible: p = 1, and half of it under mid-p
         assert ordered[17] == 0.0 and ordered[18] == (np.log(0.5) if midp else 0.0)
+
+
+def test_a_column_of_unit_weights_is_the_dosage_sum_bit_for_bit(gpu_lib):
+    """w = 1.0 exactly: w * scored is `scored`, so the reference's SCORE_SUM and NAMED_ALLELE_DOSAGE_SUM are the same
+    doubles added in the same order (streaming_threading.test:226-233 asserts it on 50,000 variants).  Here they are
+    two columns of the contraction: the unit column must come out equal to the dosage sum to the last bit, whatever the
+    order of the slices' atomic additions, next to other columns, with flips, in both imputation modes."""
+    L = gpu_lib
+    m, n = 30000, 4001
+    ds = L.Dataset.synth(0, m, n, SEED + 31, 0.04)
+    rng = np.random.default_rng(9)
+    vidx = np.sort(rng.choice(m, 25000, replace=False)).astype(np.uint32)
+    flip = (rng.random(len(vidx)) < 0.2).astype(np.uint8)
+    for ncols, unit in ((1, 0), (3, 1), (16, 15)):
+        w = rng.standard_normal((len(vidx), ncols))
+        w[:, unit] = 1.0
+        for mode in (L.SCORE_MEAN_IMPUTE, L.SCORE_NO_MEAN_IMPUTATION):
+            s, d, _ = ds.score(vidx, w, flip, mode)
+            assert np.array_equal(s[:, unit], d)

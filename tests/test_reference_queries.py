@@ -34,18 +34,42 @@ def localise(v):
     return v
 
 
-def provider(settings, threads):
+class Relation:
+    def __init__(self, names, types, rows):
+        self.names, self.types, self.rows = names, types, rows
+
+
+def companion_reader(function, path):
+    """read_pvar / read_psam as join partners in the reference's queries: the oracle's text loaders stand in for them
+    (the readers themselves are outside this path)."""
+    import oracle.oracle as O
+
+    if function == "read_pvar":
+        v = O.load_pvar(path)
+        return Relation(["CHROM", "POS", "ID", "REF", "ALT"], ["VARCHAR", "INTEGER", "VARCHAR", "VARCHAR", "VARCHAR"],
+                        list(zip(v["chrom"], v["pos"], v["id"], v["ref"], v["alt"])))
+    p = O.load_psam(path)
+    sex = [int(x) if int(x) in (1, 2) else None for x in p["sex"]]
+    if any(f is not None for f in p["fid"]):
+        return Relation(["FID", "IID", "SEX"], ["VARCHAR", "VARCHAR", "INTEGER"], list(zip(p["fid"], p["iid"], sex)))
+    return Relation(["IID", "SEX"], ["VARCHAR", "INTEGER"], list(zip(p["iid"], sex)))
+
+
+def provider(settings, threads, variables=None):
     def call(function, args, named):
         args = [localise(a) for a in args]
+        if function in ("read_pvar", "read_psam"):
+            return companion_reader(function, args[0])
         named = {k: (localise(v) if k in PATH_PARAMS else v) for k, v in named.items()}
         return F.query(function, *args, settings=settings, threads=threads, **named)
 
+    call.variables = variables
     return call
 
 
 def run_case(case, threads=4):
     q = sqlmini.parse_sql(case["sql"])
-    _, _, got = sqlmini.run_select(q, provider(case.get("settings"), threads))
+    _, _, got = sqlmini.run_select(q, provider(case.get("settings"), threads, case.get("variables")))
     want = case["expected"]
     types = case["types"]
     assert len(got) == len(want), f"{len(got)} rows, the reference's test expects {len(want)}"
