@@ -254,8 +254,31 @@ class Parser:
                     if self.peek()[1] == ",":
                         self.take()
                 self.take()
-                if self.kw("filter") or self.kw("over"):
-                    raise Unsupported("FILTER / OVER")
+                if self.kw("filter"):
+                    raise Unsupported("FILTER")
+                if self.kw("over"):
+                    self.take()
+                    self.take("op", "(")
+                    if self.kw("partition"):
+                        raise Unsupported("PARTITION BY")
+                    order = []
+                    if self.kw("order"):
+                        self.take()
+                        self.take("id", "by")
+                        while True:
+                            node = self.expr()
+                            desc = False
+                            if self.kw("asc") or self.kw("desc"):
+                                desc = self.take().lower() == "desc"
+                            order.append((node, desc, ""))
+                            if self.peek()[1] == ",":
+                                self.take()
+                                continue
+                            break
+                    self.take("op", ")")
+                    if low not in ("lag", "lead", "row_number"):
+                        raise Unsupported("window function " + low)
+                    return ("window", low, args, order)
                 return ("call", low, args)
             self.take()
             return ("col", v.strip('"'))
@@ -667,6 +690,33 @@ def run_select(q, provider, ctes=None):
     out_names = []
     for node, alias in items:
         out_names.extend(names if node == ("star",) else [item_name(node, alias)])
+    # window functions (no PARTITION BY): a value per row of the filtered relation, in the window's own order
+    windows = []
+
+    def find_windows(n):
+        if isinstance(n, tuple):
+            if n and n[0] == "window":
+                windows.append(n)
+                return
+            for x in n[1:]:
+                find_windows(x)
+        elif isinstance(n, list):
+            for x in n:
+                find_windows(x)
+
+    for node, _ in items:
+        find_windows(node)
+    for d in dicts:
+        d["__win__"] = {}
+    for wnode in windows:
+        order = sorted(range(len(dicts)), key=lambda i: _order_key(wnode[3], dicts[i], tmap)) if wnode[3] else list(range(len(dicts)))
+        for pos, i in enumerate(order):
+            if wnode[1] == "row_number":
+                v = pos + 1
+            else:
+                j = pos - 1 if wnode[1] == "lag" else pos + 1
+                v = ev(wnode[2][0], dicts[order[j]], tmap) if 0 <= j < len(order) else None
+            dicts[i]["__win__"][id(wnode)] = v
     is_agg = any(has_aggregate(n) for n, _ in items)
     if q["group"]:
         groups = {}
@@ -871,6 +921,8 @@ def ev(node, row, types):
         return [ev(x, row, types) for x in node[1]]
     if kind == "struct":
         return {k: ev(x, row, types) for k, x in node[1]}
+    if kind == "window":
+        return row["__win__"][id(node)]
     if kind == "slice":
         base, lo, hi = ev(node[1], row, types), ev(node[2], row, types), ev(node[3], row, types)
         return None if base is None else list(base[lo - 1:hi])
